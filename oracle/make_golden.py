@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""
+TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz from the REAL reference.
+
+Runs oracle/_ref/ref_driver (the unmodified reference sources of /root/reference compiled
+by oracle/Makefile) on small instances of the BASELINE.json workloads and stores inputs
+(the case parameters; all data are a pure function of them through the counter hash) and
+expected outputs as compressed .npz fixtures.  Only this container can run it (the
+reference does not travel to the GPU box); the fixtures are committed.
+
+usage: python oracle/make_golden.py [--only NAME]
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def read_rec(path):
+    """Parse the record format documented at the top of oracle/ref_driver.cpp."""
+    out = {}
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    while pos < len(data):
+        (ln,) = struct.unpack_from("<i", data, pos)
+        pos += 4
+        name = data[pos : pos + ln].decode()
+        pos += ln
+        dt, cnt = struct.unpack_from("<iq", data, pos)
+        pos += 12
+        if dt == 0:
+            arr = np.frombuffer(data, dtype="<f8", count=cnt, offset=pos).copy()
+            pos += 8 * cnt
+        else:
+            arr = np.frombuffer(data, dtype="<i4", count=cnt, offset=pos).copy()
+            pos += 4 * cnt
+        out[name] = arr
+    return out
+
+
+def run_driver(mode, args, ranks=1):
+    env = dict(os.environ)
+    env["MKL_NUM_THREADS"] = "1"
+    env["PATH"] = "/opt/conda/bin:" + env.get("PATH", "")
+    cmd = [DRIVER, mode] + ["%s=%s" % (k, v) for k, v in args.items()]
+    if ranks > 1:
+        cmd = [MPIEXEC, "-n", str(ranks)] + cmd
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=tempfile.gettempdir())
+    if res.returncode not in (0,):
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("ref_driver failed: %s" % " ".join(cmd))
+    return res.stdout
+
+
+# The option sets of the reference examples (examples/random_quadratic/random_quadratic.py:92-102,
+# examples/random_convex/random_convex.py:116-126)
+EXAMPLE_OPTS = {
+    "opt.abs_res_tol": 1e-8,
+    "opt.starting_point_strategy": "affine_step",
+    "opt.barrier_strategy": "monotone",
+    "opt.start_affine_multiplier_min": 0.01,
+    "opt.penalty_gamma": 1000.0,
+    "opt.write_output_frequency": 1,
+}
+
+CASES = {}
+
+
+def case(name, mode, ranks=1, **args):
+    CASES[name] = (mode, ranks, args)
+
+
+# --- vector reductions ---
+for n in (1, 63, 1000, 4097):
+    for nv in (1, 8, 33):
+        case("vecops_n%d_nv%d" % (n, nv), "vecops", n=n, nvecs=nv)
+case("vecops_n4097_nv8_r2", "vecops", ranks=2, n=4097, nvecs=8)
+case("vecops_n1000_nv33_r4", "vecops", ranks=4, n=1000, nvecs=33)
+
+# --- quasi-Newton sequences (item 2) ---
+for typ, upd in (("bfgs", "skip"), ("bfgs", "damped"), ("sr1", "skip")):
+    for msub in (3, 10):
+        case("qn_%s_%s_m%d" % (typ, upd, msub), "qn", type=typ, update=upd, msub=msub, n=200, steps=25)
+case("qn_bfgs_damped_m3_sts", "qn", type="bfgs", update="damped", msub=3, n=200, steps=25, diag="yts_over_sts")
+
+# --- interior-point trajectories (items 3-5) ---
+ip_common = dict(EXAMPLE_OPTS)
+case(
+    "ip_quadratic_n257_c3_bfgs",
+    "ip",
+    problem="quadratic",
+    n=257,
+    c=3,
+    dump_vecs_every=5,
+    kat_iter=12,
+    **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}),
+)
+case(
+    "ip_quadratic_n1000_c8_bfgs20",
+    "ip",
+    problem="quadratic",
+    n=1000,
+    c=8,
+    dump_vecs_every=20,
+    kat_iter=30,
+    **dict(ip_common, **{"opt.qn_subspace_size": 20, "opt.qn_type": "bfgs", "opt.max_major_iters": 150}),
+)
+case(
+    "ip_quadratic_illcond_n500_c4",
+    "ip",
+    problem="quadratic",
+    n=500,
+    c=4,
+    eig_max=1e5,
+    dump_vecs_every=25,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 80}),
+)
+case(
+    "ip_quadratic_damped_n300_c2",
+    "ip",
+    problem="quadratic",
+    n=300,
+    c=2,
+    dump_vecs_every=10,
+    **dict(
+        ip_common,
+        **{
+            "opt.qn_subspace_size": 6,
+            "opt.qn_type": "bfgs",
+            "opt.qn_update_type": "damped_update",
+            "opt.max_major_iters": 60,
+        },
+    ),
+)
+case(
+    "ip_convex_n300_c5_bfgs",
+    "ip",
+    problem="convex",
+    n=300,
+    c=5,
+    dump_vecs_every=10,
+    kat_iter=8,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 80}),
+)
+case(
+    "ip_convex_n300_c5_sr1",
+    "ip",
+    problem="convex",
+    n=300,
+    c=5,
+    dump_vecs_every=5,
+    kat_iter=8,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 25}),
+)
+case(
+    "ip_convex_n2000_c32_sr1",
+    "ip",
+    problem="convex",
+    n=2000,
+    c=32,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 20}),
+)
+case(
+    "ip_convex_n2000_c32_bfgs",
+    "ip",
+    problem="convex",
+    n=2000,
+    c=32,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}),
+)
+case(
+    "ip_convex_n2000_c32_bfgs_r2",
+    "ip",
+    ranks=2,
+    problem="convex",
+    n=2000,
+    c=32,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}),
+)
+# config 1: examples/rosenbrock/rosenbrock.cpp with algorithm=ip, w=0
+case(
+    "ip_rosenbrock_n100",
+    "ip",
+    problem="rosenbrock",
+    n=100,
+    dump_vecs_every=10,
+    **{
+        "opt.qn_subspace_size": 10,
+        "opt.qn_type": "bfgs",
+        "opt.abs_res_tol": 1e-6,
+        "opt.barrier_strategy": "monotone",
+        "opt.write_output_frequency": 1,
+        "opt.max_major_iters": 120,
+    },
+)
+case(
+    "ip_quadratic_compfrac_n200_c2",
+    "ip",
+    problem="quadratic",
+    n=200,
+    c=2,
+    dump_vecs_every=0,
+    **dict(
+        ip_common,
+        **{
+            "opt.qn_subspace_size": 5,
+            "opt.barrier_strategy": "complementarity_fraction",
+            "opt.max_major_iters": 60,
+        },
+    ),
+)
+case(
+    "ip_quadratic_nolinesearch_n200_c2",
+    "ip",
+    problem="quadratic",
+    n=200,
+    c=2,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.use_line_search": 0, "opt.max_major_iters": 40}),
+)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    if not os.path.exists(DRIVER):
+        subprocess.check_call(["make", "-C", HERE])
+    os.makedirs(GOLDEN, exist_ok=True)
+    manifest = {}
+    for name, (mode, ranks, args) in sorted(CASES.items()):
+        if a.only and a.only not in name:
+            continue
+        with tempfile.TemporaryDirectory() as td:
+            rec = os.path.join(td, "out.rec")
+            dargs = dict(args)
+            dargs["out"] = rec
+            if mode == "ip":
+                dargs["text"] = os.path.join(td, "paropt.out")
+            run_driver(mode, dargs, ranks)
+            d = read_rec(rec)
+            if mode == "ip":
+                with open(dargs["text"]) as f:
+                    lines = [ln.rstrip("\n") for ln in f]
+                # keep only the iteration table (drop the options echo)
+                start = next((i for i, ln in enumerate(lines) if ln.startswith("iter ")), 0)
+                d["paropt_out"] = np.array("\n".join(lines[start:]))
+        d["case_json"] = np.array(json.dumps(dict(mode=mode, ranks=ranks, args=args)))
+        path = os.path.join(GOLDEN, name + ".npz")
+        np.savez_compressed(path, **d)
+        manifest[name] = dict(mode=mode, ranks=ranks, args=args, bytes=os.path.getsize(path))
+        print("%-40s %8d bytes  %d records" % (name, manifest[name]["bytes"], len(d)))
+    if not a.only:
+        with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1308 @@
+"""
+TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the ParOpt interior-point hot path.
+
+This module restates, in plain numpy, the algorithm of the reference implementation
+(smdogroup/paropt v2.1.5) for the path named by BASELINE.json:
+
+  * the distributed vector reductions      src/ParOptVec.cpp:63-204
+  * compact L-BFGS / L-SR1                 src/ParOptQuasiNewton.cpp:162-459, 636-809
+  * the interior-point iteration (w = 0)   src/ParOptInteriorPoint.cpp:1337-5656
+
+It follows the reference's *operation order* ("mirror mode"), so that it is an
+independent check of the fused HIP product in paropt_amd/.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product
+never does.
+
+Parity pin: every function here is checked against golden vectors produced by the real
+reference compiled from /root/reference (oracle/Makefile -> oracle/_ref/ref_driver,
+oracle/make_golden.py -> tests/golden/*.npz); see tests/test_oracle_golden.py.
+
+The small dense factorizations use scipy.linalg.lu_factor/lu_solve, i.e. LAPACK
+dgetrf/dgetrs -- the routines the reference calls (src/ParOptBlasLapack.h:29-30).
+"""
+import math
+
+import numpy as np
+import scipy.linalg as sla
+
+# --------------------------------------------------------------------------------------
+# Counter-hash synthetic data (DESIGN.md "Synthetic data"): u01(seed, array id, global i)
+# --------------------------------------------------------------------------------------
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def u01(seed, aid, idx):
+    """U[0,1) as a pure function of (seed, array id, global index)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(aid) * np.uint64(
+            0xD1B54A32D192ED03
+        )
+        h = splitmix64(base + idx)
+    return (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def shard(n, rank, size):
+    """Contiguous row blocks: (nlocal, offset); the first n % size ranks get one extra."""
+    base, rem = divmod(int(n), int(size))
+    nlocal = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return nlocal, offset
+
+
+# --------------------------------------------------------------------------------------
+# Communicators: the reference's MPI_Allreduce sites
+# --------------------------------------------------------------------------------------
+class SelfComm:
+    rank = 0
+    size = 1
+
+    def allreduce(self, arr, op="sum"):
+        return np.array(arr, dtype=np.float64, copy=True)
+
+
+class TorchComm:
+    """torch.distributed (gloo on CPU) stand-in for the MPI communicator."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+
+    def allreduce(self, arr, op="sum"):
+        import torch
+
+        t = torch.tensor(np.atleast_1d(np.asarray(arr, dtype=np.float64)))
+        ops = {
+            "sum": self.dist.ReduceOp.SUM,
+            "min": self.dist.ReduceOp.MIN,
+            "max": self.dist.ReduceOp.MAX,
+        }
+        self.dist.all_reduce(t, op=ops[op])
+        return t.numpy().copy()
+
+
+# --------------------------------------------------------------------------------------
+# Vector reductions -- src/ParOptVec.cpp
+# --------------------------------------------------------------------------------------
+class VecOps:
+    def __init__(self, comm=None):
+        self.comm = comm if comm is not None else SelfComm()
+
+    def dot(self, x, y):  # src/ParOptVec.cpp:124-143
+        return float(self.comm.allreduce([np.dot(x, y)])[0])
+
+    def mdot(self, x, vecs):  # src/ParOptVec.cpp:152-170
+        loc = np.array([np.dot(x, v) for v in vecs], dtype=np.float64)
+        if len(vecs) == 0:
+            return loc
+        return self.comm.allreduce(loc)
+
+    def norm(self, x):  # src/ParOptVec.cpp:63-80 (dnrm2, squared, summed, sqrt)
+        return math.sqrt(float(self.comm.allreduce([np.dot(x, x)])[0]))
+
+    def maxabs(self, x):  # src/ParOptVec.cpp:87-99
+        loc = float(np.max(np.abs(x))) if x.size else 0.0
+        return float(self.comm.allreduce([loc], "max")[0])
+
+    def l1norm(self, x):  # src/ParOptVec.cpp:106-116
+        return float(self.comm.allreduce([np.sum(np.abs(x))])[0])
+
+
+# --------------------------------------------------------------------------------------
+# Compact quasi-Newton -- src/ParOptQuasiNewton.cpp
+# --------------------------------------------------------------------------------------
+class _CompactQN:
+    """Shared storage/rotation logic of ParOptLBFGS and ParOptLSR1."""
+
+    def __init__(self, n, msub_max, ops):
+        self.ops = ops
+        self.n = n
+        self.msub_max = msub_max
+        self.S = [np.zeros(n) for _ in range(msub_max)]
+        self.Y = [np.zeros(n) for _ in range(msub_max)]
+        self.diag_type = "yty_over_yts"
+        self.reset()
+
+    def reset(self):  # src/ParOptQuasiNewton.cpp:127-142 / 603-618
+        self.msub = 0
+        self.b0 = 1.0
+        m = self.msub_max
+        self.D = np.zeros(m)
+        self.L = np.zeros((m, m))  # L[i, j] = S[i].Y[j], j < i
+        self.B = np.zeros((m, m))  # B = S^T S
+        self.M = np.zeros((0, 0))
+        self.d0 = np.zeros(0)
+        self.Z = []
+        self.lu = None
+
+    def _store(self, s, y):
+        """Append (or rotate in) a pair and refresh B, D, L: :266-321 / :650-705."""
+        m = self.msub_max
+        if self.msub < m:
+            self.S[self.msub][:] = s
+            self.Y[self.msub][:] = y
+            self.msub += 1
+        elif self.msub == m and m > 0:
+            self.S[0][:] = s
+            self.Y[0][:] = y
+            self.S = self.S[1:] + self.S[:1]
+            self.Y = self.Y[1:] + self.Y[:1]
+            k = self.msub
+            self.D[: k - 1] = self.D[1:k].copy()
+            self.B[: k - 1, : k - 1] = self.B[1:k, 1:k].copy()
+            # only the strictly-lower part is shifted in the reference (:298-302)
+            Lold = self.L.copy()
+            for i in range(k - 1):
+                for j in range(i):
+                    self.L[i, j] = Lold[i + 1, j + 1]
+        k = self.msub
+        dot = self.ops.dot
+        for i in range(k):
+            self.B[k - 1, i] = dot(self.S[k - 1], self.S[i])
+            self.B[i, k - 1] = self.B[k - 1, i]
+        if k > 0:
+            self.D[k - 1] = dot(self.S[k - 1], self.Y[k - 1])
+        for i in range(k - 1):
+            self.L[k - 1, i] = dot(self.S[k - 1], self.Y[i])
+
+    def _factor(self):
+        if self.M.shape[0] > 0:
+            self.lu = sla.lu_factor(self.M, check_finite=False)
+        else:
+            self.lu = None
+
+    def get_compact(self):
+        """(b0, d0, M, Z): src/ParOptQuasiNewton.cpp:471-487 / 821-837."""
+        return self.b0, self.d0, self.M, self.Z
+
+    def mult(self, x):  # :390-418 / :760-778
+        y = self.b0 * x
+        if len(self.Z) > 0:
+            rz = self.ops.mdot(x, self.Z)
+            rz = rz * self.d0
+            rz = sla.lu_solve(self.lu, rz, check_finite=False)
+            rz = rz * self.d0
+            for i in range(len(self.Z)):
+                y = y - rz[i] * self.Z[i]
+        return y
+
+    def mult_add(self, alpha, x, y):  # :432-459 / :791-809 (y updated in place)
+        y += (self.b0 * alpha) * x
+        if len(self.Z) > 0:
+            rz = self.ops.mdot(x, self.Z)
+            rz = rz * self.d0
+            rz = sla.lu_solve(self.lu, rz, check_finite=False)
+            rz = rz * self.d0
+            for i in range(len(self.Z)):
+                y -= (alpha * rz[i]) * self.Z[i]
+        return y
+
+
+class LBFGS(_CompactQN):
+    """ParOptLBFGS: B = b0 I - Z diag(d0) M^-1 diag(d0) Z^T, Z = [S, Y]."""
+
+    def __init__(self, n, msub_max, ops, update_type="skip_negative_curvature"):
+        self.update_type = update_type
+        super().__init__(n, msub_max, ops)
+
+    def max_size(self):
+        return 2 * self.msub_max
+
+    def update(self, s, y):  # src/ParOptQuasiNewton.cpp:162-334
+        dot = self.ops.dot
+        yTy = dot(y, y)
+        yTs = dot(y, s)
+        sTs = dot(s, s)
+        if 1e-8 * yTy >= abs(yTs):
+            return 2
+        r = self.mult(s)
+        sTBs = dot(r, s)
+        eps = 1e-12
+        if yTs >= eps:
+            b0_init = yTs / sTs if self.diag_type == "yts_over_sts" else yTy / yTs
+        else:
+            b0_init = 0.5 * (abs(yTy / yTs) + abs(yTs / sTs))
+        rc = 0
+        y_update = None
+        if yTs >= 0.01 * sTBs:
+            y_update = y
+            self.b0 = b0_init
+        elif self.update_type == "skip_negative_curvature":
+            return 2
+        else:  # damped update :241-263
+            rc = 1
+            theta = 0.8 * sTBs / (sTBs - yTs)
+            r = (1.0 - theta) * r
+            r = r + theta * y
+            y_update = r
+            yTy = dot(y_update, y_update)
+            yTs = dot(s, y_update)
+            self.b0 = yTs / sTs if self.diag_type == "yts_over_sts" else yTy / yTs
+        self._store(s, y_update)
+        self._mat_update()
+        return rc
+
+    def _mat_update(self):  # computeMatUpdate :339-377
+        k = self.msub
+        M = np.zeros((2 * k, 2 * k))
+        M[:k, :k] = self.b0 * self.B[:k, :k]
+        for i in range(k):
+            for j in range(i):
+                M[i, j + k] = self.L[i, j]
+                M[j + k, i] = self.L[i, j]
+            M[k + i, k + i] = -self.D[i]
+        self.M = M
+        self.d0 = np.concatenate([np.full(k, self.b0), np.ones(k)])
+        self.Z = [self.S[i] for i in range(k)] + [self.Y[i] for i in range(k)]
+        self._factor()
+
+
+class LSR1(_CompactQN):
+    """ParOptLSR1: B = b0 I - Z M^-1 Z^T, Z_i = Y_i - b0 S_i."""
+
+    def max_size(self):
+        return self.msub_max
+
+    def update(self, s, y):  # src/ParOptQuasiNewton.cpp:636-747
+        dot = self.ops.dot
+        yTy = dot(y, y)
+        sTy = dot(s, y)
+        self.b0 = yTy / sTy if sTy > 1e-12 * yTy else 1.0
+        self._store(s, y)
+        k = self.msub
+        M = self.b0 * self.B[:k, :k].copy()
+        for i in range(k):
+            for j in range(i):
+                M[i, j] -= self.L[i, j]
+                M[j, i] -= self.L[i, j]
+            M[i, i] -= self.D[i]
+        self.M = M
+        self.Z = [self.Y[i] - self.b0 * self.S[i] for i in range(k)]
+        self.d0 = np.ones(k)
+        self._factor()
+        return 0
+
+
+# --------------------------------------------------------------------------------------
+# Problems (DESIGN.md "Workloads")
+# --------------------------------------------------------------------------------------
+class SepProblem:
+    """Separable restrictions of the reference's example problems.
+
+    quadratic : examples/random_quadratic/random_quadratic.py:30-57,86-88 with A = diag(q)
+    convex    : examples/random_convex/random_convex.py:31-71,104-111 with Q = I, Affine = 1e-3 I
+    rosenbrock: examples/rosenbrock/rosenbrock.cpp:34-107 (w = 0 variant)
+    """
+
+    def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None):
+        self.comm = comm if comm is not None else SelfComm()
+        self.kind = kind
+        self.nglobal = int(n)
+        self.nlocal, self.offset = shard(n, self.comm.rank, self.comm.size)
+        self.c = 2 if kind == "rosenbrock" else int(c)
+        self.seed = seed
+        idx = np.arange(self.offset, self.offset + self.nlocal, dtype=np.uint64)
+        self.idx = idx
+        if kind == "quadratic":
+            self.q = eig_min + (eig_max - eig_min) * u01(seed, 1, idx)
+            self.b = u01(seed, 2, idx)
+            self.A = [u01(seed, 100 + j, idx) for j in range(self.c)]
+            self.beta = u01(seed, 4, np.arange(self.c, dtype=np.uint64))
+        elif kind == "convex":
+            self.b = u01(seed, 2, idx)
+            self.A = [u01(seed, 100 + j, idx) for j in range(self.c)]
+            loc = np.array([np.sum(a) for a in self.A])
+            self.beta = 0.25 * self.comm.allreduce(loc)
+        elif kind != "rosenbrock":
+            raise ValueError(kind)
+
+    def vars_and_bounds(self):
+        n = self.nlocal
+        if self.kind == "quadratic":
+            return -2.0 + u01(self.seed, 3, self.idx), np.full(n, -5.0), np.full(n, 5.0)
+        if self.kind == "convex":
+            return 0.05 + 0.9 * u01(self.seed, 3, self.idx), np.zeros(n), np.ones(n)
+        return np.full(n, -1.0), np.full(n, -2.0), np.full(n, 1.0)
+
+    def eval_obj_con(self, x):
+        c = self.c
+        loc = np.zeros(c + 1)
+        if self.kind == "quadratic":
+            loc[0] = np.sum(0.5 * self.q * x * x + self.b * x)
+            for j in range(c):
+                loc[1 + j] = np.dot(self.A[j], x)
+        elif self.kind == "convex":
+            loc[0] = np.sum(self.b * self.b / (1e-3 + x))
+            for j in range(c):
+                loc[1 + j] = -np.dot(self.A[j], x)
+        else:
+            loc[0] = np.sum((1.0 - x[:-1]) ** 2 + 100.0 * (x[1:] - x[:-1] ** 2) ** 2)
+            loc[1] = -np.sum(x * x)
+            loc[2] = np.sum(x[::2])
+        tot = self.comm.allreduce(loc)
+        cons = tot[1:].copy()
+        if self.kind == "rosenbrock":
+            cons[0] += 0.25
+            cons[1] += 10.0
+        else:
+            cons += self.beta
+        return 0, float(tot[0]), cons
+
+    def eval_obj_con_gradient(self, x):
+        if self.kind == "quadratic":
+            return 0, self.q * x + self.b, [a.copy() for a in self.A]
+        if self.kind == "convex":
+            d = 1e-3 + x
+            return 0, -(self.b * self.b) / (d * d), [-a for a in self.A]
+        g = np.zeros_like(x)
+        g[:-1] += -2.0 * (1.0 - x[:-1]) + 200.0 * (x[1:] - x[:-1] ** 2) * (-2.0 * x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        a1 = np.zeros_like(x)
+        a1[::2] = 1.0
+        return 0, g, [-2.0 * x, a1]
+
+
+# --------------------------------------------------------------------------------------
+# Interior point -- src/ParOptInteriorPoint.cpp (dense constraints only, nwcon = 0)
+# --------------------------------------------------------------------------------------
+DEFAULT_OPTIONS = {  # src/ParOptInteriorPoint.cpp:536-727
+    "max_bound_value": 1e20,
+    "abs_res_tol": 1e-6,
+    "rel_func_tol": 0.0,
+    "abs_step_tol": 0.0,
+    "init_barrier_param": 0.1,
+    "penalty_gamma": 1000.0,
+    "penalty_descent_fraction": 0.3,
+    "min_rho_penalty_search": 0.0,
+    "init_rho_penalty_search": 0.0,
+    "armijo_constant": 1e-5,
+    "monotone_barrier_fraction": 0.25,
+    "monotone_barrier_power": 1.1,
+    "rel_bound_barrier": 1.0,
+    "min_fraction_to_boundary": 0.95,
+    "qn_sigma": 0.0,
+    "function_precision": 1e-10,
+    "design_precision": 1e-14,
+    "start_affine_multiplier_min": 1.0,
+    "use_line_search": True,
+    "use_backtracking_alpha": False,
+    "sequential_linear_method": False,
+    "use_quasi_newton_update": True,
+    "qn_subspace_size": 10,
+    "max_major_iters": 5000,
+    "max_line_iters": 10,
+    "iterative_refinement_steps": 1,
+    "hessian_reset_freq": 1000000,
+    "qn_type": "bfgs",
+    "qn_update_type": "skip_negative_curvature",
+    "qn_diag_type": "yty_over_yts",
+    "norm_type": "infinity",
+    "barrier_strategy": "monotone",
+    "starting_point_strategy": "affine_step",
+}
+
+LS_SUCCESS, LS_FAILURE, LS_MIN_STEP, LS_MAX_ITERS, LS_NO_IMPROVEMENT, LS_SHORT_STEP = (
+    1,
+    2,
+    4,
+    8,
+    16,
+    32,
+)  # src/ParOptInteriorPoint.h:220-225
+
+
+class Vars:
+    """ParOptVars for nwcon = 0: src/ParOptInteriorPoint.h:373-389."""
+
+    def __init__(self, n, c):
+        self.x = np.zeros(n)
+        self.zl = np.zeros(n)
+        self.zu = np.zeros(n)
+        self.z = np.zeros(c)
+        self.s = np.zeros(c)
+        self.t = np.zeros(c)
+        self.zs = np.zeros(c)
+        self.zt = np.zeros(c)
+
+    NAMES = ("x", "zl", "zu", "z", "s", "t", "zs", "zt")
+
+    def add(self, o, sign=1.0):  # :128-167
+        for k in self.NAMES:
+            getattr(self, k)[...] += sign * getattr(o, k)
+
+
+class InteriorPoint:
+    def __init__(self, prob, options=None, comm=None):
+        self.prob = prob
+        self.comm = comm if comm is not None else prob.comm
+        self.ops = VecOps(self.comm)
+        self.opt = dict(DEFAULT_OPTIONS)
+        if options:
+            for k, v in options.items():
+                if k not in self.opt:
+                    raise KeyError("unknown option %s" % k)
+                self.opt[k] = v
+        o = self.opt
+        n, c = prob.nlocal, prob.c
+        self.n, self.c = n, c
+        self.ninequality = c
+        self.use_lower = self.use_upper = True
+        self.vars = Vars(n, c)
+        self.res = Vars(n, c)
+        self.step = Vars(n, c)
+        self.refine = Vars(n, c)
+        qt = o["qn_type"]
+        if qt == "bfgs":
+            self.qn = LBFGS(n, o["qn_subspace_size"], self.ops, o["qn_update_type"])
+        elif qt == "sr1":
+            self.qn = LSR1(n, o["qn_subspace_size"], self.ops)
+        else:
+            self.qn = None
+        if self.qn is not None:
+            dt = o["qn_diag_type"]
+            self.qn.diag_type = "yts_over_sts" if dt in ("yts_over_sts",) else "yty_over_yts"
+        gamma = o["penalty_gamma"]
+        self.gamma_s = np.array([0.0 if i < self.ninequality else gamma for i in range(c)])
+        self.gamma_t = np.full(c, gamma)
+        self.barrier_param = o["init_barrier_param"]
+        self.rho = o["init_rho_penalty_search"]
+        self.niter = self.neval = self.ngeval = 0
+        self.fobj = 0.0
+        self.cvals = np.zeros(c)
+        self.g = np.zeros(n)
+        self.Ac = [np.zeros(n) for _ in range(c)]
+        self.Dinv = np.ones(n)
+        self.Glu = None
+        self.Celu = None
+        self.trace = []
+        self.hook = None  # called as hook(self, k) at the top of every iteration
+        self._init_and_check_bounds()
+        v = self.vars
+        v.zl[:] = 1.0
+        v.zu[:] = 1.0
+        v.z[:] = 1.0
+        v.s[:] = 1.0
+        v.t[:] = 1.0
+        v.zs[:] = 1.0
+        v.zt[:] = 1.0
+
+    # ---- bound masks -----------------------------------------------------------------
+    def _masks(self):
+        mb = self.opt["max_bound_value"]
+        return (self.lb > -mb) & self.use_lower, (self.ub < mb) & self.use_upper
+
+    def _init_and_check_bounds(self):  # :4277-4361
+        mb = self.opt["max_bound_value"]
+        x, lb, ub = self.prob.vars_and_bounds()
+        x, lb, ub = x.copy(), lb.copy(), ub.copy()
+        rel_bound = 0.001 * self.barrier_param
+        if self.use_lower and self.use_upper:
+            L = lb > -mb
+            U = ub < mb
+            both = L & U
+            bad = both & (lb >= ub)
+            if np.any(bad):
+                lbn = 0.5 * (lb[bad] + ub[bad]) - 0.5 * rel_bound
+                lb[bad] = lbn
+                ub[bad] = lbn + rel_bound
+            delta = np.where(both, ub - lb, 1.0)
+            lo = L & (x < lb + rel_bound * delta)
+            x = np.where(lo, lb + rel_bound * delta, x)
+            hi = U & (x > ub - rel_bound * delta)
+            x = np.where(hi, ub - rel_bound * delta, x)
+        self.vars.x[:] = x
+        self.lb, self.ub = lb, ub
+        self.vars.zl[lb <= -mb] = 0.0
+        self.vars.zu[ub >= mb] = 0.0
+
+    # ---- residuals -------------------------------------------------------------------
+    def compute_kkt_res(self, v, barrier, r):  # :1337-1446
+        o = self.opt
+        beta = o["rel_bound_barrier"]
+        L, U = self._masks()
+        rx = v.zl.copy() if self.use_lower else np.zeros(self.n)
+        if self.use_upper:
+            rx += -1.0 * v.zu
+        rx += -1.0 * self.g
+        for i in range(self.c):
+            rx += v.z[i] * self.Ac[i]
+        r.x[:] = rx
+        r.z[:] = -(self.cvals - v.s + v.t)
+        r.s[:] = -(self.gamma_s - v.zs + v.z)
+        r.t[:] = -(self.gamma_t - v.zt - v.z)
+        r.zs[:] = -(v.s * v.zs - barrier)
+        r.zt[:] = -(v.t * v.zt - barrier)
+        r.zl[:] = np.where(L, -((v.x - self.lb) * v.zl - beta * barrier), 0.0)
+        r.zu[:] = np.where(U, -((self.ub - v.x) * v.zu - beta * barrier), 0.0)
+
+    def add_kkt_res_step(self, v, p, r):  # :1451-1583 (quasi-Newton branch)
+        o = self.opt
+        L, U = self._masks()
+        if self.qn is not None and not o["sequential_linear_method"]:
+            self.qn.mult_add(-1.0, p.x, r.x)
+        if o["qn_sigma"] != 0.0:
+            r.x += -o["qn_sigma"] * p.x
+        for i in range(self.c):
+            r.x += p.z[i] * self.Ac[i]
+        if self.use_lower:
+            r.x += p.zl
+        if self.use_upper:
+            r.x += -1.0 * p.zu
+        for i in range(self.c):
+            r.z[i] -= self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
+            r.s[i] += p.zs[i] - p.z[i]
+            r.t[i] += p.zt[i] + p.z[i]
+            r.zs[i] -= p.s[i] * v.zs[i] + v.s[i] * p.zs[i]
+            r.zt[i] -= p.t[i] * v.zt[i] + v.t[i] * p.zt[i]
+        r.zl[:] -= np.where(L, (v.x - self.lb) * p.zl + p.x * v.zl, 0.0)
+        r.zu[:] -= np.where(U, (self.ub - v.x) * p.zu - p.x * v.zu, 0.0)
+
+    def compute_res_norm(self, r):  # :1588-1723
+        nt = self.opt["norm_type"]
+        ops = self.ops
+        if nt == "infinity":
+            mp = ops.maxabs(r.x)
+            mi = 0.0
+            md = 0.0
+            for i in range(self.c):
+                mp = max(mp, abs(r.s[i]), abs(r.t[i]))
+                mi = max(mi, abs(r.z[i]))
+                md = max(md, abs(r.zs[i]), abs(r.zt[i]))
+            if self.use_lower:
+                md = max(md, ops.maxabs(r.zl))
+            if self.use_upper:
+                md = max(md, ops.maxabs(r.zu))
+        elif nt == "l1":
+            mp = ops.l1norm(r.x) + float(np.sum(np.abs(r.s)) + np.sum(np.abs(r.t)))
+            mi = float(np.sum(np.abs(r.z)))
+            md = float(np.sum(np.abs(r.zs)) + np.sum(np.abs(r.zt)))
+            md += ops.l1norm(r.zl) + ops.l1norm(r.zu)
+        else:
+            mp = ops.norm(r.x) ** 2 + float(np.sum(r.s**2 + r.t**2))
+            mi = float(np.sum(r.z**2))
+            md = float(np.sum(r.zs**2 + r.zt**2)) + ops.norm(r.zl) ** 2 + ops.norm(r.zu) ** 2
+            mp, mi, md = math.sqrt(mp), math.sqrt(mi), math.sqrt(md)
+        return mp, md, mi, max(mp, md, mi)
+
+    # ---- KKT system ------------------------------------------------------------------
+    def setup_kkt_diag_system(self, v, use_qn):  # :1832-1971
+        o = self.opt
+        L, U = self._masks()
+        b0 = 0.0
+        if self.qn is not None and use_qn:
+            b0 = self.qn.b0
+        d = np.full(self.n, b0 + o["qn_sigma"])
+        d = d + np.where(L, v.zl / np.where(L, v.x - self.lb, 1.0), 0.0)
+        d = d + np.where(U, v.zu / np.where(U, self.ub - v.x, 1.0), 0.0)
+        self.Dinv = 1.0 / d
+        c = self.c
+        G = np.zeros((c, c))
+        for j in range(c):
+            xt = self.Dinv * self.Ac[j]
+            for i in range(j, c):
+                G[i, j] += self.ops.dot(self.Ac[i], xt)
+        for j in range(c):
+            for i in range(j + 1, c):
+                G[j, i] = G[i, j]
+        for i in range(c):
+            G[i, i] += v.s[i] / v.zs[i] + v.t[i] / v.zt[i]
+        self.G = G.copy()
+        self.Glu = sla.lu_factor(G, check_finite=False) if c > 0 else None
+
+    def _gsolve(self, rhs):
+        if self.c == 0:
+            return rhs
+        return sla.lu_solve(self.Glu, rhs, check_finite=False)
+
+    def solve_kkt_diag_full(self, v, b, y):  # :2074-2243
+        L, U = self._masks()
+        xl = np.where(L, v.x - self.lb, 1.0)
+        xu = np.where(U, self.ub - v.x, 1.0)
+        d1 = b.x.copy()
+        d1 += np.where(L, b.zl / xl, 0.0)
+        d1 -= np.where(U, b.zu / xu, 0.0)
+        yx = self.Dinv * d1
+        yz = self.ops.mdot(yx, self.Ac)
+        yz = b.z + (b.zs + v.s * b.s) / v.zs - (b.zt + v.t * b.t) / v.zt - yz
+        yz = self._gsolve(yz)
+        y.z[:] = yz
+        y.zs[:] = yz - b.s
+        y.zt[:] = -b.t - yz
+        y.s[:] = (b.zs - v.s * y.zs) / v.zs
+        y.t[:] = (b.zt - v.t * y.zt) / v.zt
+        for i in range(self.c):
+            d1 += yz[i] * self.Ac[i]
+        y.x[:] = self.Dinv * d1
+        y.zl[:] = np.where(L, (b.zl - v.zl * y.x) / xl, 0.0)
+        y.zu[:] = np.where(U, (b.zu + v.zu * y.x) / xu, 0.0)
+
+    def solve_kkt_diag_bx(self, v, bx, y):  # :2257-2369
+        L, U = self._masks()
+        xl = np.where(L, v.x - self.lb, 1.0)
+        xu = np.where(U, self.ub - v.x, 1.0)
+        d1 = bx.copy()
+        yx = self.Dinv * d1
+        yz = -self.ops.mdot(yx, self.Ac)
+        yz = self._gsolve(yz)
+        y.z[:] = yz
+        y.zs[:] = yz
+        y.zt[:] = -yz
+        y.s[:] = -(v.s * y.zs) / v.zs
+        y.t[:] = -(v.t * y.zt) / v.zt
+        for i in range(self.c):
+            d1 += yz[i] * self.Ac[i]
+        y.x[:] = self.Dinv * d1
+        y.zl[:] = np.where(L, -(v.zl * y.x) / xl, 0.0)
+        y.zu[:] = np.where(U, (v.zu * y.x) / xu, 0.0)
+
+    def solve_kkt_diag_x(self, v, bx):  # :2385-2428 -> yx only
+        d1 = bx.copy()
+        yx = self.Dinv * d1
+        yz = -self.ops.mdot(yx, self.Ac)
+        yz = self._gsolve(yz)
+        for i in range(self.c):
+            d1 += yz[i] * self.Ac[i]
+        return self.Dinv * d1
+
+    def setup_kkt_system(self, v, use_qn):  # :2634-2667
+        self.Celu = None
+        if self.qn is not None and use_qn:
+            b0, d0, M, Z = self.qn.get_compact()
+            k = len(Z)
+            if k > 0:
+                Ce = np.zeros((k, k))
+                for i in range(k):
+                    xt = self.solve_kkt_diag_x(v, Z[i])
+                    Ce[:, i] = self.ops.mdot(xt, Z)
+                Ce -= M / np.outer(d0, d0)
+                self.Ce = Ce.copy()
+                self.Celu = sla.lu_factor(Ce, check_finite=False)
+
+    def compute_kkt_step(self, v, r, p, use_qn):  # :2700-2737 (r is clobbered)
+        Z = []
+        if self.qn is not None and use_qn:
+            Z = self.qn.get_compact()[3]
+        self.solve_kkt_diag_full(v, r, p)
+        if len(Z) > 0:
+            zt = self.ops.mdot(p.x, Z)
+            zt = sla.lu_solve(self.Celu, zt, check_finite=False)
+            xt = np.zeros(self.n)
+            for i in range(len(Z)):
+                xt += zt[i] * Z[i]
+            self.solve_kkt_diag_bx(v, xt, r)
+            p.add(r, -1.0)
+
+    # ---- complementarity / step lengths ---------------------------------------------
+    def compute_comp(self, v):  # :2742-2820
+        L, U = self._masks()
+        prod = float(np.sum(np.where(L, v.zl * (v.x - self.lb), 0.0)))
+        prod += float(np.sum(np.where(U, v.zu * (self.ub - v.x), 0.0)))
+        cnt = float(np.count_nonzero(L) + np.count_nonzero(U))
+        prod = prod / self.opt["rel_bound_barrier"]
+        out = self.comm.allreduce([prod, cnt])
+        prod, cnt = float(out[0]), float(out[1])
+        prod += float(np.sum(v.s * v.zs + v.t * v.zt))
+        cnt += 2.0 * self.c
+        return prod / cnt if cnt != 0.0 else 0.0
+
+    def compute_comp_step(self, v, ax, az, p):  # :2825-2923
+        L, U = self._masks()
+        xn = v.x + ax * p.x
+        prod = float(np.sum(np.where(L, (v.zl + az * p.zl) * (xn - self.lb), 0.0)))
+        prod += float(np.sum(np.where(U, (v.zu + az * p.zu) * (self.ub - xn), 0.0)))
+        cnt = float(np.count_nonzero(L) + np.count_nonzero(U))
+        prod = prod / self.opt["rel_bound_barrier"]
+        out = self.comm.allreduce([prod, cnt])
+        prod, cnt = float(out[0]), float(out[1])
+        prod += float(
+            np.sum((v.s + ax * p.s) * (v.zs + az * p.zs) + (v.t + ax * p.t) * (v.zt + az * p.zt))
+        )
+        cnt += 2.0 * self.c
+        return prod / cnt if cnt != 0.0 else 0.0
+
+    @staticmethod
+    def _min_ratio(tau, num, den, mask):
+        if not np.any(mask):
+            return 1.0
+        return float(min(1.0, np.min(-tau * num[mask] / den[mask])))
+
+    def compute_max_step(self, v, tau, p):  # :2942-3103 (primal loops are NOT masked)
+        mx, mz = 1.0, 1.0
+        if self.use_lower:
+            m = p.x < 0.0
+            mx = min(mx, self._min_ratio(tau, v.x - self.lb, p.x, m))
+        if self.use_upper:
+            m = p.x > 0.0
+            if np.any(m):
+                mx = min(mx, float(np.min(tau * (self.ub - v.x)[m] / p.x[m])))
+        mx = min(mx, self._min_ratio(tau, v.s, p.s, p.s < 0.0))
+        mx = min(mx, self._min_ratio(tau, v.t, p.t, p.t < 0.0))
+        mz = min(mz, self._min_ratio(tau, v.zs, p.zs, p.zs < 0.0))
+        mz = min(mz, self._min_ratio(tau, v.zt, p.zt, p.zt < 0.0))
+        if self.use_lower:
+            mz = min(mz, self._min_ratio(tau, v.zl, p.zl, p.zl < 0.0))
+        if self.use_upper:
+            mz = min(mz, self._min_ratio(tau, v.zu, p.zu, p.zu < 0.0))
+        out = self.comm.allreduce([mx, mz], "min")
+        return float(out[0]), float(out[1])
+
+    def scale_kkt_step(self, v, p, tau, comp):  # :3196-3274
+        ax, az = self.compute_max_step(v, tau, p)
+        ceq = 0
+        bnd = 100.0
+        if ax > az:
+            if ax > bnd * az:
+                ax = bnd * az
+            elif ax < az / bnd:
+                ax = az / bnd
+        else:
+            if az > bnd * ax:
+                az = bnd * ax
+            elif az < ax / bnd:
+                az = ax / bnd
+        comp_new = self.compute_comp_step(v, ax, az, p)
+        if comp_new > 10.0 * comp:
+            ceq = 1
+            if ax > az:
+                ax = az
+            else:
+                az = ax
+        p.x *= ax
+        p.zl *= az
+        p.zu *= az
+        p.s *= ax
+        p.t *= ax
+        p.z *= az
+        p.zs *= az
+        p.zt *= az
+        return ceq, ax, az
+
+    # ---- merit function --------------------------------------------------------------
+    def _clamp_step(self, x, alpha, p, lb=None, ub=None, lower_value=None):  # computeStep :3146-3191
+        eps = self.opt["design_precision"]
+        x = x + alpha * p
+        if lb is not None:
+            x = np.where(x <= lb + eps, lb + eps, x)
+        elif lower_value is not None:
+            x = np.where(x <= lower_value + eps, lower_value + eps, x)
+        if ub is not None:
+            x = np.where(x + eps >= ub, ub - eps, x)
+        return x
+
+    def _barrier_sums(self, x):
+        L, U = self._masks()
+        dl = np.where(L, x - self.lb, 1.0)
+        du = np.where(U, self.ub - x, 1.0)
+        ll = np.log(dl)
+        lu = np.log(du)
+        pos = float(np.sum(np.where(L & (dl > 1.0), ll, 0.0)) + np.sum(np.where(U & (du > 1.0), lu, 0.0)))
+        neg = float(np.sum(np.where(L & ~(dl > 1.0), ll, 0.0)) + np.sum(np.where(U & ~(du > 1.0), lu, 0.0)))
+        return pos, neg, L, U, dl, du
+
+    def eval_merit_func(self, fk, ck, xk, sk, tk):  # :3524-3637
+        beta = self.opt["rel_bound_barrier"]
+        pos, neg, *_ = self._barrier_sums(xk)
+        out = self.comm.allreduce([pos * beta, neg * beta])
+        pos, neg = float(out[0]), float(out[1])
+        for i in range(self.c):
+            for val in (sk[i], tk[i]):
+                if val > 1.0:
+                    pos += math.log(val)
+                else:
+                    neg += math.log(val)
+        infeas = math.sqrt(float(np.sum((ck - sk + tk) ** 2)))
+        merit = fk - self.barrier_param * (pos + neg) + self.rho * infeas
+        for i in range(self.c):
+            merit += self.gamma_s[i] * sk[i] + self.gamma_t[i] * tk[i]
+        return merit
+
+    def eval_merit_init_deriv(self, v, p, max_x):  # :3652-3924
+        o = self.opt
+        beta = o["rel_bound_barrier"]
+        pos, neg, L, U, dl, du = self._barrier_sums(v.x)
+        px = p.x
+        ql = np.where(L, px / dl, 0.0)
+        qu = np.where(U, px / du, 0.0)
+        ppos = float(np.sum(np.where(L & (px > 0.0), ql, 0.0)) - np.sum(np.where(U & ~(px > 0.0), qu, 0.0)))
+        pneg = float(np.sum(np.where(L & ~(px > 0.0), ql, 0.0)) - np.sum(np.where(U & (px > 0.0), qu, 0.0)))
+        out = self.comm.allreduce([pos * beta, neg * beta, ppos * beta, pneg * beta])
+        pos, neg, ppos, pneg = (float(a) for a in out)
+        for i in range(self.c):
+            for val, pv in ((v.s[i], p.s[i]), (v.t[i], p.t[i])):
+                if val > 1.0:
+                    pos += math.log(val)
+                else:
+                    neg += math.log(val)
+                if pv > 0.0:
+                    ppos += pv / val
+                else:
+                    pneg += pv / val
+        # evalInfeasDeriv :3465-3509
+        dense_infeas = 0.0
+        pdense = 0.0
+        for i in range(self.c):
+            cval = self.cvals[i] - v.s[i] + v.t[i]
+            pcval = self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
+            dense_infeas += cval * cval
+            pdense += cval * pcval
+        infeas = math.sqrt(dense_infeas)
+        infeas_proj = pdense / infeas if infeas > 0.0 else 0.0
+        pTBp = 0.0
+        if self.qn is not None and not o["sequential_linear_method"]:
+            xt = self.qn.mult(p.x)
+            pTBp = 0.5 * self.ops.dot(xt, p.x)
+        merit = self.fobj - self.barrier_param * (pos + neg)
+        pmerit = self.ops.dot(self.g, p.x) - self.barrier_param * (ppos + pneg)
+        for i in range(self.c):
+            merit += self.gamma_s[i] * v.s[i] + self.gamma_t[i] * v.t[i]
+            pmerit += self.gamma_s[i] * p.s[i] + self.gamma_t[i] * p.t[i]
+        numer = pmerit
+        if pTBp > 0.0:
+            numer += 0.5 * pTBp
+        frac = o["penalty_descent_fraction"]
+        small = infeas < 0.1 * o["abs_res_tol"]
+        rho_hat = 0.0
+        if small:
+            denom = -(1.0 - frac) * max_x * infeas
+            if numer >= 0.0 and denom < 0.0:
+                rho_hat = -(numer / denom)
+        else:
+            denom = infeas_proj + frac * max_x * infeas
+            if numer >= 0.0:
+                if denom < 0.0:
+                    rho_hat = -(numer / denom)
+                else:
+                    denom = -(1.0 - frac) * max_x * infeas
+                    rho_hat = -(numer / denom)
+        if rho_hat > self.rho:
+            self.rho = rho_hat
+        else:
+            self.rho *= 0.5
+            if self.rho < rho_hat:
+                self.rho = rho_hat
+        if self.rho < o["min_rho_penalty_search"]:
+            self.rho = o["min_rho_penalty_search"]
+        merit += self.rho * infeas
+        if small:
+            pmerit -= self.rho * max_x * infeas
+        else:
+            pmerit += self.rho * infeas_proj
+        return merit, pmerit
+
+    # ---- line search -----------------------------------------------------------------
+    def line_search(self, alpha_min, alpha, m0, dm0):  # :3939-4156
+        o = self.opt
+        v, p, r = self.vars, self.step, self.res
+        fp = o["function_precision"]
+        fail = LS_FAILURE
+        merit = 0.0
+        best_merit = 0.0
+        best_alpha = -1.0
+        max_it = o["max_line_iters"]
+        j = 0
+        self.ls_trials = 0
+        while j < max_it:
+            r.x[:] = self._clamp_step(v.x, alpha, p.x, self.lb, self.ub)
+            r.s[:] = self._clamp_step(v.s, alpha, p.s, lower_value=0.0)
+            r.t[:] = self._clamp_step(v.t, alpha, p.t, lower_value=0.0)
+            fail_obj, self.fobj, self.cvals = self.prob.eval_obj_con(r.x)
+            self.neval += 1
+            self.ls_trials += 1
+            if fail_obj:
+                alpha *= 0.1
+                j += 1
+                continue
+            merit = self.eval_merit_func(self.fobj, self.cvals, r.x, r.s, r.t)
+            if best_alpha < 0.0 or merit < best_merit:
+                best_alpha = alpha
+                best_merit = merit
+            if merit - o["armijo_constant"] * alpha * dm0 < m0 + fp:
+                if fail & LS_MIN_STEP:
+                    fail = LS_SUCCESS | LS_MIN_STEP
+                else:
+                    fail = LS_SUCCESS
+                if merit <= m0 + fp and merit + fp >= m0:
+                    fail |= LS_NO_IMPROVEMENT
+                break
+            elif fail & LS_MIN_STEP:
+                break
+            if j < max_it - 1:
+                if o["use_backtracking_alpha"]:
+                    alpha = 0.5 * alpha
+                    if alpha <= alpha_min:
+                        alpha = alpha_min
+                        fail |= LS_MIN_STEP
+                else:
+                    alpha_new = -0.5 * dm0 * (alpha * alpha) / (merit - m0 - dm0 * alpha)
+                    if alpha_new <= alpha_min:
+                        alpha = alpha_min
+                        fail |= LS_MIN_STEP
+                    elif alpha_new < 0.01 * alpha:
+                        alpha = 0.01 * alpha
+                    else:
+                        alpha = alpha_new
+            j += 1
+        if j == max_it:
+            fail |= LS_MAX_ITERS
+        if not (fail & LS_SUCCESS):
+            if best_merit <= m0 + fp:
+                fail |= LS_SUCCESS
+                fail &= ~LS_FAILURE
+            elif merit <= m0 + fp and merit + fp >= m0:
+                fail |= LS_NO_IMPROVEMENT
+            if alpha != best_alpha:
+                alpha = best_alpha
+                r.x[:] = self._clamp_step(v.x, alpha, p.x, self.lb, self.ub)
+                fail_obj, self.fobj, self.cvals = self.prob.eval_obj_con(r.x)
+                self.neval += 1
+                if fail_obj:
+                    fail = LS_FAILURE
+            else:
+                alpha = best_alpha
+        return fail, alpha
+
+    def compute_step_and_update(self, v, alpha, p, eval_obj_con, perform_qn_update):  # :4169-4267
+        o = self.opt
+        use_qnu = o["use_quasi_newton_update"]
+        v.zl[:] = self._clamp_step(v.zl, alpha, p.zl, lower_value=0.0)
+        v.zu[:] = self._clamp_step(v.zu, alpha, p.zu, lower_value=0.0)
+        v.s[:] = self._clamp_step(v.s, alpha, p.s, lower_value=0.0)
+        v.t[:] = self._clamp_step(v.t, alpha, p.t, lower_value=0.0)
+        v.z[:] = v.z + alpha * p.z
+        v.zs[:] = self._clamp_step(v.zs, alpha, p.zs, lower_value=0.0)
+        v.zt[:] = self._clamp_step(v.zt, alpha, p.zt, lower_value=0.0)
+        y_qn = None
+        if self.qn is not None and perform_qn_update and use_qnu:
+            y_qn = -1.0 * self.g
+            for i in range(self.c):
+                y_qn += v.z[i] * self.Ac[i]
+        v.x[:] = self._clamp_step(v.x, alpha, p.x, self.lb, self.ub)
+        if eval_obj_con:
+            fail, self.fobj, self.cvals = self.prob.eval_obj_con(v.x)
+            self.neval += 1
+            if fail:
+                return fail
+        _, self.g, self.Ac = self.prob.eval_obj_con_gradient(v.x)
+        self.ngeval += 1
+        update_type = 0
+        if self.qn is not None and perform_qn_update and use_qnu:
+            s_qn = alpha * p.x
+            y_qn += self.g
+            for i in range(self.c):
+                y_qn += -v.z[i] * self.Ac[i]
+            update_type = self.qn.update(s_qn, y_qn)
+        return update_type
+
+    # ---- starting point --------------------------------------------------------------
+    def init_least_squares_multipliers(self, v, r):  # :5366-5534
+        o = self.opt
+        mb = o["max_bound_value"]
+        mu0 = o["init_barrier_param"]
+        v.zl[:] = mu0
+        v.zu[:] = mu0
+        v.z[:] = mu0
+        v.s[:] = mu0
+        v.t[:] = mu0
+        v.zs[:] = mu0
+        v.zt[:] = mu0
+        v.zl[self.lb <= -mb] = 0.0
+        v.zu[self.ub >= mb] = 0.0
+        small = 1e-4
+        self.Dinv = np.ones(self.n)
+        c = self.c
+        G = np.zeros((c, c))
+        for j in range(c):
+            xt = self.Dinv * self.Ac[j]
+            for i in range(j, c):
+                G[i, j] += self.ops.dot(self.Ac[i], xt)
+        for j in range(c):
+            for i in range(j + 1, c):
+                G[j, i] = G[i, j]
+        for i in range(c):
+            G[i, i] += small
+        self.Glu = sla.lu_factor(G, check_finite=False) if c > 0 else None
+        rx = self.g.copy()
+        rx += -1.0 * v.zl
+        rx += v.zu
+        rx *= -1.0
+        yx = self.Dinv * rx
+        z = -self.ops.mdot(yx, self.Ac)
+        z = self._gsolve(z)
+        v.z[:] = z
+        for i in range(c):
+            gam = 10.0 * max(self.gamma_s[i], self.gamma_t[i])
+            if v.z[i] < -gam or v.z[i] > gam:
+                v.z[i] = 0.0
+
+    def init_affine_step_multipliers(self, v, r, p):  # :5536-5656
+        o = self.opt
+        mb = o["max_bound_value"]
+        amin = o["start_affine_multiplier_min"]
+        self.init_least_squares_multipliers(v, r)
+        v.zl[self.lb <= -mb] = 0.0
+        v.zu[self.ub >= mb] = 0.0
+        self.compute_kkt_res(v, 0.0, r)
+        use_qn = 0 if o["sequential_linear_method"] else 1
+        self.setup_kkt_diag_system(v, use_qn)
+        self.setup_kkt_system(v, use_qn)
+        self.compute_kkt_step(v, r, p, use_qn)
+        v.z[:] = v.z + p.z
+        v.s[:] = np.maximum(amin, np.abs(v.s + p.s))
+        v.t[:] = np.maximum(amin, np.abs(v.t + p.t))
+        v.zs[:] = np.maximum(amin, np.abs(v.zs + p.zs))
+        v.zt[:] = np.maximum(amin, np.abs(v.zt + p.zt))
+        L, U = self._masks()
+        v.zl[:] = np.where(L, np.maximum(amin, np.abs(v.zl + p.zl)), v.zl)
+        v.zu[:] = np.where(U, np.maximum(amin, np.abs(v.zu + p.zu)), v.zu)
+        self.barrier_param = self.compute_comp(v)
+
+    # ---- the major iteration ---------------------------------------------------------
+    def _kkt_step_with_refinement(self, v, barrier_for_res, use_qn):
+        self.compute_kkt_step(v, self.res, self.step, use_qn)
+        for _ in range(self.opt["iterative_refinement_steps"]):  # :4985-4991
+            self.compute_kkt_res(v, barrier_for_res, self.res)
+            self.add_kkt_res_step(v, self.step, self.res)
+            self.compute_kkt_step(v, self.res, self.refine, use_qn)
+            self.step.add(self.refine)
+
+    def optimize(self):  # :4399-5333 (quasi-Newton branch, monotone / complementarity-fraction)
+        o = self.opt
+        abs_res_tol = o["abs_res_tol"]
+        fprec = o["function_precision"]
+        v = self.vars
+        barrier_strategy = "monotone"
+        input_strategy = o["barrier_strategy"]
+        if input_strategy not in ("monotone", "complementarity_fraction"):
+            raise NotImplementedError("oracle covers monotone / complementarity_fraction barrier strategies")
+        self.barrier_param = o["init_barrier_param"]
+        self.rho = o["init_rho_penalty_search"]
+        self.niter = self.neval = self.ngeval = 0
+        if self.qn is None and not o["sequential_linear_method"]:
+            return 1
+        self._init_and_check_bounds()
+        fail, self.fobj, self.cvals = self.prob.eval_obj_con(v.x)
+        self.neval += 1
+        if fail:
+            return fail
+        _, self.g, self.Ac = self.prob.eval_obj_con_gradient(v.x)
+        self.ngeval += 1
+        sp = o["starting_point_strategy"]
+        if sp == "affine_step":
+            self.init_affine_step_multipliers(v, self.res, self.step)
+        elif sp == "least_squares_multipliers":
+            self.init_least_squares_multipliers(v, self.res)
+        fobj_prev = 0.0
+        alpha_prev = alpha_xprev = alpha_zprev = 0.0
+        dm0_prev = 0.0
+        no_merit_improvement = 0
+        line_search_test = 0
+        line_search_failed = 0
+        info = ""
+        self.trace = []
+        k = 0
+        while k < o["max_major_iters"]:
+            qn_reset = 0
+            if self.qn is not None and not o["sequential_linear_method"]:
+                if k > 0 and k % o["hessian_reset_freq"] == 0 and o["use_quasi_newton_update"]:
+                    self.qn.reset()
+                    qn_reset = 1
+            if self.hook is not None:
+                self.hook(self, k)
+            rel_function_test = (
+                alpha_xprev == 1.0
+                and alpha_zprev == 1.0
+                and abs(self.fobj - fobj_prev) < o["rel_func_tol"] * abs(fobj_prev)
+            )
+            if no_merit_improvement:
+                line_search_test += 1
+            else:
+                line_search_test = 0
+            comp = self.compute_comp(v)
+            monotone_converged = 0
+            if barrier_strategy == "monotone":
+                self.compute_kkt_res(v, self.barrier_param, self.res)
+                mp, md, mi, res_norm = self.compute_res_norm(self.res)
+                if k > 0 and (res_norm < 10.0 * self.barrier_param or rel_function_test or line_search_test >= 2):
+                    monotone_converged = 1
+                if monotone_converged:
+                    if self.barrier_param > 0.1 * abs_res_tol:
+                        line_search_test = 0
+                    mu_frac = o["monotone_barrier_fraction"] * self.barrier_param
+                    mu_pow = math.pow(self.barrier_param, o["monotone_barrier_power"])
+                    new_mu = min(mu_frac, mu_pow) if mu_pow < mu_frac else mu_frac
+                    if new_mu < 0.1 * abs_res_tol:
+                        new_mu = 0.09999 * abs_res_tol
+                    self.compute_kkt_res(v, new_mu, self.res)
+                    mp, md, mi, res_norm = self.compute_res_norm(self.res)
+                    self.rho = o["min_rho_penalty_search"]
+                    self.barrier_param = new_mu
+            else:  # complementarity_fraction :4747-4762
+                self.barrier_param = o["monotone_barrier_fraction"] * comp
+                if self.barrier_param < 0.1 * abs_res_tol:
+                    self.barrier_param = 0.1 * abs_res_tol
+                self.compute_kkt_res(v, self.barrier_param, self.res)
+                mp, md, mi, res_norm = self.compute_res_norm(self.res)
+            self.trace.append(
+                dict(
+                    iter=k,
+                    neval=self.neval,
+                    ngeval=self.ngeval,
+                    alpha=alpha_prev,
+                    alpha_x=alpha_xprev,
+                    alpha_z=alpha_zprev,
+                    fobj=self.fobj,
+                    max_prime=mp,
+                    max_infeas=mi,
+                    max_dual=md,
+                    mu=self.barrier_param,
+                    comp=comp,
+                    dmerit=dm0_prev,
+                    rho=self.rho,
+                    info=info,
+                )
+            )
+            converged = 0
+            if (
+                k > 0
+                and self.barrier_param <= 0.1 * abs_res_tol
+                and (res_norm < abs_res_tol or rel_function_test or line_search_test >= 2)
+            ):
+                converged = 1
+            if converged:
+                break
+            fobj_prev = self.fobj
+            seq_linear_step = 0
+            diagonal_qn_step = 0
+            use_qn = 0 if o["sequential_linear_method"] else 1
+            self.setup_kkt_diag_system(v, use_qn)
+            self.setup_kkt_system(v, use_qn)
+            self._kkt_step_with_refinement(v, self.barrier_param, use_qn)
+            tau = max(o["min_fraction_to_boundary"], 1.0 - self.barrier_param)
+            ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp)
+            alpha = 1.0
+            line_fail = LS_FAILURE
+            update_type = 0
+            line_search_skipped = 0
+            no_merit_improvement = 0
+            if o["use_line_search"]:
+                m0, dm0 = self.eval_merit_init_deriv(v, self.step, alpha_x)
+                dm0_prev = dm0
+                if 0.0 <= dm0 <= fprec:
+                    line_search_skipped = 1
+                    update_type = self.compute_step_and_update(v, alpha, self.step, 1, 1)
+                    if fobj_prev + fprec <= self.fobj and self.fobj + fprec <= fobj_prev:
+                        line_fail = LS_NO_IMPROVEMENT
+                else:
+                    if dm0 >= 0.0:  # :5130-5173
+                        if self.qn is not None:
+                            qn_reset = 1
+                            self.qn.reset()
+                        self.compute_kkt_res(v, self.barrier_param, self.res)
+                        mp, md, mi, res_norm = self.compute_res_norm(self.res)
+                        diagonal_qn_step = 1
+                        self.setup_kkt_diag_system(v, 1)
+                        self._kkt_step_with_refinement(v, self.barrier_param, 1)
+                        ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp)
+                        m0, dm0 = self.eval_merit_init_deriv(v, self.step, alpha_x)
+                        dm0_prev = dm0
+                    if dm0 >= 0.0:
+                        line_fail = LS_FAILURE
+                    else:
+                        px_norm = self.ops.maxabs(self.step.x)
+                        alpha_min = 1.0
+                        if px_norm != 0.0:
+                            alpha_min = fprec / px_norm
+                        if alpha_min > 0.5:
+                            alpha_min = 0.5
+                        line_fail, alpha = self.line_search(alpha_min, alpha, m0, dm0)
+                        if px_norm < o["design_precision"]:
+                            line_fail |= LS_SHORT_STEP
+                        if not (line_fail & LS_FAILURE):
+                            update_type = self.compute_step_and_update(v, alpha, self.step, 0, 1)
+            else:
+                m0, dm0 = self.eval_merit_init_deriv(v, self.step, alpha_x)
+                dm0_prev = dm0
+                line_fail = LS_SUCCESS
+                update_type = self.compute_step_and_update(v, alpha, self.step, 1, 1)
+                m1 = self.eval_merit_func(self.fobj, self.cvals, v.x, v.s, v.t)
+                if m1 <= m0 + fprec and m1 + fprec >= m0:
+                    line_fail |= LS_NO_IMPROVEMENT
+                elif abs(dm0) <= fprec:
+                    line_fail = LS_NO_IMPROVEMENT
+            no_merit_improvement = int(
+                bool(line_fail & (LS_NO_IMPROVEMENT | LS_MIN_STEP | LS_SHORT_STEP | LS_FAILURE))
+            )
+            line_search_failed = line_fail & LS_FAILURE
+            alpha_prev, alpha_xprev, alpha_zprev = alpha, alpha_x, alpha_z
+            if self.qn is not None and o["use_quasi_newton_update"] and (line_fail & LS_FAILURE):
+                qn_reset = 1
+                self.qn.reset()
+            toks = []
+            if update_type == 1:
+                toks.append("dampH")
+            elif update_type == 2:
+                toks.append("skipH")
+            if qn_reset:
+                toks.append("resetH")
+            if line_fail & LS_FAILURE:
+                toks.append("LFail")
+            if line_fail & LS_MIN_STEP:
+                toks.append("LMnStp")
+            if line_fail & LS_MAX_ITERS:
+                toks.append("LMxItr")
+            if line_fail & LS_NO_IMPROVEMENT:
+                toks.append("LNoImprv")
+            if seq_linear_step:
+                toks.append("SLP")
+            if diagonal_qn_step:
+                toks.append("DQN")
+            if line_search_skipped:
+                toks.append("LSkip")
+            if ceq_step:
+                toks.append("cmpEq")
+            info = " ".join(toks)
+            if monotone_converged:
+                barrier_strategy = input_strategy
+            k += 1
+            self.niter += 1
+        return 0
+
+    # ---- state snapshot in the layout of oracle/ref_driver.cpp ----------------------
+    def snapshot(self):
+        v = self.vars
+        d = dict(
+            mu=self.barrier_param,
+            rho=self.rho,
+            fobj=self.fobj,
+            c=self.cvals.copy(),
+            z=v.z.copy(),
+            s=v.s.copy(),
+            t=v.t.copy(),
+            zs=v.zs.copy(),
+            zt=v.zt.copy(),
+            counters=np.array([self.niter, self.neval, self.ngeval]),
+            norms=np.array([self.ops.norm(v.x), self.ops.norm(v.zl), self.ops.norm(v.zu)]),
+            x=v.x.copy(),
+            zl=v.zl.copy(),
+            zu=v.zu.copy(),
+        )
+        if self.qn is not None:
+            b0, d0, M, Z = self.qn.get_compact()
+            d["qn_size"] = len(Z)
+            d["qn_b0"] = b0
+            d["qn_d0"] = np.array(d0).copy()
+            d["qn_M"] = np.array(M).copy()
+        return d

@@ -1,0 +1,672 @@
+// TEST INFRASTRUCTURE ONLY (oracle/): driver that links the *unmodified* reference
+// sources where they lie under /root/reference/src and dumps golden vectors.
+//
+// Nothing from the reference is copied into this repository: this file only
+// #includes the reference headers by path at build time (see oracle/Makefile) and
+// is compiled to oracle/_ref/ref_driver, which is git-ignored.
+//
+// Modes
+//   vecops  : ParOptBasicVec dot/mdot/norm/maxabs/l1norm/axpy/scale  (src/ParOptVec.cpp:32-217)
+//   qn      : scripted ParOptLBFGS / ParOptLSR1 update sequences      (src/ParOptQuasiNewton.cpp:162-837)
+//   ip      : ParOptInteriorPoint::optimize traces with per-iteration state dumps
+//             (src/ParOptInteriorPoint.cpp:4399-5333) on the separable problems of DESIGN.md
+//   bench   : timing of optimize() / mdot for the CPU baseline (kind = "reference")
+//
+// Record file format (little endian): repeated
+//   int32 name_len, char name[name_len], int32 dtype (0=f64, 1=i32), int64 count, payload
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <complex>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mpi.h"
+
+// Expose the private state of the solver so single-step known-answer tests can be
+// produced. The standard headers above are pre-included so
+// that only reference classes are affected.
+#define private public
+#define protected public
+#include "ParOptInteriorPoint.h"
+#include "ParOptQuasiNewton.h"
+#undef private
+#undef protected
+
+// ---------------------------------------------------------------------------
+// Counter-hash synthetic data: identical in oracle/paropt_oracle.py and in the
+// HIP product (paropt_amd/csrc/problems.hip).  u01(seed, array_id, global index).
+// ---------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+static inline double u01(uint64_t seed, uint64_t aid, uint64_t i) {
+  uint64_t h = splitmix64(seed * 0x9E3779B97F4A7C15ULL + aid * 0xD1B54A32D192ED03ULL + i);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------
+// Record writer
+// ---------------------------------------------------------------------------
+struct RecFile {
+  FILE *fp;
+  RecFile() : fp(NULL) {}
+  void open(const char *name) { fp = fopen(name, "wb"); }
+  void close() {
+    if (fp) fclose(fp);
+    fp = NULL;
+  }
+  void put(const char *name, int dtype, int64_t count, const void *data) {
+    if (!fp) return;
+    int32_t len = (int32_t)strlen(name);
+    fwrite(&len, 4, 1, fp);
+    fwrite(name, 1, len, fp);
+    int32_t dt = dtype;
+    fwrite(&dt, 4, 1, fp);
+    fwrite(&count, 8, 1, fp);
+    fwrite(data, dtype == 0 ? 8 : 4, count, fp);
+  }
+  void f64(const char *name, const double *v, int64_t n) { put(name, 0, n, v); }
+  void f64s(const char *name, double v) { put(name, 0, 1, &v); }
+  void i32(const char *name, const int *v, int64_t n) { put(name, 1, n, v); }
+  void i32s(const char *name, int v) { put(name, 1, 1, &v); }
+  void vec(const char *name, ParOptVec *v) {
+    double *a;
+    int n = v->getArray(&a);
+    f64(name, a, n);
+  }
+};
+
+static std::string fmt(const char *f, ...) {
+  char buf[256];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof(buf), f, ap);
+  va_end(ap);
+  return std::string(buf);
+}
+
+// ---------------------------------------------------------------------------
+// Problems (DESIGN.md "Workloads"): separable restrictions of the reference's
+// examples/random_quadratic/random_quadratic.py and examples/random_convex/random_convex.py,
+// and the w=0 variant of examples/rosenbrock/rosenbrock.cpp.
+// ---------------------------------------------------------------------------
+class ParOptInteriorPoint;
+struct DumpHook;
+
+class SepProblem : public ParOptProblem {
+ public:
+  enum Kind { QUADRATIC = 0, CONVEX = 1, ROSENBROCK = 2 };
+  SepProblem(MPI_Comm comm, Kind _kind, int nlocal, int64_t _offset, int64_t _nglobal, int _ncon,
+             uint64_t _seed, double _eig_min, double _eig_max)
+      : ParOptProblem(comm) {
+    kind = _kind;
+    offset = _offset;
+    nglobal = _nglobal;
+    seed = _seed;
+    eig_min = _eig_min;
+    eig_max = _eig_max;
+    setProblemSizes(nlocal, _ncon, 0);
+    setNumInequalities(_ncon, 0);
+    hook = NULL;
+    beta.resize(_ncon);
+    if (kind == QUADRATIC) {
+      for (int j = 0; j < _ncon; j++) beta[j] = u01(seed, 4, j);
+    } else if (kind == CONVEX) {
+      for (int j = 0; j < _ncon; j++) {
+        double loc = 0.0, tot = 0.0;
+        for (int i = 0; i < nlocal; i++) loc += u01(seed, 100 + j, offset + i);
+        MPI_Allreduce(&loc, &tot, 1, MPI_DOUBLE, MPI_SUM, comm);
+        beta[j] = 0.25 * tot;
+      }
+    }
+  }
+  ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefBlockMat(this, 1); }
+
+  void getVarsAndBounds(ParOptVec *xv, ParOptVec *lbv, ParOptVec *ubv) {
+    double *x, *lb, *ub;
+    xv->getArray(&x);
+    lbv->getArray(&lb);
+    ubv->getArray(&ub);
+    for (int i = 0; i < nvars; i++) {
+      if (kind == QUADRATIC) {
+        x[i] = -2.0 + u01(seed, 3, offset + i);
+        lb[i] = -5.0;
+        ub[i] = 5.0;
+      } else if (kind == CONVEX) {
+        x[i] = 0.05 + 0.9 * u01(seed, 3, offset + i);
+        lb[i] = 0.0;
+        ub[i] = 1.0;
+      } else {
+        x[i] = -1.0;
+        lb[i] = -2.0;
+        ub[i] = 1.0;
+      }
+    }
+  }
+
+  int evalObjCon(ParOptVec *xv, ParOptScalar *fobj, ParOptScalar *cons) {
+    double *x;
+    xv->getArray(&x);
+    std::vector<double> loc(ncon + 1, 0.0), tot(ncon + 1, 0.0);
+    if (kind == QUADRATIC) {
+      for (int i = 0; i < nvars; i++) {
+        double q = eig_min + (eig_max - eig_min) * u01(seed, 1, offset + i);
+        double b = u01(seed, 2, offset + i);
+        loc[0] += 0.5 * q * x[i] * x[i] + b * x[i];
+      }
+      for (int j = 0; j < ncon; j++) {
+        double s = 0.0;
+        for (int i = 0; i < nvars; i++) s += u01(seed, 100 + j, offset + i) * x[i];
+        loc[1 + j] = s;
+      }
+    } else if (kind == CONVEX) {
+      for (int i = 0; i < nvars; i++) {
+        double b = u01(seed, 2, offset + i);
+        loc[0] += b * b / (1e-3 + x[i]);
+      }
+      for (int j = 0; j < ncon; j++) {
+        double s = 0.0;
+        for (int i = 0; i < nvars; i++) s += u01(seed, 100 + j, offset + i) * x[i];
+        loc[1 + j] = -s;
+      }
+    } else {
+      // Rank-local chained Rosenbrock, as examples/rosenbrock/rosenbrock.cpp:49-78
+      for (int i = 0; i < nvars - 1; i++) {
+        loc[0] += ((1.0 - x[i]) * (1.0 - x[i]) +
+                   100.0 * (x[i + 1] - x[i] * x[i]) * (x[i + 1] - x[i] * x[i]));
+      }
+      for (int i = 0; i < nvars; i++) loc[1] -= x[i] * x[i];
+      for (int i = 0; i < nvars; i += 2) loc[2] += x[i];
+    }
+    MPI_Allreduce(&loc[0], &tot[0], ncon + 1, MPI_DOUBLE, MPI_SUM, comm);
+    *fobj = tot[0];
+    for (int j = 0; j < ncon; j++) cons[j] = tot[1 + j];
+    if (kind == QUADRATIC || kind == CONVEX) {
+      for (int j = 0; j < ncon; j++) cons[j] += beta[j];
+    } else {
+      cons[0] += 0.25;
+      cons[1] += 10.0;
+    }
+    return 0;
+  }
+
+  int evalObjConGradient(ParOptVec *xv, ParOptVec *gv, ParOptVec **Ac) {
+    double *x, *g;
+    xv->getArray(&x);
+    gv->getArray(&g);
+    if (kind == QUADRATIC) {
+      for (int i = 0; i < nvars; i++) {
+        double q = eig_min + (eig_max - eig_min) * u01(seed, 1, offset + i);
+        g[i] = q * x[i] + u01(seed, 2, offset + i);
+      }
+      for (int j = 0; j < ncon; j++) {
+        double *a;
+        Ac[j]->getArray(&a);
+        for (int i = 0; i < nvars; i++) a[i] = u01(seed, 100 + j, offset + i);
+      }
+    } else if (kind == CONVEX) {
+      for (int i = 0; i < nvars; i++) {
+        double b = u01(seed, 2, offset + i);
+        double d = 1e-3 + x[i];
+        g[i] = -(b * b) / (d * d);
+      }
+      for (int j = 0; j < ncon; j++) {
+        double *a;
+        Ac[j]->getArray(&a);
+        for (int i = 0; i < nvars; i++) a[i] = -u01(seed, 100 + j, offset + i);
+      }
+    } else {
+      gv->zeroEntries();
+      for (int i = 0; i < nvars - 1; i++) {
+        g[i] += (-2.0 * (1.0 - x[i]) + 200.0 * (x[i + 1] - x[i] * x[i]) * (-2.0 * x[i]));
+        g[i + 1] += 200.0 * (x[i + 1] - x[i] * x[i]);
+      }
+      double *a;
+      Ac[0]->getArray(&a);
+      for (int i = 0; i < nvars; i++) a[i] = -2.0 * x[i];
+      Ac[1]->getArray(&a);
+      for (int i = 0; i < nvars; i++) a[i] = 0.0;
+      for (int i = 0; i < nvars; i += 2) a[i] = 1.0;
+    }
+    return 0;
+  }
+
+  void writeOutput(int iter, ParOptVec *x);
+
+  Kind kind;
+  int64_t offset, nglobal;
+  uint64_t seed;
+  double eig_min, eig_max;
+  std::vector<double> beta;
+  DumpHook *hook;
+};
+
+struct DumpHook {
+  ParOptInteriorPoint *ip;
+  RecFile *rec;
+  int kat_iter;  // iteration at which the private single-step KAT is dumped (-1: never)
+  int dump_vecs_every;
+};
+
+void SepProblem::writeOutput(int iter, ParOptVec *x) {
+  if (!hook || !hook->rec) return;  // collective: every rank runs the reductions below
+  ParOptInteriorPoint *ip = hook->ip;
+  RecFile &R = *hook->rec;
+  int c = ncon;
+  std::string p = fmt("it%03d/", iter);
+  R.f64s((p + "mu").c_str(), ip->barrier_param);
+  R.f64s((p + "rho").c_str(), ip->rho_penalty_search);
+  R.f64s((p + "fobj").c_str(), ip->fobj);
+  R.f64((p + "c").c_str(), ip->c, c);
+  R.f64((p + "z").c_str(), ip->variables.z, c);
+  R.f64((p + "s").c_str(), ip->variables.s, c);
+  R.f64((p + "t").c_str(), ip->variables.t, c);
+  R.f64((p + "zs").c_str(), ip->variables.zs, c);
+  R.f64((p + "zt").c_str(), ip->variables.zt, c);
+  int cnt[3] = {ip->niter, ip->neval, ip->ngeval};
+  R.i32((p + "counters").c_str(), cnt, 3);
+  if (ip->qn) {
+    ParOptScalar b0;
+    const ParOptScalar *d0, *M;
+    ParOptVec **Z;
+    int k = ip->qn->getCompactMat(&b0, &d0, &M, &Z);
+    R.i32s((p + "qn_size").c_str(), k);
+    R.f64s((p + "qn_b0").c_str(), b0);
+    if (k > 0) {
+      R.f64((p + "qn_d0").c_str(), d0, k);
+      R.f64((p + "qn_M").c_str(), M, (int64_t)k * k);
+    }
+  }
+  // Scalar fingerprints of the distributed vectors (collective calls)
+  double nx = ip->variables.x->norm(), nzl = ip->variables.zl->norm(),
+         nzu = ip->variables.zu->norm();
+  double fp[3] = {nx, nzl, nzu};
+  R.f64((p + "norms").c_str(), fp, 3);
+  if (hook->dump_vecs_every > 0 && (iter % hook->dump_vecs_every) == 0) {
+    R.vec((p + "x").c_str(), ip->variables.x);
+    R.vec((p + "zl").c_str(), ip->variables.zl);
+    R.vec((p + "zu").c_str(), ip->variables.zu);
+  }
+  if (iter == hook->kat_iter) {
+    // Single-step KAT through the private methods, in the order optimize() uses
+    // them (src/ParOptInteriorPoint.cpp:4670,4971-4982). All scratch that is touched
+    // is recomputed by optimize() right after this hook returns.
+    ip->computeKKTRes(ip->variables, ip->barrier_param, ip->residual);
+    double mp, md, mi, rn;
+    ip->computeResNorm(PAROPT_INFTY_NORM, ip->residual, &mp, &md, &mi, &rn);
+    double rnorms[4] = {mp, md, mi, rn};
+    R.f64("kat/res_norms", rnorms, 4);
+    R.vec("kat/g", ip->g);
+    for (int j = 0; j < c; j++) R.vec(fmt("kat/Ac%d", j).c_str(), ip->Ac[j]);
+    R.vec("kat/lb", ip->lb);
+    R.vec("kat/ub", ip->ub);
+    R.vec("kat/x", ip->variables.x);
+    R.vec("kat/zl", ip->variables.zl);
+    R.vec("kat/zu", ip->variables.zu);
+    R.vec("kat/res_x", ip->residual.x);
+    R.vec("kat/res_zl", ip->residual.zl);
+    R.vec("kat/res_zu", ip->residual.zu);
+    R.f64("kat/res_z", ip->residual.z, c);
+    R.f64("kat/res_s", ip->residual.s, c);
+    R.f64("kat/res_t", ip->residual.t, c);
+    R.f64("kat/res_zs", ip->residual.zs, c);
+    R.f64("kat/res_zt", ip->residual.zt, c);
+    ip->setUpKKTDiagSystem(ip->variables, ip->s_qn, ip->wtemp, 1);
+    R.vec("kat/Dinv", ip->Dinv);
+    R.f64("kat/Gmat_lu", ip->Gmat, (int64_t)c * c);
+    R.i32("kat/gpiv", ip->gpiv, c);
+    ip->setUpKKTSystem(ip->variables, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, 1);
+    if (ip->qn) {
+      ParOptScalar b0;
+      const ParOptScalar *d0, *M;
+      ParOptVec **Z;
+      int k = ip->qn->getCompactMat(&b0, &d0, &M, &Z);
+      for (int j = 0; j < k; j++) R.vec(fmt("kat/Z%d", j).c_str(), Z[j]);
+      if (k > 0) {
+        R.f64("kat/Ce_lu", ip->Ce, (int64_t)k * k);
+        R.i32("kat/cpiv", ip->cpiv, k);
+      }
+    }
+    ip->computeKKTStep(ip->variables, ip->residual, ip->update, ip->ztemp, ip->s_qn, ip->y_qn,
+                       ip->wtemp, 1);
+    R.vec("kat/step_x", ip->update.x);
+    R.vec("kat/step_zl", ip->update.zl);
+    R.vec("kat/step_zu", ip->update.zu);
+    R.f64("kat/step_z", ip->update.z, c);
+    R.f64("kat/step_s", ip->update.s, c);
+    R.f64("kat/step_t", ip->update.t, c);
+    R.f64("kat/step_zs", ip->update.zs, c);
+    R.f64("kat/step_zt", ip->update.zt, c);
+    double comp = ip->computeComp(ip->variables);
+    R.f64s("kat/comp", comp);
+    double mx, mz;
+    ip->computeMaxStep(ip->variables, 0.95, ip->update, &mx, &mz);
+    double ms[2] = {mx, mz};
+    R.f64("kat/max_step_tau095", ms, 2);
+    double compstep = ip->computeCompStep(ip->variables, mx, mz, ip->update);
+    R.f64s("kat/comp_step", compstep);
+  }
+}
+
+// ---------------------------------------------------------------------------
+static std::map<std::string, std::string> parse_args(int argc, char **argv) {
+  std::map<std::string, std::string> m;
+  for (int i = 2; i < argc; i++) {
+    std::string a(argv[i]);
+    size_t eq = a.find('=');
+    if (eq != std::string::npos) m[a.substr(0, eq)] = a.substr(eq + 1);
+  }
+  return m;
+}
+static std::string gets(std::map<std::string, std::string> &m, const char *k, const char *d) {
+  return m.count(k) ? m[k] : std::string(d);
+}
+static long geti(std::map<std::string, std::string> &m, const char *k, long d) {
+  return m.count(k) ? atol(m[k].c_str()) : d;
+}
+static double getf(std::map<std::string, std::string> &m, const char *k, double d) {
+  return m.count(k) ? atof(m[k].c_str()) : d;
+}
+
+static void shard(int64_t n, int rank, int size, int *nlocal, int64_t *offset) {
+  int64_t base = n / size, rem = n % size;
+  *nlocal = (int)(base + (rank < rem ? 1 : 0));
+  *offset = rank * base + (rank < rem ? rank : rem);
+}
+
+class DummyProblem : public ParOptProblem {
+ public:
+  DummyProblem(MPI_Comm comm, int n) : ParOptProblem(comm) { setProblemSizes(n, 0, 0); }
+  ParOptQuasiDefMat *createQuasiDefMat() { return NULL; }
+  void getVarsAndBounds(ParOptVec *, ParOptVec *, ParOptVec *) {}
+  int evalObjCon(ParOptVec *, ParOptScalar *, ParOptScalar *) { return 0; }
+  int evalObjConGradient(ParOptVec *, ParOptVec *, ParOptVec **) { return 0; }
+};
+
+static void fill(ParOptVec *v, uint64_t seed, uint64_t aid, int64_t offset, double scale,
+                 double shift) {
+  double *a;
+  int n = v->getArray(&a);
+  for (int i = 0; i < n; i++) a[i] = shift + scale * u01(seed, aid, offset + i);
+}
+
+// ---------------------------------------------------------------------------
+static int mode_vecops(std::map<std::string, std::string> &A, MPI_Comm comm, int rank, int size) {
+  int64_t n = geti(A, "n", 1000);
+  int nvecs = (int)geti(A, "nvecs", 8);
+  uint64_t seed = (uint64_t)geti(A, "seed", 0);
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  RecFile R;
+  if (rank == 0) R.open(gets(A, "out", "vecops.rec").c_str());
+  ParOptBasicVec *x = new ParOptBasicVec(comm, nlocal);
+  x->incref();
+  ParOptBasicVec *y = new ParOptBasicVec(comm, nlocal);
+  y->incref();
+  std::vector<ParOptVec *> V(nvecs);
+  fill(x, seed, 10, offset, 2.0, -1.0);
+  fill(y, seed, 11, offset, 2.0, -1.0);
+  for (int j = 0; j < nvecs; j++) {
+    V[j] = new ParOptBasicVec(comm, nlocal);
+    V[j]->incref();
+    fill(V[j], seed, 20 + j, offset, 2.0, -1.0);
+  }
+  R.i32s("n", (int)n);
+  R.i32s("nvecs", nvecs);
+  R.f64s("dot", x->dot(y));
+  R.f64s("norm", x->norm());
+  R.f64s("maxabs", x->maxabs());
+  R.f64s("l1norm", x->l1norm());
+  std::vector<double> out(nvecs);
+  x->mdot(&V[0], nvecs, &out[0]);
+  R.f64("mdot", &out[0], nvecs);
+  // y <- 0.75*y ; y <- y + (-1.25)*x
+  y->scale(0.75);
+  y->axpy(-1.25, x);
+  R.f64s("post_norm", y->norm());
+  R.f64s("post_l1", y->l1norm());
+  R.f64s("post_dot", y->dot(x));
+  if (n <= 5000 && size == 1) R.vec("post_y", y);
+  R.close();
+  return 0;
+}
+
+// Scripted quasi-Newton sequence: s_k, y_k from the hash with engineered curvature.
+static int mode_qn(std::map<std::string, std::string> &A, MPI_Comm comm, int rank, int size) {
+  int64_t n = geti(A, "n", 200);
+  int msub = (int)geti(A, "msub", 3);
+  int steps = (int)geti(A, "steps", 25);
+  uint64_t seed = (uint64_t)geti(A, "seed", 0);
+  std::string type = gets(A, "type", "bfgs");
+  std::string upd = gets(A, "update", "skip");
+  std::string diag = gets(A, "diag", "yty_over_yts");
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  DummyProblem *prob = new DummyProblem(comm, nlocal);
+  prob->incref();
+  ParOptCompactQuasiNewton *qn;
+  if (type == "bfgs") {
+    ParOptLBFGS *b = new ParOptLBFGS(prob, msub);
+    b->setBFGSUpdateType(upd == "damped" ? PAROPT_DAMPED_UPDATE : PAROPT_SKIP_NEGATIVE_CURVATURE);
+    qn = b;
+  } else {
+    qn = new ParOptLSR1(prob, msub);
+  }
+  qn->incref();
+  qn->setInitDiagonalType(diag == "yts_over_sts" ? PAROPT_YTS_OVER_STS : PAROPT_YTY_OVER_YTS);
+  RecFile R;
+  if (rank == 0) R.open(gets(A, "out", "qn.rec").c_str());
+  R.i32s("n", (int)n);
+  R.i32s("msub_max", msub);
+  R.i32s("steps", steps);
+  ParOptVec *s = prob->createDesignVec();
+  s->incref();
+  ParOptVec *y = prob->createDesignVec();
+  y->incref();
+  ParOptVec *xp = prob->createDesignVec();
+  xp->incref();
+  ParOptVec *out = prob->createDesignVec();
+  out->incref();
+  fill(xp, seed, 7, offset, 2.0, -1.0);
+  double *sa, *ya;
+  s->getArray(&sa);
+  y->getArray(&ya);
+  for (int k = 0; k < steps; k++) {
+    // y = h.*s + noise, h in [0.5, 4.5]; every 5th pair has negative curvature,
+    // every 7th has a tiny y^T s (Nocedal skip test, src/ParOptQuasiNewton.cpp:175-179).
+    for (int i = 0; i < nlocal; i++) {
+      double sv = 2.0 * u01(seed, 1000 + k, offset + i) - 1.0;
+      double h = 0.5 + 4.0 * u01(seed, 5, offset + i);
+      double noise = 0.2 * (2.0 * u01(seed, 2000 + k, offset + i) - 1.0);
+      double yv = h * sv + noise;
+      if (k % 5 == 4) yv = -0.3 * h * sv + noise;
+      if (k % 7 == 6) yv = 1e10 * noise;  // |y^T s| <= 1e-8 y^T y
+      sa[i] = sv;
+      ya[i] = yv;
+    }
+    int rc = qn->update(NULL, NULL, NULL, s, y);
+    ParOptScalar b0;
+    const ParOptScalar *d0, *M;
+    ParOptVec **Z;
+    int ksz = qn->getCompactMat(&b0, &d0, &M, &Z);
+    std::string p = fmt("k%02d/", k);
+    R.i32s((p + "rc").c_str(), rc);
+    R.i32s((p + "size").c_str(), ksz);
+    R.f64s((p + "b0").c_str(), b0);
+    if (ksz > 0) {
+      R.f64((p + "d0").c_str(), d0, ksz);
+      R.f64((p + "M").c_str(), M, (int64_t)ksz * ksz);
+    }
+    qn->mult(xp, out);
+    double fp[3] = {out->norm(), out->dot(xp), out->l1norm()};
+    R.f64((p + "mult_fp").c_str(), fp, 3);
+    if (size == 1 && n <= 2000) R.vec((p + "mult").c_str(), out);
+    out->copyValues(s);
+    qn->multAdd(-0.5, xp, out);
+    double fp2[2] = {out->norm(), out->dot(xp)};
+    R.f64((p + "multadd_fp").c_str(), fp2, 2);
+  }
+  R.close();
+  return 0;
+}
+
+static SepProblem::Kind kind_of(const std::string &s) {
+  if (s == "quadratic") return SepProblem::QUADRATIC;
+  if (s == "convex") return SepProblem::CONVEX;
+  return SepProblem::ROSENBROCK;
+}
+
+static void set_options(ParOptOptions *opt, std::map<std::string, std::string> &A) {
+  // Every "opt.<name>=<value>" argument is forwarded to ParOptOptions::setOption with the
+  // type the reference registered for it (src/ParOptInteriorPoint.cpp:536-727).
+  for (std::map<std::string, std::string>::iterator it = A.begin(); it != A.end(); ++it) {
+    if (it->first.compare(0, 4, "opt.") != 0) continue;
+    std::string name = it->first.substr(4);
+    int t = opt->getOptionType(name.c_str());
+    if (t == ParOptOptions::PAROPT_FLOAT_OPTION) {
+      opt->setOption(name.c_str(), atof(it->second.c_str()));
+    } else if (t == ParOptOptions::PAROPT_INT_OPTION || t == ParOptOptions::PAROPT_BOOLEAN_OPTION) {
+      opt->setOption(name.c_str(), atoi(it->second.c_str()));
+    } else {
+      opt->setOption(name.c_str(), it->second.c_str());
+    }
+  }
+}
+
+static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int rank, int size,
+                   bool bench) {
+  int64_t n = geti(A, "n", 1000);
+  int c = (int)geti(A, "c", 8);
+  uint64_t seed = (uint64_t)geti(A, "seed", 0);
+  std::string pname = gets(A, "problem", "quadratic");
+  SepProblem::Kind kind = kind_of(pname);
+  if (kind == SepProblem::ROSENBROCK) c = 2;
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  SepProblem *prob = new SepProblem(comm, kind, nlocal, offset, n, c, seed, getf(A, "eig_min", 1.0),
+                                    getf(A, "eig_max", 100.0));
+  prob->incref();
+  ParOptOptions *opt = new ParOptOptions(comm);
+  opt->incref();
+  ParOptInteriorPoint::addDefaultOptions(opt);
+  std::string outfile = gets(A, "text", "");
+  if (outfile.size()) {
+    opt->setOption("output_file", outfile.c_str());
+  } else {
+    opt->setOption("output_file", "/dev/null");
+  }
+  set_options(opt, A);
+  ParOptInteriorPoint *ip = new ParOptInteriorPoint(prob, opt);
+  ip->incref();
+  RecFile R;
+  DumpHook hook;
+  hook.ip = ip;
+  hook.rec = &R;
+  hook.kat_iter = (int)geti(A, "kat_iter", -1);
+  hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
+  if (!bench) {
+    if (rank == 0) R.open(gets(A, "out", "ip.rec").c_str());
+    prob->hook = &hook;
+    R.i32s("n", (int)n);
+    R.i32s("c", c);
+  }
+  double t0 = MPI_Wtime();
+  int rc = ip->optimize(NULL);
+  double t1 = MPI_Wtime();
+  int niter, neval, ngeval;
+  ip->getIterationCounters(&niter, &neval, &ngeval);
+  if (!bench) {
+    R.i32s("final/rc", rc);
+    int cnt[3] = {niter, neval, ngeval};
+    R.i32("final/counters", cnt, 3);
+    R.f64s("final/fobj", ip->fobj);
+    R.f64s("final/mu", ip->barrier_param);
+    R.f64((std::string("final/z")).c_str(), ip->variables.z, c);
+    double fp[3] = {ip->variables.x->norm(), ip->variables.zl->norm(), ip->variables.zu->norm()};
+    R.f64("final/norms", fp, 3);
+    if (hook.dump_vecs_every > 0) {
+      R.vec("final/x", ip->variables.x);
+      R.vec("final/zl", ip->variables.zl);
+      R.vec("final/zu", ip->variables.zu);
+    }
+    R.close();
+  }
+  if (rank == 0) {
+    printf(
+        "{\"mode\":\"ip\",\"problem\":\"%s\",\"n\":%ld,\"c\":%d,\"ranks\":%d,\"niter\":%d,"
+        "\"neval\":%d,\"ngeval\":%d,\"seconds\":%.6f,\"it_per_s\":%.6f,\"fobj\":%.17g}\n",
+        pname.c_str(), (long)n, c, size, niter, neval, ngeval, t1 - t0,
+        niter / (t1 - t0 > 0 ? t1 - t0 : 1.0), ip->fobj);
+  }
+  ip->decref();
+  return rc;
+}
+
+static int mode_mdot_bench(std::map<std::string, std::string> &A, MPI_Comm comm, int rank,
+                           int size) {
+  int64_t n = geti(A, "n", 10000000);
+  int nvecs = (int)geti(A, "nvecs", 32);
+  int reps = (int)geti(A, "reps", 5);
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  ParOptBasicVec *x = new ParOptBasicVec(comm, nlocal);
+  x->incref();
+  fill(x, 0, 10, offset, 2.0, -1.0);
+  std::vector<ParOptVec *> V(nvecs);
+  for (int j = 0; j < nvecs; j++) {
+    V[j] = new ParOptBasicVec(comm, nlocal);
+    V[j]->incref();
+    fill(V[j], 0, 20 + j, offset, 2.0, -1.0);
+  }
+  std::vector<double> out(nvecs);
+  x->mdot(&V[0], nvecs, &out[0]);
+  MPI_Barrier(comm);
+  double t0 = MPI_Wtime();
+  for (int r = 0; r < reps; r++) x->mdot(&V[0], nvecs, &out[0]);
+  MPI_Barrier(comm);
+  double t1 = MPI_Wtime();
+  if (rank == 0) {
+    double sec = (t1 - t0) / reps;
+    printf(
+        "{\"mode\":\"mdot\",\"n\":%ld,\"nvecs\":%d,\"ranks\":%d,\"seconds\":%.6f,"
+        "\"alg_GBps\":%.3f,\"out0\":%.17g}\n",
+        (long)n, nvecs, size, sec, 8.0 * (nvecs + 1) * n / sec * 1e-9, out[0]);
+  }
+  return 0;
+}
+
+int main(int argc, char *argv[]) {
+  MPI_Init(&argc, &argv);
+  MPI_Comm comm = MPI_COMM_WORLD;
+  int rank, size;
+  MPI_Comm_rank(comm, &rank);
+  MPI_Comm_size(comm, &size);
+  int rc = 1;
+  if (argc >= 2) {
+    std::map<std::string, std::string> A = parse_args(argc, argv);
+    std::string mode(argv[1]);
+    if (mode == "vecops") rc = mode_vecops(A, comm, rank, size);
+    if (mode == "qn") rc = mode_qn(A, comm, rank, size);
+    if (mode == "ip") rc = mode_ip(A, comm, rank, size, false);
+    if (mode == "bench") rc = mode_ip(A, comm, rank, size, true);
+    if (mode == "mdot") rc = mode_mdot_bench(A, comm, rank, size);
+  } else if (rank == 0) {
+    fprintf(stderr, "usage: ref_driver vecops|qn|ip|bench|mdot key=value ...\n");
+  }
+  MPI_Finalize();
+  return rc;
+}

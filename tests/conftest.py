@@ -1,0 +1,41 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+    """A fixture produced by oracle/make_golden.py from the compiled reference."""
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False))
+    case = json.loads(str(d.pop("case_json")))
+    return d, case
+
+
+def golden_names(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def ip_options_from_case(case):
+    """Translate the ref_driver 'opt.*' arguments into an options dict."""
+    opts = {}
+    for k, v in case["args"].items():
+        if k.startswith("opt."):
+            opts[k[4:]] = v
+    return opts
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN_DIR

@@ -1,0 +1,225 @@
+"""
+Pins the numpy oracle (oracle/paropt_oracle.py) against golden vectors produced by the REAL
+reference (oracle/_ref/ref_driver built from /root/reference/src; oracle/make_golden.py).
+
+Tolerances (fp64): reductions 1e-13 relative to sum|terms|; quasi-Newton compact matrices
+1e-11; interior-point trajectories: per-iteration scalars 1e-7 relative over the compared
+window (the iteration is nonlinear and the summation order differs from MKL's), integer
+bookkeeping (counters, quasi-Newton size, update return codes, info tokens) bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, ip_options_from_case, load_golden
+from oracle import paropt_oracle as po
+
+
+def fill(seed, aid, n, offset=0, scale=2.0, shift=-1.0):
+    return shift + scale * po.u01(seed, aid, np.arange(offset, offset + n, dtype=np.uint64))
+
+
+@pytest.mark.parametrize("name", golden_names("vecops_"))
+def test_vecops(name):
+    g, case = load_golden(name)
+    n, nv = int(g["n"][0]), int(g["nvecs"][0])
+    ops = po.VecOps()
+    x = fill(0, 10, n)
+    y = fill(0, 11, n)
+    V = [fill(0, 20 + j, n) for j in range(nv)]
+    tol = 1e-13 * n
+    assert abs(ops.dot(x, y) - g["dot"][0]) <= tol
+    assert abs(ops.norm(x) - g["norm"][0]) <= tol
+    assert ops.maxabs(x) == g["maxabs"][0]  # max is exact
+    assert abs(ops.l1norm(x) - g["l1norm"][0]) <= tol
+    np.testing.assert_allclose(ops.mdot(x, V), g["mdot"], rtol=0, atol=tol)
+    y = 0.75 * y
+    y = y + (-1.25) * x
+    assert abs(ops.norm(y) - g["post_norm"][0]) <= tol
+    assert abs(ops.l1norm(y) - g["post_l1"][0]) <= tol
+    assert abs(ops.dot(y, x) - g["post_dot"][0]) <= tol
+    if "post_y" in g:
+        np.testing.assert_allclose(y, g["post_y"], rtol=1e-15, atol=1e-15)
+
+
+def qn_pair(seed, k, n):
+    idx = np.arange(n, dtype=np.uint64)
+    sv = 2.0 * po.u01(seed, 1000 + k, idx) - 1.0
+    h = 0.5 + 4.0 * po.u01(seed, 5, idx)
+    noise = 0.2 * (2.0 * po.u01(seed, 2000 + k, idx) - 1.0)
+    yv = h * sv + noise
+    if k % 5 == 4:
+        yv = -0.3 * h * sv + noise
+    if k % 7 == 6:
+        yv = 1e10 * noise
+    return sv, yv
+
+
+@pytest.mark.parametrize("name", golden_names("qn_"))
+def test_quasi_newton(name):
+    g, case = load_golden(name)
+    a = case["args"]
+    n, msub, steps = int(g["n"][0]), int(g["msub_max"][0]), int(g["steps"][0])
+    ops = po.VecOps()
+    if a["type"] == "bfgs":
+        qn = po.LBFGS(n, msub, ops, "damped_update" if a["update"] == "damped" else "skip_negative_curvature")
+    else:
+        qn = po.LSR1(n, msub, ops)
+    qn.diag_type = a.get("diag", "yty_over_yts")
+    xp = fill(0, 7, n)
+    rcs = []
+    for k in range(steps):
+        s, y = qn_pair(0, k, n)
+        rc = qn.update(s, y)
+        rcs.append(rc)
+        p = "k%02d/" % k
+        assert rc == int(g[p + "rc"][0]), "update return code at step %d" % k
+        b0, d0, M, Z = qn.get_compact()
+        assert len(Z) == int(g[p + "size"][0])
+        assert abs(b0 - g[p + "b0"][0]) <= 1e-12 * abs(b0)
+        if len(Z):
+            np.testing.assert_allclose(d0, g[p + "d0"], rtol=1e-12)
+            Mref = g[p + "M"].reshape(len(Z), len(Z)).T  # column-major in the reference
+            np.testing.assert_allclose(M, Mref, rtol=1e-11, atol=1e-11 * np.abs(Mref).max())
+        out = qn.mult(xp)
+        scale = np.abs(g[p + "mult"]).max()
+        # L-SR1's M is indefinite and, with the 1e10-scaled pair in memory, ill-conditioned:
+        # the solve amplifies rounding differences between LAPACK builds (M itself agrees to 1e-11)
+        mtol = 1e-8 if a["type"] == "bfgs" else 5e-6
+        np.testing.assert_allclose(out, g[p + "mult"], rtol=0, atol=mtol * scale)
+        out2 = qn.mult_add(-0.5, xp, s.copy())
+        fp2 = np.array([ops.norm(out2), ops.dot(out2, xp)])
+        np.testing.assert_allclose(fp2, g[p + "multadd_fp"], rtol=mtol)
+    # the scripted sequence must exercise every return code the variant can produce
+    if a["type"] == "bfgs":
+        assert 2 in rcs
+        if a["update"] == "damped":
+            assert 1 in rcs
+
+
+def run_oracle_ip(case, nmax=None):
+    a = case["args"]
+    prob = po.SepProblem(
+        a["problem"], a["n"], a.get("c", 2), seed=a.get("seed", 0),
+        eig_min=a.get("eig_min", 1.0), eig_max=a.get("eig_max", 100.0),
+    )
+    opts = ip_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    for k in ("use_line_search",):
+        if k in opts:
+            opts[k] = bool(opts[k])
+    ip = po.InteriorPoint(prob, opts)
+    snaps = []
+    ip.hook = lambda s, k: snaps.append(s.snapshot())
+    rc = ip.optimize()
+    return ip, snaps, rc
+
+
+def info_tokens(paropt_out):
+    """Per-iteration info tokens from the reference's iteration table."""
+    toks = {}
+    for ln in str(paropt_out).splitlines():
+        parts = ln.split()
+        if len(parts) >= 15 and parts[0].isdigit():
+            toks[int(parts[0])] = parts[15:]
+    return toks
+
+
+IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2")]
+
+
+@pytest.mark.parametrize("name", IP_CASES)
+def test_ip_trajectory(name):
+    g, case = load_golden(name)
+    ip, snaps, rc = run_oracle_ip(case)
+    assert rc == int(g["final/rc"][0])
+    nref = 1 + max(int(k[2:5]) for k in g if k.startswith("it") and k.endswith("/mu"))
+    # L-SR1 inside the line-search IP is non-convergent on this problem:
+    # compare the first iterations only; convergent cases are compared over 25 iterations
+    # tightly and to the end loosely.
+    window = 8 if "sr1" in name else 25
+    ncmp = min(window, nref, len(snaps))
+    assert ncmp >= min(window, nref)
+    for k in range(ncmp):
+        p = "it%03d/" % k
+        s = snaps[k]
+        np.testing.assert_array_equal(s["counters"], g[p + "counters"], err_msg="counters @%d" % k)
+        assert s.get("qn_size", 0) == int(g[p + "qn_size"][0]), "qn size @%d" % k
+        rt = 1e-7
+        assert abs(s["mu"] - g[p + "mu"][0]) <= rt * abs(g[p + "mu"][0]), "mu @%d" % k
+        assert abs(s["fobj"] - g[p + "fobj"][0]) <= rt * max(1.0, abs(g[p + "fobj"][0])), "fobj @%d" % k
+        np.testing.assert_allclose(s["norms"], g[p + "norms"], rtol=rt, err_msg="norms @%d" % k)
+        for key in ("z", "s", "t", "zs", "zt"):
+            ref = g[p + key]
+            np.testing.assert_allclose(s[key], ref, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                       err_msg="%s @%d" % (key, k))
+        if p + "x" in g:
+            for key in ("x", "zl", "zu"):
+                ref = g[p + key]
+                np.testing.assert_allclose(s[key], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                           err_msg="%s @%d" % (key, k))
+    # integer trace: info tokens of the compared window
+    toks = info_tokens(g["paropt_out"])
+    for k in range(1, ncmp):
+        mine = ip.trace[k]["info"].split() if k < len(ip.trace) else None
+        assert mine == toks.get(k, []), "info tokens @%d: %s vs %s" % (k, mine, toks.get(k))
+    if "sr1" not in name:
+        # same number of major iterations and evaluations, same optimum
+        np.testing.assert_array_equal(
+            np.array([ip.niter, ip.neval, ip.ngeval]), g["final/counters"], err_msg="final counters")
+        assert abs(ip.fobj - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("ip_") if "kat/step_x" in np.load(
+    __import__("os").path.join(__import__("conftest").GOLDEN_DIR, n + ".npz")).files])
+def test_ip_single_step_kat(name):
+    """Single KKT step from the reference's private methods."""
+    g, case = load_golden(name)
+    kat_iter = case["args"]["kat_iter"]
+    a = case["args"]
+    prob = po.SepProblem(a["problem"], a["n"], a.get("c", 2), eig_min=a.get("eig_min", 1.0),
+                         eig_max=a.get("eig_max", 100.0))
+    opts = ip_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    ip = po.InteriorPoint(prob, opts)
+    out = {}
+
+    def hook(s, k):
+        if k != kat_iter:
+            return
+        s.compute_kkt_res(s.vars, s.barrier_param, s.res)
+        out["res_norms"] = np.array(s.compute_res_norm(s.res))
+        out["res_x"] = s.res.x.copy()
+        s.setup_kkt_diag_system(s.vars, 1)
+        out["Dinv"] = s.Dinv.copy()
+        s.setup_kkt_system(s.vars, 1)
+        s.compute_kkt_step(s.vars, s.res, s.step, 1)
+        for key in po.Vars.NAMES:
+            out["step_" + key] = getattr(s.step, key).copy()
+        out["comp"] = s.compute_comp(s.vars)
+        out["max_step"] = np.array(s.compute_max_step(s.vars, 0.95, s.step))
+        out["comp_step"] = s.compute_comp_step(s.vars, out["max_step"][0], out["max_step"][1], s.step)
+        # the state the KAT starts from must match the reference closely for the
+        # comparison to be meaningful
+        out["x"] = s.vars.x.copy()
+
+    ip.hook = hook
+    ip.optimize()
+    assert "step_x" in out
+    np.testing.assert_allclose(out["x"], g["kat/x"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out["res_norms"], g["kat/res_norms"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(out["Dinv"], g["kat/Dinv"], rtol=1e-6)
+    for key in po.Vars.NAMES:
+        ref = g["kat/step_" + key]
+        np.testing.assert_allclose(out["step_" + key], ref, rtol=0,
+                                   atol=2e-5 * max(1e-3, np.abs(ref).max()), err_msg=key)
+    assert abs(out["comp"] - g["kat/comp"][0]) <= 1e-6 * abs(g["kat/comp"][0])
+    np.testing.assert_allclose(out["max_step"], g["kat/max_step_tau095"], rtol=1e-5)
+    assert abs(out["comp_step"] - g["kat/comp_step"][0]) <= 1e-5 * abs(g["kat/comp_step"][0])
+
+
+def test_rank_count_independence_of_reference():
+    """The reference itself, on 1 and 2 MPI ranks, yields the same trajectory."""
+    g1, _ = load_golden("ip_convex_n2000_c32_bfgs")
+    g2, _ = load_golden("ip_convex_n2000_c32_bfgs_r2")
+    np.testing.assert_array_equal(g1["final/counters"], g2["final/counters"])
+    assert abs(g1["final/fobj"][0] - g2["final/fobj"][0]) <= 1e-9 * abs(g1["final/fobj"][0])
