@@ -1,0 +1,200 @@
+/*
+ * paropt_amd -- C ABI of the MI355X-native interior-point hot path.
+ *
+ * This header is the drop-in boundary.  The reference (smdogroup/paropt v2.1.5) exposes this
+ * path as a C++ virtual-class API (ParOptVec / ParOptCompactQuasiNewton / ParOptProblem /
+ * ParOptInteriorPoint); its own FFI (the Cython layer) reaches it through C function-pointer
+ * trampolines (src/CyParOptProblem.h:44-69).  Every entry point below names the reference
+ * interface it replaces (file:line relative to the reference tree).  Signatures use plain
+ * pointers, sizes and opaque handles only -- no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a non-zero PO_ERR_* code on failure; the text of
+ *     the last failure on the calling thread is available from po_last_error().  Nothing aborts.
+ *   - one po_ctx per process/GPU (one HIP stream, one communicator); all reducing calls are
+ *     collective over the ranks of the context, like the reference's MPI calls.
+ *   - vectors hold fp64 and live in HBM.  Ownership is the reference's intrusive refcount
+ *     (src/ParOptVec.h:28-47): create returns a vector with count 1 (the reference's
+ *     "create + incref" pair), po_vec_decref frees it at 0.
+ */
+#ifndef PAROPT_AMD_H
+#define PAROPT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct po_ctx_s *po_ctx;
+typedef struct po_vec_s *po_vec;
+typedef struct po_qn_s *po_qn;
+typedef struct po_problem_s *po_problem;
+typedef struct po_ip_s *po_ip;
+
+enum {
+  PO_OK = 0,
+  PO_ERR_HIP = 1,       /* a HIP runtime call failed */
+  PO_ERR_ARG = 2,       /* invalid argument / size mismatch */
+  PO_ERR_COMM = 3,      /* RCCL / communicator failure */
+  PO_ERR_NO_DEVICE = 4, /* no usable gfx950 device: the product has no CPU fallback */
+  PO_ERR_OPTION = 5,    /* unknown option or wrong type (src/ParOptOptions.cpp:310-386) */
+  PO_ERR_USER = 6       /* a problem callback returned non-zero */
+};
+
+const char *po_last_error(void);
+/* Library identification: "paropt_amd <version> gfx950". */
+const char *po_version(void);
+
+/* ---- context / communicator (replaces MPI_Comm of src/ParOptProblem.cpp:7-11) ------------- */
+int po_ctx_create(int device, po_ctx *out);
+int po_ctx_destroy(po_ctx ctx);
+int po_ctx_synchronize(po_ctx ctx);
+int po_ctx_rank(po_ctx ctx, int *rank, int *size);
+/* The HIP stream every kernel of this context is launched on (a hipStream_t). */
+void *po_ctx_stream(po_ctx ctx);
+/* RCCL over xGMI: rank 0 calls po_rccl_unique_id, ships the bytes to the other ranks by any
+ * side channel (the Python harness uses the torch.distributed store), then every rank calls
+ * po_ctx_comm_init_rccl.  Replaces the MPI_Allreduce/Reduce/Bcast sites of SURVEY.md 2.3. */
+#define PO_RCCL_ID_BYTES 128
+int po_rccl_unique_id(void *id128);
+int po_ctx_comm_init_rccl(po_ctx ctx, int rank, int size, const void *id128);
+/* Host-side communicator hook: `allgather` must gather `count` doubles from every rank into
+ * `out` (rank-major).  Lets a maintainer keep MPI (or gloo) underneath. */
+typedef int (*po_allgather_fn)(const double *in, double *out, int count, void *user);
+int po_ctx_comm_init_callback(po_ctx ctx, int rank, int size, po_allgather_fn fn, void *user);
+
+/* ---- ParOptVec: src/ParOptVec.h:53-70, src/ParOptVec.cpp ---------------------------------- */
+int po_vec_create(po_ctx ctx, int64_t nlocal, po_vec *out); /* ParOptBasicVec ctor :15-20 (zero-filled) */
+int po_vec_incref(po_vec v);                                /* ParOptBase::incref  src/ParOptVec.h:34 */
+int po_vec_decref(po_vec v);                                /* ParOptBase::decref  src/ParOptVec.h:38-43 */
+int po_vec_size(po_vec v, int64_t *nlocal);
+int po_vec_set(po_vec v, double alpha);                     /* set          :32-36 */
+int po_vec_zero(po_vec v);                                  /* zeroEntries  :41-43 */
+int po_vec_copy(po_vec dst, po_vec src);                    /* copyValues   :50-56 */
+int po_vec_scale(po_vec v, double alpha);                   /* scale        :177-186 */
+int po_vec_axpy(po_vec y, double alpha, po_vec x);          /* axpy         :191-204 */
+int po_vec_dot(po_vec x, po_vec y, double *out);            /* dot          :124-143 */
+int po_vec_mdot(po_vec x, const po_vec *vecs, int nvecs, double *out); /* mdot :152-170 (host out) */
+int po_vec_norm(po_vec x, double *out);                     /* norm         :63-80 */
+int po_vec_maxabs(po_vec x, double *out);                   /* maxabs       :87-99 */
+int po_vec_l1norm(po_vec x, double *out);                   /* l1norm       :106-116 */
+/* getArray :212-217 -- a pinned HOST mirror; the first call downloads the device data.  Writes
+ * made through the pointer reach the device at po_vec_sync_to_device.  The solver itself never
+ * uses host mirrors. */
+int po_vec_get_array(po_vec v, double **host);
+int po_vec_sync_to_device(po_vec v);
+int po_vec_sync_to_host(po_vec v);
+/* Device-resident problems use the raw HBM pointer instead. */
+int po_vec_get_device_array(po_vec v, double **device);
+/* y <- beta*y + sum_j alpha[j]*vecs[j]: the fused form of the reference's axpy loops
+ * (src/ParOptQuasiNewton.cpp:414-416, src/ParOptInteriorPoint.cpp:1354-1356). */
+int po_vec_maxpy(po_vec y, double beta, const double *alpha, const po_vec *vecs, int nvecs);
+/* Deterministic counter-hash fill: v[i] = shift + scale*u01(seed, array_id, offset+i). */
+int po_vec_fill_hash(po_vec v, uint64_t seed, uint64_t array_id, int64_t offset, double scale,
+                     double shift);
+
+/* ---- ParOptCompactQuasiNewton: src/ParOptQuasiNewton.h:32-220 ----------------------------- */
+enum { PO_QN_BFGS = 0, PO_QN_SR1 = 1 };
+enum { PO_BFGS_SKIP_NEGATIVE_CURVATURE = 0, PO_BFGS_DAMPED_UPDATE = 1 }; /* :10-13 */
+enum { PO_QN_YTY_OVER_YTS = 0, PO_QN_YTS_OVER_STS = 1 };                 /* :18-23 */
+int po_qn_create(po_ctx ctx, int type, int64_t nlocal, int subspace, po_qn *out); /* ctors .cpp:18-74, 496-556 */
+int po_qn_destroy(po_qn qn);
+int po_qn_set_update_type(po_qn qn, int bfgs_update_type);  /* setBFGSUpdateType .cpp:107-109 */
+int po_qn_set_diag_type(po_qn qn, int diag_type);           /* setInitDiagonalType .cpp:116-119 */
+int po_qn_reset(po_qn qn);                                  /* reset .cpp:127-142, 603-618 */
+/* update(x,z,zw,s,y) .cpp:162-334, 636-747: returns the update type through *rc
+ * (0 normal, 1 damped, 2 skipped).  s and y are not modified. */
+int po_qn_update(po_qn qn, po_vec s, po_vec y, int *rc);
+int po_qn_mult(po_qn qn, po_vec x, po_vec y);               /* mult .cpp:390-418, 760-778 */
+int po_qn_mult_add(po_qn qn, double alpha, po_vec x, po_vec y); /* multAdd .cpp:432-459, 791-809 */
+/* getCompactMat .cpp:471-487, 821-837: *size = k; b0; d0[k]; M[k*k] column-major; Z[k] borrowed
+ * handles valid until the next update/reset.  Any output pointer may be NULL. */
+int po_qn_get_compact(po_qn qn, int *size, double *b0, const double **d0, const double **M,
+                      const po_vec **Z);
+int po_qn_max_size(po_qn qn, int *size);                    /* getMaxLimitedMemorySize */
+
+/* ---- ParOptProblem: src/ParOptProblem.h:42-296 -------------------------------------------- */
+/* User problems are bound the way the reference's own FFI binds them: a table of C callbacks
+ * (src/CyParOptProblem.h:44-69).  Callbacks receive device vectors; use
+ * po_vec_get_device_array (device kernels) or po_vec_get_array + po_vec_sync_to_device (host). */
+typedef struct {
+  void *user;
+  /* getVarsAndBounds :133 */
+  int (*get_vars_and_bounds)(void *user, po_vec x, po_vec lb, po_vec ub);
+  /* evalObjCon :146-158 -- fobj and cons[ncon] must be identical on all ranks */
+  int (*eval_obj_con)(void *user, po_vec x, double *fobj, double *cons);
+  /* evalObjConGradient :171-172 */
+  int (*eval_obj_con_gradient)(void *user, po_vec x, po_vec g, const po_vec *Ac);
+  /* computeQuasiNewtonUpdateCorrection :211-213 (may be NULL) */
+  int (*qn_update_correction)(void *user, po_vec x, const double *z, po_vec s, po_vec y);
+  /* writeOutput :289 (may be NULL) */
+  int (*write_output)(void *user, int iter, po_vec x);
+} po_problem_callbacks;
+int po_problem_create_callbacks(po_ctx ctx, int64_t nlocal, int ncon, int ninequality,
+                                const po_problem_callbacks *cb, po_problem *out);
+/* Built-in device-resident workloads of BASELINE.json (DESIGN.md "Workloads"): */
+enum { PO_PROBLEM_QUADRATIC = 0, PO_PROBLEM_CONVEX = 1, PO_PROBLEM_ROSENBROCK = 2 };
+int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon, uint64_t seed,
+                                double eig_min, double eig_max, po_problem *out);
+int po_problem_destroy(po_problem p);
+int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon);
+int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons);
+int po_problem_eval_obj_con_gradient(po_problem p, po_vec x, po_vec g, const po_vec *Ac);
+int po_problem_get_vars_and_bounds(po_problem p, po_vec x, po_vec lb, po_vec ub);
+
+/* ---- ParOptInteriorPoint: src/ParOptInteriorPoint.h:128-217 ------------------------------- */
+int po_ip_create(po_problem prob, po_ip *out);              /* ctor .cpp:182-450 (default options) */
+int po_ip_destroy(po_ip ip);
+/* ParOptOptions::setOption overloads, src/ParOptOptions.h:35-37; names/defaults of
+ * ParOptInteriorPoint::addDefaultOptions .cpp:536-727.  Must be called before po_ip_optimize;
+ * qn_type / qn_subspace_size must be set before the first optimize. */
+int po_ip_set_option_str(po_ip ip, const char *name, const char *value);
+int po_ip_set_option_int(po_ip ip, const char *name, int value);
+int po_ip_set_option_float(po_ip ip, const char *name, double value);
+int po_ip_optimize(po_ip ip, const char *checkpoint);       /* optimize .cpp:4399-5333 */
+/* getOptimizedPoint .cpp:793-826: borrowed handles (NULL allowed) */
+int po_ip_get_optimized_point(po_ip ip, po_vec *x, const double **z, po_vec *zl, po_vec *zu);
+/* getOptimizedSlacks .cpp:848-866 (+ the slack multipliers) */
+int po_ip_get_optimized_slacks(po_ip ip, const double **s, const double **t, const double **zs,
+                               const double **zt);
+int po_ip_get_counters(po_ip ip, int *niter, int *neval, int *ngeval); /* getIterationCounters .h:203-217 */
+int po_ip_get_barrier_parameter(po_ip ip, double *mu);      /* .cpp:1110 */
+int po_ip_get_complementarity(po_ip ip, double *comp);      /* .cpp:1118-1120 */
+int po_ip_get_objective(po_ip ip, double *fobj, double *rho);
+int po_ip_set_penalty_gamma(po_ip ip, double gamma);        /* .cpp:1127-1151 */
+int po_ip_reset_design_and_bounds(po_ip ip);                /* .cpp:1249-1251 */
+int po_ip_reset_quasi_newton(po_ip ip);                     /* resetQuasiNewtonHessian .cpp:1241-1245 */
+int po_ip_get_quasi_newton(po_ip ip, po_qn *qn);            /* borrowed */
+int po_ip_write_solution_file(po_ip ip, const char *filename); /* .cpp:883-972 (rank-local shard) */
+/* Per-iteration observer, called at the point the reference calls prob->writeOutput
+ * (.cpp:4620-4630); used by the parity tests to snapshot the state. */
+typedef int (*po_ip_iteration_fn)(void *user, int iter);
+int po_ip_set_iteration_callback(po_ip ip, po_ip_iteration_fn fn, void *user);
+/* The iteration table of the last optimize() in the reference's paropt.out column layout
+ * (.cpp:4777-4801); *text is owned by the solver. */
+int po_ip_get_history(po_ip ip, const char **text);
+/* Time (seconds, HIP events on the context stream) spent per phase during the last optimize;
+ * names is a ';'-separated list matching seconds[]. */
+int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, int *count);
+/* Single-step entry points used by the known-answer tests (reference private methods
+ * computeKKTRes/setUpKKTDiagSystem/setUpKKTSystem/computeKKTStep, .cpp:1337, 1832, 2634, 2700):
+ * computes the KKT step at the current state with barrier mu into internal step storage and
+ * returns borrowed handles / pointers to it. */
+int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,
+                         const double **pz, const double **ps, const double **pt,
+                         const double **pzs, const double **pzt);
+
+/* ---- standalone hot kernels for the roofline bench ----------------------------------------- */
+/* W = P^T diag(d) P, P = [vecs], column-major nvecs x nvecs on the host (MFMA fp64). */
+int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W);
+/* Launch mdot `reps` times back to back on the context stream and return the average kernel
+ * time in milliseconds measured with HIP events on that stream (bench.py's roofline leg). */
+int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out);
+int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAROPT_AMD_H */

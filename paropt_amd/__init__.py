@@ -1,0 +1,17 @@
+"""paropt_amd -- MI355X-native interior-point hot path behind ParOpt's API.
+
+Importing the package loads libparopt_amd.so; it raises if the library has not been built.
+"""
+from .api import (  # noqa: F401
+    LBFGS,
+    LSR1,
+    Context,
+    InteriorPoint,
+    Problem,
+    PVec,
+    SeparableProblem,
+    bench_mdot,
+    bench_wgram,
+    wgram,
+)
+from .lib import LIB_PATH, ParOptAMDError  # noqa: F401

@@ -1,0 +1,489 @@
+"""
+Python host harness over the C ABI (paropt_amd/lib.py).  Class and method names follow the
+reference's Python layer (paropt/ParOpt.pyx:761-1521: PVec, LBFGS, LSR1, Problem,
+InteriorPoint) so tests read like the reference's own; all arithmetic happens in
+libparopt_amd.so on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as L
+from .lib import check, lib
+
+
+class Context:
+    """One per process / GPU: HIP stream + communicator (replaces the MPI communicator)."""
+
+    def __init__(self, device=0):
+        self._h = L.po_ctx()
+        check(lib.po_ctx_create(int(device), C.byref(self._h)))
+        self._keep = []
+
+    @property
+    def handle(self):
+        return self._h
+
+    def rank_size(self):
+        r, s = C.c_int(), C.c_int()
+        check(lib.po_ctx_rank(self._h, C.byref(r), C.byref(s)))
+        return r.value, s.value
+
+    def synchronize(self):
+        check(lib.po_ctx_synchronize(self._h))
+
+    def init_rccl_from_torch(self):
+        """One process per GPU: ship the RCCL unique id over torch.distributed, then init."""
+        import torch.distributed as dist
+
+        rank, size = dist.get_rank(), dist.get_world_size()
+        if size == 1:
+            return
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            check(lib.po_rccl_unique_id(buf))
+        obj = [bytes(buf) if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0)
+        idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
+        check(lib.po_ctx_comm_init_rccl(self._h, rank, size, idbuf))
+
+    def init_callback_from_torch(self):
+        """Host-side allgather through torch.distributed (gloo or nccl): the maintainer's-MPI hook."""
+        import torch
+        import torch.distributed as dist
+
+        rank, size = dist.get_rank(), dist.get_world_size()
+
+        def _gather(inp, out, count, user):
+            try:
+                loc = torch.from_numpy(np.ctypeslib.as_array(inp, shape=(count,)).copy())
+                parts = [torch.empty_like(loc) for _ in range(size)]
+                dist.all_gather(parts, loc)
+                dst = np.ctypeslib.as_array(out, shape=(count * size,))
+                for r in range(size):
+                    dst[r * count : (r + 1) * count] = parts[r].numpy()
+                return 0
+            except Exception:  # pragma: no cover
+                return 1
+
+        cb = L.ALLGATHER_FN(_gather)
+        self._keep.append(cb)
+        check(lib.po_ctx_comm_init_callback(self._h, rank, size, cb, None))
+
+    def close(self):
+        if self._h:
+            lib.po_ctx_destroy(self._h)
+            self._h = None
+
+
+class PVec:
+    """ParOptVec in HBM (reference: paropt/ParOpt.pyx PVec, src/ParOptVec.h:53-70)."""
+
+    def __init__(self, ctx, n=None, handle=None, owned=True):
+        self.ctx = ctx
+        if handle is None:
+            h = L.po_vec()
+            check(lib.po_vec_create(ctx.handle, int(n), C.byref(h)))
+            self._h = h
+            self._owned = True
+        else:
+            self._h = handle if isinstance(handle, C.c_void_p) else L.po_vec(handle)
+            self._owned = owned
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        n = C.c_int64()
+        check(lib.po_vec_size(self._h, C.byref(n)))
+        return n.value
+
+    def __del__(self):
+        try:
+            if self._owned and self._h:
+                lib.po_vec_decref(self._h)
+        except Exception:
+            pass
+
+    # -- the 11 virtuals of ParOptVec --------------------------------------------------------
+    def set(self, alpha):
+        check(lib.po_vec_set(self._h, float(alpha)))
+
+    def zeroEntries(self):
+        check(lib.po_vec_zero(self._h))
+
+    def copyValues(self, other):
+        check(lib.po_vec_copy(self._h, other.handle))
+
+    def norm(self):
+        out = C.c_double()
+        check(lib.po_vec_norm(self._h, C.byref(out)))
+        return out.value
+
+    def maxabs(self):
+        out = C.c_double()
+        check(lib.po_vec_maxabs(self._h, C.byref(out)))
+        return out.value
+
+    def l1norm(self):
+        out = C.c_double()
+        check(lib.po_vec_l1norm(self._h, C.byref(out)))
+        return out.value
+
+    def dot(self, other):
+        out = C.c_double()
+        check(lib.po_vec_dot(self._h, other.handle, C.byref(out)))
+        return out.value
+
+    def mdot(self, vecs):
+        nv = len(vecs)
+        out = np.zeros(max(nv, 1))
+        arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+        check(lib.po_vec_mdot(self._h, arr, nv, out.ctypes.data_as(L.c_double_p)))
+        return out[:nv]
+
+    def scale(self, alpha):
+        check(lib.po_vec_scale(self._h, float(alpha)))
+
+    def axpy(self, alpha, other):
+        check(lib.po_vec_axpy(self._h, float(alpha), other.handle))
+
+    def maxpy(self, beta, alphas, vecs):
+        nv = len(vecs)
+        a = np.ascontiguousarray(alphas, dtype=np.float64)
+        arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+        check(lib.po_vec_maxpy(self._h, float(beta), a.ctypes.data_as(L.c_double_p), arr, nv))
+
+    def getArray(self):
+        """Host mirror as a numpy view (call syncToDevice after writing)."""
+        p = L.c_double_p()
+        check(lib.po_vec_get_array(self._h, C.byref(p)))
+        n = len(self)
+        if n == 0:
+            return np.zeros(0)
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def syncToDevice(self):
+        check(lib.po_vec_sync_to_device(self._h))
+
+    def syncToHost(self):
+        check(lib.po_vec_sync_to_host(self._h))
+
+    # -- conveniences --------------------------------------------------------------------------
+    def to_numpy(self):
+        a = self.getArray()
+        self.syncToHost()
+        return np.array(a, copy=True)
+
+    def from_numpy(self, arr):
+        a = self.getArray()
+        a[:] = arr
+        self.syncToDevice()
+        return self
+
+    def fill_hash(self, seed, aid, offset=0, scale=1.0, shift=0.0):
+        check(lib.po_vec_fill_hash(self._h, int(seed), int(aid), int(offset), float(scale), float(shift)))
+        return self
+
+    def device_ptr(self):
+        p = L.c_double_p()
+        check(lib.po_vec_get_device_array(self._h, C.byref(p)))
+        return C.cast(p, C.c_void_p).value
+
+
+class _QuasiNewton:
+    def __init__(self, ctx, kind, n, subspace, handle=None):
+        self.ctx = ctx
+        if handle is None:
+            self._h = L.po_qn()
+            check(lib.po_qn_create(ctx.handle, kind, int(n), int(subspace), C.byref(self._h)))
+            self._owned = True
+        else:
+            self._h = handle
+            self._owned = False
+
+    def __del__(self):
+        try:
+            if self._owned and self._h:
+                lib.po_qn_destroy(self._h)
+        except Exception:
+            pass
+
+    def reset(self):
+        check(lib.po_qn_reset(self._h))
+
+    def update(self, s, y):
+        rc = C.c_int()
+        check(lib.po_qn_update(self._h, s.handle, y.handle, C.byref(rc)))
+        return rc.value
+
+    def mult(self, x, y):
+        check(lib.po_qn_mult(self._h, x.handle, y.handle))
+
+    def multAdd(self, alpha, x, y):
+        check(lib.po_qn_mult_add(self._h, float(alpha), x.handle, y.handle))
+
+    def setInitDiagonalType(self, t):
+        check(lib.po_qn_set_diag_type(self._h, 1 if t in (1, "yts_over_sts") else 0))
+
+    def getCompactMat(self):
+        k, b0 = C.c_int(), C.c_double()
+        d0, M, Z = L.c_double_p(), L.c_double_p(), L.vec_p()
+        check(lib.po_qn_get_compact(self._h, C.byref(k), C.byref(b0), C.byref(d0), C.byref(M), C.byref(Z)))
+        n = k.value
+        d = np.array([d0[i] for i in range(n)])
+        Mm = np.array([M[i] for i in range(n * n)]).reshape(n, n).T if n else np.zeros((0, 0))
+        Zs = [PVec(self.ctx, handle=L.po_vec(Z[i]), owned=False) for i in range(n)]
+        return b0.value, d, Mm, Zs
+
+
+class LBFGS(_QuasiNewton):
+    def __init__(self, ctx, n, subspace=10, update_type="skip_negative_curvature"):
+        super().__init__(ctx, 0, n, subspace)
+        check(lib.po_qn_set_update_type(self._h, 1 if update_type in (1, "damped_update", "damped") else 0))
+
+
+class LSR1(_QuasiNewton):
+    def __init__(self, ctx, n, subspace=10):
+        super().__init__(ctx, 1, n, subspace)
+
+
+class Problem:
+    """Base class for user problems implemented in Python (host arrays through getArray).
+
+    Mirrors paropt.ParOpt.Problem: override getVarsAndBounds(x, lb, ub), evalObjCon(x) ->
+    (fail, fobj, con) and evalObjConGradient(x, g, A) -> fail, all on numpy views.
+    """
+
+    def __init__(self, ctx, nvars, ncon, ninequality=-1):
+        self.ctx = ctx
+        self.nvars, self.ncon = int(nvars), int(ncon)
+        cb = L.ProblemCallbacks()
+
+        def _gvb(user, x, lb, ub):
+            vx, vl, vu = (PVec(ctx, handle=L.po_vec(h), owned=False) for h in (x, lb, ub))
+            ax, al, au = vx.getArray(), vl.getArray(), vu.getArray()
+            self.getVarsAndBounds(ax, al, au)
+            vx.syncToDevice(), vl.syncToDevice(), vu.syncToDevice()
+            return 0
+
+        def _eval(user, x, fobj, cons):
+            vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+            fail, f, con = self.evalObjCon(vx.to_numpy())
+            fobj[0] = float(f)
+            for j in range(self.ncon):
+                cons[j] = float(con[j])
+            return int(fail)
+
+        def _grad(user, x, g, Ac):
+            vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+            vg = PVec(ctx, handle=L.po_vec(g), owned=False)
+            va = [PVec(ctx, handle=L.po_vec(Ac[j]), owned=False) for j in range(self.ncon)]
+            ag = vg.getArray()
+            aa = [v.getArray() for v in va]
+            fail = self.evalObjConGradient(vx.to_numpy(), ag, aa)
+            vg.syncToDevice()
+            for v in va:
+                v.syncToDevice()
+            return int(fail or 0)
+
+        self._cbs = (L.GET_VARS_FN(_gvb), L.EVAL_FN(_eval), L.GRAD_FN(_grad))
+        cb.user = None
+        cb.get_vars_and_bounds, cb.eval_obj_con, cb.eval_obj_con_gradient = self._cbs
+        cb.qn_update_correction = L.QNCORR_FN()
+        cb.write_output = L.WRITE_FN()
+        self._cb_struct = cb
+        self._h = L.po_problem()
+        check(lib.po_problem_create_callbacks(ctx.handle, self.nvars, self.ncon, int(ninequality),
+                                              C.byref(cb), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class SeparableProblem:
+    """Built-in device-resident workloads: 'quadratic', 'convex', 'rosenbrock'."""
+
+    KINDS = {"quadratic": 0, "convex": 1, "rosenbrock": 2}
+
+    def __init__(self, ctx, kind, n, c=2, seed=0, eig_min=1.0, eig_max=100.0):
+        self.ctx = ctx
+        self._h = L.po_problem()
+        check(lib.po_problem_create_separable(ctx.handle, self.KINDS[kind], int(n), int(c), int(seed),
+                                              float(eig_min), float(eig_max), C.byref(self._h)))
+        nl, off, nc = C.c_int64(), C.c_int64(), C.c_int()
+        check(lib.po_problem_sizes(self._h, C.byref(nl), C.byref(off), C.byref(nc)))
+        self.nvars, self.offset, self.ncon = nl.value, off.value, nc.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def evalObjCon(self, x):
+        f = C.c_double()
+        con = np.zeros(max(self.ncon, 1))
+        check(lib.po_problem_eval_obj_con(self._h, x.handle, C.byref(f), con.ctypes.data_as(L.c_double_p)))
+        return 0, f.value, con[: self.ncon]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.po_problem_destroy(self._h)
+        except Exception:
+            pass
+
+
+class InteriorPoint:
+    """ParOptInteriorPoint (reference src/ParOptInteriorPoint.h:128-217)."""
+
+    def __init__(self, problem, options=None):
+        self.problem = problem
+        self.ctx = problem.ctx
+        self._h = L.po_ip()
+        check(lib.po_ip_create(problem.handle, C.byref(self._h)))
+        self._iter_cb = None
+        for k, v in (options or {}).items():
+            self.setOption(k, v)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.po_ip_destroy(self._h)
+        except Exception:
+            pass
+
+    def setOption(self, name, value):
+        nm = name.encode()
+        if isinstance(value, bool):
+            check(lib.po_ip_set_option_int(self._h, nm, int(value)))
+        elif isinstance(value, int):
+            # int given for a float option is a type error in the reference too; be lenient only
+            # in the obvious direction (python ints for float-valued settings)
+            rc = lib.po_ip_set_option_int(self._h, nm, value)
+            if rc != 0:
+                check(lib.po_ip_set_option_float(self._h, nm, float(value)))
+        elif isinstance(value, float):
+            check(lib.po_ip_set_option_float(self._h, nm, value))
+        else:
+            check(lib.po_ip_set_option_str(self._h, nm, str(value).encode()))
+
+    def setIterationCallback(self, fn):
+        def _cb(user, k):
+            fn(k)
+            return 0
+
+        self._iter_cb = L.ITER_FN(_cb)
+        check(lib.po_ip_set_iteration_callback(self._h, self._iter_cb, None))
+
+    def optimize(self, checkpoint=None):
+        rc = lib.po_ip_optimize(self._h, checkpoint.encode() if checkpoint else None)
+        if rc not in (0,):
+            raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
+        return rc
+
+    def getOptimizedPoint(self):
+        x, zl, zu = L.po_vec(), L.po_vec(), L.po_vec()
+        z = L.c_double_p()
+        check(lib.po_ip_get_optimized_point(self._h, C.byref(x), C.byref(z), C.byref(zl), C.byref(zu)))
+        c = self.problem.ncon
+        return (PVec(self.ctx, handle=x, owned=False), np.array([z[i] for i in range(c)]),
+                PVec(self.ctx, handle=zl, owned=False), PVec(self.ctx, handle=zu, owned=False))
+
+    def getOptimizedSlacks(self):
+        ptrs = [L.c_double_p() for _ in range(4)]
+        check(lib.po_ip_get_optimized_slacks(self._h, *[C.byref(p) for p in ptrs]))
+        c = self.problem.ncon
+        return tuple(np.array([p[i] for i in range(c)]) for p in ptrs)
+
+    def getIterationCounters(self):
+        a, b, d = C.c_int(), C.c_int(), C.c_int()
+        check(lib.po_ip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(d)))
+        return a.value, b.value, d.value
+
+    def getBarrierParameter(self):
+        v = C.c_double()
+        check(lib.po_ip_get_barrier_parameter(self._h, C.byref(v)))
+        return v.value
+
+    def getComplementarity(self):
+        v = C.c_double()
+        check(lib.po_ip_get_complementarity(self._h, C.byref(v)))
+        return v.value
+
+    def getObjective(self):
+        f, rho = C.c_double(), C.c_double()
+        check(lib.po_ip_get_objective(self._h, C.byref(f), C.byref(rho)))
+        return f.value, rho.value
+
+    def getQuasiNewton(self):
+        h = L.po_qn()
+        check(lib.po_ip_get_quasi_newton(self._h, C.byref(h)))
+        return _QuasiNewton(self.ctx, 0, 0, 0, handle=h) if h else None
+
+    def getHistory(self):
+        t = C.c_char_p()
+        check(lib.po_ip_get_history(self._h, C.byref(t)))
+        return t.value.decode()
+
+    def getPhaseTimes(self):
+        names, secs, cnt = C.c_char_p(), L.c_double_p(), C.c_int()
+        check(lib.po_ip_get_phase_times(self._h, C.byref(names), C.byref(secs), C.byref(cnt)))
+        nm = names.value.decode().split(";") if cnt.value else []
+        return {nm[i]: secs[i] for i in range(cnt.value)}
+
+    def debugKKTStep(self, mu):
+        px, pzl, pzu = L.po_vec(), L.po_vec(), L.po_vec()
+        d = [L.c_double_p() for _ in range(5)]
+        check(lib.po_ip_debug_kkt_step(self._h, float(mu), C.byref(px), C.byref(pzl), C.byref(pzu),
+                                       *[C.byref(p) for p in d]))
+        c = self.problem.ncon
+        out = dict(x=PVec(self.ctx, handle=px, owned=False).to_numpy(),
+                   zl=PVec(self.ctx, handle=pzl, owned=False).to_numpy(),
+                   zu=PVec(self.ctx, handle=pzu, owned=False).to_numpy())
+        for name, p in zip(("z", "s", "t", "zs", "zt"), d):
+            out[name] = np.array([p[i] for i in range(c)])
+        return out
+
+    def snapshot(self):
+        """State in the layout of oracle snapshots / golden 'itNNN/' records."""
+        x, z, zl, zu = self.getOptimizedPoint()
+        s, t, zs, zt = self.getOptimizedSlacks()
+        niter, neval, ngeval = self.getIterationCounters()
+        f, rho = self.getObjective()
+        d = dict(mu=self.getBarrierParameter(), rho=rho, fobj=f, z=z, s=s, t=t, zs=zs, zt=zt,
+                 counters=np.array([niter, neval, ngeval]),
+                 norms=np.array([x.norm(), zl.norm(), zu.norm()]))
+        qn = self.getQuasiNewton()
+        if qn is not None:
+            k, b0 = C.c_int(), C.c_double()
+            check(lib.po_qn_get_compact(qn._h, C.byref(k), C.byref(b0), None, None, None))
+            d["qn_size"] = k.value
+            d["qn_b0"] = b0.value
+        return d
+
+
+def wgram(d, vecs):
+    nv = len(vecs)
+    W = np.zeros((nv, nv))
+    arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+    check(lib.po_wgram(d.handle, arr, nv, W.ctypes.data_as(L.c_double_p)))
+    return W.T  # column-major symmetric
+
+
+def bench_mdot(x, vecs, reps=10):
+    nv = len(vecs)
+    arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+    ms = C.c_double()
+    out = np.zeros(max(nv, 1))
+    check(lib.po_bench_mdot(x.handle, arr, nv, int(reps), C.byref(ms), out.ctypes.data_as(L.c_double_p)))
+    return ms.value, out[:nv]
+
+
+def bench_wgram(d, vecs, reps=10):
+    nv = len(vecs)
+    arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+    ms = C.c_double()
+    check(lib.po_bench_wgram(d.handle, arr, nv, int(reps), C.byref(ms)))
+    return ms.value

@@ -1,0 +1,558 @@
+// extern "C" surface of libparopt_amd.so (include/paropt_amd.h).
+#include <string.h>
+
+#include "ip.hpp"
+#include "problem.hpp"
+#include "qn.hpp"
+
+namespace po {
+const char *last_error();
+int ctx_create(int device, Ctx **out);
+int ctx_destroy(Ctx *c);
+int rccl_unique_id(void *id128);
+int comm_init_rccl(Ctx *c, int rank, int size, const void *id128);
+int comm_init_callback(Ctx *c, int rank, int size, po_allgather_fn fn, void *user);
+}  // namespace po
+
+using namespace po;
+
+#define PO_CHECK_PTR(p)                         \
+  do {                                          \
+    if (!(p)) {                                 \
+      po::set_error("null argument: %s", #p);   \
+      return PO_ERR_ARG;                        \
+    }                                           \
+  } while (0)
+
+static int same_layout(po_vec a, po_vec b) {
+  if (a->ctx != b->ctx || a->n != b->n) {
+    po::set_error("vector mismatch (different context or local size %lld vs %lld)", (long long)a->n,
+                  (long long)b->n);
+    return PO_ERR_ARG;
+  }
+  return PO_OK;
+}
+
+extern "C" {
+
+const char *po_last_error(void) { return po::last_error(); }
+const char *po_version(void) { return "paropt_amd 0.1 gfx950"; }
+
+int po_ctx_create(int device, po_ctx *out) {
+  PO_CHECK_PTR(out);
+  Ctx *c = nullptr;
+  int rc = ctx_create(device, &c);
+  *out = static_cast<po_ctx>(c);
+  return rc;
+}
+int po_ctx_destroy(po_ctx ctx) { return ctx_destroy(ctx); }
+int po_ctx_synchronize(po_ctx ctx) {
+  PO_CHECK_PTR(ctx);
+  PO_HIP(hipStreamSynchronize(ctx->stream));
+  return PO_OK;
+}
+int po_ctx_rank(po_ctx ctx, int *rank, int *size) {
+  PO_CHECK_PTR(ctx);
+  if (rank) *rank = ctx->rank;
+  if (size) *size = ctx->size;
+  return PO_OK;
+}
+void *po_ctx_stream(po_ctx ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int po_rccl_unique_id(void *id128) {
+  PO_CHECK_PTR(id128);
+  return rccl_unique_id(id128);
+}
+int po_ctx_comm_init_rccl(po_ctx ctx, int rank, int size, const void *id128) {
+  PO_CHECK_PTR(ctx);
+  return comm_init_rccl(ctx, rank, size, id128);
+}
+int po_ctx_comm_init_callback(po_ctx ctx, int rank, int size, po_allgather_fn fn, void *user) {
+  PO_CHECK_PTR(ctx);
+  return comm_init_callback(ctx, rank, size, fn, user);
+}
+
+// ---- vectors ------------------------------------------------------------------------------------
+int po_vec_create(po_ctx ctx, int64_t nlocal, po_vec *out) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(out);
+  if (nlocal < 0) {
+    po::set_error("negative vector length");
+    return PO_ERR_ARG;
+  }
+  Vec *v = vec_new(ctx, nlocal);
+  *out = static_cast<po_vec>(v);
+  return v ? PO_OK : PO_ERR_HIP;
+}
+int po_vec_incref(po_vec v) {
+  PO_CHECK_PTR(v);
+  v->ref++;
+  return PO_OK;
+}
+int po_vec_decref(po_vec v) {
+  PO_CHECK_PTR(v);
+  vec_decref(v);
+  return PO_OK;
+}
+int po_vec_size(po_vec v, int64_t *nlocal) {
+  PO_CHECK_PTR(v);
+  *nlocal = v->n;
+  return PO_OK;
+}
+int po_vec_set(po_vec v, double alpha) {
+  PO_CHECK_PTR(v);
+  return k_fill(v->ctx, v->d, v->n, alpha);
+}
+int po_vec_zero(po_vec v) {
+  PO_CHECK_PTR(v);
+  return k_fill(v->ctx, v->d, v->n, 0.0);
+}
+int po_vec_copy(po_vec dst, po_vec src) {
+  PO_CHECK_PTR(dst);
+  PO_CHECK_PTR(src);
+  PO_TRY(same_layout(dst, src));
+  return k_copy(dst->ctx, dst->d, src->d, dst->n);
+}
+int po_vec_scale(po_vec v, double alpha) {
+  PO_CHECK_PTR(v);
+  return k_scale(v->ctx, v->d, v->n, alpha);
+}
+int po_vec_axpy(po_vec y, double alpha, po_vec x) {
+  PO_CHECK_PTR(y);
+  PO_CHECK_PTR(x);
+  PO_TRY(same_layout(y, x));
+  return k_axpy(y->ctx, y->d, alpha, x->d, y->n);
+}
+int po_vec_dot(po_vec x, po_vec y, double *out) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(y);
+  PO_CHECK_PTR(out);
+  PO_TRY(same_layout(x, y));
+  return k_reduce1(x->ctx, RED_DOT, x->d, y->d, x->n, out);
+}
+int po_vec_mdot(po_vec x, const po_vec *vecs, int nvecs, double *out) {
+  PO_CHECK_PTR(x);
+  if (nvecs <= 0) return PO_OK;
+  PO_CHECK_PTR(vecs);
+  PO_CHECK_PTR(out);
+  std::vector<const double *> p(nvecs);
+  for (int j = 0; j < nvecs; j++) {
+    PO_CHECK_PTR(vecs[j]);
+    PO_TRY(same_layout(x, vecs[j]));
+    p[j] = vecs[j]->d;
+  }
+  // wider panels than one kernel accepts are processed in slabs
+  int j0 = 0;
+  while (j0 < nvecs) {
+    const int w = (nvecs - j0 > kMaxPanel) ? kMaxPanel : nvecs - j0;
+    PO_TRY(k_mdot(x->ctx, x->d, p.data() + j0, w, x->n, out + j0));
+    j0 += w;
+  }
+  return PO_OK;
+}
+int po_vec_norm(po_vec x, double *out) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(out);
+  double ss = 0.0;
+  PO_TRY(k_reduce1(x->ctx, RED_SUMSQ, x->d, nullptr, x->n, &ss));
+  *out = sqrt(ss);
+  return PO_OK;
+}
+int po_vec_maxabs(po_vec x, double *out) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(out);
+  return k_reduce1(x->ctx, RED_AMAX, x->d, nullptr, x->n, out);
+}
+int po_vec_l1norm(po_vec x, double *out) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(out);
+  return k_reduce1(x->ctx, RED_ASUM, x->d, nullptr, x->n, out);
+}
+int po_vec_get_array(po_vec v, double **host) {
+  PO_CHECK_PTR(v);
+  PO_CHECK_PTR(host);
+  if (!v->h) {
+    PO_HIP(hipHostMalloc((void **)&v->h, sizeof(double) * (size_t)(v->n > 0 ? v->n : 1), hipHostMallocDefault));
+    PO_TRY(po_vec_sync_to_host(v));
+  }
+  *host = v->h;
+  return PO_OK;
+}
+int po_vec_sync_to_device(po_vec v) {
+  PO_CHECK_PTR(v);
+  if (!v->h) return PO_OK;
+  PO_HIP(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->n, hipMemcpyHostToDevice, v->ctx->stream));
+  PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  return PO_OK;
+}
+int po_vec_sync_to_host(po_vec v) {
+  PO_CHECK_PTR(v);
+  if (!v->h) {
+    double *h;
+    return po_vec_get_array(v, &h);
+  }
+  PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
+  PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  return PO_OK;
+}
+int po_vec_get_device_array(po_vec v, double **device) {
+  PO_CHECK_PTR(v);
+  PO_CHECK_PTR(device);
+  *device = v->d;
+  return PO_OK;
+}
+int po_vec_maxpy(po_vec y, double beta, const double *alpha, const po_vec *vecs, int nvecs) {
+  PO_CHECK_PTR(y);
+  if (nvecs > kMaxPanel) {
+    po::set_error("maxpy of %d vectors exceeds %d", nvecs, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  std::vector<const double *> p(nvecs > 0 ? nvecs : 1);
+  for (int j = 0; j < nvecs; j++) {
+    PO_CHECK_PTR(vecs[j]);
+    PO_TRY(same_layout(y, vecs[j]));
+    p[j] = vecs[j]->d;
+  }
+  return k_panel_axpy(y->ctx, y->d, 0.0, nullptr, beta, alpha, p.data(), nvecs, y->n);
+}
+int po_vec_fill_hash(po_vec v, uint64_t seed, uint64_t array_id, int64_t offset, double scale,
+                     double shift) {
+  PO_CHECK_PTR(v);
+  return k_fill_hash(v->ctx, v->d, v->n, seed, array_id, offset, scale, shift);
+}
+
+// ---- quasi-Newton -------------------------------------------------------------------------------
+int po_qn_create(po_ctx ctx, int type, int64_t nlocal, int subspace, po_qn *out) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(out);
+  if (subspace < 0 || nlocal < 0 || (type != PO_QN_BFGS && type != PO_QN_SR1)) {
+    po::set_error("bad quasi-Newton arguments");
+    return PO_ERR_ARG;
+  }
+  po_qn_s *h = new po_qn_s();
+  if (type == PO_QN_BFGS) {
+    h->qn = new LBFGS(ctx, nlocal, subspace);
+  } else {
+    h->qn = new LSR1(ctx, nlocal, subspace);
+  }
+  *out = h;
+  return PO_OK;
+}
+int po_qn_destroy(po_qn qn) {
+  if (!qn) return PO_OK;
+  delete qn->qn;
+  delete qn;
+  return PO_OK;
+}
+int po_qn_set_update_type(po_qn qn, int t) {
+  PO_CHECK_PTR(qn);
+  LBFGS *b = dynamic_cast<LBFGS *>(qn->qn);
+  if (b) b->setBFGSUpdateType(t);
+  return PO_OK;
+}
+int po_qn_set_diag_type(po_qn qn, int t) {
+  PO_CHECK_PTR(qn);
+  qn->qn->setInitDiagonalType(t);
+  return PO_OK;
+}
+int po_qn_reset(po_qn qn) {
+  PO_CHECK_PTR(qn);
+  qn->qn->reset();
+  return PO_OK;
+}
+int po_qn_update(po_qn qn, po_vec s, po_vec y, int *rc) {
+  PO_CHECK_PTR(qn);
+  PO_CHECK_PTR(s);
+  PO_CHECK_PTR(y);
+  int r = 0;
+  PO_TRY(qn->qn->update(s, y, &r));
+  if (rc) *rc = r;
+  return PO_OK;
+}
+int po_qn_mult(po_qn qn, po_vec x, po_vec y) {
+  PO_CHECK_PTR(qn);
+  return qn->qn->mult(x, y);
+}
+int po_qn_mult_add(po_qn qn, double alpha, po_vec x, po_vec y) {
+  PO_CHECK_PTR(qn);
+  return qn->qn->multAdd(alpha, x, y);
+}
+int po_qn_get_compact(po_qn qn, int *size, double *b0, const double **d0, const double **M,
+                      const po_vec **Z) {
+  PO_CHECK_PTR(qn);
+  Vec **z = nullptr;
+  int k = qn->qn->getCompactMat(b0, d0, M, &z);
+  if (size) *size = k;
+  if (Z) {
+    qn->zhandles.resize(k > 0 ? k : 1);
+    for (int i = 0; i < k; i++) qn->zhandles[i] = static_cast<po_vec>(z[i]);
+    *Z = qn->zhandles.data();
+  }
+  return PO_OK;
+}
+int po_qn_max_size(po_qn qn, int *size) {
+  PO_CHECK_PTR(qn);
+  *size = qn->qn->getMaxLimitedMemorySize();
+  return PO_OK;
+}
+
+// ---- problems -------------------------------------------------------------------------------------
+int po_problem_create_callbacks(po_ctx ctx, int64_t nlocal, int ncon, int ninequality,
+                                const po_problem_callbacks *cb, po_problem *out) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(cb);
+  PO_CHECK_PTR(out);
+  if (!cb->get_vars_and_bounds || !cb->eval_obj_con || !cb->eval_obj_con_gradient) {
+    po::set_error("get_vars_and_bounds, eval_obj_con and eval_obj_con_gradient are mandatory");
+    return PO_ERR_ARG;
+  }
+  po_problem_s *h = new po_problem_s();
+  h->p = new CallbackProblem(ctx, nlocal, ncon, ninequality < 0 ? ncon : ninequality, *cb);
+  *out = h;
+  return PO_OK;
+}
+int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon, uint64_t seed,
+                                double eig_min, double eig_max, po_problem *out) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(out);
+  if (kind < 0 || kind > 2 || nglobal < 1 || ncon < 0) {
+    po::set_error("bad separable problem arguments");
+    return PO_ERR_ARG;
+  }
+  SeparableProblem *p = new SeparableProblem(ctx, kind, nglobal, ncon, seed, eig_min, eig_max);
+  int rc = p->init();
+  if (rc != PO_OK) {
+    delete p;
+    return rc;
+  }
+  po_problem_s *h = new po_problem_s();
+  h->p = p;
+  *out = h;
+  return PO_OK;
+}
+int po_problem_destroy(po_problem p) {
+  if (!p) return PO_OK;
+  delete p->p;
+  delete p;
+  return PO_OK;
+}
+int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon) {
+  PO_CHECK_PTR(p);
+  if (nlocal) *nlocal = p->p->nlocal;
+  if (offset) *offset = p->p->offset;
+  if (ncon) *ncon = p->p->ncon;
+  return PO_OK;
+}
+int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons) {
+  PO_CHECK_PTR(p);
+  return p->p->evalObjCon(x, fobj, cons);
+}
+int po_problem_eval_obj_con_gradient(po_problem p, po_vec x, po_vec g, const po_vec *Ac) {
+  PO_CHECK_PTR(p);
+  std::vector<Vec *> a(p->p->ncon > 0 ? p->p->ncon : 1);
+  for (int j = 0; j < p->p->ncon; j++) a[j] = Ac[j];
+  return p->p->evalObjConGradient(x, g, a.data());
+}
+int po_problem_get_vars_and_bounds(po_problem p, po_vec x, po_vec lb, po_vec ub) {
+  PO_CHECK_PTR(p);
+  return p->p->getVarsAndBounds(x, lb, ub);
+}
+
+// ---- interior point -----------------------------------------------------------------------------
+int po_ip_create(po_problem prob, po_ip *out) {
+  PO_CHECK_PTR(prob);
+  PO_CHECK_PTR(out);
+  po_ip_s *h = new po_ip_s();
+  h->ip = new InteriorPoint(prob->p);
+  int rc = h->ip->allocate();
+  if (rc != PO_OK) {
+    delete h->ip;
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return PO_OK;
+}
+int po_ip_destroy(po_ip ip) {
+  if (!ip) return PO_OK;
+  delete ip->ip;
+  delete ip;
+  return PO_OK;
+}
+int po_ip_set_option_str(po_ip ip, const char *name, const char *value) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(name);
+  return ip->ip->options.set(name, value);
+}
+int po_ip_set_option_int(po_ip ip, const char *name, int value) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(name);
+  return ip->ip->options.set(name, value);
+}
+int po_ip_set_option_float(po_ip ip, const char *name, double value) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(name);
+  int rc = ip->ip->options.set(name, value);
+  if (rc == PO_OK && strcmp(name, "penalty_gamma") == 0) ip->ip->setPenaltyGamma(value);
+  return rc;
+}
+int po_ip_optimize(po_ip ip, const char *checkpoint) {
+  PO_CHECK_PTR(ip);
+  return ip->ip->optimize(checkpoint);
+}
+int po_ip_get_optimized_point(po_ip ip, po_vec *x, const double **z, po_vec *zl, po_vec *zu) {
+  PO_CHECK_PTR(ip);
+  Vec *vx, *vzl, *vzu;
+  ip->ip->getOptimizedPoint(&vx, z, &vzl, &vzu);
+  if (x) *x = static_cast<po_vec>(vx);
+  if (zl) *zl = static_cast<po_vec>(vzl);
+  if (zu) *zu = static_cast<po_vec>(vzu);
+  return PO_OK;
+}
+int po_ip_get_optimized_slacks(po_ip ip, const double **s, const double **t, const double **zs,
+                               const double **zt) {
+  PO_CHECK_PTR(ip);
+  ip->ip->getOptimizedSlacks(s, t, zs, zt);
+  return PO_OK;
+}
+int po_ip_get_counters(po_ip ip, int *niter, int *neval, int *ngeval) {
+  PO_CHECK_PTR(ip);
+  ip->ip->getIterationCounters(niter, neval, ngeval);
+  return PO_OK;
+}
+int po_ip_get_barrier_parameter(po_ip ip, double *mu) {
+  PO_CHECK_PTR(ip);
+  *mu = ip->ip->getBarrierParameter();
+  return PO_OK;
+}
+int po_ip_get_complementarity(po_ip ip, double *comp) {
+  PO_CHECK_PTR(ip);
+  return ip->ip->getComplementarity(comp);
+}
+int po_ip_get_objective(po_ip ip, double *fobj, double *rho) {
+  PO_CHECK_PTR(ip);
+  if (fobj) *fobj = ip->ip->fobj;
+  if (rho) *rho = ip->ip->rho_penalty_search;
+  return PO_OK;
+}
+int po_ip_set_penalty_gamma(po_ip ip, double gamma) {
+  PO_CHECK_PTR(ip);
+  ip->ip->setPenaltyGamma(gamma);
+  return PO_OK;
+}
+int po_ip_reset_design_and_bounds(po_ip ip) {
+  PO_CHECK_PTR(ip);
+  return ip->ip->resetDesignAndBounds();
+}
+int po_ip_reset_quasi_newton(po_ip ip) {
+  PO_CHECK_PTR(ip);
+  ip->ip->resetQuasiNewtonHessian();
+  return PO_OK;
+}
+int po_ip_get_quasi_newton(po_ip ip, po_qn *qn) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(qn);
+  *qn = ip->ip->qn ? &ip->ip->qn_handle : nullptr;
+  return PO_OK;
+}
+int po_ip_write_solution_file(po_ip ip, const char *filename) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(filename);
+  return ip->ip->writeSolutionFile(filename);
+}
+int po_ip_set_iteration_callback(po_ip ip, po_ip_iteration_fn fn, void *user) {
+  PO_CHECK_PTR(ip);
+  ip->ip->iter_cb = fn;
+  ip->ip->iter_cb_user = user;
+  return PO_OK;
+}
+int po_ip_get_history(po_ip ip, const char **text) {
+  PO_CHECK_PTR(ip);
+  *text = ip->ip->history.c_str();
+  return PO_OK;
+}
+int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, int *count) {
+  PO_CHECK_PTR(ip);
+  InteriorPoint *p = ip->ip;
+  p->phase_names_joined.clear();
+  for (size_t i = 0; i < p->phase_names.size(); i++) {
+    if (i) p->phase_names_joined += ";";
+    p->phase_names_joined += p->phase_names[i];
+  }
+  if (names) *names = p->phase_names_joined.c_str();
+  if (seconds) *seconds = p->phase_seconds.data();
+  if (count) *count = (int)p->phase_seconds.size();
+  return PO_OK;
+}
+int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,
+                         const double **pz, const double **ps, const double **pt,
+                         const double **pzs, const double **pzt) {
+  PO_CHECK_PTR(ip);
+  InteriorPoint *p = ip->ip;
+  PO_TRY(p->debugKKTStep(mu));
+  if (px) *px = static_cast<po_vec>(p->px);
+  if (pzl) *pzl = static_cast<po_vec>(p->pzl);
+  if (pzu) *pzu = static_cast<po_vec>(p->pzu);
+  if (pz) *pz = p->step.z.data();
+  if (ps) *ps = p->step.s.data();
+  if (pt) *pt = p->step.t.data();
+  if (pzs) *pzs = p->step.zs.data();
+  if (pzt) *pzt = p->step.zt.data();
+  return PO_OK;
+}
+
+// ---- standalone hot kernels -----------------------------------------------------------------------
+static int gather_ptrs(po_vec ref, const po_vec *vecs, int nvecs, std::vector<const double *> &p) {
+  p.resize(nvecs > 0 ? nvecs : 1);
+  for (int j = 0; j < nvecs; j++) {
+    PO_CHECK_PTR(vecs[j]);
+    PO_TRY(same_layout(ref, vecs[j]));
+    p[j] = vecs[j]->d;
+  }
+  return PO_OK;
+}
+int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W) {
+  PO_CHECK_PTR(d);
+  PO_CHECK_PTR(W);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(d, vecs, nvecs, p));
+  return k_wgram(d->ctx, d->d, p.data(), nvecs, d->n, W);
+}
+int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(avg_ms);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(x, vecs, nvecs, p));
+  Ctx *c = x->ctx;
+  int grid = 0;
+  PO_TRY(k_mdot_launch(c, x->d, p.data(), nvecs, x->n, &grid));  // warm-up, sizes partials
+  PO_HIP(hipStreamSynchronize(c->stream));
+  PO_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int r = 0; r < reps; r++) PO_TRY(k_mdot_launch(c, x->d, p.data(), nvecs, x->n, &grid));
+  PO_HIP(hipEventRecord(c->ev1, c->stream));
+  PO_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *avg_ms = (double)ms / (reps > 0 ? reps : 1);
+  if (out) PO_TRY(reduce_finish(c, grid, nvecs, 0, 0, out));
+  return PO_OK;
+}
+int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *avg_ms) {
+  PO_CHECK_PTR(d);
+  PO_CHECK_PTR(avg_ms);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(d, vecs, nvecs, p));
+  Ctx *c = d->ctx;
+  int grid = 0, nslots = 0;
+  PO_TRY(k_wgram_launch(c, d->d, p.data(), nvecs, d->n, &grid, &nslots));
+  PO_HIP(hipStreamSynchronize(c->stream));
+  PO_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int r = 0; r < reps; r++) PO_TRY(k_wgram_launch(c, d->d, p.data(), nvecs, d->n, &grid, &nslots));
+  PO_HIP(hipEventRecord(c->ev1, c->stream));
+  PO_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *avg_ms = (double)ms / (reps > 0 ? reps : 1);
+  return PO_OK;
+}
+
+}  // extern "C"

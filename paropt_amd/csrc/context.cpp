@@ -1,0 +1,235 @@
+// Context, communicator and the host side of the two-stage deterministic reductions.
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "core.hpp"
+
+namespace po {
+
+static thread_local char g_err[1024] = "";
+thread_local int g_last_code = 0;
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "paropt_amd: %s\n", g_err);
+}
+const char *last_error() { return g_err; }
+
+int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin);
+
+// ---- RCCL through dlopen: the library is only needed for world sizes > 1 ----------------------
+struct Id128 {  // ncclUniqueId: 128 opaque bytes passed BY VALUE to ncclCommInitRank
+  char b[PO_RCCL_ID_BYTES];
+};
+struct RcclApi {
+  void *handle = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.handle) return PO_OK;
+  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void *h = nullptr;
+  for (const char *nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    set_error("cannot dlopen librccl.so: %s", dlerror());
+    return PO_ERR_COMM;
+  }
+  g_rccl.GetUniqueId = (int (*)(void *))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(h, "ncclCommInitRank");
+  g_rccl.AllGather =
+      (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+  g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+  g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+    set_error("librccl.so lacks an expected symbol");
+    dlclose(h);
+    return PO_ERR_COMM;
+  }
+  g_rccl.handle = h;
+  return PO_OK;
+}
+
+int rccl_unique_id(void *id128) {
+  PO_TRY(load_rccl());
+  Id128 id;
+  memset(&id, 0, sizeof(id));
+  int rc = g_rccl.GetUniqueId(&id);
+  if (rc != 0) {
+    set_error("ncclGetUniqueId failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PO_ERR_COMM;
+  }
+  memcpy(id128, &id, sizeof(id));
+  return PO_OK;
+}
+
+int comm_init_rccl(Ctx *c, int rank, int size, const void *id128) {
+  if (size < 1 || rank < 0 || rank >= size) {
+    set_error("bad rank/size %d/%d", rank, size);
+    return PO_ERR_ARG;
+  }
+  c->rank = rank;
+  c->size = size;
+  if (size == 1) {
+    c->comm_kind = COMM_SELF;
+    return PO_OK;
+  }
+  PO_TRY(load_rccl());
+  PO_HIP(hipSetDevice(c->device));
+  Id128 id;
+  memcpy(&id, id128, sizeof(id));
+  void *comm = nullptr;
+  int rc = g_rccl.CommInitRank(&comm, size, id, rank);
+  if (rc != 0) {
+    set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return PO_ERR_COMM;
+  }
+  c->rccl_comm = comm;
+  c->comm_kind = COMM_RCCL;
+  // gather buffers sized for the communicator
+  if (c->d_gather) (void)hipFree(c->d_gather);
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  PO_HIP(hipMalloc((void **)&c->d_gather, sizeof(double) * (size_t)size * kMaxRed));
+  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * (size_t)size * kMaxRed, hipHostMallocDefault));
+  return PO_OK;
+}
+
+int comm_init_callback(Ctx *c, int rank, int size, po_allgather_fn fn, void *user) {
+  if (size < 1 || rank < 0 || rank >= size || (size > 1 && !fn)) {
+    set_error("bad callback communicator %d/%d", rank, size);
+    return PO_ERR_ARG;
+  }
+  c->rank = rank;
+  c->size = size;
+  c->cb_allgather = fn;
+  c->cb_user = user;
+  c->comm_kind = size > 1 ? COMM_CALLBACK : COMM_SELF;
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * (size_t)(size + 1) * kMaxRed, hipHostMallocDefault));
+  return PO_OK;
+}
+
+int ctx_create(int device, Ctx **out) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("no HIP device available (%s): paropt_amd has no CPU fallback",
+              e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return PO_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("device %d out of range (have %d)", device, ndev);
+    return PO_ERR_ARG;
+  }
+  PO_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PO_HIP(hipGetDeviceProperties(&prop, device));
+  po_ctx_s *c = new po_ctx_s();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->max_blocks = c->num_cu * 8;
+  PO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  PO_HIP(hipMalloc((void **)&c->d_red, sizeof(double) * kMaxRed));
+  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * kMaxRed, hipHostMallocDefault));
+  PO_HIP(hipEventCreate(&c->ev0));
+  PO_HIP(hipEventCreate(&c->ev1));
+  c->partials_cap = 0;
+  *out = c;
+  return ensure_partials(c, (size_t)c->max_blocks * 64);
+}
+
+int ctx_destroy(Ctx *c) {
+  if (!c) return PO_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_red) (void)hipFree(c->d_red);
+  if (c->d_gather) (void)hipFree(c->d_gather);
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete static_cast<po_ctx_s *>(c);
+  return PO_OK;
+}
+
+int ensure_partials(Ctx *c, size_t doubles) {
+  if (doubles <= c->partials_cap) return PO_OK;
+  // growth happens outside hot loops in practice (first use of a wider kernel)
+  PO_HIP(hipStreamSynchronize(c->stream));
+  if (c->d_partials) PO_HIP(hipFree(c->d_partials));
+  size_t cap = doubles + doubles / 4;
+  PO_HIP(hipMalloc((void **)&c->d_partials, cap * sizeof(double)));
+  c->partials_cap = cap;
+  return PO_OK;
+}
+
+int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out) {
+  const int nslots = nsum + nmin + nmax;
+  if (nslots > kMaxRed) {
+    set_error("reduction of %d slots exceeds kMaxRed=%d", nslots, kMaxRed);
+    return PO_ERR_ARG;
+  }
+  PO_TRY(launch_reduce_final(c, nblocks, nslots, nsum, nmin));
+  c->n_reductions++;
+  const size_t bytes = sizeof(double) * (size_t)nslots;
+  int nparts = 1;
+  const double *parts = c->h_red;
+  if (c->comm_kind == COMM_RCCL) {
+    int rc = g_rccl.AllGather(c->d_red, c->d_gather, (size_t)nslots, /*ncclDouble*/ 8, c->rccl_comm,
+                              c->stream);
+    if (rc != 0) {
+      set_error("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+      return PO_ERR_COMM;
+    }
+    PO_HIP(hipMemcpyAsync(c->h_red, c->d_gather, bytes * c->size, hipMemcpyDeviceToHost, c->stream));
+    PO_HIP(hipStreamSynchronize(c->stream));
+    nparts = c->size;
+  } else {
+    PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
+    PO_HIP(hipStreamSynchronize(c->stream));
+    if (c->comm_kind == COMM_CALLBACK) {
+      double *all = c->h_red + kMaxRed;
+      int rc = c->cb_allgather(c->h_red, all, nslots, c->cb_user);
+      if (rc != 0) {
+        set_error("allgather callback failed with code %d", rc);
+        return PO_ERR_COMM;
+      }
+      parts = all;
+      nparts = c->size;
+    }
+  }
+  // combine the rank contributions in rank order: bit-identical on every rank
+  for (int s = 0; s < nslots; s++) {
+    double acc = parts[s];
+    for (int r = 1; r < nparts; r++) {
+      const double v = parts[(size_t)r * nslots + s];
+      if (s < nsum) {
+        acc += v;
+      } else if (s < nsum + nmin) {
+        acc = fmin(acc, v);
+      } else {
+        acc = fmax(acc, v);
+      }
+    }
+    host_out[s] = acc;
+  }
+  return PO_OK;
+}
+
+}  // namespace po

@@ -1,0 +1,185 @@
+// paropt_amd internal core: context, device vector, reduction plumbing, kernel launchers.
+//
+// Everything in this directory is the PRODUCT: gfx950-only HIP, no CPU fallback.  The host
+// control flow (quasi-Newton bookkeeping, interior-point iteration) lives in qn.cpp / ip.cpp
+// and only ever touches n-sized data through the launchers declared here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/paropt_amd.h"
+
+namespace po {
+
+void set_error(const char *fmt, ...);
+extern thread_local int g_last_code;
+
+#define PO_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      po::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                    __LINE__);                                                           \
+      return PO_ERR_HIP;                                                                 \
+    }                                                                                    \
+  } while (0)
+
+#define PO_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != PO_OK) return _rc; \
+  } while (0)
+
+constexpr int kBlock = 256;          // 4 wavefronts of 64
+constexpr int kMaxPanel = 96;        // widest panel [Ac | Z] (+ a few extras) a kernel accepts
+constexpr int kMaxRed = 8192;        // widest reduction payload (wgram: 15 blocks * 256 + slack)
+constexpr int kWgramMaxVecs = 80;    // 5 block rows of 16
+
+enum CommKind { COMM_SELF = 0, COMM_RCCL = 1, COMM_CALLBACK = 2 };
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  int max_blocks = 2048;  // persistent-grid cap for streaming kernels
+  // communicator
+  int rank = 0, size = 1;
+  CommKind comm_kind = COMM_SELF;
+  void *rccl_comm = nullptr;
+  po_allgather_fn cb_allgather = nullptr;
+  void *cb_user = nullptr;
+  // reduction plumbing
+  double *d_partials = nullptr;  // [slot][block] first-stage partials
+  size_t partials_cap = 0;       // doubles
+  double *d_red = nullptr;       // [kMaxRed] rank-local reduced values
+  double *d_gather = nullptr;    // [size * kMaxRed]
+  double *h_red = nullptr;       // pinned [size * kMaxRed]
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  long n_reductions = 0;  // statistics: host-synchronising reductions issued
+  long n_launches = 0;
+};
+
+struct Vec {
+  Ctx *ctx;
+  int64_t n;
+  double *d;
+  int ref;
+  double *h;  // pinned host mirror (lazy)
+};
+
+// A small table of raw device pointers passed by value as a kernel argument.
+struct PtrTable {
+  const double *p[kMaxPanel];
+};
+struct CoefTable {
+  double a[kMaxPanel];
+};
+
+// Reduction finish: combine first-stage partials ([slot][nblocks] in ctx->d_partials) into
+// host_out[nsum+nmin+nmax]; slots are ordered sums, then mins, then maxs.  Collective.
+int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out);
+int ensure_partials(Ctx *c, size_t doubles);
+int grid_for(Ctx *c, int64_t n);  // persistent grid size for an n-element streaming kernel
+
+// ---- vector kernels (kernels.hip) -----------------------------------------------------------
+int k_fill(Ctx *c, double *y, int64_t n, double alpha);
+int k_fill_hash(Ctx *c, double *y, int64_t n, uint64_t seed, uint64_t aid, int64_t offset,
+                double scale, double shift);
+int k_copy(Ctx *c, double *y, const double *x, int64_t n);
+int k_scale(Ctx *c, double *y, int64_t n, double alpha);
+int k_axpy(Ctx *c, double *y, double alpha, const double *x, int64_t n);
+// y <- a*x + b*y + sum_j alpha[j]*V[j]   (x may be null when a == 0; b == 0 never reads y)
+int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
+                 const double *const *V, int nv, int64_t n);
+enum Red1 { RED_DOT = 0, RED_SUMSQ = 1, RED_ASUM = 2, RED_AMAX = 3 };
+int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out);
+int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out);
+// launch-only variant for the roofline bench (no host sync); result stays in partials
+int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks);
+int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W);
+int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
+                   int *nblocks, int *nslots);
+
+// ---- interior-point kernels -------------------------------------------------------------------
+struct Bounds {  // the per-element data every bound-aware kernel needs
+  const double *x, *lb, *ub, *zl, *zu;
+  double max_bound;  // max_bound_value (1e20)
+  int use_lower, use_upper;
+};
+// rx = [L]zl - [U]zu - g + sum z_j A_j ; out = {comp product, active-bound count, max|rx|,
+// max|rzl|, max|rzu|} with rzl = -((x-lb) zl - beta*mu), rzu = -((ub-x) zu - beta*mu).
+// (computeKKTRes :1337-1446 + computeComp :2742-2820 + computeResNorm :1588-1723)
+int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
+              int nc, double beta_mu, int64_t n, double *rx, double out[5]);
+// the mu-dependent part only (when the barrier parameter changes): out = {comp product,
+// count, max|rzl|, max|rzu|}
+int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[4]);
+// Dinv = 1/(diag + [L] zl/(x-lb) + [U] zu/(ub-x))   (setUpKKTDiagSystem :1864-1910)
+int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv);
+// t = Dinv*(rx + [L] rzl/(x-lb) - [U] rzu/(ub-x)) with rzl, rzu recomputed from beta_mu
+// (the d1 build of solveKKTDiagSystem :2091-2108 followed by mat->apply :2139)
+int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
+         double *t);
+// Second half of the bordered solve.  acc = sum_j alpha_j P_j ; dx = t + Dinv*acc.
+//   first solve  (refine == 0): px = dx; pzl = [L](rzl - zl dx)/(x-lb); pzu = [U](rzu + zu dx)/(ub-x)
+//   refinement   (refine == 1): r'zl = rzl - [L]((x-lb) pzl + px zl), r'zu likewise;
+//                               px += dx; pzl += [L](r'zl - zl dx)/(x-lb); pzu += ...
+// out = {max_x, max_z}: the fraction-to-boundary minima of computeMaxStep :2942-3103 for the
+// final (px, pzl, pzu) with fraction tau (NOT masked by the bound predicates for px, as in the
+// reference).
+int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+             const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
+             double *px, double *pzl, double *pzu, double out[2]);
+// Residual of the linearised KKT system for iterative refinement, already folded into the next
+// solve's right-hand side:  r'x = rx - diag*px + sum coef_j P_j + [L]pzl - [U]pzu ;
+// r'zl, r'zu as above ; t' = Dinv*(r'x + [L] r'zl/(x-lb) - [U] r'zu/(ub-x)).
+// (computeKKTRes + addKKTResStep :1451-1583 + the d1 build of the following solve)
+int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
+               const double *pzu, const double *dinv, const double *coef, const double *const *P,
+               int nv, double diag, double beta_mu, int64_t n, double *tprime);
+// computeCompStep :2825-2923 at (x + ax*px, zl + az*pzl, zu + az*pzu): out = {product, count}
+int k_comp_step(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
+                double ax, double az, int64_t n, double out[2]);
+// evalMeritInitDeriv :3652-3714 barrier part + the three design-space inner products:
+// out = {pos log, neg log, pos presult, neg presult, g.px, px.px}; px is scaled by sx.
+int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double *g, int64_t n,
+             double out[6]);
+// trial point of the line search (:3997-4001) xt = clamp(x + a*px, lb+eps, ub-eps) and the
+// log-barrier partial sums of evalMeritFunc :3541-3565 at xt: out = {pos, neg}
+int k_trial(Ctx *c, const Bounds &b, const double *px, double a, double eps, int64_t n, double *xt,
+            double out[2]);
+// zl <- max(zl + a*pzl, eps) ; zu likewise  (computeStepAndUpdate :4186-4191)
+int k_update_mult(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
+                  double eps, int use_lower, int use_upper, int64_t n);
+// initAffineStepMultipliers :5630-5652: zl = [L] max(amin, |zl + pzl|) (unchanged otherwise)
+int k_affine_mult(Ctx *c, const Bounds &b, double *zl, const double *pzl, double *zu,
+                  const double *pzu, double amin, int64_t n);
+// initAndCheckDesignAndBounds :4290-4360; out flag bits 1/2/4; zl/zu zeroed on inactive bounds
+int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double *zu,
+                   double max_bound, double rel_bound, int both, int64_t n, int *flag);
+int k_zero_inactive(Ctx *c, const double *lb, const double *ub, double *zl, double *zu,
+                    double max_bound, int64_t n);
+
+// ---- built-in problems --------------------------------------------------------------------------
+// f-parts: quadratic sum(0.5 q x^2 + b x), convex sum(b^2/(eps+x)), rosenbrock chain
+int k_quadratic_f(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *f);
+int k_quadratic_g(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *g);
+int k_convex_f(Ctx *c, const double *b, const double *x, int64_t n, double *f);
+int k_convex_g(Ctx *c, const double *b, const double *x, int64_t n, double *g);
+int k_rosen_f(Ctx *c, const double *x, int64_t n, double out[3]);
+int k_rosen_g(Ctx *c, const double *x, int64_t n, double *g, double *a0, double *a1);
+
+// ---- host dense algebra (lu.cpp) --------------------------------------------------------------
+// LAPACK-dgetf2-style LU with partial pivoting, column-major, pivots 0-based.  Returns info
+// (index+1 of the first exactly-zero pivot, or 0); like the reference, callers ignore it
+// (src/ParOptInteriorPoint.cpp:1968-1969).
+int lu_factor(int n, double *A, int lda, int *piv);
+void lu_solve(int n, const double *A, int lda, const int *piv, double *b);
+
+}  // namespace po
+
+struct po_ctx_s : po::Ctx {};
+struct po_vec_s : po::Vec {};

@@ -1,0 +1,143 @@
+// Host-side mirror of ParOptInteriorPoint (reference src/ParOptInteriorPoint.h:128-217) for the
+// quasi-Newton branch with dense constraints (nwcon = 0).  Same public method names, option
+// names/defaults and return codes; every n-sized operation is a HIP kernel launch (core.hpp).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "problem.hpp"
+#include "qn.hpp"
+
+namespace po {
+
+// Typed option registry with the names, defaults and ranges of
+// ParOptInteriorPoint::addDefaultOptions (src/ParOptInteriorPoint.cpp:536-727).
+class Options {
+ public:
+  enum Type { STR = 1, BOOL = 2, INT = 3, FLOAT = 4, ENUM = 5 };
+  struct Entry {
+    Type type;
+    std::string s;
+    int i = 0, ilo = 0, ihi = 0;
+    double f = 0, flo = 0, fhi = 0;
+    std::vector<std::string> choices;
+  };
+  Options();
+  int set(const char *name, const char *value);
+  int set(const char *name, int value);
+  int set(const char *name, double value);
+  const char *str(const char *name) const;
+  int integer(const char *name) const;
+  double real(const char *name) const;
+  bool has(const char *name) const { return e.count(name) > 0; }
+
+ private:
+  std::map<std::string, Entry> e;
+};
+
+struct Dense {  // the c-sized blocks of ParOptVars (src/ParOptInteriorPoint.h:373-389)
+  std::vector<double> z, s, t, zs, zt;
+  void resize(int c) {
+    z.assign(c, 0.0);
+    s.assign(c, 0.0);
+    t.assign(c, 0.0);
+    zs.assign(c, 0.0);
+    zt.assign(c, 0.0);
+  }
+};
+
+class InteriorPoint {
+ public:
+  InteriorPoint(Problem *prob);
+  ~InteriorPoint();
+  int allocate();  // device storage (fails with PO_ERR_HIP when HBM is exhausted)
+
+  Options options;
+  int optimize(const char *checkpoint);
+  void getOptimizedPoint(Vec **x, const double **z, Vec **zl, Vec **zu);
+  void getOptimizedSlacks(const double **s, const double **t, const double **zs, const double **zt);
+  void getIterationCounters(int *niter_, int *neval_, int *ngeval_);
+  double getBarrierParameter() const { return barrier_param; }
+  int getComplementarity(double *comp);
+  void setPenaltyGamma(double gamma);
+  int resetDesignAndBounds();
+  void resetQuasiNewtonHessian();
+  int writeSolutionFile(const char *filename);
+  int debugKKTStep(double mu);
+
+  Problem *prob;
+  Ctx *ctx;
+  int64_t n;
+  int c;
+  CompactQuasiNewton *qn;
+  po_qn_s qn_handle;
+
+  // state
+  Vec *x, *zl, *zu, *lb, *ub, *g;
+  std::vector<Vec *> Ac;
+  Dense vars, res, step, refine;
+  double fobj, barrier_param, rho_penalty_search;
+  std::vector<double> cvals;
+  int niter, neval, ngeval;
+
+  // observer + history
+  po_ip_iteration_fn iter_cb;
+  void *iter_cb_user;
+  std::string history;
+  std::vector<std::string> phase_names;
+  std::vector<double> phase_seconds;
+  std::string phase_names_joined;
+
+  // step storage (exposed for the single-step known-answer tests)
+  Vec *px, *pzl, *pzu;
+
+ private:
+  // work vectors
+  Vec *Dinv, *rx, *tvec, *xt, *y_qn, *s_qn;
+  std::vector<double> gamma_s, gamma_t;
+  int use_lower, use_upper;
+  bool qn_created;
+
+  // small dense systems
+  std::vector<double> W;            // (c+k)^2 weighted Gram, column-major
+  int wk;                           // k used when W was assembled
+  std::vector<double> Gf, Cef;      // LU factors
+  std::vector<int> gpiv, cpiv;
+  // residual bookkeeping of the last computeResidual call
+  double comp_prod, comp_count, max_rx, max_rzl, max_rzu;
+  // lazily applied step scalings (scaleKKTStep :3253-3268)
+  double sx, sz;
+  double step_mins[2];
+
+  Bounds bounds() const;
+  std::vector<const double *> panel(bool use_qn, int *k) const;
+
+  int createQuasiNewton();
+  int initAndCheckDesignAndBounds();
+  int initLeastSquaresMultipliers();
+  int initAffineStepMultipliers();
+  void denseResidual(double mu, Dense &r) const;
+  int computeResidual(double mu, bool vectors);
+  void resNorms(const Dense &r, double *max_prime, double *max_dual, double *max_infeas,
+                double *res_norm) const;
+  double compFromSums(double prod, double count, const Dense &v) const;
+  int setUpKKTSystem(bool use_qn);
+  int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out);
+  int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);
+  int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq);
+  int evalMeritInitDeriv(double max_x, double *merit, double *pmerit);
+  double evalMeritFromSums(double fk, const double *ck, const double *sk, const double *tk,
+                           double pos, double neg) const;
+  int lineSearch(double alpha_min, double *alpha, double m0, double dm0, int *fail);
+  int computeStepAndUpdate(double alpha, int eval_obj_con, int perform_qn_update, int *update_type);
+  void phaseBegin();
+  void phaseEnd(const char *name);
+  double phase_t0;
+};
+
+}  // namespace po
+
+struct po_ip_s {
+  po::InteriorPoint *ip;
+};

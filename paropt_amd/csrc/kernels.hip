@@ -1,0 +1,1218 @@
+// paropt_amd -- hand-written gfx950 (CDNA4, wave64) kernels of the interior-point hot path.
+//
+// Design rules (DESIGN.md "Kernels"):
+//   * every n-sized kernel is HBM-bound fp64 streaming: 16 B per lane per load (double2),
+//     256-thread workgroups (4 wavefronts of 64), persistent grid-stride grids capped at
+//     8 workgroups per CU so the 256 CUs / 8 XCDs are filled many times over;
+//   * reductions are two-stage and deterministic: per-wave butterfly shuffles -> LDS across
+//     the 4 waves -> one partial per workgroup per slot ([slot][block] layout) -> a second
+//     tiny kernel that sums each slot over blocks in a fixed order;
+//   * panel kernels keep the per-vector accumulators in VGPRs (compile-time panel blocks) and
+//     read the multiplying vector once per block of up to 32 panel columns;
+//   * the weighted Gram matrix is the only MFMA user (v_mfma_f64_16x16x4_f64, LDS-staged).
+#include "core.hpp"
+
+#include <math.h>
+
+namespace po {
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#define PO_PAIR_LOOP(q, n)                                                                 \
+  const int64_t _npairs = ((n) + 1) >> 1;                                                  \
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < _npairs;            \
+       q += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t q, int64_t n) {
+  const int64_t i = 2 * q;
+  if (i + 1 < n) return *reinterpret_cast<const double2 *>(p + i);
+  return make_double2(p[i], 0.0);
+}
+__device__ __forceinline__ void st2(double *__restrict__ p, int64_t q, int64_t n, double2 v) {
+  const int64_t i = 2 * q;
+  if (i + 1 < n) {
+    *reinterpret_cast<double2 *>(p + i) = v;
+  } else {
+    p[i] = v.x;
+  }
+}
+
+enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
+
+template <int OP>
+__device__ __forceinline__ double combine(double a, double b) {
+  if (OP == OP_SUM) return a + b;
+  if (OP == OP_MIN) return fmin(a, b);
+  return fmax(a, b);
+}
+
+template <int OP>
+__device__ __forceinline__ double wave_reduce(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = combine<OP>(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Reduce N per-thread values over the 256-thread workgroup and store one partial per slot at
+// partials[(slot0 + j) * gridDim.x + blockIdx.x].  `sm` must hold 4*N doubles.
+template <int N, int OP>
+__device__ __forceinline__ void block_reduce_store(double (&a)[N], double *__restrict__ partials,
+                                                   int slot0, double *sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double v = wave_reduce<OP>(a[j]);
+    if (lane == 0) sm[wave * N + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int j = threadIdx.x;
+    double v = combine<OP>(combine<OP>(sm[j], sm[N + j]), combine<OP>(sm[2 * N + j], sm[3 * N + j]));
+    partials[(size_t)(slot0 + j) * gridDim.x + blockIdx.x] = v;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kBlock)
+    reduce_final_kernel(const double *__restrict__ partials, int nblocks, int nslots, int nsum,
+                        int nmin, double *__restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= nslots) return;
+  const double *p = partials + (size_t)slot * nblocks;
+  if (slot < nsum) {
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += p[b];
+    acc = wave_reduce<OP_SUM>(acc);
+    if (lane == 0) out[slot] = acc;
+  } else if (slot < nsum + nmin) {
+    double acc = INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmin(acc, p[b]);
+    acc = wave_reduce<OP_MIN>(acc);
+    if (lane == 0) out[slot] = acc;
+  } else {
+    double acc = -INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmax(acc, p[b]);
+    acc = wave_reduce<OP_MAX>(acc);
+    if (lane == 0) out[slot] = acc;
+  }
+}
+
+int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin) {
+  const int grid = (nslots + 3) / 4;
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(grid), dim3(kBlock), 0, c->stream, c->d_partials,
+                     nblocks, nslots, nsum, nmin, c->d_red);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  return PO_OK;
+}
+
+int grid_for(Ctx *c, int64_t n) {
+  const int64_t npairs = (n + 1) >> 1;
+  int64_t blocks = (npairs + kBlock - 1) / kBlock;
+  if (blocks > c->max_blocks) blocks = c->max_blocks;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+#define PO_LAUNCH(kernel, grid, ...)                                                      \
+  do {                                                                                    \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, __VA_ARGS__);      \
+    c->n_launches++;                                                                      \
+    PO_HIP(hipGetLastError());                                                            \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// counter hash (DESIGN.md "Synthetic data"): identical to oracle/paropt_oracle.py::u01
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ double u01(uint64_t base, uint64_t i) {
+  return (double)(splitmix64(base + i) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BLAS-1 style kernels (ParOptBasicVec, src/ParOptVec.cpp:32-204)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) fill_kernel(double *__restrict__ y, int64_t n, double a) {
+  PO_PAIR_LOOP(q, n) { st2(y, q, n, make_double2(a, a)); }
+}
+__global__ void __launch_bounds__(kBlock)
+    fill_hash_kernel(double *__restrict__ y, int64_t n, uint64_t base, int64_t offset, double scale,
+                     double shift) {
+  PO_PAIR_LOOP(q, n) {
+    const uint64_t i = (uint64_t)(offset + 2 * q);
+    st2(y, q, n, make_double2(shift + scale * u01(base, i), shift + scale * u01(base, i + 1)));
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    copy_kernel(double *__restrict__ y, const double *__restrict__ x, int64_t n) {
+  PO_PAIR_LOOP(q, n) { st2(y, q, n, ld2(x, q, n)); }
+}
+__global__ void __launch_bounds__(kBlock) scale_kernel(double *__restrict__ y, int64_t n, double a) {
+  PO_PAIR_LOOP(q, n) {
+    double2 v = ld2(y, q, n);
+    st2(y, q, n, make_double2(a * v.x, a * v.y));
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    axpy_kernel(double *__restrict__ y, double a, const double *__restrict__ x, int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    double2 v = ld2(y, q, n), w = ld2(x, q, n);
+    st2(y, q, n, make_double2(v.x + a * w.x, v.y + a * w.y));
+  }
+}
+
+int k_fill(Ctx *c, double *y, int64_t n, double a) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(fill_kernel, grid_for(c, n), y, n, a);
+  return PO_OK;
+}
+int k_fill_hash(Ctx *c, double *y, int64_t n, uint64_t seed, uint64_t aid, int64_t offset,
+                double scale, double shift) {
+  if (n <= 0) return PO_OK;
+  const uint64_t base = seed * 0x9E3779B97F4A7C15ULL + aid * 0xD1B54A32D192ED03ULL;
+  PO_LAUNCH(fill_hash_kernel, grid_for(c, n), y, n, base, offset, scale, shift);
+  return PO_OK;
+}
+int k_copy(Ctx *c, double *y, const double *x, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(copy_kernel, grid_for(c, n), y, x, n);
+  return PO_OK;
+}
+int k_scale(Ctx *c, double *y, int64_t n, double a) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(scale_kernel, grid_for(c, n), y, n, a);
+  return PO_OK;
+}
+int k_axpy(Ctx *c, double *y, double a, const double *x, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(axpy_kernel, grid_for(c, n), y, a, x, n);
+  return PO_OK;
+}
+
+// y <- a*x + b*y + sum_j alpha_j V_j : runtime panel width, no per-column registers needed.
+__global__ void __launch_bounds__(kBlock)
+    panel_axpy_kernel(double *__restrict__ y, double a, const double *__restrict__ x, double b,
+                      CoefTable alpha, PtrTable V, int nv, int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    double2 acc = make_double2(0.0, 0.0);
+    if (a != 0.0) {
+      double2 v = ld2(x, q, n);
+      acc.x = a * v.x;
+      acc.y = a * v.y;
+    }
+    if (b != 0.0) {
+      double2 v = ld2(y, q, n);
+      acc.x += b * v.x;
+      acc.y += b * v.y;
+    }
+#pragma unroll 8
+    for (int j = 0; j < nv; j++) {
+      double2 v = ld2(V.p[j], q, n);
+      acc.x += alpha.a[j] * v.x;
+      acc.y += alpha.a[j] * v.y;
+    }
+    st2(y, q, n, acc);
+  }
+}
+
+static void fill_tables(const double *alpha, const double *const *V, int nv, CoefTable *ct,
+                        PtrTable *pt) {
+  for (int j = 0; j < kMaxPanel; j++) {
+    ct->a[j] = (alpha && j < nv) ? alpha[j] : 0.0;
+    pt->p[j] = (V && j < nv) ? V[j] : nullptr;
+  }
+}
+
+int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
+                 const double *const *V, int nv, int64_t n) {
+  if (n <= 0) return PO_OK;
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  CoefTable ct;
+  PtrTable pt;
+  fill_tables(alpha, V, nv, &ct, &pt);
+  PO_LAUNCH(panel_axpy_kernel, grid_for(c, n), y, a, x, b, ct, pt, nv, n);
+  return PO_OK;
+}
+
+// dot / sum of squares / asum / amax
+template <int KIND>
+__global__ void __launch_bounds__(kBlock)
+    reduce1_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
+                   double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double acc[1] = {0.0};
+  PO_PAIR_LOOP(q, n) {
+    double2 v = ld2(x, q, n);
+    if (KIND == RED_DOT) {
+      double2 w = ld2(y, q, n);
+      acc[0] += v.x * w.x + v.y * w.y;
+    } else if (KIND == RED_SUMSQ) {
+      acc[0] += v.x * v.x + v.y * v.y;
+    } else if (KIND == RED_ASUM) {
+      acc[0] += fabs(v.x) + fabs(v.y);
+    } else {
+      acc[0] = fmax(acc[0], fmax(fabs(v.x), fabs(v.y)));
+    }
+  }
+  if (KIND == RED_AMAX) {
+    block_reduce_store<1, OP_MAX>(acc, partials, 0, sm);
+  } else {
+    block_reduce_store<1, OP_SUM>(acc, partials, 0, sm);
+  }
+}
+
+int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid));
+  switch (kind) {
+    case RED_DOT:
+      PO_LAUNCH(reduce1_kernel<RED_DOT>, grid, x, y, n, c->d_partials);
+      break;
+    case RED_SUMSQ:
+      PO_LAUNCH(reduce1_kernel<RED_SUMSQ>, grid, x, y, n, c->d_partials);
+      break;
+    case RED_ASUM:
+      PO_LAUNCH(reduce1_kernel<RED_ASUM>, grid, x, y, n, c->d_partials);
+      break;
+    default:
+      PO_LAUNCH(reduce1_kernel<RED_AMAX>, grid, x, y, n, c->d_partials);
+      break;
+  }
+  if (kind == RED_AMAX) return reduce_finish(c, grid, 0, 0, 1, out);
+  return reduce_finish(c, grid, 1, 0, 0, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mdot: out_j = sum_i x_i V_j[i]   (ParOptBasicVec::mdot, src/ParOptVec.cpp:152-170)
+// x is read once per block of NVB panel columns; the NVB accumulators live in VGPRs.
+// Algorithmic traffic: 8*(nvecs+1)*n bytes.
+// ---------------------------------------------------------------------------------------------
+template <int NVB>
+__global__ void __launch_bounds__(kBlock)
+    mdot_kernel(const double *__restrict__ x, PtrTable V, int j0, int nv, int64_t n,
+                double *__restrict__ partials) {
+  __shared__ double sm[4 * NVB];
+  double acc[NVB];
+#pragma unroll
+  for (int j = 0; j < NVB; j++) acc[j] = 0.0;
+  PO_PAIR_LOOP(q, n) {
+    const double2 xv = ld2(x, q, n);
+#pragma unroll
+    for (int j = 0; j < NVB; j++) {
+      if (j < nv) {
+        const double2 v = ld2(V.p[j0 + j], q, n);
+        acc[j] = fma(xv.x, v.x, fma(xv.y, v.y, acc[j]));
+      }
+    }
+  }
+  block_reduce_store<NVB, OP_SUM>(acc, partials, j0, sm);
+}
+
+int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks) {
+  if (nv > kMaxPanel) {
+    set_error("mdot of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int grid = grid_for(c, n);
+  // every group writes NVB slots, so reserve for the padded width
+  PO_TRY(ensure_partials(c, (size_t)grid * (nv + 32)));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(nullptr, V, nv, &ct, &pt);
+  // padded columns must still be valid pointers for nothing: they are never dereferenced
+  int j0 = 0;
+  while (j0 < nv) {
+    const int rem = nv - j0;
+    if (rem >= 32) {
+      PO_LAUNCH(mdot_kernel<32>, grid, x, pt, j0, 32, n, c->d_partials);
+      j0 += 32;
+    } else if (rem > 16) {
+      PO_LAUNCH(mdot_kernel<32>, grid, x, pt, j0, rem, n, c->d_partials);
+      j0 += rem;
+    } else if (rem > 8) {
+      PO_LAUNCH(mdot_kernel<16>, grid, x, pt, j0, rem, n, c->d_partials);
+      j0 += rem;
+    } else if (rem > 4) {
+      PO_LAUNCH(mdot_kernel<8>, grid, x, pt, j0, rem, n, c->d_partials);
+      j0 += rem;
+    } else {
+      PO_LAUNCH(mdot_kernel<4>, grid, x, pt, j0, rem, n, c->d_partials);
+      j0 += rem;
+    }
+  }
+  *nblocks = grid;
+  return PO_OK;
+}
+
+int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out) {
+  if (nv <= 0) return PO_OK;
+  int grid = 0;
+  PO_TRY(k_mdot_launch(c, x, V, nv, n, &grid));
+  return reduce_finish(c, grid, nv, 0, 0, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weighted Gram  W = P^T diag(d) P  on the fp64 matrix cores.
+//
+// Replaces the reference's c(c+1)/2 dots of setUpKKTDiagSystem (src/ParOptInteriorPoint.cpp:
+// 1935-1950) AND the k diagonal-KKT solves + k mdots of setUpKKTSystem (:2648-2654) by one pass
+// over the panel.  Algorithmic traffic 8*(m+1)*n bytes, m(m+1)n flops.
+//
+// Mapping: one workgroup stages a tile of TILE rows of all m (padded to 16*MB) columns in LDS
+// ([column][row], row stride TILE+2 doubles so that the ds_read_b64 operand fetches of a
+// 16-column x 4-row fragment hit 32 distinct 8-byte slots); the 4 wavefronts split the tile's
+// rows (K split) and each accumulates all MB(MB+1)/2 upper-triangular 16x16 blocks with
+// v_mfma_f64_16x16x4_f64:  A fragment = P[16r + (lane&15)][row0 + (lane>>4)],
+//                          B fragment = d[row] * P[16s + (lane&15)][row]          (r <= s).
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int kGramTile = 128;            // rows per LDS tile
+constexpr int kGramLd = kGramTile + 2;    // LDS row stride in doubles (== 2 mod 32)
+
+template <int MB>
+__global__ void __launch_bounds__(kBlock)
+    wgram_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
+                 double *__restrict__ partials) {
+  constexpr int M = 16 * MB;
+  constexpr int NBLK = MB * (MB + 1) / 2;
+  extern __shared__ double lds[];  // [M][kGramLd] panel tile, then [kGramTile] weights
+  double *pt = lds;
+  double *dw = lds + M * kGramLd;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  f64x4 acc[NBLK];
+#pragma unroll
+  for (int b = 0; b < NBLK; b++) acc[b] = (f64x4){0.0, 0.0, 0.0, 0.0};
+
+  // zero the padded columns once (they are never written by the staging loop)
+  for (int idx = tid; idx < (M - nv) * kGramLd; idx += kBlock) pt[nv * kGramLd + idx] = 0.0;
+
+  const int col_in_pass = tid >> 6;        // 4 columns per staging pass, 64 lanes per column
+  const int pair = tid & 63;               // 64 lanes * 2 doubles = 128 rows
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kGramTile;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage: global -> LDS, 16 B per lane, fully coalesced 1 KiB per column ----
+    for (int j = col_in_pass; j < nv; j += 4) {
+      const int64_t i = row0 + 2 * pair;
+      double2 v = make_double2(0.0, 0.0);
+      if (i + 1 < n) {
+        v = *reinterpret_cast<const double2 *>(V.p[j] + i);
+      } else if (i < n) {
+        v.x = V.p[j][i];
+      }
+      *reinterpret_cast<double2 *>(pt + j * kGramLd + 2 * pair) = v;
+    }
+    if (tid < 64) {
+      const int64_t i = row0 + 2 * tid;
+      double2 v = make_double2(0.0, 0.0);
+      if (i + 1 < n) {
+        v = *reinterpret_cast<const double2 *>(d + i);
+      } else if (i < n) {
+        v.x = d[i];
+      }
+      *reinterpret_cast<double2 *>(dw + 2 * tid) = v;
+    }
+    __syncthreads();
+    // ---- compute: wave w owns rows [32w, 32w+32) of the tile: 8 k-steps of 4 rows ----
+    const int colq = lane & 15, rowq = lane >> 4;
+#pragma unroll 2
+    for (int ks = 0; ks < kGramTile / 16; ks++) {
+      const int r = wave * (kGramTile / 4) + ks * 4 + rowq;
+      const double w = dw[r];
+      double a[MB], bw[MB];
+#pragma unroll
+      for (int m = 0; m < MB; m++) {
+        a[m] = pt[(16 * m + colq) * kGramLd + r];
+        bw[m] = a[m] * w;
+      }
+      int b = 0;
+#pragma unroll
+      for (int rb = 0; rb < MB; rb++) {
+#pragma unroll
+        for (int sb = rb; sb < MB; sb++) {
+          acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], bw[sb], acc[b], 0, 0, 0);
+          b++;
+        }
+      }
+    }
+  }
+  // ---- cross-wave (K split) reduction through LDS, then one partial per workgroup ----
+  __syncthreads();
+  double *red = lds;  // reuse: [4 waves][NBLK*256]
+  // each lane holds 4 values of each block: element (row = rowq + 4*e, col = colq)
+#pragma unroll
+  for (int b = 0; b < NBLK; b++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int row = (lane >> 4) + 4 * e, col = lane & 15;
+      red[(wave * NBLK + b) * 256 + row * 16 + col] = acc[b][e];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NBLK * 256; idx += kBlock) {
+    const double v = (red[idx] + red[NBLK * 256 + idx]) + (red[2 * NBLK * 256 + idx] + red[3 * NBLK * 256 + idx]);
+    partials[(size_t)idx * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+template <int MB>
+static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int grid,
+                          int64_t ntiles) {
+  constexpr int M = 16 * MB;
+  constexpr int NBLK = MB * (MB + 1) / 2;
+  size_t lds_stage = (size_t)(M * kGramLd + kGramTile) * sizeof(double);
+  size_t lds_red = (size_t)4 * NBLK * 256 * sizeof(double);
+  size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_kernel<MB>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgram_kernel<MB>, dim3(grid), dim3(kBlock), lds, c->stream, d, pt, nv, n,
+                     ntiles, c->d_partials);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  return PO_OK;
+}
+
+int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, int *nblocks,
+                   int *nslots) {
+  if (nv > kWgramMaxVecs || nv < 1) {
+    set_error("wgram panel width %d outside 1..%d", nv, kWgramMaxVecs);
+    return PO_ERR_ARG;
+  }
+  const int MB = (nv + 15) / 16;
+  const int NBLK = MB * (MB + 1) / 2;
+  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
+  int64_t g = c->num_cu * (MB <= 3 ? 3 : 2);
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  const int grid = (int)g;
+  PO_TRY(ensure_partials(c, (size_t)grid * NBLK * 256));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(nullptr, V, nv, &ct, &pt);
+  switch (MB) {
+    case 1: PO_TRY(wgram_launch_t<1>(c, d, pt, nv, n, grid, ntiles)); break;
+    case 2: PO_TRY(wgram_launch_t<2>(c, d, pt, nv, n, grid, ntiles)); break;
+    case 3: PO_TRY(wgram_launch_t<3>(c, d, pt, nv, n, grid, ntiles)); break;
+    case 4: PO_TRY(wgram_launch_t<4>(c, d, pt, nv, n, grid, ntiles)); break;
+    default: PO_TRY(wgram_launch_t<5>(c, d, pt, nv, n, grid, ntiles)); break;
+  }
+  *nblocks = grid;
+  *nslots = NBLK * 256;
+  return PO_OK;
+}
+
+int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W) {
+  if (nv <= 0) return PO_OK;
+  int grid = 0, nslots = 0;
+  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots));
+  std::vector<double> blocks(nslots);
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));
+  const int MB = (nv + 15) / 16;
+  int b = 0;
+  for (int rb = 0; rb < MB; rb++) {
+    for (int sb = rb; sb < MB; sb++, b++) {
+      for (int r = 0; r < 16; r++) {
+        for (int s = 0; s < 16; s++) {
+          const int i = 16 * rb + r, j = 16 * sb + s;
+          if (i < nv && j < nv) {
+            const double v = blocks[(size_t)b * 256 + r * 16 + s];
+            if (rb == sb) {
+              // diagonal block: both triangles were computed; symmetrise exactly
+              if (r <= s) {
+                W[i + (size_t)nv * j] = v;
+                W[j + (size_t)nv * i] = v;
+              }
+            } else {
+              W[i + (size_t)nv * j] = v;
+              W[j + (size_t)nv * i] = v;
+            }
+          }
+        }
+      }
+    }
+  }
+  return PO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// interior-point element kernels
+// ---------------------------------------------------------------------------------------------
+struct BE {  // per-element bound data
+  bool L, U;
+  double xl, xu, zl, zu;
+};
+__device__ __forceinline__ BE bound_elem(double x, double lb, double ub, double zl, double zu,
+                                         double maxb, int use_lower, int use_upper) {
+  BE e;
+  e.L = use_lower && (lb > -maxb);
+  e.U = use_upper && (ub < maxb);
+  e.xl = e.L ? (x - lb) : 1.0;
+  e.xu = e.U ? (ub - x) : 1.0;
+  e.zl = zl;
+  e.zu = zu;
+  return e;
+}
+#define PO_LOAD_BOUNDS(b, q, n)                                                         \
+  const double2 _x = ld2((b).x, q, n), _lb = ld2((b).lb, q, n), _ub = ld2((b).ub, q, n), \
+                _zl = ld2((b).zl, q, n), _zu = ld2((b).zu, q, n);                        \
+  const bool _has2 = (2 * q + 1 < n);                                                    \
+  const BE e0 = bound_elem(_x.x, _lb.x, _ub.x, _zl.x, _zu.x, (b).max_bound, (b).use_lower, \
+                           (b).use_upper);                                               \
+  BE e1 = bound_elem(_x.y, _lb.y, _ub.y, _zl.y, _zu.y, (b).max_bound, (b).use_lower,     \
+                     (b).use_upper);                                                     \
+  if (!_has2) {                                                                          \
+    e1.L = false;                                                                        \
+    e1.U = false;                                                                        \
+    e1.xl = 1.0;                                                                         \
+    e1.xu = 1.0;                                                                         \
+  }
+
+// rx, complementarity, residual norms -----------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    kkt_res_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc,
+                   double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ partials) {
+  __shared__ double sm[4 * 3];
+  double sums[2] = {0.0, 0.0};  // comp product, active count
+  double maxs[3] = {0.0, 0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 gv = ld2(g, q, n);
+    double2 r;
+    r.x = (b.use_lower ? _zl.x : 0.0);
+    r.y = (b.use_lower ? _zl.y : 0.0);
+    if (b.use_upper) {
+      r.x += -1.0 * _zu.x;
+      r.y += -1.0 * _zu.y;
+    }
+    r.x += -1.0 * gv.x;
+    r.y += -1.0 * gv.y;
+#pragma unroll 8
+    for (int j = 0; j < nc; j++) {
+      const double2 a = ld2(A.p[j], q, n);
+      r.x += z.a[j] * a.x;
+      r.y += z.a[j] * a.y;
+    }
+    if (!_has2) r.y = 0.0;
+    st2(rx, q, n, r);
+    maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
+    if (e0.L) {
+      sums[0] += e0.zl * e0.xl;
+      sums[1] += 1.0;
+      maxs[1] = fmax(maxs[1], fabs(-(e0.xl * e0.zl - beta_mu)));
+    }
+    if (e1.L) {
+      sums[0] += e1.zl * e1.xl;
+      sums[1] += 1.0;
+      maxs[1] = fmax(maxs[1], fabs(-(e1.xl * e1.zl - beta_mu)));
+    }
+    if (e0.U) {
+      sums[0] += e0.zu * e0.xu;
+      sums[1] += 1.0;
+      maxs[2] = fmax(maxs[2], fabs(-(e0.xu * e0.zu - beta_mu)));
+    }
+    if (e1.U) {
+      sums[0] += e1.zu * e1.xu;
+      sums[1] += 1.0;
+      maxs[2] = fmax(maxs[2], fabs(-(e1.xu * e1.zu - beta_mu)));
+    }
+  }
+  block_reduce_store<2, OP_SUM>(sums, partials, 0, sm);
+  block_reduce_store<3, OP_MAX>(maxs, partials, 2, sm);
+}
+
+int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
+              int nc, double beta_mu, int64_t n, double *rx, double out[5]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 5));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(z, A, nc, &ct, &pt);
+  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, c->d_partials);
+  return reduce_finish(c, grid, 2, 0, 3, out);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    res_norms_kernel(Bounds b, double beta_mu, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double sums[2] = {0.0, 0.0};
+  double maxs[2] = {0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    if (e0.L) {
+      sums[0] += e0.zl * e0.xl;
+      sums[1] += 1.0;
+      maxs[0] = fmax(maxs[0], fabs(-(e0.xl * e0.zl - beta_mu)));
+    }
+    if (e1.L) {
+      sums[0] += e1.zl * e1.xl;
+      sums[1] += 1.0;
+      maxs[0] = fmax(maxs[0], fabs(-(e1.xl * e1.zl - beta_mu)));
+    }
+    if (e0.U) {
+      sums[0] += e0.zu * e0.xu;
+      sums[1] += 1.0;
+      maxs[1] = fmax(maxs[1], fabs(-(e0.xu * e0.zu - beta_mu)));
+    }
+    if (e1.U) {
+      sums[0] += e1.zu * e1.xu;
+      sums[1] += 1.0;
+      maxs[1] = fmax(maxs[1], fabs(-(e1.xu * e1.zu - beta_mu)));
+    }
+  }
+  block_reduce_store<2, OP_SUM>(sums, partials, 0, sm);
+  block_reduce_store<2, OP_MAX>(maxs, partials, 2, sm);
+}
+
+int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[4]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 4));
+  PO_LAUNCH(res_norms_kernel, grid, b, beta_mu, n, c->d_partials);
+  return reduce_finish(c, grid, 2, 0, 2, out);
+}
+
+// Dinv ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dinv_elem(const BE &e, double diag) {
+  double v = diag;
+  if (e.L) v += e.zl / e.xl;
+  if (e.U) v += e.zu / e.xu;
+  return 1.0 / v;
+}
+__global__ void __launch_bounds__(kBlock)
+    dinv_kernel(Bounds b, double diag, int64_t n, double *__restrict__ dinv) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    st2(dinv, q, n, make_double2(dinv_elem(e0, diag), dinv_elem(e1, diag)));
+  }
+}
+int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(dinv_kernel, grid_for(c, n), b, diag, n, dinv);
+  return PO_OK;
+}
+
+// t = Dinv * d1 -----------------------------------------------------------------------------------
+__device__ __forceinline__ double d1_elem(const BE &e, double rx, double beta_mu) {
+  double d1 = rx;
+  if (e.L) d1 += (-(e.xl * e.zl - beta_mu)) / e.xl;
+  if (e.U) d1 -= (-(e.xu * e.zu - beta_mu)) / e.xu;
+  return d1;
+}
+__global__ void __launch_bounds__(kBlock)
+    d1_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ dinv,
+              double beta_mu, int64_t n, double *__restrict__ t) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 r = ld2(rx, q, n), dv = ld2(dinv, q, n);
+    st2(t, q, n, make_double2(dv.x * d1_elem(e0, r.x, beta_mu), dv.y * d1_elem(e1, r.y, beta_mu)));
+  }
+}
+int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
+         double *t) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(d1_kernel, grid_for(c, n), b, rx, dinv, beta_mu, n, t);
+  return PO_OK;
+}
+
+// second half of the bordered solve ------------------------------------------------------------
+struct Step3 {
+  double px, pzl, pzu;
+};
+template <int REFINE>
+__device__ __forceinline__ Step3 solve2_elem(const BE &e, double dx, double beta_mu, double px0,
+                                             double pzl0, double pzu0) {
+  Step3 s;
+  const double rzl = e.L ? -(e.xl * e.zl - beta_mu) : 0.0;
+  const double rzu = e.U ? -(e.xu * e.zu - beta_mu) : 0.0;
+  if (REFINE) {
+    const double rzl2 = e.L ? rzl - (e.xl * pzl0 + px0 * e.zl) : 0.0;
+    const double rzu2 = e.U ? rzu - (e.xu * pzu0 - px0 * e.zu) : 0.0;
+    s.px = px0 + dx;
+    s.pzl = pzl0 + (e.L ? (rzl2 - e.zl * dx) / e.xl : 0.0);
+    s.pzu = pzu0 + (e.U ? (rzu2 + e.zu * dx) / e.xu : 0.0);
+  } else {
+    s.px = dx;
+    s.pzl = e.L ? (rzl - e.zl * dx) / e.xl : 0.0;
+    s.pzu = e.U ? (rzu + e.zu * dx) / e.xu : 0.0;
+  }
+  return s;
+}
+// fraction-to-boundary minima (computeMaxStep :2958-2980, 3064-3090): the primal tests use the
+// raw x-lb / ub-x and are not masked by the bound predicates, exactly as the reference.
+__device__ __forceinline__ void max_step_elem(const Bounds &b, double x, double lb, double ub,
+                                              double zl, double zu, const Step3 &s, double tau,
+                                              double &mx, double &mz) {
+  if (b.use_lower) {
+    if (s.px < 0.0) mx = fmin(mx, -tau * (x - lb) / s.px);
+    if (s.pzl < 0.0) mz = fmin(mz, -tau * zl / s.pzl);
+  }
+  if (b.use_upper) {
+    if (s.px > 0.0) mx = fmin(mx, tau * (ub - x) / s.px);
+    if (s.pzu < 0.0) mz = fmin(mz, -tau * zu / s.pzu);
+  }
+}
+
+template <int REFINE>
+__global__ void __launch_bounds__(kBlock)
+    solve2_kernel(Bounds b, const double *__restrict__ t, const double *__restrict__ dinv,
+                  CoefTable alpha, PtrTable P, int nv, double beta_mu, double tau, int64_t n,
+                  double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
+                  double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double mins[2] = {1.0, 1.0};
+  PO_PAIR_LOOP(q, n) {
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll 8
+    for (int j = 0; j < nv; j++) {
+      const double2 v = ld2(P.p[j], q, n);
+      acc.x += alpha.a[j] * v.x;
+      acc.y += alpha.a[j] * v.y;
+    }
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
+    const double dx0 = tv.x + dv.x * acc.x, dx1 = tv.y + dv.y * acc.y;
+    double2 p0 = make_double2(0.0, 0.0), l0 = p0, u0 = p0;
+    if (REFINE) {
+      p0 = ld2(px, q, n);
+      l0 = ld2(pzl, q, n);
+      u0 = ld2(pzu, q, n);
+    }
+    const Step3 s0 = solve2_elem<REFINE>(e0, dx0, beta_mu, p0.x, l0.x, u0.x);
+    Step3 s1 = solve2_elem<REFINE>(e1, dx1, beta_mu, p0.y, l0.y, u0.y);
+    if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+    st2(px, q, n, make_double2(s0.px, s1.px));
+    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+    if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+  }
+  block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
+}
+
+int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+             const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
+             double *px, double *pzl, double *pzu, double out[2]) {
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(alpha, P, nv, &ct, &pt);
+  if (refine) {
+    PO_LAUNCH(solve2_kernel<1>, grid, b, t, dinv, ct, pt, nv, beta_mu, tau, n, px, pzl, pzu,
+              c->d_partials);
+  } else {
+    PO_LAUNCH(solve2_kernel<0>, grid, b, t, dinv, ct, pt, nv, beta_mu, tau, n, px, pzl, pzu,
+              c->d_partials);
+  }
+  return reduce_finish(c, grid, 0, 2, 0, out);
+}
+
+// refinement residual folded into the next right-hand side -----------------------------------------
+__device__ __forceinline__ double res_step_elem(const BE &e, double rx, double acc, double diag,
+                                                double px, double pzl, double pzu, double dinv,
+                                                double beta_mu, int use_lower, int use_upper) {
+  double r = rx - diag * px + acc;
+  if (use_lower) r += pzl;
+  if (use_upper) r -= pzu;
+  double d1 = r;
+  if (e.L) {
+    const double rzl2 = -(e.xl * e.zl - beta_mu) - (e.xl * pzl + px * e.zl);
+    d1 += rzl2 / e.xl;
+  }
+  if (e.U) {
+    const double rzu2 = -(e.xu * e.zu - beta_mu) - (e.xu * pzu - px * e.zu);
+    d1 -= rzu2 / e.xu;
+  }
+  return dinv * d1;
+}
+__global__ void __launch_bounds__(kBlock)
+    res_step_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ px,
+                    const double *__restrict__ pzl, const double *__restrict__ pzu,
+                    const double *__restrict__ dinv, CoefTable coef, PtrTable P, int nv, double diag,
+                    double beta_mu, int64_t n, double *__restrict__ tp) {
+  PO_PAIR_LOOP(q, n) {
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll 8
+    for (int j = 0; j < nv; j++) {
+      const double2 v = ld2(P.p[j], q, n);
+      acc.x += coef.a[j] * v.x;
+      acc.y += coef.a[j] * v.y;
+    }
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n),
+                  dv = ld2(dinv, q, n);
+    st2(tp, q, n,
+        make_double2(res_step_elem(e0, r.x, acc.x, diag, p.x, l.x, u.x, dv.x, beta_mu, b.use_lower,
+                                   b.use_upper),
+                     res_step_elem(e1, r.y, acc.y, diag, p.y, l.y, u.y, dv.y, beta_mu, b.use_lower,
+                                   b.use_upper)));
+  }
+}
+int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
+               const double *pzu, const double *dinv, const double *coef, const double *const *P,
+               int nv, double diag, double beta_mu, int64_t n, double *tprime) {
+  if (n <= 0) return PO_OK;
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(coef, P, nv, &ct, &pt);
+  PO_LAUNCH(res_step_kernel, grid_for(c, n), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
+            tprime);
+  return PO_OK;
+}
+
+// complementarity at a trial step -------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    comp_step_kernel(Bounds b, const double *__restrict__ px, const double *__restrict__ pzl,
+                     const double *__restrict__ pzu, double ax, double az, int64_t n,
+                     double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double sums[2] = {0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    const double xn0 = _x.x + ax * p.x, xn1 = _x.y + ax * p.y;
+    if (e0.L) {
+      sums[0] += (_zl.x + az * l.x) * (xn0 - _lb.x);
+      sums[1] += 1.0;
+    }
+    if (e1.L) {
+      sums[0] += (_zl.y + az * l.y) * (xn1 - _lb.y);
+      sums[1] += 1.0;
+    }
+    if (e0.U) {
+      sums[0] += (_zu.x + az * u.x) * (_ub.x - xn0);
+      sums[1] += 1.0;
+    }
+    if (e1.U) {
+      sums[0] += (_zu.y + az * u.y) * (_ub.y - xn1);
+      sums[1] += 1.0;
+    }
+  }
+  block_reduce_store<2, OP_SUM>(sums, partials, 0, sm);
+}
+int k_comp_step(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
+                double ax, double az, int64_t n, double out[2]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PO_LAUNCH(comp_step_kernel, grid, b, px, pzl, pzu, ax, az, n, c->d_partials);
+  return reduce_finish(c, grid, 2, 0, 0, out);
+}
+
+// merit function pieces ---------------------------------------------------------------------------
+__device__ __forceinline__ void barrier_elem(const BE &e, double &pos, double &neg) {
+  if (e.L) {
+    const double v = log(e.xl);
+    if (e.xl > 1.0) pos += v; else neg += v;
+  }
+  if (e.U) {
+    const double v = log(e.xu);
+    if (e.xu > 1.0) pos += v; else neg += v;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    merit0_kernel(Bounds b, const double *__restrict__ px, double sx, const double *__restrict__ g,
+                  int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 6];
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    double2 p = ld2(px, q, n);
+    const double2 gv = ld2(g, q, n);
+    p.x *= sx;
+    p.y *= sx;
+    barrier_elem(e0, s[0], s[1]);
+    barrier_elem(e1, s[0], s[1]);
+    // directional derivative of the log terms, split by sign (:3692-3714)
+    if (e0.L) { if (p.x > 0.0) s[2] += p.x / e0.xl; else s[3] += p.x / e0.xl; }
+    if (e1.L) { if (p.y > 0.0) s[2] += p.y / e1.xl; else s[3] += p.y / e1.xl; }
+    if (e0.U) { if (p.x > 0.0) s[3] -= p.x / e0.xu; else s[2] -= p.x / e0.xu; }
+    if (e1.U) { if (p.y > 0.0) s[3] -= p.y / e1.xu; else s[2] -= p.y / e1.xu; }
+    s[4] += gv.x * p.x + gv.y * p.y;
+    s[5] += p.x * p.x + p.y * p.y;
+  }
+  block_reduce_store<6, OP_SUM>(s, partials, 0, sm);
+}
+int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double *g, int64_t n,
+             double out[6]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 6));
+  PO_LAUNCH(merit0_kernel, grid, b, px, sx, g, n, c->d_partials);
+  return reduce_finish(c, grid, 6, 0, 0, out);
+}
+
+__device__ __forceinline__ double clamp_elem(double v, bool has_l, double lb, bool has_u, double ub,
+                                             double eps) {
+  if (has_l && v <= lb + eps) v = lb + eps;
+  if (has_u && v + eps >= ub) v = ub - eps;
+  return v;
+}
+__global__ void __launch_bounds__(kBlock)
+    trial_kernel(Bounds b, const double *__restrict__ px, double a, double eps, int64_t n,
+                 double *__restrict__ xt, double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double s[2] = {0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 x = ld2(b.x, q, n), lb = ld2(b.lb, q, n), ub = ld2(b.ub, q, n), p = ld2(px, q, n);
+    const bool has2 = (2 * q + 1 < n);
+    // computeStep :3146-3191: the clamps use the bound vectors themselves (no predicate)
+    double2 v;
+    v.x = clamp_elem(x.x + a * p.x, true, lb.x, true, ub.x, eps);
+    v.y = clamp_elem(x.y + a * p.y, true, lb.y, true, ub.y, eps);
+    st2(xt, q, n, v);
+    BE e0 = bound_elem(v.x, lb.x, ub.x, 0.0, 0.0, b.max_bound, b.use_lower, b.use_upper);
+    barrier_elem(e0, s[0], s[1]);
+    if (has2) {
+      BE e1 = bound_elem(v.y, lb.y, ub.y, 0.0, 0.0, b.max_bound, b.use_lower, b.use_upper);
+      barrier_elem(e1, s[0], s[1]);
+    }
+  }
+  block_reduce_store<2, OP_SUM>(s, partials, 0, sm);
+}
+int k_trial(Ctx *c, const Bounds &b, const double *px, double a, double eps, int64_t n, double *xt,
+            double out[2]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PO_LAUNCH(trial_kernel, grid, b, px, a, eps, n, xt, c->d_partials);
+  return reduce_finish(c, grid, 2, 0, 0, out);
+}
+
+__global__ void __launch_bounds__(kBlock)
+    update_mult_kernel(double *__restrict__ zl, const double *__restrict__ pzl,
+                       double *__restrict__ zu, const double *__restrict__ pzu, double a, double eps,
+                       int use_lower, int use_upper, int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    if (use_lower) {
+      const double2 z = ld2(zl, q, n), p = ld2(pzl, q, n);
+      st2(zl, q, n,
+          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
+                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+    }
+    if (use_upper) {
+      const double2 z = ld2(zu, q, n), p = ld2(pzu, q, n);
+      st2(zu, q, n,
+          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
+                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+    }
+  }
+}
+int k_update_mult(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
+                  double eps, int use_lower, int use_upper, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(update_mult_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, n);
+  return PO_OK;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    affine_mult_kernel(Bounds b, double *__restrict__ zl, const double *__restrict__ pzl,
+                       double *__restrict__ zu, const double *__restrict__ pzu, double amin,
+                       int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    double2 nl = _zl, nu = _zu;
+    if (e0.L) nl.x = fmax(amin, fabs(_zl.x + l.x));
+    if (e1.L) nl.y = fmax(amin, fabs(_zl.y + l.y));
+    if (e0.U) nu.x = fmax(amin, fabs(_zu.x + u.x));
+    if (e1.U) nu.y = fmax(amin, fabs(_zu.y + u.y));
+    if (b.use_lower) st2(zl, q, n, nl);
+    if (b.use_upper) st2(zu, q, n, nu);
+  }
+}
+int k_affine_mult(Ctx *c, const Bounds &b, double *zl, const double *pzl, double *zu,
+                  const double *pzu, double amin, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(affine_mult_kernel, grid_for(c, n), b, zl, pzl, zu, pzu, amin, n);
+  return PO_OK;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    check_bounds_kernel(double *__restrict__ x, double *__restrict__ lb, double *__restrict__ ub,
+                        double *__restrict__ zl, double *__restrict__ zu, double maxb,
+                        double rel_bound, int both, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 3];
+  double flags[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    double xv = x[i], l = lb[i], u = ub[i];
+    if (both) {
+      double delta = 1.0;
+      if (l > -maxb && u < maxb) {
+        if (l >= u) {
+          flags[0] = 1.0;
+          l = 0.5 * (l + u) - 0.5 * rel_bound;
+          u = l + rel_bound;
+          lb[i] = l;
+          ub[i] = u;
+        }
+        delta = u - l;
+      }
+      if (l > -maxb && xv < l + rel_bound * delta) {
+        flags[1] = 1.0;
+        xv = l + rel_bound * delta;
+      }
+      if (u < maxb && xv > u - rel_bound * delta) {
+        flags[2] = 1.0;
+        xv = u - rel_bound * delta;
+      }
+      x[i] = xv;
+    }
+    if (l <= -maxb) zl[i] = 0.0;
+    if (u >= maxb) zu[i] = 0.0;
+  }
+  block_reduce_store<3, OP_MAX>(flags, partials, 0, sm);
+}
+int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double *zu,
+                   double max_bound, double rel_bound, int both, int64_t n, int *flag) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 3));
+  PO_LAUNCH(check_bounds_kernel, grid, x, lb, ub, zl, zu, max_bound, rel_bound, both, n,
+            c->d_partials);
+  double out[3];
+  PO_TRY(reduce_finish(c, grid, 0, 0, 3, out));
+  *flag = (out[0] > 0.0 ? 1 : 0) | (out[1] > 0.0 ? 2 : 0) | (out[2] > 0.0 ? 4 : 0);
+  return PO_OK;
+}
+
+__global__ void __launch_bounds__(kBlock)
+    zero_inactive_kernel(const double *__restrict__ lb, const double *__restrict__ ub,
+                         double *__restrict__ zl, double *__restrict__ zu, double maxb, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (lb[i] <= -maxb) zl[i] = 0.0;
+    if (ub[i] >= maxb) zu[i] = 0.0;
+  }
+}
+int k_zero_inactive(Ctx *c, const double *lb, const double *ub, double *zl, double *zu,
+                    double max_bound, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(zero_inactive_kernel, grid_for(c, n), lb, ub, zl, zu, max_bound, n);
+  return PO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// built-in problems (DESIGN.md "Workloads")
+// ---------------------------------------------------------------------------------------------
+template <int KIND>  // 0 quadratic, 1 convex
+__global__ void __launch_bounds__(kBlock)
+    sep_f_kernel(const double *__restrict__ qv, const double *__restrict__ bv,
+                 const double *__restrict__ x, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double acc[1] = {0.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 xv = ld2(x, q, n), b = ld2(bv, q, n);
+    const bool has2 = (2 * q + 1 < n);
+    if (KIND == 0) {
+      const double2 qq = ld2(qv, q, n);
+      acc[0] += 0.5 * qq.x * xv.x * xv.x + b.x * xv.x;
+      if (has2) acc[0] += 0.5 * qq.y * xv.y * xv.y + b.y * xv.y;
+    } else {
+      acc[0] += b.x * b.x / (1e-3 + xv.x);
+      if (has2) acc[0] += b.y * b.y / (1e-3 + xv.y);
+    }
+  }
+  block_reduce_store<1, OP_SUM>(acc, partials, 0, sm);
+}
+template <int KIND>
+__global__ void __launch_bounds__(kBlock)
+    sep_g_kernel(const double *__restrict__ qv, const double *__restrict__ bv,
+                 const double *__restrict__ x, int64_t n, double *__restrict__ g) {
+  PO_PAIR_LOOP(q, n) {
+    const double2 xv = ld2(x, q, n), b = ld2(bv, q, n);
+    double2 r;
+    if (KIND == 0) {
+      const double2 qq = ld2(qv, q, n);
+      r.x = qq.x * xv.x + b.x;
+      r.y = qq.y * xv.y + b.y;
+    } else {
+      const double d0 = 1e-3 + xv.x, d1 = 1e-3 + xv.y;
+      r.x = -(b.x * b.x) / (d0 * d0);
+      r.y = -(b.y * b.y) / (d1 * d1);
+    }
+    st2(g, q, n, r);
+  }
+}
+int k_quadratic_f(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *f) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid));
+  PO_LAUNCH(sep_f_kernel<0>, grid, q, b, x, n, c->d_partials);
+  return reduce_finish(c, grid, 1, 0, 0, f);
+}
+int k_convex_f(Ctx *c, const double *b, const double *x, int64_t n, double *f) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid));
+  PO_LAUNCH(sep_f_kernel<1>, grid, (const double *)nullptr, b, x, n, c->d_partials);
+  return reduce_finish(c, grid, 1, 0, 0, f);
+}
+int k_quadratic_g(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *g) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(sep_g_kernel<0>, grid_for(c, n), q, b, x, n, g);
+  return PO_OK;
+}
+int k_convex_g(Ctx *c, const double *b, const double *x, int64_t n, double *g) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(sep_g_kernel<1>, grid_for(c, n), (const double *)nullptr, b, x, n, g);
+  return PO_OK;
+}
+
+// rank-local chained Rosenbrock (examples/rosenbrock/rosenbrock.cpp:49-107)
+__global__ void __launch_bounds__(kBlock)
+    rosen_f_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 3];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double xi = x[i];
+    if (i + 1 < n) {
+      const double xn = x[i + 1];
+      s[0] += (1.0 - xi) * (1.0 - xi) + 100.0 * (xn - xi * xi) * (xn - xi * xi);
+    }
+    s[1] -= xi * xi;
+    if ((i & 1) == 0) s[2] += xi;
+  }
+  block_reduce_store<3, OP_SUM>(s, partials, 0, sm);
+}
+__global__ void __launch_bounds__(kBlock)
+    rosen_g_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ g,
+                   double *__restrict__ a0, double *__restrict__ a1) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double xi = x[i];
+    double gi = 0.0;
+    if (i + 1 < n) gi += -2.0 * (1.0 - xi) + 200.0 * (x[i + 1] - xi * xi) * (-2.0 * xi);
+    if (i > 0) gi += 200.0 * (xi - x[i - 1] * x[i - 1]);
+    g[i] = gi;
+    a0[i] = -2.0 * xi;
+    a1[i] = ((i & 1) == 0) ? 1.0 : 0.0;
+  }
+}
+int k_rosen_f(Ctx *c, const double *x, int64_t n, double out[3]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 3));
+  PO_LAUNCH(rosen_f_kernel, grid, x, n, c->d_partials);
+  return reduce_finish(c, grid, 3, 0, 0, out);
+}
+int k_rosen_g(Ctx *c, const double *x, int64_t n, double *g, double *a0, double *a1) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(rosen_g_kernel, grid_for(c, n), x, n, g, a0, a1);
+  return PO_OK;
+}
+
+}  // namespace po

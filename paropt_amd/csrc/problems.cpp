@@ -1,0 +1,159 @@
+// Problem implementations: the C-callback problem and the device-resident separable workloads.
+#include <math.h>
+
+#include "problem.hpp"
+
+namespace po {
+
+static void shard(int64_t n, int rank, int size, int64_t *nlocal, int64_t *offset) {
+  const int64_t base = n / size, rem = n % size;
+  *nlocal = base + (rank < rem ? 1 : 0);
+  *offset = rank * base + (rank < rem ? rank : rem);
+}
+
+// ---- callbacks --------------------------------------------------------------------------------
+int CallbackProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
+  if (!cb.get_vars_and_bounds) {
+    set_error("problem callbacks lack get_vars_and_bounds");
+    return PO_ERR_ARG;
+  }
+  int rc = cb.get_vars_and_bounds(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(lb),
+                                  static_cast<po_vec>(ub));
+  return rc;
+}
+int CallbackProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
+  return cb.eval_obj_con(cb.user, static_cast<po_vec>(x), fobj, cons);
+}
+int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
+  std::vector<po_vec> h(ncon > 0 ? ncon : 1);
+  for (int j = 0; j < ncon; j++) h[j] = static_cast<po_vec>(Ac[j]);
+  return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data());
+}
+int CallbackProblem::computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) {
+  if (!cb.qn_update_correction) return 0;
+  return cb.qn_update_correction(cb.user, static_cast<po_vec>(x), z, static_cast<po_vec>(s),
+                                 static_cast<po_vec>(y));
+}
+int CallbackProblem::writeOutput(int iter, Vec *x) {
+  if (!cb.write_output) return 0;
+  return cb.write_output(cb.user, iter, static_cast<po_vec>(x));
+}
+
+// ---- separable workloads ----------------------------------------------------------------------
+SeparableProblem::SeparableProblem(Ctx *c, int kind_, int64_t nglobal_, int ncon_, uint64_t seed_,
+                                   double eig_min_, double eig_max_)
+    : Problem(c, 0, kind_ == PO_PROBLEM_ROSENBROCK ? 2 : ncon_,
+              kind_ == PO_PROBLEM_ROSENBROCK ? 2 : ncon_),
+      kind(kind_), seed(seed_), eig_min(eig_min_), eig_max(eig_max_), q(nullptr), b(nullptr) {
+  nglobal = nglobal_;
+  shard(nglobal_, c->rank, c->size, &nlocal, &offset);
+}
+
+SeparableProblem::~SeparableProblem() {
+  vec_decref(q);
+  vec_decref(b);
+  for (Vec *v : A) vec_decref(v);
+}
+
+int SeparableProblem::init() {
+  const int64_t n = nlocal;
+  beta.assign(ncon, 0.0);
+  if (kind == PO_PROBLEM_ROSENBROCK) return PO_OK;
+  b = vec_new(ctx, n);
+  if (!b) return PO_ERR_HIP;
+  PO_TRY(k_fill_hash(ctx, b->d, n, seed, 2, offset, 1.0, 0.0));
+  if (kind == PO_PROBLEM_QUADRATIC) {
+    q = vec_new(ctx, n);
+    if (!q) return PO_ERR_HIP;
+    PO_TRY(k_fill_hash(ctx, q->d, n, seed, 1, offset, eig_max - eig_min, eig_min));
+  }
+  for (int j = 0; j < ncon; j++) {
+    Vec *a = vec_new(ctx, n);
+    if (!a) return PO_ERR_HIP;
+    PO_TRY(k_fill_hash(ctx, a->d, n, seed, 100 + j, offset, 1.0, 0.0));
+    A.push_back(a);
+  }
+  if (kind == PO_PROBLEM_QUADRATIC) {
+    // beta_j = u01(seed, 4, j): same hash on the host
+    for (int j = 0; j < ncon; j++) {
+      uint64_t z = seed * 0x9E3779B97F4A7C15ULL + 4 * 0xD1B54A32D192ED03ULL + (uint64_t)j;
+      z += 0x9E3779B97F4A7C15ULL;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+      z = z ^ (z >> 31);
+      beta[j] = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+  } else {
+    // beta_j = 0.25 * sum_i a_j[i]  (examples/random_convex/random_convex.py:110-111): the sums of
+    // all rows in one pass, as dot products with a vector of ones
+    Vec *ones = vec_new(ctx, n);
+    if (!ones) return PO_ERR_HIP;
+    PO_TRY(k_fill(ctx, ones->d, n, 1.0));
+    std::vector<const double *> ap;
+    for (Vec *v : A) ap.push_back(v->d);
+    if (ncon > 0) PO_TRY(k_mdot(ctx, ones->d, ap.data(), ncon, n, beta.data()));
+    for (int j = 0; j < ncon; j++) beta[j] *= 0.25;
+    vec_decref(ones);
+  }
+  return PO_OK;
+}
+
+int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
+  const int64_t n = nlocal;
+  if (kind == PO_PROBLEM_QUADRATIC) {
+    PO_TRY(k_fill_hash(ctx, x->d, n, seed, 3, offset, 1.0, -2.0));
+    PO_TRY(k_fill(ctx, lb->d, n, -5.0));
+    PO_TRY(k_fill(ctx, ub->d, n, 5.0));
+  } else if (kind == PO_PROBLEM_CONVEX) {
+    PO_TRY(k_fill_hash(ctx, x->d, n, seed, 3, offset, 0.9, 0.05));
+    PO_TRY(k_fill(ctx, lb->d, n, 0.0));
+    PO_TRY(k_fill(ctx, ub->d, n, 1.0));
+  } else {
+    PO_TRY(k_fill(ctx, x->d, n, -1.0));
+    PO_TRY(k_fill(ctx, lb->d, n, -2.0));
+    PO_TRY(k_fill(ctx, ub->d, n, 1.0));
+  }
+  return PO_OK;
+}
+
+int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
+  const int64_t n = nlocal;
+  if (kind == PO_PROBLEM_ROSENBROCK) {
+    double out[3];
+    PO_TRY(k_rosen_f(ctx, x->d, n, out));
+    *fobj = out[0];
+    cons[0] = out[1] + 0.25;
+    cons[1] = out[2] + 10.0;
+    return PO_OK;
+  }
+  if (kind == PO_PROBLEM_QUADRATIC) {
+    PO_TRY(k_quadratic_f(ctx, q->d, b->d, x->d, n, fobj));
+  } else {
+    PO_TRY(k_convex_f(ctx, b->d, x->d, n, fobj));
+  }
+  std::vector<const double *> ap;
+  for (Vec *v : A) ap.push_back(v->d);
+  if (ncon > 0) PO_TRY(k_mdot(ctx, x->d, ap.data(), ncon, n, cons));
+  for (int j = 0; j < ncon; j++) {
+    cons[j] = (kind == PO_PROBLEM_QUADRATIC) ? cons[j] + beta[j] : -cons[j] + beta[j];
+  }
+  return PO_OK;
+}
+
+int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
+  const int64_t n = nlocal;
+  if (kind == PO_PROBLEM_ROSENBROCK) {
+    return k_rosen_g(ctx, x->d, n, g->d, Ac[0]->d, Ac[1]->d);
+  }
+  if (kind == PO_PROBLEM_QUADRATIC) {
+    PO_TRY(k_quadratic_g(ctx, q->d, b->d, x->d, n, g->d));
+    for (int j = 0; j < ncon; j++) PO_TRY(k_copy(ctx, Ac[j]->d, A[j]->d, n));
+  } else {
+    PO_TRY(k_convex_g(ctx, b->d, x->d, n, g->d));
+    for (int j = 0; j < ncon; j++)
+      PO_TRY(k_panel_axpy(ctx, Ac[j]->d, -1.0, A[j]->d, 0.0, nullptr, nullptr, 0, n));
+  }
+  return PO_OK;
+}
+
+}  // namespace po

@@ -1,0 +1,84 @@
+// Compact limited-memory quasi-Newton approximations with the S/Y/Z panels resident in HBM.
+// Host-side mirror of ParOptCompactQuasiNewton / ParOptLBFGS / ParOptLSR1
+// (reference src/ParOptQuasiNewton.h:32-220): same method names, argument meaning and return
+// codes; the k x k matrices (B = S^T S, L, D, M and its LU factors) stay on the host, replicated
+// on every rank, exactly as in the reference.
+#pragma once
+#include <vector>
+
+#include "core.hpp"
+
+namespace po {
+
+Vec *vec_new(Ctx *c, int64_t n);
+void vec_decref(Vec *v);
+
+class CompactQuasiNewton {
+ public:
+  CompactQuasiNewton(Ctx *ctx, int64_t n, int msub_max, bool keep_z);
+  virtual ~CompactQuasiNewton();
+
+  void setInitDiagonalType(int t) { diag_type = t; }
+  virtual void reset();
+  // returns PO_* status; *rc = 0 normal, 1 damped, 2 skipped (src/ParOptQuasiNewton.cpp:162-334)
+  virtual int update(Vec *s, Vec *y, int *rc) = 0;
+  int mult(Vec *x, Vec *y);                    // y = B x
+  int multAdd(double alpha, Vec *x, Vec *y);   // y += alpha B x
+  // (b0, d0, M, Z) of B = b0 I - Z diag(d0) M^-1 diag(d0) Z^T; returns the size k
+  int getCompactMat(double *b0_, const double **d0_, const double **M_, Vec ***Z_);
+  virtual int getMaxLimitedMemorySize() = 0;
+
+  // rz <- diag(d0) M^-1 diag(d0) rz   (the host part of mult, :399-411)
+  void applyCompactInverse(double *rz) const;
+  int size() const { return (int)Z.size(); }
+  double diag() const { return b0; }
+  std::vector<const double *> zPointers() const;
+
+  Ctx *ctx;
+  int64_t n;
+
+ protected:
+  // append / rotate a pair and refresh B, D, L from dots already available on the host:
+  // sS[i] = s.S_i, sY[i] = s.Y_i for the pairs held BEFORE the update (old ordering)
+  int storePair(Vec *s, Vec *y, const double *sS, const double *sY, double sTs, double sTy);
+  void factorM();
+
+  int msub_max, msub;
+  double b0;
+  int diag_type;
+  std::vector<Vec *> S, Y;  // owned, in current (rotated) order
+  std::vector<Vec *> Zown;  // L-SR1 only: materialised Z_i = Y_i - b0 S_i
+  std::vector<Vec *> Z;     // borrowed: current compact panel
+  Vec *r;                   // scratch (damped update)
+  std::vector<double> D, L, B;  // msub_max, msub_max^2 (column-major, ld = msub_max)
+  std::vector<double> M, Mf, d0;
+  std::vector<int> piv;
+};
+
+class LBFGS : public CompactQuasiNewton {
+ public:
+  LBFGS(Ctx *ctx, int64_t n, int msub_max) : CompactQuasiNewton(ctx, n, msub_max, false) {
+    update_type = PO_BFGS_SKIP_NEGATIVE_CURVATURE;
+  }
+  void setBFGSUpdateType(int t) { update_type = t; }
+  int update(Vec *s, Vec *y, int *rc) override;
+  int getMaxLimitedMemorySize() override { return 2 * msub_max; }
+
+ private:
+  void computeMatUpdate();
+  int update_type;
+};
+
+class LSR1 : public CompactQuasiNewton {
+ public:
+  LSR1(Ctx *ctx, int64_t n, int msub_max) : CompactQuasiNewton(ctx, n, msub_max, true) {}
+  int update(Vec *s, Vec *y, int *rc) override;
+  int getMaxLimitedMemorySize() override { return msub_max; }
+};
+
+}  // namespace po
+
+struct po_qn_s {
+  po::CompactQuasiNewton *qn;
+  std::vector<po_vec> zhandles;
+};

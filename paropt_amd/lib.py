@@ -1,0 +1,162 @@
+"""
+ctypes binding of libparopt_amd.so (include/paropt_amd.h).
+
+There is NO fallback: if the shared library has not been built (``python -c 'import
+__graft_entry__ as g; g.build()'`` or ``make -C paropt_amd/csrc``) importing this module raises,
+and every call on a machine without a gfx950 device fails with PO_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libparopt_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "paropt_amd: %s is missing -- build it with `make -C paropt_amd/csrc` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+    )
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+po_ctx = C.c_void_p
+po_vec = C.c_void_p
+po_qn = C.c_void_p
+po_problem = C.c_void_p
+po_ip = C.c_void_p
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_i64_p = C.POINTER(C.c_int64)
+vec_p = C.POINTER(po_vec)
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, c_double_p, c_double_p, C.c_int, C.c_void_p)
+ITER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+GET_VARS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, po_vec)
+EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p)
+GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p)
+QNCORR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec)
+WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, po_vec)
+
+
+class ProblemCallbacks(C.Structure):
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("get_vars_and_bounds", GET_VARS_FN),
+        ("eval_obj_con", EVAL_FN),
+        ("eval_obj_con_gradient", GRAD_FN),
+        ("qn_update_correction", QNCORR_FN),
+        ("write_output", WRITE_FN),
+    ]
+
+
+# Every symbol include/paropt_amd.h declares, with its signature (restype is always int unless
+# stated).  tests/test_capi_symbols.py checks this table against the header and the .so.
+SIGNATURES = {
+    "po_last_error": (C.c_char_p, []),
+    "po_version": (C.c_char_p, []),
+    "po_ctx_create": (C.c_int, [C.c_int, C.POINTER(po_ctx)]),
+    "po_ctx_destroy": (C.c_int, [po_ctx]),
+    "po_ctx_synchronize": (C.c_int, [po_ctx]),
+    "po_ctx_rank": (C.c_int, [po_ctx, c_int_p, c_int_p]),
+    "po_ctx_stream": (C.c_void_p, [po_ctx]),
+    "po_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "po_ctx_comm_init_rccl": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_void_p]),
+    "po_ctx_comm_init_callback": (C.c_int, [po_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
+    "po_vec_create": (C.c_int, [po_ctx, C.c_int64, C.POINTER(po_vec)]),
+    "po_vec_incref": (C.c_int, [po_vec]),
+    "po_vec_decref": (C.c_int, [po_vec]),
+    "po_vec_size": (C.c_int, [po_vec, c_i64_p]),
+    "po_vec_set": (C.c_int, [po_vec, C.c_double]),
+    "po_vec_zero": (C.c_int, [po_vec]),
+    "po_vec_copy": (C.c_int, [po_vec, po_vec]),
+    "po_vec_scale": (C.c_int, [po_vec, C.c_double]),
+    "po_vec_axpy": (C.c_int, [po_vec, C.c_double, po_vec]),
+    "po_vec_dot": (C.c_int, [po_vec, po_vec, c_double_p]),
+    "po_vec_mdot": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
+    "po_vec_norm": (C.c_int, [po_vec, c_double_p]),
+    "po_vec_maxabs": (C.c_int, [po_vec, c_double_p]),
+    "po_vec_l1norm": (C.c_int, [po_vec, c_double_p]),
+    "po_vec_get_array": (C.c_int, [po_vec, C.POINTER(c_double_p)]),
+    "po_vec_sync_to_device": (C.c_int, [po_vec]),
+    "po_vec_sync_to_host": (C.c_int, [po_vec]),
+    "po_vec_get_device_array": (C.c_int, [po_vec, C.POINTER(c_double_p)]),
+    "po_vec_maxpy": (C.c_int, [po_vec, C.c_double, c_double_p, vec_p, C.c_int]),
+    "po_vec_fill_hash": (C.c_int, [po_vec, C.c_uint64, C.c_uint64, C.c_int64, C.c_double, C.c_double]),
+    "po_qn_create": (C.c_int, [po_ctx, C.c_int, C.c_int64, C.c_int, C.POINTER(po_qn)]),
+    "po_qn_destroy": (C.c_int, [po_qn]),
+    "po_qn_set_update_type": (C.c_int, [po_qn, C.c_int]),
+    "po_qn_set_diag_type": (C.c_int, [po_qn, C.c_int]),
+    "po_qn_reset": (C.c_int, [po_qn]),
+    "po_qn_update": (C.c_int, [po_qn, po_vec, po_vec, c_int_p]),
+    "po_qn_mult": (C.c_int, [po_qn, po_vec, po_vec]),
+    "po_qn_mult_add": (C.c_int, [po_qn, C.c_double, po_vec, po_vec]),
+    "po_qn_get_compact": (
+        C.c_int,
+        [po_qn, c_int_p, c_double_p, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(vec_p)],
+    ),
+    "po_qn_max_size": (C.c_int, [po_qn, c_int_p]),
+    "po_problem_create_callbacks": (
+        C.c_int,
+        [po_ctx, C.c_int64, C.c_int, C.c_int, C.POINTER(ProblemCallbacks), C.POINTER(po_problem)],
+    ),
+    "po_problem_create_separable": (
+        C.c_int,
+        [po_ctx, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_double, C.c_double, C.POINTER(po_problem)],
+    ),
+    "po_problem_destroy": (C.c_int, [po_problem]),
+    "po_problem_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p, c_int_p]),
+    "po_problem_eval_obj_con": (C.c_int, [po_problem, po_vec, c_double_p, c_double_p]),
+    "po_problem_eval_obj_con_gradient": (C.c_int, [po_problem, po_vec, po_vec, vec_p]),
+    "po_problem_get_vars_and_bounds": (C.c_int, [po_problem, po_vec, po_vec, po_vec]),
+    "po_ip_create": (C.c_int, [po_problem, C.POINTER(po_ip)]),
+    "po_ip_destroy": (C.c_int, [po_ip]),
+    "po_ip_set_option_str": (C.c_int, [po_ip, C.c_char_p, C.c_char_p]),
+    "po_ip_set_option_int": (C.c_int, [po_ip, C.c_char_p, C.c_int]),
+    "po_ip_set_option_float": (C.c_int, [po_ip, C.c_char_p, C.c_double]),
+    "po_ip_optimize": (C.c_int, [po_ip, C.c_char_p]),
+    "po_ip_get_optimized_point": (
+        C.c_int,
+        [po_ip, C.POINTER(po_vec), C.POINTER(c_double_p), C.POINTER(po_vec), C.POINTER(po_vec)],
+    ),
+    "po_ip_get_optimized_slacks": (
+        C.c_int,
+        [po_ip, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p)],
+    ),
+    "po_ip_get_counters": (C.c_int, [po_ip, c_int_p, c_int_p, c_int_p]),
+    "po_ip_get_barrier_parameter": (C.c_int, [po_ip, c_double_p]),
+    "po_ip_get_complementarity": (C.c_int, [po_ip, c_double_p]),
+    "po_ip_get_objective": (C.c_int, [po_ip, c_double_p, c_double_p]),
+    "po_ip_set_penalty_gamma": (C.c_int, [po_ip, C.c_double]),
+    "po_ip_reset_design_and_bounds": (C.c_int, [po_ip]),
+    "po_ip_reset_quasi_newton": (C.c_int, [po_ip]),
+    "po_ip_get_quasi_newton": (C.c_int, [po_ip, C.POINTER(po_qn)]),
+    "po_ip_write_solution_file": (C.c_int, [po_ip, C.c_char_p]),
+    "po_ip_set_iteration_callback": (C.c_int, [po_ip, ITER_FN, C.c_void_p]),
+    "po_ip_get_history": (C.c_int, [po_ip, C.POINTER(C.c_char_p)]),
+    "po_ip_get_phase_times": (C.c_int, [po_ip, C.POINTER(C.c_char_p), C.POINTER(c_double_p), c_int_p]),
+    "po_ip_debug_kkt_step": (
+        C.c_int,
+        [po_ip, C.c_double, C.POINTER(po_vec), C.POINTER(po_vec), C.POINTER(po_vec)]
+        + [C.POINTER(c_double_p)] * 5,
+    ),
+    "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
+    "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
+    "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == the .so does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class ParOptAMDError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("paropt_amd error %d: %s" % (code, text))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,212 @@
+"""
+GPU parity of the interior-point path (through the C ABI).
+
+  * against the golden trajectories of the compiled reference (tests/golden/ip_*.npz):
+    integer bookkeeping (iteration / evaluation counters, quasi-Newton size, info tokens)
+    bit-exact over the compared window; mu, fobj, vector norms to 1e-6 relative; dense multipliers
+    to 1e-5 (the iteration is nonlinear, the product re-associates every reduction and fuses
+    the Schur complements: DESIGN.md "Parity");
+  * against the numpy oracle on larger hash-seeded instances where no golden exists;
+  * single KKT step against the reference's private-method dump (1e-5 of the step's max).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, ip_options_from_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paropt_amd as pa
+
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def info_tokens(text):
+    toks = {}
+    for ln in str(text).splitlines():
+        parts = ln.split()
+        if len(parts) >= 15 and parts[0].isdigit():
+            toks[int(parts[0])] = parts[15:]
+    return toks
+
+
+def run_gpu(ctx, case, want_vectors=False):
+    import paropt_amd as pa
+
+    a = case["args"]
+    prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), a.get("seed", 0),
+                               a.get("eig_min", 1.0), a.get("eig_max", 100.0))
+    opts = ip_options_from_case(case)
+    opts["write_output_frequency"] = 0
+    ip = pa.InteriorPoint(prob, opts)
+    snaps = []
+
+    def cb(k):
+        s = ip.snapshot()
+        if want_vectors:
+            x, z, zl, zu = ip.getOptimizedPoint()
+            s["x"], s["zl"], s["zu"] = x.to_numpy(), zl.to_numpy(), zu.to_numpy()
+        snaps.append(s)
+
+    ip.setIterationCallback(cb)
+    ip.optimize()
+    return ip, snaps
+
+
+IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2")]
+
+
+@pytest.mark.parametrize("name", IP_CASES)
+def test_ip_trajectory_golden(ctx, name):
+    g, case = load_golden(name)
+    ip, snaps = run_gpu(ctx, case, want_vectors=True)
+    nref = 1 + max(int(k[2:5]) for k in g if k.startswith("it") and k.endswith("/mu"))
+    window = 8 if "sr1" in name else 25
+    ncmp = min(window, nref, len(snaps))
+    assert ncmp >= min(window, nref)
+    for k in range(ncmp):
+        p = "it%03d/" % k
+        s = snaps[k]
+        np.testing.assert_array_equal(s["counters"], g[p + "counters"], err_msg="counters @%d" % k)
+        assert s.get("qn_size", 0) == int(g[p + "qn_size"][0]), "qn size @%d" % k
+        rt = 1e-6
+        assert abs(s["mu"] - g[p + "mu"][0]) <= rt * abs(g[p + "mu"][0]), "mu @%d" % k
+        assert abs(s["fobj"] - g[p + "fobj"][0]) <= rt * max(1.0, abs(g[p + "fobj"][0])), "fobj @%d" % k
+        np.testing.assert_allclose(s["norms"], g[p + "norms"], rtol=rt, err_msg="norms @%d" % k)
+        for key in ("z", "s", "t", "zs", "zt"):
+            ref = g[p + key]
+            np.testing.assert_allclose(s[key], ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()),
+                                       err_msg="%s @%d" % (key, k))
+        if p + "x" in g:
+            for key in ("x", "zl", "zu"):
+                ref = g[p + key]
+                np.testing.assert_allclose(s[key], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                           err_msg="%s @%d" % (key, k))
+    toks = info_tokens(g["paropt_out"])
+    mine = info_tokens(ip.getHistory())
+    for k in range(1, ncmp):
+        assert mine.get(k, []) == toks.get(k, []), "info tokens @%d: %s vs %s" % (k, mine.get(k), toks.get(k))
+    if "sr1" not in name:
+        np.testing.assert_array_equal(np.array(ip.getIterationCounters()), g["final/counters"])
+        assert abs(ip.getObjective()[0] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+
+
+KAT_CASES = ["ip_quadratic_n257_c3_bfgs", "ip_quadratic_n1000_c8_bfgs20", "ip_convex_n300_c5_bfgs",
+             "ip_convex_n300_c5_sr1"]
+
+
+@pytest.mark.parametrize("name", KAT_CASES)
+def test_ip_single_step_kat(ctx, name):
+    """computeKKTRes + setUpKKTDiagSystem + setUpKKTSystem + computeKKTStep of the reference
+    (private methods) at iteration kat_iter vs the fused device step from the same state."""
+    import paropt_amd as pa
+
+    g, case = load_golden(name)
+    a = case["args"]
+    kat = a["kat_iter"]
+    prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), 0, a.get("eig_min", 1.0),
+                               a.get("eig_max", 100.0))
+    opts = ip_options_from_case(case)
+    opts["write_output_frequency"] = 0
+    ip = pa.InteriorPoint(prob, opts)
+    out = {}
+
+    def cb(k):
+        if k == kat:
+            out["x"] = ip.getOptimizedPoint()[0].to_numpy()
+            out.update({"step_" + key: v for key, v in ip.debugKKTStep(ip.getBarrierParameter()).items()})
+            out["comp"] = ip.getComplementarity()
+
+    ip.setIterationCallback(cb)
+    ip.optimize()
+    assert "step_x" in out
+    np.testing.assert_allclose(out["x"], g["kat/x"], rtol=0, atol=1e-7)
+    for key in ("x", "zl", "zu", "z", "s", "t", "zs", "zt"):
+        ref = g["kat/step_" + key]
+        np.testing.assert_allclose(out["step_" + key], ref, rtol=0,
+                                   atol=2e-5 * max(1e-3, np.abs(ref).max()), err_msg=key)
+    assert abs(out["comp"] - g["kat/comp"][0]) <= 1e-6 * abs(g["kat/comp"][0])
+
+
+@pytest.mark.parametrize("problem,n,c,qn,m", [
+    ("quadratic", 100003, 8, "bfgs", 20),   # config 2 shape (c=8, L-BFGS(20)), odd n
+    ("convex", 65536, 32, "bfgs", 10),      # config 3 shape with the convergent L-BFGS variant
+    ("convex", 50001, 32, "sr1", 10),       # config 3 proper (L-SR1): short window
+])
+def test_ip_vs_oracle_large(ctx, problem, n, c, qn, m):
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    opts = {"qn_subspace_size": m, "qn_type": qn, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 12 if qn == "sr1" else 30}
+    oip = po.InteriorPoint(po.SepProblem(problem, n, c), opts)
+    osn = []
+    oip.hook = lambda s, k: osn.append(s.snapshot())
+    oip.optimize()
+    gopts = dict(opts, write_output_frequency=0)
+    ip = pa.InteriorPoint(pa.SeparableProblem(ctx, problem, n, c), gopts)
+    gsn = []
+    ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
+    ip.optimize()
+    ncmp = min(len(osn), len(gsn), 8 if qn == "sr1" else 30)
+    assert ncmp >= (8 if qn == "sr1" else 12)
+    for k in range(ncmp):
+        np.testing.assert_array_equal(gsn[k]["counters"], osn[k]["counters"], err_msg="counters @%d" % k)
+        assert gsn[k]["qn_size"] == osn[k]["qn_size"]
+        assert abs(gsn[k]["mu"] - osn[k]["mu"]) <= 1e-6 * abs(osn[k]["mu"])
+        assert abs(gsn[k]["fobj"] - osn[k]["fobj"]) <= 1e-6 * max(1.0, abs(osn[k]["fobj"]))
+        np.testing.assert_allclose(gsn[k]["norms"], osn[k]["norms"], rtol=1e-6)
+    assert [t["info"].split() for t in oip.trace[1:ncmp]] == [
+        info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)]
+
+
+def test_python_callback_problem(ctx):
+    """The drop-in boundary for user problems: a Python-implemented problem (host arrays via
+    getArray, as the reference's examples do) driven by the device solver -- the 2-constraint
+    Rosenbrock of examples/rosenbrock/rosenbrock.cpp, compared with the built-in device problem."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    n = 100
+    oracle_prob = po.SepProblem("rosenbrock", n, 2)
+
+    class Rosen(pa.Problem):
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = -1.0, -2.0, 1.0
+
+        def evalObjCon(self, x):
+            return oracle_prob.eval_obj_con(x)
+
+        def evalObjConGradient(self, x, g, A):
+            _, gg, aa = oracle_prob.eval_obj_con_gradient(x)
+            g[:] = gg
+            A[0][:], A[1][:] = aa[0], aa[1]
+            return 0
+
+    opts = {"qn_subspace_size": 10, "abs_res_tol": 1e-6, "max_major_iters": 120, "write_output_frequency": 0}
+    ip1 = pa.InteriorPoint(Rosen(ctx, n, 2), opts)
+    ip1.optimize()
+    ip2 = pa.InteriorPoint(pa.SeparableProblem(ctx, "rosenbrock", n), opts)
+    ip2.optimize()
+    assert ip1.getIterationCounters() == ip2.getIterationCounters()
+    np.testing.assert_allclose(ip1.getOptimizedPoint()[0].to_numpy(), ip2.getOptimizedPoint()[0].to_numpy(),
+                               rtol=0, atol=1e-9)
+    g, _ = load_golden("ip_rosenbrock_n100")
+    np.testing.assert_array_equal(np.array(ip1.getIterationCounters()), g["final/counters"])
+
+
+def test_option_errors(ctx):
+    import paropt_amd as pa
+
+    ip = pa.InteriorPoint(pa.SeparableProblem(ctx, "quadratic", 100, 2))
+    with pytest.raises(pa.ParOptAMDError):
+        ip.setOption("no_such_option", 1)
+    with pytest.raises(pa.ParOptAMDError):
+        ip.setOption("qn_type", "nonsense")
+    with pytest.raises(pa.ParOptAMDError):
+        ip.setOption("max_line_iters", 1000)  # out of range [1, 100]

@@ -1,0 +1,145 @@
+"""
+GPU parity of the vector kernels (through the C ABI) against the golden vectors of the compiled
+reference and against the numpy oracle on the same hash-seeded inputs.
+
+Tolerance: fp64 reductions re-associate (two-stage tree vs BLAS order), bound
+|err| <= 4 * eps * sqrt(n) * sum|terms|, written below as 1e-13 * n relative to O(1) data;
+element-wise results (axpy/scale/copy/fill) are bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paropt_amd as pa
+
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def hvec(ctx, n, aid, seed=0, scale=2.0, shift=-1.0, offset=0):
+    import paropt_amd as pa
+
+    return pa.PVec(ctx, n).fill_hash(seed, aid, offset, scale, shift)
+
+
+def hnp(n, aid, seed=0, scale=2.0, shift=-1.0, offset=0):
+    from oracle import paropt_oracle as po
+
+    return shift + scale * po.u01(seed, aid, np.arange(offset, offset + n, dtype=np.uint64))
+
+
+def test_hash_fill_bit_exact(ctx):
+    for n in (1, 2, 63, 1000, 4097):
+        v = hvec(ctx, n, 10, seed=3, offset=12345)
+        np.testing.assert_array_equal(v.to_numpy(), hnp(n, 10, seed=3, offset=12345))
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("vecops_") if "_r" not in n])
+def test_vecops_golden(ctx, name):
+    g, case = load_golden(name)
+    n, nv = int(g["n"][0]), int(g["nvecs"][0])
+    x, y = hvec(ctx, n, 10), hvec(ctx, n, 11)
+    V = [hvec(ctx, n, 20 + j) for j in range(nv)]
+    tol = 1e-13 * n
+    assert abs(x.dot(y) - g["dot"][0]) <= tol
+    assert abs(x.norm() - g["norm"][0]) <= tol
+    assert x.maxabs() == g["maxabs"][0]
+    assert abs(x.l1norm() - g["l1norm"][0]) <= tol
+    np.testing.assert_allclose(x.mdot(V), g["mdot"], rtol=0, atol=tol)
+    y.scale(0.75)
+    y.axpy(-1.25, x)
+    assert abs(y.norm() - g["post_norm"][0]) <= tol
+    assert abs(y.l1norm() - g["post_l1"][0]) <= tol
+    assert abs(y.dot(x) - g["post_dot"][0]) <= tol
+    if "post_y" in g:
+        np.testing.assert_allclose(y.to_numpy(), g["post_y"], rtol=1e-15, atol=1e-15)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 511, 513, 100003, (1 << 20) + 3])
+@pytest.mark.parametrize("nv", [1, 4, 5, 8, 9, 16, 17, 32, 33, 40, 72])
+def test_mdot_vs_oracle(ctx, n, nv):
+    if n > 200000 and nv not in (1, 33, 72):
+        pytest.skip("large n covered for a subset of widths")
+    x = hvec(ctx, n, 10)
+    V = [hvec(ctx, n, 20 + j) for j in range(nv)]
+    xn = hnp(n, 10)
+    ref = np.array([np.dot(xn, hnp(n, 20 + j)) for j in range(nv)])
+    np.testing.assert_allclose(x.mdot(V), ref, rtol=0, atol=1e-13 * max(n, 16))
+
+
+def test_elementwise_bit_exact(ctx):
+    import paropt_amd as pa
+
+    for n in (1, 7, 1000, 4097):
+        x, y = hvec(ctx, n, 10), hvec(ctx, n, 11)
+        xn, yn = hnp(n, 10), hnp(n, 11)
+        z = pa.PVec(ctx, n)
+        np.testing.assert_array_equal(z.to_numpy(), np.zeros(n))  # zero-initialised like ParOptBasicVec
+        z.copyValues(x)
+        np.testing.assert_array_equal(z.to_numpy(), xn)
+        z.set(0.5)
+        np.testing.assert_array_equal(z.to_numpy(), np.full(n, 0.5))
+        z.zeroEntries()
+        np.testing.assert_array_equal(z.to_numpy(), np.zeros(n))
+        y.axpy(-1.25, x)
+        # fma contraction on the device: one rounding instead of two
+        np.testing.assert_allclose(y.to_numpy(), yn + (-1.25) * xn, rtol=0, atol=2e-16 * 3)
+        V = [hvec(ctx, n, 20 + j) for j in range(5)]
+        al = np.array([0.3, -1.5, 2.0, 0.0, 1e-3])
+        z.copyValues(x)
+        z.maxpy(0.5, al, V)
+        ref = 0.5 * xn + sum(al[j] * hnp(n, 20 + j) for j in range(5))
+        np.testing.assert_allclose(z.to_numpy(), ref, rtol=0, atol=1e-15 * 8)
+
+
+def test_get_array_roundtrip(ctx):
+    import paropt_amd as pa
+
+    v = pa.PVec(ctx, 1001)
+    a = v.getArray()
+    a[:] = np.arange(1001.0)
+    v.syncToDevice()
+    assert v.l1norm() == 1000 * 1001 / 2
+    v.scale(2.0)
+    np.testing.assert_array_equal(v.to_numpy(), 2.0 * np.arange(1001.0))
+
+
+def test_empty_vector(ctx):
+    """Rank-local size 0 is legal in the reference (getArray may return NULL, src/ParOptVec.cpp:212)."""
+    import paropt_amd as pa
+
+    v, w = pa.PVec(ctx, 0), pa.PVec(ctx, 0)
+    assert v.dot(w) == 0.0 and v.norm() == 0.0 and v.maxabs() == 0.0 and v.l1norm() == 0.0
+    np.testing.assert_array_equal(v.mdot([w, w]), np.zeros(2))
+
+
+def test_size_mismatch_is_an_error(ctx):
+    import paropt_amd as pa
+
+    with pytest.raises(pa.ParOptAMDError):
+        pa.PVec(ctx, 10).dot(pa.PVec(ctx, 11))
+
+
+@pytest.mark.parametrize("n", [1, 5, 127, 128, 129, 1000, 70001])
+@pytest.mark.parametrize("nv", [1, 5, 16, 17, 32, 42, 48, 49, 72, 80])
+def test_wgram_vs_numpy(ctx, n, nv):
+    """W = P^T diag(d) P on the fp64 MFMA path; asymmetric data catches row/col swaps."""
+    import paropt_amd as pa
+
+    if n > 10000 and nv not in (5, 42, 80):
+        pytest.skip("large n covered for a subset of widths")
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)]
+    dn = hnp(n, 9, scale=1.0, shift=0.5)
+    P = np.stack([hnp(n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)], axis=1)
+    ref = P.T @ (dn[:, None] * P)
+    W = pa.wgram(d, V)
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
+    np.testing.assert_array_equal(W, W.T)
