@@ -71,6 +71,8 @@ class Context:
         check(lib.po_ctx_comm_init_callback(self._h, rank, size, cb, None))
 
     def close(self):
+        """Destroy the context.  Objects created from it must not be used afterwards (their
+        destructors become no-ops: the device memory went with the context's process)."""
         if self._h:
             lib.po_ctx_destroy(self._h)
             self._h = None
@@ -101,7 +103,7 @@ class PVec:
 
     def __del__(self):
         try:
-            if self._owned and self._h:
+            if self._owned and self._h and self.ctx._h:
                 lib.po_vec_decref(self._h)
         except Exception:
             pass
@@ -205,7 +207,7 @@ class _QuasiNewton:
 
     def __del__(self):
         try:
-            if self._owned and self._h:
+            if self._owned and self._h and self.ctx._h:
                 lib.po_qn_destroy(self._h)
         except Exception:
             pass
@@ -329,7 +331,7 @@ class SeparableProblem:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and self.ctx._h:
                 lib.po_problem_destroy(self._h)
         except Exception:
             pass
@@ -349,7 +351,7 @@ class InteriorPoint:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and self.ctx._h:
                 lib.po_ip_destroy(self._h)
         except Exception:
             pass

@@ -24,19 +24,20 @@ namespace po {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < _npairs;            \
        q += (int64_t)gridDim.x * blockDim.x)
 
+// Every device vector is allocated with an even number of (zero-initialised) elements plus slack
+// (qn.cpp::vec_new), so the last pair of an odd-length vector can be loaded and stored as a full
+// 16-byte access without a branch; the pad element is kept at exactly 0.0 by st2.
 __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t q, int64_t n) {
-  const int64_t i = 2 * q;
-  if (i + 1 < n) return *reinterpret_cast<const double2 *>(p + i);
-  return make_double2(p[i], 0.0);
+  return *reinterpret_cast<const double2 *>(p + 2 * q);
 }
 __device__ __forceinline__ void st2(double *__restrict__ p, int64_t q, int64_t n, double2 v) {
-  const int64_t i = 2 * q;
-  if (i + 1 < n) {
-    *reinterpret_cast<double2 *>(p + i) = v;
-  } else {
-    p[i] = v.x;
-  }
+  if (2 * q + 1 >= n) v.y = 0.0;
+  *reinterpret_cast<double2 *>(p + 2 * q) = v;
 }
+
+// native vector types: register arrays of HIP's double2 class get demoted to scratch across barriers
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
 
@@ -196,6 +197,39 @@ int k_axpy(Ctx *c, double *y, double a, const double *x, int64_t n) {
   return PO_OK;
 }
 
+
+// sum_j coef_j P_j at pair q, streamed in register batches of 8 / 4 / 2 / 1 columns: the loads of a
+// batch are issued back to back before its FMAs (see mdot_kernel for why).
+template <int B>
+__device__ __forceinline__ void panel_batch(const PtrTable &P, const CoefTable &a, int j, int64_t q,
+                                            f64x2 &acc) {
+  f64x2 v[B];
+#pragma unroll
+  for (int u = 0; u < B; u++) v[u] = *reinterpret_cast<const f64x2 *>(P.p[j + u] + 2 * q);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < B; u++) {
+    acc.x += a.a[j + u] * v[u].x;
+    acc.y += a.a[j + u] * v[u].y;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ double2 panel_sum(const PtrTable &P, const CoefTable &a, int nv, int64_t q) {
+  f64x2 acc = (f64x2){0.0, 0.0};
+  int j = 0;
+  for (; j + 8 <= nv; j += 8) panel_batch<8>(P, a, j, q, acc);
+  if (j + 4 <= nv) {
+    panel_batch<4>(P, a, j, q, acc);
+    j += 4;
+  }
+  if (j + 2 <= nv) {
+    panel_batch<2>(P, a, j, q, acc);
+    j += 2;
+  }
+  if (j < nv) panel_batch<1>(P, a, j, q, acc);
+  return make_double2(acc.x, acc.y);
+}
+
 // y <- a*x + b*y + sum_j alpha_j V_j : runtime panel width, no per-column registers needed.
 __global__ void __launch_bounds__(kBlock)
     panel_axpy_kernel(double *__restrict__ y, double a, const double *__restrict__ x, double b,
@@ -212,12 +246,9 @@ __global__ void __launch_bounds__(kBlock)
       acc.x += b * v.x;
       acc.y += b * v.y;
     }
-#pragma unroll 8
-    for (int j = 0; j < nv; j++) {
-      double2 v = ld2(V.p[j], q, n);
-      acc.x += alpha.a[j] * v.x;
-      acc.y += alpha.a[j] * v.y;
-    }
+    const double2 ps = panel_sum(V, alpha, nv, q);
+    acc.x += ps.x;
+    acc.y += ps.y;
     st2(y, q, n, acc);
   }
 }
@@ -299,24 +330,53 @@ int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, dou
 // ---------------------------------------------------------------------------------------------
 template <int NVB>
 __global__ void __launch_bounds__(kBlock)
-    mdot_kernel(const double *__restrict__ x, PtrTable V, int j0, int nv, int64_t n,
+    mdot_kernel(const double *__restrict__ x, PtrTable V, int j0, int64_t n,
                 double *__restrict__ partials) {
+  // The panel block is streamed in batches of up to 8 columns, double-buffered in registers:
+  // the 8 loads of batch b+1 are issued before the FMAs of batch b (hipcc otherwise serialises
+  // load -> wait -> fma per column to minimise registers, which starves the memory system).
+  constexpr int B = NVB >= 8 ? 8 : NVB;
+  constexpr int NB = (NVB + B - 1) / B;
   __shared__ double sm[4 * NVB];
   double acc[NVB];
+  const double *vp[NVB];
 #pragma unroll
-  for (int j = 0; j < NVB; j++) acc[j] = 0.0;
+  for (int j = 0; j < NVB; j++) {
+    acc[j] = 0.0;
+    vp[j] = V.p[j0 + j];
+  }
   PO_PAIR_LOOP(q, n) {
-    const double2 xv = ld2(x, q, n);
+    const f64x2 xv = *reinterpret_cast<const f64x2 *>(x + 2 * q);
+    f64x2 v[2][B];
 #pragma unroll
-    for (int j = 0; j < NVB; j++) {
-      if (j < nv) {
-        const double2 v = ld2(V.p[j0 + j], q, n);
-        acc[j] = fma(xv.x, v.x, fma(xv.y, v.y, acc[j]));
+    for (int j = 0; j < B; j++) v[0][j] = *reinterpret_cast<const f64x2 *>(vp[j] + 2 * q);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int j = 0; j < B; j++) {
+          if ((b + 1) * B + j < NVB)
+            v[(b + 1) & 1][j] = *reinterpret_cast<const f64x2 *>(vp[(b + 1) * B + j] + 2 * q);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < B; j++) {
+        if (b * B + j < NVB) {
+          const f64x2 w = v[b & 1][j];
+          acc[b * B + j] = fma(xv.x, w.x, fma(xv.y, w.y, acc[b * B + j]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   block_reduce_store<NVB, OP_SUM>(acc, partials, j0, sm);
 }
+
+#define PO_MDOT_CASE(NVB)                                                          \
+  case NVB:                                                                        \
+    PO_LAUNCH(mdot_kernel<NVB>, grid, x, pt, j0, n, c->d_partials);                \
+    break;
 
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks) {
   if (nv > kMaxPanel) {
@@ -324,31 +384,23 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
     return PO_ERR_ARG;
   }
   const int grid = grid_for(c, n);
-  // every group writes NVB slots, so reserve for the padded width
   PO_TRY(ensure_partials(c, (size_t)grid * (nv + 32)));
   PtrTable pt;
   CoefTable ct;
   fill_tables(nullptr, V, nv, &ct, &pt);
-  // padded columns must still be valid pointers for nothing: they are never dereferenced
+  // panel blocks of 32 / 24 / 16 columns, then one exact block of 1..15: x is re-read once per
+  // block (nv = 42 -> 32 + 10: 44 streams instead of the ideal 43)
   int j0 = 0;
   while (j0 < nv) {
     const int rem = nv - j0;
-    if (rem >= 32) {
-      PO_LAUNCH(mdot_kernel<32>, grid, x, pt, j0, 32, n, c->d_partials);
-      j0 += 32;
-    } else if (rem > 16) {
-      PO_LAUNCH(mdot_kernel<32>, grid, x, pt, j0, rem, n, c->d_partials);
-      j0 += rem;
-    } else if (rem > 8) {
-      PO_LAUNCH(mdot_kernel<16>, grid, x, pt, j0, rem, n, c->d_partials);
-      j0 += rem;
-    } else if (rem > 4) {
-      PO_LAUNCH(mdot_kernel<8>, grid, x, pt, j0, rem, n, c->d_partials);
-      j0 += rem;
-    } else {
-      PO_LAUNCH(mdot_kernel<4>, grid, x, pt, j0, rem, n, c->d_partials);
-      j0 += rem;
+    const int w = rem >= 32 ? 32 : (rem >= 24 ? 24 : (rem >= 16 ? 16 : rem));
+    switch (w) {
+      PO_MDOT_CASE(1) PO_MDOT_CASE(2) PO_MDOT_CASE(3) PO_MDOT_CASE(4) PO_MDOT_CASE(5)
+      PO_MDOT_CASE(6) PO_MDOT_CASE(7) PO_MDOT_CASE(8) PO_MDOT_CASE(9) PO_MDOT_CASE(10)
+      PO_MDOT_CASE(11) PO_MDOT_CASE(12) PO_MDOT_CASE(13) PO_MDOT_CASE(14) PO_MDOT_CASE(15)
+      PO_MDOT_CASE(16) PO_MDOT_CASE(24) PO_MDOT_CASE(32)
     }
+    j0 += w;
   }
   *nblocks = grid;
   return PO_OK;
@@ -375,7 +427,6 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
 // v_mfma_f64_16x16x4_f64:  A fragment = P[16r + (lane&15)][row0 + (lane>>4)],
 //                          B fragment = d[row] * P[16s + (lane&15)][row]          (r <= s).
 // ---------------------------------------------------------------------------------------------
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kGramTile = 128;            // rows per LDS tile
 constexpr int kGramLd = kGramTile + 2;    // LDS row stride in doubles (== 2 mod 32)
 
@@ -385,6 +436,7 @@ __global__ void __launch_bounds__(kBlock)
                  double *__restrict__ partials) {
   constexpr int M = 16 * MB;
   constexpr int NBLK = MB * (MB + 1) / 2;
+  constexpr int NPASS = 4 * MB;  // staging passes: 4 columns (one per wave) per pass
   extern __shared__ double lds[];  // [M][kGramLd] panel tile, then [kGramTile] weights
   double *pt = lds;
   double *dw = lds + M * kGramLd;
@@ -397,33 +449,44 @@ __global__ void __launch_bounds__(kBlock)
   // zero the padded columns once (they are never written by the staging loop)
   for (int idx = tid; idx < (M - nv) * kGramLd; idx += kBlock) pt[nv * kGramLd + idx] = 0.0;
 
-  const int col_in_pass = tid >> 6;        // 4 columns per staging pass, 64 lanes per column
-  const int pair = tid & 63;               // 64 lanes * 2 doubles = 128 rows
+  // wave w stages columns w, w+4, ...; lane l holds rows 2l, 2l+1 of the 128-row tile.
+  // Columns beyond nv re-read the last column (never written to LDS), so that the loads carry
+  // no branch and are all issued before the first wait.
+  const double *colp[NPASS];
+#pragma unroll
+  for (int it = 0; it < NPASS; it++) {
+    const int j = wave + 4 * it;
+    colp[it] = V.p[j < nv ? j : nv - 1];
+  }
+  const int64_t ilast = ((n - 1) >> 1) << 1;
+  // Software pipeline: the global loads of the NEXT tile are issued (all of them, back to back)
+  // before the current tile is multiplied, and are only waited for at the next LDS store.  Rows
+  // past n are read from the zero pad when they fall in the last pair and clamped to the last
+  // in-range pair otherwise; their weight is forced to zero, so they contribute nothing.
+  f64x2 buf[NPASS];
+  f64x2 dbuf = (f64x2){0.0, 0.0};
+#define PO_GRAM_PREFETCH(TILE)                                                             \
+  {                                                                                        \
+    int64_t _i = (TILE) * kGramTile + 2 * lane;                                            \
+    const bool _in = (_i < n);                                                             \
+    if (!_in) _i = ilast;                                                                  \
+    _Pragma("unroll") for (int it = 0; it < NPASS; it++) buf[it] =                         \
+        *reinterpret_cast<const f64x2 *>(colp[it] + _i);                                   \
+    dbuf = *reinterpret_cast<const f64x2 *>(d + _i);                                       \
+    if (!_in) dbuf = (f64x2){0.0, 0.0};                                                    \
+    else if (_i + 1 >= n) dbuf.y = 0.0;                                                    \
+  }
+  if ((int64_t)blockIdx.x < ntiles) PO_GRAM_PREFETCH((int64_t)blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t row0 = tile * kGramTile;
     __syncthreads();  // previous tile fully consumed
-    // ---- stage: global -> LDS, 16 B per lane, fully coalesced 1 KiB per column ----
-    for (int j = col_in_pass; j < nv; j += 4) {
-      const int64_t i = row0 + 2 * pair;
-      double2 v = make_double2(0.0, 0.0);
-      if (i + 1 < n) {
-        v = *reinterpret_cast<const double2 *>(V.p[j] + i);
-      } else if (i < n) {
-        v.x = V.p[j][i];
-      }
-      *reinterpret_cast<double2 *>(pt + j * kGramLd + 2 * pair) = v;
+#pragma unroll
+    for (int it = 0; it < NPASS; it++) {
+      const int j = wave + 4 * it;
+      if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = buf[it];
     }
-    if (tid < 64) {
-      const int64_t i = row0 + 2 * tid;
-      double2 v = make_double2(0.0, 0.0);
-      if (i + 1 < n) {
-        v = *reinterpret_cast<const double2 *>(d + i);
-      } else if (i < n) {
-        v.x = d[i];
-      }
-      *reinterpret_cast<double2 *>(dw + 2 * tid) = v;
-    }
+    if (wave == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = dbuf;
     __syncthreads();
+    if (tile + gridDim.x < ntiles) PO_GRAM_PREFETCH(tile + gridDim.x);
     // ---- compute: wave w owns rows [32w, 32w+32) of the tile: 8 k-steps of 4 rows ----
     const int colq = lane & 15, rowq = lane >> 4;
 #pragma unroll 2
@@ -447,6 +510,7 @@ __global__ void __launch_bounds__(kBlock)
       }
     }
   }
+#undef PO_GRAM_PREFETCH
   // ---- cross-wave (K split) reduction through LDS, then one partial per workgroup ----
   __syncthreads();
   double *red = lds;  // reuse: [4 waves][NBLK*256]
@@ -601,12 +665,9 @@ __global__ void __launch_bounds__(kBlock)
     }
     r.x += -1.0 * gv.x;
     r.y += -1.0 * gv.y;
-#pragma unroll 8
-    for (int j = 0; j < nc; j++) {
-      const double2 a = ld2(A.p[j], q, n);
-      r.x += z.a[j] * a.x;
-      r.y += z.a[j] * a.y;
-    }
+    const double2 ps = panel_sum(A, z, nc, q);
+    r.x += ps.x;
+    r.y += ps.y;
     if (!_has2) r.y = 0.0;
     st2(rx, q, n, r);
     maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
@@ -775,13 +836,7 @@ __global__ void __launch_bounds__(kBlock)
   __shared__ double sm[4 * 2];
   double mins[2] = {1.0, 1.0};
   PO_PAIR_LOOP(q, n) {
-    double2 acc = make_double2(0.0, 0.0);
-#pragma unroll 8
-    for (int j = 0; j < nv; j++) {
-      const double2 v = ld2(P.p[j], q, n);
-      acc.x += alpha.a[j] * v.x;
-      acc.y += alpha.a[j] * v.y;
-    }
+    const double2 acc = panel_sum(P, alpha, nv, q);
     PO_LOAD_BOUNDS(b, q, n);
     const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
     const double dx0 = tv.x + dv.x * acc.x, dx1 = tv.y + dv.y * acc.y;
@@ -849,13 +904,7 @@ __global__ void __launch_bounds__(kBlock)
                     const double *__restrict__ dinv, CoefTable coef, PtrTable P, int nv, double diag,
                     double beta_mu, int64_t n, double *__restrict__ tp) {
   PO_PAIR_LOOP(q, n) {
-    double2 acc = make_double2(0.0, 0.0);
-#pragma unroll 8
-    for (int j = 0; j < nv; j++) {
-      const double2 v = ld2(P.p[j], q, n);
-      acc.x += coef.a[j] * v.x;
-      acc.y += coef.a[j] * v.y;
-    }
+    const double2 acc = panel_sum(P, coef, nv, q);
     PO_LOAD_BOUNDS(b, q, n);
     const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n),
                   dv = ld2(dinv, q, n);

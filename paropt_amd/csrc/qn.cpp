@@ -11,6 +11,10 @@
 
 namespace po {
 
+// Device vectors are allocated with an even element count plus slack and zero-filled, so the
+// kernels can always use full 16-byte accesses on the last pair (kernels.hip::ld2/st2).
+static size_t padded_elems(int64_t n) { return (size_t)(((n + 1) >> 1) << 1) + 2; }
+
 Vec *vec_new(Ctx *c, int64_t n) {
   po_vec_s *v = new po_vec_s();
   v->ctx = c;
@@ -18,13 +22,13 @@ Vec *vec_new(Ctx *c, int64_t n) {
   v->d = nullptr;
   v->ref = 1;
   v->h = nullptr;
-  if (hipSetDevice(c->device) != hipSuccess ||
-      hipMalloc((void **)&v->d, sizeof(double) * (size_t)(n > 0 ? n : 1)) != hipSuccess) {
+  const size_t bytes = sizeof(double) * padded_elems(n);
+  if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void **)&v->d, bytes) != hipSuccess) {
     set_error("hipMalloc of %lld doubles failed", (long long)n);
     delete v;
     return nullptr;
   }
-  if (hipMemsetAsync(v->d, 0, sizeof(double) * (size_t)(n > 0 ? n : 1), c->stream) != hipSuccess) {
+  if (hipMemsetAsync(v->d, 0, bytes, c->stream) != hipSuccess) {
     set_error("hipMemsetAsync failed");
   }
   return v;
