@@ -141,7 +141,7 @@ int ctx_create(int device, Ctx **out) {
   po_ctx_s *c = new po_ctx_s();
   c->device = device;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  c->max_blocks = c->num_cu * 8;
+  c->max_blocks = c->num_cu * 8;  // upper bound used only to size the partials buffer
   PO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PO_HIP(hipMalloc((void **)&c->d_red, sizeof(double) * kMaxRed));
   PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * kMaxRed, hipHostMallocDefault));

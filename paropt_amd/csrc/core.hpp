@@ -82,7 +82,8 @@ struct CoefTable {
 // host_out[nsum+nmin+nmax]; slots are ordered sums, then mins, then maxs.  Collective.
 int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out);
 int ensure_partials(Ctx *c, size_t doubles);
-int grid_for(Ctx *c, int64_t n);  // persistent grid size for an n-element streaming kernel
+int grid_for(Ctx *c, int64_t n);           // persistent grid, 4 workgroups per CU
+int grid_for(Ctx *c, int64_t n, int bpc);  // ... with an explicit workgroups-per-CU cap
 
 // ---- vector kernels (kernels.hip) -----------------------------------------------------------
 int k_fill(Ctx *c, double *y, int64_t n, double alpha);

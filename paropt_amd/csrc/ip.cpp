@@ -14,6 +14,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -194,11 +195,15 @@ static const int LS_SUCCESS = 1, LS_FAILURE = 2, LS_MIN_STEP = 4, LS_MAX_ITERS =
 InteriorPoint::InteriorPoint(Problem *p)
     : prob(p), ctx(p->ctx), n(p->nlocal), c(p->ncon), qn(nullptr), x(nullptr), zl(nullptr),
       zu(nullptr), lb(nullptr), ub(nullptr), g(nullptr), fobj(0.0), barrier_param(0.1),
-      rho_penalty_search(0.0), niter(0), neval(0), ngeval(0), iter_cb(nullptr),
+      rho_penalty_search(0.0), niter(0), neval(0), ngeval(0), analytic_panel_dots(true),
+      iter_cb(nullptr),
       iter_cb_user(nullptr), px(nullptr), pzl(nullptr), pzu(nullptr), Dinv(nullptr), rx(nullptr),
       tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), qn_created(false), wk(0),
-      comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0), phase_t0(0) {
+      comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0),
+      ptpx_valid(false), phase_t0(0) {
   qn_handle.qn = nullptr;
+  // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
+  if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
   use_lower = prob->useLowerBounds();
   use_upper = prob->useUpperBounds();
   vars.resize(c);
@@ -468,6 +473,7 @@ int InteriorPoint::getComplementarity(double *comp) {
 // the KKT system
 // ================================================================================================
 int InteriorPoint::setUpKKTSystem(bool use_qn) {  // setUpKKTDiagSystem + setUpKKTSystem
+  ptpx_valid = false;
   const double sigma = options.real("qn_sigma");
   const double b0 = (qn && use_qn) ? qn->diag() : 0.0;
   PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d));
@@ -553,6 +559,14 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   for (int j = 0; j < k; j++) alpha[c + j] = -zeta[j];
   PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
                   refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins));
+  // P^T (t + Dinv P alpha) = dots + W alpha
+  if (!refine_pass) ptpx.assign(m > 0 ? m : 1, 0.0);
+  for (int i = 0; i < m; i++) {
+    double v = dots[i];
+    for (int j = 0; j < m; j++) v += W[i + (size_t)m * j] * alpha[j];
+    ptpx[i] = refine_pass ? ptpx[i] + v : v;
+  }
+  ptpx_valid = true;
   // dense blocks: full solve (:2165-2170) minus the bx-only solve (:2300-2305)
   for (int i = 0; i < c; i++) {
     const double zs1 = yz[i] - b.s[i];
@@ -577,7 +591,11 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
     std::vector<const double *> Pq = panel(qn && !options.integer("sequential_linear_method"), &kq);
     const int mq = c + kq;
     std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
-    if (mq > 0) PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+    if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
+      for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
+    } else if (mq > 0) {
+      PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+    }
     double diag = options.real("qn_sigma");
     std::vector<double> coef(mq > 0 ? mq : 1, 0.0);
     for (int i = 0; i < c; i++) coef[i] = step.z[i];
@@ -720,7 +738,11 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
   std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
   const int mq = c + kq;
   std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
-  if (mq > 0) PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+  if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
+    for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
+  } else if (mq > 0) {
+    PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+  }
   for (int i = 0; i < mq; i++) dots[i] *= sx;
   for (int i = 0; i < c; i++) {
     if (vars.s[i] > 1.0) pos += log(vars.s[i]); else neg += log(vars.s[i]);

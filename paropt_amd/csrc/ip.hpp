@@ -82,6 +82,7 @@ class InteriorPoint {
   int niter, neval, ngeval;
 
   // observer + history
+  bool analytic_panel_dots;  // debugging switch: false re-measures P^T px with an mdot pass
   po_ip_iteration_fn iter_cb;
   void *iter_cb_user;
   std::string history;
@@ -109,6 +110,11 @@ class InteriorPoint {
   // lazily applied step scalings (scaleKKTStep :3253-3268)
   double sx, sz;
   double step_mins[2];
+  // P^T px of the current (unscaled) step, P = [Ac | Z]: maintained analytically from the solves
+  // (px = t + Dinv*(P alpha)  =>  P^T px = P^T t + W alpha), so that neither iterative refinement
+  // nor the merit derivative needs another pass over the panel
+  std::vector<double> ptpx;
+  bool ptpx_valid;
 
   Bounds bounds() const;
   std::vector<const double *> panel(bool use_qn, int *k) const;

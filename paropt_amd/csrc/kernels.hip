@@ -39,6 +39,11 @@ __device__ __forceinline__ void st2(double *__restrict__ p, int64_t q, int64_t n
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Panel columns are read exactly once per pass: non-temporal loads (+2-3 % in tools/tune_mdot.hip).
+__device__ __forceinline__ f64x2 ld_stream(const double *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+}
+
 enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
 
 template <int OP>
@@ -109,13 +114,18 @@ int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin) {
   return PO_OK;
 }
 
-int grid_for(Ctx *c, int64_t n) {
+// Persistent grid for an n-element streaming kernel: `bpc` workgroups per CU (tools/tune_mdot.hip:
+// 3-6 resident workgroups per CU stream at 6.2-6.5 TB/s; 8 per CU with ~6 resident leaves a
+// 1.33-wave tail and drops to 5.5 TB/s), fewer when n is small.
+int grid_for(Ctx *c, int64_t n, int bpc) {
   const int64_t npairs = (n + 1) >> 1;
   int64_t blocks = (npairs + kBlock - 1) / kBlock;
-  if (blocks > c->max_blocks) blocks = c->max_blocks;
+  const int64_t cap = (int64_t)c->num_cu * bpc;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
+int grid_for(Ctx *c, int64_t n) { return grid_for(c, n, 4); }
 
 #define PO_LAUNCH(kernel, grid, ...)                                                      \
   do {                                                                                    \
@@ -205,7 +215,7 @@ __device__ __forceinline__ void panel_batch(const PtrTable &P, const CoefTable &
                                             f64x2 &acc) {
   f64x2 v[B];
 #pragma unroll
-  for (int u = 0; u < B; u++) v[u] = *reinterpret_cast<const f64x2 *>(P.p[j + u] + 2 * q);
+  for (int u = 0; u < B; u++) v[u] = ld_stream(P.p[j + u] + 2 * q);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < B; u++) {
@@ -271,7 +281,7 @@ int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const d
   CoefTable ct;
   PtrTable pt;
   fill_tables(alpha, V, nv, &ct, &pt);
-  PO_LAUNCH(panel_axpy_kernel, grid_for(c, n), y, a, x, b, ct, pt, nv, n);
+  PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, 3), y, a, x, b, ct, pt, nv, n);
   return PO_OK;
 }
 
@@ -332,11 +342,9 @@ template <int NVB>
 __global__ void __launch_bounds__(kBlock)
     mdot_kernel(const double *__restrict__ x, PtrTable V, int j0, int64_t n,
                 double *__restrict__ partials) {
-  // The panel block is streamed in batches of up to 8 columns, double-buffered in registers:
-  // the 8 loads of batch b+1 are issued before the FMAs of batch b (hipcc otherwise serialises
-  // load -> wait -> fma per column to minimise registers, which starves the memory system).
-  constexpr int B = NVB >= 8 ? 8 : NVB;
-  constexpr int NB = (NVB + B - 1) / B;
+  // tools/tune_mdot.hip on MI355X (n = 50 M, 32 columns): this plain form -- hipcc keeps one or
+  // two 16-byte loads in flight per lane at ~6 waves per SIMD -- with non-temporal loads and 4-6
+  // workgroups per CU streams at 6.4-6.5 TB/s; explicit 8-deep register batches reach 6.1-6.3.
   __shared__ double sm[4 * NVB];
   double acc[NVB];
   const double *vp[NVB];
@@ -347,27 +355,10 @@ __global__ void __launch_bounds__(kBlock)
   }
   PO_PAIR_LOOP(q, n) {
     const f64x2 xv = *reinterpret_cast<const f64x2 *>(x + 2 * q);
-    f64x2 v[2][B];
 #pragma unroll
-    for (int j = 0; j < B; j++) v[0][j] = *reinterpret_cast<const f64x2 *>(vp[j] + 2 * q);
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-      if (b + 1 < NB) {
-#pragma unroll
-        for (int j = 0; j < B; j++) {
-          if ((b + 1) * B + j < NVB)
-            v[(b + 1) & 1][j] = *reinterpret_cast<const f64x2 *>(vp[(b + 1) * B + j] + 2 * q);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < B; j++) {
-        if (b * B + j < NVB) {
-          const f64x2 w = v[b & 1][j];
-          acc[b * B + j] = fma(xv.x, w.x, fma(xv.y, w.y, acc[b * B + j]));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NVB; j++) {
+      const f64x2 w = ld_stream(vp[j] + 2 * q);
+      acc[j] = fma(xv.x, w.x, fma(xv.y, w.y, acc[j]));
     }
   }
   block_reduce_store<NVB, OP_SUM>(acc, partials, j0, sm);
@@ -383,7 +374,7 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
     set_error("mdot of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
   }
-  const int grid = grid_for(c, n);
+  const int grid = grid_for(c, n, 5);
   PO_TRY(ensure_partials(c, (size_t)grid * (nv + 32)));
   PtrTable pt;
   CoefTable ct;
@@ -471,7 +462,7 @@ __global__ void __launch_bounds__(kBlock)
     const bool _in = (_i < n);                                                             \
     if (!_in) _i = ilast;                                                                  \
     _Pragma("unroll") for (int it = 0; it < NPASS; it++) buf[it] =                         \
-        *reinterpret_cast<const f64x2 *>(colp[it] + _i);                                   \
+        ld_stream(colp[it] + _i);                                   \
     dbuf = *reinterpret_cast<const f64x2 *>(d + _i);                                       \
     if (!_in) dbuf = (f64x2){0.0, 0.0};                                                    \
     else if (_i + 1 >= n) dbuf.y = 0.0;                                                    \
@@ -698,7 +689,7 @@ __global__ void __launch_bounds__(kBlock)
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
               int nc, double beta_mu, int64_t n, double *rx, double out[5]) {
-  const int grid = grid_for(c, n);
+  const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 5));
   PtrTable pt;
   CoefTable ct;
@@ -865,7 +856,7 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
   }
-  const int grid = grid_for(c, n);
+  const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PtrTable pt;
   CoefTable ct;
@@ -922,7 +913,7 @@ int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, cons
   PtrTable pt;
   CoefTable ct;
   fill_tables(coef, P, nv, &ct, &pt);
-  PO_LAUNCH(res_step_kernel, grid_for(c, n), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
+  PO_LAUNCH(res_step_kernel, grid_for(c, n, 3), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
             tprime);
   return PO_OK;
 }
