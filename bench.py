@@ -148,9 +148,17 @@ def main():
     ms, _ = pa.bench_mdot(x, V, 20)
     alg_bytes = 8.0 * (a.ncon + 1) * nl
     achieved = alg_bytes / (ms * 1e-3) * 1e-9
+    traffic = None
+    try:  # PMC bytes per launch from the committed rocprofv3 passes, valid for this exact shape
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        if pm["n"] == nl and a.ncon == 32:
+            k = pm["raw"]["void po::mdot_kernel<32>"]
+            traffic = k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "mdot_kernel<32> (ParOptVec::mdot, nvecs=%d, n_local=%d)" % (a.ncon, nl),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "avg_launch_ms": ms, "algorithmic_bytes": alg_bytes}
+                "traffic": traffic, "avg_launch_ms": ms, "algorithmic_bytes": alg_bytes}
 
     if rank == 0:
         cpu = None

@@ -1,0 +1,96 @@
+"""
+Two ranks sharing ONE GPU (the test box has a single MI355X): the sharded product path -- shard
+offsets, global-index data, per-rank partial reductions, rank-ordered all-gather combine -- through
+the host-callback communicator (gloo underneath).  RCCL itself needs one GPU per rank and is
+exercised by bench.py on the multi-GPU node.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    assert ctx.rank_size() == (rank, world)
+    n, c = 40003, 6
+    prob = pa.SeparableProblem(ctx, "convex", n, c)
+    # vector reductions over the sharded vector
+    v = pa.PVec(ctx, prob.nvars).fill_hash(0, 10, prob.offset, 2.0, -1.0)
+    w = pa.PVec(ctx, prob.nvars).fill_hash(0, 11, prob.offset, 2.0, -1.0)
+    red = (v.dot(w), v.norm(), v.maxabs(), v.l1norm(), list(v.mdot([w, v])))
+    opts = {"qn_type": "bfgs", "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 20, "write_output_frequency": 0}
+    ip = pa.InteriorPoint(prob, opts)
+    snaps = []
+    ip.setIterationCallback(lambda k: snaps.append(ip.snapshot()))
+    ip.optimize()
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    xs = [None] * world
+    dist.all_gather_object(xs, (prob.offset, x))
+    if rank == 0:
+        q.put((red, [(tuple(s["counters"]), s["qn_size"], s["fobj"], s["mu"], tuple(s["norms"])) for s in snaps],
+               np.concatenate([a for _, a in sorted(xs, key=lambda t: t[0])])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_rank():
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    n, c = 40003, 6
+    prob = pa.SeparableProblem(ctx, "convex", n, c)
+    v = pa.PVec(ctx, n).fill_hash(0, 10, 0, 2.0, -1.0)
+    w = pa.PVec(ctx, n).fill_hash(0, 11, 0, 2.0, -1.0)
+    red1 = (v.dot(w), v.norm(), v.maxabs(), v.l1norm(), list(v.mdot([w, v])))
+    opts = {"qn_type": "bfgs", "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 20, "write_output_frequency": 0}
+    ip = pa.InteriorPoint(prob, opts)
+    s1 = []
+    ip.setIterationCallback(lambda k: s1.append(ip.snapshot()))
+    ip.optimize()
+    x1 = ip.getOptimizedPoint()[0].to_numpy()
+
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    red2, s2, x2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(red2[0], red1[0], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(red2[1], red1[1], rtol=1e-13)
+    assert red2[2] == red1[2]
+    np.testing.assert_allclose(red2[3], red1[3], rtol=1e-13)
+    np.testing.assert_allclose(red2[4], red1[4], rtol=0, atol=1e-9)
+    assert len(s2) == len(s1)
+    for a, b in zip(s2, s1):
+        assert a[0] == tuple(b["counters"]) and a[1] == b["qn_size"]
+        assert abs(a[2] - b["fobj"]) <= 1e-7 * max(1.0, abs(b["fobj"]))
+        assert abs(a[3] - b["mu"]) <= 1e-7 * abs(b["mu"])
+        np.testing.assert_allclose(a[4], b["norms"], rtol=1e-7)
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-7)
