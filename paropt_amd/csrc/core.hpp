@@ -131,9 +131,18 @@ int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double b
 // out = {max_x, max_z}: the fraction-to-boundary minima of computeMaxStep :2942-3103 for the
 // final (px, pzl, pzu) with fraction tau (NOT masked by the bound predicates for px, as in the
 // reference).
+// When coef2 != nullptr (first pass only) the same panel pass also evaluates the refinement
+// residual with coefficient set coef2 and writes t' = Dinv*d1' (see k_res_step) to tout (which may
+// alias t): one panel pass less per iteration.
 int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
              const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
-             double *px, double *pzl, double *pzu, double out[2]);
+             double *px, double *pzl, double *pzu, double out[2], const double *coef2 = nullptr,
+             const double *rx = nullptr, double diag = 0.0, double *tout = nullptr,
+             double *va = nullptr, int nca = 0);
+// multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
+int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
+                      double eps, int use_lower, int use_upper, const double *rx, const double *va,
+                      double az, int64_t n, double *yqn);
 // Residual of the linearised KKT system for iterative refinement, already folded into the next
 // solve's right-hand side:  r'x = rx - diag*px + sum coef_j P_j + [L]pzl - [U]pzu ;
 // r'zl, r'zu as above ; t' = Dinv*(r'x + [L] r'zl/(x-lb) - [U] r'zu/(ub-x)).

@@ -198,9 +198,9 @@ InteriorPoint::InteriorPoint(Problem *p)
       rho_penalty_search(0.0), niter(0), neval(0), ngeval(0), analytic_panel_dots(true),
       iter_cb(nullptr),
       iter_cb_user(nullptr), px(nullptr), pzl(nullptr), pzu(nullptr), Dinv(nullptr), rx(nullptr),
-      tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), qn_created(false), wk(0),
+      tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), vA(nullptr), qn_created(false), wk(0),
       comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0),
-      ptpx_valid(false), phase_t0(0) {
+      ptpx_valid(false), residual_fused(false), residual_cached(false), phase_t0(0) {
   qn_handle.qn = nullptr;
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
@@ -216,7 +216,7 @@ InteriorPoint::InteriorPoint(Problem *p)
 }
 
 int InteriorPoint::allocate() {
-  Vec **all[] = {&x, &zl, &zu, &lb, &ub, &g, &px, &pzl, &pzu, &Dinv, &rx, &tvec, &xt, &y_qn, &s_qn};
+  Vec **all[] = {&x, &zl, &zu, &lb, &ub, &g, &px, &pzl, &pzu, &Dinv, &rx, &tvec, &xt, &y_qn, &s_qn, &vA};
   for (Vec **v : all) {
     *v = vec_new(ctx, n);
     if (!*v) return PO_ERR_HIP;
@@ -236,7 +236,7 @@ int InteriorPoint::allocate() {
 }
 
 InteriorPoint::~InteriorPoint() {
-  Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn};
+  Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn, vA};
   for (Vec *v : all) vec_decref(v);
   for (Vec *v : Ac) vec_decref(v);
   delete qn;
@@ -520,7 +520,7 @@ int InteriorPoint::setUpKKTSystem(bool use_qn) {  // setUpKKTDiagSystem + setUpK
 //   first pass : b is the residual (rx on the device, dense blocks in `b`)  -> writes px, pzl, pzu
 //   refine pass: tvec already holds Dinv*d1' (k_res_step)                    -> accumulates
 int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau,
-                            Dense &out) {
+                            Dense &out, bool fuse_residual) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   int k = 0;
   std::vector<const double *> P = panel(use_qn, &k);
@@ -557,8 +557,6 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   std::vector<double> alpha(m > 0 ? m : 1, 0.0);
   for (int i = 0; i < c; i++) alpha[i] = yz[i] - yz2[i];
   for (int j = 0; j < k; j++) alpha[c + j] = -zeta[j];
-  PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
-                  refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins));
   // P^T (t + Dinv P alpha) = dots + W alpha
   if (!refine_pass) ptpx.assign(m > 0 ? m : 1, 0.0);
   for (int i = 0; i < m; i++) {
@@ -567,6 +565,29 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     ptpx[i] = refine_pass ? ptpx[i] + v : v;
   }
   ptpx_valid = true;
+  // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
+  // the axpy pass starts (A-part = p.z = alpha_A; Z-part = d0 M^-1 d0 Z^T px with Z^T px = ptpx),
+  // so the same pass over P also emits the right-hand side t' of the refinement solve.
+  const bool seq_lin = options.integer("sequential_linear_method");
+  const int kq = (qn && !seq_lin) ? qn->size() : 0;
+  const bool fuse = fuse_residual && !refine_pass && analytic_panel_dots && kq == k;
+  std::vector<double> coef(m > 0 ? m : 1, 0.0);
+  double diag = options.real("qn_sigma");
+  if (fuse) {
+    for (int i = 0; i < c; i++) coef[i] = alpha[i];
+    if (qn && !seq_lin) {
+      diag += qn->diag();
+      if (k > 0) {
+        std::vector<double> rz(ptpx.begin() + c, ptpx.begin() + c + k);
+        qn->applyCompactInverse(rz.data());
+        for (int j = 0; j < k; j++) coef[c + j] = rz[j];
+      }
+    }
+  }
+  PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
+                  refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins,
+                  fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c));
+  residual_fused = fuse;
   // dense blocks: full solve (:2165-2170) minus the bx-only solve (:2300-2305)
   for (int i = 0; i < c; i++) {
     const double zs1 = yz[i] - b.s[i];
@@ -584,7 +605,7 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
   const int nref = options.integer("iterative_refinement_steps");
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   denseResidual(mu, res);
-  PO_TRY(solveKKT(res, mu, use_qn, false, tau, step));
+  PO_TRY(solveKKT(res, mu, use_qn, false, tau, step, nref > 0));
   for (int it = 0; it < nref; it++) {  // :4985-4991
     // dots of the current step with [Ac | Z_qn]: A px for r'.z, Z^T px for B px
     int kq = 0;
@@ -607,8 +628,10 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
         for (int j = 0; j < kq; j++) coef[c + j] = rz[j];
       }
     }
-    PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, Dinv->d, coef.data(), Pq.data(),
-                      mq, diag, beta_mu, n, tvec->d));
+    if (!(it == 0 && residual_fused)) {
+      PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, Dinv->d, coef.data(), Pq.data(),
+                        mq, diag, beta_mu, n, tvec->d));
+    }
     Dense r2;
     r2.resize(c);
     denseResidual(mu, r2);
@@ -912,7 +935,19 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   const bool use_qnu = options.integer("use_quasi_newton_update");
   const double eps = options.real("design_precision");
   *update_type = 0;
-  PO_TRY(k_update_mult(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper, n));
+  const bool do_qn = qn && perform_qn_update && use_qnu;
+  // The gradient difference y_qn = [-g + A^T z+]_old + [g - A^T z+]_new (:4197-4206, 4243-4251)
+  // is assembled without streaming the constraint gradients: the first bracket from this
+  // iteration's KKT residual rx = [lo]zl - [up]zu - g + A^T z and va = A^T pz (kept by the solves),
+  // the second from the NEXT iteration's residual, which is evaluated right after the gradient and
+  // reused at the top of the loop.
+  const bool fast_yqn = do_qn && analytic_panel_dots;
+  if (fast_yqn) {
+    PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
+                             rx->d, vA->d, alpha * sz, n, y_qn->d));
+  } else {
+    PO_TRY(k_update_mult(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper, n));
+  }
   for (int i = 0; i < c; i++) {
     double v = vars.s[i] + alpha * step.s[i];
     vars.s[i] = (v <= eps) ? eps : v;
@@ -926,8 +961,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   }
   std::vector<const double *> A;
   for (Vec *a : Ac) A.push_back(a->d);
-  const bool do_qn = qn && perform_qn_update && use_qnu;
-  if (do_qn) {  // y_qn = -g + A^T z  at the old point with the new multipliers
+  if (do_qn && !fast_yqn) {  // y_qn = -g + A^T z  at the old point with the new multipliers
     PO_TRY(k_panel_axpy(ctx, y_qn->d, -1.0, g->d, 0.0, vars.z.data(), A.data(), c, n));
   }
   if (eval_obj_con) {
@@ -948,11 +982,20 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   int fail_g = prob->evalObjConGradient(x, g, Ac.data());
   ngeval++;
   if (fail_g) fprintf(stderr, "ParOpt: Gradient evaluation failed at final line search\n");
-  if (qn && perform_qn_update && use_qnu) {
+  if (do_qn) {
     PO_TRY(k_panel_axpy(ctx, s_qn->d, alpha * sx, px->d, 0.0, nullptr, nullptr, 0, n));
-    std::vector<double> mz(c > 0 ? c : 1);
-    for (int i = 0; i < c; i++) mz[i] = -vars.z[i];
-    PO_TRY(k_panel_axpy(ctx, y_qn->d, 1.0, g->d, 1.0, mz.data(), A.data(), c, n));
+    if (fast_yqn) {
+      // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
+      PO_TRY(computeResidual(barrier_param, true));
+      residual_cached = true;
+      const double cf[3] = {use_lower ? 1.0 : 0.0, use_upper ? -1.0 : 0.0, -1.0};
+      const double *vv[3] = {zl->d, zu->d, rx->d};
+      PO_TRY(k_panel_axpy(ctx, y_qn->d, 0.0, nullptr, 1.0, cf, vv, 3, n));
+    } else {
+      std::vector<double> mz(c > 0 ? c : 1);
+      for (int i = 0; i < c; i++) mz[i] = -vars.z[i];
+      PO_TRY(k_panel_axpy(ctx, y_qn->d, 1.0, g->d, 1.0, mz.data(), A.data(), c, n));
+    }
     int rcc = prob->computeQuasiNewtonUpdateCorrection(x, vars.z.data(), s_qn, y_qn);
     if (rcc != 0) return PO_ERR_USER;
     PO_TRY(qn->update(s_qn, y_qn, update_type));
@@ -1015,6 +1058,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const int write_freq = options.integer("write_output_frequency");
   const std::string start = options.str("starting_point_strategy");
   niter = neval = ngeval = 0;
+  residual_cached = false;
   history.clear();
   phase_names.clear();
   phase_seconds.clear();
@@ -1080,7 +1124,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
     int monotone_barrier_converged = 0;
     double comp = 0.0;
     if (monotone) {
-      PO_TRY(computeResidual(barrier_param, true));
+      if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
+      residual_cached = false;
       comp = compFromSums(comp_prod, comp_count, vars);
       denseResidual(barrier_param, res);
       resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
@@ -1101,7 +1146,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
         barrier_param = new_mu;
       }
     } else {  // complementarity fraction (:4747-4762)
-      PO_TRY(computeResidual(barrier_param, true));
+      if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
+      residual_cached = false;
       comp = compFromSums(comp_prod, comp_count, vars);
       barrier_param = options.real("monotone_barrier_fraction") * comp;
       if (barrier_param < 0.1 * abs_res_tol) barrier_param = 0.1 * abs_res_tol;

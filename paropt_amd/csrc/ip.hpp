@@ -96,6 +96,7 @@ class InteriorPoint {
  private:
   // work vectors
   Vec *Dinv, *rx, *tvec, *xt, *y_qn, *s_qn;
+  Vec *vA;  // A^T pz of the current (unscaled) step, accumulated by the solves
   std::vector<double> gamma_s, gamma_t;
   int use_lower, use_upper;
   bool qn_created;
@@ -115,6 +116,8 @@ class InteriorPoint {
   // nor the merit derivative needs another pass over the panel
   std::vector<double> ptpx;
   bool ptpx_valid;
+  bool residual_fused;  // the last first-pass solve already wrote the refinement rhs t'
+  bool residual_cached; // rx / norms of the CURRENT state were already evaluated (step update)
 
   Bounds bounds() const;
   std::vector<const double *> panel(bool use_qn, int *k) const;
@@ -129,7 +132,8 @@ class InteriorPoint {
                 double *res_norm) const;
   double compFromSums(double prod, double count, const Dense &v) const;
   int setUpKKTSystem(bool use_qn);
-  int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out);
+  int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
+               bool fuse_residual = false);
   int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);
   int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq);
   int evalMeritInitDeriv(double max_x, double *merit, double *pmerit);

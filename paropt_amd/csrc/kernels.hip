@@ -224,9 +224,9 @@ __device__ __forceinline__ void panel_batch(const PtrTable &P, const CoefTable &
   }
   __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ double2 panel_sum(const PtrTable &P, const CoefTable &a, int nv, int64_t q) {
+__device__ __forceinline__ double2 panel_sum(const PtrTable &P, const CoefTable &a, int nv, int64_t q,
+                                             int j = 0) {
   f64x2 acc = (f64x2){0.0, 0.0};
-  int j = 0;
   for (; j + 8 <= nv; j += 8) panel_batch<8>(P, a, j, q, acc);
   if (j + 4 <= nv) {
     panel_batch<4>(P, a, j, q, acc);
@@ -238,6 +238,40 @@ __device__ __forceinline__ double2 panel_sum(const PtrTable &P, const CoefTable 
   }
   if (j < nv) panel_batch<1>(P, a, j, q, acc);
   return make_double2(acc.x, acc.y);
+}
+
+// two coefficient sets over the same panel in one pass (solve + refinement residual)
+template <int B>
+__device__ __forceinline__ void panel_batch2(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
+                                             int j, int64_t q, f64x2 &acc, f64x2 &acc2) {
+  f64x2 v[B];
+#pragma unroll
+  for (int u = 0; u < B; u++) v[u] = ld_stream(P.p[j + u] + 2 * q);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < B; u++) {
+    acc.x += a.a[j + u] * v[u].x;
+    acc.y += a.a[j + u] * v[u].y;
+    acc2.x += b2.a[j + u] * v[u].x;
+    acc2.y += b2.a[j + u] * v[u].y;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void panel_sum2(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
+                                           int nv, int64_t q, double2 &s1, double2 &s2, int j = 0) {
+  f64x2 acc = (f64x2){0.0, 0.0}, acc2 = (f64x2){0.0, 0.0};
+  for (; j + 8 <= nv; j += 8) panel_batch2<8>(P, a, b2, j, q, acc, acc2);
+  if (j + 4 <= nv) {
+    panel_batch2<4>(P, a, b2, j, q, acc, acc2);
+    j += 4;
+  }
+  if (j + 2 <= nv) {
+    panel_batch2<2>(P, a, b2, j, q, acc, acc2);
+    j += 2;
+  }
+  if (j < nv) panel_batch2<1>(P, a, b2, j, q, acc, acc2);
+  s1 = make_double2(acc.x, acc.y);
+  s2 = make_double2(acc2.x, acc2.y);
 }
 
 // y <- a*x + b*y + sum_j alpha_j V_j : runtime panel width, no per-column registers needed.
@@ -818,59 +852,6 @@ __device__ __forceinline__ void max_step_elem(const Bounds &b, double x, double 
   }
 }
 
-template <int REFINE>
-__global__ void __launch_bounds__(kBlock)
-    solve2_kernel(Bounds b, const double *__restrict__ t, const double *__restrict__ dinv,
-                  CoefTable alpha, PtrTable P, int nv, double beta_mu, double tau, int64_t n,
-                  double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
-                  double *__restrict__ partials) {
-  __shared__ double sm[4 * 2];
-  double mins[2] = {1.0, 1.0};
-  PO_PAIR_LOOP(q, n) {
-    const double2 acc = panel_sum(P, alpha, nv, q);
-    PO_LOAD_BOUNDS(b, q, n);
-    const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
-    const double dx0 = tv.x + dv.x * acc.x, dx1 = tv.y + dv.y * acc.y;
-    double2 p0 = make_double2(0.0, 0.0), l0 = p0, u0 = p0;
-    if (REFINE) {
-      p0 = ld2(px, q, n);
-      l0 = ld2(pzl, q, n);
-      u0 = ld2(pzu, q, n);
-    }
-    const Step3 s0 = solve2_elem<REFINE>(e0, dx0, beta_mu, p0.x, l0.x, u0.x);
-    Step3 s1 = solve2_elem<REFINE>(e1, dx1, beta_mu, p0.y, l0.y, u0.y);
-    if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
-    st2(px, q, n, make_double2(s0.px, s1.px));
-    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
-    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
-    max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
-    if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
-  }
-  block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
-}
-
-int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
-             const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
-             double *px, double *pzl, double *pzu, double out[2]) {
-  if (nv > kMaxPanel) {
-    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
-    return PO_ERR_ARG;
-  }
-  const int grid = grid_for(c, n, 3);
-  PO_TRY(ensure_partials(c, (size_t)grid * 2));
-  PtrTable pt;
-  CoefTable ct;
-  fill_tables(alpha, P, nv, &ct, &pt);
-  if (refine) {
-    PO_LAUNCH(solve2_kernel<1>, grid, b, t, dinv, ct, pt, nv, beta_mu, tau, n, px, pzl, pzu,
-              c->d_partials);
-  } else {
-    PO_LAUNCH(solve2_kernel<0>, grid, b, t, dinv, ct, pt, nv, beta_mu, tau, n, px, pzl, pzu,
-              c->d_partials);
-  }
-  return reduce_finish(c, grid, 0, 2, 0, out);
-}
-
 // refinement residual folded into the next right-hand side -----------------------------------------
 __device__ __forceinline__ double res_step_elem(const BE &e, double rx, double acc, double diag,
                                                 double px, double pzl, double pzu, double dinv,
@@ -889,33 +870,95 @@ __device__ __forceinline__ double res_step_elem(const BE &e, double rx, double a
   }
   return dinv * d1;
 }
+// REFINE: accumulate into (px, pzl, pzu).  FUSE (first pass only): also stream the second
+// coefficient set and emit t' = Dinv*d1' of the refinement right-hand side in the same pass
+// (what res_step_kernel computes), in place of t.
+template <int REFINE, int FUSE>
 __global__ void __launch_bounds__(kBlock)
-    res_step_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ px,
-                    const double *__restrict__ pzl, const double *__restrict__ pzu,
-                    const double *__restrict__ dinv, CoefTable coef, PtrTable P, int nv, double diag,
-                    double beta_mu, int64_t n, double *__restrict__ tp) {
+    solve2_kernel(Bounds b, const double *t, const double *__restrict__ dinv, CoefTable alpha,
+                  CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
+                  const double *__restrict__ rx, double diag, int64_t n, double *__restrict__ px,
+                  double *__restrict__ pzl, double *__restrict__ pzu, double *tout,
+                  double *__restrict__ va, int nca, double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double mins[2] = {1.0, 1.0};
   PO_PAIR_LOOP(q, n) {
-    const double2 acc = panel_sum(P, coef, nv, q);
+    // the first nca columns are the constraint gradients: their partial sum A^T pz is kept in `va`
+    // (accumulated over the refinement pass) for the quasi-Newton gradient difference
+    const double2 accA = panel_sum(P, alpha, nca, q);
+    if (va) {
+      double2 w = accA;
+      if (REFINE) {
+        const double2 w0 = ld2(va, q, n);
+        w.x += w0.x;
+        w.y += w0.y;
+      }
+      st2(va, q, n, w);
+    }
+    double2 acc, acc2 = make_double2(0.0, 0.0);
+    if (FUSE) {
+      panel_sum2(P, alpha, coef2, nv, q, acc, acc2, nca);
+      acc2.x += accA.x;  // coef2 == alpha on the constraint columns
+      acc2.y += accA.y;
+    } else {
+      acc = panel_sum(P, alpha, nv, q, nca);
+    }
+    acc.x += accA.x;
+    acc.y += accA.y;
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n),
-                  dv = ld2(dinv, q, n);
-    st2(tp, q, n,
-        make_double2(res_step_elem(e0, r.x, acc.x, diag, p.x, l.x, u.x, dv.x, beta_mu, b.use_lower,
-                                   b.use_upper),
-                     res_step_elem(e1, r.y, acc.y, diag, p.y, l.y, u.y, dv.y, beta_mu, b.use_lower,
-                                   b.use_upper)));
+    const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
+    const double dx0 = tv.x + dv.x * acc.x, dx1 = tv.y + dv.y * acc.y;
+    double2 p0 = make_double2(0.0, 0.0), l0 = p0, u0 = p0;
+    if (REFINE) {
+      p0 = ld2(px, q, n);
+      l0 = ld2(pzl, q, n);
+      u0 = ld2(pzu, q, n);
+    }
+    const Step3 s0 = solve2_elem<REFINE>(e0, dx0, beta_mu, p0.x, l0.x, u0.x);
+    Step3 s1 = solve2_elem<REFINE>(e1, dx1, beta_mu, p0.y, l0.y, u0.y);
+    if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+    st2(px, q, n, make_double2(s0.px, s1.px));
+    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    if (FUSE) {
+      const double2 r = ld2(rx, q, n);
+      st2(tout, q, n,
+          make_double2(res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, dv.x, beta_mu,
+                                     b.use_lower, b.use_upper),
+                       res_step_elem(e1, r.y, acc2.y, diag, s1.px, s1.pzl, s1.pzu, dv.y, beta_mu,
+                                     b.use_lower, b.use_upper)));
+    }
+    max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+    if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
   }
+  block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
 }
-int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
-               const double *pzu, const double *dinv, const double *coef, const double *const *P,
-               int nv, double diag, double beta_mu, int64_t n, double *tprime) {
-  if (n <= 0) return PO_OK;
+
+int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+             const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
+             double *px, double *pzl, double *pzu, double out[2], const double *coef2,
+             const double *rx, double diag, double *tout, double *va, int nca) {
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int grid = grid_for(c, n, 3);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PtrTable pt;
-  CoefTable ct;
-  fill_tables(coef, P, nv, &ct, &pt);
-  PO_LAUNCH(res_step_kernel, grid_for(c, n, 3), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
-            tprime);
-  return PO_OK;
+  CoefTable ct, ct2;
+  fill_tables(alpha, P, nv, &ct, &pt);
+  fill_tables(coef2, P, nv, &ct2, &pt);
+  if (refine) {
+    PO_LAUNCH((solve2_kernel<1, 0>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
+              pzl, pzu, tout, va, nca, c->d_partials);
+  } else if (coef2) {
+    PO_LAUNCH((solve2_kernel<0, 1>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
+              pzl, pzu, tout, va, nca, c->d_partials);
+  } else {
+    PO_LAUNCH((solve2_kernel<0, 0>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
+              pzl, pzu, tout, va, nca, c->d_partials);
+  }
+  return reduce_finish(c, grid, 0, 2, 0, out);
 }
 
 // complementarity at a trial step -------------------------------------------------------------------
@@ -1057,6 +1100,47 @@ int k_update_mult(Ctx *c, double *zl, const double *pzl, double *zu, const doubl
                   double eps, int use_lower, int use_upper, int64_t n) {
   if (n <= 0) return PO_OK;
   PO_LAUNCH(update_mult_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, n);
+  return PO_OK;
+}
+
+// zl, zu update fused with the first half of the quasi-Newton gradient difference
+//   y_qn = -g + A^T z+  =  rx - [lo] zl_old + [up] zu_old + az * (A^T pz)
+// (rx = [lo] zl - [up] zu - g + A^T z is the KKT residual of this iteration; va = A^T pz was
+// accumulated by the solves), replacing a pass over all constraint gradients (:4200-4206).
+__global__ void __launch_bounds__(kBlock)
+    update_mult_yqn_kernel(double *__restrict__ zl, const double *__restrict__ pzl,
+                           double *__restrict__ zu, const double *__restrict__ pzu, double a,
+                           double eps, int use_lower, int use_upper, const double *__restrict__ rx,
+                           const double *__restrict__ va, double az, int64_t n,
+                           double *__restrict__ yqn) {
+  PO_PAIR_LOOP(q, n) {
+    const double2 r = ld2(rx, q, n), w = ld2(va, q, n);
+    double2 y = make_double2(r.x + az * w.x, r.y + az * w.y);
+    if (use_lower) {
+      const double2 z = ld2(zl, q, n), p = ld2(pzl, q, n);
+      y.x -= z.x;
+      y.y -= z.y;
+      st2(zl, q, n,
+          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
+                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+    }
+    if (use_upper) {
+      const double2 z = ld2(zu, q, n), p = ld2(pzu, q, n);
+      y.x += z.x;
+      y.y += z.y;
+      st2(zu, q, n,
+          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
+                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+    }
+    st2(yqn, q, n, y);
+  }
+}
+int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
+                      double eps, int use_lower, int use_upper, const double *rx, const double *va,
+                      double az, int64_t n, double *yqn) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(update_mult_yqn_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, rx,
+            va, az, n, yqn);
   return PO_OK;
 }
 

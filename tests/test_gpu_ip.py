@@ -210,3 +210,34 @@ def test_option_errors(ctx):
         ip.setOption("qn_type", "nonsense")
     with pytest.raises(pa.ParOptAMDError):
         ip.setOption("max_line_iters", 1000)  # out of range [1, 100]
+
+
+def test_explicit_and_analytic_panel_dots_agree(ctx, monkeypatch):
+    """The W-based shortcuts (P^T px from the weighted Gram, fused refinement residual, rx-based
+    quasi-Newton gradient difference) against the same solver with every one of those quantities
+    re-measured by explicit passes (PAROPT_AMD_EXPLICIT_DOTS=1)."""
+    import paropt_amd as pa
+
+    opts = {"qn_subspace_size": 8, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 40, "write_output_frequency": 0}
+    runs = []
+    for explicit in (False, True):
+        if explicit:
+            monkeypatch.setenv("PAROPT_AMD_EXPLICIT_DOTS", "1")
+        else:
+            monkeypatch.delenv("PAROPT_AMD_EXPLICIT_DOTS", raising=False)
+        ip = pa.InteriorPoint(pa.SeparableProblem(ctx, "convex", 30011, 12), opts)
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        ip.optimize()
+        runs.append((sn, ip.getHistory(), ip.getOptimizedPoint()[0].to_numpy()))
+    monkeypatch.delenv("PAROPT_AMD_EXPLICIT_DOTS", raising=False)
+    a, b = runs
+    assert len(a[0]) == len(b[0])
+    for sa, sb in zip(a[0], b[0]):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["qn_size"] == sb["qn_size"]
+        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-8 * max(1.0, abs(sb["fobj"]))
+        np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-8)
+    assert info_tokens(a[1]) == info_tokens(b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8)
