@@ -961,6 +961,37 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
 
+// stand-alone refinement residual (second and later refinement steps, or when the fused form of
+// solve2_kernel is not applicable)
+__global__ void __launch_bounds__(kBlock)
+    res_step_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ px,
+                    const double *__restrict__ pzl, const double *__restrict__ pzu,
+                    const double *__restrict__ dinv, CoefTable coef, PtrTable P, int nv, double diag,
+                    double beta_mu, int64_t n, double *__restrict__ tp) {
+  PO_PAIR_LOOP(q, n) {
+    const double2 acc = panel_sum(P, coef, nv, q);
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n),
+                  dv = ld2(dinv, q, n);
+    st2(tp, q, n,
+        make_double2(res_step_elem(e0, r.x, acc.x, diag, p.x, l.x, u.x, dv.x, beta_mu, b.use_lower,
+                                   b.use_upper),
+                     res_step_elem(e1, r.y, acc.y, diag, p.y, l.y, u.y, dv.y, beta_mu, b.use_lower,
+                                   b.use_upper)));
+  }
+}
+int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
+               const double *pzu, const double *dinv, const double *coef, const double *const *P,
+               int nv, double diag, double beta_mu, int64_t n, double *tprime) {
+  if (n <= 0) return PO_OK;
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(coef, P, nv, &ct, &pt);
+  PO_LAUNCH(res_step_kernel, grid_for(c, n, 3), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
+            tprime);
+  return PO_OK;
+}
+
 // complementarity at a trial step -------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
     comp_step_kernel(Bounds b, const double *__restrict__ px, const double *__restrict__ pzl,
