@@ -103,8 +103,15 @@ def main():
     import paropt_amd as pa
 
     ctx = pa.Context(local_rank)
+    comm_kind = "self"
     if world > 1:
-        ctx.init_rccl_from_torch()
+        try:
+            ctx.init_rccl_from_torch()  # native ncclAllGather on the solver's own stream
+            comm_kind = "rccl"
+        except Exception as e:  # pragma: no cover - keeps the scaling run alive if RCCL init fails
+            log("native RCCL communicator failed (%r); falling back to torch.distributed all_gather" % (e,))
+            ctx.init_callback_from_torch(device=torch.device("cuda", local_rank))
+            comm_kind = "torch.distributed(nccl) callback"
 
     def barrier_sync():
         ctx.synchronize()
@@ -179,7 +186,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "config 3: separable random_convex n=%d, m=%d dense + bounds, L-%s(%d), "
                                    "design vector sharded over %d GPU(s)" % (a.n, a.ncon, a.qn.upper(), QN_SIZE, world),
-                       "n_global": a.n, "ncon": a.ncon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter)},
+                       "n_global": a.n, "ncon": a.ncon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter),
+                       "collective": comm_kind},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "phase_ms_per_iter": {k: 1e3 * v / niter for k, v in phases.items()},

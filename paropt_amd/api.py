@@ -47,8 +47,9 @@ class Context:
         idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
         check(lib.po_ctx_comm_init_rccl(self._h, rank, size, idbuf))
 
-    def init_callback_from_torch(self):
-        """Host-side allgather through torch.distributed (gloo or nccl): the maintainer's-MPI hook."""
+    def init_callback_from_torch(self, device=None):
+        """Host-side allgather through torch.distributed (gloo, or nccl with `device`): the
+        maintainer's-MPI hook."""
         import torch
         import torch.distributed as dist
 
@@ -57,11 +58,13 @@ class Context:
         def _gather(inp, out, count, user):
             try:
                 loc = torch.from_numpy(np.ctypeslib.as_array(inp, shape=(count,)).copy())
+                if device is not None:
+                    loc = loc.to(device)
                 parts = [torch.empty_like(loc) for _ in range(size)]
                 dist.all_gather(parts, loc)
                 dst = np.ctypeslib.as_array(out, shape=(count * size,))
                 for r in range(size):
-                    dst[r * count : (r + 1) * count] = parts[r].numpy()
+                    dst[r * count : (r + 1) * count] = parts[r].cpu().numpy()
                 return 0
             except Exception:  # pragma: no cover
                 return 1
