@@ -94,17 +94,27 @@ def main():
 
     import torch
 
+    # test hook for the 1-GPU development box: all ranks share GPU 0 and reduce over gloo
+    share_gpu = os.environ.get("PAROPT_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     import paropt_amd as pa
 
     ctx = pa.Context(local_rank)
     comm_kind = "self"
-    if world > 1:
+    if world > 1 and share_gpu:
+        ctx.init_callback_from_torch()
+        comm_kind = "gloo callback (shared-GPU test mode)"
+    elif world > 1:
         try:
             ctx.init_rccl_from_torch()  # native ncclAllGather on the solver's own stream
             comm_kind = "rccl"
@@ -139,7 +149,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - stamp["t0"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     niter, neval, ngeval = ip.getIterationCounters()
