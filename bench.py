@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=12)
-    XX
+    ap.add_argument("--nglobal", dest="n", type=int, default=N_GLOBAL,
+                    help="global design variables (default: the metric's 50M)")
     ap.add_argument("--ncon", type=int, default=NCON)
     ap.add_argument("--qn", type=str, default="sr1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
