@@ -235,6 +235,38 @@ case(
 )
 
 
+for strat in ("mehrotra", "mehrotra_predictor_corrector"):
+    case(
+        "ip_quadratic_%s_n300_c3" % ("mpc" if "corrector" in strat else "mehrotra"),
+        "ip",
+        problem="quadratic",
+        n=300,
+        c=3,
+        dump_vecs_every=10,
+        **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.barrier_strategy": strat, "opt.max_major_iters": 80}),
+    )
+# the option set of examples/rosenbrock/rosenbrock.cpp:234-242 (barrier_strategy = mehrotra)
+case(
+    "ip_rosenbrock_mehrotra_n100",
+    "ip",
+    problem="rosenbrock",
+    n=100,
+    dump_vecs_every=10,
+    **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-6,
+       "opt.barrier_strategy": "mehrotra", "opt.write_output_frequency": 1, "opt.max_major_iters": 150},
+)
+for nt in ("l1", "l2"):
+    case(
+        "ip_quadratic_norm_%s_n300_c3" % nt,
+        "ip",
+        problem="quadratic",
+        n=300,
+        c=3,
+        dump_vecs_every=0,
+        **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.norm_type": nt, "opt.max_major_iters": 80}),
+    )
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)

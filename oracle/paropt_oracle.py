@@ -570,6 +570,13 @@ class InteriorPoint:
         r.zl[:] -= np.where(L, (v.x - self.lb) * p.zl + p.x * v.zl, 0.0)
         r.zu[:] -= np.where(U, (self.ub - v.x) * p.zu - p.x * v.zu, 0.0)
 
+    def add_mehrotra_corrector_residual(self, p, r):  # :1729-1789
+        L, U = self._masks()
+        r.zs[:] -= p.s * p.zs
+        r.zt[:] -= p.t * p.zt
+        r.zl[:] -= np.where(L, p.x * p.zl, 0.0)
+        r.zu[:] += np.where(U, p.x * p.zu, 0.0)
+
     def compute_res_norm(self, r):  # :1588-1723
         nt = self.opt["norm_type"]
         ops = self.ops
@@ -1085,8 +1092,7 @@ class InteriorPoint:
         v = self.vars
         barrier_strategy = "monotone"
         input_strategy = o["barrier_strategy"]
-        if input_strategy not in ("monotone", "complementarity_fraction"):
-            raise NotImplementedError("oracle covers monotone / complementarity_fraction barrier strategies")
+        mehrotra_names = ("mehrotra", "mehrotra_predictor_corrector")
         self.barrier_param = o["init_barrier_param"]
         self.rho = o["init_rho_penalty_search"]
         self.niter = self.neval = self.ngeval = 0
@@ -1149,6 +1155,9 @@ class InteriorPoint:
                     mp, md, mi, res_norm = self.compute_res_norm(self.res)
                     self.rho = o["min_rho_penalty_search"]
                     self.barrier_param = new_mu
+            elif barrier_strategy in mehrotra_names:  # :4737-4746
+                self.compute_kkt_res(v, self.barrier_param, self.res)
+                mp, md, mi, res_norm = self.compute_res_norm(self.res)
             else:  # complementarity_fraction :4747-4762
                 self.barrier_param = o["monotone_barrier_fraction"] * comp
                 if self.barrier_param < 0.1 * abs_res_tol:
@@ -1187,9 +1196,29 @@ class InteriorPoint:
             seq_linear_step = 0
             diagonal_qn_step = 0
             use_qn = 0 if o["sequential_linear_method"] else 1
+            mu_for_res = self.barrier_param
+            if barrier_strategy in mehrotra_names:  # affine residual :4958-4964
+                mu_for_res = 0.0
+                self.compute_kkt_res(v, 0.0, self.res)
+                self.compute_res_norm(self.res)
             self.setup_kkt_diag_system(v, use_qn)
             self.setup_kkt_system(v, use_qn)
-            self._kkt_step_with_refinement(v, self.barrier_param, use_qn)
+            self._kkt_step_with_refinement(v, mu_for_res, use_qn)
+            if barrier_strategy in mehrotra_names:  # :4999-5052
+                max_x, max_z = self.compute_max_step(v, 1.0, self.step)
+                comp_affine = self.compute_comp_step(v, max_x, max_z, self.step)
+                s1 = comp_affine / comp
+                sigma = max(s1 * s1 * s1, 0.01)
+                self.barrier_param = sigma * comp
+                if self.barrier_param < 0.09999 * abs_res_tol:
+                    self.barrier_param = 0.09999 * abs_res_tol
+                self.compute_kkt_res(v, self.barrier_param, self.res)
+                mp, md, mi, res_norm = self.compute_res_norm(self.res)
+                if barrier_strategy == "mehrotra_predictor_corrector":
+                    self.add_mehrotra_corrector_residual(self.step, self.res)
+                    self.compute_kkt_step(v, self.res, self.step, use_qn)
+                else:
+                    self._kkt_step_with_refinement(v, self.barrier_param, use_qn)
             tau = max(o["min_fraction_to_boundary"], 1.0 - self.barrier_param)
             ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp)
             alpha = 1.0

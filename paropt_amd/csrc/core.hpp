@@ -110,20 +110,24 @@ struct Bounds {  // the per-element data every bound-aware kernel needs
   double max_bound;  // max_bound_value (1e20)
   int use_lower, use_upper;
 };
-// rx = [L]zl - [U]zu - g + sum z_j A_j ; out = {comp product, active-bound count, max|rx|,
-// max|rzl|, max|rzu|} with rzl = -((x-lb) zl - beta*mu), rzu = -((ub-x) zu - beta*mu).
+// rx = [L]zl - [U]zu - g + sum z_j A_j ; out = {comp product, active-bound count, l1 rx, l1 rzl,
+// l1 rzu, l2^2 rx, l2^2 rzl, l2^2 rzu, max|rx|, max|rzl|, max|rzu|} with
+// rzl = -((x-lb) zl - beta*mu), rzu = -((ub-x) zu - beta*mu).
 // (computeKKTRes :1337-1446 + computeComp :2742-2820 + computeResNorm :1588-1723)
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[5]);
+              int nc, double beta_mu, int64_t n, double *rx, double out[11]);
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
-int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[4]);
+int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);
 // Dinv = 1/(diag + [L] zl/(x-lb) + [U] zu/(ub-x))   (setUpKKTDiagSystem :1864-1910)
 int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv);
 // t = Dinv*(rx + [L] rzl/(x-lb) - [U] rzu/(ub-x)) with rzl, rzu recomputed from beta_mu
 // (the d1 build of solveKKTDiagSystem :2091-2108 followed by mat->apply :2139)
 int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
-         double *t);
+         double *t, const double *cl = nullptr, const double *cu = nullptr);
+// Mehrotra corrector products of the affine step (addMehrotraCorrectorResidual :1765-1788)
+int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
+                int64_t n, double *cl, double *cu);
 // Second half of the bordered solve.  acc = sum_j alpha_j P_j ; dx = t + Dinv*acc.
 //   first solve  (refine == 0): px = dx; pzl = [L](rzl - zl dx)/(x-lb); pzu = [U](rzu + zu dx)/(ub-x)
 //   refinement   (refine == 1): r'zl = rzl - [L]((x-lb) pzl + px zl), r'zu likewise;
@@ -138,7 +142,8 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
              const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
              double *px, double *pzl, double *pzu, double out[2], const double *coef2 = nullptr,
              const double *rx = nullptr, double diag = 0.0, double *tout = nullptr,
-             double *va = nullptr, int nca = 0);
+             double *va = nullptr, int nca = 0, const double *cl = nullptr,
+             const double *cu = nullptr);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

@@ -200,7 +200,8 @@ InteriorPoint::InteriorPoint(Problem *p)
       iter_cb_user(nullptr), px(nullptr), pzl(nullptr), pzu(nullptr), Dinv(nullptr), rx(nullptr),
       tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), vA(nullptr), qn_created(false), wk(0),
       comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0),
-      ptpx_valid(false), residual_fused(false), residual_cached(false), phase_t0(0) {
+      ptpx_valid(false), residual_fused(false), residual_cached(false), corrector_active(false),
+      norm_type(0), phase_t0(0) {
   qn_handle.qn = nullptr;
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
@@ -416,37 +417,67 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
 
 int InteriorPoint::computeResidual(double mu, bool vectors) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
+  double out[11];
   if (vectors) {
     std::vector<const double *> A;
     for (Vec *a : Ac) A.push_back(a->d);
-    double out[5];
     PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), vars.z.data(), c, beta_mu, n, rx->d, out));
-    comp_prod = out[0];
-    comp_count = out[1];
-    max_rx = out[2];
-    max_rzl = out[3];
-    max_rzu = out[4];
+    l1_rx = out[2];
+    l2_rx = out[5];
+    max_rx = out[8];
   } else {
-    double out[4];
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
-    comp_prod = out[0];
-    comp_count = out[1];
-    max_rzl = out[2];
-    max_rzu = out[3];
   }
+  comp_prod = out[0];
+  comp_count = out[1];
+  l1_rzl = out[3];
+  l1_rzu = out[4];
+  l2_rzl = out[6];
+  l2_rzu = out[7];
+  max_rzl = out[9];
+  max_rzu = out[10];
   return PO_OK;
 }
 
 void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual,
-                             double *max_infeas, double *res_norm) const {  // :1588-1723 (infinity)
-  double mp = max_rx, md = 0.0, mi = 0.0;
-  for (int i = 0; i < c; i++) {
-    mp = std::max(mp, std::max(fabs(r.s[i]), fabs(r.t[i])));
-    mi = std::max(mi, fabs(r.z[i]));
-    md = std::max(md, std::max(fabs(r.zs[i]), fabs(r.zt[i])));
+                             double *max_infeas, double *res_norm) const {  // :1588-1723
+  double mp = 0.0, md = 0.0, mi = 0.0;
+  if (norm_type == 0) {  // infinity
+    mp = max_rx;
+    for (int i = 0; i < c; i++) {
+      mp = std::max(mp, std::max(fabs(r.s[i]), fabs(r.t[i])));
+      mi = std::max(mi, fabs(r.z[i]));
+      md = std::max(md, std::max(fabs(r.zs[i]), fabs(r.zt[i])));
+    }
+    if (use_lower) md = std::max(md, max_rzl);
+    if (use_upper) md = std::max(md, max_rzu);
+  } else if (norm_type == 1) {  // l1
+    mp = l1_rx;
+    for (int i = 0; i < c; i++) {
+      mp += fabs(r.s[i]);
+      mp += fabs(r.t[i]);
+      mi += fabs(r.z[i]);
+      md += fabs(r.zs[i]);
+      md += fabs(r.zt[i]);
+    }
+    if (use_lower) md += l1_rzl;
+    if (use_upper) md += l1_rzu;
+  } else {  // l2
+    double prime = 0.0, infeas = 0.0, dual = 0.0;
+    for (int i = 0; i < c; i++) {
+      prime += r.s[i] * r.s[i] + r.t[i] * r.t[i];
+      infeas += r.z[i] * r.z[i];
+      dual += r.zs[i] * r.zs[i] + r.zt[i] * r.zt[i];
+    }
+    mp = l2_rx + prime;
+    mi = infeas;
+    md = dual;
+    if (use_lower) md += l2_rzl;
+    if (use_upper) md += l2_rzu;
+    mp = sqrt(mp);
+    mi = sqrt(mi);
+    md = sqrt(md);
   }
-  if (use_lower) md = std::max(md, max_rzl);
-  if (use_upper) md = std::max(md, max_rzu);
   *max_prime = mp;
   *max_dual = md;
   *max_infeas = mi;
@@ -463,7 +494,7 @@ double InteriorPoint::compFromSums(double prod, double count, const Dense &v) co
 }
 
 int InteriorPoint::getComplementarity(double *comp) {
-  double out[4];
+  double out[11];
   PO_TRY(k_res_norms(ctx, bounds(), 0.0, n, out));
   *comp = compFromSums(out[0], out[1], vars);
   return PO_OK;
@@ -529,7 +560,9 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     return PO_ERR_ARG;
   }
   const int m = c + k;
-  if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d));
+  const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
+  const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
+  if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
   std::vector<double> dots(m > 0 ? m : 1, 0.0);
   if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
   // yz = G^-1 (d3 - A yx0)   (:2150-2159)
@@ -586,7 +619,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   }
   PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
                   refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins,
-                  fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c));
+                  fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c, cl, cu));
   residual_fused = fuse;
   // dense blocks: full solve (:2165-2170) minus the bx-only solve (:2300-2305)
   for (int i = 0; i < c; i++) {
@@ -1031,22 +1064,21 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const double rel_func_tol = options.real("rel_func_tol");
   const double fprec = options.real("function_precision");
   const double design_precision = options.real("design_precision");
-  if (std::string(options.str("norm_type")) != "infinity") {
-    set_error("norm_type=%s is not implemented on the device path (only infinity)",
-              options.str("norm_type"));
-    return PO_ERR_OPTION;
+  {
+    const std::string nt = options.str("norm_type");
+    norm_type = nt == "infinity" ? 0 : (nt == "l1" ? 1 : 2);
   }
   const std::string bname = options.str("barrier_strategy");
-  if (bname != "monotone" && bname != "complementarity_fraction") {
-    set_error("barrier_strategy=%s is not implemented on the device path", bname.c_str());
-    return PO_ERR_OPTION;
-  }
+  enum { B_MONOTONE = 0, B_MEHROTRA = 1, B_MPC = 2, B_COMPFRAC = 3 };
+  const int input_strategy = bname == "monotone" ? B_MONOTONE
+                             : bname == "mehrotra" ? B_MEHROTRA
+                             : bname == "mehrotra_predictor_corrector" ? B_MPC : B_COMPFRAC;
+  int barrier_strategy = B_MONOTONE;  // always start monotone (:4427-4441)
+  corrector_active = false;
   if (options.integer("use_hvec_product") || options.integer("use_diag_hessian")) {
     set_error("use_hvec_product / use_diag_hessian are not implemented on the device path");
     return PO_ERR_OPTION;
   }
-  const bool input_monotone = (bname == "monotone");
-  bool monotone = true;  // always start monotone (:4427-4441)
   barrier_param = options.real("init_barrier_param");
   rho_penalty_search = options.real("init_rho_penalty_search");
   const int max_major_iters = options.integer("max_major_iters");
@@ -1123,7 +1155,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
     double max_prime = 0.0, max_dual = 0.0, max_infeas = 0.0, res_norm = 0.0;
     int monotone_barrier_converged = 0;
     double comp = 0.0;
-    if (monotone) {
+    if (barrier_strategy == B_MONOTONE) {
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
       comp = compFromSums(comp_prod, comp_count, vars);
@@ -1145,6 +1177,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
         rho_penalty_search = options.real("min_rho_penalty_search");
         barrier_param = new_mu;
       }
+    } else if (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC) {  // :4737-4746
+      if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
+      residual_cached = false;
+      comp = compFromSums(comp_prod, comp_count, vars);
+      denseResidual(barrier_param, res);
+      resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
     } else {  // complementarity fraction (:4747-4762)
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
@@ -1201,13 +1239,58 @@ int InteriorPoint::optimize(const char *checkpoint) {
     int seq_linear_step = 0, diagonal_quasi_newton_step = 0;
     bool use_qn = !seq_lin;
 
+    const bool mehrotra = (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC);
     double tau = min_frac;
-    const double tau_mu = 1.0 - barrier_param;
-    if (tau_mu >= tau) tau = tau_mu;
+    if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
 
     PO_TRY(setUpKKTSystem(use_qn));
     phaseEnd("setup_kkt");
-    PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
+    if (!mehrotra) {
+      PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
+    } else {
+      // affine (mu = 0) predictor step, probed all the way to the boundary (:4956-5009)
+      PO_TRY(computeKKTStepWithRefinement(0.0, use_qn, 1.0));
+      double max_x = std::min(1.0, step_mins[0]), max_z = std::min(1.0, step_mins[1]);
+      for (int i = 0; i < c; i++) {
+        if (step.s[i] < 0.0) max_x = std::min(max_x, -vars.s[i] / step.s[i]);
+        if (step.t[i] < 0.0) max_x = std::min(max_x, -vars.t[i] / step.t[i]);
+        if (step.zs[i] < 0.0) max_z = std::min(max_z, -vars.zs[i] / step.zs[i]);
+        if (step.zt[i] < 0.0) max_z = std::min(max_z, -vars.zt[i] / step.zt[i]);
+      }
+      double cs[2];
+      PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
+      double prod = cs[0] / options.real("rel_bound_barrier"), count = cs[1];
+      for (int i = 0; i < c; i++) {
+        prod += ((vars.s[i] + max_x * step.s[i]) * (vars.zs[i] + max_z * step.zs[i]) +
+                 (vars.t[i] + max_x * step.t[i]) * (vars.zt[i] + max_z * step.zt[i]));
+        count += 2.0;
+      }
+      const double comp_affine = count != 0.0 ? prod / count : 0.0;
+      const double s1 = comp_affine / comp;
+      double sigma = s1 * s1 * s1;
+      if (sigma < 0.01) sigma = 0.01;
+      barrier_param = sigma * comp;
+      if (barrier_param < 0.09999 * abs_res_tol) barrier_param = 0.09999 * abs_res_tol;
+      tau = min_frac;
+      if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
+      if (barrier_strategy == B_MPC) {
+        // corrector: res.zl -= px*pzl, res.zu += px*pzu, res.zs -= ps*pzs, res.zt -= pt*pzt of the
+        // affine step (:1729-1789); no refinement with the corrector (:5040-5041)
+        PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
+        denseResidual(barrier_param, res);
+        for (int i = 0; i < c; i++) {
+          res.zs[i] -= step.s[i] * step.zs[i];
+          res.zt[i] -= step.t[i] * step.zt[i];
+        }
+        corrector_active = true;
+        int rcs = solveKKT(res, barrier_param, use_qn, false, tau, step);
+        corrector_active = false;
+        PO_TRY(rcs);
+        sx = sz = 1.0;
+      } else {
+        PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
+      }
+    }
     phaseEnd("kkt_step");
 
     double alpha_x = 1.0, alpha_z = 1.0;
@@ -1310,7 +1393,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
       memset(info, 0, sizeof(info));
       strncpy(info, s.c_str(), sizeof(info) - 1);
     }
-    if (monotone_barrier_converged) monotone = input_monotone;
+    if (monotone_barrier_converged) barrier_strategy = input_strategy;
   }
   return 0;
 }

@@ -108,6 +108,7 @@ class InteriorPoint {
   std::vector<int> gpiv, cpiv;
   // residual bookkeeping of the last computeResidual call
   double comp_prod, comp_count, max_rx, max_rzl, max_rzu;
+  double l1_rx = 0, l1_rzl = 0, l1_rzu = 0, l2_rx = 0, l2_rzl = 0, l2_rzu = 0;
   // lazily applied step scalings (scaleKKTStep :3253-3268)
   double sx, sz;
   double step_mins[2];
@@ -118,6 +119,8 @@ class InteriorPoint {
   bool ptpx_valid;
   bool residual_fused;  // the last first-pass solve already wrote the refinement rhs t'
   bool residual_cached; // rx / norms of the CURRENT state were already evaluated (step update)
+  bool corrector_active;  // Mehrotra predictor-corrector: s_qn / y_qn hold the corrector products
+  int norm_type;          // 0 infinity, 1 l1, 2 l2 (ParOptNormType)
 
   Bounds bounds() const;
   std::vector<const double *> panel(bool use_qn, int *k) const;

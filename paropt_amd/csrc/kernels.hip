@@ -672,11 +672,31 @@ __device__ __forceinline__ BE bound_elem(double x, double lb, double ub, double 
   }
 
 // rx, complementarity, residual norms -----------------------------------------------------------
+// sums: {comp product, active count, l1|rx|, l1|rzl|, l1|rzu|, l2 rx, l2 rzl, l2 rzu}; maxs: {rx, rzl, rzu}
+__device__ __forceinline__ void res_bound_acc(const BE &e, double beta_mu, double *sums, double *maxs,
+                                              int il1, int il2, int imax) {
+  if (e.L) {
+    sums[0] += e.zl * e.xl;
+    sums[1] += 1.0;
+    const double r = fabs(-(e.xl * e.zl - beta_mu));
+    sums[il1] += r;
+    sums[il2] += r * r;
+    maxs[imax] = fmax(maxs[imax], r);
+  }
+  if (e.U) {
+    sums[0] += e.zu * e.xu;
+    sums[1] += 1.0;
+    const double r = fabs(-(e.xu * e.zu - beta_mu));
+    sums[il1 + 1] += r;
+    sums[il2 + 1] += r * r;
+    maxs[imax + 1] = fmax(maxs[imax + 1], r);
+  }
+}
 __global__ void __launch_bounds__(kBlock)
     kkt_res_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc,
                    double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ partials) {
-  __shared__ double sm[4 * 3];
-  double sums[2] = {0.0, 0.0};  // comp product, active count
+  __shared__ double sm[4 * 8];
+  double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[3] = {0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
@@ -696,79 +716,47 @@ __global__ void __launch_bounds__(kBlock)
     if (!_has2) r.y = 0.0;
     st2(rx, q, n, r);
     maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
-    if (e0.L) {
-      sums[0] += e0.zl * e0.xl;
-      sums[1] += 1.0;
-      maxs[1] = fmax(maxs[1], fabs(-(e0.xl * e0.zl - beta_mu)));
-    }
-    if (e1.L) {
-      sums[0] += e1.zl * e1.xl;
-      sums[1] += 1.0;
-      maxs[1] = fmax(maxs[1], fabs(-(e1.xl * e1.zl - beta_mu)));
-    }
-    if (e0.U) {
-      sums[0] += e0.zu * e0.xu;
-      sums[1] += 1.0;
-      maxs[2] = fmax(maxs[2], fabs(-(e0.xu * e0.zu - beta_mu)));
-    }
-    if (e1.U) {
-      sums[0] += e1.zu * e1.xu;
-      sums[1] += 1.0;
-      maxs[2] = fmax(maxs[2], fabs(-(e1.xu * e1.zu - beta_mu)));
-    }
+    sums[2] += fabs(r.x) + fabs(r.y);
+    sums[5] += r.x * r.x + r.y * r.y;
+    res_bound_acc(e0, beta_mu, sums, maxs, 3, 6, 1);
+    res_bound_acc(e1, beta_mu, sums, maxs, 3, 6, 1);
   }
-  block_reduce_store<2, OP_SUM>(sums, partials, 0, sm);
-  block_reduce_store<3, OP_MAX>(maxs, partials, 2, sm);
+  block_reduce_store<8, OP_SUM>(sums, partials, 0, sm);
+  block_reduce_store<3, OP_MAX>(maxs, partials, 8, sm);
 }
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[5]) {
+              int nc, double beta_mu, int64_t n, double *rx, double out[11]) {
   const int grid = grid_for(c, n, 3);
-  PO_TRY(ensure_partials(c, (size_t)grid * 5));
+  PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
   PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, c->d_partials);
-  return reduce_finish(c, grid, 2, 0, 3, out);
+  return reduce_finish(c, grid, 8, 0, 3, out);
 }
 
+// the mu-dependent part only: sums {comp product, count, -, l1 rzl, l1 rzu, -, l2 rzl, l2 rzu}
+// (slots 2 and 5 stay zero so the layout matches kkt_res_kernel), maxs {-, rzl, rzu}
 __global__ void __launch_bounds__(kBlock)
     res_norms_kernel(Bounds b, double beta_mu, int64_t n, double *__restrict__ partials) {
-  __shared__ double sm[4 * 2];
-  double sums[2] = {0.0, 0.0};
-  double maxs[2] = {0.0, 0.0};
+  __shared__ double sm[4 * 8];
+  double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double maxs[3] = {0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
-    if (e0.L) {
-      sums[0] += e0.zl * e0.xl;
-      sums[1] += 1.0;
-      maxs[0] = fmax(maxs[0], fabs(-(e0.xl * e0.zl - beta_mu)));
-    }
-    if (e1.L) {
-      sums[0] += e1.zl * e1.xl;
-      sums[1] += 1.0;
-      maxs[0] = fmax(maxs[0], fabs(-(e1.xl * e1.zl - beta_mu)));
-    }
-    if (e0.U) {
-      sums[0] += e0.zu * e0.xu;
-      sums[1] += 1.0;
-      maxs[1] = fmax(maxs[1], fabs(-(e0.xu * e0.zu - beta_mu)));
-    }
-    if (e1.U) {
-      sums[0] += e1.zu * e1.xu;
-      sums[1] += 1.0;
-      maxs[1] = fmax(maxs[1], fabs(-(e1.xu * e1.zu - beta_mu)));
-    }
+    res_bound_acc(e0, beta_mu, sums, maxs, 3, 6, 1);
+    res_bound_acc(e1, beta_mu, sums, maxs, 3, 6, 1);
   }
-  block_reduce_store<2, OP_SUM>(sums, partials, 0, sm);
-  block_reduce_store<2, OP_MAX>(maxs, partials, 2, sm);
+  block_reduce_store<8, OP_SUM>(sums, partials, 0, sm);
+  block_reduce_store<3, OP_MAX>(maxs, partials, 8, sm);
 }
 
-int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[4]) {
+int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]) {
   const int grid = grid_for(c, n);
-  PO_TRY(ensure_partials(c, (size_t)grid * 4));
+  PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PO_LAUNCH(res_norms_kernel, grid, b, beta_mu, n, c->d_partials);
-  return reduce_finish(c, grid, 2, 0, 2, out);
+  return reduce_finish(c, grid, 8, 0, 3, out);
 }
 
 // Dinv ------------------------------------------------------------------------------------------
@@ -792,25 +780,54 @@ int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv) {
 }
 
 // t = Dinv * d1 -----------------------------------------------------------------------------------
-__device__ __forceinline__ double d1_elem(const BE &e, double rx, double beta_mu) {
+// cl / cu: Mehrotra corrector terms (addMehrotraCorrectorResidual :1765-1788), zero otherwise
+__device__ __forceinline__ double d1_elem(const BE &e, double rx, double beta_mu, double cl = 0.0,
+                                          double cu = 0.0) {
   double d1 = rx;
-  if (e.L) d1 += (-(e.xl * e.zl - beta_mu)) / e.xl;
-  if (e.U) d1 -= (-(e.xu * e.zu - beta_mu)) / e.xu;
+  if (e.L) d1 += (-(e.xl * e.zl - beta_mu) - cl) / e.xl;
+  if (e.U) d1 -= (-(e.xu * e.zu - beta_mu) + cu) / e.xu;
   return d1;
 }
 __global__ void __launch_bounds__(kBlock)
     d1_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ dinv,
-              double beta_mu, int64_t n, double *__restrict__ t) {
+              double beta_mu, const double *__restrict__ cl, const double *__restrict__ cu, int64_t n,
+              double *__restrict__ t) {
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
     const double2 r = ld2(rx, q, n), dv = ld2(dinv, q, n);
-    st2(t, q, n, make_double2(dv.x * d1_elem(e0, r.x, beta_mu), dv.y * d1_elem(e1, r.y, beta_mu)));
+    double2 c0 = make_double2(0.0, 0.0), c1 = c0;
+    if (cl) {
+      c0 = ld2(cl, q, n);
+      c1 = ld2(cu, q, n);
+    }
+    st2(t, q, n,
+        make_double2(dv.x * d1_elem(e0, r.x, beta_mu, c0.x, c1.x),
+                     dv.y * d1_elem(e1, r.y, beta_mu, c0.y, c1.y)));
   }
 }
 int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
-         double *t) {
+         double *t, const double *cl, const double *cu) {
   if (n <= 0) return PO_OK;
-  PO_LAUNCH(d1_kernel, grid_for(c, n), b, rx, dinv, beta_mu, n, t);
+  PO_LAUNCH(d1_kernel, grid_for(c, n), b, rx, dinv, beta_mu, cl, cu, n, t);
+  return PO_OK;
+}
+
+// corrector products of the affine step: cl = [L] px*pzl, cu = [U] px*pzu
+__global__ void __launch_bounds__(kBlock)
+    corrector_kernel(Bounds b, const double *__restrict__ px, const double *__restrict__ pzl,
+                     const double *__restrict__ pzu, int64_t n, double *__restrict__ cl,
+                     double *__restrict__ cu) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    st2(cl, q, n, make_double2(e0.L ? p.x * l.x : 0.0, e1.L ? p.y * l.y : 0.0));
+    st2(cu, q, n, make_double2(e0.U ? p.x * u.x : 0.0, e1.U ? p.y * u.y : 0.0));
+  }
+}
+int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
+                int64_t n, double *cl, double *cu) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(corrector_kernel, grid_for(c, n), b, px, pzl, pzu, n, cl, cu);
   return PO_OK;
 }
 
@@ -820,10 +837,11 @@ struct Step3 {
 };
 template <int REFINE>
 __device__ __forceinline__ Step3 solve2_elem(const BE &e, double dx, double beta_mu, double px0,
-                                             double pzl0, double pzu0) {
+                                             double pzl0, double pzu0, double cl = 0.0,
+                                             double cu = 0.0) {
   Step3 s;
-  const double rzl = e.L ? -(e.xl * e.zl - beta_mu) : 0.0;
-  const double rzu = e.U ? -(e.xu * e.zu - beta_mu) : 0.0;
+  const double rzl = e.L ? -(e.xl * e.zl - beta_mu) - cl : 0.0;
+  const double rzu = e.U ? -(e.xu * e.zu - beta_mu) + cu : 0.0;
   if (REFINE) {
     const double rzl2 = e.L ? rzl - (e.xl * pzl0 + px0 * e.zl) : 0.0;
     const double rzu2 = e.U ? rzu - (e.xu * pzu0 - px0 * e.zu) : 0.0;
@@ -879,7 +897,8 @@ __global__ void __launch_bounds__(kBlock)
                   CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
                   const double *__restrict__ rx, double diag, int64_t n, double *__restrict__ px,
                   double *__restrict__ pzl, double *__restrict__ pzu, double *tout,
-                  double *__restrict__ va, int nca, double *__restrict__ partials) {
+                  double *__restrict__ va, int nca, const double *__restrict__ cl,
+                  const double *__restrict__ cu, double *__restrict__ partials) {
   __shared__ double sm[4 * 2];
   double mins[2] = {1.0, 1.0};
   PO_PAIR_LOOP(q, n) {
@@ -914,8 +933,13 @@ __global__ void __launch_bounds__(kBlock)
       l0 = ld2(pzl, q, n);
       u0 = ld2(pzu, q, n);
     }
-    const Step3 s0 = solve2_elem<REFINE>(e0, dx0, beta_mu, p0.x, l0.x, u0.x);
-    Step3 s1 = solve2_elem<REFINE>(e1, dx1, beta_mu, p0.y, l0.y, u0.y);
+    double2 c0 = make_double2(0.0, 0.0), c1 = c0;
+    if (!REFINE && !FUSE && cl) {
+      c0 = ld2(cl, q, n);
+      c1 = ld2(cu, q, n);
+    }
+    const Step3 s0 = solve2_elem<REFINE>(e0, dx0, beta_mu, p0.x, l0.x, u0.x, c0.x, c1.x);
+    Step3 s1 = solve2_elem<REFINE>(e1, dx1, beta_mu, p0.y, l0.y, u0.y, c0.y, c1.y);
     if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
     st2(px, q, n, make_double2(s0.px, s1.px));
     st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
@@ -937,7 +961,8 @@ __global__ void __launch_bounds__(kBlock)
 int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
              const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
              double *px, double *pzl, double *pzu, double out[2], const double *coef2,
-             const double *rx, double diag, double *tout, double *va, int nca) {
+             const double *rx, double diag, double *tout, double *va, int nca, const double *cl,
+             const double *cu) {
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -950,13 +975,13 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
   fill_tables(coef2, P, nv, &ct2, &pt);
   if (refine) {
     PO_LAUNCH((solve2_kernel<1, 0>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
-              pzl, pzu, tout, va, nca, c->d_partials);
+              pzl, pzu, tout, va, nca, cl, cu, c->d_partials);
   } else if (coef2) {
     PO_LAUNCH((solve2_kernel<0, 1>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
-              pzl, pzu, tout, va, nca, c->d_partials);
+              pzl, pzu, tout, va, nca, cl, cu, c->d_partials);
   } else {
     PO_LAUNCH((solve2_kernel<0, 0>), grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, px,
-              pzl, pzu, tout, va, nca, c->d_partials);
+              pzl, pzu, tout, va, nca, cl, cu, c->d_partials);
   }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
