@@ -235,6 +235,17 @@ case(
 )
 
 
+# solution-file format: written at iterations 0 and 10, the file left behind is iteration 10's
+case(
+    "ip_quadratic_checkpoint_n130_c3",
+    "ip",
+    problem="quadratic",
+    n=130,
+    c=3,
+    dump_vecs_every=10,
+    checkpoint=1,
+    **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}),
+)
 for strat in ("mehrotra", "mehrotra_predictor_corrector"):
     case(
         "ip_quadratic_%s_n300_c3" % ("mpc" if "corrector" in strat else "mehrotra"),
@@ -284,8 +295,13 @@ def main():
             dargs["out"] = rec
             if mode == "ip":
                 dargs["text"] = os.path.join(td, "paropt.out")
+            if dargs.get("checkpoint"):
+                dargs["checkpoint"] = os.path.join(td, "checkpoint.bin")
             run_driver(mode, dargs, ranks)
             d = read_rec(rec)
+            if dargs.get("checkpoint"):
+                # the reference's binary solution file (src/ParOptInteriorPoint.cpp:883-972), verbatim
+                d["checkpoint_bytes"] = np.fromfile(dargs["checkpoint"], dtype=np.uint8)
             if mode == "ip":
                 with open(dargs["text"]) as f:
                     lines = [ln.rstrip("\n") for ln in f]

@@ -584,7 +584,8 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
     R.i32s("c", c);
   }
   double t0 = MPI_Wtime();
-  int rc = ip->optimize(NULL);
+  std::string ckpt = gets(A, "checkpoint", "");
+  int rc = ip->optimize(ckpt.size() ? ckpt.c_str() : NULL);
   double t1 = MPI_Wtime();
   int niter, neval, ngeval;
   ip->getIterationCounters(&niter, &neval, &ngeval);

@@ -388,6 +388,12 @@ class InteriorPoint:
             raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
         return rc
 
+    def writeSolutionFile(self, filename):
+        check(lib.po_ip_write_solution_file(self._h, filename.encode()))
+
+    def readSolutionFile(self, filename):
+        check(lib.po_ip_read_solution_file(self._h, filename.encode()))
+
     def getOptimizedPoint(self):
         x, zl, zu = L.po_vec(), L.po_vec(), L.po_vec()
         z = L.c_double_p()

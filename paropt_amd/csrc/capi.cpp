@@ -459,6 +459,11 @@ int po_ip_write_solution_file(po_ip ip, const char *filename) {
   PO_CHECK_PTR(filename);
   return ip->ip->writeSolutionFile(filename);
 }
+int po_ip_read_solution_file(po_ip ip, const char *filename) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(filename);
+  return ip->ip->readSolutionFile(filename);
+}
 int po_ip_set_iteration_callback(po_ip ip, po_ip_iteration_fn fn, void *user) {
   PO_CHECK_PTR(ip);
   ip->ip->iter_cb = fn;

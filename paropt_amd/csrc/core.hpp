@@ -95,6 +95,9 @@ int k_axpy(Ctx *c, double *y, double alpha, const double *x, int64_t n);
 // y <- a*x + b*y + sum_j alpha[j]*V[j]   (x may be null when a == 0; b == 0 never reads y)
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
                  const double *const *V, int nv, int64_t n);
+// dst_j <- a*X_j + b*Y_j, j < nv, one launch (Y may be null)
+int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X, double b,
+                    const double *const *Y, int nv, int64_t n);
 enum Red1 { RED_DOT = 0, RED_SUMSQ = 1, RED_ASUM = 2, RED_AMAX = 3 };
 int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out);
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out);

@@ -1432,4 +1432,41 @@ int InteriorPoint::writeSolutionFile(const char *filename) {
   return PO_OK;
 }
 
+// readSolutionFile (:983-1104): restart state written by writeSolutionFile (same layout)
+int InteriorPoint::readSolutionFile(const char *filename) {
+  std::string name = filename;
+  if (ctx->size > 1) name += "." + std::to_string(ctx->rank);
+  FILE *fp = fopen(name.c_str(), "rb");
+  if (!fp) {
+    set_error("cannot open solution file %s", name.c_str());
+    return PO_ERR_ARG;
+  }
+  int sizes[3] = {0, 0, 0};
+  bool ok = fread(sizes, sizeof(int), 3, fp) == 3;
+  if (!ok || sizes[0] != (int)prob->nglobal || sizes[1] != 0 || sizes[2] != c) {
+    fclose(fp);
+    set_error("ParOpt: Problem size incompatible with solution file");
+    return PO_ERR_ARG;
+  }
+  ok = ok && fread(&barrier_param, sizeof(double), 1, fp) == 1;
+  std::vector<double> *blocks[5] = {&vars.s, &vars.t, &vars.z, &vars.zs, &vars.zt};
+  for (auto *b : blocks) ok = ok && fread(b->data(), sizeof(double), c, fp) == (size_t)c;
+  std::vector<double> host((size_t)(n > 0 ? n : 1));
+  Vec *vs[3] = {x, zl, zu};
+  for (Vec *v : vs) {
+    ok = ok && fread(host.data(), sizeof(double), (size_t)n, fp) == (size_t)n;
+    if (ok && (hipMemcpyAsync(v->d, host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
+                              ctx->stream) != hipSuccess ||
+               hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+      ok = false;
+    }
+  }
+  fclose(fp);
+  if (!ok) {
+    set_error("short read or upload failure on solution file %s", name.c_str());
+    return PO_ERR_ARG;
+  }
+  return PO_OK;
+}
+
 }  // namespace po

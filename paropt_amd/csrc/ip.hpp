@@ -64,6 +64,7 @@ class InteriorPoint {
   int resetDesignAndBounds();
   void resetQuasiNewtonHessian();
   int writeSolutionFile(const char *filename);
+  int readSolutionFile(const char *filename);
   int debugKKTStep(double mu);
 
   Problem *prob;

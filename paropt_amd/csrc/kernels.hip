@@ -319,6 +319,45 @@ int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const d
   return PO_OK;
 }
 
+// dst_j <- a*X_j + b*Y_j for a whole panel in ONE launch (constraint-Jacobian copies of the built-in
+// problems, L-SR1's Z_j = Y_j - b0 S_j rebuild): same bytes as nv separate launches, nv-1 fewer
+// launches per call, which matters once the per-GPU shard is small (multi-GPU strong scaling).
+struct PtrTableW {
+  double *p[kMaxPanel];
+};
+__global__ void __launch_bounds__(kBlock)
+    panel_lincomb_kernel(PtrTableW dst, double a, PtrTable X, double b, PtrTable Y, int nv, int has_y,
+                         int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    for (int j = 0; j < nv; j++) {
+      const f64x2 xv = ld_stream(X.p[j] + 2 * q);
+      double2 r = make_double2(a * xv.x, a * xv.y);
+      if (has_y) {
+        const f64x2 yv = ld_stream(Y.p[j] + 2 * q);
+        r.x += b * yv.x;
+        r.y += b * yv.y;
+      }
+      st2(dst.p[j], q, n, r);
+    }
+  }
+}
+int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X, double b,
+                    const double *const *Y, int nv, int64_t n) {
+  if (n <= 0 || nv <= 0) return PO_OK;
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  PtrTableW d;
+  PtrTable x, y;
+  CoefTable ct;
+  for (int j = 0; j < kMaxPanel; j++) d.p[j] = j < nv ? dst[j] : nullptr;
+  fill_tables(nullptr, X, nv, &ct, &x);
+  fill_tables(nullptr, Y, Y ? nv : 0, &ct, &y);
+  PO_LAUNCH(panel_lincomb_kernel, grid_for(c, n), d, a, x, b, y, nv, Y ? 1 : 0, n);
+  return PO_OK;
+}
+
 // dot / sum of squares / asum / amax
 template <int KIND>
 __global__ void __launch_bounds__(kBlock)

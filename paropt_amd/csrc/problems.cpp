@@ -147,11 +147,20 @@ int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   }
   if (kind == PO_PROBLEM_QUADRATIC) {
     PO_TRY(k_quadratic_g(ctx, q->d, b->d, x->d, n, g->d));
-    for (int j = 0; j < ncon; j++) PO_TRY(k_copy(ctx, Ac[j]->d, A[j]->d, n));
   } else {
     PO_TRY(k_convex_g(ctx, b->d, x->d, n, g->d));
-    for (int j = 0; j < ncon; j++)
-      PO_TRY(k_panel_axpy(ctx, Ac[j]->d, -1.0, A[j]->d, 0.0, nullptr, nullptr, 0, n));
+  }
+  // the constraint Jacobian is rewritten at every gradient evaluation, as the reference's example
+  // problems do (examples/random_convex/random_convex.py:67-71): Ac_j = +-a_j, one launch
+  std::vector<double *> dst;
+  std::vector<const double *> src;
+  for (int j = 0; j < ncon; j++) {
+    dst.push_back(Ac[j]->d);
+    src.push_back(A[j]->d);
+  }
+  if (ncon > 0) {
+    PO_TRY(k_panel_lincomb(ctx, dst.data(), kind == PO_PROBLEM_QUADRATIC ? 1.0 : -1.0, src.data(), 0.0,
+                           nullptr, ncon, n));
   }
   return PO_OK;
 }

@@ -289,12 +289,15 @@ int LSR1::update(Vec *s, Vec *y, int *rc) {  // :636-747
   // Z_i = Y_i - b0 S_i re-materialised for every held pair (:730-735), one fused pass each
   Z.clear();
   d0.assign(k, 1.0);
+  std::vector<double *> zd;
+  std::vector<const double *> yp, sp;
   for (int i = 0; i < k; i++) {
-    const double a = -b0;
-    const double *sp = S[i]->d;
-    PO_TRY(k_panel_axpy(ctx, Zown[i]->d, 1.0, Y[i]->d, 0.0, &a, &sp, 1, n));
+    zd.push_back(Zown[i]->d);
+    yp.push_back(Y[i]->d);
+    sp.push_back(S[i]->d);
     Z.push_back(Zown[i]);
   }
+  PO_TRY(k_panel_lincomb(ctx, zd.data(), 1.0, yp.data(), -b0, sp.data(), k, n));
   factorM();
   return PO_OK;
 }

@@ -131,6 +131,7 @@ SIGNATURES = {
     "po_ip_reset_quasi_newton": (C.c_int, [po_ip]),
     "po_ip_get_quasi_newton": (C.c_int, [po_ip, C.POINTER(po_qn)]),
     "po_ip_write_solution_file": (C.c_int, [po_ip, C.c_char_p]),
+    "po_ip_read_solution_file": (C.c_int, [po_ip, C.c_char_p]),
     "po_ip_set_iteration_callback": (C.c_int, [po_ip, ITER_FN, C.c_void_p]),
     "po_ip_get_history": (C.c_int, [po_ip, C.POINTER(C.c_char_p)]),
     "po_ip_get_phase_times": (C.c_int, [po_ip, C.POINTER(C.c_char_p), C.POINTER(c_double_p), c_int_p]),

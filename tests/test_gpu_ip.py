@@ -58,7 +58,7 @@ def run_gpu(ctx, case, want_vectors=False):
     return ip, snaps
 
 
-IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2")]
+IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2") and "checkpoint" not in n]
 
 
 @pytest.mark.parametrize("name", IP_CASES)
@@ -241,3 +241,39 @@ def test_explicit_and_analytic_panel_dots_agree(ctx, monkeypatch):
         np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-8)
     assert info_tokens(a[1]) == info_tokens(b[1])
     np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8)
+
+
+def test_solution_file_format(ctx, tmp_path):
+    """The binary checkpoint of writeSolutionFile (src/ParOptInteriorPoint.cpp:883-972): same
+    layout as the file the reference left behind (header ints bit-exact, payload to 1e-6), and a
+    readSolutionFile round trip."""
+    import struct
+
+    import paropt_amd as pa
+
+    g, case = load_golden("ip_quadratic_checkpoint_n130_c3")
+    ref = g["checkpoint_bytes"].tobytes()
+    a = case["args"]
+    prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a["c"])
+    opts = ip_options_from_case(case)
+    ip = pa.InteriorPoint(prob, opts)
+    path = str(tmp_path / "ckpt.bin")
+    ip.optimize(checkpoint=path)
+    mine = open(path, "rb").read()
+    assert len(mine) == len(ref) == 12 + (5 * a["c"] + 1) * 8 + 3 * a["n"] * 8
+    assert mine[:12] == ref[:12] and struct.unpack("<3i", mine[:12]) == (a["n"], 0, a["c"])
+    pm = np.frombuffer(mine[12:], dtype="<f8")
+    pr = np.frombuffer(ref[12:], dtype="<f8")
+    np.testing.assert_allclose(pm, pr, rtol=1e-6, atol=1e-6 * np.abs(pr).max())
+    # restart: a fresh solver reads the reference's own file
+    refpath = str(tmp_path / "ref.bin")
+    open(refpath, "wb").write(ref)
+    ip2 = pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"], a["c"]), opts)
+    ip2.readSolutionFile(refpath)
+    x, z, zl, zu = ip2.getOptimizedPoint()
+    c = a["c"]
+    np.testing.assert_array_equal(x.to_numpy(), pr[1 + 5 * c: 1 + 5 * c + a["n"]])
+    np.testing.assert_array_equal(z, pr[1 + 2 * c: 1 + 3 * c])
+    assert ip2.getBarrierParameter() == pr[0]
+    with pytest.raises(pa.ParOptAMDError):
+        pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"] + 1, a["c"]), opts).readSolutionFile(refpath)

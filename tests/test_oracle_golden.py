@@ -124,7 +124,7 @@ def info_tokens(paropt_out):
     return toks
 
 
-IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2")]
+IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2") and "checkpoint" not in n]
 
 
 @pytest.mark.parametrize("name", IP_CASES)
@@ -223,3 +223,23 @@ def test_rank_count_independence_of_reference():
     g2, _ = load_golden("ip_convex_n2000_c32_bfgs_r2")
     np.testing.assert_array_equal(g1["final/counters"], g2["final/counters"])
     assert abs(g1["final/fobj"][0] - g2["final/fobj"][0]) <= 1e-9 * abs(g1["final/fobj"][0])
+
+
+def test_reference_checkpoint_layout():
+    """The reference's binary solution file decodes with the layout of DESIGN.md / SURVEY 5.4 and
+    holds the state of the last written iteration (oracle state at iteration 10)."""
+    g, case = load_golden("ip_quadratic_checkpoint_n130_c3")
+    raw = g["checkpoint_bytes"].tobytes()
+    a = case["args"]
+    n, c = a["n"], a["c"]
+    assert len(raw) == 12 + (5 * c + 1) * 8 + 3 * n * 8
+    assert tuple(np.frombuffer(raw[:12], dtype="<i4")) == (n, 0, c)
+    pay = np.frombuffer(raw[12:], dtype="<f8")
+    ip, snaps, rc = run_oracle_ip(case)
+    s10 = snaps[10]
+    assert abs(pay[0] - s10["mu"]) <= 1e-7 * abs(s10["mu"])
+    for i, key in enumerate(("s", "t", "z", "zs", "zt")):
+        np.testing.assert_allclose(pay[1 + i * c: 1 + (i + 1) * c], s10[key], rtol=1e-6, atol=1e-7)
+    off = 1 + 5 * c
+    for i, key in enumerate(("x", "zl", "zu")):
+        np.testing.assert_allclose(pay[off + i * n: off + (i + 1) * n], s10[key], rtol=0, atol=1e-6)
