@@ -349,7 +349,11 @@ class InteriorPoint:
         self._h = L.po_ip()
         check(lib.po_ip_create(problem.handle, C.byref(self._h)))
         self._iter_cb = None
-        for k, v in (options or {}).items():
+        opts = dict(options or {})
+        # the C ABI keeps the reference's default ("paropt.out" in the working directory); the
+        # Python harness only writes the iteration table when asked to
+        opts.setdefault("output_file", "")
+        for k, v in opts.items():
             self.setOption(k, v)
 
     def __del__(self):

@@ -1233,7 +1233,10 @@ int InteriorPoint::optimize(const char *checkpoint) {
       }
       converged = 1;
     }
-    if (converged) break;
+    if (converged) {
+      flushHistory();
+      return 0;
+    }
 
     fobj_prev = fobj;
     int seq_linear_step = 0, diagonal_quasi_newton_step = 0;
@@ -1395,7 +1398,20 @@ int InteriorPoint::optimize(const char *checkpoint) {
     }
     if (monotone_barrier_converged) barrier_strategy = input_strategy;
   }
+  flushHistory();
   return 0;
+}
+
+// The reference streams the iteration table to `output_file` on the root rank (setOutputFile
+// :1297-1309, :4777-4805); here it is accumulated in `history` and written when optimize returns.
+void InteriorPoint::flushHistory() {
+  const std::string fname = options.str("output_file");
+  if (ctx->rank != 0 || fname.empty()) return;
+  FILE *fp = fopen(fname.c_str(), "w");
+  if (!fp) return;
+  fputs("ParOptInteriorPoint (paropt_amd, MI355X)\n", fp);
+  fputs(history.c_str(), fp);
+  fclose(fp);
 }
 
 // rank-local shard of the reference's checkpoint layout (:883-972); rank r writes

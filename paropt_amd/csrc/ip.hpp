@@ -66,6 +66,7 @@ class InteriorPoint {
   int writeSolutionFile(const char *filename);
   int readSolutionFile(const char *filename);
   int debugKKTStep(double mu);
+  void flushHistory();
 
   Problem *prob;
   Ctx *ctx;

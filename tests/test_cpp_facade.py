@@ -37,9 +37,11 @@ def test_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
 @pytest.mark.gpu
 def test_cpp_rosenbrock_matches_reference(tmp_path):
     exe = build(tmp_path)
-    res = subprocess.run([exe, "nvars=100"], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([exe, "nvars=100"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert res.returncode == 0, res.stderr
     out = json.loads(res.stdout.strip().splitlines()[-1])
+    # the C ABI keeps the reference's default output file name
+    assert "iter nobj ngrd nhvc" in open(str(tmp_path / "paropt.out")).read()
     g, _ = load_golden("ip_rosenbrock_n100")
     np.testing.assert_array_equal(np.array([out["niter"], out["neval"], out["ngeval"]]), g["final/counters"])
     assert abs(out["fobj"] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))

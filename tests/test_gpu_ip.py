@@ -277,3 +277,35 @@ def test_solution_file_format(ctx, tmp_path):
     assert ip2.getBarrierParameter() == pr[0]
     with pytest.raises(pa.ParOptAMDError):
         pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"] + 1, a["c"]), opts).readSolutionFile(refpath)
+
+
+def test_output_file_table(ctx, tmp_path):
+    """`output_file` receives the iteration table in the reference's column layout
+    (src/ParOptInteriorPoint.cpp:4777-4801): the values printed by the reference and by the device
+    solver agree to the printed precision for the compared iterations."""
+    import paropt_amd as pa
+
+    g, case = load_golden("ip_quadratic_n257_c3_bfgs")
+    a = case["args"]
+    opts = ip_options_from_case(case)
+    opts["write_output_frequency"] = 0
+    opts["output_file"] = str(tmp_path / "paropt.out")
+    ip = pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"], a["c"]), opts)
+    ip.optimize()
+
+    def rows(text):
+        out = {}
+        for ln in str(text).splitlines():
+            p = ln.split()
+            if len(p) >= 15 and p[0].isdigit():
+                out[int(p[0])] = p
+        return out
+
+    mine, ref = rows(open(opts["output_file"]).read()), rows(g["paropt_out"])
+    assert len(mine) == len(ref)
+    for k in range(1, 20):
+        assert mine[k][:4] == ref[k][:4]                      # iter nobj ngrd nhvc
+        assert mine[k][4:7] == ref[k][4:7]                    # alpha alphx alphz (2 digits)
+        assert abs(float(mine[k][7]) - float(ref[k][7])) <= 2e-5 * max(1.0, abs(float(ref[k][7])))  # fobj
+        assert mine[k][11] == ref[k][11]                      # mu
+        assert mine[k][15:] == ref[k][15:]                    # info tokens
