@@ -201,10 +201,11 @@ InteriorPoint::InteriorPoint(Problem *p)
       tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), vA(nullptr), qn_created(false), wk(0),
       comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0),
       ptpx_valid(false), residual_fused(false), residual_cached(false), corrector_active(false),
-      norm_type(0), phase_t0(0) {
+      norm_type(0), tdots_valid(false), fused_dots(true), phase_t0(0) {
   qn_handle.qn = nullptr;
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
+  if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
   use_lower = prob->useLowerBounds();
   use_upper = prob->useUpperBounds();
   vars.resize(c);
@@ -564,7 +565,12 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
   if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
   std::vector<double> dots(m > 0 ? m : 1, 0.0);
-  if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  if (refine_pass && tdots_valid && (int)tdots.size() == m) {
+    dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
+  } else if (m > 0) {
+    PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  }
+  tdots_valid = false;
   // yz = G^-1 (d3 - A yx0)   (:2150-2159)
   std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
   for (int i = 0; i < c; i++) {
@@ -617,9 +623,21 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
       }
     }
   }
-  PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
-                  refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins,
-                  fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c, cl, cu));
+  if (fuse && fused_dots && m > 0 && !cl) {
+    // one pass: px, pzl, pzu, t' = refinement rhs, and P^T t' for the refinement solve
+    std::vector<double> out(m + 2, 0.0);
+    PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
+                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tvec->d, vA->d, c,
+                         out.data()));
+    tdots.assign(out.begin(), out.begin() + m);
+    tdots_valid = true;
+    step_mins[0] = out[m];
+    step_mins[1] = out[m + 1];
+  } else {
+    PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
+                    refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins,
+                    fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c, cl, cu));
+  }
   residual_fused = fuse;
   // dense blocks: full solve (:2165-2170) minus the bx-only solve (:2300-2305)
   for (int i = 0; i < c; i++) {

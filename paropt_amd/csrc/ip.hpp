@@ -123,6 +123,9 @@ class InteriorPoint {
   bool residual_cached; // rx / norms of the CURRENT state were already evaluated (step update)
   bool corrector_active;  // Mehrotra predictor-corrector: s_qn / y_qn hold the corrector products
   int norm_type;          // 0 infinity, 1 l1, 2 l2 (ParOptNormType)
+  std::vector<double> tdots;  // P^T t' produced by the fused first solve pass
+  bool tdots_valid;
+  bool fused_dots;        // use k_solve2_dots (switch PAROPT_AMD_NO_FUSED_DOTS=1 to compare)
 
   Bounds bounds() const;
   std::vector<const double *> panel(bool use_qn, int *k) const;

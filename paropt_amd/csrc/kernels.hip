@@ -1025,6 +1025,145 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
 
+// -------------------------------------------------------------------------------------------------
+// First solve pass with the refinement residual AND its panel dots fused (one pass over P instead
+// of three: solve2 + res_step + mdot).  Mapping: a workgroup owns tiles of 128 rows; wave w owns the
+// panel columns j = w (mod 4), lane l the rows 2l, 2l+1 of the tile.  Each wave keeps its column
+// slice of the tile in registers (buf), contributes partial row sums  sum_j alpha_j P_j  through
+// 12 KB of LDS, wave 0 runs the element epilogue (px, pzl, pzu, t' = Dinv*d1'), t' is broadcast back
+// through 1 KB of LDS and every wave accumulates  P_j^T t'  for its own columns from registers.
+// -------------------------------------------------------------------------------------------------
+template <int NPASS>
+__global__ void __launch_bounds__(kBlock)
+    solve2_dots_kernel(Bounds b, const double *t, const double *__restrict__ dinv, CoefTable alpha,
+                       CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
+                       const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
+                       double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
+                       double *tout, double *__restrict__ va, int nca, double *__restrict__ partials) {
+  __shared__ double sacc[4 * 64 * 6];
+  __shared__ double stp[128];
+  __shared__ double sm[4 * 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform on purpose: keeps the column pointers and coefficients in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double dotacc[NPASS];
+#pragma unroll
+  for (int it = 0; it < NPASS; it++) dotacc[it] = 0.0;
+  double mins[2] = {1.0, 1.0};
+  const int64_t qlast = (n - 1) >> 1;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int64_t q = tile * 64 + lane;  // pair index
+    const bool in = (2 * q < n);
+    if (!in) q = qlast;
+    f64x2 buf[NPASS];
+#pragma unroll
+    for (int it = 0; it < NPASS; it++) {
+      const int j = wave + 4 * it;
+      buf[it] = ld_stream(P.p[j < nv ? j : 0] + 2 * q);
+    }
+    f64x2 a1 = (f64x2){0.0, 0.0}, a2 = a1, aA = a1;
+#pragma unroll
+    for (int it = 0; it < NPASS; it++) {
+      const int j = wave + 4 * it;  // coefficient tables are zero beyond nv
+      if (!in) buf[it] = (f64x2){0.0, 0.0};
+      const double ca = alpha.a[j], cb = coef2.a[j], cA = j < nca ? ca : 0.0;
+      a1 += ca * buf[it];
+      a2 += cb * buf[it];
+      aA += cA * buf[it];
+    }
+    double *sa = sacc + (wave * 64 + lane) * 6;
+    sa[0] = a1.x;
+    sa[1] = a1.y;
+    sa[2] = a2.x;
+    sa[3] = a2.y;
+    sa[4] = aA.x;
+    sa[5] = aA.y;
+    __syncthreads();
+    if (wave == 0) {
+      double2 acc = make_double2(0.0, 0.0), acc2 = acc, accA = acc;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const double *sp = sacc + (w * 64 + lane) * 6;
+        acc.x += sp[0];
+        acc.y += sp[1];
+        acc2.x += sp[2];
+        acc2.y += sp[3];
+        accA.x += sp[4];
+        accA.y += sp[5];
+      }
+      double2 tp = make_double2(0.0, 0.0);
+      if (in) {
+        PO_LOAD_BOUNDS(b, q, n);
+        const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n), r = ld2(rx, q, n);
+        if (va) st2(va, q, n, accA);
+        const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
+        Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
+        if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+        st2(px, q, n, make_double2(s0.px, s1.px));
+        st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+        st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+        tp.x = res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, dv.x, beta_mu, b.use_lower,
+                             b.use_upper);
+        tp.y = _has2 ? res_step_elem(e1, r.y, acc2.y, diag, s1.px, s1.pzl, s1.pzu, dv.y, beta_mu,
+                                     b.use_lower, b.use_upper)
+                     : 0.0;
+        st2(tout, q, n, tp);
+        max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+        if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+      }
+      stp[2 * lane] = tp.x;
+      stp[2 * lane + 1] = tp.y;
+    }
+    __syncthreads();
+    const double t0 = stp[2 * lane], t1 = stp[2 * lane + 1];
+#pragma unroll
+    for (int it = 0; it < NPASS; it++) dotacc[it] = fma(buf[it].x, t0, fma(buf[it].y, t1, dotacc[it]));
+  }
+  // dots: wave w holds columns w + 4*it; slots 0..nv-1 (sums), then the two minima
+#pragma unroll
+  for (int it = 0; it < NPASS; it++) {
+    const double v = wave_reduce<OP_SUM>(dotacc[it]);
+    const int j = wave + 4 * it;
+    if (lane == 0 && j < nv) partials[(size_t)j * gridDim.x + blockIdx.x] = v;
+  }
+  block_reduce_store<2, OP_MIN>(mins, partials, nv, sm);
+}
+
+#define PO_S2D_CASE(NP)                                                                          \
+  case NP:                                                                                       \
+    PO_LAUNCH(solve2_dots_kernel<NP>, grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, \
+              ntiles, px, pzl, pzu, tout, va, nca, c->d_partials);                               \
+    break;
+
+// out = {dots[nv] = P^T t', max_x, max_z}
+int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+                  const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
+                  const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
+                  double *tout, double *va, int nca, double *out) {
+  if (nv > kMaxPanel || nv < 1) {
+    set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int64_t ntiles = (((n + 1) >> 1) + 63) / 64;
+  int64_t g = (int64_t)c->num_cu * 4;
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  const int grid = (int)g;
+  PO_TRY(ensure_partials(c, (size_t)grid * (nv + 2)));
+  PtrTable pt;
+  CoefTable ct, ct2;
+  fill_tables(alpha, P, nv, &ct, &pt);
+  fill_tables(coef2, P, nv, &ct2, &pt);
+  const int need = (nv + 3) / 4;
+  const int np = need <= 4 ? 4 : need <= 8 ? 8 : need <= 11 ? 11 : need <= 12 ? 12 : need <= 16 ? 16
+                 : need <= 20 ? 20 : 24;
+  switch (np) {
+    PO_S2D_CASE(4) PO_S2D_CASE(8) PO_S2D_CASE(11) PO_S2D_CASE(12) PO_S2D_CASE(16) PO_S2D_CASE(20)
+    PO_S2D_CASE(24)
+  }
+  return reduce_finish(c, grid, nv, 2, 0, out);
+}
+
 // stand-alone refinement residual (second and later refinement steps, or when the fused form of
 // solve2_kernel is not applicable)
 __global__ void __launch_bounds__(kBlock)
