@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "core.hpp"
@@ -84,7 +85,9 @@ int comm_init_rccl(Ctx *c, int rank, int size, const void *id128) {
   }
   c->rank = rank;
   c->size = size;
-  if (size == 1) {
+  // PAROPT_AMD_FORCE_RCCL=1 routes even a single rank through ncclCommInitRank / ncclAllGather, so
+  // the RCCL plumbing (dlopen, by-value unique id, stream use) can be exercised on a 1-GPU box
+  if (size == 1 && !getenv("PAROPT_AMD_FORCE_RCCL")) {
     c->comm_kind = COMM_SELF;
     return PO_OK;
   }

@@ -94,3 +94,33 @@ def test_two_ranks_one_gpu_match_single_rank():
         assert abs(a[3] - b["mu"]) <= 1e-7 * abs(b["mu"])
         np.testing.assert_allclose(a[4], b["norms"], rtol=1e-7)
     np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-7)
+
+
+def test_rccl_plumbing_single_rank(monkeypatch):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather through the dlopen'ed librccl with a
+    1-rank communicator on the only GPU of the test box: same results as the self communicator."""
+    import ctypes as C
+
+    import paropt_amd as pa
+    from paropt_amd.lib import check, lib
+
+    monkeypatch.setenv("PAROPT_AMD_FORCE_RCCL", "1")
+    ctx = pa.Context(0)
+    buf = (C.c_char * 128)()
+    check(lib.po_rccl_unique_id(buf))
+    assert any(b != b"\x00" for b in buf)
+    check(lib.po_ctx_comm_init_rccl(ctx.handle, 0, 1, buf))
+    ref = pa.Context(0)
+    n = 100003
+    outs = []
+    for c in (ctx, ref):
+        x = pa.PVec(c, n).fill_hash(0, 10, 0, 2.0, -1.0)
+        V = [pa.PVec(c, n).fill_hash(0, 20 + j, 0, 2.0, -1.0) for j in range(5)]
+        d = pa.PVec(c, n).fill_hash(0, 9, 0, 1.0, 0.5)
+        outs.append((x.mdot(V), x.norm(), x.maxabs(), pa.wgram(d, V)))
+        ip = pa.InteriorPoint(pa.SeparableProblem(c, "quadratic", 5000, 3),
+                              {"max_major_iters": 10, "write_output_frequency": 0, "qn_subspace_size": 4})
+        ip.optimize()
+        outs[-1] += (ip.getObjective()[0],)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
