@@ -80,6 +80,8 @@ def main():
                     help="global design variables (default: the metric's 50M)")
     ap.add_argument("--ncon", type=int, default=NCON)
     ap.add_argument("--qn", type=str, default="sr1")
+    ap.add_argument("--qn-size", type=int, default=QN_SIZE)
+    ap.add_argument("--problem", type=str, default="convex", choices=["convex", "quadratic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=N_GLOBAL)
     ap.add_argument("--cpu-iters", type=int, default=6)
@@ -132,8 +134,8 @@ def main():
             ctx.synchronize()
 
     K, W = a.steps, a.warmup
-    prob = pa.SeparableProblem(ctx, "convex", a.n, a.ncon, 0)
-    opts = {"qn_type": a.qn, "qn_subspace_size": QN_SIZE, "abs_res_tol": 1e-30,
+    prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
+    opts = {"qn_type": a.qn, "qn_subspace_size": a.qn_size, "abs_res_tol": 1e-30,
             "start_affine_multiplier_min": 0.01, "max_major_iters": W + K, "write_output_frequency": 0}
     ip = pa.InteriorPoint(prob, opts)
     stamp = {}
@@ -195,8 +197,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "config 3: separable random_convex n=%d, m=%d dense + bounds, L-%s(%d), "
-                                   "design vector sharded over %d GPU(s)" % (a.n, a.ncon, a.qn.upper(), QN_SIZE, world),
+            "config": {"workload": "%s: separable random_%s n=%d, m=%d dense + bounds, L-%s(%d), "
+                                   "design vector sharded over %d GPU(s)" % (
+                                       "config 3" if a.problem == "convex" else "config 2", a.problem, a.n, a.ncon,
+                                       a.qn.upper(), a.qn_size, world),
                        "n_global": a.n, "ncon": a.ncon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter),
                        "collective": comm_kind},
             "roofline": roofline,
