@@ -246,6 +246,50 @@ case(
     checkpoint=1,
     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}),
 )
+# --- weighting (sparse, block-diagonal) constraints: SURVEY 8f rank 1 / config 4 ---
+# the reference example itself: examples/rosenbrock/rosenbrock.cpp:219-222 (nwcon=5, nw=5, start 1, skip 1)
+case(
+    "ipw_rosenbrock_n100_w5",
+    "ip",
+    problem="rosenbrock",
+    n=100,
+    nwcon=5,
+    nw=5,
+    nwstart=1,
+    nwskip=1,
+    dump_vecs_every=10,
+    **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-6,
+       "opt.barrier_strategy": "monotone", "opt.write_output_frequency": 1, "opt.max_major_iters": 150},
+)
+# config-4 style: convex objective, dense constraints + one weighting constraint per group of 5
+case(
+    "ipw_convex_n400_c4_w80",
+    "ip",
+    problem="convex",
+    n=400,
+    c=4,
+    nwcon=80,
+    nw=5,
+    nwstart=0,
+    nwskip=0,
+    dump_vecs_every=10,
+    **dict(ip_common, **{"opt.qn_subspace_size": 8, "opt.qn_type": "bfgs", "opt.max_major_iters": 100}),
+)
+# equality weighting constraints (sum of each group = 1), partial coverage with gaps
+case(
+    "ipw_convex_n300_c2_w30_eq",
+    "ip",
+    problem="convex",
+    n=300,
+    c=2,
+    nwcon=30,
+    nw=4,
+    nwstart=3,
+    nwskip=5,
+    nwineq=0,
+    dump_vecs_every=10,
+    **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 100}),
+)
 for strat in ("mehrotra", "mehrotra_predictor_corrector"):
     case(
         "ip_quadratic_%s_n300_c3" % ("mpc" if "corrector" in strat else "mehrotra"),

@@ -307,8 +307,16 @@ class SepProblem:
     rosenbrock: examples/rosenbrock/rosenbrock.cpp:34-107 (w = 0 variant)
     """
 
-    def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None):
+    def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None, nwcon=0, nw=0,
+                 nwstart=0, nwskip=0, nwineq=-1):
         self.comm = comm if comm is not None else SelfComm()
+        # weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i*(nw+nwskip) + k] (the pattern of
+        # examples/rosenbrock/rosenbrock.cpp:131-184); disjoint supports, nwblock = 1
+        self.nwcon, self.nw, self.nwstart, self.nwskip = int(nwcon), int(nw), int(nwstart), int(nwskip)
+        self.nwineq = self.nwcon if nwineq < 0 else int(nwineq)
+        if self.nwcon > 0:
+            j0 = self.nwstart + np.arange(self.nwcon) * (self.nw + self.nwskip)
+            self.widx = (j0[:, None] + np.arange(self.nw)[None, :])  # (w, nw) variable indices
         self.kind = kind
         self.nglobal = int(n)
         self.nlocal, self.offset = shard(n, self.comm.rank, self.comm.size)
@@ -360,6 +368,27 @@ class SepProblem:
         else:
             cons += self.beta
         return 0, float(tot[0]), cons
+
+    # sparse-constraint callbacks: src/ParOptProblem.h:225-266
+    def eval_sparse_con(self, x):
+        if self.nwcon == 0:
+            return np.zeros(0)
+        return 1.0 - np.sum(x[self.widx], axis=1)
+
+    def add_sparse_jacobian(self, alpha, px, out):  # out += alpha * Aw px
+        if self.nwcon:
+            out -= alpha * np.sum(px[self.widx], axis=1)
+        return out
+
+    def add_sparse_jacobian_transpose(self, alpha, pzw, out):  # out += alpha * Aw^T pzw
+        if self.nwcon:
+            out[self.widx] -= alpha * pzw[:, None]
+        return out
+
+    def add_sparse_inner_product(self, alpha, cvec, A):  # A += alpha * diag(Aw diag(cvec) Aw^T)
+        if self.nwcon:
+            A += alpha * np.sum(cvec[self.widx], axis=1)
+        return A
 
     def eval_obj_con_gradient(self, x):
         if self.kind == "quadratic":
@@ -427,7 +456,7 @@ LS_SUCCESS, LS_FAILURE, LS_MIN_STEP, LS_MAX_ITERS, LS_NO_IMPROVEMENT, LS_SHORT_S
 class Vars:
     """ParOptVars for nwcon = 0: src/ParOptInteriorPoint.h:373-389."""
 
-    def __init__(self, n, c):
+    def __init__(self, n, c, w=0):
         self.x = np.zeros(n)
         self.zl = np.zeros(n)
         self.zu = np.zeros(n)
@@ -436,8 +465,13 @@ class Vars:
         self.t = np.zeros(c)
         self.zs = np.zeros(c)
         self.zt = np.zeros(c)
+        self.zw = np.zeros(w)
+        self.sw = np.zeros(w)
+        self.tw = np.zeros(w)
+        self.zsw = np.zeros(w)
+        self.ztw = np.zeros(w)
 
-    NAMES = ("x", "zl", "zu", "z", "s", "t", "zs", "zt")
+    NAMES = ("x", "zl", "zu", "z", "s", "t", "zs", "zt", "zw", "sw", "tw", "zsw", "ztw")
 
     def add(self, o, sign=1.0):  # :128-167
         for k in self.NAMES:
@@ -458,12 +492,14 @@ class InteriorPoint:
         o = self.opt
         n, c = prob.nlocal, prob.c
         self.n, self.c = n, c
+        w = getattr(prob, "nwcon", 0)
+        self.w = w
         self.ninequality = c
         self.use_lower = self.use_upper = True
-        self.vars = Vars(n, c)
-        self.res = Vars(n, c)
-        self.step = Vars(n, c)
-        self.refine = Vars(n, c)
+        self.vars = Vars(n, c, w)
+        self.res = Vars(n, c, w)
+        self.step = Vars(n, c, w)
+        self.refine = Vars(n, c, w)
         qt = o["qn_type"]
         if qt == "bfgs":
             self.qn = LBFGS(n, o["qn_subspace_size"], self.ops, o["qn_update_type"])
@@ -477,6 +513,10 @@ class InteriorPoint:
         gamma = o["penalty_gamma"]
         self.gamma_s = np.array([0.0 if i < self.ninequality else gamma for i in range(c)])
         self.gamma_t = np.full(c, gamma)
+        nwineq = getattr(prob, "nwineq", 0)
+        self.gamma_sw = np.array([0.0 if i < nwineq else gamma for i in range(w)])  # :361-374
+        self.gamma_tw = np.full(w, gamma)
+        self.Cw = np.zeros(w)
         self.barrier_param = o["init_barrier_param"]
         self.rho = o["init_rho_penalty_search"]
         self.niter = self.neval = self.ngeval = 0
@@ -498,6 +538,29 @@ class InteriorPoint:
         v.t[:] = 1.0
         v.zs[:] = 1.0
         v.zt[:] = 1.0
+        for k in ("zw", "sw", "tw", "zsw", "ztw"):
+            getattr(v, k)[:] = 1.0
+
+    # ---- quasi-definite block matrix (nwblock = 1): src/ParOptSparseMat.cpp:41-229 --------
+    def _factor(self, v, Cdiag):
+        """Cw = 1 / (Cdiag + Aw Dinv Aw^T) per constraint."""
+        if self.w:
+            A = Cdiag.copy()
+            self.prob.add_sparse_inner_product(1.0, self.Dinv, A)
+            self.Cw = 1.0 / A
+
+    def _apply(self, bx, bw=None):
+        """[D Aw^T; Aw -C] [yx; -yw] = [bx; bw]  ->  (yx, yw)   (:122-190)."""
+        yx = self.Dinv * bx
+        if self.w == 0:
+            return yx, np.zeros(0)
+        yw = np.zeros(self.w) if bw is None else bw.copy()
+        self.prob.add_sparse_jacobian(-1.0, yx, yw)
+        yw = yw * self.Cw
+        yx = bx.copy()
+        self.prob.add_sparse_jacobian_transpose(1.0, yw, yx)
+        yx = yx * self.Dinv
+        return yx, yw
 
     # ---- bound masks -----------------------------------------------------------------
     def _masks(self):
@@ -539,6 +602,13 @@ class InteriorPoint:
         rx += -1.0 * self.g
         for i in range(self.c):
             rx += v.z[i] * self.Ac[i]
+        if self.w:  # :1358-1398
+            self.prob.add_sparse_jacobian_transpose(1.0, v.zw, rx)
+            r.zw[:] = -(self.prob.eval_sparse_con(v.x) - v.sw + v.tw)
+            r.sw[:] = v.zsw - self.gamma_sw - v.zw
+            r.tw[:] = v.ztw - self.gamma_tw + v.zw
+            r.zsw[:] = barrier - v.sw * v.zsw
+            r.ztw[:] = barrier - v.tw * v.ztw
         r.x[:] = rx
         r.z[:] = -(self.cvals - v.s + v.t)
         r.s[:] = -(self.gamma_s - v.zs + v.z)
@@ -561,6 +631,17 @@ class InteriorPoint:
             r.x += p.zl
         if self.use_upper:
             r.x += -1.0 * p.zu
+        if self.w:  # :1492-1527
+            self.prob.add_sparse_jacobian_transpose(1.0, p.zw, r.x)
+            self.prob.add_sparse_jacobian(-1.0, p.x, r.zw)
+            r.zw += p.sw
+            r.zw += -1.0 * p.tw
+            r.sw += p.zsw
+            r.sw += -1.0 * p.zw
+            r.tw += p.ztw
+            r.tw += p.zw
+            r.zsw -= p.sw * v.zsw + v.sw * p.zsw
+            r.ztw -= p.tw * v.ztw + v.tw * p.ztw
         for i in range(self.c):
             r.z[i] -= self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
             r.s[i] += p.zs[i] - p.z[i]
@@ -574,6 +655,8 @@ class InteriorPoint:
         L, U = self._masks()
         r.zs[:] -= p.s * p.zs
         r.zt[:] -= p.t * p.zt
+        r.zsw[:] -= p.sw * p.zsw
+        r.ztw[:] -= p.tw * p.ztw
         r.zl[:] -= np.where(L, p.x * p.zl, 0.0)
         r.zu[:] += np.where(U, p.x * p.zu, 0.0)
 
@@ -582,8 +665,8 @@ class InteriorPoint:
         ops = self.ops
         if nt == "infinity":
             mp = ops.maxabs(r.x)
-            mi = 0.0
-            md = 0.0
+            mi = ops.maxabs(r.zw)
+            md = max(ops.maxabs(r.sw), ops.maxabs(r.tw), ops.maxabs(r.zsw), ops.maxabs(r.ztw))
             for i in range(self.c):
                 mp = max(mp, abs(r.s[i]), abs(r.t[i]))
                 mi = max(mi, abs(r.z[i]))
@@ -594,13 +677,16 @@ class InteriorPoint:
                 md = max(md, ops.maxabs(r.zu))
         elif nt == "l1":
             mp = ops.l1norm(r.x) + float(np.sum(np.abs(r.s)) + np.sum(np.abs(r.t)))
-            mi = float(np.sum(np.abs(r.z)))
-            md = float(np.sum(np.abs(r.zs)) + np.sum(np.abs(r.zt)))
+            mi = ops.l1norm(r.zw) + float(np.sum(np.abs(r.z)))
+            md = ops.l1norm(r.sw) + ops.l1norm(r.tw) + ops.l1norm(r.zsw) + ops.l1norm(r.ztw)
+            md += float(np.sum(np.abs(r.zs)) + np.sum(np.abs(r.zt)))
             md += ops.l1norm(r.zl) + ops.l1norm(r.zu)
         else:
             mp = ops.norm(r.x) ** 2 + float(np.sum(r.s**2 + r.t**2))
-            mi = float(np.sum(r.z**2))
-            md = float(np.sum(r.zs**2 + r.zt**2)) + ops.norm(r.zl) ** 2 + ops.norm(r.zu) ** 2
+            mi = ops.norm(r.zw) ** 2 + float(np.sum(r.z**2))
+            # the reference squares l1 norms of the sparse dual blocks here (:1633-1638)
+            md = ops.l1norm(r.sw) ** 2 + ops.l1norm(r.tw) ** 2 + ops.l1norm(r.zsw) ** 2 + ops.l1norm(r.ztw) ** 2
+            md += float(np.sum(r.zs**2 + r.zt**2)) + ops.norm(r.zl) ** 2 + ops.norm(r.zu) ** 2
             mp, mi, md = math.sqrt(mp), math.sqrt(mi), math.sqrt(md)
         return mp, md, mi, max(mp, md, mi)
 
@@ -615,10 +701,11 @@ class InteriorPoint:
         d = d + np.where(L, v.zl / np.where(L, v.x - self.lb, 1.0), 0.0)
         d = d + np.where(U, v.zu / np.where(U, self.ub - v.x, 1.0), 0.0)
         self.Dinv = 1.0 / d
+        self._factor(v, v.sw / v.zsw + v.tw / v.ztw if self.w else None)  # Cdiag :1912-1930
         c = self.c
         G = np.zeros((c, c))
         for j in range(c):
-            xt = self.Dinv * self.Ac[j]
+            xt, _ = self._apply(self.Ac[j])
             for i in range(j, c):
                 G[i, j] += self.ops.dot(self.Ac[i], xt)
         for j in range(c):
@@ -641,7 +728,10 @@ class InteriorPoint:
         d1 = b.x.copy()
         d1 += np.where(L, b.zl / xl, 0.0)
         d1 -= np.where(U, b.zu / xu, 0.0)
-        yx = self.Dinv * d1
+        d2 = None
+        if self.w:  # :2111-2136
+            d2 = b.zw + (b.zsw + v.sw * b.sw) / v.zsw - (b.ztw + v.tw * b.tw) / v.ztw
+        yx, _ = self._apply(d1, d2)
         yz = self.ops.mdot(yx, self.Ac)
         yz = b.z + (b.zs + v.s * b.s) / v.zs - (b.zt + v.t * b.t) / v.zt - yz
         yz = self._gsolve(yz)
@@ -652,7 +742,14 @@ class InteriorPoint:
         y.t[:] = (b.zt - v.t * y.zt) / v.zt
         for i in range(self.c):
             d1 += yz[i] * self.Ac[i]
-        y.x[:] = self.Dinv * d1
+        yx, yw = self._apply(d1, d2)
+        y.x[:] = yx
+        if self.w:  # :2180-2208
+            y.zw[:] = yw
+            y.zsw[:] = yw - b.sw
+            y.ztw[:] = -b.tw - yw
+            y.sw[:] = (b.zsw - v.sw * y.zsw) / v.zsw
+            y.tw[:] = (b.ztw - v.tw * y.ztw) / v.ztw
         y.zl[:] = np.where(L, (b.zl - v.zl * y.x) / xl, 0.0)
         y.zu[:] = np.where(U, (b.zu + v.zu * y.x) / xu, 0.0)
 
@@ -661,7 +758,8 @@ class InteriorPoint:
         xl = np.where(L, v.x - self.lb, 1.0)
         xu = np.where(U, self.ub - v.x, 1.0)
         d1 = bx.copy()
-        yx = self.Dinv * d1
+        d2 = np.zeros(self.w) if self.w else None
+        yx, _ = self._apply(d1, d2)
         yz = -self.ops.mdot(yx, self.Ac)
         yz = self._gsolve(yz)
         y.z[:] = yz
@@ -671,18 +769,25 @@ class InteriorPoint:
         y.t[:] = -(v.t * y.zt) / v.zt
         for i in range(self.c):
             d1 += yz[i] * self.Ac[i]
-        y.x[:] = self.Dinv * d1
+        yx, yw = self._apply(d1, d2)
+        y.x[:] = yx
+        if self.w:  # :2312-2334
+            y.zw[:] = yw
+            y.zsw[:] = yw
+            y.ztw[:] = -yw
+            y.sw[:] = -(v.sw * y.zsw) / v.zsw
+            y.tw[:] = -(v.tw * y.ztw) / v.ztw
         y.zl[:] = np.where(L, -(v.zl * y.x) / xl, 0.0)
         y.zu[:] = np.where(U, (v.zu * y.x) / xu, 0.0)
 
     def solve_kkt_diag_x(self, v, bx):  # :2385-2428 -> yx only
         d1 = bx.copy()
-        yx = self.Dinv * d1
+        yx, _ = self._apply(d1)
         yz = -self.ops.mdot(yx, self.Ac)
         yz = self._gsolve(yz)
         for i in range(self.c):
             d1 += yz[i] * self.Ac[i]
-        return self.Dinv * d1
+        return self._apply(d1)[0]
 
     def setup_kkt_system(self, v, use_qn):  # :2634-2667
         self.Celu = None
@@ -719,6 +824,8 @@ class InteriorPoint:
         prod += float(np.sum(np.where(U, v.zu * (self.ub - v.x), 0.0)))
         cnt = float(np.count_nonzero(L) + np.count_nonzero(U))
         prod = prod / self.opt["rel_bound_barrier"]
+        prod += float(np.sum(v.sw * v.zsw + v.tw * v.ztw))
+        cnt += 2.0 * self.w
         out = self.comm.allreduce([prod, cnt])
         prod, cnt = float(out[0]), float(out[1])
         prod += float(np.sum(v.s * v.zs + v.t * v.zt))
@@ -732,6 +839,8 @@ class InteriorPoint:
         prod += float(np.sum(np.where(U, (v.zu + az * p.zu) * (self.ub - xn), 0.0)))
         cnt = float(np.count_nonzero(L) + np.count_nonzero(U))
         prod = prod / self.opt["rel_bound_barrier"]
+        prod += float(np.sum((v.sw + ax * p.sw) * (v.zsw + az * p.zsw) + (v.tw + ax * p.tw) * (v.ztw + az * p.ztw)))
+        cnt += 2.0 * self.w
         out = self.comm.allreduce([prod, cnt])
         prod, cnt = float(out[0]), float(out[1])
         prod += float(
@@ -759,6 +868,10 @@ class InteriorPoint:
         mx = min(mx, self._min_ratio(tau, v.t, p.t, p.t < 0.0))
         mz = min(mz, self._min_ratio(tau, v.zs, p.zs, p.zs < 0.0))
         mz = min(mz, self._min_ratio(tau, v.zt, p.zt, p.zt < 0.0))
+        mx = min(mx, self._min_ratio(tau, v.sw, p.sw, p.sw < 0.0))  # :3017-3061
+        mx = min(mx, self._min_ratio(tau, v.tw, p.tw, p.tw < 0.0))
+        mz = min(mz, self._min_ratio(tau, v.zsw, p.zsw, p.zsw < 0.0))
+        mz = min(mz, self._min_ratio(tau, v.ztw, p.ztw, p.ztw < 0.0))
         if self.use_lower:
             mz = min(mz, self._min_ratio(tau, v.zl, p.zl, p.zl < 0.0))
         if self.use_upper:
@@ -790,6 +903,11 @@ class InteriorPoint:
         p.x *= ax
         p.zl *= az
         p.zu *= az
+        p.sw *= ax
+        p.tw *= ax
+        p.zw *= az
+        p.zsw *= az
+        p.ztw *= az
         p.s *= ax
         p.t *= ax
         p.z *= az
@@ -819,10 +937,25 @@ class InteriorPoint:
         neg = float(np.sum(np.where(L & ~(dl > 1.0), ll, 0.0)) + np.sum(np.where(U & ~(du > 1.0), lu, 0.0)))
         return pos, neg, L, U, dl, du
 
-    def eval_merit_func(self, fk, ck, xk, sk, tk):  # :3524-3637
+    @staticmethod
+    def _log_split(vals):
+        if vals.size == 0:
+            return 0.0, 0.0
+        lg = np.log(vals)
+        big = vals > 1.0
+        return float(np.sum(lg[big])), float(np.sum(lg[~big]))
+
+    def eval_merit_func(self, fk, ck, xk, sk, tk, swk=None, twk=None):  # :3524-3637
         beta = self.opt["rel_bound_barrier"]
         pos, neg, *_ = self._barrier_sums(xk)
-        out = self.comm.allreduce([pos * beta, neg * beta])
+        pos, neg = pos * beta, neg * beta
+        if swk is None:
+            swk = twk = np.zeros(0)
+        for arr in (swk, twk):  # :3572-3590 (not scaled by rel_bound_barrier)
+            a, b_ = self._log_split(arr)
+            pos += a
+            neg += b_
+        out = self.comm.allreduce([pos, neg])
         pos, neg = float(out[0]), float(out[1])
         for i in range(self.c):
             for val in (sk[i], tk[i]):
@@ -830,8 +963,14 @@ class InteriorPoint:
                     pos += math.log(val)
                 else:
                     neg += math.log(val)
-        infeas = math.sqrt(float(np.sum((ck - sk + tk) ** 2)))
-        merit = fk - self.barrier_param * (pos + neg) + self.rho * infeas
+        dense = float(np.sum((ck - sk + tk) ** 2))
+        sparse = 0.0
+        if self.w:  # evalInfeas :3438-3462
+            rw = self.prob.eval_sparse_con(xk) - swk + twk
+            sparse = self.ops.norm(rw)
+        infeas = math.sqrt(dense + sparse * sparse)
+        merit = (fk + (self.ops.dot(self.gamma_sw, swk) + self.ops.dot(self.gamma_tw, twk))
+                 - self.barrier_param * (pos + neg) + self.rho * infeas)
         for i in range(self.c):
             merit += self.gamma_s[i] * sk[i] + self.gamma_t[i] * tk[i]
         return merit
@@ -845,7 +984,16 @@ class InteriorPoint:
         qu = np.where(U, px / du, 0.0)
         ppos = float(np.sum(np.where(L & (px > 0.0), ql, 0.0)) - np.sum(np.where(U & ~(px > 0.0), qu, 0.0)))
         pneg = float(np.sum(np.where(L & ~(px > 0.0), ql, 0.0)) - np.sum(np.where(U & (px > 0.0), qu, 0.0)))
-        out = self.comm.allreduce([pos * beta, neg * beta, ppos * beta, pneg * beta])
+        pos, neg, ppos, pneg = pos * beta, neg * beta, ppos * beta, pneg * beta
+        for arr, parr in ((v.sw, p.sw), (v.tw, p.tw)):  # :3735-3765
+            a, b_ = self._log_split(arr)
+            pos += a
+            neg += b_
+            if arr.size:
+                q_ = parr / arr
+                ppos += float(np.sum(q_[parr > 0.0]))
+                pneg += float(np.sum(q_[~(parr > 0.0)]))
+        out = self.comm.allreduce([pos, neg, ppos, pneg])
         pos, neg, ppos, pneg = (float(a) for a in out)
         for i in range(self.c):
             for val, pv in ((v.s[i], p.s[i]), (v.t[i], p.t[i])):
@@ -865,14 +1013,25 @@ class InteriorPoint:
             pcval = self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
             dense_infeas += cval * cval
             pdense += cval * pcval
-        infeas = math.sqrt(dense_infeas)
-        infeas_proj = pdense / infeas if infeas > 0.0 else 0.0
+        sparse_infeas = 0.0
+        psparse = 0.0
+        if self.w:  # :3489-3503
+            rw1 = self.prob.eval_sparse_con(v.x) - v.sw + v.tw
+            sparse_infeas = self.ops.norm(rw1)
+            rw2 = np.zeros(self.w)
+            self.prob.add_sparse_jacobian(1.0, p.x, rw2)
+            rw2 = rw2 - p.sw + p.tw
+            psparse = self.ops.dot(rw1, rw2)
+        infeas = math.sqrt(dense_infeas + sparse_infeas * sparse_infeas)
+        infeas_proj = (pdense + psparse) / infeas if infeas > 0.0 else 0.0
         pTBp = 0.0
         if self.qn is not None and not o["sequential_linear_method"]:
             xt = self.qn.mult(p.x)
             pTBp = 0.5 * self.ops.dot(xt, p.x)
-        merit = self.fobj - self.barrier_param * (pos + neg)
-        pmerit = self.ops.dot(self.g, p.x) - self.barrier_param * (ppos + pneg)
+        merit = (self.fobj + (self.ops.dot(self.gamma_sw, v.sw) + self.ops.dot(self.gamma_tw, v.tw))
+                 - self.barrier_param * (pos + neg))
+        pmerit = (self.ops.dot(self.g, p.x) + (self.ops.dot(self.gamma_sw, p.sw) + self.ops.dot(self.gamma_tw, p.tw))
+                  - self.barrier_param * (ppos + pneg))
         for i in range(self.c):
             merit += self.gamma_s[i] * v.s[i] + self.gamma_t[i] * v.t[i]
             pmerit += self.gamma_s[i] * p.s[i] + self.gamma_t[i] * p.t[i]
@@ -923,6 +1082,8 @@ class InteriorPoint:
         self.ls_trials = 0
         while j < max_it:
             r.x[:] = self._clamp_step(v.x, alpha, p.x, self.lb, self.ub)
+            r.sw[:] = self._clamp_step(v.sw, alpha, p.sw, lower_value=0.0)
+            r.tw[:] = self._clamp_step(v.tw, alpha, p.tw, lower_value=0.0)
             r.s[:] = self._clamp_step(v.s, alpha, p.s, lower_value=0.0)
             r.t[:] = self._clamp_step(v.t, alpha, p.t, lower_value=0.0)
             fail_obj, self.fobj, self.cvals = self.prob.eval_obj_con(r.x)
@@ -932,7 +1093,7 @@ class InteriorPoint:
                 alpha *= 0.1
                 j += 1
                 continue
-            merit = self.eval_merit_func(self.fobj, self.cvals, r.x, r.s, r.t)
+            merit = self.eval_merit_func(self.fobj, self.cvals, r.x, r.s, r.t, r.sw, r.tw)
             if best_alpha < 0.0 or merit < best_merit:
                 best_alpha = alpha
                 best_merit = merit
@@ -984,6 +1145,11 @@ class InteriorPoint:
     def compute_step_and_update(self, v, alpha, p, eval_obj_con, perform_qn_update):  # :4169-4267
         o = self.opt
         use_qnu = o["use_quasi_newton_update"]
+        v.sw[:] = self._clamp_step(v.sw, alpha, p.sw, lower_value=0.0)  # :4177-4183
+        v.tw[:] = self._clamp_step(v.tw, alpha, p.tw, lower_value=0.0)
+        v.zw[:] = v.zw + alpha * p.zw
+        v.zsw[:] = self._clamp_step(v.zsw, alpha, p.zsw, lower_value=0.0)
+        v.ztw[:] = self._clamp_step(v.ztw, alpha, p.ztw, lower_value=0.0)
         v.zl[:] = self._clamp_step(v.zl, alpha, p.zl, lower_value=0.0)
         v.zu[:] = self._clamp_step(v.zu, alpha, p.zu, lower_value=0.0)
         v.s[:] = self._clamp_step(v.s, alpha, p.s, lower_value=0.0)
@@ -996,6 +1162,8 @@ class InteriorPoint:
             y_qn = -1.0 * self.g
             for i in range(self.c):
                 y_qn += v.z[i] * self.Ac[i]
+            if self.w:
+                self.prob.add_sparse_jacobian_transpose(1.0, v.zw, y_qn)
         v.x[:] = self._clamp_step(v.x, alpha, p.x, self.lb, self.ub)
         if eval_obj_con:
             fail, self.fobj, self.cvals = self.prob.eval_obj_con(v.x)
@@ -1010,6 +1178,8 @@ class InteriorPoint:
             y_qn += self.g
             for i in range(self.c):
                 y_qn += -v.z[i] * self.Ac[i]
+            if self.w:
+                self.prob.add_sparse_jacobian_transpose(-1.0, v.zw, y_qn)
             update_type = self.qn.update(s_qn, y_qn)
         return update_type
 
@@ -1025,14 +1195,17 @@ class InteriorPoint:
         v.t[:] = mu0
         v.zs[:] = mu0
         v.zt[:] = mu0
+        for k in ("zw", "sw", "tw", "zsw", "ztw"):
+            getattr(v, k)[:] = mu0
         v.zl[self.lb <= -mb] = 0.0
         v.zu[self.ub >= mb] = 0.0
         small = 1e-4
         self.Dinv = np.ones(self.n)
+        self._factor(v, np.full(self.w, small))
         c = self.c
         G = np.zeros((c, c))
         for j in range(c):
-            xt = self.Dinv * self.Ac[j]
+            xt, _ = self._apply(self.Ac[j])
             for i in range(j, c):
                 G[i, j] += self.ops.dot(self.Ac[i], xt)
         for j in range(c):
@@ -1045,14 +1218,21 @@ class InteriorPoint:
         rx += -1.0 * v.zl
         rx += v.zu
         rx *= -1.0
-        yx = self.Dinv * rx
+        rzw = np.zeros(self.w) if self.w else None
+        yx, _ = self._apply(rx, rzw)
         z = -self.ops.mdot(yx, self.Ac)
         z = self._gsolve(z)
         v.z[:] = z
         for i in range(c):
+            rx += z[i] * self.Ac[i]
+        _, zw = self._apply(rx, rzw)
+        for i in range(c):
             gam = 10.0 * max(self.gamma_s[i], self.gamma_t[i])
             if v.z[i] < -gam or v.z[i] > gam:
                 v.z[i] = 0.0
+        if self.w:  # :5522-5533
+            gam = 10.0 * np.maximum(self.gamma_sw, self.gamma_tw)
+            v.zw[:] = np.where((zw < -gam) | (zw > gam), 0.0, zw)
 
     def init_affine_step_multipliers(self, v, r, p):  # :5536-5656
         o = self.opt
@@ -1071,6 +1251,12 @@ class InteriorPoint:
         v.t[:] = np.maximum(amin, np.abs(v.t + p.t))
         v.zs[:] = np.maximum(amin, np.abs(v.zs + p.zs))
         v.zt[:] = np.maximum(amin, np.abs(v.zt + p.zt))
+        if self.w:  # :5601-5628
+            v.zw[:] = v.zw + p.zw
+            v.sw[:] = np.maximum(amin, np.abs(v.sw + p.sw))
+            v.tw[:] = np.maximum(amin, np.abs(v.tw + p.tw))
+            v.zsw[:] = np.maximum(amin, np.abs(v.zsw + p.zsw))
+            v.ztw[:] = np.maximum(amin, np.abs(v.ztw + p.ztw))
         L, U = self._masks()
         v.zl[:] = np.where(L, np.maximum(amin, np.abs(v.zl + p.zl)), v.zl)
         v.zu[:] = np.where(U, np.maximum(amin, np.abs(v.zu + p.zu)), v.zu)
@@ -1266,7 +1452,7 @@ class InteriorPoint:
                 dm0_prev = dm0
                 line_fail = LS_SUCCESS
                 update_type = self.compute_step_and_update(v, alpha, self.step, 1, 1)
-                m1 = self.eval_merit_func(self.fobj, self.cvals, v.x, v.s, v.t)
+                m1 = self.eval_merit_func(self.fobj, self.cvals, v.x, v.s, v.t, v.sw, v.tw)
                 if m1 <= m0 + fprec and m1 + fprec >= m0:
                     line_fail |= LS_NO_IMPROVEMENT
                 elif abs(dm0) <= fprec:
@@ -1328,6 +1514,10 @@ class InteriorPoint:
             zl=v.zl.copy(),
             zu=v.zu.copy(),
         )
+        if self.w:
+            d["wnorms"] = np.array([self.ops.norm(getattr(v, k)) for k in ("zw", "sw", "tw", "zsw", "ztw")])
+            for k in ("zw", "sw", "tw", "zsw", "ztw"):
+                d[k] = getattr(v, k).copy()
         if self.qn is not None:
             b0, d0, M, Z = self.qn.get_compact()
             d["qn_size"] = len(Z)

@@ -107,16 +107,23 @@ class SepProblem : public ParOptProblem {
  public:
   enum Kind { QUADRATIC = 0, CONVEX = 1, ROSENBROCK = 2 };
   SepProblem(MPI_Comm comm, Kind _kind, int nlocal, int64_t _offset, int64_t _nglobal, int _ncon,
-             uint64_t _seed, double _eig_min, double _eig_max)
+             uint64_t _seed, double _eig_min, double _eig_max, int _nwcon = 0, int _nw = 0,
+             int _nwstart = 0, int _nwskip = 0, int _nwineq = -1)
       : ParOptProblem(comm) {
+    // weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i*(nw+nwskip) + k]  (the pattern of
+    // examples/rosenbrock/rosenbrock.cpp:131-184), disjoint supports => nwblock = 1
+    wn = _nwcon;
+    nw = _nw;
+    nwstart = _nwstart;
+    nwskip = _nwskip;
     kind = _kind;
     offset = _offset;
     nglobal = _nglobal;
     seed = _seed;
     eig_min = _eig_min;
     eig_max = _eig_max;
-    setProblemSizes(nlocal, _ncon, 0);
-    setNumInequalities(_ncon, 0);
+    setProblemSizes(nlocal, _ncon, _nwcon);
+    setNumInequalities(_ncon, _nwineq < 0 ? _nwcon : _nwineq);
     hook = NULL;
     beta.resize(_ncon);
     if (kind == QUADRATIC) {
@@ -241,8 +248,47 @@ class SepProblem : public ParOptProblem {
     return 0;
   }
 
+  void evalSparseCon(ParOptVec *xv, ParOptVec *outv) {
+    double *x, *out;
+    xv->getArray(&x);
+    outv->getArray(&out);
+    for (int i = 0; i < wn; i++) {
+      double s = 1.0;
+      const int j0 = nwstart + i * (nw + nwskip);
+      for (int k = 0; k < nw; k++) s -= x[j0 + k];
+      out[i] = s;
+    }
+  }
+  void addSparseJacobian(ParOptScalar alpha, ParOptVec *, ParOptVec *pxv, ParOptVec *outv) {
+    double *px, *out;
+    pxv->getArray(&px);
+    outv->getArray(&out);
+    for (int i = 0; i < wn; i++) {
+      const int j0 = nwstart + i * (nw + nwskip);
+      for (int k = 0; k < nw; k++) out[i] -= alpha * px[j0 + k];
+    }
+  }
+  void addSparseJacobianTranspose(ParOptScalar alpha, ParOptVec *, ParOptVec *pzwv, ParOptVec *outv) {
+    double *pzw, *out;
+    pzwv->getArray(&pzw);
+    outv->getArray(&out);
+    for (int i = 0; i < wn; i++) {
+      const int j0 = nwstart + i * (nw + nwskip);
+      for (int k = 0; k < nw; k++) out[j0 + k] -= alpha * pzw[i];
+    }
+  }
+  void addSparseInnerProduct(ParOptScalar alpha, ParOptVec *, ParOptVec *cvecv, ParOptScalar *A) {
+    double *cv;
+    cvecv->getArray(&cv);
+    for (int i = 0; i < wn; i++) {
+      const int j0 = nwstart + i * (nw + nwskip);
+      for (int k = 0; k < nw; k++) A[i] += alpha * cv[j0 + k];
+    }
+  }
+
   void writeOutput(int iter, ParOptVec *x);
 
+  int wn, nw, nwstart, nwskip;
   Kind kind;
   int64_t offset, nglobal;
   uint64_t seed;
@@ -296,6 +342,18 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     R.vec((p + "x").c_str(), ip->variables.x);
     R.vec((p + "zl").c_str(), ip->variables.zl);
     R.vec((p + "zu").c_str(), ip->variables.zu);
+  }
+  if (wn > 0) {
+    double wn5[5] = {ip->variables.zw->norm(), ip->variables.sw->norm(), ip->variables.tw->norm(),
+                     ip->variables.zsw->norm(), ip->variables.ztw->norm()};
+    R.f64((p + "wnorms").c_str(), wn5, 5);
+    if (hook->dump_vecs_every > 0 && (iter % hook->dump_vecs_every) == 0) {
+      R.vec((p + "zw").c_str(), ip->variables.zw);
+      R.vec((p + "sw").c_str(), ip->variables.sw);
+      R.vec((p + "tw").c_str(), ip->variables.tw);
+      R.vec((p + "zsw").c_str(), ip->variables.zsw);
+      R.vec((p + "ztw").c_str(), ip->variables.ztw);
+    }
   }
   if (iter == hook->kat_iter) {
     // Single-step KAT through the private methods, in the order optimize() uses
@@ -557,7 +615,9 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   int64_t offset;
   shard(n, rank, size, &nlocal, &offset);
   SepProblem *prob = new SepProblem(comm, kind, nlocal, offset, n, c, seed, getf(A, "eig_min", 1.0),
-                                    getf(A, "eig_max", 100.0));
+                                    getf(A, "eig_max", 100.0), (int)geti(A, "nwcon", 0),
+                                    (int)geti(A, "nw", 0), (int)geti(A, "nwstart", 0),
+                                    (int)geti(A, "nwskip", 0), (int)geti(A, "nwineq", -1));
   prob->incref();
   ParOptOptions *opt = new ParOptOptions(comm);
   opt->incref();

@@ -101,6 +101,8 @@ def run_oracle_ip(case, nmax=None):
     prob = po.SepProblem(
         a["problem"], a["n"], a.get("c", 2), seed=a.get("seed", 0),
         eig_min=a.get("eig_min", 1.0), eig_max=a.get("eig_max", 100.0),
+        nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
+        nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
     )
     opts = ip_options_from_case(case)
     opts.pop("write_output_frequency", None)
@@ -124,7 +126,7 @@ def info_tokens(paropt_out):
     return toks
 
 
-IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2") and "checkpoint" not in n]
+IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_") if not n.endswith("_r2") and "checkpoint" not in n]
 
 
 @pytest.mark.parametrize("name", IP_CASES)
@@ -154,6 +156,13 @@ def test_ip_trajectory(name):
                                        err_msg="%s @%d" % (key, k))
         if p + "x" in g:
             for key in ("x", "zl", "zu"):
+                ref = g[p + key]
+                np.testing.assert_allclose(s[key], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
+                                           err_msg="%s @%d" % (key, k))
+        if p + "wnorms" in g:
+            np.testing.assert_allclose(s["wnorms"], g[p + "wnorms"], rtol=1e-6, err_msg="wnorms @%d" % k)
+        if p + "zw" in g:
+            for key in ("zw", "sw", "tw", "zsw", "ztw"):
                 ref = g[p + key]
                 np.testing.assert_allclose(s[key], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
                                            err_msg="%s @%d" % (key, k))
@@ -193,7 +202,7 @@ def test_ip_single_step_kat(name):
         out["Dinv"] = s.Dinv.copy()
         s.setup_kkt_system(s.vars, 1)
         s.compute_kkt_step(s.vars, s.res, s.step, 1)
-        for key in po.Vars.NAMES:
+        for key in po.Vars.NAMES[:8]:
             out["step_" + key] = getattr(s.step, key).copy()
         out["comp"] = s.compute_comp(s.vars)
         out["max_step"] = np.array(s.compute_max_step(s.vars, 0.95, s.step))
@@ -208,7 +217,7 @@ def test_ip_single_step_kat(name):
     np.testing.assert_allclose(out["x"], g["kat/x"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(out["res_norms"], g["kat/res_norms"], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(out["Dinv"], g["kat/Dinv"], rtol=1e-6)
-    for key in po.Vars.NAMES:
+    for key in po.Vars.NAMES[:8]:
         ref = g["kat/step_" + key]
         np.testing.assert_allclose(out["step_" + key], ref, rtol=0,
                                    atol=2e-5 * max(1e-3, np.abs(ref).max()), err_msg=key)
