@@ -134,10 +134,34 @@ typedef struct {
 } po_problem_callbacks;
 int po_problem_create_callbacks(po_ctx ctx, int64_t nlocal, int ncon, int ninequality,
                                 const po_problem_callbacks *cb, po_problem *out);
+/* Sparse ("weighting") constraints with block-diagonal Aw D^-1 Aw^T and nwblock = 1
+ * (src/ParOptProblem.h:215-262, src/ParOptSparseMat.cpp:11-229).  `out`, `pzw` and `A` are
+ * w-sized device vectors (nwcon local entries); A is the diagonal the reference passes as a raw
+ * array.  The first nwinequality local constraints are inequalities (cw >= 0). */
+typedef struct po_problem_sparse_callbacks {
+  /* evalSparseCon :215: out = cw(x) */
+  int (*eval_sparse_con)(void *user, po_vec x, po_vec out);
+  /* addSparseJacobian :226: out += alpha * Aw(x) * px */
+  int (*add_sparse_jacobian)(void *user, double alpha, po_vec x, po_vec px, po_vec out);
+  /* addSparseJacobianTranspose :239: out += alpha * Aw(x)^T * pzw */
+  int (*add_sparse_jacobian_transpose)(void *user, double alpha, po_vec x, po_vec pzw, po_vec out);
+  /* addSparseInnerProduct :252: A += alpha * diag(Aw(x) * diag(cvec) * Aw(x)^T) */
+  int (*add_sparse_inner_product)(void *user, double alpha, po_vec x, po_vec cvec, po_vec A);
+} po_problem_sparse_callbacks;
+/* setProblemSizes / setNumInequalities for the sparse block (src/ParOptProblem.h:88-96); only
+ * valid on a problem made by po_problem_create_callbacks, before po_ip_create */
+int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequality,
+                                    const po_problem_sparse_callbacks *cb);
 /* Built-in device-resident workloads of BASELINE.json (DESIGN.md "Workloads"): */
 enum { PO_PROBLEM_QUADRATIC = 0, PO_PROBLEM_CONVEX = 1, PO_PROBLEM_ROSENBROCK = 2 };
 int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon, uint64_t seed,
                                 double eig_min, double eig_max, po_problem *out);
+/* Weighting constraints on a built-in workload (BASELINE.json configs[3]; the pattern of
+ * examples/rosenbrock/rosenbrock.cpp:131-184): cw_i = 1 - sum_{k<nw} x[nwstart + i (nw+nwskip) + k],
+ * i < nwcon (global indices), the first nwinequality of them inequalities.  Before po_ip_create. */
+int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstart, int nwskip,
+                             int64_t nwinequality);
+int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequality_local);
 int po_problem_destroy(po_problem p);
 int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon);
 int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons);
@@ -159,6 +183,9 @@ int po_ip_get_optimized_point(po_ip ip, po_vec *x, const double **z, po_vec *zl,
 /* getOptimizedSlacks .cpp:848-866 (+ the slack multipliers) */
 int po_ip_get_optimized_slacks(po_ip ip, const double **s, const double **t, const double **zs,
                                const double **zt);
+/* the w-sized blocks zw, sw, tw, zsw, ztw of the optimized point (NULL handles when nwcon = 0) */
+int po_ip_get_optimized_sparse(po_ip ip, po_vec *zw, po_vec *sw, po_vec *tw, po_vec *zsw,
+                               po_vec *ztw);
 int po_ip_get_counters(po_ip ip, int *niter, int *neval, int *ngeval); /* getIterationCounters .h:203-217 */
 int po_ip_get_barrier_parameter(po_ip ip, double *mu);      /* .cpp:1110 */
 int po_ip_get_complementarity(po_ip ip, double *comp);      /* .cpp:1118-1120 */

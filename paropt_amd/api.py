@@ -258,12 +258,16 @@ class Problem:
     """Base class for user problems implemented in Python (host arrays through getArray).
 
     Mirrors paropt.ParOpt.Problem: override getVarsAndBounds(x, lb, ub), evalObjCon(x) ->
-    (fail, fobj, con) and evalObjConGradient(x, g, A) -> fail, all on numpy views.
+    (fail, fobj, con) and evalObjConGradient(x, g, A) -> fail, all on numpy views.  With
+    nwcon > 0 (sparse constraints, nwblock = 1) also override evalSparseCon(x, out),
+    addSparseJacobian(alpha, x, px, out), addSparseJacobianTranspose(alpha, x, pzw, out) and
+    addSparseInnerProduct(alpha, x, cvec, A) (A is the w-sized diagonal), all in place on numpy views.
     """
 
-    def __init__(self, ctx, nvars, ncon, ninequality=-1):
+    def __init__(self, ctx, nvars, ncon, ninequality=-1, nwcon=0, nwinequality=0):
         self.ctx = ctx
         self.nvars, self.ncon = int(nvars), int(ncon)
+        self.nwcon = int(nwcon)
         cb = L.ProblemCallbacks()
 
         def _gvb(user, x, lb, ub):
@@ -302,6 +306,35 @@ class Problem:
         self._h = L.po_problem()
         check(lib.po_problem_create_callbacks(ctx.handle, self.nvars, self.ncon, int(ninequality),
                                               C.byref(cb), C.byref(self._h)))
+        if self.nwcon > 0:
+            def _wrap(method):
+                def _f(user, alpha, x, v, out):
+                    vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+                    vv = PVec(ctx, handle=L.po_vec(v), owned=False)
+                    vo = PVec(ctx, handle=L.po_vec(out), owned=False)
+                    ao = vo.getArray()
+                    vo.syncToHost()
+                    method(float(alpha), vx.to_numpy(), vv.to_numpy(), ao)
+                    vo.syncToDevice()
+                    return 0
+                return _f
+
+            def _wcon(user, x, out):
+                vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+                vo = PVec(ctx, handle=L.po_vec(out), owned=False)
+                ao = vo.getArray()
+                self.evalSparseCon(vx.to_numpy(), ao)
+                vo.syncToDevice()
+                return 0
+
+            scb = L.ProblemSparseCallbacks()
+            self._scbs = (L.SPARSE_CON_FN(_wcon), L.SPARSE_JAC_FN(_wrap(self.addSparseJacobian)),
+                          L.SPARSE_JAC_FN(_wrap(self.addSparseJacobianTranspose)),
+                          L.SPARSE_JAC_FN(_wrap(self.addSparseInnerProduct)))
+            (scb.eval_sparse_con, scb.add_sparse_jacobian, scb.add_sparse_jacobian_transpose,
+             scb.add_sparse_inner_product) = self._scbs
+            self._scb_struct = scb
+            check(lib.po_problem_set_sparse_callbacks(self._h, self.nwcon, int(nwinequality), C.byref(scb)))
 
     @property
     def handle(self):
@@ -321,6 +354,19 @@ class SeparableProblem:
         nl, off, nc = C.c_int64(), C.c_int64(), C.c_int()
         check(lib.po_problem_sizes(self._h, C.byref(nl), C.byref(off), C.byref(nc)))
         self.nvars, self.offset, self.ncon = nl.value, off.value, nc.value
+        self.nwcon = 0
+
+    def setWeighting(self, nwcon, nw, nwstart=0, nwskip=0, nwinequality=None):
+        """cw_i = 1 - sum_{k<nw} x[nwstart + i (nw + nwskip) + k], i < nwcon (global indices);
+        the first nwinequality of them are inequalities (all by default)."""
+        if nwinequality is None:
+            nwinequality = nwcon
+        check(lib.po_problem_set_weighting(self._h, int(nwcon), int(nw), int(nwstart), int(nwskip),
+                                           int(nwinequality)))
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.po_problem_sparse_sizes(self._h, C.byref(a), C.byref(b)))
+        self.nwcon = a.value
+        return self
 
     @property
     def handle(self):
@@ -412,6 +458,14 @@ class InteriorPoint:
         c = self.problem.ncon
         return tuple(np.array([p[i] for i in range(c)]) for p in ptrs)
 
+    def getOptimizedSparse(self):
+        """(zw, sw, tw, zsw, ztw) as borrowed PVec handles, or None when nwcon = 0."""
+        hs = [L.po_vec() for _ in range(5)]
+        check(lib.po_ip_get_optimized_sparse(self._h, *[C.byref(h) for h in hs]))
+        if not hs[0]:
+            return None
+        return tuple(PVec(self.ctx, handle=h, owned=False) for h in hs)
+
     def getIterationCounters(self):
         a, b, d = C.c_int(), C.c_int(), C.c_int()
         check(lib.po_ip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(d)))
@@ -470,6 +524,9 @@ class InteriorPoint:
         d = dict(mu=self.getBarrierParameter(), rho=rho, fobj=f, z=z, s=s, t=t, zs=zs, zt=zt,
                  counters=np.array([niter, neval, ngeval]),
                  norms=np.array([x.norm(), zl.norm(), zu.norm()]))
+        wv = self.getOptimizedSparse()
+        if wv is not None:
+            d["wnorms"] = np.array([v.norm() for v in wv])
         qn = self.getQuasiNewton()
         if qn is not None:
             k, b0 = C.c_int(), C.c_double()

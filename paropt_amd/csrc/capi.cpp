@@ -329,6 +329,42 @@ int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon,
   *out = h;
   return PO_OK;
 }
+int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequality,
+                                    const po_problem_sparse_callbacks *cb) {
+  PO_CHECK_PTR(p);
+  PO_CHECK_PTR(cb);
+  CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);
+  if (!q) {
+    po::set_error("po_problem_set_sparse_callbacks needs a callback problem");
+    return PO_ERR_ARG;
+  }
+  if (nwcon < 0 || nwinequality < 0 || nwinequality > nwcon || !cb->eval_sparse_con ||
+      !cb->add_sparse_jacobian || !cb->add_sparse_jacobian_transpose || !cb->add_sparse_inner_product) {
+    po::set_error("bad sparse constraint sizes or missing sparse callbacks");
+    return PO_ERR_ARG;
+  }
+  q->sparse.cb = *cb;
+  q->sparse.set = true;
+  q->nwcon = nwcon;
+  q->nwinequality = nwinequality;
+  return PO_OK;
+}
+int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstart, int nwskip,
+                             int64_t nwinequality) {
+  PO_CHECK_PTR(p);
+  SeparableProblem *q = dynamic_cast<SeparableProblem *>(p->p);
+  if (!q) {
+    po::set_error("po_problem_set_weighting needs a built-in separable problem");
+    return PO_ERR_ARG;
+  }
+  return q->setWeighting(nwcon, nw, nwstart, nwskip, nwinequality);
+}
+int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequality_local) {
+  PO_CHECK_PTR(p);
+  if (nwcon_local) *nwcon_local = p->p->nwcon;
+  if (nwinequality_local) *nwinequality_local = p->p->nwinequality;
+  return PO_OK;
+}
 int po_problem_destroy(po_problem p) {
   if (!p) return PO_OK;
   delete p->p;
@@ -412,6 +448,16 @@ int po_ip_get_optimized_slacks(po_ip ip, const double **s, const double **t, con
                                const double **zt) {
   PO_CHECK_PTR(ip);
   ip->ip->getOptimizedSlacks(s, t, zs, zt);
+  return PO_OK;
+}
+int po_ip_get_optimized_sparse(po_ip ip, po_vec *zw, po_vec *sw, po_vec *tw, po_vec *zsw,
+                               po_vec *ztw) {
+  PO_CHECK_PTR(ip);
+  Vec *v[5];
+  ip->ip->getOptimizedSparse(v);
+  po_vec *o[5] = {zw, sw, tw, zsw, ztw};
+  for (int i = 0; i < 5; i++)
+    if (o[i]) *o[i] = static_cast<po_vec>(v[i]);
   return PO_OK;
 }
 int po_ip_get_counters(po_ip ip, int *niter, int *neval, int *ngeval) {

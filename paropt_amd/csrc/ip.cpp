@@ -203,6 +203,13 @@ InteriorPoint::InteriorPoint(Problem *p)
       ptpx_valid(false), residual_fused(false), residual_cached(false), corrector_active(false),
       norm_type(0), tdots_valid(false), fused_dots(true), phase_t0(0) {
   qn_handle.qn = nullptr;
+  nw = p->nwcon;
+  has_w = false;
+  nw_global = 0.0;
+  gsw = gtw = Cw = wd2 = wyw = wtmp = wtmp2 = d1v = nullptr;
+  for (int i = 0; i < 5; i++) wvar[i] = wresv[i] = wstepv[i] = nullptr;
+  for (int i = 0; i < 7; i++) w_sums[i] = 0.0;
+  for (int i = 0; i < 5; i++) w_maxs[i] = 0.0;
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
@@ -234,6 +241,7 @@ int InteriorPoint::allocate() {
   PO_TRY(k_fill(ctx, zl->d, n, 1.0));
   PO_TRY(k_fill(ctx, zu->d, n, 1.0));
   for (int i = 0; i < c; i++) vars.z[i] = vars.s[i] = vars.t[i] = vars.zs[i] = vars.zt[i] = 1.0;
+  PO_TRY(allocateW());
   return PO_OK;
 }
 
@@ -241,6 +249,14 @@ InteriorPoint::~InteriorPoint() {
   Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn, vA};
   for (Vec *v : all) vec_decref(v);
   for (Vec *v : Ac) vec_decref(v);
+  Vec *wall[] = {gsw, gtw, Cw, wd2, wyw, wtmp, wtmp2, d1v};
+  for (Vec *v : wall) vec_decref(v);
+  for (int i = 0; i < 5; i++) {
+    vec_decref(wvar[i]);
+    vec_decref(wresv[i]);
+    vec_decref(wstepv[i]);
+  }
+  for (Vec *v : Uw) vec_decref(v);
   delete qn;
 }
 
@@ -249,6 +265,7 @@ void InteriorPoint::setPenaltyGamma(double gamma) {  // :1127-1151
   gamma_s.assign(c, gamma);
   gamma_t.assign(c, gamma);
   for (int i = 0; i < c && i < prob->ninequality; i++) gamma_s[i] = 0.0;
+  if (has_w) k_w_gamma(ctx, gsw->d, gtw->d, gamma, prob->nwinequality, nw);  // :1139-1150
 }
 
 int InteriorPoint::createQuasiNewton() {  // ctor :262-292
@@ -354,6 +371,7 @@ int InteriorPoint::initLeastSquaresMultipliers() {  // :5366-5534 (w = 0)
   PO_TRY(k_fill(ctx, zu->d, n, mu0));
   for (int i = 0; i < c; i++) vars.z[i] = vars.s[i] = vars.t[i] = vars.zs[i] = vars.zt[i] = mu0;
   PO_TRY(k_zero_inactive(ctx, lb->d, ub->d, zl->d, zu->d, options.real("max_bound_value"), n));
+  if (has_w) return initLeastSquaresMultipliersW();
   if (c == 0) return PO_OK;
   const double small = 1e-4;
   PO_TRY(k_fill(ctx, Dinv->d, n, 1.0));
@@ -388,7 +406,12 @@ int InteriorPoint::initAffineStepMultipliers() {  // :5536-5656
                   !options.integer("use_qn_gmres_precon") || options.integer("use_diag_hessian"));
   PO_TRY(setUpKKTSystem(use_qn));
   denseResidual(0.0, res);
-  PO_TRY(solveKKT(res, 0.0, use_qn, false, 1.0, step));
+  if (has_w) {
+    PO_TRY(solveKKTW(res, 0.0, use_qn, false, 1.0, step));
+    PO_TRY(k_w_affine(ctx, wv(), wp(), amin, nw));  // :5601-5628
+  } else {
+    PO_TRY(solveKKT(res, 0.0, use_qn, false, 1.0, step));
+  }
   for (int i = 0; i < c; i++) {
     vars.z[i] = vars.z[i] + step.z[i];
     vars.s[i] = std::max(amin, fabs(vars.s[i] + step.s[i]));
@@ -419,10 +442,18 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
 int InteriorPoint::computeResidual(double mu, bool vectors) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   double out[11];
+  if (has_w) PO_TRY(computeResidualW(mu));
   if (vectors) {
     std::vector<const double *> A;
     for (Vec *a : Ac) A.push_back(a->d);
-    PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), vars.z.data(), c, beta_mu, n, rx->d, out));
+    std::vector<double> zc(vars.z);
+    if (has_w) {  // + Aw^T zw as one more panel column (:1358-1361)
+      PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
+      if (prob->addSparseJacobianTranspose(1.0, x, wvar[0], tvec) != 0) return PO_ERR_USER;
+      A.push_back(tvec->d);
+      zc.push_back(1.0);
+    }
+    PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out));
     l1_rx = out[2];
     l2_rx = out[5];
     max_rx = out[8];
@@ -452,6 +483,10 @@ void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual
     }
     if (use_lower) md = std::max(md, max_rzl);
     if (use_upper) md = std::max(md, max_rzu);
+    if (has_w) {  // :1599-1612
+      mi = std::max(mi, w_maxs[0]);
+      md = std::max(md, std::max(std::max(w_maxs[1], w_maxs[2]), std::max(w_maxs[3], w_maxs[4])));
+    }
   } else if (norm_type == 1) {  // l1
     mp = l1_rx;
     for (int i = 0; i < c; i++) {
@@ -463,6 +498,10 @@ void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual
     }
     if (use_lower) md += l1_rzl;
     if (use_upper) md += l1_rzu;
+    if (has_w) {
+      mi += w_sums[1];
+      md += w_sums[3] + w_sums[4] + w_sums[5] + w_sums[6];
+    }
   } else {  // l2
     double prime = 0.0, infeas = 0.0, dual = 0.0;
     for (int i = 0; i < c; i++) {
@@ -475,6 +514,11 @@ void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual
     md = dual;
     if (use_lower) md += l2_rzl;
     if (use_upper) md += l2_rzu;
+    if (has_w) {  // the reference squares the l1 norms of the sparse dual blocks here (:1633-1638)
+      mi += w_sums[2];
+      md += w_sums[3] * w_sums[3] + w_sums[4] * w_sums[4] + w_sums[5] * w_sums[5] +
+            w_sums[6] * w_sums[6];
+    }
     mp = sqrt(mp);
     mi = sqrt(mi);
     md = sqrt(md);
@@ -485,8 +529,13 @@ void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual
   *res_norm = std::max(mp, std::max(md, mi));
 }
 
-double InteriorPoint::compFromSums(double prod, double count, const Dense &v) const {  // :2742-2820
+double InteriorPoint::compFromSums(double prod, double count, const Dense &v,
+                                   double wprod) const {  // :2742-2820
   prod = prod / options.real("rel_bound_barrier");
+  if (has_w) {
+    prod += wprod;
+    count += 2.0 * nw_global;
+  }
   for (int i = 0; i < c; i++) {
     prod += v.s[i] * v.zs[i] + v.t[i] * v.zt[i];
     count += 2.0;
@@ -497,7 +546,9 @@ double InteriorPoint::compFromSums(double prod, double count, const Dense &v) co
 int InteriorPoint::getComplementarity(double *comp) {
   double out[11];
   PO_TRY(k_res_norms(ctx, bounds(), 0.0, n, out));
-  *comp = compFromSums(out[0], out[1], vars);
+  double wprod = 0.0;
+  if (has_w) PO_TRY(wCompStep(0.0, 0.0, &wprod));
+  *comp = compFromSums(out[0], out[1], vars, wprod);
   return PO_OK;
 }
 
@@ -515,6 +566,12 @@ int InteriorPoint::setUpKKTSystem(bool use_qn) {  // setUpKKTDiagSystem + setUpK
   wk = k;
   W.assign((size_t)m * m, 0.0);
   if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+  if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930), then W -= U^T Cw U
+    PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
+    if (prob->addSparseInnerProduct(1.0, x, Dinv, Cw) != 0) return PO_ERR_USER;
+    PO_TRY(k_recip(ctx, Cw->d, nw));
+    PO_TRY(sparseGramCorrection(P, m));
+  }
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)
   Gf.assign((size_t)c * c, 0.0);
   gpiv.assign(c, 0);
@@ -653,6 +710,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
 }
 
 int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double tau) {
+  if (has_w) return computeKKTStepWithRefinementW(mu, use_qn, tau);
   const int nref = options.integer("iterative_refinement_steps");
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   denseResidual(mu, res);
@@ -711,7 +769,11 @@ int InteriorPoint::debugKKTStep(double mu) {
   PO_TRY(computeResidual(mu, true));
   PO_TRY(setUpKKTSystem(true));
   denseResidual(mu, res);
-  PO_TRY(solveKKT(res, mu, true, false, 0.95, step));
+  if (has_w) {
+    PO_TRY(solveKKTW(res, mu, true, false, 0.95, step));
+  } else {
+    PO_TRY(solveKKT(res, mu, true, false, 0.95, step));
+  }
   sx = sz = 1.0;
   return PO_OK;
 }
@@ -746,6 +808,12 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
   double out[2];
   PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, n, out));
   double prod = out[0] / options.real("rel_bound_barrier"), count = out[1];
+  if (has_w) {  // :2866-2889
+    double wprod = 0.0;
+    PO_TRY(wCompStep(ax, az, &wprod));
+    prod += wprod;
+    count += 2.0 * nw_global;
+  }
   for (int i = 0; i < c; i++) {
     prod += ((vars.s[i] + ax * step.s[i]) * (vars.zs[i] + az * step.zs[i]) +
              (vars.t[i] + ax * step.t[i]) * (vars.zt[i] + az * step.zt[i]));
@@ -779,11 +847,17 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
 // merit function and line search
 // ================================================================================================
 double InteriorPoint::evalMeritFromSums(double fk, const double *ck, const double *sk,
-                                        const double *tk, double pos, double neg) const {
-  // evalMeritFunc :3569-3636 after the reduction of the bound terms
+                                        const double *tk, double pos, double neg,
+                                        const double *wsums) const {
+  // evalMeritFunc :3569-3636 after the reduction of the bound terms; wsums (k_w_trial layout) =
+  // {pos log, neg log, |cw - sw + tw|^2, gsw.sw, gtw.tw} of the sparse slacks (not scaled by beta)
   const double beta = options.real("rel_bound_barrier");
   pos *= beta;
   neg *= beta;
+  if (wsums) {
+    pos += wsums[0];
+    neg += wsums[1];
+  }
   for (int i = 0; i < c; i++) {
     if (sk[i] > 1.0) pos += log(sk[i]); else neg += log(sk[i]);
     if (tk[i] > 1.0) pos += log(tk[i]); else neg += log(tk[i]);
@@ -793,8 +867,13 @@ double InteriorPoint::evalMeritFromSums(double fk, const double *ck, const doubl
     const double cv = ck[i] - sk[i] + tk[i];
     dense_infeas += cv * cv;
   }
-  const double infeas = sqrt(dense_infeas);
-  double merit = fk - barrier_param * (pos + neg) + rho_penalty_search * infeas;
+  double sparse_infeas = 0.0, wgam = 0.0;
+  if (wsums) {
+    sparse_infeas = sqrt(wsums[2]);
+    wgam = wsums[3] + wsums[4];
+  }
+  const double infeas = sqrt(dense_infeas + sparse_infeas * sparse_infeas);
+  double merit = (fk + wgam) - barrier_param * (pos + neg) + rho_penalty_search * infeas;
   for (int i = 0; i < c; i++) merit += gamma_s[i] * sk[i] + gamma_t[i] * tk[i];
   return merit;
 }
@@ -818,6 +897,17 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
     PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
   }
   for (int i = 0; i < mq; i++) dots[i] *= sx;
+  double wm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (has_w) {  // :3735-3765, 3489-3503
+    if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
+    PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
+    if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
+    PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, wtmp->d, wtmp2->d, nw, wm));
+    pos += wm[0];
+    neg += wm[1];
+    ppos += wm[2];
+    pneg += wm[3];
+  }
   for (int i = 0; i < c; i++) {
     if (vars.s[i] > 1.0) pos += log(vars.s[i]); else neg += log(vars.s[i]);
     if (step.s[i] > 0.0) ppos += step.s[i] / vars.s[i]; else pneg += step.s[i] / vars.s[i];
@@ -832,8 +922,10 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
     dense_infeas += cval * cval;
     pdense += cval * pcval;
   }
-  const double infeas = sqrt(dense_infeas);
-  const double infeas_proj = infeas > 0.0 ? pdense / infeas : 0.0;
+  const double sparse_infeas = has_w ? sqrt(wm[8]) : 0.0;
+  const double psparse = wm[9];
+  const double infeas = sqrt(dense_infeas + sparse_infeas * sparse_infeas);
+  const double infeas_proj = infeas > 0.0 ? (pdense + psparse) / infeas : 0.0;
   // pTBp = 0.5 px^T B px  (:3820-3821), B px never formed
   double pTBp = 0.0;
   if (qn && !seq_lin) {
@@ -846,8 +938,8 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
     }
     pTBp = 0.5 * v;
   }
-  double merit = fobj - barrier_param * (pos + neg);
-  double pmerit = gpx - barrier_param * (ppos + pneg);
+  double merit = (fobj + (wm[4] + wm[5])) - barrier_param * (pos + neg);
+  double pmerit = (gpx + (wm[6] + wm[7])) - barrier_param * (ppos + pneg);
   for (int i = 0; i < c; i++) {
     merit += gamma_s[i] * vars.s[i] + gamma_t[i] * vars.t[i];
     pmerit += gamma_s[i] * step.s[i] + gamma_t[i] * step.t[i];
@@ -922,7 +1014,13 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       alpha *= 0.1;
       continue;
     }
-    merit = evalMeritFromSums(fobj, cvals.data(), rs.data(), rt.data(), sums[0], sums[1]);
+    double wsums[5];
+    if (has_w) {
+      if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
+      PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
+    }
+    merit = evalMeritFromSums(fobj, cvals.data(), rs.data(), rt.data(), sums[0], sums[1],
+                              has_w ? wsums : nullptr);
     if (best_alpha < 0.0 || merit < best_merit) {
       best_alpha = alpha;
       best_merit = merit;
@@ -992,7 +1090,8 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // iteration's KKT residual rx = [lo]zl - [up]zu - g + A^T z and va = A^T pz (kept by the solves),
   // the second from the NEXT iteration's residual, which is evaluated right after the gradient and
   // reused at the top of the loop.
-  const bool fast_yqn = do_qn && analytic_panel_dots;
+  const bool fast_yqn = do_qn && analytic_panel_dots && !has_w;
+  if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
   if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
                              rx->d, vA->d, alpha * sz, n, y_qn->d));
@@ -1014,6 +1113,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   for (Vec *a : Ac) A.push_back(a->d);
   if (do_qn && !fast_yqn) {  // y_qn = -g + A^T z  at the old point with the new multipliers
     PO_TRY(k_panel_axpy(ctx, y_qn->d, -1.0, g->d, 0.0, vars.z.data(), A.data(), c, n));
+    if (has_w && prob->addSparseJacobianTranspose(1.0, x, wvar[0], y_qn) != 0) return PO_ERR_USER;
   }
   if (eval_obj_con) {
     // the line search was skipped: form the new point now
@@ -1046,6 +1146,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
       std::vector<double> mz(c > 0 ? c : 1);
       for (int i = 0; i < c; i++) mz[i] = -vars.z[i];
       PO_TRY(k_panel_axpy(ctx, y_qn->d, 1.0, g->d, 1.0, mz.data(), A.data(), c, n));
+      if (has_w && prob->addSparseJacobianTranspose(-1.0, x, wvar[0], y_qn) != 0) return PO_ERR_USER;
     }
     int rcc = prob->computeQuasiNewtonUpdateCorrection(x, vars.z.data(), s_qn, y_qn);
     if (rcc != 0) return PO_ERR_USER;
@@ -1176,7 +1277,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
     if (barrier_strategy == B_MONOTONE) {
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
-      comp = compFromSums(comp_prod, comp_count, vars);
+      comp = compFromSums(comp_prod, comp_count, vars, w_sums[0]);
       denseResidual(barrier_param, res);
       resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
       if (k > 0 && ((res_norm < 10.0 * barrier_param) || rel_function_test || (line_search_test >= 2))) {
@@ -1198,13 +1299,13 @@ int InteriorPoint::optimize(const char *checkpoint) {
     } else if (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC) {  // :4737-4746
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
-      comp = compFromSums(comp_prod, comp_count, vars);
+      comp = compFromSums(comp_prod, comp_count, vars, w_sums[0]);
       denseResidual(barrier_param, res);
       resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
     } else {  // complementarity fraction (:4747-4762)
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
-      comp = compFromSums(comp_prod, comp_count, vars);
+      comp = compFromSums(comp_prod, comp_count, vars, w_sums[0]);
       barrier_param = options.real("monotone_barrier_fraction") * comp;
       if (barrier_param < 0.1 * abs_res_tol) barrier_param = 0.1 * abs_res_tol;
       PO_TRY(computeResidual(barrier_param, false));
@@ -1281,6 +1382,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
       double cs[2];
       PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
       double prod = cs[0] / options.real("rel_bound_barrier"), count = cs[1];
+      if (has_w) {
+        double wprod = 0.0;
+        PO_TRY(wCompStep(max_x, max_z, &wprod));
+        prod += wprod;
+        count += 2.0 * nw_global;
+      }
       for (int i = 0; i < c; i++) {
         prod += ((vars.s[i] + max_x * step.s[i]) * (vars.zs[i] + max_z * step.zs[i]) +
                  (vars.t[i] + max_x * step.t[i]) * (vars.zt[i] + max_z * step.zt[i]));
@@ -1303,8 +1410,13 @@ int InteriorPoint::optimize(const char *checkpoint) {
           res.zs[i] -= step.s[i] * step.zs[i];
           res.zt[i] -= step.t[i] * step.zt[i];
         }
+        if (has_w) {
+          PO_TRY(computeResidualW(barrier_param));
+          PO_TRY(k_w_corrector(ctx, wp(), wr(), nw));
+        }
         corrector_active = true;
-        int rcs = solveKKT(res, barrier_param, use_qn, false, tau, step);
+        int rcs = has_w ? solveKKTW(res, barrier_param, use_qn, false, tau, step)
+                        : solveKKT(res, barrier_param, use_qn, false, tau, step);
         corrector_active = false;
         PO_TRY(rcs);
         sx = sz = 1.0;
@@ -1379,7 +1491,13 @@ int InteriorPoint::optimize(const char *checkpoint) {
       // merit at the new point (:5236-5237): barrier sums of x itself (a zero step from x)
       double bs[2];
       PO_TRY(k_trial(ctx, bounds(), px->d, 0.0, design_precision, n, xt->d, bs));
-      const double m1 = evalMeritFromSums(fobj, cvals.data(), vars.s.data(), vars.t.data(), bs[0], bs[1]);
+      double wsums[5];
+      if (has_w) {
+        if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
+        PO_TRY(k_w_trial(ctx, wv(), wp(), 0.0, design_precision, gsw->d, gtw->d, wtmp->d, nw, wsums));
+      }
+      const double m1 = evalMeritFromSums(fobj, cvals.data(), vars.s.data(), vars.t.data(), bs[0], bs[1],
+                                          has_w ? wsums : nullptr);
       if ((m1 <= m0 + fprec) && (m1 + fprec >= m0)) {
         line_fail |= LS_NO_IMPROVEMENT;
       } else if (fabs(dm0) <= fprec) {
@@ -1442,7 +1560,7 @@ int InteriorPoint::writeSolutionFile(const char *filename) {
     set_error("cannot open checkpoint file %s", name.c_str());
     return PO_ERR_ARG;
   }
-  int sizes[3] = {(int)prob->nglobal, 0, c};
+  int sizes[3] = {(int)prob->nglobal, (int)nw_global, c};
   fwrite(sizes, sizeof(int), 3, fp);
   fwrite(&barrier_param, sizeof(double), 1, fp);
   fwrite(vars.s.data(), sizeof(double), c, fp);
@@ -1462,6 +1580,19 @@ int InteriorPoint::writeSolutionFile(const char *filename) {
     }
     fwrite(host.data(), sizeof(double), (size_t)n, fp);
   }
+  if (has_w) {  // zw then sw, as the reference (:951-968)
+    std::vector<double> hw((size_t)(nw > 0 ? nw : 1));
+    for (int i = 0; i < 2; i++) {
+      if (hipMemcpyAsync(hw.data(), wvar[i]->d, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost,
+                         ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        fclose(fp);
+        set_error("checkpoint download failed");
+        return PO_ERR_HIP;
+      }
+      fwrite(hw.data(), sizeof(double), (size_t)nw, fp);
+    }
+  }
   fclose(fp);
   return PO_OK;
 }
@@ -1477,7 +1608,7 @@ int InteriorPoint::readSolutionFile(const char *filename) {
   }
   int sizes[3] = {0, 0, 0};
   bool ok = fread(sizes, sizeof(int), 3, fp) == 3;
-  if (!ok || sizes[0] != (int)prob->nglobal || sizes[1] != 0 || sizes[2] != c) {
+  if (!ok || sizes[0] != (int)prob->nglobal || sizes[1] != (int)nw_global || sizes[2] != c) {
     fclose(fp);
     set_error("ParOpt: Problem size incompatible with solution file");
     return PO_ERR_ARG;
@@ -1493,6 +1624,17 @@ int InteriorPoint::readSolutionFile(const char *filename) {
                               ctx->stream) != hipSuccess ||
                hipStreamSynchronize(ctx->stream) != hipSuccess)) {
       ok = false;
+    }
+  }
+  if (has_w) {
+    std::vector<double> hw((size_t)(nw > 0 ? nw : 1));
+    for (int i = 0; i < 2; i++) {
+      ok = ok && fread(hw.data(), sizeof(double), (size_t)nw, fp) == (size_t)nw;
+      if (ok && (hipMemcpyAsync(wvar[i]->d, hw.data(), sizeof(double) * (size_t)nw,
+                                hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                 hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        ok = false;
+      }
     }
   }
   fclose(fp);

@@ -1,6 +1,7 @@
 // Host-side mirror of ParOptInteriorPoint (reference src/ParOptInteriorPoint.h:128-217) for the
-// quasi-Newton branch with dense constraints (nwcon = 0).  Same public method names, option
-// names/defaults and return codes; every n-sized operation is a HIP kernel launch (core.hpp).
+// quasi-Newton branch: dense constraints, plus the sparse "weighting" constraints with nwblock = 1
+// (ip_w.cpp).  Same public method names, option names/defaults and return codes; every n- or
+// w-sized operation is a HIP kernel launch (core.hpp, wcon.hpp).
 #pragma once
 #include <map>
 #include <string>
@@ -57,6 +58,7 @@ class InteriorPoint {
   int optimize(const char *checkpoint);
   void getOptimizedPoint(Vec **x, const double **z, Vec **zl, Vec **zu);
   void getOptimizedSlacks(const double **s, const double **t, const double **zs, const double **zt);
+  void getOptimizedSparse(Vec *v[5]);  // zw, sw, tw, zsw, ztw (null when nwcon = 0)
   void getIterationCounters(int *niter_, int *neval_, int *ngeval_);
   double getBarrierParameter() const { return barrier_param; }
   int getComplementarity(double *comp);
@@ -95,6 +97,12 @@ class InteriorPoint {
   // step storage (exposed for the single-step known-answer tests)
   Vec *px, *pzl, *pzu;
 
+  // sparse constraint blocks (nwblock = 1): zw, sw, tw, zsw, ztw of the variables / residual / step
+  int64_t nw;        // local number of sparse constraints
+  bool has_w;        // some rank has sparse constraints (uniform across ranks)
+  double nw_global;  // total count (for the complementarity average)
+  Vec *wvar[5], *wresv[5], *wstepv[5];
+
  private:
   // work vectors
   Vec *Dinv, *rx, *tvec, *xt, *y_qn, *s_qn;
@@ -127,6 +135,23 @@ class InteriorPoint {
   bool tdots_valid;
   bool fused_dots;        // use k_solve2_dots (switch PAROPT_AMD_NO_FUSED_DOTS=1 to compare)
 
+  // ---- sparse-constraint path (ip_w.cpp) ----
+  Vec *gsw, *gtw, *Cw, *wd2, *wyw, *wtmp, *wtmp2;
+  Vec *d1v;                 // n-sized: raw d1, then v = d1 + P alpha
+  std::vector<Vec *> Uw;    // U_j = Aw (Dinv o P_j)
+  double w_sums[7], w_maxs[5];  // reductions of the last w residual (k_w_res layout)
+  WVars wv() const;
+  WVars wr() const;
+  WVars wp() const;
+  int allocateW();
+  int applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw);
+  int computeResidualW(double mu);
+  int sparseGramCorrection(const std::vector<const double *> &P, int m);
+  int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out);
+  int computeKKTStepWithRefinementW(double mu, bool use_qn, double tau);
+  int initLeastSquaresMultipliersW();
+  int wCompStep(double ax, double az, double *prod);
+
   Bounds bounds() const;
   std::vector<const double *> panel(bool use_qn, int *k) const;
 
@@ -138,7 +163,7 @@ class InteriorPoint {
   int computeResidual(double mu, bool vectors);
   void resNorms(const Dense &r, double *max_prime, double *max_dual, double *max_infeas,
                 double *res_norm) const;
-  double compFromSums(double prod, double count, const Dense &v) const;
+  double compFromSums(double prod, double count, const Dense &v, double wprod = 0.0) const;
   int setUpKKTSystem(bool use_qn);
   int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                bool fuse_residual = false);
@@ -146,7 +171,7 @@ class InteriorPoint {
   int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq);
   int evalMeritInitDeriv(double max_x, double *merit, double *pmerit);
   double evalMeritFromSums(double fk, const double *ck, const double *sk, const double *tk,
-                           double pos, double neg) const;
+                           double pos, double neg, const double *wsums = nullptr) const;
   int lineSearch(double alpha_min, double *alpha, double m0, double dm0, int *fail);
   int computeStepAndUpdate(double alpha, int eval_obj_con, int perform_qn_update, int *update_type);
   void phaseBegin();

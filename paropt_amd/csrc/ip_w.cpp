@@ -1,0 +1,287 @@
+// The sparse ("weighting") constraint path of the interior-point mirror: nwcon > 0 with nwblock = 1,
+// i.e. a diagonal Cw = (Cdiag + Aw D^-1 Aw^T)^-1 (reference src/ParOptSparseMat.cpp:41-229 and the
+// `nwcon > 0` branches of src/ParOptInteriorPoint.cpp cited per function).
+//
+// The design-space operator of K0 changes from diag(Dinv) to
+//     D0x^-1 = Dinv - Dinv Aw^T Cw Aw Dinv                      (ParOptQuasiDefBlockMat::apply :122-190)
+// and everything the dense path does with the weighted Gram  W = P^T Dinv P  carries over with
+//     W = P^T Dinv P - U^T Cw U,   U_j = Aw (Dinv o P_j)        (one extra w-sized Gram)
+// so the Schur complements G, Ce and the analytic P^T px bookkeeping are unchanged (ip.cpp).
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "ip.hpp"
+
+namespace po {
+
+WVars InteriorPoint::wv() const { return WVars{wvar[0]->d, wvar[1]->d, wvar[2]->d, wvar[3]->d, wvar[4]->d}; }
+WVars InteriorPoint::wr() const {
+  return WVars{wresv[0]->d, wresv[1]->d, wresv[2]->d, wresv[3]->d, wresv[4]->d};
+}
+WVars InteriorPoint::wp() const {
+  return WVars{wstepv[0]->d, wstepv[1]->d, wstepv[2]->d, wstepv[3]->d, wstepv[4]->d};
+}
+
+void InteriorPoint::getOptimizedSparse(Vec *v[5]) {
+  for (int i = 0; i < 5; i++) v[i] = has_w ? wvar[i] : nullptr;
+}
+
+int InteriorPoint::allocateW() {
+  // path selection must be uniform across ranks (every reduction is collective)
+  Vec *cnt = vec_new(ctx, 1);
+  if (!cnt) return PO_ERR_HIP;
+  PO_TRY(k_fill(ctx, cnt->d, 1, (double)nw));
+  double total = 0.0;
+  PO_TRY(k_reduce1(ctx, RED_ASUM, cnt->d, nullptr, 1, &total));
+  vec_decref(cnt);
+  nw_global = total;
+  has_w = total > 0.0;
+  if (!has_w) return PO_OK;
+  Vec **all[] = {&gsw, &gtw, &Cw, &wd2, &wyw, &wtmp, &wtmp2};
+  for (Vec **v : all) {
+    *v = vec_new(ctx, nw);
+    if (!*v) return PO_ERR_HIP;
+  }
+  for (int i = 0; i < 5; i++) {
+    wvar[i] = vec_new(ctx, nw);
+    wresv[i] = vec_new(ctx, nw);
+    wstepv[i] = vec_new(ctx, nw);
+    if (!wvar[i] || !wresv[i] || !wstepv[i]) return PO_ERR_HIP;
+    PO_TRY(k_fill(ctx, wvar[i]->d, nw, 1.0));  // constructor state (:439-446)
+  }
+  d1v = vec_new(ctx, n);
+  if (!d1v) return PO_ERR_HIP;
+  PO_TRY(k_w_gamma(ctx, gsw->d, gtw->d, options.real("penalty_gamma"), prob->nwinequality, nw));
+  return PO_OK;
+}
+
+// (yx, yw) <- K0^-1 (bx, bw), ParOptQuasiDefBlockMat::apply (src/ParOptSparseMat.cpp:122-190);
+// bw == nullptr stands for a zero block.  bx must not alias yx->d.
+int InteriorPoint::applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw) {
+  PO_TRY(k_mul(ctx, yx->d, 1.0, Dinv->d, bx, n));
+  if (bw) {
+    PO_TRY(k_copy(ctx, yw->d, bw, nw));
+  } else {
+    PO_TRY(k_fill(ctx, yw->d, nw, 0.0));
+  }
+  if (prob->addSparseJacobian(-1.0, x, yx, yw) != 0) return PO_ERR_USER;
+  PO_TRY(k_mul(ctx, yw->d, 1.0, Cw->d, yw->d, nw));
+  PO_TRY(k_copy(ctx, yx->d, bx, n));
+  if (prob->addSparseJacobianTranspose(1.0, x, yw, yx) != 0) return PO_ERR_USER;
+  PO_TRY(k_mul(ctx, yx->d, 1.0, Dinv->d, yx->d, n));
+  return PO_OK;
+}
+
+// the w blocks of computeKKTRes (:1358-1398) and their norms
+int InteriorPoint::computeResidualW(double mu) {
+  if (prob->evalSparseCon(x, wresv[0]) != 0) return PO_ERR_USER;
+  double out[12];
+  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, out));
+  for (int i = 0; i < 7; i++) w_sums[i] = out[i];
+  for (int i = 0; i < 5; i++) w_maxs[i] = out[7 + i];
+  return PO_OK;
+}
+
+int InteriorPoint::wCompStep(double ax, double az, double *prod) {
+  return k_w_comp_step(ctx, wv(), wp(), ax, az, nw, prod);
+}
+
+// W -= U^T Cw U with U_j = Aw (Dinv o P_j)
+int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m) {
+  if (m <= 0) return PO_OK;
+  while ((int)Uw.size() < m) {
+    Vec *u = vec_new(ctx, nw);
+    if (!u) return PO_ERR_HIP;
+    Uw.push_back(u);
+  }
+  std::vector<double *> U(m);
+  std::vector<const double *> Uc(m);
+  for (int j = 0; j < m; j++) {
+    U[j] = Uw[j]->d;
+    Uc[j] = Uw[j]->d;
+  }
+  PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), tvec));
+  std::vector<double> W2((size_t)m * m, 0.0);
+  PO_TRY(k_wgram(ctx, Cw->d, Uc.data(), m, nw, W2.data()));
+  for (size_t i = 0; i < W2.size(); i++) W[i] -= W2[i];
+  return PO_OK;
+}
+
+// computeKKTStep (:2700-2737) with both solveKKTDiagSystem overloads folded together, sparse blocks
+// included.  first pass: rhs = (rx, wres, b); refine pass: d1v already holds the raw d1' and wres r'.
+int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau,
+                             Dense &out) {
+  const double beta_mu = options.real("rel_bound_barrier") * mu;
+  int k = 0;
+  std::vector<const double *> P = panel(use_qn, &k);
+  if (k != wk) {
+    set_error("internal: panel width changed between setUpKKTSystem and solve (%d vs %d)", k, wk);
+    return PO_ERR_ARG;
+  }
+  const int m = c + k;
+  const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
+  const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
+  if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, beta_mu, n, d1v->d, cl, cu));
+  PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
+  PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+  std::vector<double> dots(m > 0 ? m : 1, 0.0);
+  if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
+  for (int i = 0; i < c; i++) {
+    yz[i] = (b.z[i] + (b.zs[i] + vars.s[i] * b.s[i]) / vars.zs[i] -
+             (b.zt[i] + vars.t[i] * b.t[i]) / vars.zt[i] - dots[i]);
+  }
+  if (c > 0) lu_solve(c, Gf.data(), c, gpiv.data(), yz.data());
+  if (k > 0) {
+    for (int i = 0; i < k; i++) {
+      double v = dots[c + i];
+      for (int l = 0; l < c; l++) v += W[(c + i) + (size_t)m * l] * yz[l];
+      zeta[i] = v;
+    }
+    lu_solve(k, Cef.data(), k, cpiv.data(), zeta.data());
+    for (int i = 0; i < c; i++) {
+      double v = 0.0;
+      for (int j = 0; j < k; j++) v += W[i + (size_t)m * (c + j)] * zeta[j];
+      yz2[i] = -v;
+    }
+    if (c > 0) lu_solve(c, Gf.data(), c, gpiv.data(), yz2.data());
+  }
+  std::vector<double> alpha(m > 0 ? m : 1, 0.0);
+  for (int i = 0; i < c; i++) alpha[i] = yz[i] - yz2[i];
+  for (int j = 0; j < k; j++) alpha[c + j] = -zeta[j];
+  if (!refine_pass) ptpx.assign(m > 0 ? m : 1, 0.0);
+  for (int i = 0; i < m; i++) {
+    double v = dots[i];
+    for (int j = 0; j < m; j++) v += W[i + (size_t)m * j] * alpha[j];
+    ptpx[i] = refine_pass ? ptpx[i] + v : v;
+  }
+  ptpx_valid = true;
+  tdots_valid = false;
+  residual_fused = false;
+  // (dx, dzw) = K0^-1 (d1 + P alpha, d2): by linearity the full solve minus the bx-only solve
+  if (m > 0) PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, alpha.data(), P.data(), m, n));
+  PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+  double mins_x[2], mins_w[2];
+  PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, nullptr, nullptr, 0, beta_mu, refine_pass ? 1 : 0,
+                  tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
+                  cu));
+  PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
+  step_mins[0] = std::min(mins_x[0], mins_w[0]);
+  step_mins[1] = std::min(mins_x[1], mins_w[1]);
+  for (int i = 0; i < c; i++) {
+    const double zs1 = yz[i] - b.s[i];
+    const double zt1 = -b.t[i] - yz[i];
+    out.z[i] = yz[i] - yz2[i];
+    out.zs[i] = zs1 - yz2[i];
+    out.zt[i] = zt1 + yz2[i];
+    out.s[i] = (b.zs[i] - vars.s[i] * zs1) / vars.zs[i] + (vars.s[i] * yz2[i]) / vars.zs[i];
+    out.t[i] = (b.zt[i] - vars.t[i] * zt1) / vars.zt[i] - (vars.t[i] * yz2[i]) / vars.zt[i];
+  }
+  return PO_OK;
+}
+
+int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double tau) {
+  const int nref = options.integer("iterative_refinement_steps");
+  const double beta_mu = options.real("rel_bound_barrier") * mu;
+  const bool seq_lin = options.integer("sequential_linear_method");
+  PO_TRY(computeResidualW(mu));
+  denseResidual(mu, res);
+  PO_TRY(solveKKTW(res, mu, use_qn, false, tau, step));
+  for (int it = 0; it < nref; it++) {  // :4985-4991
+    int kq = 0;
+    std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
+    const int mq = c + kq;
+    std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
+    if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
+      for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
+    } else if (mq > 0) {
+      PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+    }
+    double diag = options.real("qn_sigma");
+    std::vector<double> coef(mq + 1, 0.0);
+    for (int i = 0; i < c; i++) coef[i] = step.z[i];
+    if (qn && !seq_lin) {
+      diag += qn->diag();
+      if (kq > 0) {
+        std::vector<double> rz(dots.begin() + c, dots.begin() + c + kq);
+        qn->applyCompactInverse(rz.data());
+        for (int j = 0; j < kq; j++) coef[c + j] = rz[j];
+      }
+    }
+    // addKKTResStep (:1451-1583): design rows with the extra column Aw^T pzw, raw d1' into d1v
+    PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
+    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
+    Pq.push_back(tvec->d);
+    coef[mq] = 1.0;
+    PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
+                      mq + 1, diag, beta_mu, n, d1v->d));
+    // sparse rows (:1492-1527)
+    PO_TRY(computeResidualW(mu));
+    if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;
+    PO_TRY(k_w_res_step(ctx, wv(), wp(), wr(), nw));
+    Dense r2;
+    r2.resize(c);
+    denseResidual(mu, r2);
+    for (int i = 0; i < c; i++) {  // dense rows :1529-1535
+      r2.z[i] -= (dots[i] - step.s[i] + step.t[i]);
+      r2.s[i] += (step.zs[i] - step.z[i]);
+      r2.t[i] += (step.zt[i] + step.z[i]);
+      r2.zs[i] -= (step.s[i] * vars.zs[i] + vars.s[i] * step.zs[i]);
+      r2.zt[i] -= (step.t[i] * vars.zt[i] + vars.t[i] * step.zt[i]);
+    }
+    PO_TRY(solveKKTW(r2, mu, use_qn, true, tau, refine));
+    for (int i = 0; i < c; i++) {
+      step.z[i] += refine.z[i];
+      step.s[i] += refine.s[i];
+      step.t[i] += refine.t[i];
+      step.zs[i] += refine.zs[i];
+      step.zt[i] += refine.zt[i];
+    }
+  }
+  sx = sz = 1.0;
+  return PO_OK;
+}
+
+// initLeastSquaresMultipliers (:5366-5534) with the sparse blocks
+int InteriorPoint::initLeastSquaresMultipliersW() {
+  const double mu0 = options.real("init_barrier_param");
+  for (int i = 0; i < 5; i++) PO_TRY(k_fill(ctx, wvar[i]->d, nw, mu0));
+  const double small = 1e-4;
+  PO_TRY(k_fill(ctx, Dinv->d, n, 1.0));
+  PO_TRY(k_fill(ctx, Cw->d, nw, small));
+  if (prob->addSparseInnerProduct(1.0, x, Dinv, Cw) != 0) return PO_ERR_USER;
+  PO_TRY(k_recip(ctx, Cw->d, nw));
+  int k = 0;
+  std::vector<const double *> A = panel(false, &k);
+  W.assign((size_t)c * c, 0.0);
+  std::vector<int> piv(c > 0 ? c : 1);
+  if (c > 0) {
+    PO_TRY(k_wgram(ctx, Dinv->d, A.data(), c, n, W.data()));
+    PO_TRY(sparseGramCorrection(A, c));
+    for (int i = 0; i < c; i++) W[(size_t)i * (c + 1)] += small;
+    lu_factor(c, W.data(), c, piv.data());
+  }
+  // rx = -(g - zl + zu)
+  const double al[2] = {1.0, -1.0};
+  const double *vv[2] = {zl->d, zu->d};
+  PO_TRY(k_panel_axpy(ctx, d1v->d, -1.0, g->d, 0.0, al, vv, 2, n));
+  PO_TRY(applyK0(d1v->d, nullptr, tvec, wyw));
+  std::vector<double> z(c > 0 ? c : 1, 0.0);
+  if (c > 0) {
+    PO_TRY(k_mdot(ctx, tvec->d, A.data(), c, n, z.data()));
+    for (int i = 0; i < c; i++) z[i] = -z[i];
+    lu_solve(c, W.data(), c, piv.data(), z.data());
+    PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, z.data(), A.data(), c, n));
+  }
+  PO_TRY(applyK0(d1v->d, nullptr, tvec, wyw));
+  for (int i = 0; i < c; i++) {
+    const double gam = 10.0 * std::max(gamma_s[i], gamma_t[i]);
+    vars.z[i] = (z[i] < -gam || z[i] > gam) ? 0.0 : z[i];
+  }
+  PO_TRY(k_w_clip(ctx, wvar[0]->d, wyw->d, gsw->d, gtw->d, nw));
+  return PO_OK;
+}
+
+}  // namespace po

@@ -833,7 +833,8 @@ __global__ void __launch_bounds__(kBlock)
               double *__restrict__ t) {
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 r = ld2(rx, q, n), dv = ld2(dinv, q, n);
+    const double2 r = ld2(rx, q, n);
+    const double2 dv = dinv ? ld2(dinv, q, n) : make_double2(1.0, 1.0);  // null: raw d1
     double2 c0 = make_double2(0.0, 0.0), c1 = c0;
     if (cl) {
       c0 = ld2(cl, q, n);
@@ -1174,8 +1175,8 @@ __global__ void __launch_bounds__(kBlock)
   PO_PAIR_LOOP(q, n) {
     const double2 acc = panel_sum(P, coef, nv, q);
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n),
-                  dv = ld2(dinv, q, n);
+    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    const double2 dv = dinv ? ld2(dinv, q, n) : make_double2(1.0, 1.0);  // null: raw d1'
     st2(tp, q, n,
         make_double2(res_step_elem(e0, r.x, acc.x, diag, p.x, l.x, u.x, dv.x, beta_mu, b.use_lower,
                                    b.use_upper),

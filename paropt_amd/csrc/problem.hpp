@@ -1,10 +1,12 @@
-// Host-side mirror of the reference's ParOptProblem interface (src/ParOptProblem.h:42-296) for
-// dense constraints (nwcon = 0): same method names and argument meaning, device vectors.
+// Host-side mirror of the reference's ParOptProblem interface (src/ParOptProblem.h:42-296): dense
+// constraints plus the sparse "weighting" constraints with nwblock = 1 (block-diagonal
+// Aw D^-1 Aw^T): same method names and argument meaning, device vectors.
 #pragma once
 #include <vector>
 
 #include "core.hpp"
 #include "qn.hpp"
+#include "wcon.hpp"
 
 namespace po {
 
@@ -20,10 +22,25 @@ class Problem {
   virtual int writeOutput(int iter, Vec *x) { return 0; }
   virtual int useLowerBounds() { return 1; }
   virtual int useUpperBounds() { return 1; }
+  // sparse constraints (src/ParOptProblem.h:215-262); out / pzw / A are w-sized device vectors
+  virtual int evalSparseCon(Vec *x, Vec *out) { return 0; }
+  virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) { return 0; }
+  virtual int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) { return 0; }
+  virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) { return 0; }
+  // U_j = Aw (d o P_j) for a whole panel; the default goes column by column through
+  // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
+  virtual int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
+                                  Vec *work);
 
   Ctx *ctx;
   int64_t nlocal, offset, nglobal;
   int ncon, ninequality;
+  int64_t nwcon = 0, nwinequality = 0;  // local counts, as in the reference
+};
+
+struct SparseCallbacks {
+  po_problem_sparse_callbacks cb;
+  bool set = false;
 };
 
 // C callback table (the shape of the reference's Cython trampolines, src/CyParOptProblem.h:44-69)
@@ -36,7 +53,12 @@ class CallbackProblem : public Problem {
   int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) override;
   int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) override;
   int writeOutput(int iter, Vec *x) override;
+  int evalSparseCon(Vec *x, Vec *out) override;
+  int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
+  int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
+  int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   po_problem_callbacks cb;
+  SparseCallbacks sparse;
 };
 
 // Device-resident separable workloads (DESIGN.md "Workloads").
@@ -49,6 +71,16 @@ class SeparableProblem : public Problem {
   int getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) override;
   int evalObjCon(Vec *x, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) override;
+  // weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i (nw + nwskip) + k] on GLOBAL indices;
+  // groups must not straddle rank boundaries (checked)
+  int setWeighting(int64_t nwcon_global, int nw, int64_t nwstart, int nwskip, int64_t nwineq_global);
+  int evalSparseCon(Vec *x, Vec *out) override;
+  int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
+  int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
+  int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
+  int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
+                          Vec *work) override;
+  GroupMap gmap;
 
   int kind;
   uint64_t seed;

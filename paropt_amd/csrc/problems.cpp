@@ -11,6 +11,18 @@ static void shard(int64_t n, int rank, int size, int64_t *nlocal, int64_t *offse
   *offset = rank * base + (rank < rem ? rank : rem);
 }
 
+// ---- generic sparse-panel fallback ------------------------------------------------------------
+int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
+                                 Vec *work) {
+  for (int j = 0; j < nv; j++) {
+    PO_TRY(k_mul(ctx, work->d, 1.0, d->d, P[j], nlocal));
+    PO_TRY(k_fill(ctx, U[j], nwcon, 0.0));
+    Vec u{ctx, nwcon, U[j], 1, nullptr};
+    if (addSparseJacobian(1.0, x, work, &u) != 0) return PO_ERR_USER;
+  }
+  return PO_OK;
+}
+
 // ---- callbacks --------------------------------------------------------------------------------
 int CallbackProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
   if (!cb.get_vars_and_bounds) {
@@ -37,6 +49,26 @@ int CallbackProblem::computeQuasiNewtonUpdateCorrection(Vec *x, const double *z,
 int CallbackProblem::writeOutput(int iter, Vec *x) {
   if (!cb.write_output) return 0;
   return cb.write_output(cb.user, iter, static_cast<po_vec>(x));
+}
+
+int CallbackProblem::evalSparseCon(Vec *x, Vec *out) {
+  if (!sparse.set || !sparse.cb.eval_sparse_con) return nwcon > 0 ? 1 : 0;
+  return sparse.cb.eval_sparse_con(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(out));
+}
+int CallbackProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  if (!sparse.set || !sparse.cb.add_sparse_jacobian) return nwcon > 0 ? 1 : 0;
+  return sparse.cb.add_sparse_jacobian(cb.user, alpha, static_cast<po_vec>(x),
+                                       static_cast<po_vec>(px), static_cast<po_vec>(out));
+}
+int CallbackProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  if (!sparse.set || !sparse.cb.add_sparse_jacobian_transpose) return nwcon > 0 ? 1 : 0;
+  return sparse.cb.add_sparse_jacobian_transpose(cb.user, alpha, static_cast<po_vec>(x),
+                                                 static_cast<po_vec>(pzw), static_cast<po_vec>(out));
+}
+int CallbackProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
+  if (!sparse.set || !sparse.cb.add_sparse_inner_product) return nwcon > 0 ? 1 : 0;
+  return sparse.cb.add_sparse_inner_product(cb.user, alpha, static_cast<po_vec>(x),
+                                            static_cast<po_vec>(cvec), static_cast<po_vec>(A));
 }
 
 // ---- separable workloads ----------------------------------------------------------------------
@@ -96,6 +128,57 @@ int SeparableProblem::init() {
     vec_decref(ones);
   }
   return PO_OK;
+}
+
+int SeparableProblem::setWeighting(int64_t nwg, int nw, int64_t nwstart, int nwskip, int64_t nwineq) {
+  if (nwg < 0 || nw <= 0 || nwstart < 0 || nwskip < 0 || nwineq < 0 || nwineq > nwg) {
+    set_error("setWeighting: bad arguments");
+    return PO_ERR_ARG;
+  }
+  const int64_t period = (int64_t)nw + nwskip;
+  if (nwstart + (nwg - 1) * period + nw > nglobal && nwg > 0) {
+    set_error("setWeighting: groups reach past the last variable");
+    return PO_ERR_ARG;
+  }
+  int64_t first = 0, count = nwg;  // global index of this rank's first group, number of local groups
+  int64_t lstart = nwstart;
+  if (ctx->size > 1) {
+    // group i lives where its first variable lives; it must end on the same rank
+    if (nwstart + nw > period || nlocal % period != 0 || offset % period != 0) {
+      set_error("setWeighting: with %d ranks the shard size (%lld) must be a multiple of nw+nwskip",
+                ctx->size, (long long)nlocal);
+      return PO_ERR_ARG;
+    }
+    first = offset / period;
+    count = nlocal / period;
+    if (first > nwg) first = nwg;
+    if (first + count > nwg) count = nwg - first;
+  }
+  gmap.nwcon = count;
+  gmap.start = lstart;
+  gmap.nw = nw;
+  gmap.skip = nwskip;
+  nwcon = count;
+  nwinequality = nwineq - first;
+  if (nwinequality < 0) nwinequality = 0;
+  if (nwinequality > count) nwinequality = count;
+  return PO_OK;
+}
+int SeparableProblem::evalSparseCon(Vec *x, Vec *out) {
+  return k_group_sum(ctx, gmap, out->d, 0, 1.0, -1.0, x->d);
+}
+int SeparableProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  return k_group_sum(ctx, gmap, out->d, 1, 0.0, -alpha, px->d);
+}
+int SeparableProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  return k_group_scatter(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
+}
+int SeparableProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
+  return k_group_sum(ctx, gmap, A->d, 1, 0.0, alpha, cvec->d);
+}
+int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
+                                          double *const *U, Vec *work) {
+  return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
 }
 
 int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {

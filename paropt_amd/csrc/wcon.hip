@@ -1,0 +1,429 @@
+// Kernels of the weighting / sparse-constraint blocks (nwcon > 0, block-diagonal Aw D^-1 Aw^T with
+// nwblock = 1): the w-sized pieces of ParOptInteriorPoint (zw, sw, tw, zsw, ztw) and of
+// ParOptQuasiDefBlockMat (reference src/ParOptSparseMat.cpp:11-229), plus the structured Jacobian
+// of the built-in workloads (one constraint per group of `nw` consecutive variables, the pattern of
+// examples/rosenbrock/rosenbrock.cpp:131-184).  w is a small fraction of n (config 4: n/20), so
+// these are plain one-element-per-thread kernels; the n-sized passes stay in kernels.hip.
+#include <math.h>
+
+#include "core.hpp"
+#include "wcon.hpp"
+
+namespace po {
+
+#define PO_W_LOOP(i, n)                                                                   \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);               \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+#define PO_WLAUNCH(kernel, grid, ...)                                                     \
+  do {                                                                                    \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, __VA_ARGS__);      \
+    c->n_launches++;                                                                      \
+    PO_HIP(hipGetLastError());                                                            \
+  } while (0)
+
+static int wgrid(Ctx *c, int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > (int64_t)c->num_cu * 4) b = (int64_t)c->num_cu * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int OP>
+__device__ __forceinline__ double wcomb(double a, double b) {
+  if (OP == 0) return a + b;
+  if (OP == 1) return fmin(a, b);
+  return fmax(a, b);
+}
+template <int N, int OP>
+__device__ __forceinline__ void w_block_reduce(double (&a)[N], double *partials, int slot0, double *sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double v = a[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = wcomb<OP>(v, __shfl_xor(v, o, 64));
+    if (lane == 0) sm[wave * N + j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < N) {
+    const int j = threadIdx.x;
+    partials[(size_t)(slot0 + j) * gridDim.x + blockIdx.x] =
+        wcomb<OP>(wcomb<OP>(sm[j], sm[N + j]), wcomb<OP>(sm[2 * N + j], sm[3 * N + j]));
+  }
+  __syncthreads();
+}
+
+// ---- structured Jacobian of the built-in problems --------------------------------------------------
+// out_i = (init ? out_i : cst) + alpha * sum_{k<nw} v[start + i*(nw+skip) + k]
+__global__ void __launch_bounds__(kBlock)
+    group_sum_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
+                     const double *__restrict__ v) {
+  PO_W_LOOP(i, m.nwcon) {
+    const int64_t j0 = m.start + i * (int64_t)(m.nw + m.skip);
+    double s = 0.0;
+    for (int k = 0; k < m.nw; k++) s += v[j0 + k];
+    out[i] = (init ? out[i] : cst) + alpha * s;
+  }
+}
+int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
+                const double *v) {
+  if (m.nwcon <= 0) return PO_OK;
+  PO_WLAUNCH(group_sum_kernel, wgrid(c, m.nwcon), m, out, init, cst, alpha, v);
+  return PO_OK;
+}
+// out[g] += alpha * w[i(g)] for every variable g that belongs to a group
+__global__ void __launch_bounds__(kBlock)
+    group_scatter_kernel(GroupMap m, double *__restrict__ out, double alpha, const double *__restrict__ w,
+                         int64_t n) {
+  const int64_t period = m.nw + m.skip;
+  PO_W_LOOP(g, n) {
+    const int64_t r = g - m.start;
+    if (r >= 0) {
+      const int64_t i = r / period;
+      if (i < m.nwcon && (r - i * period) < m.nw) out[g] += alpha * w[i];
+    }
+  }
+}
+int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n) {
+  if (m.nwcon <= 0 || n <= 0) return PO_OK;
+  PO_WLAUNCH(group_scatter_kernel, wgrid(c, n), m, out, alpha, w, n);
+  return PO_OK;
+}
+// U_j[i] = alpha * sum_k d[g] * P_j[g] over the group of constraint i, for all panel columns at once
+__global__ void __launch_bounds__(kBlock)
+    group_panel_kernel(GroupMap m, PtrTable P, int nv, const double *__restrict__ d, double alpha,
+                       PtrTableW U) {
+  PO_W_LOOP(i, m.nwcon) {
+    const int64_t j0 = m.start + i * (int64_t)(m.nw + m.skip);
+    for (int j = 0; j < nv; j++) {
+      double s = 0.0;
+      for (int k = 0; k < m.nw; k++) s += d[j0 + k] * P.p[j][j0 + k];
+      U.p[j][i] = alpha * s;
+    }
+  }
+}
+int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, const double *d,
+                  double alpha, double *const *U) {
+  if (m.nwcon <= 0 || nv <= 0) return PO_OK;
+  PtrTable pt;
+  PtrTableW ut;
+  for (int j = 0; j < kMaxPanel; j++) {
+    pt.p[j] = j < nv ? P[j] : nullptr;
+    ut.p[j] = j < nv ? U[j] : nullptr;
+  }
+  PO_WLAUNCH(group_panel_kernel, wgrid(c, m.nwcon), m, pt, nv, d, alpha, ut);
+  return PO_OK;
+}
+
+// ---- small element-wise helpers ---------------------------------------------------------------------
+// y = a * x1 * x2   (x2 may be null -> y = a * x1)
+__global__ void __launch_bounds__(kBlock)
+    mul_kernel(double *y, double a, const double *x1, const double *x2, int64_t n) {  // y may alias
+  PO_W_LOOP(i, n) y[i] = x2 ? a * x1[i] * x2[i] : a * x1[i];
+}
+int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_WLAUNCH(mul_kernel, wgrid(c, n), y, a, x1, x2, n);
+  return PO_OK;
+}
+// Cw = 1 / Cw
+__global__ void __launch_bounds__(kBlock) recip_kernel(double *__restrict__ y, int64_t n) {
+  PO_W_LOOP(i, n) y[i] = 1.0 / y[i];
+}
+int k_recip(Ctx *c, double *y, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_WLAUNCH(recip_kernel, wgrid(c, n), y, n);
+  return PO_OK;
+}
+
+// ---- residual blocks of the sparse constraints (computeKKTRes :1362-1398) ---------------------------
+// in: rzw holds cw(x).  out: rzw = -(cw - sw + tw), rsw = zsw - gsw - zw, rtw = ztw - gtw + zw,
+// rzsw = mu - sw zsw, rztw = mu - tw ztw.
+// sums {sw.zsw + tw.ztw, l1 rzw, l2^2 rzw, l1 rsw, l1 rtw, l1 rzsw, l1 rztw}; maxs {rzw, rsw, rtw, rzsw, rztw}
+__global__ void __launch_bounds__(kBlock)
+    w_res_kernel(WVars v, WVars r, const double *__restrict__ gsw, const double *__restrict__ gtw,
+                 double mu, int64_t w, double *__restrict__ partials) {
+  __shared__ double sm[4 * 7];
+  double sums[7] = {0, 0, 0, 0, 0, 0, 0};
+  double maxs[5] = {0, 0, 0, 0, 0};
+  PO_W_LOOP(i, w) {
+    const double sw = v.sw[i], tw = v.tw[i], zw = v.zw[i], zsw = v.zsw[i], ztw = v.ztw[i];
+    const double a = -(r.zw[i] - sw + tw);
+    const double b = zsw - gsw[i] - zw;
+    const double cc = ztw - gtw[i] + zw;
+    const double d = mu - sw * zsw;
+    const double e = mu - tw * ztw;
+    r.zw[i] = a;
+    r.sw[i] = b;
+    r.tw[i] = cc;
+    r.zsw[i] = d;
+    r.ztw[i] = e;
+    sums[0] += sw * zsw + tw * ztw;
+    sums[1] += fabs(a);
+    sums[2] += a * a;
+    sums[3] += fabs(b);
+    sums[4] += fabs(cc);
+    sums[5] += fabs(d);
+    sums[6] += fabs(e);
+    maxs[0] = fmax(maxs[0], fabs(a));
+    maxs[1] = fmax(maxs[1], fabs(b));
+    maxs[2] = fmax(maxs[2], fabs(cc));
+    maxs[3] = fmax(maxs[3], fabs(d));
+    maxs[4] = fmax(maxs[4], fabs(e));
+  }
+  w_block_reduce<7, 0>(sums, partials, 0, sm);
+  w_block_reduce<5, 2>(maxs, partials, 7, sm);
+}
+int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
+            int64_t w, double out[12]) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid * 12));
+  PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, mu, w, c->d_partials);
+  return reduce_finish(c, grid, 7, 0, 5, out);
+}
+
+// Cdiag = sw/zsw + tw/ztw (setUpKKTDiagSystem :1912-1927)
+__global__ void __launch_bounds__(kBlock) w_cdiag_kernel(WVars v, int64_t w, double *__restrict__ cd) {
+  PO_W_LOOP(i, w) cd[i] = v.sw[i] / v.zsw[i] + v.tw[i] / v.ztw[i];
+}
+int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_cdiag_kernel, wgrid(c, w), v, w, cd);
+  return PO_OK;
+}
+
+// d2 = b.zw + (b.zsw + sw b.sw)/zsw - (b.ztw + tw b.tw)/ztw (:2111-2136)
+__global__ void __launch_bounds__(kBlock)
+    w_d2_kernel(WVars v, WVars b, int64_t w, double *__restrict__ d2) {
+  PO_W_LOOP(i, w) {
+    d2[i] = b.zw[i] + (b.zsw[i] + v.sw[i] * b.sw[i]) / v.zsw[i] - (b.ztw[i] + v.tw[i] * b.tw[i]) / v.ztw[i];
+  }
+}
+int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_d2_kernel, wgrid(c, w), v, b, w, d2);
+  return PO_OK;
+}
+
+// step blocks (:2180-2208), y.zw = dzw given; refine accumulates into p.
+// out mins {max_x over sw, tw ; max_z over zsw, ztw} with fraction tau (computeMaxStep :3017-3061)
+__global__ void __launch_bounds__(kBlock)
+    w_step_kernel(WVars v, WVars b, const double *__restrict__ dzw, int refine, double tau, WVars p,
+                  int64_t w, double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double mins[2] = {1.0, 1.0};
+  PO_W_LOOP(i, w) {
+    const double yzw = dzw[i];
+    const double yzsw = yzw - b.sw[i];
+    const double yztw = -b.tw[i] - yzw;
+    const double ysw = (b.zsw[i] - v.sw[i] * yzsw) / v.zsw[i];
+    const double ytw = (b.ztw[i] - v.tw[i] * yztw) / v.ztw[i];
+    double q0 = yzw, q1 = ysw, q2 = ytw, q3 = yzsw, q4 = yztw;
+    if (refine) {
+      q0 += p.zw[i];
+      q1 += p.sw[i];
+      q2 += p.tw[i];
+      q3 += p.zsw[i];
+      q4 += p.ztw[i];
+    }
+    p.zw[i] = q0;
+    p.sw[i] = q1;
+    p.tw[i] = q2;
+    p.zsw[i] = q3;
+    p.ztw[i] = q4;
+    if (q1 < 0.0) mins[0] = fmin(mins[0], -tau * v.sw[i] / q1);
+    if (q2 < 0.0) mins[0] = fmin(mins[0], -tau * v.tw[i] / q2);
+    if (q3 < 0.0) mins[1] = fmin(mins[1], -tau * v.zsw[i] / q3);
+    if (q4 < 0.0) mins[1] = fmin(mins[1], -tau * v.ztw[i] / q4);
+  }
+  w_block_reduce<2, 1>(mins, partials, 0, sm);
+}
+int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
+             const WVars &p, int64_t w, double out[2]) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PO_WLAUNCH(w_step_kernel, grid, v, b, dzw, refine, tau, p, w, c->d_partials);
+  return reduce_finish(c, grid, 0, 2, 0, out);
+}
+
+// addKKTResStep, w blocks (:1498-1527); r.zw already holds r.zw - Aw px.
+__global__ void __launch_bounds__(kBlock) w_res_step_kernel(WVars v, WVars p, WVars r, int64_t w) {
+  PO_W_LOOP(i, w) {
+    r.zw[i] += p.sw[i] - p.tw[i];
+    r.sw[i] += p.zsw[i] - p.zw[i];
+    r.tw[i] += p.ztw[i] + p.zw[i];
+    r.zsw[i] -= p.sw[i] * v.zsw[i] + v.sw[i] * p.zsw[i];
+    r.ztw[i] -= p.tw[i] * v.ztw[i] + v.tw[i] * p.ztw[i];
+  }
+}
+int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_res_step_kernel, wgrid(c, w), v, p, r, w);
+  return PO_OK;
+}
+// Mehrotra corrector (:1733-1750): r.zsw -= psw pzsw, r.ztw -= ptw pztw
+__global__ void __launch_bounds__(kBlock) w_corrector_kernel(WVars p, WVars r, int64_t w) {
+  PO_W_LOOP(i, w) {
+    r.zsw[i] -= p.sw[i] * p.zsw[i];
+    r.ztw[i] -= p.tw[i] * p.ztw[i];
+  }
+}
+int k_w_corrector(Ctx *c, const WVars &p, const WVars &r, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_corrector_kernel, wgrid(c, w), p, r, w);
+  return PO_OK;
+}
+
+// computeCompStep, w part (:2866-2889): sum (sw + ax psw)(zsw + az pzsw) + (tw + ax ptw)(ztw + az pztw)
+__global__ void __launch_bounds__(kBlock)
+    w_comp_step_kernel(WVars v, WVars p, double ax, double az, int64_t w, double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double s[1] = {0.0};
+  PO_W_LOOP(i, w) {
+    s[0] += (v.sw[i] + ax * p.sw[i]) * (v.zsw[i] + az * p.zsw[i]) +
+            (v.tw[i] + ax * p.tw[i]) * (v.ztw[i] + az * p.ztw[i]);
+  }
+  w_block_reduce<1, 0>(s, partials, 0, sm);
+}
+int k_w_comp_step(Ctx *c, const WVars &v, const WVars &p, double ax, double az, int64_t w, double *out) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid));
+  PO_WLAUNCH(w_comp_step_kernel, grid, v, p, ax, az, w, c->d_partials);
+  return reduce_finish(c, grid, 1, 0, 0, out);
+}
+
+// evalMeritInitDeriv, w part (:3735-3765, 3489-3503). cw = cw(x), awpx = Aw px (unscaled).
+// out {pos log, neg log, pos presult, neg presult, gsw.sw, gtw.tw, gsw.psw, gtw.ptw, |rw1|^2, rw1.rw2}
+__global__ void __launch_bounds__(kBlock)
+    w_merit_kernel(WVars v, WVars p, double sx, const double *__restrict__ gsw,
+                   const double *__restrict__ gtw, const double *__restrict__ cw,
+                   const double *__restrict__ awpx, int64_t w, double *__restrict__ partials) {
+  __shared__ double sm[4 * 10];
+  double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  PO_W_LOOP(i, w) {
+    const double sw = v.sw[i], tw = v.tw[i], psw = sx * p.sw[i], ptw = sx * p.tw[i];
+    const double ls = log(sw), lt = log(tw);
+    if (sw > 1.0) s[0] += ls; else s[1] += ls;
+    if (tw > 1.0) s[0] += lt; else s[1] += lt;
+    if (psw > 0.0) s[2] += psw / sw; else s[3] += psw / sw;
+    if (ptw > 0.0) s[2] += ptw / tw; else s[3] += ptw / tw;
+    s[4] += gsw[i] * sw;
+    s[5] += gtw[i] * tw;
+    s[6] += gsw[i] * psw;
+    s[7] += gtw[i] * ptw;
+    const double r1 = cw[i] - sw + tw;
+    const double r2 = sx * awpx[i] - psw + ptw;
+    s[8] += r1 * r1;
+    s[9] += r1 * r2;
+  }
+  w_block_reduce<10, 0>(s, partials, 0, sm);
+}
+int k_w_merit(Ctx *c, const WVars &v, const WVars &p, double sx, const double *gsw, const double *gtw,
+              const double *cw, const double *awpx, int64_t w, double out[10]) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid * 10));
+  PO_WLAUNCH(w_merit_kernel, grid, v, p, sx, gsw, gtw, cw, awpx, w, c->d_partials);
+  return reduce_finish(c, grid, 10, 0, 0, out);
+}
+
+// line-search trial, w part (:4003-4008 + evalMeritFunc :3572-3590, 3438-3462): rsw = max(sw + a psw, eps) ...
+// out {pos log, neg log, |cw(xt) - rsw + rtw|^2, gsw.rsw, gtw.rtw}
+__global__ void __launch_bounds__(kBlock)
+    w_trial_kernel(WVars v, WVars p, double a, double eps, const double *__restrict__ gsw,
+                   const double *__restrict__ gtw, const double *__restrict__ cwt, int64_t w,
+                   double *__restrict__ partials) {
+  __shared__ double sm[4 * 5];
+  double s[5] = {0, 0, 0, 0, 0};
+  PO_W_LOOP(i, w) {
+    double rs = v.sw[i] + a * p.sw[i];
+    if (rs <= eps) rs = eps;
+    double rt = v.tw[i] + a * p.tw[i];
+    if (rt <= eps) rt = eps;
+    const double ls = log(rs), lt = log(rt);
+    if (rs > 1.0) s[0] += ls; else s[1] += ls;
+    if (rt > 1.0) s[0] += lt; else s[1] += lt;
+    const double r1 = cwt[i] - rs + rt;
+    s[2] += r1 * r1;
+    s[3] += gsw[i] * rs;
+    s[4] += gtw[i] * rt;
+  }
+  w_block_reduce<5, 0>(s, partials, 0, sm);
+}
+int k_w_trial(Ctx *c, const WVars &v, const WVars &p, double a, double eps, const double *gsw,
+              const double *gtw, const double *cwt, int64_t w, double out[5]) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid * 5));
+  PO_WLAUNCH(w_trial_kernel, grid, v, p, a, eps, gsw, gtw, cwt, w, c->d_partials);
+  return reduce_finish(c, grid, 5, 0, 0, out);
+}
+
+// computeStepAndUpdate, w part (:4177-4183): primal slacks with ax-scaled step, multipliers with az
+__global__ void __launch_bounds__(kBlock)
+    w_update_kernel(WVars v, WVars p, double ax, double az, double eps, int64_t w) {
+  PO_W_LOOP(i, w) {
+    double q = v.sw[i] + ax * p.sw[i];
+    v.sw[i] = q <= eps ? eps : q;
+    q = v.tw[i] + ax * p.tw[i];
+    v.tw[i] = q <= eps ? eps : q;
+    v.zw[i] = v.zw[i] + az * p.zw[i];
+    q = v.zsw[i] + az * p.zsw[i];
+    v.zsw[i] = q <= eps ? eps : q;
+    q = v.ztw[i] + az * p.ztw[i];
+    v.ztw[i] = q <= eps ? eps : q;
+  }
+}
+int k_w_update(Ctx *c, const WVars &v, const WVars &p, double ax, double az, double eps, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_update_kernel, wgrid(c, w), v, p, ax, az, eps, w);
+  return PO_OK;
+}
+
+// initAffineStepMultipliers, w part (:5601-5628)
+__global__ void __launch_bounds__(kBlock) w_affine_kernel(WVars v, WVars p, double amin, int64_t w) {
+  PO_W_LOOP(i, w) {
+    v.zw[i] = v.zw[i] + p.zw[i];
+    v.sw[i] = fmax(amin, fabs(v.sw[i] + p.sw[i]));
+    v.tw[i] = fmax(amin, fabs(v.tw[i] + p.tw[i]));
+    v.zsw[i] = fmax(amin, fabs(v.zsw[i] + p.zsw[i]));
+    v.ztw[i] = fmax(amin, fabs(v.ztw[i] + p.ztw[i]));
+  }
+}
+int k_w_affine(Ctx *c, const WVars &v, const WVars &p, double amin, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_affine_kernel, wgrid(c, w), v, p, amin, w);
+  return PO_OK;
+}
+
+// least-squares multiplier clip (:5522-5533): zw = |zw| > 10 max(gsw, gtw) ? 0 : zw
+__global__ void __launch_bounds__(kBlock)
+    w_clip_kernel(double *__restrict__ zw, const double *__restrict__ src, const double *__restrict__ gsw,
+                  const double *__restrict__ gtw, int64_t w) {
+  PO_W_LOOP(i, w) {
+    const double gam = 10.0 * fmax(gsw[i], gtw[i]);
+    const double z = src[i];
+    zw[i] = (z < -gam || z > gam) ? 0.0 : z;
+  }
+}
+int k_w_clip(Ctx *c, double *zw, const double *src, const double *gsw, const double *gtw, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_clip_kernel, wgrid(c, w), zw, src, gsw, gtw, w);
+  return PO_OK;
+}
+
+// penalty vectors (:361-374): gsw_i = i < nwinequality ? 0 : gamma ; gtw = gamma  (global index)
+__global__ void __launch_bounds__(kBlock)
+    w_gamma_kernel(double *__restrict__ gsw, double *__restrict__ gtw, double gamma, int64_t nwineq,
+                   int64_t w) {
+  PO_W_LOOP(i, w) {
+    gsw[i] = i < nwineq ? 0.0 : gamma;
+    gtw[i] = gamma;
+  }
+}
+int k_w_gamma(Ctx *c, double *gsw, double *gtw, double gamma, int64_t nwineq, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_gamma_kernel, wgrid(c, w), gsw, gtw, gamma, nwineq, w);
+  return PO_OK;
+}
+
+}  // namespace po

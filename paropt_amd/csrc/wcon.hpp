@@ -1,0 +1,49 @@
+// Launchers for the sparse ("weighting") constraint blocks, nwblock = 1 (wcon.hip).
+#pragma once
+#include "core.hpp"
+
+namespace po {
+
+// the five w-sized blocks of ParOptVars (src/ParOptInteriorPoint.h:391-399), device pointers
+struct WVars {
+  double *zw, *sw, *tw, *zsw, *ztw;
+};
+struct PtrTableW {
+  double *p[kMaxPanel];
+};
+
+// Constraint i (local) acts on the local variables start + i*(nw+skip) + [0, nw):
+// cw_i = 1 - sum of those variables (examples/rosenbrock/rosenbrock.cpp:131-184).
+struct GroupMap {
+  int64_t nwcon = 0, start = 0;
+  int nw = 0, skip = 0;
+};
+
+int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
+                const double *v);
+int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n);
+int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, const double *d,
+                  double alpha, double *const *U);
+
+int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n);
+int k_recip(Ctx *c, double *y, int64_t n);
+
+int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
+            int64_t w, double out[12]);
+int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd);
+int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2);
+int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
+             const WVars &p, int64_t w, double out[2]);
+int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w);
+int k_w_corrector(Ctx *c, const WVars &p, const WVars &r, int64_t w);
+int k_w_comp_step(Ctx *c, const WVars &v, const WVars &p, double ax, double az, int64_t w, double *out);
+int k_w_merit(Ctx *c, const WVars &v, const WVars &p, double sx, const double *gsw, const double *gtw,
+              const double *cw, const double *awpx, int64_t w, double out[10]);
+int k_w_trial(Ctx *c, const WVars &v, const WVars &p, double a, double eps, const double *gsw,
+              const double *gtw, const double *cwt, int64_t w, double out[5]);
+int k_w_update(Ctx *c, const WVars &v, const WVars &p, double ax, double az, double eps, int64_t w);
+int k_w_affine(Ctx *c, const WVars &v, const WVars &p, double amin, int64_t w);
+int k_w_clip(Ctx *c, double *zw, const double *src, const double *gsw, const double *gtw, int64_t w);
+int k_w_gamma(Ctx *c, double *gsw, double *gtw, double gamma, int64_t nwineq, int64_t w);
+
+}  // namespace po

@@ -36,6 +36,8 @@ EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p)
 GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p)
 QNCORR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec)
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, po_vec)
+SPARSE_CON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec)
+SPARSE_JAC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, po_vec, po_vec, po_vec)
 
 
 class ProblemCallbacks(C.Structure):
@@ -46,6 +48,15 @@ class ProblemCallbacks(C.Structure):
         ("eval_obj_con_gradient", GRAD_FN),
         ("qn_update_correction", QNCORR_FN),
         ("write_output", WRITE_FN),
+    ]
+
+
+class ProblemSparseCallbacks(C.Structure):
+    _fields_ = [
+        ("eval_sparse_con", SPARSE_CON_FN),
+        ("add_sparse_jacobian", SPARSE_JAC_FN),
+        ("add_sparse_jacobian_transpose", SPARSE_JAC_FN),
+        ("add_sparse_inner_product", SPARSE_JAC_FN),
     ]
 
 
@@ -103,6 +114,10 @@ SIGNATURES = {
         C.c_int,
         [po_ctx, C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_double, C.c_double, C.POINTER(po_problem)],
     ),
+    "po_problem_set_sparse_callbacks": (
+        C.c_int, [po_problem, C.c_int64, C.c_int64, C.POINTER(ProblemSparseCallbacks)]),
+    "po_problem_set_weighting": (C.c_int, [po_problem, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64]),
+    "po_problem_sparse_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p]),
     "po_problem_destroy": (C.c_int, [po_problem]),
     "po_problem_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p, c_int_p]),
     "po_problem_eval_obj_con": (C.c_int, [po_problem, po_vec, c_double_p, c_double_p]),
@@ -122,6 +137,7 @@ SIGNATURES = {
         C.c_int,
         [po_ip, C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p), C.POINTER(c_double_p)],
     ),
+    "po_ip_get_optimized_sparse": (C.c_int, [po_ip] + [C.POINTER(po_vec)] * 5),
     "po_ip_get_counters": (C.c_int, [po_ip, c_int_p, c_int_p, c_int_p]),
     "po_ip_get_barrier_parameter": (C.c_int, [po_ip, c_double_p]),
     "po_ip_get_complementarity": (C.c_int, [po_ip, c_double_p]),

@@ -41,6 +41,9 @@ def run_gpu(ctx, case, want_vectors=False):
     a = case["args"]
     prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), a.get("seed", 0),
                                a.get("eig_min", 1.0), a.get("eig_max", 100.0))
+    if a.get("nwcon", 0) > 0:
+        prob.setWeighting(a["nwcon"], a["nw"], a.get("nwstart", 0), a.get("nwskip", 0),
+                          a.get("nwineq", a["nwcon"]))
     opts = ip_options_from_case(case)
     opts["write_output_frequency"] = 0
     ip = pa.InteriorPoint(prob, opts)
@@ -51,6 +54,10 @@ def run_gpu(ctx, case, want_vectors=False):
         if want_vectors:
             x, z, zl, zu = ip.getOptimizedPoint()
             s["x"], s["zl"], s["zu"] = x.to_numpy(), zl.to_numpy(), zu.to_numpy()
+            wv = ip.getOptimizedSparse()
+            if wv is not None:
+                for key, v in zip(("zw", "sw", "tw", "zsw", "ztw"), wv):
+                    s[key] = v.to_numpy()
         snaps.append(s)
 
     ip.setIterationCallback(cb)
@@ -58,7 +65,8 @@ def run_gpu(ctx, case, want_vectors=False):
     return ip, snaps
 
 
-IP_CASES = [n for n in golden_names("ip_") if not n.endswith("_r2") and "checkpoint" not in n]
+IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_")
+            if not n.endswith("_r2") and "checkpoint" not in n]
 
 
 @pytest.mark.parametrize("name", IP_CASES)
@@ -82,8 +90,11 @@ def test_ip_trajectory_golden(ctx, name):
             ref = g[p + key]
             np.testing.assert_allclose(s[key], ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()),
                                        err_msg="%s @%d" % (key, k))
+        if p + "wnorms" in g:
+            np.testing.assert_allclose(s["wnorms"], g[p + "wnorms"], rtol=rt, err_msg="wnorms @%d" % k)
         if p + "x" in g:
-            for key in ("x", "zl", "zu"):
+            keys = ("x", "zl", "zu") + (("zw", "sw", "tw", "zsw", "ztw") if p + "zw" in g else ())
+            for key in keys:
                 ref = g[p + key]
                 np.testing.assert_allclose(s[key], ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
                                            err_msg="%s @%d" % (key, k))
