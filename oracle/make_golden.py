@@ -246,6 +246,20 @@ case(
     checkpoint=1,
     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}),
 )
+case(
+    "ipw_convex_checkpoint_n120_c2_w20",
+    "ip",
+    problem="convex",
+    n=120,
+    c=2,
+    nwcon=20,
+    nw=5,
+    nwstart=4,
+    nwskip=0,
+    dump_vecs_every=10,
+    checkpoint=1,
+    **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}),
+)
 # --- weighting (sparse, block-diagonal) constraints: SURVEY 8f rank 1 / config 4 ---
 # the reference example itself: examples/rosenbrock/rosenbrock.cpp:219-222 (nwcon=5, nw=5, start 1, skip 1)
 case(
@@ -290,6 +304,29 @@ case(
     dump_vecs_every=10,
     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 100}),
 )
+# weighting constraints with the other barrier strategies / norms / the SR1 update
+for tag, extra in (
+    ("mpc", {"opt.barrier_strategy": "mehrotra_predictor_corrector"}),
+    ("mehrotra", {"opt.barrier_strategy": "mehrotra"}),
+    ("l2", {"opt.norm_type": "l2"}),
+    ("l1_compfrac", {"opt.norm_type": "l1", "opt.barrier_strategy": "complementarity_fraction"}),
+    ("sr1", {"opt.qn_type": "sr1"}),
+):
+    case(
+        "ipw_convex_n240_c3_w40_%s" % tag,
+        "ip",
+        problem="convex",
+        n=240,
+        c=3,
+        nwcon=40,
+        nw=4,
+        nwstart=2,
+        nwskip=2,
+        nwineq=25,
+        dump_vecs_every=10,
+        **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
+                                  "opt.max_major_iters": 60}, **extra)),
+    )
 for strat in ("mehrotra", "mehrotra_predictor_corrector"):
     case(
         "ip_quadratic_%s_n300_c3" % ("mpc" if "corrector" in strat else "mehrotra"),
@@ -357,9 +394,14 @@ def main():
         np.savez_compressed(path, **d)
         manifest[name] = dict(mode=mode, ranks=ranks, args=args, bytes=os.path.getsize(path))
         print("%-40s %8d bytes  %d records" % (name, manifest[name]["bytes"], len(d)))
-    if not a.only:
-        with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
-            json.dump(manifest, f, indent=1, sort_keys=True)
+    mpath = os.path.join(GOLDEN, "MANIFEST.json")
+    if a.only and os.path.exists(mpath):  # partial regeneration: merge into the existing manifest
+        with open(mpath) as f:
+            old = json.load(f)
+        old.update(manifest)
+        manifest = old
+    with open(mpath, "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

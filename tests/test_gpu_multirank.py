@@ -96,6 +96,75 @@ def test_two_ranks_one_gpu_match_single_rank():
     np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-7)
 
 
+def _worker_w(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    n, c, nw = 8000, 3, 20
+    prob = pa.SeparableProblem(ctx, "convex", n, c).setWeighting(n // nw, nw, 0, 0)
+    assert prob.nwcon == n // nw // world
+    ip = pa.InteriorPoint(prob, W_OPTS)
+    snaps = []
+    ip.setIterationCallback(lambda k: snaps.append(ip.snapshot()))
+    ip.optimize()
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    zw = ip.getOptimizedSparse()[0].to_numpy()
+    xs = [None] * world
+    dist.all_gather_object(xs, (prob.offset, x, zw))
+    if rank == 0:
+        xs = sorted(xs, key=lambda t: t[0])
+        q.put(([(tuple(s["counters"]), s["qn_size"], s["fobj"], s["mu"], tuple(s["norms"]), tuple(s["wnorms"]))
+                for s in snaps], np.concatenate([a for _, a, _ in xs]), np.concatenate([b for _, _, b in xs])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+W_OPTS = {"qn_type": "bfgs", "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+          "starting_point_strategy": "affine_step", "penalty_gamma": 1000.0, "max_major_iters": 15,
+          "write_output_frequency": 0}
+
+
+def test_two_ranks_weighting_constraints_match_single_rank():
+    """Sparse (weighting) constraints sharded over two ranks: each rank owns the groups of its own
+    variables, every w-sized reduction goes through the same rank-ordered combine."""
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    n, c, nw = 8000, 3, 20
+    prob = pa.SeparableProblem(ctx, "convex", n, c).setWeighting(n // nw, nw, 0, 0)
+    ip = pa.InteriorPoint(prob, W_OPTS)
+    s1 = []
+    ip.setIterationCallback(lambda k: s1.append(ip.snapshot()))
+    ip.optimize()
+    x1 = ip.getOptimizedPoint()[0].to_numpy()
+    zw1 = ip.getOptimizedSparse()[0].to_numpy()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_w, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    s2, x2, zw2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(s2) == len(s1)
+    for a, b in zip(s2, s1):
+        assert a[0] == tuple(b["counters"]) and a[1] == b["qn_size"]
+        assert abs(a[2] - b["fobj"]) <= 1e-7 * max(1.0, abs(b["fobj"]))
+        assert abs(a[3] - b["mu"]) <= 1e-6 * abs(b["mu"])
+        np.testing.assert_allclose(a[4], b["norms"], rtol=1e-6)
+        np.testing.assert_allclose(a[5], b["wnorms"], rtol=1e-6)
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(zw2, zw1, rtol=0, atol=1e-6 * max(1.0, np.abs(zw1).max()))
+
+
 def test_rccl_plumbing_single_rank(monkeypatch):
     """ncclGetUniqueId / ncclCommInitRank / ncclAllGather through the dlopen'ed librccl with a
     1-rank communicator on the only GPU of the test box: same results as the self communicator."""
