@@ -28,7 +28,7 @@ QN_SIZE = 10
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(n, ncon, iters, log):
+def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0):
     """Reference (oracle/_ref/ref_driver, the unmodified C++ reference + MKL under MPICH) timed on
     this box's host cores on a bounded sample; falls back to the numpy restatement."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
@@ -42,6 +42,13 @@ def cpu_baseline(n, ncon, iters, log):
                "opt.qn_type=sr1", "opt.qn_subspace_size=%d" % QN_SIZE, "opt.abs_res_tol=1e-30",
                "opt.start_affine_multiplier_min=0.01", "opt.max_major_iters=%d" % iters,
                "opt.write_output_frequency=0"]
+        if nwcon > 0:
+            # the driver's weighting groups are rank-local (as in examples/rosenbrock): pick a rank count
+            # whose shards hold whole groups so that the sharded problem IS the global one
+            while ranks > 1 and (n % ranks or (n // ranks) % nw or nwcon % ranks):
+                ranks -= 1
+            cmd[2] = str(ranks)
+            cmd += ["nwcon=%d" % (nwcon // ranks), "nw=%d" % nw, "nwstart=0", "nwskip=0"]
         try:
             t0 = time.time()
             out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd="/tmp")
@@ -63,7 +70,8 @@ def cpu_baseline(n, ncon, iters, log):
     ns = 1_000_000
     opts = {"qn_type": "sr1", "qn_subspace_size": QN_SIZE, "abs_res_tol": 1e-30,
             "start_affine_multiplier_min": 0.01, "max_major_iters": 6}
-    ip = po.InteriorPoint(po.SepProblem("convex", ns, ncon), opts)
+    wargs = dict(nwcon=int(nwcon * ns // n), nw=nw, nwstart=0, nwskip=0) if nwcon > 0 else {}
+    ip = po.InteriorPoint(po.SepProblem("convex", ns, ncon, **wargs), opts)
     t0 = time.time()
     ip.optimize()
     dt = time.time() - t0
@@ -82,6 +90,9 @@ def main():
     ap.add_argument("--qn", type=str, default="sr1")
     ap.add_argument("--qn-size", type=int, default=QN_SIZE)
     ap.add_argument("--problem", type=str, default="convex", choices=["convex", "quadratic"])
+    ap.add_argument("--nwcon", type=int, default=0,
+                    help="config 4: number of sparse weighting constraints (one per group of --nw variables)")
+    ap.add_argument("--nw", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=N_GLOBAL)
     ap.add_argument("--cpu-iters", type=int, default=6)
@@ -135,6 +146,8 @@ def main():
 
     K, W = a.steps, a.warmup
     prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
+    if a.nwcon > 0:
+        prob.setWeighting(a.nwcon, a.nw, 0, 0)
     opts = {"qn_type": a.qn, "qn_subspace_size": a.qn_size, "abs_res_tol": 1e-30,
             "start_affine_multiplier_min": 0.01, "max_major_iters": W + K, "write_output_frequency": 0}
     ip = pa.InteriorPoint(prob, opts)
@@ -183,7 +196,7 @@ def main():
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(a.cpu_n, a.ncon, a.cpu_iters, log)
+            cpu = cpu_baseline(a.cpu_n, a.ncon, a.cpu_iters, log, a.nwcon * a.cpu_n // a.n, a.nw)
         res = {
             "metric": "IP iterations/sec (KKT solve+line search), n=50M vars m=32, 1/2/4/8 GPUs",
             "value": K / elapsed,
@@ -199,9 +212,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: separable random_%s n=%d, m=%d dense + bounds, L-%s(%d), "
                                    "design vector sharded over %d GPU(s)" % (
-                                       "config 3" if a.problem == "convex" else "config 2", a.problem, a.n, a.ncon,
-                                       a.qn.upper(), a.qn_size, world),
-                       "n_global": a.n, "ncon": a.ncon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter),
+                                       ("config 4 (+%d weighting constraints on groups of %d)" % (a.nwcon, a.nw))
+                                       if a.nwcon > 0 else ("config 3" if a.problem == "convex" else "config 2"),
+                                       a.problem, a.n, a.ncon, a.qn.upper(), a.qn_size, world),
+                       "n_global": a.n, "ncon": a.ncon, "nwcon": a.nwcon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter),
                        "collective": comm_kind},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -55,6 +55,88 @@ __device__ __forceinline__ void w_block_reduce(double (&a)[N], double *partials,
 }
 
 // ---- structured Jacobian of the built-in problems --------------------------------------------------
+// Tiled segmented sums.  A workgroup owns a tile of G whole groups = TV = (G-1)*period + nw consecutive
+// variables (TV <= kGroupTile): lanes load the tile coalesced (lane <-> variable), products go to LDS,
+// then one thread per (group, column) adds its nw LDS values and the results leave coalesced over the
+// group index.  JB panel columns share one tile pass (one d load, JB independent loads in flight).
+constexpr int kGroupTile = 512;  // variables per tile = 2 per thread
+template <int JB>
+__global__ void __launch_bounds__(kBlock)
+    group_panel_tiled_kernel(GroupMap m, PtrTable P, int nv, const double *__restrict__ d, double alpha,
+                             PtrTableW U, int G, int64_t ntiles) {
+  __shared__ double sm[JB * kGroupTile];
+  const int64_t period = m.nw + m.skip;
+  const int tid = threadIdx.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int64_t v0 = m.start + g0 * period;
+    const int nvv = (int)((ng - 1) * period + m.nw);
+    const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
+    const double d0 = in0 ? (d ? d[v0 + tid] : 1.0) : 0.0;
+    const double d1 = in1 ? (d ? d[v0 + tid + kBlock] : 1.0) : 0.0;
+    for (int jb = 0; jb < nv; jb += JB) {
+      double a0[JB], a1[JB];
+#pragma unroll
+      for (int u = 0; u < JB; u++) {
+        const double *pj = P.p[(jb + u < nv) ? jb + u : jb];
+        a0[u] = in0 ? __builtin_nontemporal_load(pj + v0 + tid) : 0.0;
+        a1[u] = in1 ? __builtin_nontemporal_load(pj + v0 + tid + kBlock) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < JB; u++) {
+        sm[u * kGroupTile + tid] = d0 * a0[u];
+        sm[u * kGroupTile + tid + kBlock] = d1 * a1[u];
+      }
+      __syncthreads();
+      for (int pair = tid; pair < ng * JB; pair += kBlock) {
+        const int u = pair / ng, gi = pair - u * ng;
+        if (jb + u < nv) {
+          const double *row = sm + u * kGroupTile + gi * period;
+          double sacc = 0.0;
+          for (int k = 0; k < m.nw; k++) sacc += row[k];
+          U.p[jb + u][g0 + gi] = alpha * sacc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+// out_i = (init ? out_i : cst) + alpha * (group sum of v), same tiling with a single column
+__global__ void __launch_bounds__(kBlock)
+    group_sum_tiled_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
+                           const double *__restrict__ v, int G, int64_t ntiles) {
+  __shared__ double sm[kGroupTile];
+  const int64_t period = m.nw + m.skip;
+  const int tid = threadIdx.x;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int64_t v0 = m.start + g0 * period;
+    const int nvv = (int)((ng - 1) * period + m.nw);
+    sm[tid] = tid < nvv ? v[v0 + tid] : 0.0;
+    sm[tid + kBlock] = tid + kBlock < nvv ? v[v0 + tid + kBlock] : 0.0;
+    __syncthreads();
+    if (tid < ng) {
+      const double *row = sm + tid * period;
+      double sacc = 0.0;
+      for (int k = 0; k < m.nw; k++) sacc += row[k];
+      out[g0 + tid] = (init ? out[g0 + tid] : cst) + alpha * sacc;
+    }
+    __syncthreads();
+  }
+}
+static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles) {
+  const int64_t period = (int64_t)m.nw + m.skip;
+  if (m.nw > kGroupTile || period <= 0) return false;
+  int64_t g = (kGroupTile - m.nw) / period + 1;  // (g-1)*period + nw <= kGroupTile
+  if (g > kBlock) g = kBlock;
+  if (g < 1) return false;
+  *G = (int)g;
+  *ntiles = (m.nwcon + g - 1) / g;
+  return true;
+}
+
 // out_i = (init ? out_i : cst) + alpha * sum_{k<nw} v[start + i*(nw+skip) + k]
 __global__ void __launch_bounds__(kBlock)
     group_sum_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
@@ -69,6 +151,13 @@ __global__ void __launch_bounds__(kBlock)
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
                 const double *v) {
   if (m.nwcon <= 0) return PO_OK;
+  int G = 0;
+  int64_t ntiles = 0;
+  if (group_tiling(m, &G, &ntiles)) {
+    int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
+    PO_WLAUNCH(group_sum_tiled_kernel, (int)grid, m, out, init, cst, alpha, v, G, ntiles);
+    return PO_OK;
+  }
   PO_WLAUNCH(group_sum_kernel, wgrid(c, m.nwcon), m, out, init, cst, alpha, v);
   return PO_OK;
 }
@@ -91,6 +180,7 @@ int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const 
   return PO_OK;
 }
 // U_j[i] = alpha * sum_k d[g] * P_j[g] over the group of constraint i, for all panel columns at once
+// (fallback for groups wider than a tile: one thread per constraint)
 __global__ void __launch_bounds__(kBlock)
     group_panel_kernel(GroupMap m, PtrTable P, int nv, const double *__restrict__ d, double alpha,
                        PtrTableW U) {
@@ -111,6 +201,17 @@ int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, con
   for (int j = 0; j < kMaxPanel; j++) {
     pt.p[j] = j < nv ? P[j] : nullptr;
     ut.p[j] = j < nv ? U[j] : nullptr;
+  }
+  int G = 0;
+  int64_t ntiles = 0;
+  if (group_tiling(m, &G, &ntiles)) {
+    int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
+    if (nv > 4) {
+      PO_WLAUNCH(group_panel_tiled_kernel<8>, (int)grid, m, pt, nv, d, alpha, ut, G, ntiles);
+    } else {
+      PO_WLAUNCH(group_panel_tiled_kernel<4>, (int)grid, m, pt, nv, d, alpha, ut, G, ntiles);
+    }
+    return PO_OK;
   }
   PO_WLAUNCH(group_panel_kernel, wgrid(c, m.nwcon), m, pt, nv, d, alpha, ut);
   return PO_OK;
