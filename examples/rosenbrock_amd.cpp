@@ -1,7 +1,9 @@
 // The reference's C++ usage pattern (examples/rosenbrock/rosenbrock.cpp: subclass ParOptProblem,
 // fill host arrays through getArray, hand it to ParOptInteriorPoint) on the MI355X path through
-// include/ParOptAMD.hpp.  Dense-constraint (w = 0) variant: f = sum (1-x_i)^2 + 100 (x_{i+1}-x_i^2)^2,
-// c0 = 0.25 - sum x^2 >= 0, c1 = 10 + sum_{i even} x_i >= 0, -2 <= x <= 1, x0 = -1.
+// include/ParOptAMD.hpp: f = sum (1-x_i)^2 + 100 (x_{i+1}-x_i^2)^2,
+// c0 = 0.25 - sum x^2 >= 0, c1 = 10 + sum_{i even} x_i >= 0, -2 <= x <= 1, x0 = -1, and with nwcon=5
+// the reference example's sparse constraints cw_i = 1 - sum_{k<5} x[1 + 6 i + k] >= 0
+// (rosenbrock.cpp:131-184: nwcon = 5, nw = 5, nwstart = 1, nwskip = 1).
 //
 // build: g++ -std=c++17 -Iinclude examples/rosenbrock_amd.cpp -Lparopt_amd -lparopt_amd
 //        -Wl,-rpath,$PWD/paropt_amd -o examples/rosenbrock_amd ; run: ./examples/rosenbrock_amd nvars=100
@@ -12,10 +14,46 @@
 
 class Rosenbrock : public ParOptProblem {
  public:
-  Rosenbrock(po_ctx ctx, int n) : ParOptProblem(ctx) {
-    setProblemSizes(n, 2, 0);
-    setNumInequalities(2, 0);
+  Rosenbrock(po_ctx ctx, int n, int _nwcon = 0) : ParOptProblem(ctx) {
+    nw = 5;
+    nwstart = 1;
+    nwskip = 1;
+    setProblemSizes(n, 2, _nwcon);
+    setNumInequalities(2, _nwcon);
   }
+  void evalSparseCon(ParOptVec *x, ParOptVec *out) {
+    ParOptScalar *xvals, *cw;
+    x->getArray(&xvals);
+    out->getArray(&cw);
+    for (int i = 0, j = nwstart; i < nwcon; i++, j += nw + nwskip) {
+      cw[i] = 1.0;
+      for (int k = 0; k < nw; k++) cw[i] -= xvals[j + k];
+    }
+  }
+  void addSparseJacobian(ParOptScalar alpha, ParOptVec *, ParOptVec *px, ParOptVec *out) {
+    ParOptScalar *pxvals, *cw;
+    px->getArray(&pxvals);
+    out->getArray(&cw);
+    for (int i = 0, j = nwstart; i < nwcon; i++, j += nw + nwskip) {
+      for (int k = 0; k < nw; k++) cw[i] -= alpha * pxvals[j + k];
+    }
+  }
+  void addSparseJacobianTranspose(ParOptScalar alpha, ParOptVec *, ParOptVec *pzw, ParOptVec *out) {
+    ParOptScalar *outvals, *zw;
+    out->getArray(&outvals);
+    pzw->getArray(&zw);
+    for (int i = 0, j = nwstart; i < nwcon; i++, j += nw + nwskip) {
+      for (int k = 0; k < nw; k++) outvals[j + k] -= alpha * zw[i];
+    }
+  }
+  void addSparseInnerProduct(ParOptScalar alpha, ParOptVec *, ParOptVec *cvec, ParOptScalar *A) {
+    ParOptScalar *cvals;
+    cvec->getArray(&cvals);
+    for (int i = 0, j = nwstart; i < nwcon; i++, j += nw + nwskip) {
+      for (int k = 0; k < nw; k++) A[i] += alpha * cvals[j + k];
+    }
+  }
+  int nw, nwstart, nwskip;
   void getVarsAndBounds(ParOptVec *xvec, ParOptVec *lbvec, ParOptVec *ubvec) {
     ParOptScalar *x, *lb, *ub;
     xvec->getArray(&x);
@@ -61,14 +99,17 @@ class Rosenbrock : public ParOptProblem {
 };
 
 int main(int argc, char *argv[]) {
-  int nvars = 100;
-  for (int k = 1; k < argc; k++) sscanf(argv[k], "nvars=%d", &nvars);
+  int nvars = 100, nwcon = 0;
+  for (int k = 1; k < argc; k++) {
+    sscanf(argv[k], "nvars=%d", &nvars);
+    sscanf(argv[k], "nwcon=%d", &nwcon);
+  }
   po_ctx ctx = NULL;
   if (po_ctx_create(0, &ctx) != 0) {
     fprintf(stderr, "no MI355X available: %s\n", po_last_error());
     return 2;
   }
-  Rosenbrock *rosen = new Rosenbrock(ctx, nvars);
+  Rosenbrock *rosen = new Rosenbrock(ctx, nvars, nwcon);
   rosen->incref();
   ParOptOptions *options = new ParOptOptions();
   options->incref();
@@ -76,20 +117,21 @@ int main(int argc, char *argv[]) {
   options->setOption("qn_subspace_size", 10);
   options->setOption("abs_res_tol", 1e-6);
   options->setOption("barrier_strategy", "monotone");
-  options->setOption("max_major_iters", 120);
+  options->setOption("max_major_iters", 150);
   ParOptInteriorPoint *opt = new ParOptInteriorPoint(rosen, options);
   opt->incref();
   int rc = opt->optimize();
   int niter, neval, ngeval;
   opt->getIterationCounters(&niter, &neval, &ngeval);
-  ParOptVec *x;
+  ParOptVec *x, *zw = NULL;
   ParOptScalar *z;
-  opt->getOptimizedPoint(&x, &z, NULL, NULL, NULL);
+  opt->getOptimizedPoint(&x, &z, &zw, NULL, NULL);
   ParOptScalar fobj, cons[2];
   x->syncToHost();
   rosen->evalObjCon(x, &fobj, cons);
   printf("{\"rc\": %d, \"niter\": %d, \"neval\": %d, \"ngeval\": %d, \"fobj\": %.15e, \"xnorm\": %.15e, "
-         "\"z0\": %.15e, \"z1\": %.15e}\n", rc, niter, neval, ngeval, fobj, x->norm(), z[0], z[1]);
+         "\"z0\": %.15e, \"z1\": %.15e, \"zwnorm\": %.15e}\n", rc, niter, neval, ngeval, fobj, x->norm(),
+         z[0], z[1], zw ? zw->norm() : 0.0);
   opt->decref();
   options->decref();
   rosen->decref();

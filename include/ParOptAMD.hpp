@@ -108,7 +108,8 @@ class ParOptOptions : public ParOptBase {
 // ---- ParOptProblem --------------------------------------------------------------------------------
 class ParOptProblem : public ParOptBase {
  public:
-  explicit ParOptProblem(po_ctx _ctx) : ctx(_ctx), nvars(0), ncon(0), nwcon(0), ninequality(-1), hprob(NULL) {}
+  explicit ParOptProblem(po_ctx _ctx)
+      : ctx(_ctx), nvars(0), ncon(0), nwcon(0), ninequality(-1), nwinequality(-1), hprob(NULL) {}
   virtual ~ParOptProblem() {
     if (hprob) po_problem_destroy(hprob);
   }
@@ -118,8 +119,12 @@ class ParOptProblem : public ParOptBase {
     ncon = _ncon;
     nwcon = _nwcon;
     if (ninequality < 0) ninequality = ncon;
+    if (nwinequality < 0) nwinequality = nwcon;
   }
-  void setNumInequalities(int _ninequality, int) { ninequality = _ninequality; }
+  void setNumInequalities(int _ninequality, int _nwinequality) {
+    ninequality = _ninequality;
+    nwinequality = _nwinequality;
+  }
   void getProblemSizes(int *_nvars, int *_ncon, int *_nwcon) {
     if (_nvars) *_nvars = nvars;
     if (_ncon) *_ncon = ncon;
@@ -133,6 +138,11 @@ class ParOptProblem : public ParOptBase {
   virtual void computeQuasiNewtonUpdateCorrection(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *,
                                                   ParOptVec *) {}
   virtual void writeOutput(int, ParOptVec *) {}
+  // sparse constraints, nwblock = 1 (src/ParOptProblem.h:215-262); `out` / `pzw` are w-sized
+  virtual void evalSparseCon(ParOptVec *, ParOptVec *) {}
+  virtual void addSparseJacobian(ParOptScalar, ParOptVec *, ParOptVec *, ParOptVec *) {}
+  virtual void addSparseJacobianTranspose(ParOptScalar, ParOptVec *, ParOptVec *, ParOptVec *) {}
+  virtual void addSparseInnerProduct(ParOptScalar, ParOptVec *, ParOptVec *, ParOptScalar *) {}
 
   // the C-callback problem handed to the library (created on first use)
   po_problem handle() {
@@ -147,13 +157,23 @@ class ParOptProblem : public ParOptBase {
       if (po_problem_create_callbacks(ctx, nvars, ncon, ninequality, &cb, &hprob) != 0) {
         fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
       }
+      if (hprob && nwcon > 0) {
+        po_problem_sparse_callbacks scb;
+        scb.eval_sparse_con = &ParOptProblem::tramp_wcon;
+        scb.add_sparse_jacobian = &ParOptProblem::tramp_wjac;
+        scb.add_sparse_jacobian_transpose = &ParOptProblem::tramp_wjact;
+        scb.add_sparse_inner_product = &ParOptProblem::tramp_winner;
+        if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0) {
+          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        }
+      }
     }
     return hprob;
   }
 
  protected:
   po_ctx ctx;
-  int nvars, ncon, nwcon, ninequality;
+  int nvars, ncon, nwcon, ninequality, nwinequality;
 
  private:
   po_problem hprob;
@@ -194,6 +214,44 @@ class ParOptProblem : public ParOptBase {
       va[j]->decref();
     }
     return fail;
+  }
+  static int tramp_wcon(void *self, po_vec x, po_vec out) {
+    ParOptVec vx(x), vo(out);
+    double *p;
+    vx.syncToHost();
+    vo.getArray(&p);
+    static_cast<ParOptProblem *>(self)->evalSparseCon(&vx, &vo);
+    vo.syncToDevice();
+    return 0;
+  }
+  static int tramp_wjac(void *self, double alpha, po_vec x, po_vec px, po_vec out) {
+    ParOptVec vx(x), vp(px), vo(out);
+    vx.syncToHost();
+    vp.syncToHost();
+    vo.syncToHost();
+    static_cast<ParOptProblem *>(self)->addSparseJacobian(alpha, &vx, &vp, &vo);
+    vo.syncToDevice();
+    return 0;
+  }
+  static int tramp_wjact(void *self, double alpha, po_vec x, po_vec pzw, po_vec out) {
+    ParOptVec vx(x), vp(pzw), vo(out);
+    vx.syncToHost();
+    vp.syncToHost();
+    vo.syncToHost();
+    static_cast<ParOptProblem *>(self)->addSparseJacobianTranspose(alpha, &vx, &vp, &vo);
+    vo.syncToDevice();
+    return 0;
+  }
+  static int tramp_winner(void *self, double alpha, po_vec x, po_vec cvec, po_vec A) {
+    ParOptVec vx(x), vc(cvec), va(A);
+    vx.syncToHost();
+    vc.syncToHost();
+    va.syncToHost();
+    double *a;
+    va.getArray(&a);
+    static_cast<ParOptProblem *>(self)->addSparseInnerProduct(alpha, &vx, &vc, a);
+    va.syncToDevice();
+    return 0;
   }
   static int tramp_write(void *self, int iter, po_vec x) {
     ParOptVec vx(x);
@@ -276,7 +334,7 @@ class ParOptLSR1 : public ParOptCompactQuasiNewton {
 class ParOptInteriorPoint : public ParOptBase {
  public:
   ParOptInteriorPoint(ParOptProblem *_prob, ParOptOptions *_options = NULL)
-      : prob(_prob), options(_options), ip(NULL), x(NULL), zl(NULL), zu(NULL) {
+      : prob(_prob), options(_options), ip(NULL), x(NULL), zl(NULL), zu(NULL), zw(NULL), sw(NULL), tw(NULL) {
     prob->incref();
     if (options) options->incref();
     if (po_ip_create(prob->handle(), &ip) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
@@ -286,6 +344,9 @@ class ParOptInteriorPoint : public ParOptBase {
     if (x) x->decref();
     if (zl) zl->decref();
     if (zu) zu->decref();
+    if (zw) zw->decref();
+    if (sw) sw->decref();
+    if (tw) tw->decref();
     if (ip) po_ip_destroy(ip);
     if (options) options->decref();
     prob->decref();
@@ -303,17 +364,28 @@ class ParOptInteriorPoint : public ParOptBase {
     wrap(&zu, hzu);
     if (_x) *_x = x;
     if (_z) *_z = const_cast<double *>(z);
-    if (_zw) *_zw = NULL;
+    if (_zw) {
+      po_vec hzw = NULL;
+      po_ip_get_optimized_sparse(ip, &hzw, NULL, NULL, NULL, NULL);
+      wrap(&zw, hzw);
+      *_zw = zw;
+    }
     if (_zl) *_zl = zl;
     if (_zu) *_zu = zu;
   }
-  void getOptimizedSlacks(ParOptScalar **s, ParOptScalar **t, ParOptVec **sw, ParOptVec **tw) {
+  void getOptimizedSlacks(ParOptScalar **s, ParOptScalar **t, ParOptVec **_sw, ParOptVec **_tw) {
     const double *ps, *pt, *pzs, *pzt;
     po_ip_get_optimized_slacks(ip, &ps, &pt, &pzs, &pzt);
     if (s) *s = const_cast<double *>(ps);
     if (t) *t = const_cast<double *>(pt);
-    if (sw) *sw = NULL;
-    if (tw) *tw = NULL;
+    if (_sw || _tw) {
+      po_vec hsw = NULL, htw = NULL;
+      po_ip_get_optimized_sparse(ip, NULL, &hsw, &htw, NULL, NULL);
+      wrap(&sw, hsw);
+      wrap(&tw, htw);
+      if (_sw) *_sw = sw;
+      if (_tw) *_tw = tw;
+    }
   }
   void getIterationCounters(int *niter = NULL, int *neval = NULL, int *ngeval = NULL, int *nhvec = NULL) {
     po_ip_get_counters(ip, niter, neval, ngeval);
@@ -340,7 +412,7 @@ class ParOptInteriorPoint : public ParOptBase {
   ParOptProblem *prob;
   ParOptOptions *options;
   po_ip ip;
-  ParOptVec *x, *zl, *zu;
+  ParOptVec *x, *zl, *zu, *zw, *sw, *tw;
 };
 
 #endif  // PAROPT_AMD_HPP

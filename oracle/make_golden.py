@@ -327,6 +327,27 @@ for tag, extra in (
         **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
                                   "opt.max_major_iters": 60}, **extra)),
     )
+# --- trust-region driver: ParOptOptimizer's algorithm="tr" set-up ---
+tr_common = {"opt.qn_subspace_size": 5, "tr.tr_max_iterations": 60}
+case("tr_quadratic_n200_c3_bfgs", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10, **tr_common)
+case("tr_convex_n300_c4_bfgs", "tr", problem="convex", n=300, c=4, dump_vecs_every=10,
+     **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05}))
+case("tr_rosenbrock_n60_bfgs", "tr", problem="rosenbrock", n=60, dump_vecs_every=10,
+     **dict(tr_common, **{"opt.qn_subspace_size": 10, "tr.tr_max_iterations": 80}))
+# L-SR1: Rosenbrock, whose first steps are not collinear (on the separable quadratic the first three
+# steps all sit on the trust-region box in the same direction, which makes the SR1 compact matrix
+# exactly rank one and the reference's own trajectory a round-off artefact)
+case("tr_rosenbrock_n60_sr1", "tr", problem="rosenbrock", n=60, dump_vecs_every=10,
+     **dict(tr_common, **{"opt.qn_type": "sr1", "opt.qn_subspace_size": 4, "tr.tr_max_iterations": 40}))
+case("tr_quadratic_n150_c2_fixedgamma", "tr", problem="quadratic", n=150, c=2, dump_vecs_every=10,
+     **dict(tr_common, **{"tr.tr_adaptive_gamma_update": 0, "opt.penalty_gamma": 50.0}))
+case("tr_convex_n200_c2_w40", "tr", problem="convex", n=200, c=2, nwcon=40, nw=5, nwstart=0, nwskip=0,
+     dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05}))
+# compact eigenvalue subproblem (config 5 shape): constraint 0 modelled with N curvature directions
+case("tr_eig_quadratic_n200_c2_N4", "tr", problem="quadratic", n=200, c=2, eig_N=4, eig_index=0, eig_curv=2.0,
+     dump_vecs_every=10, **tr_common)
+case("tr_eig_convex_n300_c3_N6", "tr", problem="convex", n=300, c=3, eig_N=6, eig_index=1, eig_curv=0.5,
+     dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05}))
 for strat in ("mehrotra", "mehrotra_predictor_corrector"):
     case(
         "ip_quadratic_%s_n300_c3" % ("mpc" if "corrector" in strat else "mehrotra"),
@@ -376,6 +397,8 @@ def main():
             dargs["out"] = rec
             if mode == "ip":
                 dargs["text"] = os.path.join(td, "paropt.out")
+            if mode == "tr":
+                dargs["text"] = os.path.join(td, "paropt.tr")
             if dargs.get("checkpoint"):
                 dargs["checkpoint"] = os.path.join(td, "checkpoint.bin")
             run_driver(mode, dargs, ranks)
@@ -389,6 +412,11 @@ def main():
                 # keep only the iteration table (drop the options echo)
                 start = next((i for i, ln in enumerate(lines) if ln.startswith("iter ")), 0)
                 d["paropt_out"] = np.array("\n".join(lines[start:]))
+            if mode == "tr":
+                with open(dargs["text"]) as f:
+                    lines = [ln.rstrip("\n") for ln in f]
+                start = next((i for i, ln in enumerate(lines) if ln.strip().startswith("iter ")), 0)
+                d["paropt_tr"] = np.array("\n".join(lines[start:]))
         d["case_json"] = np.array(json.dumps(dict(mode=mode, ranks=ranks, args=args)))
         path = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(path, **d)

@@ -136,6 +136,9 @@ class _CompactQN:
         self.diag_type = "yty_over_yts"
         self.reset()
 
+    def update_mult(self, x, z, zw):  # update(x, z, zw): no-op in the base classes (.h:60-63)
+        return 0
+
     def reset(self):  # src/ParOptQuasiNewton.cpp:127-142 / 603-618
         self.msub = 0
         self.b0 = 1.0
@@ -540,6 +543,33 @@ class InteriorPoint:
         v.zt[:] = 1.0
         for k in ("zw", "sw", "tw", "zsw", "ztw"):
             getattr(v, k)[:] = 1.0
+
+    # ---- driver-facing setters (used by the trust-region driver) -------------------------
+    def set_quasi_newton(self, qn):  # :1193-1234
+        self.qn = qn
+
+    def reset_problem_instance(self, prob):  # :745-764 (sizes must match)
+        assert (prob.nlocal, prob.c, getattr(prob, "nwcon", 0)) == (self.n, self.c, self.w)
+        self.prob = prob
+
+    def reset_design_and_bounds(self):  # :1249-1251
+        x, lb, ub = self.prob.vars_and_bounds()
+        self.vars.x[:] = x
+        self.lb, self.ub = lb.copy(), ub.copy()
+
+    def set_penalty_gamma(self, gamma):  # scalar :1128-1151, array :1160-1172 (dense blocks only)
+        if np.isscalar(gamma):
+            if gamma >= 0.0:
+                nwineq = getattr(self.prob, "nwineq", 0)
+                self.gamma_s = np.array([0.0 if i < self.ninequality else gamma for i in range(self.c)])
+                self.gamma_t = np.full(self.c, float(gamma))
+                self.gamma_sw = np.array([0.0 if i < nwineq else gamma for i in range(self.w)])
+                self.gamma_tw = np.full(self.w, float(gamma))
+        else:
+            for i in range(self.c):
+                if gamma[i] >= 0.0:
+                    self.gamma_s[i] = 0.0 if i < self.ninequality else gamma[i]
+                    self.gamma_t[i] = gamma[i]
 
     # ---- quasi-definite block matrix (nwblock = 1): src/ParOptSparseMat.cpp:41-229 --------
     def _factor(self, v, Cdiag):
@@ -1181,6 +1211,8 @@ class InteriorPoint:
             if self.w:
                 self.prob.add_sparse_jacobian_transpose(-1.0, v.zw, y_qn)
             update_type = self.qn.update(s_qn, y_qn)
+        elif self.qn is not None and perform_qn_update:  # :4261-4263
+            update_type = self.qn.update_mult(v.x, v.z, v.zw)
         return update_type
 
     # ---- starting point --------------------------------------------------------------
@@ -1296,6 +1328,8 @@ class InteriorPoint:
             self.init_affine_step_multipliers(v, self.res, self.step)
         elif sp == "least_squares_multipliers":
             self.init_least_squares_multipliers(v, self.res)
+        if self.qn is not None and not o["use_quasi_newton_update"]:  # :4571-4573
+            self.qn.update_mult(v.x, v.z, v.zw)
         fobj_prev = 0.0
         alpha_prev = alpha_xprev = alpha_zprev = 0.0
         dm0_prev = 0.0
@@ -1381,14 +1415,24 @@ class InteriorPoint:
             fobj_prev = self.fobj
             seq_linear_step = 0
             diagonal_qn_step = 0
-            use_qn = 0 if o["sequential_linear_method"] else 1
+            use_qn = 1
+            if o["sequential_linear_method"]:
+                use_qn = 0
+            elif line_search_failed and not o["use_quasi_newton_update"]:  # :4923-4939
+                # fixed quasi-Newton approximation and a failed line search: sequential linear step,
+                # or only the diagonal b0 of the approximation when it is positive
+                use_qn = 0
+                seq_linear_step = 1
+                if self.qn is not None and self.qn.get_compact()[0] > 0.0:
+                    seq_linear_step = 0
+                    diagonal_qn_step = 1
             mu_for_res = self.barrier_param
             if barrier_strategy in mehrotra_names:  # affine residual :4958-4964
                 mu_for_res = 0.0
                 self.compute_kkt_res(v, 0.0, self.res)
                 self.compute_res_norm(self.res)
-            self.setup_kkt_diag_system(v, use_qn)
-            self.setup_kkt_system(v, use_qn)
+            self.setup_kkt_diag_system(v, 1 if diagonal_qn_step else use_qn)  # :4968-4980
+            self.setup_kkt_system(v, 1 if diagonal_qn_step else use_qn)
             self._kkt_step_with_refinement(v, mu_for_res, use_qn)
             if barrier_strategy in mehrotra_names:  # :4999-5052
                 max_x, max_z = self.compute_max_step(v, 1.0, self.step)

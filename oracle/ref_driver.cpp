@@ -36,6 +36,8 @@
 #define protected public
 #include "ParOptInteriorPoint.h"
 #include "ParOptQuasiNewton.h"
+#include "ParOptTrustRegion.h"
+#include "ParOptCompactEigenvalueApprox.h"
 #undef private
 #undef protected
 
@@ -125,6 +127,7 @@ class SepProblem : public ParOptProblem {
     setProblemSizes(nlocal, _ncon, _nwcon);
     setNumInequalities(_ncon, _nwineq < 0 ? _nwcon : _nwineq);
     hook = NULL;
+    tr_hook = NULL;
     beta.resize(_ncon);
     if (kind == QUADRATIC) {
       for (int j = 0; j < _ncon; j++) beta[j] = u01(seed, 4, j);
@@ -295,6 +298,15 @@ class SepProblem : public ParOptProblem {
   double eig_min, eig_max;
   std::vector<double> beta;
   DumpHook *hook;
+  struct TrHook *tr_hook;
+};
+
+// state dumped at the top of every trust-region iteration (tr_write_output_frequency = 1)
+struct TrHook {
+  ParOptTrustRegion *tr;
+  ParOptTrustRegionSubproblem *sub;
+  RecFile *rec;
+  int dump_vecs_every;
 };
 
 struct DumpHook {
@@ -305,6 +317,34 @@ struct DumpHook {
 };
 
 void SepProblem::writeOutput(int iter, ParOptVec *x) {
+  if (tr_hook && tr_hook->rec) {
+    RecFile &R = *tr_hook->rec;
+    ParOptTrustRegion *tr = tr_hook->tr;
+    std::string p = fmt("tr%03d/", iter);
+    ParOptVec *xk, *gk, **Ak;
+    ParOptScalar fk;
+    const ParOptScalar *ck;
+    int m = tr_hook->sub->getLinearModel(&xk, &fk, &gk, &ck, &Ak);
+    R.f64s((p + "tr_size").c_str(), tr->tr_size);
+    R.f64((p + "penalty_gamma").c_str(), tr->penalty_gamma, m);
+    R.f64s((p + "fk").c_str(), fk);
+    R.f64((p + "ck").c_str(), ck, m);
+    int it[3] = {tr->iter_count, tr->subproblem_iters, tr->adaptive_subproblem_iters};
+    R.i32((p + "iters").c_str(), it, 3);
+    double nr[2] = {xk->norm(), gk->norm()};
+    R.f64((p + "norms").c_str(), nr, 2);
+    ParOptCompactQuasiNewton *q = tr_hook->sub->getQuasiNewton();
+    if (q) {
+      ParOptScalar b0 = 0.0;
+      const ParOptScalar *d0, *M;
+      ParOptVec **Z;
+      int k = q->getCompactMat(&b0, &d0, &M, &Z);
+      R.i32s((p + "qn_size").c_str(), k);
+      R.f64s((p + "qn_b0").c_str(), b0);
+    }
+    if (tr_hook->dump_vecs_every > 0 && (iter % tr_hook->dump_vecs_every) == 0) R.vec((p + "x").c_str(), xk);
+    return;
+  }
   if (!hook || !hook->rec) return;  // collective: every rank runs the reductions below
   ParOptInteriorPoint *ip = hook->ip;
   RecFile &R = *hook->rec;
@@ -676,6 +716,154 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   return rc;
 }
 
+// Trust-region driver (src/ParOptTrustRegion.cpp) over the quadratic subproblem, or over the compact
+// eigenvalue subproblem (src/ParOptCompactEigenvalueApprox.cpp) when eig_N > 0, set up the way
+// ParOptOptimizer::optimize does for algorithm = "tr" (src/ParOptOptimizer.cpp:108-183).
+// "tr.<name>=<value>" and "opt.<name>=<value>" both go to the single shared options object.
+struct EigData {
+  int N;
+  uint64_t seed;
+  int64_t offset;
+  double curv;
+};
+static void eig_update(void *data, ParOptVec *x, ParOptCompactEigenApprox *approx) {
+  // SPD model curvature, fixed random directions: M = -curv * I (concave constraint model
+  // c(s) = c0 + g0^T s - 0.5 curv |H^T s|^2), Minv its inverse; hvecs from the counter hash.
+  EigData *E = (EigData *)data;
+  ParOptScalar *c0, *M, *Minv;
+  ParOptVec *g0, **hvecs;
+  int N;
+  approx->getApproximation(&c0, &g0, &N, &M, &Minv, &hvecs);
+  for (int i = 0; i < N; i++) {
+    double *h;
+    int nl = hvecs[i]->getArray(&h);
+    for (int k = 0; k < nl; k++) h[k] = 2.0 * u01(E->seed, 300 + i, E->offset + k) - 1.0;
+    ParOptScalar nrm = hvecs[i]->norm();
+    hvecs[i]->scale(1.0 / nrm);
+    for (int j = 0; j < N; j++) {
+      M[i * N + j] = (i == j) ? -E->curv * (1.0 + 0.1 * i) : 0.0;
+      Minv[i * N + j] = (i == j) ? 1.0 / (-E->curv * (1.0 + 0.1 * i)) : 0.0;
+    }
+  }
+}
+
+static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int rank, int size,
+                   bool bench) {
+  int64_t n = geti(A, "n", 1000);
+  int c = (int)geti(A, "c", 8);
+  uint64_t seed = (uint64_t)geti(A, "seed", 0);
+  std::string pname = gets(A, "problem", "quadratic");
+  SepProblem::Kind kind = kind_of(pname);
+  if (kind == SepProblem::ROSENBROCK) c = 2;
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  SepProblem *prob = new SepProblem(comm, kind, nlocal, offset, n, c, seed, getf(A, "eig_min", 1.0),
+                                    getf(A, "eig_max", 100.0), (int)geti(A, "nwcon", 0),
+                                    (int)geti(A, "nw", 0), (int)geti(A, "nwstart", 0),
+                                    (int)geti(A, "nwskip", 0), (int)geti(A, "nwineq", -1));
+  prob->incref();
+  ParOptOptions *opt = new ParOptOptions(comm);
+  opt->incref();
+  ParOptInteriorPoint::addDefaultOptions(opt);
+  ParOptTrustRegion::addDefaultOptions(opt);
+  opt->setOption("output_file", "/dev/null");
+  std::string trfile = gets(A, "text", "");
+  opt->setOption("tr_output_file", trfile.size() ? trfile.c_str() : "/dev/null");
+  opt->setOption("tr_write_output_frequency", 1);
+  set_options(opt, A);
+  for (std::map<std::string, std::string>::iterator it = A.begin(); it != A.end(); ++it) {
+    if (it->first.compare(0, 3, "tr.") != 0) continue;
+    std::string name = it->first.substr(3);
+    int t = opt->getOptionType(name.c_str());
+    if (t == ParOptOptions::PAROPT_FLOAT_OPTION) {
+      opt->setOption(name.c_str(), atof(it->second.c_str()));
+    } else if (t == ParOptOptions::PAROPT_INT_OPTION || t == ParOptOptions::PAROPT_BOOLEAN_OPTION) {
+      opt->setOption(name.c_str(), atoi(it->second.c_str()));
+    } else {
+      opt->setOption(name.c_str(), it->second.c_str());
+    }
+  }
+  // quasi-Newton object as ParOptOptimizer builds it (:121-166)
+  ParOptCompactQuasiNewton *qn = NULL;
+  std::string qt = opt->getEnumOption("qn_type");
+  int msub = opt->getIntOption("qn_subspace_size");
+  if (qt == "bfgs") {
+    ParOptLBFGS *b = new ParOptLBFGS(prob, msub);
+    std::string ut = opt->getEnumOption("qn_update_type");
+    b->setBFGSUpdateType(ut == "damped_update" ? PAROPT_DAMPED_UPDATE : PAROPT_SKIP_NEGATIVE_CURVATURE);
+    qn = b;
+  } else if (qt == "sr1") {
+    qn = new ParOptLSR1(prob, msub);
+  }
+  if (qn) {
+    qn->incref();
+    std::string dt = opt->getEnumOption("qn_diag_type");
+    qn->setInitDiagonalType(dt == "yts_over_sts" ? PAROPT_YTS_OVER_STS : PAROPT_YTY_OVER_YTS);
+  }
+  int eigN = (int)geti(A, "eig_N", 0);
+  ParOptTrustRegionSubproblem *sub = NULL;
+  EigData E;
+  if (eigN > 0) {
+    ParOptCompactEigenApprox *eigh = new ParOptCompactEigenApprox(prob, eigN);
+    ParOptEigenQuasiNewton *eqn = new ParOptEigenQuasiNewton(qn, eigh, (int)geti(A, "eig_index", 0));
+    ParOptEigenSubproblem *es = new ParOptEigenSubproblem(prob, eqn);
+    E.N = eigN;
+    E.seed = seed;
+    E.offset = offset;
+    E.curv = getf(A, "eig_curv", 1.0);
+    es->setEigenModelUpdate(&E, eig_update);
+    sub = es;
+  } else {
+    sub = new ParOptQuadraticSubproblem(prob, qn);
+  }
+  sub->incref();
+  ParOptInteriorPoint *ip = new ParOptInteriorPoint(sub, opt);
+  ip->incref();
+  ParOptTrustRegion *tr = new ParOptTrustRegion(sub, opt);
+  tr->incref();
+  RecFile R;
+  TrHook hook;
+  hook.tr = tr;
+  hook.sub = sub;
+  hook.rec = &R;
+  hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
+  if (!bench) {
+    if (rank == 0) R.open(gets(A, "out", "tr.rec").c_str());
+    prob->tr_hook = &hook;
+    R.i32s("n", (int)n);
+    R.i32s("c", c);
+  }
+  double t0 = MPI_Wtime();
+  tr->optimize(ip);
+  double t1 = MPI_Wtime();
+  ParOptVec *xk;
+  ParOptScalar fk;
+  const ParOptScalar *ck;
+  sub->getLinearModel(&xk, &fk, NULL, &ck, NULL);
+  ParOptScalar *z;
+  ip->getOptimizedPoint(NULL, &z, NULL, NULL, NULL);
+  if (!bench) {
+    R.i32s("final/iter_count", tr->iter_count);
+    R.f64s("final/fk", fk);
+    R.f64("final/ck", ck, c);
+    R.f64("final/z", z, c);
+    R.f64s("final/tr_size", tr->tr_size);
+    R.f64("final/penalty_gamma", tr->penalty_gamma, c);
+    R.f64s("final/xnorm", xk->norm());
+    if (hook.dump_vecs_every > 0) R.vec("final/x", xk);
+    R.close();
+  }
+  if (rank == 0) {
+    printf(
+        "{\"mode\":\"tr\",\"problem\":\"%s\",\"n\":%ld,\"c\":%d,\"ranks\":%d,\"tr_iters\":%d,"
+        "\"seconds\":%.6f,\"it_per_s\":%.6f,\"fobj\":%.17g}\n",
+        pname.c_str(), (long)n, c, size, tr->iter_count, t1 - t0,
+        tr->iter_count / (t1 - t0 > 0 ? t1 - t0 : 1.0), fk);
+  }
+  return 0;
+}
+
 static int mode_mdot_bench(std::map<std::string, std::string> &A, MPI_Comm comm, int rank,
                            int size) {
   int64_t n = geti(A, "n", 10000000);
@@ -725,8 +913,10 @@ int main(int argc, char *argv[]) {
     if (mode == "ip") rc = mode_ip(A, comm, rank, size, false);
     if (mode == "bench") rc = mode_ip(A, comm, rank, size, true);
     if (mode == "mdot") rc = mode_mdot_bench(A, comm, rank, size);
+    if (mode == "tr") rc = mode_tr(A, comm, rank, size, false);
+    if (mode == "trbench") rc = mode_tr(A, comm, rank, size, true);
   } else if (rank == 0) {
-    fprintf(stderr, "usage: ref_driver vecops|qn|ip|bench|mdot key=value ...\n");
+    fprintf(stderr, "usage: ref_driver vecops|qn|ip|bench|mdot|tr|trbench key=value ...\n");
   }
   MPI_Finalize();
   return rc;

@@ -47,3 +47,19 @@ def test_cpp_rosenbrock_matches_reference(tmp_path):
     assert abs(out["fobj"] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
     np.testing.assert_allclose(out["xnorm"], g["final/norms"][0], rtol=1e-7)
     np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_cpp_rosenbrock_sparse_constraints_match_reference(tmp_path):
+    """The reference example WITH its sparse constraints (nwcon = 5), host callbacks through the
+    facade's evalSparseCon / addSparseJacobian / addSparseJacobianTranspose / addSparseInnerProduct."""
+    exe = build(tmp_path)
+    res = subprocess.run([exe, "nvars=100", "nwcon=5"], capture_output=True, text=True, timeout=300,
+                         cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    g, _ = load_golden("ipw_rosenbrock_n100_w5")
+    np.testing.assert_array_equal(np.array([out["niter"], out["neval"], out["ngeval"]]), g["final/counters"])
+    assert abs(out["fobj"] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+    np.testing.assert_allclose(out["xnorm"], g["final/norms"][0], rtol=1e-7)
+    np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,28 @@
+"""
+The numpy restatement of the trust-region driver (oracle/tr_oracle.py: quadratic / infeasibility /
+compact-eigenvalue subproblems, SL1QP with the adaptive penalty update) pinned against trajectories
+of the compiled reference (tests/golden/tr_*.npz from oracle/ref_driver.cpp mode "tr"): the
+iteration table to its print precision, accept/reject and quasi-Newton flags exactly, the
+interior-point iteration counts of both subproblem solves, trust-region radius, penalty parameters,
+model values and the iterate itself.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from tr_helpers import compare_tr, run_oracle_tr
+
+TR_CASES = golden_names("tr_")
+
+
+@pytest.mark.parametrize("name", TR_CASES)
+def test_tr_trajectory(name):
+    g, case = load_golden(name)
+    window = 40 if "sr1" in name else 60
+    rows, snaps, final = run_oracle_tr(case)
+    n = compare_tr(g, rows, snaps, final, window)
+    if "sr1" not in name:
+        assert final["iter_count"] == int(g["final/iter_count"][0])
+        assert abs(final["fk"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+        np.testing.assert_allclose(final["x"], g["final/x"], rtol=0, atol=1e-5 * max(1.0, np.abs(g["final/x"]).max()))
+    assert n >= 20
