@@ -222,6 +222,48 @@ int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W);
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out);
 int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *avg_ms);
 
+/* ---- ParOptTrustRegion over the quadratic / compact-eigenvalue subproblem ------------------------
+ * src/ParOptTrustRegion.h:376-480, set up as ParOptOptimizer does for algorithm = "tr"
+ * (src/ParOptOptimizer.cpp:108-183): quasi-Newton object from qn_type / qn_subspace_size /
+ * qn_update_type / qn_diag_type, ParOptQuadraticSubproblem (or ParOptEigenSubproblem), an
+ * interior-point solver on the subproblem and the SL1QP driver.  ONE options registry holds the
+ * interior-point options (.cpp:536-727) and the trust-region options
+ * (src/ParOptTrustRegion.cpp:739-847), as in the reference.  `prob` is borrowed. */
+typedef struct po_tr_s *po_tr;
+typedef struct po_eig_s *po_eig;
+int po_tr_create(po_problem prob, po_tr *out);
+int po_tr_destroy(po_tr tr);
+int po_tr_set_option_str(po_tr tr, const char *name, const char *value);
+int po_tr_set_option_int(po_tr tr, const char *name, int value);
+int po_tr_set_option_float(po_tr tr, const char *name, double value);
+/* ParOptEigenSubproblem::setEigenModelUpdate (src/ParOptCompactEigenvalueApprox.h:166-170):
+ * constraint `index` is modelled as c0 + g0^T s + 1/2 s^T H M H^T s with N directions; `update` is
+ * called at the initial point and at every accepted point with c0, g0 preset to the linearisation and
+ * must fill hvecs, M and Minv (row-major N x N).  Call before the first po_tr_optimize. */
+typedef int (*po_eig_update_fn)(void *user, po_vec x, po_eig approx);
+int po_tr_set_eigen_model(po_tr tr, int N, int index, po_eig_update_fn update, void *user);
+/* built-in synthetic model of BASELINE.json configs[4]: unit hash directions (seed, array ids 300+i),
+ * M = -curv (1 + 0.1 i) I (oracle/ref_driver.cpp eig_update) */
+int po_tr_set_eigen_model_synthetic(po_tr tr, int N, int index, uint64_t seed, double curv);
+/* ParOptCompactEigenApprox::getApproximation (.cpp:66-90): borrowed pointers */
+int po_eig_get_approximation(po_eig approx, double **c0, po_vec *g0, int *N, double **M, double **Minv,
+                             const po_vec **hvecs);
+int po_tr_optimize(po_tr tr);                                /* optimize .cpp:2365-2384 */
+/* getOptimizedPoint .cpp:872-876 (+ the multipliers of the last subproblem solve) */
+int po_tr_get_optimized_point(po_tr tr, po_vec *x, const double **z, po_vec *zw);
+/* driver state: radius, iteration count, subproblem iteration counts of the last iteration,
+ * penalty parameters (borrowed), model values fk / ck (borrowed) */
+int po_tr_get_state(po_tr tr, double *tr_size, int *iter_count, int *subproblem_iters,
+                    int *adaptive_subproblem_iters, const double **penalty_gamma, double *fk,
+                    const double **ck);
+/* the last row of the iteration table (12 numeric columns without the wall time) and its info string */
+int po_tr_get_last_row(po_tr tr, const double **row12, const char **info);
+int po_tr_get_history(po_tr tr, const char **text);          /* the paropt.tr table :1406-1438 */
+int po_tr_get_quasi_newton(po_tr tr, po_qn *qn);             /* subproblem->getQuasiNewton() */
+int po_tr_get_model_vectors(po_tr tr, po_vec *xk, po_vec *gk);
+typedef int (*po_tr_iteration_fn)(void *user, int iter);     /* where the reference calls writeOutput */
+int po_tr_set_iteration_callback(po_tr tr, po_tr_iteration_fn fn, void *user);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,8 @@ from .api import (  # noqa: F401
     Problem,
     PVec,
     SeparableProblem,
+    TrustRegion,
+    EigenApprox,
     bench_mdot,
     bench_wgram,
     wgram,

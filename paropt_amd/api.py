@@ -536,6 +536,149 @@ class InteriorPoint:
         return d
 
 
+class EigenApprox:
+    """ParOptCompactEigenApprox as seen by the model-update callback: c0 (settable), g0 (PVec), N,
+    M and Minv (row-major N x N numpy views, writable), hvecs (list of PVec)."""
+
+    def __init__(self, ctx, handle):
+        c0, g0, N = L.c_double_p(), L.po_vec(), C.c_int()
+        M, Minv, hv = L.c_double_p(), L.c_double_p(), L.vec_p()
+        check(lib.po_eig_get_approximation(handle, C.byref(c0), C.byref(g0), C.byref(N), C.byref(M),
+                                           C.byref(Minv), C.byref(hv)))
+        self.N = N.value
+        self._c0 = c0
+        self.g0 = PVec(ctx, handle=g0, owned=False)
+        self.M = np.ctypeslib.as_array(M, shape=(self.N, self.N))
+        self.Minv = np.ctypeslib.as_array(Minv, shape=(self.N, self.N))
+        self.hvecs = [PVec(ctx, handle=L.po_vec(hv[i]), owned=False) for i in range(self.N)]
+
+    @property
+    def c0(self):
+        return self._c0[0]
+
+    @c0.setter
+    def c0(self, v):
+        self._c0[0] = float(v)
+
+
+class TrustRegion:
+    """ParOptTrustRegion over ParOptQuadraticSubproblem (or ParOptEigenSubproblem), assembled the
+    way ParOptOptimizer does for algorithm='tr' (reference src/ParOptOptimizer.cpp:108-183).
+    `options` may mix interior-point and trust-region option names (one shared registry)."""
+
+    COLS = ("fobj", "infeas", "l1", "linfty", "smax", "tr", "rho", "model_reduc", "zav", "zmax", "gav", "gmax")
+
+    def __init__(self, problem, options=None):
+        self.problem = problem
+        self.ctx = problem.ctx
+        self._h = L.po_tr()
+        check(lib.po_tr_create(problem.handle, C.byref(self._h)))
+        self._cbs = []
+        opts = dict(options or {})
+        opts.setdefault("tr_output_file", "")
+        for k, v in opts.items():
+            self.setOption(k, v)
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib.po_tr_destroy(self._h)
+        except Exception:
+            pass
+
+    def setOption(self, name, value):
+        nm = name.encode()
+        if isinstance(value, bool):
+            check(lib.po_tr_set_option_int(self._h, nm, int(value)))
+        elif isinstance(value, int):
+            rc = lib.po_tr_set_option_int(self._h, nm, value)
+            if rc != 0:
+                check(lib.po_tr_set_option_float(self._h, nm, float(value)))
+        elif isinstance(value, float):
+            check(lib.po_tr_set_option_float(self._h, nm, value))
+        else:
+            check(lib.po_tr_set_option_str(self._h, nm, str(value).encode()))
+
+    def setEigenModel(self, N, index, update):
+        """update(x: PVec, approx: EigenApprox) fills approx.hvecs / M / Minv (c0, g0 are preset)."""
+        def _cb(user, x, approx):
+            update(PVec(self.ctx, handle=L.po_vec(x), owned=False), EigenApprox(self.ctx, L.po_eig(approx)))
+            return 0
+
+        fn = L.EIG_UPDATE_FN(_cb)
+        self._cbs.append(fn)
+        check(lib.po_tr_set_eigen_model(self._h, int(N), int(index), fn, None))
+
+    def setEigenModelSynthetic(self, N, index, seed=0, curv=1.0):
+        check(lib.po_tr_set_eigen_model_synthetic(self._h, int(N), int(index), int(seed), float(curv)))
+
+    def setIterationCallback(self, fn):
+        def _cb(user, k):
+            fn(k)
+            return 0
+
+        cb = L.TR_ITER_FN(_cb)
+        self._cbs.append(cb)
+        check(lib.po_tr_set_iteration_callback(self._h, cb, None))
+
+    def optimize(self):
+        rc = lib.po_tr_optimize(self._h)
+        if rc != 0:
+            raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
+        return rc
+
+    def getOptimizedPoint(self):
+        x, z, zw = L.po_vec(), L.c_double_p(), L.po_vec()
+        check(lib.po_tr_get_optimized_point(self._h, C.byref(x), C.byref(z), C.byref(zw)))
+        c = self.problem.ncon
+        return (PVec(self.ctx, handle=x, owned=False), np.array([z[i] for i in range(c)]),
+                PVec(self.ctx, handle=zw, owned=False) if zw else None)
+
+    def getState(self):
+        tr, it, si, ai, fk = C.c_double(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        pg, ck = L.c_double_p(), L.c_double_p()
+        check(lib.po_tr_get_state(self._h, C.byref(tr), C.byref(it), C.byref(si), C.byref(ai), C.byref(pg),
+                                  C.byref(fk), C.byref(ck)))
+        c = self.problem.ncon
+        return dict(tr_size=tr.value, iter_count=it.value, subproblem_iters=si.value,
+                    adaptive_subproblem_iters=ai.value, penalty_gamma=np.array([pg[i] for i in range(c)]),
+                    fk=fk.value, ck=np.array([ck[i] for i in range(c)]))
+
+    def getLastRow(self):
+        row, info = L.c_double_p(), C.c_char_p()
+        check(lib.po_tr_get_last_row(self._h, C.byref(row), C.byref(info)))
+        return [row[i] for i in range(12)], info.value.decode().split()
+
+    def getHistory(self):
+        t = C.c_char_p()
+        check(lib.po_tr_get_history(self._h, C.byref(t)))
+        return t.value.decode()
+
+    def getQuasiNewton(self):
+        h = L.po_qn()
+        check(lib.po_tr_get_quasi_newton(self._h, C.byref(h)))
+        return _QuasiNewton(self.ctx, 0, 0, 0, handle=h) if h else None
+
+    def getModelVectors(self):
+        xk, gk = L.po_vec(), L.po_vec()
+        check(lib.po_tr_get_model_vectors(self._h, C.byref(xk), C.byref(gk)))
+        return PVec(self.ctx, handle=xk, owned=False), PVec(self.ctx, handle=gk, owned=False)
+
+    def snapshot(self):
+        """State in the layout of the golden 'trNNN/' records (oracle/ref_driver.cpp TrHook)."""
+        s = self.getState()
+        xk, gk = self.getModelVectors()
+        d = dict(tr_size=s["tr_size"], penalty_gamma=s["penalty_gamma"], fk=s["fk"], ck=s["ck"],
+                 iters=np.array([s["iter_count"], s["subproblem_iters"], s["adaptive_subproblem_iters"]]),
+                 norms=np.array([xk.norm(), gk.norm()]), qn_size=0, qn_b0=0.0)
+        qn = self.getQuasiNewton()
+        if qn is not None:
+            k, b0 = C.c_int(), C.c_double()
+            check(lib.po_qn_get_compact(qn._h, C.byref(k), C.byref(b0), None, None, None))
+            d["qn_size"], d["qn_b0"] = k.value, b0.value
+        return d
+
+
 def wgram(d, vecs):
     nv = len(vecs)
     W = np.zeros((nv, nv))

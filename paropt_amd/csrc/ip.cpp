@@ -118,6 +118,74 @@ Options::Options() {
     {"least_squares_multipliers", "affine_step", "no_start_strategy"});
 }
 
+void Options::addTrustRegionDefaults() {
+  auto S = [&](const char *n, const char *v) {
+    Entry x;
+    x.type = STR;
+    x.s = v ? v : "";
+    e[n] = x;
+  };
+  auto F = [&](const char *n, double v, double lo, double hi) {
+    Entry x;
+    x.type = FLOAT;
+    x.f = v;
+    x.flo = lo;
+    x.fhi = hi;
+    e[n] = x;
+  };
+  auto B = [&](const char *n, int v) {
+    Entry x;
+    x.type = BOOL;
+    x.i = v;
+    x.ilo = 0;
+    x.ihi = 1;
+    e[n] = x;
+  };
+  auto I = [&](const char *n, int v, int lo, int hi) {
+    Entry x;
+    x.type = INT;
+    x.i = v;
+    x.ilo = lo;
+    x.ihi = hi;
+    e[n] = x;
+  };
+  auto E = [&](const char *n, const char *v, std::vector<std::string> ch) {
+    Entry x;
+    x.type = ENUM;
+    x.s = v;
+    x.choices = ch;
+    e[n] = x;
+  };
+  S("tr_output_file", "paropt.tr");
+  F("tr_init_size", 0.1, 0.0, 1e20);
+  F("tr_min_size", 1e-3, 0.0, 1e20);
+  F("tr_max_size", 1.0, 0.0, 1e20);
+  F("tr_eta", 0.25, 0.0, 1.0);
+  F("tr_bound_relax", 1e-4, 0.0, 1e20);
+  I("tr_write_output_frequency", 10, 0, 1000000);
+  B("tr_adaptive_gamma_update", 1);
+  E("tr_accept_step_strategy", "penalty_method", {"penalty_method", "filter_method"});
+  B("filter_sufficient_reduction", 1);
+  F("filter_gamma", 1e-5, 0.0, 1.0);
+  B("filter_has_feas_restore_phase", 1);
+  B("tr_use_soc", 0);
+  B("tr_soc_update_qn", 0);
+  I("tr_max_soc_iterations", 20, 0, 1000000);
+  I("tr_max_iterations", 200, 0, 1000000);
+  F("tr_l1_tol", 1e-6, 0.0, 1e20);
+  F("tr_linfty_tol", 1e-6, 0.0, 1e20);
+  F("tr_infeas_tol", 1e-5, 0.0, 1e20);
+  F("tr_penalty_gamma_max", 1e4, 0.0, 1e20);
+  F("tr_penalty_gamma_min", 0.0, 0.0, 1e20);
+  E("tr_adaptive_objective", "linear_objective",
+    {"constant_objective", "linear_objective", "subproblem_objective"});
+  E("tr_adaptive_constraint", "linear_constraint", {"linear_constraint", "subproblem_constraint"});
+  E("tr_steering_barrier_strategy", "mehrotra_predictor_corrector",
+    {"monotone", "mehrotra", "mehrotra_predictor_corrector", "complementarity_fraction", "default"});
+  E("tr_steering_starting_point_strategy", "affine_step",
+    {"least_squares_multipliers", "affine_step", "no_start_strategy", "default"});
+}
+
 int Options::set(const char *name, const char *value) {
   auto it = e.find(name);
   if (it == e.end()) {
@@ -198,7 +266,7 @@ InteriorPoint::InteriorPoint(Problem *p)
       rho_penalty_search(0.0), niter(0), neval(0), ngeval(0), analytic_panel_dots(true),
       iter_cb(nullptr),
       iter_cb_user(nullptr), px(nullptr), pzl(nullptr), pzu(nullptr), Dinv(nullptr), rx(nullptr),
-      tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), vA(nullptr), qn_created(false), wk(0),
+      tvec(nullptr), xt(nullptr), y_qn(nullptr), s_qn(nullptr), vA(nullptr), qn_created(false), qn_owned(true), wk(0),
       comp_prod(0), comp_count(0), max_rx(0), max_rzl(0), max_rzu(0), sx(1.0), sz(1.0),
       ptpx_valid(false), residual_fused(false), residual_cached(false), corrector_active(false),
       norm_type(0), tdots_valid(false), fused_dots(true), phase_t0(0) {
@@ -257,7 +325,7 @@ InteriorPoint::~InteriorPoint() {
     vec_decref(wstepv[i]);
   }
   for (Vec *v : Uw) vec_decref(v);
-  delete qn;
+  if (qn_owned) delete qn;
 }
 
 void InteriorPoint::setPenaltyGamma(double gamma) {  // :1127-1151
@@ -266,6 +334,34 @@ void InteriorPoint::setPenaltyGamma(double gamma) {  // :1127-1151
   gamma_t.assign(c, gamma);
   for (int i = 0; i < c && i < prob->ninequality; i++) gamma_s[i] = 0.0;
   if (has_w) k_w_gamma(ctx, gsw->d, gtw->d, gamma, prob->nwinequality, nw);  // :1139-1150
+}
+
+int InteriorPoint::setQuasiNewton(CompactQuasiNewton *qn_) {  // :1193-1234
+  if (qn_owned) delete qn;
+  qn = qn_;
+  qn_owned = false;
+  qn_created = true;
+  qn_handle.qn = qn;
+  return PO_OK;
+}
+
+int InteriorPoint::resetProblemInstance(Problem *p) {  // :745-764
+  if (p->nlocal != prob->nlocal || p->ncon != prob->ncon || p->nwcon != prob->nwcon ||
+      p->ninequality != prob->ninequality || p->nwinequality != prob->nwinequality) {
+    set_error("ParOpt: Incompatible problem instance");
+    return PO_ERR_ARG;
+  }
+  prob = p;
+  return PO_OK;
+}
+
+void InteriorPoint::setPenaltyGammaArray(const double *gamma) {  // :1160-1172 (dense blocks only)
+  for (int i = 0; i < c; i++) {
+    if (gamma[i] >= 0.0) {
+      gamma_s[i] = i < prob->ninequality ? 0.0 : gamma[i];
+      gamma_t[i] = gamma[i];
+    }
+  }
 }
 
 int InteriorPoint::createQuasiNewton() {  // ctor :262-292
@@ -555,13 +651,13 @@ int InteriorPoint::getComplementarity(double *comp) {
 // ================================================================================================
 // the KKT system
 // ================================================================================================
-int InteriorPoint::setUpKKTSystem(bool use_qn) {  // setUpKKTDiagSystem + setUpKKTSystem
+int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDiagSystem + setUpKKTSystem
   ptpx_valid = false;
   const double sigma = options.real("qn_sigma");
-  const double b0 = (qn && use_qn) ? qn->diag() : 0.0;
+  const double b0 = (qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
   PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d));
   int k = 0;
-  std::vector<const double *> P = panel(use_qn, &k);
+  std::vector<const double *> P = panel(use_qn && !diag_only, &k);
   const int m = c + k;
   wk = k;
   W.assign((size_t)m * m, 0.0);
@@ -1151,6 +1247,9 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     int rcc = prob->computeQuasiNewtonUpdateCorrection(x, vars.z.data(), s_qn, y_qn);
     if (rcc != 0) return PO_ERR_USER;
     PO_TRY(qn->update(s_qn, y_qn, update_type));
+  } else if (qn && perform_qn_update) {  // :4261-4263
+    if (qn->updateMult(x, vars.z.data(), has_w ? wvar[0] : nullptr) != 0) return PO_ERR_USER;
+    *update_type = 0;
   }
   return PO_OK;
 }
@@ -1239,10 +1338,13 @@ int InteriorPoint::optimize(const char *checkpoint) {
   } else if (start == "least_squares_multipliers") {
     PO_TRY(initLeastSquaresMultipliers());
   }
+  if (qn && !use_qnu) {  // :4569-4573
+    if (qn->updateMult(x, vars.z.data(), has_w ? wvar[0] : nullptr) != 0) return PO_ERR_USER;
+  }
   phaseEnd("init");
 
   double fobj_prev = 0.0, alpha_prev = 0.0, alpha_xprev = 0.0, alpha_zprev = 0.0, dm0_prev = 0.0;
-  int no_merit_function_improvement = 0, line_search_test = 0;
+  int no_merit_function_improvement = 0, line_search_test = 0, line_search_failed = 0;
   char info[64];
   memset(info, 0, sizeof(info));
   char line[512];
@@ -1360,12 +1462,22 @@ int InteriorPoint::optimize(const char *checkpoint) {
     fobj_prev = fobj;
     int seq_linear_step = 0, diagonal_quasi_newton_step = 0;
     bool use_qn = !seq_lin;
+    if (!seq_lin && line_search_failed && !use_qnu) {
+      // a fixed quasi-Newton approximation whose line search failed (:4923-4939): sequential linear
+      // step, or only the diagonal b0 of the approximation when that is positive
+      use_qn = false;
+      seq_linear_step = 1;
+      if (qn && qn->diag() > 0.0) {
+        seq_linear_step = 0;
+        diagonal_quasi_newton_step = 1;
+      }
+    }
 
     const bool mehrotra = (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC);
     double tau = min_frac;
     if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
 
-    PO_TRY(setUpKKTSystem(use_qn));
+    PO_TRY(setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0));
     phaseEnd("setup_kkt");
     if (!mehrotra) {
       PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
@@ -1509,6 +1621,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
     no_merit_function_improvement =
         ((line_fail & LS_NO_IMPROVEMENT) || (line_fail & LS_MIN_STEP) ||
          (line_fail & LS_SHORT_STEP) || (line_fail & LS_FAILURE));
+    line_search_failed = (line_fail & LS_FAILURE) ? 1 : 0;
     alpha_prev = alpha;
     alpha_xprev = alpha_x;
     alpha_zprev = alpha_z;

@@ -25,6 +25,8 @@ class Options {
     std::vector<std::string> choices;
   };
   Options();
+  // ParOptTrustRegion::addDefaultOptions (src/ParOptTrustRegion.cpp:739-847) into the same registry
+  void addTrustRegionDefaults();
   int set(const char *name, const char *value);
   int set(const char *name, int value);
   int set(const char *name, double value);
@@ -63,8 +65,12 @@ class InteriorPoint {
   double getBarrierParameter() const { return barrier_param; }
   int getComplementarity(double *comp);
   void setPenaltyGamma(double gamma);
+  void setPenaltyGammaArray(const double *gamma);  // per-constraint values (:1160-1172)
   int resetDesignAndBounds();
   void resetQuasiNewtonHessian();
+  // drivers that own the quasi-Newton object / swap the problem (trust region): :1193-1234, :745-764
+  int setQuasiNewton(CompactQuasiNewton *qn_);
+  int resetProblemInstance(Problem *p);
   int writeSolutionFile(const char *filename);
   int readSolutionFile(const char *filename);
   int debugKKTStep(double mu);
@@ -110,6 +116,7 @@ class InteriorPoint {
   std::vector<double> gamma_s, gamma_t;
   int use_lower, use_upper;
   bool qn_created;
+  bool qn_owned;
 
   // small dense systems
   std::vector<double> W;            // (c+k)^2 weighted Gram, column-major
@@ -164,7 +171,9 @@ class InteriorPoint {
   void resNorms(const Dense &r, double *max_prime, double *max_dual, double *max_infeas,
                 double *res_norm) const;
   double compFromSums(double prod, double count, const Dense &v, double wprod = 0.0) const;
-  int setUpKKTSystem(bool use_qn);
+  // diag_only: keep b0 of the quasi-Newton approximation in Dinv but leave its low-rank part out
+  // (the "diagonal quasi-Newton step" of :4923-4980)
+  int setUpKKTSystem(bool use_qn, bool diag_only = false);
   int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                bool fuse_residual = false);
   int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);

@@ -22,17 +22,20 @@ class CompactQuasiNewton {
   virtual void reset();
   // returns PO_* status; *rc = 0 normal, 1 damped, 2 skipped (src/ParOptQuasiNewton.cpp:162-334)
   virtual int update(Vec *s, Vec *y, int *rc) = 0;
-  int mult(Vec *x, Vec *y);                    // y = B x
-  int multAdd(double alpha, Vec *x, Vec *y);   // y += alpha B x
+  // update(x, z, zw): multiplier-only update, a no-op for the limited-memory classes
+  // (src/ParOptQuasiNewton.h:60-63); ParOptEigenQuasiNewton records z[index] here
+  virtual int updateMult(Vec *x, const double *z, Vec *zw) { return 0; }
+  virtual int mult(Vec *x, Vec *y);                    // y = B x
+  virtual int multAdd(double alpha, Vec *x, Vec *y);   // y += alpha B x
   // (b0, d0, M, Z) of B = b0 I - Z diag(d0) M^-1 diag(d0) Z^T; returns the size k
-  int getCompactMat(double *b0_, const double **d0_, const double **M_, Vec ***Z_);
+  virtual int getCompactMat(double *b0_, const double **d0_, const double **M_, Vec ***Z_);
   virtual int getMaxLimitedMemorySize() = 0;
 
   // rz <- diag(d0) M^-1 diag(d0) rz   (the host part of mult, :399-411)
-  void applyCompactInverse(double *rz) const;
-  int size() const { return (int)Z.size(); }
-  double diag() const { return b0; }
-  std::vector<const double *> zPointers() const;
+  virtual void applyCompactInverse(double *rz) const;
+  virtual int size() const { return (int)Z.size(); }
+  virtual double diag() const { return b0; }
+  virtual std::vector<const double *> zPointers() const;
 
   Ctx *ctx;
   int64_t n;

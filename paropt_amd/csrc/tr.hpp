@@ -1,0 +1,218 @@
+// Host-side mirror of the reference's trust-region layer (src/ParOptTrustRegion.h:15-493,
+// src/ParOptCompactEigenvalueApprox.h:9-206): the subproblem interface, the quadratic and
+// compact-eigenvalue subproblems, the infeasibility (steering) problem and the SL1QP driver with the
+// adaptive penalty update.  Same method names and argument meaning; every n-sized operation is a
+// launch of the kernels the interior-point path already uses (mdot / panel_axpy / panel_lincomb).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "ip.hpp"
+
+namespace po {
+
+int k_tr_bounds(Ctx *c, const double *xk, const double *lb, const double *ub, double tr, int64_t n,
+                double *lk, double *uk);
+int k_kkt_error(Ctx *c, const double *xk, const double *lb, const double *ub, const double *t,
+                double relax, int64_t n, double out[2]);
+
+// c(s) = c0 + g0^T s + 1/2 s^T H M H^T s   (ParOptCompactEigenApprox, .cpp:23-120); M, Minv row-major
+class CompactEigenApprox {
+ public:
+  CompactEigenApprox(Ctx *ctx, int64_t n, int N);
+  ~CompactEigenApprox();
+  int allocate();
+  std::vector<const double *> hPointers() const;
+  Ctx *ctx;
+  int64_t n;
+  int N;
+  double c0;
+  Vec *g0;
+  std::vector<double> M, Minv;
+  std::vector<Vec *> hvecs;
+  std::vector<po_vec> hhandles;
+};
+
+// B = B_qn - z0 * H M H^T as one compact matrix over [Z_qn | H]  (ParOptEigenQuasiNewton :122-291)
+class EigenQuasiNewton : public CompactQuasiNewton {
+ public:
+  EigenQuasiNewton(CompactQuasiNewton *qn, CompactEigenApprox *eigh, int index);
+  void reset() override;
+  int update(Vec *s, Vec *y, int *rc) override;
+  int updateMult(Vec *x, const double *z, Vec *zw) override;
+  int mult(Vec *x, Vec *y) override;
+  int multAdd(double alpha, Vec *x, Vec *y) override;
+  int getCompactMat(double *b0_, const double **d0_, const double **M_, Vec ***Z_) override;
+  int getMaxLimitedMemorySize() override;
+  void applyCompactInverse(double *rz) const override;
+  int size() const override;
+  double diag() const override;
+  std::vector<const double *> zPointers() const override;
+
+  CompactQuasiNewton *qn;  // borrowed, may be null
+  CompactEigenApprox *eigh;
+  int index;
+  double z0;
+  int use_qn_objective;
+
+ private:
+  int qnSize() const { return (qn && use_qn_objective) ? qn->size() : 0; }
+  std::vector<double> dall, Mall;
+  std::vector<Vec *> Zall;
+};
+
+class TrustRegionSubproblem : public Problem {
+ public:
+  TrustRegionSubproblem(Problem *p);
+  virtual ~TrustRegionSubproblem();
+  int allocate();
+  virtual CompactQuasiNewton *getQuasiNewton() = 0;
+  virtual int initModelAndBounds(double tr_size);
+  int setTrustRegionBounds(double tr_size);
+  virtual int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
+                                     double *cons) = 0;
+  virtual int acceptTrialStep(Vec *step, const double *z, Vec *zw) = 0;
+  void rejectTrialStep();
+  int getQuasiNewtonUpdateType() const { return qn_update_type; }
+  // linear model values at a step: f = fk + gk.s, cons = ck + Ak s (one panel-dot pass)
+  int evalLinearModel(Vec *step, double *f, double *cons);
+
+  // ParOptProblem side, seen by the interior-point solver
+  int getVarsAndBounds(Vec *x, Vec *l, Vec *u) override;
+  int evalSparseCon(Vec *step, Vec *out) override;
+  int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
+  int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
+  int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
+  int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
+                          Vec *work) override;
+  int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
+
+  Problem *prob;
+  int m;
+  Vec *xk, *lk, *uk, *lb, *ub, *gk, *gt, *t, *xtemp;
+  std::vector<Vec *> Ak, At;
+  double fk, ft;
+  std::vector<double> ck, ct;
+
+ protected:
+  int evalTrialPoint(Vec *step, double *fobj, double *cons);
+  int lagrangianGradientDifference(const double *z, Vec *zw);  // into t (:187-205)
+  void acceptModel();
+  int qn_update_type;
+};
+
+class QuadraticSubproblem : public TrustRegionSubproblem {  // :27-466
+ public:
+  QuadraticSubproblem(Problem *p, CompactQuasiNewton *qn_) : TrustRegionSubproblem(p), qn(qn_) {}
+  CompactQuasiNewton *getQuasiNewton() override { return qn; }
+  int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
+                             double *cons) override;
+  int acceptTrialStep(Vec *step, const double *z, Vec *zw) override;
+  int evalObjCon(Vec *step, double *fobj, double *cons) override;
+  int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  CompactQuasiNewton *qn;
+};
+
+typedef int (*EigenModelUpdate)(void *user, Vec *x, CompactEigenApprox *approx);
+
+class EigenSubproblem : public TrustRegionSubproblem {  // ParOptCompactEigenvalueApprox.cpp:295-724
+ public:
+  EigenSubproblem(Problem *p, EigenQuasiNewton *approx_)
+      : TrustRegionSubproblem(p), approx(approx_), update_model(nullptr), update_user(nullptr) {}
+  CompactQuasiNewton *getQuasiNewton() override { return approx; }
+  int initModelAndBounds(double tr_size) override;
+  int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
+                             double *cons) override;
+  int acceptTrialStep(Vec *step, const double *z, Vec *zw) override;
+  int evalObjCon(Vec *step, double *fobj, double *cons) override;
+  int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  EigenQuasiNewton *approx;
+  EigenModelUpdate update_model;
+  void *update_user;
+
+ private:
+  int modelDots(Vec *step, std::vector<double> &dots, int *kq);
+};
+
+class InfeasSubproblem : public Problem {  // :468-650
+ public:
+  enum { CONSTANT_OBJECTIVE = 0, LINEAR_OBJECTIVE = 1, SUBPROBLEM_OBJECTIVE = 2 };
+  enum { LINEAR_CONSTRAINT = 0, SUBPROBLEM_CONSTRAINT = 1 };
+  InfeasSubproblem(TrustRegionSubproblem *sub_, int objective_, int constraint_);
+  int getVarsAndBounds(Vec *x, Vec *l, Vec *u) override { return sub->getVarsAndBounds(x, l, u); }
+  int evalObjCon(Vec *step, double *fobj, double *cons) override;
+  int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  int evalSparseCon(Vec *step, Vec *out) override { return sub->evalSparseCon(step, out); }
+  int addSparseJacobian(double a, Vec *x, Vec *px, Vec *out) override {
+    return sub->addSparseJacobian(a, x, px, out);
+  }
+  int addSparseJacobianTranspose(double a, Vec *x, Vec *pzw, Vec *out) override {
+    return sub->addSparseJacobianTranspose(a, x, pzw, out);
+  }
+  int addSparseInnerProduct(double a, Vec *x, Vec *cvec, Vec *A) override {
+    return sub->addSparseInnerProduct(a, x, cvec, A);
+  }
+  int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
+                          Vec *work) override {
+    return sub->sparseJacobianPanel(x, d, P, nv, U, work);
+  }
+  TrustRegionSubproblem *sub;
+  int objective, constraint;
+  double obj_scale;
+};
+
+typedef int (*TrIterationFn)(void *user, int iter);
+
+class TrustRegion {
+ public:
+  explicit TrustRegion(Problem *prob);
+  ~TrustRegion();
+  Options &options() { return ip ? ip->options : opts; }
+  // compact eigenvalue model for constraint `index` with N curvature directions (before optimize)
+  int setEigenModel(int N, int index, EigenModelUpdate update, void *user);
+  int optimize();
+  int build();  // quasi-Newton, subproblem, interior point from the current options (idempotent)
+
+  Problem *prob;
+  Ctx *ctx;
+  Options opts;  // registry until the interior-point object exists, then ip->options is the one
+  CompactQuasiNewton *qn;
+  CompactEigenApprox *eigh;
+  EigenQuasiNewton *eqn;
+  TrustRegionSubproblem *sub;
+  InfeasSubproblem *infeas;
+  InteriorPoint *ip;
+  po_qn_s qn_handle;
+
+  int m, nineq;
+  std::vector<double> penalty_gamma;
+  double tr_size;
+  int iter_count, subproblem_iters, adaptive_subproblem_iters;
+  std::string history;
+  TrIterationFn iter_cb;
+  void *iter_cb_user;
+  // last iteration's table row (for observers): fobj, infeas, l1, linfty, smax, tr, rho, model_reduc,
+  // zav, zmax, gav, gmax
+  double row[12];
+  std::string row_info;
+
+ private:
+  int eig_N, eig_index;
+  EigenModelUpdate eig_update;
+  void *eig_user;
+  Vec *tvec;
+  double infeasOf(const double *c, const double *weights) const;
+  int computeKKTError(const double *z, Vec *zw, double *l1, double *linfty);
+  int minimizeInfeas(std::vector<double> &best_con_infeas);
+  int sl1qpUpdate(Vec *step, const double *z, Vec *zw, double *infeas, double *l1, double *linfty);
+  void flushHistory();
+};
+
+}  // namespace po
+
+struct po_tr_s {
+  po::TrustRegion *tr;
+};
+struct po_eig_s {
+  po::CompactEigenApprox *e;
+};

@@ -24,6 +24,8 @@ po_vec = C.c_void_p
 po_qn = C.c_void_p
 po_problem = C.c_void_p
 po_ip = C.c_void_p
+po_tr = C.c_void_p
+po_eig = C.c_void_p
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 c_i64_p = C.POINTER(C.c_int64)
@@ -36,6 +38,8 @@ EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p)
 GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p)
 QNCORR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec)
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, po_vec)
+EIG_UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_eig)
+TR_ITER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 SPARSE_CON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec)
 SPARSE_JAC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, po_vec, po_vec, po_vec)
 
@@ -156,6 +160,29 @@ SIGNATURES = {
         [po_ip, C.c_double, C.POINTER(po_vec), C.POINTER(po_vec), C.POINTER(po_vec)]
         + [C.POINTER(c_double_p)] * 5,
     ),
+    "po_tr_create": (C.c_int, [po_problem, C.POINTER(po_tr)]),
+    "po_tr_destroy": (C.c_int, [po_tr]),
+    "po_tr_set_option_str": (C.c_int, [po_tr, C.c_char_p, C.c_char_p]),
+    "po_tr_set_option_int": (C.c_int, [po_tr, C.c_char_p, C.c_int]),
+    "po_tr_set_option_float": (C.c_int, [po_tr, C.c_char_p, C.c_double]),
+    "po_tr_set_eigen_model": (C.c_int, [po_tr, C.c_int, C.c_int, EIG_UPDATE_FN, C.c_void_p]),
+    "po_tr_set_eigen_model_synthetic": (C.c_int, [po_tr, C.c_int, C.c_int, C.c_uint64, C.c_double]),
+    "po_eig_get_approximation": (
+        C.c_int,
+        [po_eig, C.POINTER(c_double_p), C.POINTER(po_vec), c_int_p, C.POINTER(c_double_p),
+         C.POINTER(c_double_p), C.POINTER(vec_p)],
+    ),
+    "po_tr_optimize": (C.c_int, [po_tr]),
+    "po_tr_get_optimized_point": (C.c_int, [po_tr, C.POINTER(po_vec), C.POINTER(c_double_p), C.POINTER(po_vec)]),
+    "po_tr_get_state": (
+        C.c_int,
+        [po_tr, c_double_p, c_int_p, c_int_p, c_int_p, C.POINTER(c_double_p), c_double_p, C.POINTER(c_double_p)],
+    ),
+    "po_tr_get_last_row": (C.c_int, [po_tr, C.POINTER(c_double_p), C.POINTER(C.c_char_p)]),
+    "po_tr_get_history": (C.c_int, [po_tr, C.POINTER(C.c_char_p)]),
+    "po_tr_get_quasi_newton": (C.c_int, [po_tr, C.POINTER(po_qn)]),
+    "po_tr_get_model_vectors": (C.c_int, [po_tr, C.POINTER(po_vec), C.POINTER(po_vec)]),
+    "po_tr_set_iteration_callback": (C.c_int, [po_tr, TR_ITER_FN, C.c_void_p]),
     "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),

@@ -1,0 +1,110 @@
+"""
+GPU parity of the trust-region layer (through the C ABI): ParOptTrustRegion's SL1QP iteration over
+the quadratic and the compact-eigenvalue subproblems against trajectories of the compiled
+reference (tests/golden/tr_*.npz) -- the iteration table to its print precision, accept / reject and
+quasi-Newton flags exactly, the interior-point iteration counts of the two subproblem solves per
+iteration (exact in >= 80 % of the rows: the degenerate steering LP terminates on round-off level
+tests), radius, penalty parameters, model values and the iterate.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from tr_helpers import compare_tr, eig_model, tr_options_from_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paropt_amd as pa
+
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+def run_gpu_tr(ctx, case, python_eig_callback=False):
+    import paropt_amd as pa
+
+    a = case["args"]
+    prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), a.get("seed", 0),
+                               a.get("eig_min", 1.0), a.get("eig_max", 100.0))
+    if a.get("nwcon", 0) > 0:
+        prob.setWeighting(a["nwcon"], a["nw"], a.get("nwstart", 0), a.get("nwskip", 0),
+                          a.get("nwineq", a["nwcon"]))
+    opts, tropts = tr_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    tr = pa.TrustRegion(prob, dict(opts, **tropts))
+    if a.get("eig_N", 0) > 0:
+        N = a["eig_N"]
+        if python_eig_callback:
+            H, M, Minv = eig_model(a.get("seed", 0), N, a.get("eig_curv", 1.0), prob.nvars, prob.offset)
+
+            def upd(x, e):
+                for i in range(N):
+                    e.hvecs[i].from_numpy(H[i])
+                    e.hvecs[i].scale(1.0 / e.hvecs[i].norm())
+                e.M[:, :] = M
+                e.Minv[:, :] = Minv
+
+            tr.setEigenModel(N, a.get("eig_index", 0), upd)
+        else:
+            tr.setEigenModelSynthetic(N, a.get("eig_index", 0), a.get("seed", 0), a.get("eig_curv", 1.0))
+    snaps, rows = [], []
+
+    def cb(i):
+        if i > 0:
+            rows.append(tr.getLastRow())
+        s = tr.snapshot()
+        s["x"] = tr.getModelVectors()[0].to_numpy()
+        snaps.append(s)
+
+    tr.setIterationCallback(cb)
+    tr.optimize()
+    rows.append(tr.getLastRow())
+    st = tr.getState()
+    x, z, zw = tr.getOptimizedPoint()
+    final = dict(iter_count=st["iter_count"], fk=st["fk"], ck=st["ck"], x=x.to_numpy(), z=z)
+    return tr, rows, snaps, final
+
+
+TR_CASES = golden_names("tr_")
+
+
+@pytest.mark.parametrize("name", TR_CASES)
+def test_tr_trajectory_golden(ctx, name):
+    g, case = load_golden(name)
+    tr, rows, snaps, final = run_gpu_tr(ctx, case)
+    window = 40 if "sr1" in name else 60
+    n = compare_tr(g, rows, snaps, final, window)
+    assert n >= 20
+    if "sr1" not in name:
+        assert final["iter_count"] == int(g["final/iter_count"][0])
+        assert abs(final["fk"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+        np.testing.assert_allclose(final["x"], g["final/x"], rtol=0, atol=1e-5 * max(1.0, np.abs(g["final/x"]).max()))
+    # the table accumulated by the driver has the reference's layout
+    from tr_helpers import parse_tr_table
+
+    mine = parse_tr_table(tr.getHistory())
+    assert len(mine) == final["iter_count"]
+
+
+def test_tr_eigen_model_python_callback(ctx):
+    """The model-update callback boundary (setEigenModelUpdate): the same synthetic model supplied
+    from Python through po_eig_get_approximation instead of the built-in one."""
+    g, case = load_golden("tr_eig_quadratic_n200_c2_N4")
+    case["args"]["tr.tr_max_iterations"] = 12
+    tr, rows, snaps, final = run_gpu_tr(ctx, case, python_eig_callback=True)
+    compare_tr(g, rows, snaps, final, 12)
+
+
+def test_tr_option_errors(ctx):
+    import paropt_amd as pa
+
+    prob = pa.SeparableProblem(ctx, "quadratic", 100, 2)
+    tr = pa.TrustRegion(prob, {"tr_accept_step_strategy": "filter_method", "tr_max_iterations": 2})
+    with pytest.raises(pa.ParOptAMDError):
+        tr.optimize()
+    with pytest.raises(pa.ParOptAMDError):
+        pa.TrustRegion(prob, {"tr_no_such_option": 1})
