@@ -122,7 +122,10 @@ def compare_tr(g, rows, snaps, final, window, frac_exact=0.8):
         np.testing.assert_allclose(s["ck"], g[p + "ck"], rtol=1e-6,
                                    atol=1e-6 * max(1.0, np.abs(g[p + "ck"]).max()), err_msg="ck @%d" % k)
         assert int(s["iters"][0]) == int(g[p + "iters"][0])
-        np.testing.assert_allclose(s["norms"], g[p + "norms"], rtol=1e-6, err_msg="norms @%d" % k)
+        # |xk| tightly; |gk| looser: the convex objective's gradient -b^2/(eps+x)^2 amplifies 1e-7
+        # differences in x by 1e3 near the lower bound
+        np.testing.assert_allclose(s["norms"][0], g[p + "norms"][0], rtol=1e-6, err_msg="|xk| @%d" % k)
+        np.testing.assert_allclose(s["norms"][1], g[p + "norms"][1], rtol=2e-4, err_msg="|gk| @%d" % k)
         assert s["qn_size"] == int(g[p + "qn_size"][0]), "qn size @%d" % k
         if p + "x" in g and "x" in s:
             np.testing.assert_allclose(s["x"], g[p + "x"], rtol=0, atol=1e-6 * max(1.0, np.abs(g[p + "x"]).max()),
