@@ -1,0 +1,88 @@
+"""
+Config 5 of BASELINE.json: the compact-eigenvalue subproblem under the trust-region driver
+(n = 5M, N = 10 curvature directions, trust-region defaults) on one MI355X, next to the unmodified
+reference (oracle/_ref/ref_driver trbench) on the host cores.  Prints one JSON line.
+
+    python tools/bench_tr.py [--nglobal 5000000] [--ncon 4] [--eig-N 10] [--tr-iters 10]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cpu_reference(a):
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not (os.path.exists(drv) and os.path.exists(mpiexec)):
+        return None
+    ncpu = os.cpu_count() or 1
+    ranks = max(1, min(64, ncpu // 2 if ncpu >= 4 else ncpu))
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
+    cmd = [mpiexec, "-n", str(ranks), drv, "trbench", "problem=%s" % a.problem, "n=%d" % a.n, "c=%d" % a.ncon,
+           "eig_N=%d" % a.eig_N, "eig_index=0", "eig_curv=%g" % a.curv, "opt.qn_subspace_size=%d" % a.qn_size,
+           "tr.tr_max_iterations=%d" % a.cpu_tr_iters]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd="/tmp")
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            r = json.loads(ln)
+            return {"value": r["tr_iters"] / r["seconds"], "unit": "TR iterations/s", "cores": ranks,
+                    "kind": "reference", "sample": "%d trust-region iterations, wall incl. launch %.1fs" % (
+                        r["tr_iters"], time.time() - t0)}
+    sys.stderr.write(out.stderr[-400:])
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nglobal", dest="n", type=int, default=5_000_000)
+    ap.add_argument("--ncon", type=int, default=4)
+    ap.add_argument("--problem", default="quadratic")
+    ap.add_argument("--eig-N", dest="eig_N", type=int, default=10)
+    ap.add_argument("--curv", type=float, default=2.0)
+    ap.add_argument("--qn-size", type=int, default=10)
+    ap.add_argument("--tr-iters", type=int, default=10)
+    ap.add_argument("--cpu-tr-iters", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
+    tr = pa.TrustRegion(prob, {"qn_subspace_size": a.qn_size, "tr_max_iterations": a.tr_iters})
+    tr.setEigenModelSynthetic(a.eig_N, 0, 0, a.curv)
+    counts = []
+
+    def cb(i):
+        if i > 0:
+            s = tr.getState()
+            counts.append((s["subproblem_iters"], s["adaptive_subproblem_iters"]))
+
+    tr.setIterationCallback(cb)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    tr.optimize()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    s = tr.getState()
+    counts.append((s["subproblem_iters"], s["adaptive_subproblem_iters"]))
+    ip_iters = sum(x + y for x, y in counts)
+    res = {"metric": "trust-region iterations/s (compact eigenvalue subproblem, SL1QP + adaptive penalty)",
+           "value": s["iter_count"] / dt, "unit": "TR iterations/s", "n_gpus": 1, "tr_iterations": s["iter_count"],
+           "seconds": dt, "inner_ip_iterations": ip_iters, "inner_ip_iterations_per_s": ip_iters / dt,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "config 5: ParOptEigenSubproblem under ParOptTrustRegion, separable random_%s "
+                                  "n=%d, m=%d, N=%d curvature directions, L-BFGS(%d), trust-region defaults" % (
+                                      a.problem, a.n, a.ncon, a.eig_N, a.qn_size)},
+           "cpu_baseline": None if a.no_cpu_baseline else cpu_reference(a)}
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
