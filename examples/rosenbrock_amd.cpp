@@ -99,10 +99,11 @@ class Rosenbrock : public ParOptProblem {
 };
 
 int main(int argc, char *argv[]) {
-  int nvars = 100, nwcon = 0;
+  int nvars = 100, nwcon = 0, use_tr = 0;
   for (int k = 1; k < argc; k++) {
     sscanf(argv[k], "nvars=%d", &nvars);
     sscanf(argv[k], "nwcon=%d", &nwcon);
+    if (strcmp(argv[k], "algorithm=tr") == 0) use_tr = 1;
   }
   po_ctx ctx = NULL;
   if (po_ctx_create(0, &ctx) != 0) {
@@ -118,6 +119,31 @@ int main(int argc, char *argv[]) {
   options->setOption("abs_res_tol", 1e-6);
   options->setOption("barrier_strategy", "monotone");
   options->setOption("max_major_iters", 150);
+  if (use_tr) {
+    // the reference's generic entry point (src/ParOptOptimizer.cpp:108-183): trust region over the
+    // quadratic subproblem with the interior-point method as sub-solver
+    options->setOption("algorithm", "tr");
+    options->setOption("tr_max_iterations", 80);
+    options->setOption("tr_output_file", "");
+    ParOptOptimizer *optimizer = new ParOptOptimizer(rosen, options);
+    optimizer->incref();
+    optimizer->optimize();
+    ParOptVec *xt;
+    ParOptScalar *zt;
+    optimizer->getOptimizedPoint(&xt, &zt, NULL, NULL, NULL);
+    ParOptScalar ft, ct[2];
+    xt->syncToHost();
+    rosen->evalObjCon(xt, &ft, ct);
+    int ntr = 0;
+    for (const char *h = optimizer->getTrustRegionHistory(); *h; h++) ntr += (*h == '\n');
+    printf("{\"algorithm\": \"tr\", \"fobj\": %.15e, \"xnorm\": %.15e, \"z0\": %.15e, \"z1\": %.15e, "
+           "\"table_lines\": %d}\n", ft, xt->norm(), zt[0], zt[1], ntr);
+    optimizer->decref();
+    options->decref();
+    rosen->decref();
+    po_ctx_destroy(ctx);
+    return 0;
+  }
   ParOptInteriorPoint *opt = new ParOptInteriorPoint(rosen, options);
   opt->incref();
   int rc = opt->optimize();

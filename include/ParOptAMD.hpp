@@ -98,6 +98,20 @@ class ParOptOptions : public ParOptBase {
     for (auto &kv : f) bad |= po_ip_set_option_float(ip, kv.first.c_str(), kv.second);
     return bad;
   }
+  // the same, into a trust-region driver (one registry for both option sets); `algorithm` is
+  // ParOptOptimizer's own switch and is not forwarded
+  int apply(po_tr tr) {
+    int bad = 0;
+    for (auto &kv : s)
+      if (kv.first != "algorithm") bad |= po_tr_set_option_str(tr, kv.first.c_str(), kv.second.c_str());
+    for (auto &kv : i) bad |= po_tr_set_option_int(tr, kv.first.c_str(), kv.second);
+    for (auto &kv : f) bad |= po_tr_set_option_float(tr, kv.first.c_str(), kv.second);
+    return bad;
+  }
+  const char *getStringOption(const char *name, const char *def) {
+    std::map<std::string, std::string>::iterator it = s.find(name);
+    return it == s.end() ? def : it->second.c_str();
+  }
 
  private:
   std::map<std::string, std::string> s;
@@ -413,6 +427,76 @@ class ParOptInteriorPoint : public ParOptBase {
   ParOptOptions *options;
   po_ip ip;
   ParOptVec *x, *zl, *zu, *zw, *sw, *tw;
+};
+
+// ---- ParOptOptimizer: algorithm = "ip" | "tr" (src/ParOptOptimizer.cpp:65-206) ----------------------
+// The reference's generic entry point.  "tr" builds the quasi-Newton object, the quadratic
+// subproblem, the interior-point sub-solver and the trust-region driver exactly as :108-183 does.
+class ParOptOptimizer : public ParOptBase {
+ public:
+  ParOptOptimizer(ParOptProblem *_prob, ParOptOptions *_options)
+      : prob(_prob), options(_options), ip(NULL), tr(NULL), x(NULL) {
+    prob->incref();
+    options->incref();
+  }
+  ~ParOptOptimizer() {
+    if (x) x->decref();
+    if (ip) ip->decref();
+    if (tr) po_tr_destroy(tr);
+    options->decref();
+    prob->decref();
+  }
+  void optimize() {
+    const std::string algorithm = options->getStringOption("algorithm", "tr");
+    if (algorithm == "ip") {
+      if (!ip) {
+        ParOptOptions *o = options;
+        ip = new ParOptInteriorPoint(prob, o);
+        ip->incref();
+      }
+      ip->optimize();
+    } else if (algorithm == "tr") {
+      if (!tr) {
+        if (po_tr_create(prob->handle(), &tr) != 0 || options->apply(tr) != 0) {
+          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+          return;
+        }
+      }
+      if (po_tr_optimize(tr) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    } else {
+      fprintf(stderr, "ParOptOptimizer Error: Unrecognized algorithm option %s\n", algorithm.c_str());
+    }
+  }
+  void getOptimizedPoint(ParOptVec **_x, ParOptScalar **_z, ParOptVec **_zw, ParOptVec **_zl,
+                         ParOptVec **_zu) {
+    if (tr) {
+      po_vec hx = NULL;
+      const double *z = NULL;
+      po_tr_get_optimized_point(tr, &hx, &z, NULL);
+      if (x) x->decref();
+      x = new ParOptVec(hx);
+      x->incref();
+      if (_x) *_x = x;
+      if (_z) *_z = const_cast<double *>(z);
+      if (_zw) *_zw = NULL;
+      if (_zl) *_zl = NULL;
+      if (_zu) *_zu = NULL;
+    } else if (ip) {
+      ip->getOptimizedPoint(_x, _z, _zw, _zl, _zu);
+    }
+  }
+  const char *getTrustRegionHistory() {
+    const char *t = "";
+    if (tr) po_tr_get_history(tr, &t);
+    return t;
+  }
+
+ private:
+  ParOptProblem *prob;
+  ParOptOptions *options;
+  ParOptInteriorPoint *ip;
+  po_tr tr;
+  ParOptVec *x;
 };
 
 #endif  // PAROPT_AMD_HPP

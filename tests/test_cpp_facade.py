@@ -63,3 +63,18 @@ def test_cpp_rosenbrock_sparse_constraints_match_reference(tmp_path):
     assert abs(out["fobj"] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
     np.testing.assert_allclose(out["xnorm"], g["final/norms"][0], rtol=1e-7)
     np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_cpp_optimizer_trust_region(tmp_path):
+    """ParOptOptimizer with algorithm = "tr" through the facade: the reference's trust-region
+    trajectory on the same problem ends at the same point (golden tr_rosenbrock_n60_bfgs)."""
+    exe = build(tmp_path)
+    res = subprocess.run([exe, "nvars=60", "algorithm=tr"], capture_output=True, text=True, timeout=600,
+                         cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    g, _ = load_golden("tr_rosenbrock_n60_bfgs")
+    assert abs(out["fobj"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+    np.testing.assert_allclose(out["xnorm"], g["final/xnorm"][0], rtol=1e-6)
+    np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-4, atol=1e-6)
