@@ -165,6 +165,66 @@ def test_two_ranks_weighting_constraints_match_single_rank():
     np.testing.assert_allclose(zw2, zw1, rtol=0, atol=1e-6 * max(1.0, np.abs(zw1).max()))
 
 
+def _worker_tr(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    prob = pa.SeparableProblem(ctx, "quadratic", 6001, 3)
+    tr = pa.TrustRegion(prob, TR_OPTS)
+    tr.setEigenModelSynthetic(4, 0, 0, 2.0)
+    rows = []
+    tr.setIterationCallback(lambda i: rows.append(tr.getLastRow()) if i > 0 else None)
+    tr.optimize()
+    rows.append(tr.getLastRow())
+    x = tr.getOptimizedPoint()[0].to_numpy()
+    xs = [None] * world
+    dist.all_gather_object(xs, (prob.offset, x))
+    if rank == 0:
+        q.put((rows, np.concatenate([a for _, a in sorted(xs, key=lambda t: t[0])])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+TR_OPTS = {"qn_subspace_size": 5, "tr_max_iterations": 8}
+
+
+def test_two_ranks_trust_region_eigen_model_match_single_rank():
+    """The trust-region driver with the compact eigenvalue model on a sharded design vector: the
+    model directions are generated from global indices, every model evaluation is a sharded mdot."""
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    prob = pa.SeparableProblem(ctx, "quadratic", 6001, 3)
+    tr = pa.TrustRegion(prob, TR_OPTS)
+    tr.setEigenModelSynthetic(4, 0, 0, 2.0)
+    rows1 = []
+    tr.setIterationCallback(lambda i: rows1.append(tr.getLastRow()) if i > 0 else None)
+    tr.optimize()
+    rows1.append(tr.getLastRow())
+    x1 = tr.getOptimizedPoint()[0].to_numpy()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_tr, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rows2, x2 = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(rows2) == len(rows1) == 8
+    for (v2, t2), (v1, t1) in zip(rows2, rows1):
+        assert t2 == t1  # iteration counts of both subproblem solves, accept/reject flags
+        np.testing.assert_allclose(v2, v1, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(x2, x1, rtol=0, atol=1e-7)
+
+
 def test_rccl_plumbing_single_rank(monkeypatch):
     """ncclGetUniqueId / ncclCommInitRank / ncclAllGather through the dlopen'ed librccl with a
     1-rank communicator on the only GPU of the test box: same results as the self communicator."""
