@@ -343,6 +343,12 @@ case("tr_quadratic_n150_c2_fixedgamma", "tr", problem="quadratic", n=150, c=2, d
      **dict(tr_common, **{"tr.tr_adaptive_gamma_update": 0, "opt.penalty_gamma": 50.0}))
 case("tr_convex_n200_c2_w40", "tr", problem="convex", n=200, c=2, nwcon=40, nw=5, nwstart=0, nwskip=0,
      dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05}))
+# filter globalisation (filterOptimize :1690-2210)
+case("tr_filter_quadratic_n200_c3", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10,
+     **dict(tr_common, **{"tr.tr_accept_step_strategy": "filter_method"}))
+case("tr_filter_rosenbrock_n60", "tr", problem="rosenbrock", n=60, dump_vecs_every=10,
+     **dict(tr_common, **{"tr.tr_accept_step_strategy": "filter_method", "opt.qn_subspace_size": 10,
+                          "tr.filter_has_feas_restore_phase": 0}))
 # compact eigenvalue subproblem (config 5 shape): constraint 0 modelled with N curvature directions
 case("tr_eig_quadratic_n200_c2_N4", "tr", problem="quadratic", n=200, c=2, eig_N=4, eig_index=0, eig_curv=2.0,
      dump_vecs_every=10, **tr_common)

@@ -11,7 +11,8 @@ subproblems, in the reference's operation order:
 
 Pinned against tests/golden/tr_*.npz (trajectories of the compiled reference, oracle/ref_driver.cpp
 mode "tr").  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
-The filter globalisation (filter_method) and the second-order correction are not restated.
+The filter globalisation (filterOptimize :1690-2210) is restated including its quirks; the
+second-order correction is dead code in the reference (its only call site is commented out).
 """
 import math
 
@@ -33,6 +34,10 @@ TR_DEFAULTS = dict(  # ParOptTrustRegion::addDefaultOptions :739-847
     tr_infeas_tol=1e-5,
     tr_penalty_gamma_max=1e4,
     tr_penalty_gamma_min=0.0,
+    filter_sufficient_reduction=1,
+    filter_gamma=1e-5,
+    filter_has_feas_restore_phase=1,
+    tr_use_soc=0,
     tr_adaptive_objective="linear_objective",
     tr_adaptive_constraint="linear_constraint",
     tr_steering_barrier_strategy="mehrotra_predictor_corrector",
@@ -433,7 +438,27 @@ class TrustRegion:
         zmax = max(1.0, zmax)
         return l1 / max(self.ops.l1norm(s.gk), zmax), linf / max(self.ops.maxabs(s.gk), zmax)
 
-    def minimize_infeas(self, infeas_problem):  # :1105-1228
+    # ---- filter :896-966 ---------------------------------------------------------------------
+    def acceptable_by_pair(self, f_new, h_new, f_old, h_old):
+        gamma = self.opt["filter_gamma"]
+        if self.opt["filter_sufficient_reduction"]:
+            _h_old = (1.0 - gamma) * h_old
+            _f_old = f_old - gamma * h_new
+        else:
+            _h_old, _f_old = h_old, f_old
+        return 1 if (h_new < _h_old or f_new < _f_old) else 0
+
+    def acceptable_by_filter(self, f, h):
+        for fe, he in self.filter:
+            if not self.acceptable_by_pair(f, h, fe, he):
+                return 0
+        return 1
+
+    def add_to_filter(self, f, h):
+        self.filter = [(fe, he) for fe, he in self.filter if not (f <= fe and h <= he)]
+        self.filter.append((f, h))
+
+    def minimize_infeas(self, infeas_problem, want_best=True):  # :1105-1228
         o = self.opt
         ip = self.ip
         ipo = ip.opt
@@ -459,9 +484,12 @@ class TrustRegion:
         ip.reset_design_and_bounds()
         ip.optimize()
         step = ip.vars.x.copy()
-        self.adaptive_subproblem_iters = ip.niter
-        _, _, best = self.sub.eval_obj_con(step)
-        best = np.array([max(0.0, -best[j]) if j < self.nineq else abs(best[j]) for j in range(self.m)])
+        if o["tr_accept_step_strategy"] == "penalty_method" and o["tr_adaptive_gamma_update"]:
+            self.adaptive_subproblem_iters = ip.niter
+        best = None
+        if want_best:
+            _, _, best = self.sub.eval_obj_con(step)
+            best = np.array([max(0.0, -best[j]) if j < self.nineq else abs(best[j]) for j in range(self.m)])
         ip.set_penalty_gamma(self.penalty_gamma)
         ip.reset_problem_instance(self.sub)
         if eig_qn is not None:
@@ -523,11 +551,132 @@ class TrustRegion:
         self.iter_count += 1
         return infeas, l1, linfty
 
-    def optimize(self):  # sl1qpOptimize :1453-1687
+    def filter_optimize(self):  # :1690-2210
         o = self.opt
         ip = self.ip
-        if o["tr_accept_step_strategy"] != "penalty_method":
-            raise NotImplementedError("filter_method is not restated")
+        s = self.sub
+        qn = s.get_quasi_newton()
+        ip.set_quasi_newton(qn)
+        ip.opt["use_quasi_newton_update"] = 0
+        ip.set_penalty_gamma(self.penalty_gamma)
+        infeas_problem = InfeasSubproblem(s, "linear_objective", "linear_constraint")
+        s.init_model_and_bounds(self.tr_size)
+        self.iter_count = 0
+        _, f_init, c_init = s.eval_obj_con(None)
+        infeas_init = self._infeas(c_init)
+        self.filter = []
+        self.add_to_filter(-1e20, max(1e4, 1.25 * infeas_init))
+        this_resto = last_resto = 0
+        tol = o["tr_infeas_tol"]
+        for iteration in range(o["tr_max_iterations"]):
+            _, fk, ck = s.eval_obj_con(None)
+            hk = self._infeas(ck)
+            ip.reset_problem_instance(s)
+            ip.opt["sequential_linear_method"] = 0
+            ip.reset_design_and_bounds()
+            ip.optimize()
+            step = ip.vars.x.copy()
+            z = ip.vars.z.copy()
+            zw = ip.vars.zw.copy()
+            if o["filter_has_feas_restore_phase"]:
+                _, _, cm = s.eval_obj_con(step)
+                infeas = 0.0
+                for i in range(self.m):  # only the LAST constraint survives this loop (:1826-1832)
+                    infeas = max(0.0, abs(-cm[i])) if i < self.nineq else abs(cm[i])
+                if infeas > tol:
+                    this_resto = 1
+                    self.add_to_filter(fk, hk)
+                else:
+                    this_resto = 0
+                    if last_resto:
+                        qn.reset()
+            if this_resto:
+                if not last_resto:
+                    qn.reset()
+                self.minimize_infeas(infeas_problem, want_best=False)
+                # `step`, `z`, `zw` alias the solver's own storage (:1797-1799), so they now hold the
+                # restoration LP's solution
+                step = ip.vars.x.copy()
+                z = ip.vars.z.copy()
+                zw = ip.vars.zw.copy()
+            _, fobj_model, _ = s.eval_obj_con(step)
+            _, fobj_trial, con_trial = s.eval_trial_step_and_update(1, step, z, zw)
+            infeas_trial = self._infeas(con_trial)
+            smax = self.ops.maxabs(step)
+            init_tr = inc_tr = dec_tr = 0
+            accepted = 0
+            rej = ""
+            model_red = fk - fobj_model
+            actual_red = fk - fobj_trial
+            rho = actual_red / model_red if model_red != 0.0 else float("inf") * (1 if actual_red >= 0 else -1)
+            if this_resto:
+                s.accept_trial_step(step, None, None)
+                accepted = 1
+                if smax >= 0.99 * self.tr_size:
+                    inc_tr = 1
+            else:
+                by_filter = self.acceptable_by_filter(fobj_trial, infeas_trial)
+                by_pair = self.acceptable_by_pair(fobj_trial, infeas_trial, fk, hk)
+                if by_filter and by_pair:
+                    if actual_red < o["tr_eta"] * model_red and model_red > 0.0:
+                        s.reject_trial_step()
+                        smax = 0.0
+                        dec_tr = 1
+                        rej = "rej:rho"
+                    else:
+                        s.accept_trial_step(step, None, None)
+                        accepted = 1
+                        if model_red <= 0.0:
+                            self.add_to_filter(fobj_trial, infeas_trial)
+                        init_tr = 1
+                elif self.tr_size <= o["tr_min_size"]:
+                    s.accept_trial_step(step, None, None)
+                    accepted = 1
+                    if smax >= 0.99 * self.tr_size:
+                        inc_tr = 1
+                else:
+                    s.reject_trial_step()
+                    smax = 0.0
+                    dec_tr = 1
+                    rej = "rej:" + ("" if by_filter else "F") + ("" if by_pair else "xk")
+            if self.hook is not None:
+                self.hook(self, iteration)
+            l1, linfty = self.compute_kkt_error(z, zw)
+            toks = []
+            if s.qn_update_type == 1:
+                toks.append("dampH")
+            elif s.qn_update_type == 2:
+                toks.append("skipH")
+            toks.append("%d" % ip.niter)
+            toks.append("f%d" % len(self.filter))
+            if this_resto:
+                toks.append("R")
+            if not accepted:
+                toks.append(rej if rej else "rej")
+            self.trace.append(dict(iter=self.iter_count, fobj=fobj_trial, infeas=infeas_trial, l1=l1, linfty=linfty,
+                                   smax=smax, tr=self.tr_size, rho=rho, model_reduc=model_red,
+                                   zav=float(np.mean(np.abs(z))) if self.m else 0.0,
+                                   zmax=float(np.max(np.abs(z))) if self.m else 0.0,
+                                   gav=float(np.mean(self.penalty_gamma)) if self.m else 0.0,
+                                   gmax=float(np.max(self.penalty_gamma)) if self.m else 0.0, info=toks))
+            if inc_tr:
+                self.tr_size = min(2.0 * self.tr_size, o["tr_max_size"])
+            elif dec_tr:
+                self.tr_size = max(0.5 * self.tr_size, o["tr_min_size"])
+            if init_tr:
+                self.tr_size = o["tr_max_size"]
+            s.set_trust_region_bounds(self.tr_size)
+            self.iter_count += 1
+            last_resto = this_resto
+            if infeas_trial < tol and (l1 < o["tr_l1_tol"] or linfty < o["tr_linfty_tol"]):
+                break
+        return 0
+
+    def optimize(self):  # optimize :2365-2384 -> sl1qpOptimize :1453-1687
+        o = self.opt
+        ip = self.ip
+        if o["tr_accept_step_strategy"] == "filter_method":
+            return self.filter_optimize()
         ip.set_quasi_newton(self.sub.get_quasi_newton())
         ip.opt["use_quasi_newton_update"] = 0
         ip.set_penalty_gamma(self.penalty_gamma)

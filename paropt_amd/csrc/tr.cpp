@@ -349,7 +349,7 @@ int EigenSubproblem::acceptTrialStep(Vec *step, const double *z, Vec *zw) {  // 
     if (update_model(update_user, xtemp, e) != 0) return PO_ERR_USER;
   }
   CompactQuasiNewton *q = approx->qn;
-  if (q) {
+  if (q && z) {  // the filter strategy passes no multipliers (:1932): no curvature pair then
     PO_TRY(lagrangianGradientDifference(z, zw));
     if (prob->computeQuasiNewtonUpdateCorrection(xtemp, z, step, t) != 0) return PO_ERR_USER;
     int rc = 0;
@@ -604,7 +604,47 @@ int TrustRegion::computeKKTError(const double *z, Vec *zw, double *l1, double *l
   return PO_OK;
 }
 
-int TrustRegion::minimizeInfeas(std::vector<double> &best) {  // :1105-1228
+int TrustRegion::acceptableByPair(double f_new, double h_new, double f_old, double h_old) {  // :896-922
+  const double gamma = options().real("filter_gamma");
+  double _f_old = f_old, _h_old = h_old;
+  if (options().integer("filter_sufficient_reduction")) {
+    _h_old = (1.0 - gamma) * h_old;
+    _f_old = f_old - gamma * h_new;
+  }
+  return (h_new < _h_old || f_new < _f_old) ? 1 : 0;
+}
+int TrustRegion::acceptableByFilter(double f, double h) {  // :931-939
+  for (const FilterElement &e : filter)
+    if (!acceptableByPair(f, h, e.f, e.h)) return 0;
+  return 1;
+}
+void TrustRegion::addToFilter(double f, double h) {  // :947-966 (dominated pairs leave)
+  std::vector<FilterElement> keep;
+  for (const FilterElement &e : filter)
+    if (!(f <= e.f && h <= e.h)) keep.push_back(e);
+  keep.push_back(FilterElement{f, h});
+  filter.swap(keep);
+}
+
+void TrustRegion::appendRow(const double vals[12], const std::string &info, double seconds) {
+  for (int i = 0; i < 12; i++) row[i] = vals[i];
+  row_info = info;
+  if (ctx->rank != 0) return;
+  char line[512];
+  if (iter_count % 10 == 0) {
+    snprintf(line, sizeof(line), "\n%5s %12s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %-12s\n", "iter",
+             "fobj", "infeas", "l1", "linfty", "|x - xk|", "tr", "rho", "mod red.", "avg z", "max z", "avg pen.",
+             "max pen.", "time(s)", "info");
+    history += line;
+  }
+  snprintf(line, sizeof(line),
+           "%5d %12.5e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %-12s\n", iter_count,
+           vals[0], vals[1], vals[2], vals[3], vals[4], vals[5], vals[6], vals[7], vals[8], vals[9], vals[10],
+           vals[11], seconds, info.c_str());
+  history += line;
+}
+
+int TrustRegion::minimizeInfeas(std::vector<double> *best_out) {  // :1105-1228
   Options &o = ip->options;
   const std::string start_option = o.str("starting_point_strategy");
   const std::string barrier_option = o.str("barrier_strategy");
@@ -629,11 +669,16 @@ int TrustRegion::minimizeInfeas(std::vector<double> &best) {  // :1105-1228
   if (rc != 0 && rc != 1) return rc;
   Vec *step = nullptr;
   ip->getOptimizedPoint(&step, nullptr, nullptr, nullptr);
-  ip->getIterationCounters(&adaptive_subproblem_iters, nullptr, nullptr);
-  double dummy = 0.0;
-  best.assign(m > 0 ? m : 1, 0.0);
-  if (sub->evalObjCon(step, &dummy, best.data()) != 0) return PO_ERR_USER;
-  for (int j = 0; j < m; j++) best[j] = j < nineq ? std::max(0.0, -best[j]) : fabs(best[j]);
+  if (std::string(o.str("tr_accept_step_strategy")) == "penalty_method" && o.integer("tr_adaptive_gamma_update")) {
+    ip->getIterationCounters(&adaptive_subproblem_iters, nullptr, nullptr);
+  }
+  if (best_out) {
+    std::vector<double> &best = *best_out;
+    double dummy = 0.0;
+    best.assign(m > 0 ? m : 1, 0.0);
+    if (sub->evalObjCon(step, &dummy, best.data()) != 0) return PO_ERR_USER;
+    for (int j = 0; j < m; j++) best[j] = j < nineq ? std::max(0.0, -best[j]) : fabs(best[j]);
+  }
   ip->setPenaltyGammaArray(penalty_gamma.data());
   PO_TRY(ip->resetProblemInstance(sub));
   if (eqn) eqn->use_qn_objective = 1;
@@ -702,38 +747,164 @@ int TrustRegion::sl1qpUpdate(Vec *step, const double *z, Vec *zw, double *infeas
   info += buf;
   if (!accepted) info += "rej ";
   const double vals[12] = {fk, *infeas_, *l1, *linfty, smax, tr_size, rho, model_reduc, zav, zmax, gav, gmax};
-  for (int i = 0; i < 12; i++) row[i] = vals[i];
-  row_info = info;
-  if (ctx->rank == 0) {  // table :1406-1438
-    char line[512];
-    if (iter_count % 10 == 0) {
-      snprintf(line, sizeof(line),
-               "\n%5s %12s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %9s %-12s\n", "iter", "fobj", "infeas",
-               "l1", "linfty", "|x - xk|", "tr", "rho", "mod red.", "avg z", "max z", "avg pen.", "max pen.",
-               "time(s)", "info");
-      history += line;
-    }
-    snprintf(line, sizeof(line),
-             "%5d %12.5e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %9.2e %-12s\n",
-             iter_count, fk, *infeas_, *l1, *linfty, smax, tr_size, rho, model_reduc, zav, zmax, gav, gmax,
-             now_seconds() - t0, info.c_str());
-    history += line;
-  }
+  appendRow(vals, info, now_seconds() - t0);
   iter_count++;
   return PO_OK;
 }
 
-int TrustRegion::optimize() {  // sl1qpOptimize :1453-1687
+int TrustRegion::optimize() {  // optimize :2365-2384
   PO_TRY(build());
+  // tr_use_soc has no effect in the reference either: the only call of isAcceptedBySoc is commented
+  // out (:2002-2052), the option merely allocates a scratch vector (:702-706)
+  if (std::string(ip->options.str("tr_accept_step_strategy")) == "filter_method") return filterOptimize();
+  return sl1qpOptimize();
+}
+
+// filterOptimize :1690-2210, quirks included: the compatibility test after the QP looks at the LAST
+// constraint only and uses |c| for inequalities (:1826-1832)
+int TrustRegion::filterOptimize() {
   Options &o = ip->options;
-  if (std::string(o.str("tr_accept_step_strategy")) != "penalty_method") {
-    set_error("tr_accept_step_strategy=filter_method is not implemented on the device path");
-    return PO_ERR_OPTION;
+  const int max_it = o.integer("tr_max_iterations");
+  const double tr_eta = o.real("tr_eta"), tr_min = o.real("tr_min_size"), tr_max = o.real("tr_max_size");
+  const double infeas_tol = o.real("tr_infeas_tol"), l1_tol = o.real("tr_l1_tol"), linf_tol = o.real("tr_linfty_tol");
+  const int wfreq = o.integer("tr_write_output_frequency");
+  CompactQuasiNewton *q = sub->getQuasiNewton();
+  PO_TRY(ip->setQuasiNewton(q));
+  PO_TRY(o.set("use_quasi_newton_update", 0));
+  PO_TRY(o.set("write_output_frequency", 0));
+  ip->setPenaltyGammaArray(penalty_gamma.data());
+  if (!infeas) infeas = new InfeasSubproblem(sub, InfeasSubproblem::LINEAR_OBJECTIVE, InfeasSubproblem::LINEAR_CONSTRAINT);
+  infeas->objective = InfeasSubproblem::LINEAR_OBJECTIVE;
+  infeas->constraint = InfeasSubproblem::LINEAR_CONSTRAINT;
+  history.clear();
+  PO_TRY(sub->initModelAndBounds(tr_size));
+  iter_count = 0;
+  std::vector<double> con_trial(m > 0 ? m : 1), ck(m > 0 ? m : 1), cm(m > 0 ? m : 1);
+  double fobj_init = 0.0;
+  if (sub->evalObjCon(nullptr, &fobj_init, con_trial.data()) != 0) return PO_ERR_USER;
+  const double infeas_init = infeasOf(con_trial.data(), nullptr);
+  filter.clear();
+  addToFilter(-1e20, std::max(1e4, 1.25 * infeas_init));
+  int this_resto = 0, last_resto = 0;
+  for (int iteration = 0; iteration < max_it; iteration++) {
+    const double t0 = now_seconds();
+    double fk = 0.0;
+    if (sub->evalObjCon(nullptr, &fk, ck.data()) != 0) return PO_ERR_USER;
+    const double hk = infeasOf(ck.data(), nullptr);
+    PO_TRY(ip->resetProblemInstance(sub));
+    PO_TRY(o.set("sequential_linear_method", 0));
+    PO_TRY(ip->resetDesignAndBounds());
+    int rc = ip->optimize(nullptr);
+    if (rc != 0 && rc != 1) return rc;
+    // step / z / zw alias the solver's storage, so a restoration solve below replaces them (:1797-1799)
+    Vec *step = nullptr;
+    const double *z = nullptr;
+    ip->getOptimizedPoint(&step, &z, nullptr, nullptr);
+    Vec *wv[5];
+    ip->getOptimizedSparse(wv);
+    Vec *zw = wv[0];
+    if (o.integer("filter_has_feas_restore_phase")) {
+      double dummy = 0.0, infeas_v = 0.0;
+      if (sub->evalObjCon(step, &dummy, cm.data()) != 0) return PO_ERR_USER;
+      for (int i = 0; i < m; i++) infeas_v = i < nineq ? std::max(0.0, fabs(-cm[i])) : fabs(cm[i]);
+      if (infeas_v > infeas_tol) {
+        this_resto = 1;
+        addToFilter(fk, hk);
+      } else {
+        this_resto = 0;
+        if (last_resto && q) q->reset();
+      }
+    }
+    if (this_resto) {
+      if (!last_resto && q) q->reset();
+      PO_TRY(minimizeInfeas(nullptr));
+    }
+    double fobj_model = 0.0, fobj_trial = 0.0;
+    if (sub->evalObjCon(step, &fobj_model, cm.data()) != 0) return PO_ERR_USER;
+    PO_TRY(sub->evalTrialStepAndUpdate(1, step, z, zw, &fobj_trial, con_trial.data()));
+    const double infeas_trial = infeasOf(con_trial.data(), nullptr);
+    double smax = 0.0;
+    PO_TRY(k_reduce1(ctx, RED_AMAX, step->d, nullptr, prob->nlocal, &smax));
+    int init_tr = 0, inc_tr = 0, dec_tr = 0, accepted = 0;
+    std::string rej;
+    const double model_red = fk - fobj_model, actual_red = fk - fobj_trial;
+    const double rho = actual_red / model_red;
+    if (this_resto) {
+      PO_TRY(sub->acceptTrialStep(step, nullptr, nullptr));
+      accepted = 1;
+      if (smax >= 0.99 * tr_size) inc_tr = 1;
+    } else {
+      const int by_filter = acceptableByFilter(fobj_trial, infeas_trial);
+      const int by_pair = acceptableByPair(fobj_trial, infeas_trial, fk, hk);
+      if (by_filter && by_pair) {
+        if (actual_red < tr_eta * model_red && model_red > 0.0) {
+          sub->rejectTrialStep();
+          smax = 0.0;
+          dec_tr = 1;
+          rej = "rej:rho";
+        } else {
+          PO_TRY(sub->acceptTrialStep(step, nullptr, nullptr));
+          accepted = 1;
+          if (model_red <= 0.0) addToFilter(fobj_trial, infeas_trial);
+          init_tr = 1;
+        }
+      } else if (tr_size <= tr_min) {
+        PO_TRY(sub->acceptTrialStep(step, nullptr, nullptr));
+        accepted = 1;
+        if (smax >= 0.99 * tr_size) inc_tr = 1;
+      } else {
+        sub->rejectTrialStep();
+        smax = 0.0;
+        dec_tr = 1;
+        rej = "rej:";
+        if (!by_filter) rej += "F";
+        if (!by_pair) rej += "xk";
+      }
+    }
+    if (wfreq > 0 && iteration % wfreq == 0) sub->writeOutput(iteration, sub->xk);
+    if (iter_cb) iter_cb(iter_cb_user, iteration);
+    double l1 = 0.0, linfty = 0.0;
+    PO_TRY(computeKKTError(z, zw, &l1, &linfty));
+    double zmax = 0.0, zav = 0.0, gmax = 0.0, gav = 0.0;
+    for (int i = 0; i < m; i++) {
+      zav += fabs(z[i]);
+      gav += penalty_gamma[i];
+      zmax = std::max(zmax, fabs(z[i]));
+      gmax = std::max(gmax, penalty_gamma[i]);
+    }
+    zav = zav / m;
+    gav = gav / m;
+    int qp_iters = 0;
+    ip->getIterationCounters(&qp_iters, nullptr, nullptr);
+    subproblem_iters = qp_iters;
+    std::string info;
+    const int ut = sub->getQuasiNewtonUpdateType();
+    if (ut == 1) info += "dampH ";
+    else if (ut == 2) info += "skipH ";
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%d f%ld ", qp_iters, (long)filter.size());
+    info += buf;
+    if (this_resto) info += "R ";
+    if (!accepted) info += (rej.empty() ? std::string("rej") : rej) + " ";
+    const double vals[12] = {fobj_trial, infeas_trial, l1, linfty, smax, tr_size, rho, model_red, zav, zmax, gav, gmax};
+    appendRow(vals, info, now_seconds() - t0);
+    if (inc_tr) {
+      tr_size = std::min(2.0 * tr_size, tr_max);
+    } else if (dec_tr) {
+      tr_size = std::max(0.5 * tr_size, tr_min);
+    }
+    if (init_tr) tr_size = tr_max;
+    PO_TRY(sub->setTrustRegionBounds(tr_size));
+    iter_count++;
+    last_resto = this_resto;
+    if (infeas_trial < infeas_tol && (l1 < l1_tol || linfty < linf_tol)) break;
   }
-  if (o.integer("tr_use_soc")) {
-    set_error("tr_use_soc is not implemented on the device path");
-    return PO_ERR_OPTION;
-  }
+  flushHistory();
+  return 0;
+}
+
+int TrustRegion::sl1qpOptimize() {  // :1453-1687
+  Options &o = ip->options;
   const bool adaptive = o.integer("tr_adaptive_gamma_update");
   const int max_it = o.integer("tr_max_iterations");
   const double gmax = o.real("tr_penalty_gamma_max"), gmin = o.real("tr_penalty_gamma_min");
@@ -757,7 +928,7 @@ int TrustRegion::optimize() {  // sl1qpOptimize :1453-1687
   iter_count = 0;
   std::vector<double> con_infeas(m > 0 ? m : 1), model_con_infeas(m > 0 ? m : 1), best_con_infeas;
   for (int i = 0; i < max_it; i++) {
-    if (adaptive) PO_TRY(minimizeInfeas(best_con_infeas));
+    if (adaptive) PO_TRY(minimizeInfeas(&best_con_infeas));
     if (wfreq > 0 && i % wfreq == 0) sub->writeOutput(i, sub->xk);
     if (iter_cb) iter_cb(iter_cb_user, i);
     PO_TRY(ip->resetDesignAndBounds());

@@ -203,7 +203,18 @@ class TrustRegion {
   Vec *tvec;
   double infeasOf(const double *c, const double *weights) const;
   int computeKKTError(const double *z, Vec *zw, double *l1, double *linfty);
-  int minimizeInfeas(std::vector<double> &best_con_infeas);
+  int minimizeInfeas(std::vector<double> *best_con_infeas);
+  int sl1qpOptimize();
+  int filterOptimize();
+  // filter set :896-966
+  struct FilterElement {
+    double f, h;
+  };
+  std::vector<FilterElement> filter;
+  int acceptableByPair(double f_new, double h_new, double f_old, double h_old);
+  int acceptableByFilter(double f, double h);
+  void addToFilter(double f, double h);
+  void appendRow(const double vals[12], const std::string &info, double seconds);
   int sl1qpUpdate(Vec *step, const double *z, Vec *zw, double *infeas, double *l1, double *linfty);
   void flushHistory();
 };

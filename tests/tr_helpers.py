@@ -88,7 +88,7 @@ def run_oracle_tr(case, nmax=None):
     return rows, snaps, final
 
 
-def compare_tr(g, rows, snaps, final, window, frac_exact=0.8):
+def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True):
     """rows/snaps/final of a run (oracle or device) against a golden of the compiled reference."""
     ref = parse_tr_table(g["paropt_tr"])
     ncmp = min(window, len(ref), len(rows))
@@ -113,7 +113,7 @@ def compare_tr(g, rows, snaps, final, window, frac_exact=0.8):
     # interior-point iteration counts of the two subproblem solves: bit-exact except where the
     # degenerate steering LP terminates on a round-off level test (see DESIGN.md "Parity")
     assert exact >= frac_exact * ncmp, "only %d of %d info strings identical" % (exact, ncmp)
-    for k in range(min(ncmp, len(snaps))):
+    for k in range(min(ncmp, len(snaps)) if check_snaps else 0):
         p = "tr%03d/" % k
         s = snaps[k]
         assert abs(s["tr_size"] - g[p + "tr_size"][0]) <= 1e-12 * g[p + "tr_size"][0], k
