@@ -1,0 +1,259 @@
+"""
+``from paropt_amd import ParOpt`` -- the calling conventions of the reference's Python layer
+(``paropt.ParOpt``, paropt/ParOpt.pyx:761-1521) over the MI355X library, so that a problem
+written for the reference runs with the import line changed:
+
+    class Quadratic(ParOpt.Problem):
+        def __init__(self, ...):
+            super().__init__(MPI.COMM_WORLD, nvars=n, ncon=1)
+        def getVarsAndBounds(self, x, lb, ub): x[:] = ...; lb[:] = ...; ub[:] = ...
+        def evalObjCon(self, x): return fail, fobj, con
+        def evalObjConGradient(self, x, g, A): g[:] = ...; A[0][:] = ...; return fail
+    opt = ParOpt.Optimizer(problem, {"algorithm": "ip" | "tr", ...}); opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+
+Callbacks receive PVec objects with the reference's numpy-style item access on host arrays
+(``x[:]``, ``g[:] = ...``); the values move to the GPU when the callback returns.  The MPI
+communicator argument is accepted and ignored: ranks are those of the paropt_amd Context (one process
+per GPU; ``ParOpt.setContext`` to supply one that is already wired to RCCL or to a host callback).
+Not provided: MMA (``algorithm="mma"``), the CSR sparse problem form (``rowp``/``cols``).
+"""
+import numpy as np
+
+from . import api as _api
+
+_ctx = None
+dtype = np.float64
+
+
+def setContext(ctx):
+    """Use an existing paropt_amd.Context (e.g. one initialised for multi-GPU)."""
+    global _ctx
+    _ctx = ctx
+
+
+def getContext():
+    global _ctx
+    if _ctx is None:
+        _ctx = _api.Context(0)
+    return _ctx
+
+
+class PVec:
+    """paropt.ParOpt.PVec (ParOpt.pyx:914-1188): item access on the host mirror plus the reductions."""
+
+    def __init__(self, vec, fresh=False):
+        self._v = vec
+        self._a = vec.getArray()
+        if not fresh:
+            vec.syncToHost()
+
+    def __len__(self):
+        return len(self._a)
+
+    def __getitem__(self, k):
+        return self._a[k]
+
+    def __setitem__(self, k, values):
+        self._a[k] = values
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._a, dtype=dtype)
+
+    def _push(self):
+        self._v.syncToDevice()
+
+    def zeroEntries(self):
+        self._a[:] = 0.0
+
+    def copyValues(self, other):
+        self._a[:] = other[:]
+
+    def norm(self):
+        self._push()
+        return self._v.norm()
+
+    def l1norm(self):
+        self._push()
+        return self._v.l1norm()
+
+    def maxabs(self):
+        self._push()
+        return self._v.maxabs()
+
+    def dot(self, other):
+        self._push()
+        other._push()
+        return self._v.dot(other._v)
+
+
+def _sizes(kw):
+    nvars = kw.get("nvars", 0)
+    ncon = kw.get("num_dense_constraints", kw.get("ncon", 0))
+    nwcon = kw.get("num_sparse_constraints", kw.get("nwcon", 0))
+    nineq = kw.get("num_dense_inequalities", kw.get("ninequality", ncon))
+    nwineq = kw.get("num_sparse_inequalities", kw.get("nwinequality", nwcon))
+    return int(nvars), int(ncon), int(nwcon), int(nineq), int(nwineq)
+
+
+class Problem(_api.Problem):
+    """paropt.ParOpt.Problem (ParOpt.pyx:787-912): ``Problem(comm, nvars=, ncon=, nwcon=, ...)``."""
+
+    def __init__(self, comm=None, **kwargs):
+        nvars, ncon, nwcon, nineq, nwineq = _sizes(kwargs)
+        if kwargs.get("rowp") is not None or kwargs.get("cols") is not None:
+            raise NotImplementedError("the CSR sparse-constraint form is not available on the device path")
+        if nwcon > 0 and kwargs.get("nwblock", 1) not in (0, 1):
+            raise NotImplementedError("sparse constraints need nwblock = 1 on the device path")
+        self.comm = comm
+        self._user = dict(gvb=self.getVarsAndBounds, eval=self.evalObjCon, grad=self.evalObjConGradient)
+        if nwcon > 0:
+            self._user.update(wcon=self.evalSparseCon, wjac=self.addSparseJacobian,
+                              wjact=self.addSparseJacobianTranspose, winner=self.addSparseInnerProduct)
+        # route the host-array protocol of the base class to the PVec protocol of the reference
+        self.getVarsAndBounds = self._gvb
+        self.evalObjCon = self._eval
+        self.evalObjConGradient = self._grad
+        if nwcon > 0:
+            self.evalSparseCon = lambda x, out: self._user["wcon"](_Host(x), _Host(out))
+            self.addSparseJacobian = lambda a, x, px, out: self._user["wjac"](a, _Host(x), _Host(px), _Host(out))
+            self.addSparseJacobianTranspose = lambda a, x, p, out: self._user["wjact"](a, _Host(x), _Host(p), _Host(out))
+            self.addSparseInnerProduct = lambda a, x, c, A: self._user["winner"](a, _Host(x), _Host(c), A)
+        super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq)
+
+    def _gvb(self, x, lb, ub):
+        self._user["gvb"](_Host(x), _Host(lb), _Host(ub))
+
+    def _eval(self, x):
+        return self._user["eval"](_Host(x))
+
+    def _grad(self, x, g, A):
+        return self._user["grad"](_Host(x), _Host(g), [_Host(a) for a in A])
+
+
+class _Host:
+    """A numpy array dressed as a PVec for the callbacks (same item access / reductions)."""
+
+    def __init__(self, a):
+        self._a = a
+
+    def __len__(self):
+        return len(self._a)
+
+    def __getitem__(self, k):
+        return self._a[k]
+
+    def __setitem__(self, k, values):
+        self._a[k] = values
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self._a, dtype=dtype)
+
+    def zeroEntries(self):
+        self._a[:] = 0.0
+
+    def copyValues(self, other):
+        self._a[:] = other[:]
+
+    def norm(self):
+        return float(np.sqrt(np.dot(self._a, self._a)))
+
+    def l1norm(self):
+        return float(np.sum(np.abs(self._a)))
+
+    def maxabs(self):
+        return float(np.max(np.abs(self._a))) if len(self._a) else 0.0
+
+    def dot(self, other):
+        return float(np.dot(self._a, other[:]))
+
+
+def _split_options(options):
+    opts = dict(options or {})
+    algorithm = opts.pop("algorithm", "tr")
+    if opts.get("output_file", "") is None:
+        opts["output_file"] = ""
+    if opts.get("tr_output_file", "") is None:
+        opts["tr_output_file"] = ""
+    return algorithm, opts
+
+
+_TR_ONLY = ("tr_", "filter_")
+
+
+class InteriorPoint(_api.InteriorPoint):
+    """paropt.ParOpt.InteriorPoint (ParOpt.pyx:1229-1365)."""
+
+    def __init__(self, problem, options=None):
+        algorithm, opts = _split_options(options)
+        opts = {k: v for k, v in opts.items() if not k.startswith(_TR_ONLY)}
+        super().__init__(problem, opts)
+
+    def getOptimizedPoint(self):
+        x, z, zl, zu = super().getOptimizedPoint()
+        w = self.getOptimizedSparse()
+        return PVec(x), z, (PVec(w[0]) if w else None), PVec(zl), PVec(zu)
+
+
+class Optimizer:
+    """paropt.ParOpt.Optimizer (ParOpt.pyx:1461-1521, src/ParOptOptimizer.cpp:65-206)."""
+
+    def __init__(self, problem, options=None):
+        self.problem = problem
+        self.algorithm, self.options = _split_options(options)
+        self.ip = self.tr = None
+        if self.algorithm not in ("ip", "tr"):
+            raise NotImplementedError("algorithm=%r: only 'ip' and 'tr' run on the device path" % self.algorithm)
+
+    def optimize(self):
+        if self.algorithm == "ip":
+            if self.ip is None:
+                self.ip = InteriorPoint(self.problem, self.options)
+            ckpt = self.options.get("ip_checkpoint_file")
+            self.ip.optimize(ckpt if ckpt else None)
+        else:
+            if self.tr is None:
+                opts = {k: v for k, v in self.options.items() if k != "ip_checkpoint_file"}
+                self.tr = _api.TrustRegion(self.problem, opts)
+            self.tr.optimize()
+
+    def getOptimizedPoint(self):
+        if self.tr is not None:
+            x, z, zw = self.tr.getOptimizedPoint()
+            return PVec(x), z, (PVec(zw) if zw is not None else None), None, None
+        return self.ip.getOptimizedPoint()
+
+
+LBFGS = _api.LBFGS
+LSR1 = _api.LSR1
+
+
+def unpack_output(filename):
+    """Columns of an interior-point output file (ParOpt.pyx:61-133): (names, list of arrays)."""
+    args = ["iter", "nobj", "ngrd", "nhvc", "alpha", "alphx", "alphz", "fobj", "|opt|", "|infes|", "|dual|", "mu",
+            "comp", "dmerit", "rho"]
+    cols = [[] for _ in args]
+    with open(filename) as fp:
+        for line in fp:
+            p = line.split()
+            if len(p) >= len(args) and p[0].isdigit():
+                for i in range(len(args)):
+                    try:
+                        cols[i].append(int(p[i]) if i < 4 else float(p[i]))
+                    except ValueError:
+                        cols[i].append(0 if i < 4 else 0.0)
+    return args, [np.array(c, dtype=np.int32 if i < 4 else float) for i, c in enumerate(cols)]
+
+
+def unpack_tr_output(filename):
+    """Columns of a trust-region output file (ParOpt.pyx:135-206)."""
+    args = ["iter", "fobj", "infeas", "l1", "linfty", "|x - xk|", "tr", "rho", "mod red.", "avg z", "max z",
+            "avg pen.", "max pen.", "time(s)"]
+    cols = [[] for _ in args]
+    with open(filename) as fp:
+        for line in fp:
+            p = line.split()
+            if len(p) >= len(args) and p[0].isdigit():
+                for i in range(len(args)):
+                    cols[i].append(int(p[i]) if i == 0 else float(p[i]))
+    return args, [np.array(c, dtype=np.int32 if i == 0 else float) for i, c in enumerate(cols)]

@@ -1,0 +1,100 @@
+"""
+The reference's Python calling conventions (paropt.ParOpt: Problem(comm, nvars=, ncon=), PVec item
+access in the callbacks, Optimizer(problem, options) with algorithm = ip | tr) over the device
+library: a dense (non-separable) random quadratic in the style of
+examples/random_quadratic/random_quadratic.py, checked against the numpy oracle driven with the
+same data.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_data(n=40, seed=3):
+    rng = np.random.RandomState(seed)
+    B = rng.uniform(size=(n, n))
+    Q, _, _ = np.linalg.svd(B)
+    A = Q @ np.diag(np.linspace(1.0, 50.0, n)) @ Q.T
+    return A, rng.uniform(size=n), rng.uniform(size=n), rng.uniform(), -2.0 + rng.uniform(size=n)
+
+
+def test_reference_style_problem_ip_and_tr(tmp_path):
+    from oracle import paropt_oracle as po
+    from oracle import tr_oracle as tro
+    from paropt_amd import ParOpt
+
+    A, b, Acon, bcon, x0 = make_data()
+    n = len(b)
+
+    class Quadratic(ParOpt.Problem):
+        def __init__(self):
+            self.comm = None
+            self.nvars = n
+            self.ncon = 1
+            super(Quadratic, self).__init__(self.comm, nvars=self.nvars, ncon=self.ncon)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = x0
+            lb[:] = -5.0
+            ub[:] = 5.0
+
+        def evalObjCon(self, x):
+            con = np.zeros(1, dtype=ParOpt.dtype)
+            fobj = 0.5 * np.dot(x, np.dot(A, x)) + np.dot(b, x)
+            con[0] = np.dot(x, Acon) + bcon
+            return 0, fobj, con
+
+        def evalObjConGradient(self, x, g, Ac):
+            g[:] = np.dot(A, x) + b
+            Ac[0][:] = Acon[:]
+            return 0
+
+    class OracleProblem:  # the same data behind the oracle's problem protocol
+        comm = po.SelfComm()
+        nlocal, c, nwcon, nwineq = n, 1, 0, 0
+
+        def vars_and_bounds(self):
+            return x0.copy(), np.full(n, -5.0), np.full(n, 5.0)
+
+        def eval_obj_con(self, x):
+            return 0, 0.5 * x @ (A @ x) + b @ x, np.array([x @ Acon + bcon])
+
+        def eval_obj_con_gradient(self, x):
+            return 0, A @ x + b, [Acon.copy()]
+
+    outfile = str(tmp_path / "paropt.out")
+    options = {"algorithm": "ip", "abs_res_tol": 1e-8, "starting_point_strategy": "affine_step",
+               "barrier_strategy": "monotone", "start_affine_multiplier_min": 0.01, "penalty_gamma": 1000.0,
+               "qn_subspace_size": 10, "qn_type": "bfgs", "output_file": outfile}
+    opt = ParOpt.Optimizer(Quadratic(), options)
+    opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+    oip = po.InteriorPoint(OracleProblem(), {k: v for k, v in options.items() if k not in ("algorithm", "output_file")})
+    oip.optimize()
+    np.testing.assert_allclose(x[:], oip.vars.x, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(z, oip.vars.z, rtol=1e-5, atol=1e-7)
+    assert zw is None and len(zl) == n
+    names, cols = ParOpt.unpack_output(outfile)
+    assert names[0] == "iter" and len(cols[0]) == oip.niter + 1 and cols[1][-1] == oip.neval
+
+    # the same problem through the trust-region driver
+    trfile = str(tmp_path / "paropt.tr")
+    tr_options = {"algorithm": "tr", "tr_init_size": 0.05, "tr_min_size": 1e-6, "tr_max_size": 10.0, "tr_eta": 0.25,
+                  "tr_adaptive_gamma_update": True, "tr_max_iterations": 60, "qn_subspace_size": 10,
+                  "output_file": None, "tr_output_file": trfile}
+    opt2 = ParOpt.Optimizer(Quadratic(), tr_options)
+    opt2.optimize()
+    x2 = opt2.getOptimizedPoint()[0]
+    ops = po.VecOps(po.SelfComm())
+    qn = po.LBFGS(n, 10, ops, "skip_negative_curvature")
+    sub = tro.QuadraticSubproblem(OracleProblem(), qn)
+    otr = tro.TrustRegion(sub, po.InteriorPoint(sub, {"qn_subspace_size": 10}),
+                          {"tr_init_size": 0.05, "tr_min_size": 1e-6, "tr_max_size": 10.0, "tr_eta": 0.25,
+                           "tr_max_iterations": 60})
+    otr.optimize()
+    np.testing.assert_allclose(x2[:], sub.xk, rtol=0, atol=1e-5)
+    names, cols = ParOpt.unpack_tr_output(trfile)
+    assert len(cols[0]) == otr.iter_count
+    # both drivers land on the same optimum of this convex problem
+    np.testing.assert_allclose(x2[:], x[:], rtol=0, atol=1e-3)
