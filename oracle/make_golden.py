@@ -327,6 +327,25 @@ for tag, extra in (
         **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
                                   "opt.max_major_iters": 60}, **extra)),
     )
+# --- Hessian-vector products: inexact Newton-Krylov steps (computeKKTGMRESStep :5796-6191) and the
+# diagonal-Hessian variant.  nk_switch_tol / max_gmres_rtol are opened up so that
+# the GMRES branch is taken early and often.
+hv = {"opt.use_hvec_product": 1, "opt.gmres_subspace_size": 15, "opt.nk_switch_tol": 1e3, "opt.max_gmres_rtol": 1.0}
+case("ip_convex_hvec_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **dict(hv, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80})))
+case("ip_quadratic_hvec_n257_c3", "ip", problem="quadratic", n=257, c=3, dump_vecs_every=10,
+     **dict(ip_common, **dict(hv, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 80})))
+case("ip_rosenbrock_hvec_n100", "ip", problem="rosenbrock", n=100, dump_vecs_every=10,
+     **dict({"opt.qn_subspace_size": 10, "opt.abs_res_tol": 1e-6, "opt.write_output_frequency": 1,
+             "opt.max_major_iters": 150}, **dict(hv, **{"opt.nk_switch_tol": 1.0, "opt.max_gmres_rtol": 0.5})))
+case("ip_convex_hvec_noprecon_n200_c2", "ip", problem="convex", n=200, c=2, dump_vecs_every=10,
+     **dict(ip_common, **dict(hv, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80,
+                                     "opt.use_qn_gmres_precon": 0, "opt.gmres_subspace_size": 30})))
+case("ip_convex_diaghess_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.use_diag_hessian": 1, "opt.qn_subspace_size": 6, "opt.max_major_iters": 80}))
+case("ip_rosenbrock_diaghess_n100", "ip", problem="rosenbrock", n=100, dump_vecs_every=10,
+     **{"opt.use_diag_hessian": 1, "opt.qn_subspace_size": 10, "opt.abs_res_tol": 1e-6,
+        "opt.write_output_frequency": 1, "opt.max_major_iters": 150})
 # --- trust-region driver: ParOptOptimizer's algorithm="tr" set-up ---
 tr_common = {"opt.qn_subspace_size": 5, "tr.tr_max_iterations": 60}
 case("tr_quadratic_n200_c3_bfgs", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10, **tr_common)

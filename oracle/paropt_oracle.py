@@ -393,6 +393,27 @@ class SepProblem:
             A += alpha * np.sum(cvec[self.widx], axis=1)
         return A
 
+    def hessian_diag(self, x, z):  # oracle/ref_driver.cpp evalHessianDiag
+        if self.kind == "quadratic":
+            return self.q.copy()
+        if self.kind == "convex":
+            d = 1e-3 + x
+            return 2.0 * self.b * self.b / (d * d * d)
+        h = np.full(len(x), 2.0 * z[0])
+        r = x[1:] - x[:-1] ** 2
+        h[:-1] += 2.0 - 400.0 * r + 800.0 * x[:-1] ** 2
+        h[1:] += 200.0
+        return h
+
+    def hvec_product(self, x, z, px):  # oracle/ref_driver.cpp evalHvecProduct
+        if self.kind in ("quadratic", "convex"):
+            return self.hessian_diag(x, z) * px
+        h = 2.0 * z[0] * px
+        r = x[1:] - x[:-1] ** 2
+        h[:-1] += (2.0 - 400.0 * r + 800.0 * x[:-1] ** 2) * px[:-1] - 400.0 * x[:-1] * px[1:]
+        h[1:] += -400.0 * x[:-1] * px[:-1] + 200.0 * px[1:]
+        return h
+
     def eval_obj_con_gradient(self, x):
         if self.kind == "quadratic":
             return 0, self.q * x + self.b, [a.copy() for a in self.A]
@@ -444,6 +465,15 @@ DEFAULT_OPTIONS = {  # src/ParOptInteriorPoint.cpp:536-727
     "norm_type": "infinity",
     "barrier_strategy": "monotone",
     "starting_point_strategy": "affine_step",
+    "use_hvec_product": False,
+    "use_diag_hessian": False,
+    "use_qn_gmres_precon": True,
+    "nk_switch_tol": 1e-3,
+    "eisenstat_walker_alpha": 1.5,
+    "eisenstat_walker_gamma": 1.0,
+    "max_gmres_rtol": 0.1,
+    "gmres_atol": 1e-30,
+    "gmres_subspace_size": 0,
 }
 
 LS_SUCCESS, LS_FAILURE, LS_MIN_STEP, LS_MAX_ITERS, LS_NO_IMPROVEMENT, LS_SHORT_STEP = (
@@ -530,6 +560,8 @@ class InteriorPoint:
         self.Dinv = np.ones(n)
         self.Glu = None
         self.Celu = None
+        self.hdiag = np.zeros(n) if o["use_diag_hessian"] else None  # :293-297 (zero until evaluated)
+        self.nhvec = 0
         self.trace = []
         self.hook = None  # called as hook(self, k) at the top of every iteration
         self._init_and_check_bounds()
@@ -648,13 +680,18 @@ class InteriorPoint:
         r.zl[:] = np.where(L, -((v.x - self.lb) * v.zl - beta * barrier), 0.0)
         r.zu[:] = np.where(U, -((self.ub - v.x) * v.zu - beta * barrier), 0.0)
 
-    def add_kkt_res_step(self, v, p, r):  # :1451-1583 (quasi-Newton branch)
+    def add_kkt_res_step(self, v, p, r, inexact_newton_step=0):  # :1451-1583
         o = self.opt
         L, U = self._masks()
-        if self.qn is not None and not o["sequential_linear_method"]:
-            self.qn.mult_add(-1.0, p.x, r.x)
-        if o["qn_sigma"] != 0.0:
-            r.x += -o["qn_sigma"] * p.x
+        if inexact_newton_step:
+            r.x += -1.0 * self.prob.hvec_product(v.x, v.z, p.x)
+        elif o["use_diag_hessian"]:
+            r.x -= p.x * self.hdiag
+        else:
+            if self.qn is not None and not o["sequential_linear_method"]:
+                self.qn.mult_add(-1.0, p.x, r.x)
+            if o["qn_sigma"] != 0.0:
+                r.x += -o["qn_sigma"] * p.x
         for i in range(self.c):
             r.x += p.z[i] * self.Ac[i]
         if self.use_lower:
@@ -725,9 +762,11 @@ class InteriorPoint:
         o = self.opt
         L, U = self._masks()
         b0 = 0.0
-        if self.qn is not None and use_qn:
+        if o["use_diag_hessian"] and self.hdiag is not None:  # :1840-1842
+            b0 = self.hdiag
+        elif self.qn is not None and use_qn:
             b0 = self.qn.b0
-        d = np.full(self.n, b0 + o["qn_sigma"])
+        d = np.zeros(self.n) + b0 + o["qn_sigma"]
         d = d + np.where(L, v.zl / np.where(L, v.x - self.lb, 1.0), 0.0)
         d = d + np.where(U, v.zu / np.where(U, self.ub - v.x, 1.0), 0.0)
         self.Dinv = 1.0 / d
@@ -819,6 +858,171 @@ class InteriorPoint:
             d1 += yz[i] * self.Ac[i]
         return self._apply(d1)[0]
 
+    def solve_kkt_diag_alpha(self, v, bx, alpha, b, y):  # :2441-2614 (w = 0)
+        L, U = self._masks()
+        xl = np.where(L, v.x - self.lb, 1.0)
+        xu = np.where(U, self.ub - v.x, 1.0)
+        d1 = bx.copy()
+        d1 += alpha * np.where(L, b.zl / xl, 0.0)
+        d1 -= alpha * np.where(U, b.zu / xu, 0.0)
+        yx, _ = self._apply(d1)
+        yz = self.ops.mdot(yx, self.Ac)
+        yz = alpha * (b.z + (b.zs + v.s * b.s) / v.zs - (b.zt + v.t * b.t) / v.zt) - yz
+        yz = self._gsolve(yz)
+        y.z[:] = yz
+        y.zs[:] = yz - alpha * b.s
+        y.zt[:] = -alpha * b.t - yz
+        y.s[:] = (alpha * b.zs - v.s * y.zs) / v.zs
+        y.t[:] = (alpha * b.zt - v.t * y.zt) / v.zt
+        for i in range(self.c):
+            d1 += yz[i] * self.Ac[i]
+        yx, _ = self._apply(d1)
+        y.x[:] = yx
+        y.zl[:] = np.where(L, (alpha * b.zl - v.zl * y.x) / xl, 0.0)
+        y.zu[:] = np.where(U, (alpha * b.zu + v.zu * y.x) / xu, 0.0)
+
+    def eval_obj_barrier_deriv(self, v, p):  # :5669-5766
+        beta = self.opt["rel_bound_barrier"]
+        _, _, L, U, dl, du = self._barrier_sums(v.x)
+        px = p.x
+        ql = np.where(L, px / dl, 0.0)
+        qu = np.where(U, px / du, 0.0)
+        ppos = beta * float(np.sum(np.where(L & (px > 0.0), ql, 0.0)) - np.sum(np.where(U & ~(px > 0.0), qu, 0.0)))
+        pneg = beta * float(np.sum(np.where(L & ~(px > 0.0), ql, 0.0)) - np.sum(np.where(U & (px > 0.0), qu, 0.0)))
+        out = self.comm.allreduce([ppos, pneg])
+        ppos, pneg = float(out[0]), float(out[1])
+        for i in range(self.c):
+            for val, pv in ((v.s[i], p.s[i]), (v.t[i], p.t[i])):
+                if pv > 0.0:
+                    ppos += pv / val
+                else:
+                    pneg += pv / val
+        pmerit = self.ops.dot(self.g, p.x) - self.barrier_param * (ppos + pneg)
+        for i in range(self.c):
+            pmerit += self.gamma_s[i] * p.s[i] + self.gamma_t[i] * p.t[i]
+        return pmerit
+
+    def _smw_correct(self, v, p, scratch, use_qn):
+        """p -= K0^-1-solve of Z Ce^-1 Z^T p.x  (the second half of computeKKTStep, :2718-2735)."""
+        Z = self.qn.get_compact()[3] if (self.qn is not None and use_qn) else []
+        if len(Z) > 0:
+            zt = self.ops.mdot(p.x, Z)
+            zt = sla.lu_solve(self.Celu, zt, check_finite=False)
+            xt = np.zeros(self.n)
+            for i in range(len(Z)):
+                xt += zt[i] * Z[i]
+            self.solve_kkt_diag_bx(v, xt, scratch)
+            return scratch
+        return None
+
+    def compute_kkt_gmres_step(self, v, r, p, rtol, atol, use_qn):  # :5796-6191 (w = 0)
+        m = self.opt["gmres_subspace_size"]
+        if m <= 0:
+            return 0
+        c = self.c
+        H = np.zeros((m + 1) * (m + 2) // 2)
+        alpha = np.zeros(m + 1)
+        gres = np.zeros(m + 1)
+        y = np.zeros(m)
+        fproj = np.zeros(m)
+        aproj = np.zeros(m)
+        Qcos, Qsin = np.zeros(m), np.zeros(m)
+        W = [None] * (m + 1)
+        beta = float(np.sum(r.z**2 + r.s**2 + r.t**2 + r.zs**2 + r.zt**2))
+        if self.use_lower:
+            beta += self.ops.dot(r.zl, r.zl)
+        if self.use_upper:
+            beta += self.ops.dot(r.zu, r.zu)
+        bnorm = math.sqrt(self.ops.dot(r.x, r.x) + beta)
+        beta *= 1.0 / (bnorm * bnorm)
+        cinfeas = float(np.sum((self.cvals - v.s + v.t) ** 2))
+        cscale = 0.0
+        if cinfeas != 0.0:
+            cinfeas = math.sqrt(cinfeas)
+            cscale = 1.0 / cinfeas
+        gres[0] = bnorm
+        W[0] = r.x / gres[0]
+        alpha[0] = 1.0
+        niters = 0
+        scratch = Vars(self.n, c, self.w)
+        for i in range(m):
+            self.solve_kkt_diag_alpha(v, W[i], alpha[i] / bnorm, r, p)
+            corr = self._smw_correct(v, p, scratch, use_qn)
+            if corr is not None:
+                p.x += -1.0 * corr.x  # only the design part is corrected inside the loop (:5949)
+            fproj[i] = self.eval_obj_barrier_deriv(v, p)
+            aproj[i] = 0.0
+            for j in range(c):
+                cj = self.ops.dot(self.Ac[j], p.x) - p.s[j] + p.t[j]
+                aproj[i] -= cscale * r.z[j] * cj
+            W[i + 1] = self.prob.hvec_product(v.x, v.z, p.x)
+            self.nhvec += 1
+            if self.qn is not None and use_qn:
+                self.qn.mult_add(-1.0, p.x, W[i + 1])
+            W[i + 1] += 1.0 * W[i]
+            alpha[i + 1] = alpha[i]
+            hptr = (i + 1) * (i + 2) // 2 - 1
+            for j in range(i, -1, -1):
+                H[j + hptr] = self.ops.dot(W[i + 1], W[j]) + beta * alpha[i + 1] * alpha[j]
+                W[i + 1] += -H[j + hptr] * W[j]
+                alpha[i + 1] -= H[j + hptr] * alpha[j]
+            H[i + 1 + hptr] = math.sqrt(self.ops.dot(W[i + 1], W[i + 1]) + beta * alpha[i + 1] * alpha[i + 1])
+            W[i + 1] *= 1.0 / H[i + 1 + hptr]
+            alpha[i + 1] *= 1.0 / H[i + 1 + hptr]
+            for k in range(i):
+                h1, h2 = H[k + hptr], H[k + 1 + hptr]
+                H[k + hptr] = h1 * Qcos[k] + h2 * Qsin[k]
+                H[k + 1 + hptr] = -h1 * Qsin[k] + h2 * Qcos[k]
+            h1, h2 = H[i + hptr], H[i + 1 + hptr]
+            sq = math.sqrt(h1 * h1 + h2 * h2)
+            Qcos[i], Qsin[i] = h1 / sq, h2 / sq
+            H[i + hptr] = h1 * Qcos[i] + h2 * Qsin[i]
+            H[i + 1 + hptr] = -h1 * Qsin[i] + h2 * Qcos[i]
+            h1 = gres[i]
+            gres[i] = h1 * Qcos[i]
+            gres[i + 1] = -h1 * Qsin[i]
+            niters += 1
+            for j in range(niters - 1, -1, -1):
+                y[j] = gres[j]
+                for k in range(j + 1, niters):
+                    hp = (k + 1) * (k + 2) // 2 - 1
+                    y[j] = y[j] - H[j + hp] * y[k]
+                hp = (j + 1) * (j + 2) // 2 - 1
+                y[j] = y[j] / H[j + hp]
+            fpr = float(np.dot(y[:niters], fproj[:niters]))
+            cpr = float(np.dot(y[:niters], aproj[:niters]))
+            constraint_descent = 1 if cpr <= -0.01 * cinfeas else 0
+            if fpr < 0.0 or constraint_descent:
+                if abs(gres[i + 1]) < atol or abs(gres[i + 1]) < rtol * bnorm:
+                    break
+        for i in range(niters - 1, -1, -1):
+            for j in range(i + 1, niters):
+                hp = (j + 1) * (j + 2) // 2 - 1
+                gres[i] = gres[i] - H[i + hp] * gres[j]
+            hp = (i + 1) * (i + 2) // 2 - 1
+            gres[i] = gres[i] / H[i + hp]
+        W[0] = W[0] * gres[0]
+        gamma = gres[0] * alpha[0]
+        for i in range(1, niters):
+            W[0] += gres[i] * W[i]
+            gamma += gres[i] * alpha[i]
+        gamma /= bnorm
+        r.x[:] = W[0]
+        for k in ("z", "s", "t", "zs", "zt", "zl", "zu"):
+            getattr(r, k)[...] *= gamma
+        self.solve_kkt_diag_full(v, r, p)
+        corr = self._smw_correct(v, p, scratch, use_qn)
+        if corr is not None:
+            p.add(corr, -1.0)
+        fpr = self.eval_obj_barrier_deriv(v, p)
+        cpr = 0.0
+        for i in range(c):
+            deriv = self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
+            cpr += cscale * (self.cvals[i] - v.s[i] + v.t[i]) * deriv
+        if fpr < 0.0 or cpr < -0.01 * cinfeas:
+            return niters
+        return -niters
+
     def setup_kkt_system(self, v, use_qn):  # :2634-2667
         self.Celu = None
         if self.qn is not None and use_qn:
@@ -909,27 +1113,33 @@ class InteriorPoint:
         out = self.comm.allreduce([mx, mz], "min")
         return float(out[0]), float(out[1])
 
-    def scale_kkt_step(self, v, p, tau, comp):  # :3196-3274
+    def scale_kkt_step(self, v, p, tau, comp, inexact_newton_step=0):  # :3196-3274
         ax, az = self.compute_max_step(v, tau, p)
         ceq = 0
         bnd = 100.0
-        if ax > az:
-            if ax > bnd * az:
-                ax = bnd * az
-            elif ax < az / bnd:
-                ax = az / bnd
-        else:
-            if az > bnd * ax:
-                az = bnd * ax
-            elif az < ax / bnd:
-                az = ax / bnd
-        comp_new = self.compute_comp_step(v, ax, az, p)
-        if comp_new > 10.0 * comp:
-            ceq = 1
+        if inexact_newton_step:  # Newton step: one common step length (:3240-3248)
             if ax > az:
                 ax = az
             else:
                 az = ax
+        else:
+            if ax > az:
+                if ax > bnd * az:
+                    ax = bnd * az
+                elif ax < az / bnd:
+                    ax = az / bnd
+            else:
+                if az > bnd * ax:
+                    az = bnd * ax
+                elif az < ax / bnd:
+                    az = ax / bnd
+            comp_new = self.compute_comp_step(v, ax, az, p)
+            if comp_new > 10.0 * comp:
+                ceq = 1
+                if ax > az:
+                    ax = az
+                else:
+                    az = ax
         p.x *= ax
         p.zl *= az
         p.zu *= az
@@ -1055,7 +1265,9 @@ class InteriorPoint:
         infeas = math.sqrt(dense_infeas + sparse_infeas * sparse_infeas)
         infeas_proj = (pdense + psparse) / infeas if infeas > 0.0 else 0.0
         pTBp = 0.0
-        if self.qn is not None and not o["sequential_linear_method"]:
+        if o["use_diag_hessian"]:  # :3810-3818 (no factor 1/2 here)
+            pTBp = float(self.comm.allreduce([float(np.sum(p.x * p.x * self.hdiag))])[0])
+        elif self.qn is not None and not o["sequential_linear_method"]:
             xt = self.qn.mult(p.x)
             pTBp = 0.5 * self.ops.dot(xt, p.x)
         merit = (self.fobj + (self.ops.dot(self.gamma_sw, v.sw) + self.ops.dot(self.gamma_tw, v.tw))
@@ -1274,7 +1486,9 @@ class InteriorPoint:
         v.zl[self.lb <= -mb] = 0.0
         v.zu[self.ub >= mb] = 0.0
         self.compute_kkt_res(v, 0.0, r)
-        use_qn = 0 if o["sequential_linear_method"] else 1
+        use_qn = 1
+        if o["sequential_linear_method"] or not o["use_qn_gmres_precon"] or o["use_diag_hessian"]:  # :5576
+            use_qn = 0
         self.setup_kkt_diag_system(v, use_qn)
         self.setup_kkt_system(v, use_qn)
         self.compute_kkt_step(v, r, p, use_qn)
@@ -1295,11 +1509,11 @@ class InteriorPoint:
         self.barrier_param = self.compute_comp(v)
 
     # ---- the major iteration ---------------------------------------------------------
-    def _kkt_step_with_refinement(self, v, barrier_for_res, use_qn):
+    def _kkt_step_with_refinement(self, v, barrier_for_res, use_qn, inexact_newton_step=0):
         self.compute_kkt_step(v, self.res, self.step, use_qn)
         for _ in range(self.opt["iterative_refinement_steps"]):  # :4985-4991
             self.compute_kkt_res(v, barrier_for_res, self.res)
-            self.add_kkt_res_step(v, self.step, self.res)
+            self.add_kkt_res_step(v, self.step, self.res, inexact_newton_step)
             self.compute_kkt_step(v, self.res, self.refine, use_qn)
             self.step.add(self.refine)
 
@@ -1313,8 +1527,8 @@ class InteriorPoint:
         mehrotra_names = ("mehrotra", "mehrotra_predictor_corrector")
         self.barrier_param = o["init_barrier_param"]
         self.rho = o["init_rho_penalty_search"]
-        self.niter = self.neval = self.ngeval = 0
-        if self.qn is None and not o["sequential_linear_method"]:
+        self.niter = self.neval = self.ngeval = self.nhvec = 0
+        if self.qn is None and not o["sequential_linear_method"] and not o["use_diag_hessian"]:
             return 1
         self._init_and_check_bounds()
         fail, self.fobj, self.cvals = self.prob.eval_obj_con(v.x)
@@ -1336,6 +1550,7 @@ class InteriorPoint:
         no_merit_improvement = 0
         line_search_test = 0
         line_search_failed = 0
+        res_norm_prev = 0.0
         info = ""
         self.trace = []
         k = 0
@@ -1412,11 +1627,35 @@ class InteriorPoint:
                 converged = 1
             if converged:
                 break
+            gmres_iters = 0
+            inexact_newton_step = 0
+            if o["use_hvec_product"]:  # :4853-4900
+                if res_norm_prev == 0.0:
+                    gmres_rtol = float("inf")
+                else:
+                    gmres_rtol = o["eisenstat_walker_gamma"] * math.pow(res_norm / res_norm_prev,
+                                                                         o["eisenstat_walker_alpha"])
+                nk = o["nk_switch_tol"]
+                if mp < nk and md < nk and mi < nk and gmres_rtol < o["max_gmres_rtol"]:
+                    use_qn = 1
+                    if o["sequential_linear_method"] or not o["use_qn_gmres_precon"]:
+                        use_qn = 0
+                    self.setup_kkt_diag_system(v, use_qn)
+                    self.setup_kkt_system(v, use_qn)
+                    gmres_iters = self.compute_kkt_gmres_step(v, self.res, self.step, gmres_rtol, o["gmres_atol"], use_qn)
+                    if gmres_iters < 0:
+                        self.compute_kkt_res(v, self.barrier_param, self.res)
+                        mp, md, mi, res_norm = self.compute_res_norm(self.res)
+                    else:
+                        inexact_newton_step = 1
             fobj_prev = self.fobj
+            res_norm_prev = res_norm
             seq_linear_step = 0
             diagonal_qn_step = 0
             use_qn = 1
-            if o["sequential_linear_method"]:
+            if inexact_newton_step:
+                pass
+            elif o["sequential_linear_method"]:
                 use_qn = 0
             elif line_search_failed and not o["use_quasi_newton_update"]:  # :4923-4939
                 # fixed quasi-Newton approximation and a failed line search: sequential linear step,
@@ -1426,15 +1665,19 @@ class InteriorPoint:
                 if self.qn is not None and self.qn.get_compact()[0] > 0.0:
                     seq_linear_step = 0
                     diagonal_qn_step = 1
+            elif o["use_diag_hessian"]:  # :4940-4948
+                use_qn = 0
+                self.hdiag = self.prob.hessian_diag(v.x, v.z)
             mu_for_res = self.barrier_param
-            if barrier_strategy in mehrotra_names:  # affine residual :4958-4964
+            if not inexact_newton_step and barrier_strategy in mehrotra_names:  # affine residual :4958-4964
                 mu_for_res = 0.0
                 self.compute_kkt_res(v, 0.0, self.res)
                 self.compute_res_norm(self.res)
-            self.setup_kkt_diag_system(v, 1 if diagonal_qn_step else use_qn)  # :4968-4980
-            self.setup_kkt_system(v, 1 if diagonal_qn_step else use_qn)
-            self._kkt_step_with_refinement(v, mu_for_res, use_qn)
-            if barrier_strategy in mehrotra_names:  # :4999-5052
+            if not inexact_newton_step:
+                self.setup_kkt_diag_system(v, 1 if diagonal_qn_step else use_qn)  # :4968-4980
+                self.setup_kkt_system(v, 1 if diagonal_qn_step else use_qn)
+                self._kkt_step_with_refinement(v, mu_for_res, use_qn)
+            if not inexact_newton_step and barrier_strategy in mehrotra_names:  # :4999-5052
                 max_x, max_z = self.compute_max_step(v, 1.0, self.step)
                 comp_affine = self.compute_comp_step(v, max_x, max_z, self.step)
                 s1 = comp_affine / comp
@@ -1450,7 +1693,7 @@ class InteriorPoint:
                 else:
                     self._kkt_step_with_refinement(v, self.barrier_param, use_qn)
             tau = max(o["min_fraction_to_boundary"], 1.0 - self.barrier_param)
-            ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp)
+            ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp, inexact_newton_step)
             alpha = 1.0
             line_fail = LS_FAILURE
             update_type = 0
@@ -1473,7 +1716,7 @@ class InteriorPoint:
                         mp, md, mi, res_norm = self.compute_res_norm(self.res)
                         diagonal_qn_step = 1
                         self.setup_kkt_diag_system(v, 1)
-                        self._kkt_step_with_refinement(v, self.barrier_param, 1)
+                        self._kkt_step_with_refinement(v, self.barrier_param, 1, inexact_newton_step)
                         ceq_step, alpha_x, alpha_z = self.scale_kkt_step(v, self.step, tau, comp)
                         m0, dm0 = self.eval_merit_init_deriv(v, self.step, alpha_x)
                         dm0_prev = dm0
@@ -1510,6 +1753,8 @@ class InteriorPoint:
                 qn_reset = 1
                 self.qn.reset()
             toks = []
+            if gmres_iters != 0:
+                toks.append("iNK%d" % gmres_iters)
             if update_type == 1:
                 toks.append("dampH")
             elif update_type == 2:

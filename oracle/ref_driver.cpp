@@ -289,6 +289,53 @@ class SepProblem : public ParOptProblem {
     }
   }
 
+  // Hessian of the Lagrangian f - z^T c (all three workloads have diagonal or tridiagonal Hessians;
+  // only Rosenbrock's c0 = 0.25 - sum x^2 is nonlinear: -z0 * (-2 I))
+  int evalHvecProduct(ParOptVec *xv, ParOptScalar *z, ParOptVec *zw, ParOptVec *pxv, ParOptVec *hv) {
+    double *x, *px, *h;
+    xv->getArray(&x);
+    pxv->getArray(&px);
+    hv->getArray(&h);
+    if (kind == QUADRATIC) {
+      for (int i = 0; i < nvars; i++) {
+        h[i] = (eig_min + (eig_max - eig_min) * u01(seed, 1, offset + i)) * px[i];
+      }
+    } else if (kind == CONVEX) {
+      for (int i = 0; i < nvars; i++) {
+        double b = u01(seed, 2, offset + i), d = 1e-3 + x[i];
+        h[i] = 2.0 * b * b / (d * d * d) * px[i];
+      }
+    } else {
+      for (int i = 0; i < nvars; i++) h[i] = 2.0 * z[0] * px[i];
+      for (int i = 0; i < nvars - 1; i++) {
+        double r = x[i + 1] - x[i] * x[i];
+        h[i] += (2.0 - 400.0 * r + 800.0 * x[i] * x[i]) * px[i] - 400.0 * x[i] * px[i + 1];
+        h[i + 1] += -400.0 * x[i] * px[i] + 200.0 * px[i + 1];
+      }
+    }
+    return 0;
+  }
+  int evalHessianDiag(ParOptVec *xv, ParOptScalar *z, ParOptVec *zw, ParOptVec *hv) {
+    double *x, *h;
+    xv->getArray(&x);
+    hv->getArray(&h);
+    if (kind == QUADRATIC) {
+      for (int i = 0; i < nvars; i++) h[i] = eig_min + (eig_max - eig_min) * u01(seed, 1, offset + i);
+    } else if (kind == CONVEX) {
+      for (int i = 0; i < nvars; i++) {
+        double b = u01(seed, 2, offset + i), d = 1e-3 + x[i];
+        h[i] = 2.0 * b * b / (d * d * d);
+      }
+    } else {
+      for (int i = 0; i < nvars; i++) h[i] = 2.0 * z[0];
+      for (int i = 0; i < nvars - 1; i++) {
+        double r = x[i + 1] - x[i] * x[i];
+        h[i] += 2.0 - 400.0 * r + 800.0 * x[i] * x[i];
+        h[i + 1] += 200.0;
+      }
+    }
+    return 0;
+  }
   void writeOutput(int iter, ParOptVec *x);
 
   int wn, nw, nwstart, nwskip;

@@ -39,3 +39,17 @@ def ip_options_from_case(case):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
+
+
+# Trajectories whose later iterations are driven by round-off level quantities in the REFERENCE
+# itself (e.g. a penalty parameter rho = numer / (0.7 * infeas) with infeas ~ 1e-14 after an inexact
+# Newton step): compared over the stated number of leading iterations only.
+GOLDEN_WINDOWS = {
+    "ip_convex_hvec_n300_c3": 23,
+    "ip_convex_hvec_noprecon_n200_c2": 15,
+    "ipw_convex_n240_c3_w40_mpc": 15,
+}
+
+
+def golden_window(name, default):
+    return GOLDEN_WINDOWS.get(name, default)
