@@ -152,6 +152,12 @@ typedef struct po_problem_sparse_callbacks {
  * valid on a problem made by po_problem_create_callbacks, before po_ip_create */
 int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequality,
                                     const po_problem_sparse_callbacks *cb);
+/* Second-order information (src/ParOptProblem.h:160-189) for use_hvec_product / use_diag_hessian:
+ * evalHvecProduct: hvec = H(x, z, zw) px ; evalHessianDiag: hdiag = diag H(x, z, zw), with H the
+ * Hessian of the Lagrangian f - z^T c - zw^T cw.  zw is NULL when nwcon = 0.  Either may be NULL. */
+typedef int (*po_hvec_fn)(void *user, po_vec x, const double *z, po_vec zw, po_vec px, po_vec hvec);
+typedef int (*po_hdiag_fn)(void *user, po_vec x, const double *z, po_vec zw, po_vec hdiag);
+int po_problem_set_hessian_callbacks(po_problem p, po_hvec_fn hvec, po_hdiag_fn hdiag);
 /* Built-in device-resident workloads of BASELINE.json (DESIGN.md "Workloads"): */
 enum { PO_PROBLEM_QUADRATIC = 0, PO_PROBLEM_CONVEX = 1, PO_PROBLEM_ROSENBROCK = 2 };
 int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon, uint64_t seed,

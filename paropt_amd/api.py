@@ -306,6 +306,35 @@ class Problem:
         self._h = L.po_problem()
         check(lib.po_problem_create_callbacks(ctx.handle, self.nvars, self.ncon, int(ninequality),
                                               C.byref(cb), C.byref(self._h)))
+        # optional second-order callbacks (use_hvec_product / use_diag_hessian): evalHvecProduct(x, z, zw,
+        # px, hvec) and evalHessianDiag(x, z, zw, hdiag) on numpy views, as in paropt.ParOpt
+        has_hvec, has_hdiag = hasattr(self, "evalHvecProduct"), hasattr(self, "evalHessianDiag")
+        if has_hvec or has_hdiag:
+            def _views(x, z, zw):
+                vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+                za = np.array([z[j] for j in range(self.ncon)])
+                zwa = PVec(ctx, handle=L.po_vec(zw), owned=False).to_numpy() if zw else None
+                return vx.to_numpy(), za, zwa
+
+            def _hvec(user, x, z, zw, px, hvec):
+                xa, za, zwa = _views(x, z, zw)
+                vp = PVec(ctx, handle=L.po_vec(px), owned=False)
+                vh = PVec(ctx, handle=L.po_vec(hvec), owned=False)
+                ah = vh.getArray()
+                fail = self.evalHvecProduct(xa, za, zwa, vp.to_numpy(), ah)
+                vh.syncToDevice()
+                return int(fail or 0)
+
+            def _hdiag(user, x, z, zw, hdiag):
+                xa, za, zwa = _views(x, z, zw)
+                vh = PVec(ctx, handle=L.po_vec(hdiag), owned=False)
+                ah = vh.getArray()
+                fail = self.evalHessianDiag(xa, za, zwa, ah)
+                vh.syncToDevice()
+                return int(fail or 0)
+
+            self._hcbs = (L.HVEC_FN(_hvec) if has_hvec else L.HVEC_FN(), L.HDIAG_FN(_hdiag) if has_hdiag else L.HDIAG_FN())
+            check(lib.po_problem_set_hessian_callbacks(self._h, self._hcbs[0], self._hcbs[1]))
         if self.nwcon > 0:
             def _wrap(method):
                 def _f(user, alpha, x, v, out):

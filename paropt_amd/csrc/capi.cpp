@@ -349,6 +349,17 @@ int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequ
   q->nwinequality = nwinequality;
   return PO_OK;
 }
+int po_problem_set_hessian_callbacks(po_problem p, po_hvec_fn hvec, po_hdiag_fn hdiag) {
+  PO_CHECK_PTR(p);
+  CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);
+  if (!q) {
+    po::set_error("po_problem_set_hessian_callbacks needs a callback problem");
+    return PO_ERR_ARG;
+  }
+  q->hvec_fn = hvec;
+  q->hdiag_fn = hdiag;
+  return PO_OK;
+}
 int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstart, int nwskip,
                              int64_t nwinequality) {
   PO_CHECK_PTR(p);

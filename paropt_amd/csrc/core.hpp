@@ -123,7 +123,14 @@ int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, 
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);
 // Dinv = 1/(diag + [L] zl/(x-lb) + [U] zu/(ub-x))   (setUpKKTDiagSystem :1864-1910)
-int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv);
+int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv,
+           const double *hdiag = nullptr);  // hdiag: per-element Hessian diagonal added to `diag`
+// Newton-Krylov support: the alpha-scaled bordered solve (solveKKTDiagSystem :2441-2614)
+int k_d1s(Ctx *c, const Bounds &b, const double *bx, const double *dinv, double alpha, double beta_mu,
+          int64_t n, double *t);
+int k_solve2s(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *coef,
+              const double *const *P, int nv, double alpha, double beta_mu, int full, double tau, int64_t n,
+              double *px, double *pzl, double *pzu, double out[2]);
 // t = Dinv*(rx + [L] rzl/(x-lb) - [U] rzu/(ub-x)) with rzl, rzu recomputed from beta_mu
 // (the d1 build of solveKKTDiagSystem :2091-2108 followed by mat->apply :2139)
 int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
@@ -194,6 +201,10 @@ int k_convex_f(Ctx *c, const double *b, const double *x, int64_t n, double *f);
 int k_convex_g(Ctx *c, const double *b, const double *x, int64_t n, double *g);
 int k_rosen_f(Ctx *c, const double *x, int64_t n, double out[3]);
 int k_rosen_g(Ctx *c, const double *x, int64_t n, double *g, double *a0, double *a1);
+// Lagrangian Hessians of the built-in problems: h = diag(H) (px == null) or H px
+int k_sep_hess(Ctx *c, int kind, const double *q, const double *b, const double *x, const double *px,
+               int64_t n, double *h);
+int k_rosen_hess(Ctx *c, const double *x, double z0, const double *px, int64_t n, double *h);
 
 // ---- host dense algebra (lu.cpp) --------------------------------------------------------------
 // LAPACK-dgetf2-style LU with partial pivoting, column-major, pivots 0-based.  Returns info

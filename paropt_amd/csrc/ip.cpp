@@ -271,6 +271,10 @@ InteriorPoint::InteriorPoint(Problem *p)
       ptpx_valid(false), residual_fused(false), residual_cached(false), corrector_active(false),
       norm_type(0), tdots_valid(false), fused_dots(true), phase_t0(0) {
   qn_handle.qn = nullptr;
+  hdiag = nullptr;
+  vA_valid = false;
+  inexact_newton_step = false;
+  nhvec = 0;
   nw = p->nwcon;
   has_w = false;
   nw_global = 0.0;
@@ -325,6 +329,8 @@ InteriorPoint::~InteriorPoint() {
     vec_decref(wstepv[i]);
   }
   for (Vec *v : Uw) vec_decref(v);
+  for (Vec *v : gmresW) vec_decref(v);
+  vec_decref(hdiag);
   if (qn_owned) delete qn;
 }
 
@@ -500,6 +506,7 @@ int InteriorPoint::initAffineStepMultipliers() {  // :5536-5656
   PO_TRY(computeResidual(0.0, true));
   bool use_qn = !(options.integer("sequential_linear_method") ||
                   !options.integer("use_qn_gmres_precon") || options.integer("use_diag_hessian"));
+  if (options.integer("use_diag_hessian")) PO_TRY(ensureHdiag());
   PO_TRY(setUpKKTSystem(use_qn));
   denseResidual(0.0, res);
   if (has_w) {
@@ -654,8 +661,9 @@ int InteriorPoint::getComplementarity(double *comp) {
 int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDiagSystem + setUpKKTSystem
   ptpx_valid = false;
   const double sigma = options.real("qn_sigma");
-  const double b0 = (qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
-  PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d));
+  const bool use_hdiag = options.integer("use_diag_hessian") && hdiag;  // h_i replaces b0 (:1840-1842)
+  const double b0 = (!use_hdiag && qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
+  PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   int k = 0;
   std::vector<const double *> P = panel(use_qn && !diag_only, &k);
   const int m = c + k;
@@ -762,7 +770,9 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   // so the same pass over P also emits the right-hand side t' of the refinement solve.
   const bool seq_lin = options.integer("sequential_linear_method");
   const int kq = (qn && !seq_lin) ? qn->size() : 0;
-  const bool fuse = fuse_residual && !refine_pass && analytic_panel_dots && kq == k;
+  const bool fuse = fuse_residual && !refine_pass && analytic_panel_dots && kq == k &&
+                    !options.integer("use_diag_hessian") && !inexact_newton_step;
+  vA_valid = true;
   std::vector<double> coef(m > 0 ? m : 1, 0.0);
   double diag = options.real("qn_sigma");
   if (fuse) {
@@ -823,9 +833,22 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
     double diag = options.real("qn_sigma");
-    std::vector<double> coef(mq > 0 ? mq : 1, 0.0);
+    std::vector<double> coef(mq + 1, 0.0);
     for (int i = 0; i < c; i++) coef[i] = step.z[i];
-    if (qn && !options.integer("sequential_linear_method")) {
+    int mres = mq;
+    if (inexact_newton_step || options.integer("use_diag_hessian")) {
+      // addKKTResStep :1461-1473: -H px (Hessian-vector product) or -h o px replaces the whole
+      // quasi-Newton term, sigma included; it rides as one more panel column with coefficient -1
+      diag = 0.0;
+      if (inexact_newton_step) {
+        if (prob->evalHvecProduct(x, vars.z.data(), nullptr, px, xt) != 0) return PO_ERR_USER;
+      } else {
+        PO_TRY(k_mul(ctx, xt->d, 1.0, hdiag->d, px->d, n));
+      }
+      Pq.push_back(xt->d);
+      coef[mq] = -1.0;
+      mres = mq + 1;
+    } else if (qn && !options.integer("sequential_linear_method")) {
       diag += qn->diag();
       if (kq > 0) {
         std::vector<double> rz(dots.begin() + c, dots.begin() + c + kq);
@@ -835,7 +858,7 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
     }
     if (!(it == 0 && residual_fused)) {
       PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, Dinv->d, coef.data(), Pq.data(),
-                        mq, diag, beta_mu, n, tvec->d));
+                        mres, diag, beta_mu, n, tvec->d));
     }
     Dense r2;
     r2.resize(c);
@@ -877,8 +900,8 @@ int InteriorPoint::debugKKTStep(double mu) {
 // ================================================================================================
 // step lengths
 // ================================================================================================
-int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z,
-                                int *ceq) {  // :3196-3274 with computeMaxStep :2942-3103
+int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq,
+                                bool inexact) {  // :3196-3274 with computeMaxStep :2942-3103
   double ax = std::min(1.0, step_mins[0]), az = std::min(1.0, step_mins[1]);
   for (int i = 0; i < c; i++) {
     if (step.s[i] < 0.0) ax = std::min(ax, -tau * vars.s[i] / step.s[i]);
@@ -887,6 +910,25 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
     if (step.zt[i] < 0.0) az = std::min(az, -tau * vars.zt[i] / step.zt[i]);
   }
   *ceq = 0;
+  if (inexact) {  // Newton step: one common step length (:3240-3248)
+    if (ax > az) {
+      ax = az;
+    } else {
+      az = ax;
+    }
+    sx = ax;
+    sz = az;
+    for (int i = 0; i < c; i++) {
+      step.s[i] *= ax;
+      step.t[i] *= ax;
+      step.z[i] *= az;
+      step.zs[i] *= az;
+      step.zt[i] *= az;
+    }
+    *alpha_x = ax;
+    *alpha_z = az;
+    return PO_OK;
+  }
   const double max_bnd = 100.0;
   if (ax > az) {
     if (ax > max_bnd * az) {
@@ -1024,7 +1066,11 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
   const double infeas_proj = infeas > 0.0 ? (pdense + psparse) / infeas : 0.0;
   // pTBp = 0.5 px^T B px  (:3820-3821), B px never formed
   double pTBp = 0.0;
-  if (qn && !seq_lin) {
+  if (options.integer("use_diag_hessian") && hdiag) {  // sum px^2 h (no factor 1/2, :3810-3818)
+    PO_TRY(k_mul(ctx, xt->d, 1.0, hdiag->d, px->d, n));
+    PO_TRY(k_reduce1(ctx, RED_DOT, xt->d, px->d, n, &pTBp));
+    pTBp *= sx * sx;
+  } else if (qn && !seq_lin) {
     double v = qn->diag() * pxpx;
     if (kq > 0) {
       std::vector<double> rz(dots.begin() + c, dots.begin() + c + kq);
@@ -1186,7 +1232,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // iteration's KKT residual rx = [lo]zl - [up]zu - g + A^T z and va = A^T pz (kept by the solves),
   // the second from the NEXT iteration's residual, which is evaluated right after the gradient and
   // reused at the top of the loop.
-  const bool fast_yqn = do_qn && analytic_panel_dots && !has_w;
+  const bool fast_yqn = do_qn && analytic_panel_dots && !has_w && vA_valid;
   if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
   if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
@@ -1293,10 +1339,14 @@ int InteriorPoint::optimize(const char *checkpoint) {
                              : bname == "mehrotra_predictor_corrector" ? B_MPC : B_COMPFRAC;
   int barrier_strategy = B_MONOTONE;  // always start monotone (:4427-4441)
   corrector_active = false;
-  if (options.integer("use_hvec_product") || options.integer("use_diag_hessian")) {
-    set_error("use_hvec_product / use_diag_hessian are not implemented on the device path");
+  const bool use_hvec_product = options.integer("use_hvec_product");
+  const bool use_diag_hessian = options.integer("use_diag_hessian");
+  if (has_w && (use_hvec_product || use_diag_hessian)) {
+    set_error("use_hvec_product / use_diag_hessian with sparse constraints are not implemented on the device path");
     return PO_ERR_OPTION;
   }
+  if (use_diag_hessian) PO_TRY(ensureHdiag());
+  inexact_newton_step = false;
   barrier_param = options.real("init_barrier_param");
   rho_penalty_search = options.real("init_rho_penalty_search");
   const int max_major_iters = options.integer("max_major_iters");
@@ -1307,12 +1357,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const bool use_line_search = options.integer("use_line_search");
   const int write_freq = options.integer("write_output_frequency");
   const std::string start = options.str("starting_point_strategy");
-  niter = neval = ngeval = 0;
+  niter = neval = ngeval = nhvec = 0;
   residual_cached = false;
   history.clear();
   phase_names.clear();
   phase_seconds.clear();
-  if (!seq_lin && !qn) {
+  if (!seq_lin && !qn && !use_diag_hessian) {
     if (ctx->rank == 0)
       fprintf(stderr,
               "ParOpt Error: Must use a sequential linear method if no quasi-Newton approximation "
@@ -1344,6 +1394,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   phaseEnd("init");
 
   double fobj_prev = 0.0, alpha_prev = 0.0, alpha_xprev = 0.0, alpha_zprev = 0.0, dm0_prev = 0.0;
+  double res_norm_prev = 0.0;
   int no_merit_function_improvement = 0, line_search_test = 0, line_search_failed = 0;
   char info[64];
   memset(info, 0, sizeof(info));
@@ -1427,12 +1478,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
       if (k == 0) {
         snprintf(line, sizeof(line),
                  "%4d %4d %4d %4d %7s %7s %7s %12.5e %7.1e %7.1e %7.1e %7.1e %7.1e %8s %7s %s\n", k,
-                 neval, ngeval, 0, "--", "--", "--", fobj, max_prime, max_infeas, max_dual,
+                 neval, ngeval, nhvec, "--", "--", "--", fobj, max_prime, max_infeas, max_dual,
                  barrier_param, comp, "--", "--", info);
       } else {
         snprintf(line, sizeof(line),
                  "%4d %4d %4d %4d %7.1e %7.1e %7.1e %12.5e %7.1e %7.1e %7.1e %7.1e %7.1e %8.1e %7.1e %s\n",
-                 k, neval, ngeval, 0, alpha_prev, alpha_xprev, alpha_zprev, fobj, max_prime,
+                 k, neval, ngeval, nhvec, alpha_prev, alpha_xprev, alpha_zprev, fobj, max_prime,
                  max_infeas, max_dual, barrier_param, comp, dm0_prev, rho_penalty_search, info);
       }
       history += line;
@@ -1459,10 +1510,35 @@ int InteriorPoint::optimize(const char *checkpoint) {
       return 0;
     }
 
+    const bool mehrotra = (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC);
+    double tau = min_frac;
+    if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
+
+    // inexact Newton-Krylov step with exact Hessian-vector products (:4853-4900)
+    int gmres_iters = 0;
+    inexact_newton_step = false;
+    if (use_hvec_product) {
+      const double gmres_rtol =
+          res_norm_prev == 0.0 ? 1e300
+                               : options.real("eisenstat_walker_gamma") *
+                                     pow(res_norm / res_norm_prev, options.real("eisenstat_walker_alpha"));
+      const double nk = options.real("nk_switch_tol");
+      if (max_prime < nk && max_dual < nk && max_infeas < nk && gmres_rtol < options.real("max_gmres_rtol")) {
+        const bool precon_qn = !(seq_lin || !options.integer("use_qn_gmres_precon"));
+        PO_TRY(setUpKKTSystem(precon_qn));
+        PO_TRY(computeKKTGMRESStep(gmres_rtol, options.real("gmres_atol"), precon_qn, tau, &gmres_iters));
+        phaseEnd("gmres_step");
+        // negative: GMRES did not produce a descent direction (:4883-4894), fall back to the quasi-Newton step
+        if (gmres_iters > 0) inexact_newton_step = true;
+      }
+    }
     fobj_prev = fobj;
+    res_norm_prev = res_norm;
     int seq_linear_step = 0, diagonal_quasi_newton_step = 0;
     bool use_qn = !seq_lin;
-    if (!seq_lin && line_search_failed && !use_qnu) {
+    if (inexact_newton_step) {
+      // the step is already in place
+    } else if (!seq_lin && line_search_failed && !use_qnu) {
       // a fixed quasi-Newton approximation whose line search failed (:4923-4939): sequential linear
       // step, or only the diagonal b0 of the approximation when that is positive
       use_qn = false;
@@ -1471,12 +1547,17 @@ int InteriorPoint::optimize(const char *checkpoint) {
         seq_linear_step = 0;
         diagonal_quasi_newton_step = 1;
       }
+    } else if (use_diag_hessian) {  // :4940-4948
+      use_qn = false;
+      if (prob->evalHessianDiag(x, vars.z.data(), nullptr, hdiag) != 0) {
+        fprintf(stderr, "ParOpt: Hessian diagonal evaluation failed\n");
+        return PO_ERR_USER;
+      }
     }
 
-    const bool mehrotra = (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC);
-    double tau = min_frac;
-    if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
-
+    if (inexact_newton_step) {
+      // nothing to do: computeKKTGMRESStep left the step in (px, pzl, pzu, step)
+    } else {
     PO_TRY(setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0));
     phaseEnd("setup_kkt");
     if (!mehrotra) {
@@ -1536,11 +1617,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
         PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
       }
     }
+    }
     phaseEnd("kkt_step");
 
     double alpha_x = 1.0, alpha_z = 1.0;
     int ceq_step = 0;
-    PO_TRY(scaleKKTStep(tau, comp, &alpha_x, &alpha_z, &ceq_step));
+    PO_TRY(scaleKKTStep(tau, comp, &alpha_x, &alpha_z, &ceq_step, inexact_newton_step));
     phaseEnd("scale_step");
 
     double alpha = 1.0;
@@ -1631,6 +1713,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
     }
     {  // info tokens :5272-5322
       std::string s;
+      if (gmres_iters != 0) s += "iNK" + std::to_string(gmres_iters) + " ";
       if (update_type == 1) s += "dampH ";
       else if (update_type == 2) s += "skipH ";
       if (qn_hessian_reset) s += "resetH ";

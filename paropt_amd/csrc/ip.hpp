@@ -89,7 +89,7 @@ class InteriorPoint {
   Dense vars, res, step, refine;
   double fobj, barrier_param, rho_penalty_search;
   std::vector<double> cvals;
-  int niter, neval, ngeval;
+  int niter, neval, ngeval, nhvec;
 
   // observer + history
   bool analytic_panel_dots;  // debugging switch: false re-measures P^T px with an mdot pass
@@ -142,6 +142,17 @@ class InteriorPoint {
   bool tdots_valid;
   bool fused_dots;        // use k_solve2_dots (switch PAROPT_AMD_NO_FUSED_DOTS=1 to compare)
 
+  // ---- second-order information (ip_gmres.cpp) ----
+  Vec *hdiag;                  // use_diag_hessian: diagonal of the Lagrangian Hessian (zero until evaluated)
+  std::vector<Vec *> gmresW;   // Krylov basis of computeKKTGMRESStep
+  bool vA_valid;               // vA = A^T pz of the current step was maintained by the solves
+  bool inexact_newton_step;    // the current step came from computeKKTGMRESStep
+  int ensureHdiag();
+  int solveKKTAlpha(const double *bx, double alpha, const Dense &b, double mu, bool use_qn, bool full,
+                    double tau, Dense &out);
+  int evalObjBarrierDeriv(const Dense &p, double *pmerit);
+  int computeKKTGMRESStep(double rtol, double atol, bool use_qn, double tau, int *gmres_iters);
+
   // ---- sparse-constraint path (ip_w.cpp) ----
   Vec *gsw, *gtw, *Cw, *wd2, *wyw, *wtmp, *wtmp2;
   Vec *d1v;                 // n-sized: raw d1, then v = d1 + P alpha
@@ -177,7 +188,8 @@ class InteriorPoint {
   int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                bool fuse_residual = false);
   int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);
-  int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq);
+  int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq,
+                   bool inexact = false);
   int evalMeritInitDeriv(double max_x, double *merit, double *pmerit);
   double evalMeritFromSums(double fk, const double *ck, const double *sk, const double *tk,
                            double pos, double neg, const double *wsums = nullptr) const;

@@ -1,0 +1,254 @@
+// Second-order branches of the interior point: the diagonal-Hessian variant (use_diag_hessian) and the
+// inexact Newton-Krylov step (use_hvec_product): right-preconditioned GMRES on the KKT system with the
+// quasi-Newton KKT matrix as preconditioner (reference computeKKTGMRESStep,
+// src/ParOptInteriorPoint.cpp:5796-6191).  Each application of the preconditioner is the same fused
+// bordered solve as the quasi-Newton step (one panel-dot pass, host algebra on the replicated
+// (c+k)-sized blocks, one panel-axpy pass), with the right-hand side (bx, alpha * other blocks) of the
+// alpha-scaled overload of solveKKTDiagSystem (:2441-2614); A px and Z^T px come from the weighted Gram
+// matrix W, so the projections fproj / aproj cost one reduction pass.
+#include <math.h>
+
+#include <algorithm>
+
+#include "ip.hpp"
+
+namespace po {
+
+int InteriorPoint::ensureHdiag() {
+  if (hdiag) return PO_OK;
+  hdiag = vec_new(ctx, n);  // zero-initialised, as the reference's hdiag before the first evaluation
+  return hdiag ? PO_OK : PO_ERR_HIP;
+}
+
+// y = [K0 + quasi-Newton low-rank]^-1 (bx, alpha * b_other): px (and pzl, pzu, the step minima when
+// `full`); the dense blocks of `out` carry the low-rank correction only when `full`, exactly as the
+// reference corrects only step.x inside the GMRES loop (:5936-5950) and the whole step at the end
+// (:6142-6160).
+int InteriorPoint::solveKKTAlpha(const double *bx, double alpha, const Dense &b, double mu, bool use_qn,
+                                 bool full, double tau, Dense &out) {
+  const double beta_mu = options.real("rel_bound_barrier") * mu;
+  int k = 0;
+  std::vector<const double *> P = panel(use_qn, &k);
+  if (k != wk) {
+    set_error("internal: panel width changed between setUpKKTSystem and solve (%d vs %d)", k, wk);
+    return PO_ERR_ARG;
+  }
+  const int m = c + k;
+  PO_TRY(k_d1s(ctx, bounds(), bx, Dinv->d, alpha, beta_mu, n, tvec->d));
+  std::vector<double> dots(m > 0 ? m : 1, 0.0);
+  if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
+  for (int i = 0; i < c; i++) {
+    yz[i] = alpha * (b.z[i] + (b.zs[i] + vars.s[i] * b.s[i]) / vars.zs[i] -
+                     (b.zt[i] + vars.t[i] * b.t[i]) / vars.zt[i]) -
+            dots[i];
+  }
+  if (c > 0) lu_solve(c, Gf.data(), c, gpiv.data(), yz.data());
+  if (k > 0) {
+    for (int i = 0; i < k; i++) {
+      double v = dots[c + i];
+      for (int l = 0; l < c; l++) v += W[(c + i) + (size_t)m * l] * yz[l];
+      zeta[i] = v;
+    }
+    lu_solve(k, Cef.data(), k, cpiv.data(), zeta.data());
+    for (int i = 0; i < c; i++) {
+      double v = 0.0;
+      for (int j = 0; j < k; j++) v += W[i + (size_t)m * (c + j)] * zeta[j];
+      yz2[i] = -v;
+    }
+    if (c > 0) lu_solve(c, Gf.data(), c, gpiv.data(), yz2.data());
+  }
+  std::vector<double> coef(m > 0 ? m : 1, 0.0);
+  for (int i = 0; i < c; i++) coef[i] = yz[i] - yz2[i];
+  for (int j = 0; j < k; j++) coef[c + j] = -zeta[j];
+  ptpx.assign(m > 0 ? m : 1, 0.0);
+  for (int i = 0; i < m; i++) {
+    double v = dots[i];
+    for (int j = 0; j < m; j++) v += W[i + (size_t)m * j] * coef[j];
+    ptpx[i] = v;
+  }
+  ptpx_valid = true;
+  tdots_valid = false;
+  residual_fused = false;
+  vA_valid = false;
+  PO_TRY(k_solve2s(ctx, bounds(), tvec->d, Dinv->d, coef.data(), P.data(), m, alpha, beta_mu, full ? 1 : 0, tau,
+                   n, px->d, pzl->d, pzu->d, step_mins));
+  for (int i = 0; i < c; i++) {
+    const double zs1 = yz[i] - alpha * b.s[i];
+    const double zt1 = -alpha * b.t[i] - yz[i];
+    const double y2 = full ? yz2[i] : 0.0;
+    out.z[i] = yz[i] - y2;
+    out.zs[i] = zs1 - y2;
+    out.zt[i] = zt1 + y2;
+    out.s[i] = (alpha * b.zs[i] - vars.s[i] * zs1) / vars.zs[i] + (vars.s[i] * y2) / vars.zs[i];
+    out.t[i] = (alpha * b.zt[i] - vars.t[i] * zt1) / vars.zt[i] - (vars.t[i] * y2) / vars.zt[i];
+  }
+  return PO_OK;
+}
+
+// evalObjBarrierDeriv :5669-5766 for the step (px, p.s, p.t): the merit derivative without the penalty
+int InteriorPoint::evalObjBarrierDeriv(const Dense &p, double *pmerit_) {
+  const double beta = options.real("rel_bound_barrier");
+  double out[6];
+  PO_TRY(k_merit0(ctx, bounds(), px->d, 1.0, g->d, n, out));
+  double ppos = out[2] * beta, pneg = out[3] * beta;
+  for (int i = 0; i < c; i++) {
+    if (p.s[i] > 0.0) ppos += p.s[i] / vars.s[i]; else pneg += p.s[i] / vars.s[i];
+    if (p.t[i] > 0.0) ppos += p.t[i] / vars.t[i]; else pneg += p.t[i] / vars.t[i];
+  }
+  double pmerit = out[4] - barrier_param * (ppos + pneg);
+  for (int i = 0; i < c; i++) pmerit += gamma_s[i] * p.s[i] + gamma_t[i] * p.t[i];
+  *pmerit_ = pmerit;
+  return PO_OK;
+}
+
+int InteriorPoint::computeKKTGMRESStep(double rtol, double atol, bool use_qn, double tau, int *gmres_iters) {
+  const int msub = options.integer("gmres_subspace_size");
+  *gmres_iters = 0;
+  if (msub <= 0) {
+    if (ctx->rank == 0) fprintf(stderr, "ParOpt error: gmres_subspace_size not set\n");
+    return PO_OK;
+  }
+  while ((int)gmresW.size() < msub + 1) {
+    Vec *w = vec_new(ctx, n);
+    if (!w) return PO_ERR_HIP;
+    gmresW.push_back(w);
+  }
+  std::vector<Vec *> &Wk = gmresW;
+  const double mu = barrier_param;
+  denseResidual(mu, res);
+  std::vector<double> H((size_t)(msub + 1) * (msub + 2) / 2, 0.0), alpha(msub + 1, 0.0), gres(msub + 1, 0.0),
+      y(msub, 0.0), fproj(msub, 0.0), aproj(msub, 0.0), Qcos(msub, 0.0), Qsin(msub, 0.0);
+  // |b|: the x block from the residual pass, the bound blocks from its sums, the dense blocks here
+  double beta = 0.0;
+  for (int i = 0; i < c; i++) {
+    beta += res.z[i] * res.z[i] + res.s[i] * res.s[i] + res.t[i] * res.t[i] + res.zs[i] * res.zs[i] +
+            res.zt[i] * res.zt[i];
+  }
+  if (use_lower) beta += l2_rzl;
+  if (use_upper) beta += l2_rzu;
+  const double bnorm = sqrt(l2_rx + beta);
+  beta *= 1.0 / (bnorm * bnorm);
+  double cinfeas = 0.0, cscale = 0.0;
+  for (int i = 0; i < c; i++) cinfeas += (cvals[i] - vars.s[i] + vars.t[i]) * (cvals[i] - vars.s[i] + vars.t[i]);
+  if (cinfeas != 0.0) {
+    cinfeas = sqrt(cinfeas);
+    cscale = 1.0 / cinfeas;
+  }
+  gres[0] = bnorm;
+  PO_TRY(k_panel_axpy(ctx, Wk[0]->d, 1.0 / gres[0], rx->d, 0.0, nullptr, nullptr, 0, n));
+  alpha[0] = 1.0;
+  int niters = 0;
+  Dense p;
+  p.resize(c);
+  const int kq = (qn && use_qn) ? qn->size() : 0;
+  std::vector<const double *> Z;
+  if (kq > 0) Z = qn->zPointers();
+  for (int i = 0; i < msub; i++) {
+    PO_TRY(solveKKTAlpha(Wk[i]->d, alpha[i] / bnorm, res, mu, use_qn, false, tau, p));
+    PO_TRY(evalObjBarrierDeriv(p, &fproj[i]));
+    aproj[i] = 0.0;
+    for (int j = 0; j < c; j++) aproj[i] -= cscale * res.z[j] * (ptpx[j] - p.s[j] + p.t[j]);
+    // W_{i+1} = H px - B px + W_i
+    if (prob->evalHvecProduct(x, vars.z.data(), nullptr, px, Wk[i + 1]) != 0) {
+      set_error("evalHvecProduct failed or is not provided by the problem");
+      return PO_ERR_USER;
+    }
+    nhvec++;
+    {
+      std::vector<double> cf(kq + 1, 0.0);
+      std::vector<const double *> V;
+      V.push_back(px->d);
+      if (qn && use_qn) {
+        cf[0] = -qn->diag();
+        if (kq > 0) {
+          std::vector<double> rz(ptpx.begin() + c, ptpx.begin() + c + kq);
+          qn->applyCompactInverse(rz.data());
+          for (int j = 0; j < kq; j++) cf[1 + j] = rz[j];
+          V.insert(V.end(), Z.begin(), Z.end());
+        }
+      }
+      PO_TRY(k_panel_axpy(ctx, Wk[i + 1]->d, 1.0, Wk[i]->d, 1.0, cf.data(), V.data(), (int)V.size(), n));
+    }
+    alpha[i + 1] = alpha[i];
+    const int hptr = (i + 1) * (i + 2) / 2 - 1;
+    for (int j = i; j >= 0; j--) {  // modified Gram-Schmidt, as the reference (:5986-5996)
+      double d = 0.0;
+      PO_TRY(k_reduce1(ctx, RED_DOT, Wk[i + 1]->d, Wk[j]->d, n, &d));
+      H[j + hptr] = d + beta * alpha[i + 1] * alpha[j];
+      PO_TRY(k_axpy(ctx, Wk[i + 1]->d, -H[j + hptr], Wk[j]->d, n));
+      alpha[i + 1] -= H[j + hptr] * alpha[j];
+    }
+    double nrm2 = 0.0;
+    PO_TRY(k_reduce1(ctx, RED_SUMSQ, Wk[i + 1]->d, nullptr, n, &nrm2));
+    H[i + 1 + hptr] = sqrt(nrm2 + beta * alpha[i + 1] * alpha[i + 1]);
+    PO_TRY(k_scale(ctx, Wk[i + 1]->d, n, 1.0 / H[i + 1 + hptr]));
+    alpha[i + 1] *= 1.0 / H[i + 1 + hptr];
+    for (int kk = 0; kk < i; kk++) {
+      const double h1 = H[kk + hptr], h2 = H[kk + 1 + hptr];
+      H[kk + hptr] = h1 * Qcos[kk] + h2 * Qsin[kk];
+      H[kk + 1 + hptr] = -h1 * Qsin[kk] + h2 * Qcos[kk];
+    }
+    double h1 = H[i + hptr], h2 = H[i + 1 + hptr];
+    const double sq = sqrt(h1 * h1 + h2 * h2);
+    Qcos[i] = h1 / sq;
+    Qsin[i] = h2 / sq;
+    H[i + hptr] = h1 * Qcos[i] + h2 * Qsin[i];
+    H[i + 1 + hptr] = -h1 * Qsin[i] + h2 * Qcos[i];
+    h1 = gres[i];
+    gres[i] = h1 * Qcos[i];
+    gres[i + 1] = -h1 * Qsin[i];
+    niters++;
+    for (int j = niters - 1; j >= 0; j--) {
+      y[j] = gres[j];
+      for (int kk = j + 1; kk < niters; kk++) {
+        const int hp = (kk + 1) * (kk + 2) / 2 - 1;
+        y[j] = y[j] - H[j + hp] * y[kk];
+      }
+      const int hp = (j + 1) * (j + 2) / 2 - 1;
+      y[j] = y[j] / H[j + hp];
+    }
+    double fpr = 0.0, cpr = 0.0;
+    for (int j = 0; j < niters; j++) {
+      fpr += y[j] * fproj[j];
+      cpr += y[j] * aproj[j];
+    }
+    const bool constraint_descent = cpr <= -0.01 * cinfeas;
+    if (fpr < 0.0 || constraint_descent) {
+      if (fabs(gres[i + 1]) < atol || fabs(gres[i + 1]) < rtol * bnorm) break;
+    }
+  }
+  for (int i = niters - 1; i >= 0; i--) {
+    for (int j = i + 1; j < niters; j++) {
+      const int hp = (j + 1) * (j + 2) / 2 - 1;
+      gres[i] = gres[i] - H[i + hp] * gres[j];
+    }
+    const int hp = (i + 1) * (i + 2) / 2 - 1;
+    gres[i] = gres[i] / H[i + hp];
+  }
+  // u_x = sum gres_i W_i ; gamma scales every other block of the right-hand side
+  double gamma = gres[0] * alpha[0];
+  {
+    std::vector<const double *> V;
+    std::vector<double> cf;
+    for (int i = 1; i < niters; i++) {
+      V.push_back(Wk[i]->d);
+      cf.push_back(gres[i]);
+      gamma += gres[i] * alpha[i];
+    }
+    PO_TRY(k_panel_axpy(ctx, Wk[0]->d, 0.0, nullptr, gres[0], cf.data(), V.data(), (int)V.size(), n));
+  }
+  gamma /= bnorm;
+  PO_TRY(solveKKTAlpha(Wk[0]->d, gamma, res, mu, use_qn, true, tau, step));
+  sx = sz = 1.0;
+  double fpr = 0.0, cpr = 0.0;
+  PO_TRY(evalObjBarrierDeriv(step, &fpr));
+  for (int i = 0; i < c; i++) {
+    const double deriv = ptpx[i] - step.s[i] + step.t[i];
+    cpr += cscale * (cvals[i] - vars.s[i] + vars.t[i]) * deriv;
+  }
+  *gmres_iters = (fpr < 0.0 || cpr < -0.01 * cinfeas) ? niters : -niters;
+  return PO_OK;
+}
+
+}  // namespace po

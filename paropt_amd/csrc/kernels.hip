@@ -806,15 +806,18 @@ __device__ __forceinline__ double dinv_elem(const BE &e, double diag) {
   return 1.0 / v;
 }
 __global__ void __launch_bounds__(kBlock)
-    dinv_kernel(Bounds b, double diag, int64_t n, double *__restrict__ dinv) {
+    dinv_kernel(Bounds b, double diag, const double *__restrict__ hdiag, int64_t n,
+                double *__restrict__ dinv) {
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
-    st2(dinv, q, n, make_double2(dinv_elem(e0, diag), dinv_elem(e1, diag)));
+    double2 h = make_double2(0.0, 0.0);
+    if (hdiag) h = ld2(hdiag, q, n);  // use_diag_hessian: b0 -> h_i (:1840-1842)
+    st2(dinv, q, n, make_double2(dinv_elem(e0, diag + h.x), dinv_elem(e1, diag + h.y)));
   }
 }
-int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv) {
+int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv, const double *hdiag) {
   if (n <= 0) return PO_OK;
-  PO_LAUNCH(dinv_kernel, grid_for(c, n), b, diag, n, dinv);
+  PO_LAUNCH(dinv_kernel, grid_for(c, n), b, diag, hdiag, n, dinv);
   return PO_OK;
 }
 
@@ -1528,6 +1531,152 @@ int k_quadratic_g(Ctx *c, const double *q, const double *b, const double *x, int
 int k_convex_g(Ctx *c, const double *b, const double *x, int64_t n, double *g) {
   if (n <= 0) return PO_OK;
   PO_LAUNCH(sep_g_kernel<1>, grid_for(c, n), (const double *)nullptr, b, x, n, g);
+  return PO_OK;
+}
+
+// Hessian of the Lagrangian of the separable workloads: diag h_i, or h_i * px_i when px != null
+template <int KIND>
+__global__ void __launch_bounds__(kBlock)
+    sep_h_kernel(const double *__restrict__ qv, const double *__restrict__ bv,
+                 const double *__restrict__ x, const double *__restrict__ px, int64_t n,
+                 double *__restrict__ h) {
+  PO_PAIR_LOOP(q, n) {
+    double2 r;
+    if (KIND == 0) {
+      r = ld2(qv, q, n);
+    } else {
+      const double2 xv = ld2(x, q, n), b = ld2(bv, q, n);
+      const double d0 = 1e-3 + xv.x, d1 = 1e-3 + xv.y;
+      r.x = 2.0 * b.x * b.x / (d0 * d0 * d0);
+      r.y = 2.0 * b.y * b.y / (d1 * d1 * d1);
+    }
+    if (px) {
+      const double2 p = ld2(px, q, n);
+      r.x *= p.x;
+      r.y *= p.y;
+    }
+    st2(h, q, n, r);
+  }
+}
+int k_sep_hess(Ctx *c, int kind, const double *q, const double *b, const double *x, const double *px,
+               int64_t n, double *h) {
+  if (n <= 0) return PO_OK;
+  if (kind == 0) {
+    PO_LAUNCH(sep_h_kernel<0>, grid_for(c, n), q, b, x, px, n, h);
+  } else {
+    PO_LAUNCH(sep_h_kernel<1>, grid_for(c, n), q, b, x, px, n, h);
+  }
+  return PO_OK;
+}
+// chained Rosenbrock + z0 * (0.25 - sum x^2): tridiagonal Hessian times px, or its diagonal
+__global__ void __launch_bounds__(kBlock)
+    rosen_h_kernel(const double *__restrict__ x, double z0, const double *__restrict__ px, int64_t n,
+                   double *__restrict__ h) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double xi = x[i];
+    double d = 2.0 * z0, lo = 0.0, up = 0.0;  // diagonal, coupling to i-1, coupling to i+1
+    if (i + 1 < n) {
+      d += 2.0 - 400.0 * (x[i + 1] - xi * xi) + 800.0 * xi * xi;
+      up = -400.0 * xi;
+    }
+    if (i > 0) {
+      d += 200.0;
+      lo = -400.0 * x[i - 1];
+    }
+    if (px) {
+      double v = d * px[i];
+      if (i + 1 < n) v += up * px[i + 1];
+      if (i > 0) v += lo * px[i - 1];
+      h[i] = v;
+    } else {
+      h[i] = d;
+    }
+  }
+}
+int k_rosen_hess(Ctx *c, const double *x, double z0, const double *px, int64_t n, double *h) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(rosen_h_kernel, grid_for(c, n), x, z0, px, n, h);
+  return PO_OK;
+}
+
+// ---- Newton-Krylov support: the alpha-scaled bordered solve of solveKKTDiagSystem :2441-2614 ---------
+// t = Dinv * (bx + alpha * ([L] rzl/(x-lb) - [U] rzu/(ub-x))), rzl / rzu recomputed from beta_mu
+__global__ void __launch_bounds__(kBlock)
+    d1s_kernel(Bounds b, const double *__restrict__ bx, const double *__restrict__ dinv, double alpha,
+               double beta_mu, int64_t n, double *__restrict__ t) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 r = ld2(bx, q, n), dv = ld2(dinv, q, n);
+    double d0 = r.x, d1 = r.y;
+    if (e0.L) d0 += alpha * (-(e0.xl * e0.zl - beta_mu)) / e0.xl;
+    if (e0.U) d0 -= alpha * (-(e0.xu * e0.zu - beta_mu)) / e0.xu;
+    if (e1.L) d1 += alpha * (-(e1.xl * e1.zl - beta_mu)) / e1.xl;
+    if (e1.U) d1 -= alpha * (-(e1.xu * e1.zu - beta_mu)) / e1.xu;
+    st2(t, q, n, make_double2(dv.x * d0, dv.y * d1));
+  }
+}
+int k_d1s(Ctx *c, const Bounds &b, const double *bx, const double *dinv, double alpha, double beta_mu,
+          int64_t n, double *t) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(d1s_kernel, grid_for(c, n), b, bx, dinv, alpha, beta_mu, n, t);
+  return PO_OK;
+}
+// px = t + Dinv * sum coef_j P_j ; FULL: pzl = [L](alpha rzl - zl px)/(x-lb), pzu = [U](alpha rzu + zu px)/(ub-x)
+// and the fraction-to-boundary minima {max_x, max_z} with fraction tau
+template <int FULL>
+__global__ void __launch_bounds__(kBlock)
+    solve2s_kernel(Bounds b, const double *__restrict__ t, const double *__restrict__ dinv, CoefTable coef,
+                   PtrTable P, int nv, double alpha, double beta_mu, double tau, int64_t n,
+                   double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
+                   double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double mins[2] = {1.0, 1.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 acc = panel_sum(P, coef, nv, q);
+    const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
+    const double p0 = tv.x + dv.x * acc.x, p1 = tv.y + dv.y * acc.y;
+    if (FULL) {
+      PO_LOAD_BOUNDS(b, q, n);
+      Step3 s0, s1;
+      s0.px = p0;
+      s1.px = p1;
+      s0.pzl = e0.L ? (alpha * (-(e0.xl * e0.zl - beta_mu)) - e0.zl * p0) / e0.xl : 0.0;
+      s0.pzu = e0.U ? (alpha * (-(e0.xu * e0.zu - beta_mu)) + e0.zu * p0) / e0.xu : 0.0;
+      s1.pzl = e1.L ? (alpha * (-(e1.xl * e1.zl - beta_mu)) - e1.zl * p1) / e1.xl : 0.0;
+      s1.pzu = e1.U ? (alpha * (-(e1.xu * e1.zu - beta_mu)) + e1.zu * p1) / e1.xu : 0.0;
+      if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+      st2(px, q, n, make_double2(s0.px, s1.px));
+      st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+      st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+      max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+      if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+    } else {
+      st2(px, q, n, make_double2(p0, p1));
+    }
+  }
+  if (FULL) block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
+}
+int k_solve2s(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *coef,
+              const double *const *P, int nv, double alpha, double beta_mu, int full, double tau, int64_t n,
+              double *px, double *pzl, double *pzu, double out[2]) {
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int grid = grid_for(c, n, 3);
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(coef, P, nv, &ct, &pt);
+  if (full) {
+    PO_TRY(ensure_partials(c, (size_t)grid * 2));
+    PO_LAUNCH((solve2s_kernel<1>), grid, b, t, dinv, ct, pt, nv, alpha, beta_mu, tau, n, px, pzl, pzu,
+              c->d_partials);
+    return reduce_finish(c, grid, 0, 2, 0, out);
+  }
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH((solve2s_kernel<0>), grid, b, t, dinv, ct, pt, nv, alpha, beta_mu, tau, n, px, pzl, pzu,
+            c->d_partials);
   return PO_OK;
 }
 

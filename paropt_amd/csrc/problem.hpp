@@ -22,6 +22,9 @@ class Problem {
   virtual int writeOutput(int iter, Vec *x) { return 0; }
   virtual int useLowerBounds() { return 1; }
   virtual int useUpperBounds() { return 1; }
+  // Hessian of the Lagrangian f - z^T c - zw^T cw (src/ParOptProblem.h:160-189); non-zero = not available
+  virtual int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) { return 1; }
+  virtual int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) { return 1; }
   // sparse constraints (src/ParOptProblem.h:215-262); out / pzw / A are w-sized device vectors
   virtual int evalSparseCon(Vec *x, Vec *out) { return 0; }
   virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) { return 0; }
@@ -57,8 +60,12 @@ class CallbackProblem : public Problem {
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
+  int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
+  int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   po_problem_callbacks cb;
   SparseCallbacks sparse;
+  po_hvec_fn hvec_fn = nullptr;
+  po_hdiag_fn hdiag_fn = nullptr;
 };
 
 // Device-resident separable workloads (DESIGN.md "Workloads").
@@ -80,6 +87,8 @@ class SeparableProblem : public Problem {
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;
+  int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
+  int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   GroupMap gmap;
 
   int kind;

@@ -71,6 +71,16 @@ int CallbackProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec 
                                             static_cast<po_vec>(cvec), static_cast<po_vec>(A));
 }
 
+int CallbackProblem::evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) {
+  if (!hvec_fn) return 1;
+  return hvec_fn(cb.user, static_cast<po_vec>(x), z, static_cast<po_vec>(zw), static_cast<po_vec>(px),
+                 static_cast<po_vec>(hvec));
+}
+int CallbackProblem::evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) {
+  if (!hdiag_fn) return 1;
+  return hdiag_fn(cb.user, static_cast<po_vec>(x), z, static_cast<po_vec>(zw), static_cast<po_vec>(hdiag));
+}
+
 // ---- separable workloads ----------------------------------------------------------------------
 SeparableProblem::SeparableProblem(Ctx *c, int kind_, int64_t nglobal_, int ncon_, uint64_t seed_,
                                    double eig_min_, double eig_max_)
@@ -179,6 +189,18 @@ int SeparableProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec
 int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
                                           double *const *U, Vec *work) {
   return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
+}
+
+// the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
+int SeparableProblem::evalHvecProduct(Vec *x, const double *z, Vec *, Vec *px, Vec *hvec) {
+  if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], px->d, nlocal, hvec->d) != PO_OK;
+  return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, px->d, nlocal,
+                    hvec->d) != PO_OK;
+}
+int SeparableProblem::evalHessianDiag(Vec *x, const double *z, Vec *, Vec *hdiag) {
+  if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], nullptr, nlocal, hdiag->d) != PO_OK;
+  return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, nullptr, nlocal,
+                    hdiag->d) != PO_OK;
 }
 
 int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {

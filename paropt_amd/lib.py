@@ -38,6 +38,8 @@ EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p)
 GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p)
 QNCORR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec)
 WRITE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, po_vec)
+HVEC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec, po_vec)
+HDIAG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec, po_vec)
 EIG_UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_eig)
 TR_ITER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 SPARSE_CON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec)
@@ -120,6 +122,7 @@ SIGNATURES = {
     ),
     "po_problem_set_sparse_callbacks": (
         C.c_int, [po_problem, C.c_int64, C.c_int64, C.POINTER(ProblemSparseCallbacks)]),
+    "po_problem_set_hessian_callbacks": (C.c_int, [po_problem, HVEC_FN, HDIAG_FN]),
     "po_problem_set_weighting": (C.c_int, [po_problem, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64]),
     "po_problem_sparse_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p]),
     "po_problem_destroy": (C.c_int, [po_problem]),
