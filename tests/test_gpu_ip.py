@@ -292,6 +292,52 @@ def test_weighting_large_vs_oracle(ctx):
         np.testing.assert_allclose(a["wnorms"], b["wnorms"], rtol=1e-6, err_msg="wnorms @%d" % k)
 
 
+def test_python_hessian_callbacks(ctx):
+    """evalHvecProduct / evalHessianDiag through the callback boundary (use_hvec_product with the
+    GMRES inexact Newton step, use_diag_hessian): a Python problem against the built-in one and the
+    reference's golden trajectories."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    n = 100
+    op = po.SepProblem("rosenbrock", n, 2)
+
+    class Rosen(pa.Problem):
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = -1.0, -2.0, 1.0
+
+        def evalObjCon(self, x):
+            return op.eval_obj_con(x)
+
+        def evalObjConGradient(self, x, g, A):
+            _, gg, aa = op.eval_obj_con_gradient(x)
+            g[:] = gg
+            A[0][:], A[1][:] = aa[0], aa[1]
+            return 0
+
+        def evalHvecProduct(self, x, z, zw, px, hvec):
+            hvec[:] = op.hvec_product(x, z, px)
+            return 0
+
+        def evalHessianDiag(self, x, z, zw, hdiag):
+            hdiag[:] = op.hessian_diag(x, z)
+            return 0
+
+    for name in ("ip_rosenbrock_hvec_n100", "ip_rosenbrock_diaghess_n100"):
+        g, case = load_golden(name)
+        opts = ip_options_from_case(case)
+        opts["write_output_frequency"] = 0
+        ip1 = pa.InteriorPoint(Rosen(ctx, n, 2), opts)
+        ip1.optimize()
+        ip2 = pa.InteriorPoint(pa.SeparableProblem(ctx, "rosenbrock", n), opts)
+        ip2.optimize()
+        assert ip1.getIterationCounters() == ip2.getIterationCounters()
+        np.testing.assert_array_equal(np.array(ip1.getIterationCounters()), g["final/counters"])
+        np.testing.assert_allclose(ip1.getOptimizedPoint()[0].to_numpy(), g["final/x"], rtol=0, atol=1e-6)
+        if "hvec" in name:
+            assert "iNK" in ip1.getHistory()
+
+
 def test_option_errors(ctx):
     import paropt_amd as pa
 
