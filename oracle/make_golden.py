@@ -346,6 +346,14 @@ case("ip_convex_diaghess_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs
 case("ip_rosenbrock_diaghess_n100", "ip", problem="rosenbrock", n=100, dump_vecs_every=10,
      **{"opt.use_diag_hessian": 1, "opt.qn_subspace_size": 10, "opt.abs_res_tol": 1e-6,
         "opt.write_output_frequency": 1, "opt.max_major_iters": 150})
+# --- method of moving asymptotes (ParOptOptimizer algorithm = "mma", src/ParOptMMA.cpp) ---
+case("mma_convex_n300_c3", "mma", problem="convex", n=300, c=3, **{"mma.mma_max_iterations": 30})
+case("mma_quadratic_n200_c2", "mma", problem="quadratic", n=200, c=2, **{"mma.mma_max_iterations": 25})
+case("mma_rosenbrock_n60", "mma", problem="rosenbrock", n=60, **{"mma.mma_max_iterations": 25, "opt.abs_res_tol": 1e-7})
+case("mma_convex_n200_c2_linearized", "mma", problem="convex", n=200, c=2,
+     **{"mma.mma_max_iterations": 25, "mma.mma_use_constraint_linearization": 1, "mma.mma_bound_relax": 1e-4})
+case("mma_convex_n200_c2_w40", "mma", problem="convex", n=200, c=2, nwcon=40, nw=5, nwstart=0, nwskip=0,
+     **{"mma.mma_max_iterations": 20})
 # --- trust-region driver: ParOptOptimizer's algorithm="tr" set-up ---
 tr_common = {"opt.qn_subspace_size": 5, "tr.tr_max_iterations": 60}
 case("tr_quadratic_n200_c3_bfgs", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10, **tr_common)
@@ -424,6 +432,8 @@ def main():
                 dargs["text"] = os.path.join(td, "paropt.out")
             if mode == "tr":
                 dargs["text"] = os.path.join(td, "paropt.tr")
+            if mode == "mma":
+                dargs["text"] = os.path.join(td, "paropt.mma")
             if dargs.get("checkpoint"):
                 dargs["checkpoint"] = os.path.join(td, "checkpoint.bin")
             run_driver(mode, dargs, ranks)
@@ -442,6 +452,11 @@ def main():
                     lines = [ln.rstrip("\n") for ln in f]
                 start = next((i for i, ln in enumerate(lines) if ln.strip().startswith("iter ")), 0)
                 d["paropt_tr"] = np.array("\n".join(lines[start:]))
+            if mode == "mma":
+                with open(dargs["text"]) as f:
+                    lines = [ln.rstrip("\n") for ln in f]
+                start = next((i for i, ln in enumerate(lines) if ln.strip().startswith("MMA ")), 0)
+                d["paropt_mma"] = np.array("\n".join(lines[start:]))
         d["case_json"] = np.array(json.dumps(dict(mode=mode, ranks=ranks, args=args)))
         path = os.path.join(GOLDEN, name + ".npz")
         np.savez_compressed(path, **d)

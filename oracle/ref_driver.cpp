@@ -38,6 +38,7 @@
 #include "ParOptQuasiNewton.h"
 #include "ParOptTrustRegion.h"
 #include "ParOptCompactEigenvalueApprox.h"
+#include "ParOptMMA.h"
 #undef private
 #undef protected
 
@@ -911,6 +912,73 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   return 0;
 }
 
+// Method of moving asymptotes (src/ParOptMMA.cpp) with the interior point as sub-solver, set up as
+// ParOptOptimizer::optimize does for algorithm = "mma" (src/ParOptOptimizer.cpp:184-204).
+static int mode_mma(std::map<std::string, std::string> &A, MPI_Comm comm, int rank, int size, bool bench) {
+  int64_t n = geti(A, "n", 1000);
+  int c = (int)geti(A, "c", 8);
+  uint64_t seed = (uint64_t)geti(A, "seed", 0);
+  std::string pname = gets(A, "problem", "quadratic");
+  SepProblem::Kind kind = kind_of(pname);
+  if (kind == SepProblem::ROSENBROCK) c = 2;
+  int nlocal;
+  int64_t offset;
+  shard(n, rank, size, &nlocal, &offset);
+  SepProblem *prob = new SepProblem(comm, kind, nlocal, offset, n, c, seed, getf(A, "eig_min", 1.0),
+                                    getf(A, "eig_max", 100.0), (int)geti(A, "nwcon", 0),
+                                    (int)geti(A, "nw", 0), (int)geti(A, "nwstart", 0),
+                                    (int)geti(A, "nwskip", 0), (int)geti(A, "nwineq", -1));
+  prob->incref();
+  ParOptOptions *opt = new ParOptOptions(comm);
+  opt->incref();
+  ParOptInteriorPoint::addDefaultOptions(opt);
+  ParOptMMA::addDefaultOptions(opt);
+  opt->setOption("output_file", "/dev/null");
+  std::string mfile = gets(A, "text", "");
+  opt->setOption("mma_output_file", mfile.size() ? mfile.c_str() : "/dev/null");
+  set_options(opt, A);
+  for (std::map<std::string, std::string>::iterator it = A.begin(); it != A.end(); ++it) {
+    if (it->first.compare(0, 4, "mma.") != 0) continue;
+    std::string name = it->first.substr(4);
+    int t = opt->getOptionType(name.c_str());
+    if (t == ParOptOptions::PAROPT_FLOAT_OPTION) {
+      opt->setOption(name.c_str(), atof(it->second.c_str()));
+    } else if (t == ParOptOptions::PAROPT_INT_OPTION || t == ParOptOptions::PAROPT_BOOLEAN_OPTION) {
+      opt->setOption(name.c_str(), atoi(it->second.c_str()));
+    } else {
+      opt->setOption(name.c_str(), it->second.c_str());
+    }
+  }
+  ParOptMMA *mma = new ParOptMMA(prob, opt);
+  mma->incref();
+  ParOptInteriorPoint *ip = new ParOptInteriorPoint(mma, opt);
+  ip->incref();
+  double t0 = MPI_Wtime();
+  mma->optimize(ip);
+  double t1 = MPI_Wtime();
+  RecFile R;
+  if (!bench) {
+    if (rank == 0) R.open(gets(A, "out", "mma.rec").c_str());
+    R.i32s("n", (int)n);
+    R.i32s("c", c);
+    int it[2] = {mma->mma_iter, mma->subproblem_iter};
+    R.i32("final/iters", it, 2);
+    R.f64s("final/fobj", mma->fobj);
+    R.f64("final/cons", mma->cons, c);
+    R.f64("final/z", mma->z, c);
+    double nr[3] = {mma->xvec->norm(), mma->Lvec->norm(), mma->Uvec->norm()};
+    R.f64("final/norms", nr, 3);
+    R.vec("final/x", mma->xvec);
+    R.close();
+  }
+  if (rank == 0) {
+    printf("{\"mode\":\"mma\",\"problem\":\"%s\",\"n\":%ld,\"c\":%d,\"ranks\":%d,\"mma_iters\":%d,"
+           "\"sub_iters\":%d,\"seconds\":%.6f,\"fobj\":%.17g}\n",
+           pname.c_str(), (long)n, c, size, mma->mma_iter, mma->subproblem_iter, t1 - t0, mma->fobj);
+  }
+  return 0;
+}
+
 static int mode_mdot_bench(std::map<std::string, std::string> &A, MPI_Comm comm, int rank,
                            int size) {
   int64_t n = geti(A, "n", 10000000);
@@ -962,6 +1030,8 @@ int main(int argc, char *argv[]) {
     if (mode == "mdot") rc = mode_mdot_bench(A, comm, rank, size);
     if (mode == "tr") rc = mode_tr(A, comm, rank, size, false);
     if (mode == "trbench") rc = mode_tr(A, comm, rank, size, true);
+    if (mode == "mma") rc = mode_mma(A, comm, rank, size, false);
+    if (mode == "mmabench") rc = mode_mma(A, comm, rank, size, true);
   } else if (rank == 0) {
     fprintf(stderr, "usage: ref_driver vecops|qn|ip|bench|mdot|tr|trbench key=value ...\n");
   }

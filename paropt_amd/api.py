@@ -39,13 +39,23 @@ class Context:
         rank, size = dist.get_rank(), dist.get_world_size()
         if size == 1:
             return
+
+        def _all_ok(flag, what):
+            # every rank takes the same decision, so a failure on one rank cannot leave the others
+            # waiting inside a collective
+            flags = [None] * size
+            dist.all_gather_object(flags, bool(flag))
+            if not all(flags):
+                raise RuntimeError("%s failed on rank(s) %s" % (what, [r for r, f in enumerate(flags) if not f]))
+
+        # 1. librccl loads and hands out an id on EVERY rank (dlopen + symbols), before any collective
         buf = (C.c_char * 128)()
-        if rank == 0:
-            check(lib.po_rccl_unique_id(buf))
+        _all_ok(lib.po_rccl_unique_id(buf) == 0, "loading RCCL")
+        # 2. rank 0's id to everyone, collective init, and agreement that it worked
         obj = [bytes(buf) if rank == 0 else None]
         dist.broadcast_object_list(obj, src=0)
         idbuf = (C.c_char * 128).from_buffer_copy(obj[0])
-        check(lib.po_ctx_comm_init_rccl(self._h, rank, size, idbuf))
+        _all_ok(lib.po_ctx_comm_init_rccl(self._h, rank, size, idbuf) == 0, "ncclCommInitRank")
 
     def init_callback_from_torch(self, device=None):
         """Host-side allgather through torch.distributed (gloo, or nccl with `device`): the
