@@ -108,6 +108,14 @@ class ParOptOptions : public ParOptBase {
     for (auto &kv : f) bad |= po_tr_set_option_float(tr, kv.first.c_str(), kv.second);
     return bad;
   }
+  int apply(po_mma mma) {
+    int bad = 0;
+    for (auto &kv : s)
+      if (kv.first != "algorithm") bad |= po_mma_set_option_str(mma, kv.first.c_str(), kv.second.c_str());
+    for (auto &kv : i) bad |= po_mma_set_option_int(mma, kv.first.c_str(), kv.second);
+    for (auto &kv : f) bad |= po_mma_set_option_float(mma, kv.first.c_str(), kv.second);
+    return bad;
+  }
   const char *getStringOption(const char *name, const char *def) {
     std::map<std::string, std::string>::iterator it = s.find(name);
     return it == s.end() ? def : it->second.c_str();
@@ -429,13 +437,13 @@ class ParOptInteriorPoint : public ParOptBase {
   ParOptVec *x, *zl, *zu, *zw, *sw, *tw;
 };
 
-// ---- ParOptOptimizer: algorithm = "ip" | "tr" (src/ParOptOptimizer.cpp:65-206) ----------------------
+// ---- ParOptOptimizer: algorithm = "ip" | "tr" | "mma" (src/ParOptOptimizer.cpp:65-206) --------------
 // The reference's generic entry point.  "tr" builds the quasi-Newton object, the quadratic
 // subproblem, the interior-point sub-solver and the trust-region driver exactly as :108-183 does.
 class ParOptOptimizer : public ParOptBase {
  public:
   ParOptOptimizer(ParOptProblem *_prob, ParOptOptions *_options)
-      : prob(_prob), options(_options), ip(NULL), tr(NULL), x(NULL) {
+      : prob(_prob), options(_options), ip(NULL), tr(NULL), mma(NULL), x(NULL) {
     prob->incref();
     options->incref();
   }
@@ -443,6 +451,7 @@ class ParOptOptimizer : public ParOptBase {
     if (x) x->decref();
     if (ip) ip->decref();
     if (tr) po_tr_destroy(tr);
+    if (mma) po_mma_destroy(mma);
     options->decref();
     prob->decref();
   }
@@ -463,16 +472,28 @@ class ParOptOptimizer : public ParOptBase {
         }
       }
       if (po_tr_optimize(tr) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    } else if (algorithm == "mma") {
+      if (!mma) {
+        if (po_mma_create(prob->handle(), &mma) != 0 || options->apply(mma) != 0) {
+          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+          return;
+        }
+      }
+      if (po_mma_optimize(mma) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     } else {
       fprintf(stderr, "ParOptOptimizer Error: Unrecognized algorithm option %s\n", algorithm.c_str());
     }
   }
   void getOptimizedPoint(ParOptVec **_x, ParOptScalar **_z, ParOptVec **_zw, ParOptVec **_zl,
                          ParOptVec **_zu) {
-    if (tr) {
+    if (tr || mma) {
       po_vec hx = NULL;
       const double *z = NULL;
-      po_tr_get_optimized_point(tr, &hx, &z, NULL);
+      if (tr) {
+        po_tr_get_optimized_point(tr, &hx, &z, NULL);
+      } else {
+        po_mma_get_optimized_point(mma, &hx, &z, NULL, NULL, NULL);
+      }
       if (x) x->decref();
       x = new ParOptVec(hx);
       x->incref();
@@ -496,6 +517,7 @@ class ParOptOptimizer : public ParOptBase {
   ParOptOptions *options;
   ParOptInteriorPoint *ip;
   po_tr tr;
+  po_mma mma;
   ParOptVec *x;
 };
 

@@ -270,6 +270,28 @@ int po_tr_get_model_vectors(po_tr tr, po_vec *xk, po_vec *gk);
 typedef int (*po_tr_iteration_fn)(void *user, int iter);     /* where the reference calls writeOutput */
 int po_tr_set_iteration_callback(po_tr tr, po_tr_iteration_fn fn, void *user);
 
+/* ---- ParOptMMA: method of moving asymptotes (src/ParOptMMA.h:22-192), assembled as ParOptOptimizer
+ * does for algorithm = "mma" (src/ParOptOptimizer.cpp:184-204): the MMA object is the separable
+ * rational subproblem handed to an interior-point solver (use_diag_hessian = 1, use_line_search = 0)
+ * and the outer loop.  One registry holds the interior-point and the mma_* options
+ * (src/ParOptMMA.cpp:234-289).  `prob` is borrowed. */
+typedef struct po_mma_s *po_mma;
+int po_mma_create(po_problem prob, po_mma *out);
+int po_mma_destroy(po_mma mma);
+int po_mma_set_option_str(po_mma mma, const char *name, const char *value);
+int po_mma_set_option_int(po_mma mma, const char *name, int value);
+int po_mma_set_option_float(po_mma mma, const char *name, double value);
+int po_mma_optimize(po_mma mma);                             /* optimize .cpp:318-379 */
+/* getOptimizedPoint .cpp:489 (+ the multipliers of the last subproblem solve) */
+int po_mma_get_optimized_point(po_mma mma, po_vec *x, const double **z, po_vec *zw, po_vec *zl, po_vec *zu);
+int po_mma_get_asymptotes(po_mma mma, po_vec *L, po_vec *U); /* getAsymptotes .cpp:494-501 */
+/* iteration counters (mma_iter, cumulative subproblem gradient evaluations), objective, constraints */
+int po_mma_get_state(po_mma mma, int *mma_iter, int *subproblem_iter, double *fobj, const double **cons);
+int po_mma_get_last_row(po_mma mma, const double **row5);    /* fobj, l1, linfty, l1_lambda, infeas */
+int po_mma_get_history(po_mma mma, const char **text);       /* the paropt.mma table :584-592 */
+typedef int (*po_mma_iteration_fn)(void *user, int mma_iter);
+int po_mma_set_iteration_callback(po_mma mma, po_mma_iteration_fn fn, void *user);
+
 #ifdef __cplusplus
 }
 #endif

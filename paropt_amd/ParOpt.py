@@ -16,7 +16,7 @@ Callbacks receive PVec objects with the reference's numpy-style item access on h
 (``x[:]``, ``g[:] = ...``); the values move to the GPU when the callback returns.  The MPI
 communicator argument is accepted and ignored: ranks are those of the paropt_amd Context (one process
 per GPU; ``ParOpt.setContext`` to supply one that is already wired to RCCL or to a host callback).
-Not provided: MMA (``algorithm="mma"``), the CSR sparse problem form (``rowp``/``cols``).
+Not provided: the CSR sparse problem form (``rowp``/``cols``).
 """
 import numpy as np
 
@@ -179,6 +179,7 @@ def _split_options(options):
 
 
 _TR_ONLY = ("tr_", "filter_")
+_MMA_ONLY = ("mma_",)
 
 
 class InteriorPoint(_api.InteriorPoint):
@@ -186,7 +187,7 @@ class InteriorPoint(_api.InteriorPoint):
 
     def __init__(self, problem, options=None):
         algorithm, opts = _split_options(options)
-        opts = {k: v for k, v in opts.items() if not k.startswith(_TR_ONLY)}
+        opts = {k: v for k, v in opts.items() if not k.startswith(_TR_ONLY + _MMA_ONLY)}
         super().__init__(problem, opts)
 
     def getOptimizedPoint(self):
@@ -201,9 +202,9 @@ class Optimizer:
     def __init__(self, problem, options=None):
         self.problem = problem
         self.algorithm, self.options = _split_options(options)
-        self.ip = self.tr = None
-        if self.algorithm not in ("ip", "tr"):
-            raise NotImplementedError("algorithm=%r: only 'ip' and 'tr' run on the device path" % self.algorithm)
+        self.ip = self.tr = self.mma = None
+        if self.algorithm not in ("ip", "tr", "mma"):
+            raise ValueError("ParOptOptimizer Error: Unrecognized algorithm option %s" % self.algorithm)
 
     def optimize(self):
         if self.algorithm == "ip":
@@ -211,13 +212,25 @@ class Optimizer:
                 self.ip = InteriorPoint(self.problem, self.options)
             ckpt = self.options.get("ip_checkpoint_file")
             self.ip.optimize(ckpt if ckpt else None)
-        else:
+        elif self.algorithm == "tr":
             if self.tr is None:
-                opts = {k: v for k, v in self.options.items() if k != "ip_checkpoint_file"}
+                opts = {k: v for k, v in self.options.items()
+                        if k != "ip_checkpoint_file" and not k.startswith(_MMA_ONLY)}
                 self.tr = _api.TrustRegion(self.problem, opts)
             self.tr.optimize()
+        else:
+            if self.mma is None:
+                opts = {k: v for k, v in self.options.items()
+                        if k != "ip_checkpoint_file" and not k.startswith(_TR_ONLY)}
+                if opts.get("mma_output_file", "") is None:
+                    opts["mma_output_file"] = ""
+                self.mma = _api.MMA(self.problem, opts)
+            self.mma.optimize()
 
     def getOptimizedPoint(self):
+        if self.mma is not None:
+            x, z, zw, zl, zu = self.mma.getOptimizedPoint()
+            return PVec(x), z, (PVec(zw) if zw is not None else None), PVec(zl), PVec(zu)
         if self.tr is not None:
             x, z, zw = self.tr.getOptimizedPoint()
             return PVec(x), z, (PVec(zw) if zw is not None else None), None, None

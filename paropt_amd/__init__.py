@@ -5,6 +5,7 @@ Importing the package loads libparopt_amd.so; it raises if the library has not b
 from .api import (  # noqa: F401
     LBFGS,
     LSR1,
+    MMA,
     Context,
     InteriorPoint,
     Problem,

@@ -718,6 +718,85 @@ class TrustRegion:
         return d
 
 
+class MMA:
+    """ParOptMMA (reference src/ParOptMMA.h:22-192) with its interior-point sub-solver, assembled the
+    way ParOptOptimizer does for algorithm='mma'.  `options` may mix interior-point and mma_* names."""
+
+    def __init__(self, problem, options=None):
+        self.problem = problem
+        self.ctx = problem.ctx
+        self._h = L.po_mma()
+        check(lib.po_mma_create(problem.handle, C.byref(self._h)))
+        self._cbs = []
+        opts = dict(options or {})
+        opts.setdefault("mma_output_file", "")
+        for k, v in opts.items():
+            self.setOption(k, v)
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib.po_mma_destroy(self._h)
+        except Exception:
+            pass
+
+    def setOption(self, name, value):
+        nm = name.encode()
+        if isinstance(value, bool):
+            check(lib.po_mma_set_option_int(self._h, nm, int(value)))
+        elif isinstance(value, int):
+            rc = lib.po_mma_set_option_int(self._h, nm, value)
+            if rc != 0:
+                check(lib.po_mma_set_option_float(self._h, nm, float(value)))
+        elif isinstance(value, float):
+            check(lib.po_mma_set_option_float(self._h, nm, value))
+        else:
+            check(lib.po_mma_set_option_str(self._h, nm, str(value).encode()))
+
+    def setIterationCallback(self, fn):
+        def _cb(user, k):
+            fn(k)
+            return 0
+
+        cb = L.TR_ITER_FN(_cb)
+        self._cbs.append(cb)
+        check(lib.po_mma_set_iteration_callback(self._h, cb, None))
+
+    def optimize(self):
+        rc = lib.po_mma_optimize(self._h)
+        if rc != 0:
+            raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
+        return rc
+
+    def getOptimizedPoint(self):
+        x, z, zw, zl, zu = L.po_vec(), L.c_double_p(), L.po_vec(), L.po_vec(), L.po_vec()
+        check(lib.po_mma_get_optimized_point(self._h, C.byref(x), C.byref(z), C.byref(zw), C.byref(zl), C.byref(zu)))
+        c = self.problem.ncon
+        wrap = lambda h: PVec(self.ctx, handle=h, owned=False) if h else None  # noqa: E731
+        return wrap(x), np.array([z[i] for i in range(c)]), wrap(zw), wrap(zl), wrap(zu)
+
+    def getAsymptotes(self):
+        lo, up = L.po_vec(), L.po_vec()
+        check(lib.po_mma_get_asymptotes(self._h, C.byref(lo), C.byref(up)))
+        return PVec(self.ctx, handle=lo, owned=False), PVec(self.ctx, handle=up, owned=False)
+
+    def getState(self):
+        a, b, f, cons = C.c_int(), C.c_int(), C.c_double(), L.c_double_p()
+        check(lib.po_mma_get_state(self._h, C.byref(a), C.byref(b), C.byref(f), C.byref(cons)))
+        c = self.problem.ncon
+        return dict(mma_iter=a.value, subproblem_iter=b.value, fobj=f.value, cons=np.array([cons[i] for i in range(c)]))
+
+    def getLastRow(self):
+        row = L.c_double_p()
+        check(lib.po_mma_get_last_row(self._h, C.byref(row)))
+        return [row[i] for i in range(5)]
+
+    def getHistory(self):
+        t = C.c_char_p()
+        check(lib.po_mma_get_history(self._h, C.byref(t)))
+        return t.value.decode()
+
+
 def wgram(d, vecs):
     nv = len(vecs)
     W = np.zeros((nv, nv))

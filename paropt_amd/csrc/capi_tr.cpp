@@ -1,6 +1,7 @@
 // C ABI of the trust-region layer (include/paropt_amd.h, "ParOptTrustRegion").
 #include <string.h>
 
+#include "mma.hpp"
 #include "tr.hpp"
 
 using namespace po;
@@ -200,6 +201,86 @@ int po_tr_set_iteration_callback(po_tr tr, po_tr_iteration_fn fn, void *user) {
   PO_CHECK_PTR(tr);
   tr->tr->iter_cb = fn;
   tr->tr->iter_cb_user = user;
+  return PO_OK;
+}
+
+// ---- MMA -----------------------------------------------------------------------------------------
+int po_mma_create(po_problem prob, po_mma *out) {
+  PO_CHECK_PTR(prob);
+  PO_CHECK_PTR(out);
+  po_mma_s *h = new po_mma_s();
+  h->mma = new MMA(prob->p);
+  *out = h;
+  return PO_OK;
+}
+int po_mma_destroy(po_mma mma) {
+  if (!mma) return PO_OK;
+  delete mma->mma;
+  delete mma;
+  return PO_OK;
+}
+int po_mma_set_option_str(po_mma mma, const char *name, const char *value) {
+  PO_CHECK_PTR(mma);
+  PO_CHECK_PTR(name);
+  return mma->mma->options().set(name, value);
+}
+int po_mma_set_option_int(po_mma mma, const char *name, int value) {
+  PO_CHECK_PTR(mma);
+  PO_CHECK_PTR(name);
+  return mma->mma->options().set(name, value);
+}
+int po_mma_set_option_float(po_mma mma, const char *name, double value) {
+  PO_CHECK_PTR(mma);
+  PO_CHECK_PTR(name);
+  return mma->mma->options().set(name, value);
+}
+int po_mma_optimize(po_mma mma) {
+  PO_CHECK_PTR(mma);
+  return mma->mma->optimize();
+}
+int po_mma_get_optimized_point(po_mma mma, po_vec *x, const double **z, po_vec *zw, po_vec *zl, po_vec *zu) {
+  PO_CHECK_PTR(mma);
+  MMA *m = mma->mma;
+  PO_TRY(m->build());
+  if (x) *x = static_cast<po_vec>(m->xvec);
+  if (z) *z = m->z.data();
+  if (zw) *zw = static_cast<po_vec>(m->zwvec);
+  if (zl) *zl = static_cast<po_vec>(m->zlvec);
+  if (zu) *zu = static_cast<po_vec>(m->zuvec);
+  return PO_OK;
+}
+int po_mma_get_asymptotes(po_mma mma, po_vec *L, po_vec *U) {
+  PO_CHECK_PTR(mma);
+  PO_TRY(mma->mma->build());
+  if (L) *L = static_cast<po_vec>(mma->mma->Lvec);
+  if (U) *U = static_cast<po_vec>(mma->mma->Uvec);
+  return PO_OK;
+}
+int po_mma_get_state(po_mma mma, int *mma_iter, int *subproblem_iter, double *fobj, const double **cons) {
+  PO_CHECK_PTR(mma);
+  MMA *m = mma->mma;
+  if (mma_iter) *mma_iter = m->mma_iter;
+  if (subproblem_iter) *subproblem_iter = m->subproblem_iter;
+  if (fobj) *fobj = m->fobj;
+  if (cons) *cons = m->cons.data();
+  return PO_OK;
+}
+int po_mma_get_last_row(po_mma mma, const double **row5) {
+  PO_CHECK_PTR(mma);
+  PO_CHECK_PTR(row5);
+  *row5 = mma->mma->last_row;
+  return PO_OK;
+}
+int po_mma_get_history(po_mma mma, const char **text) {
+  PO_CHECK_PTR(mma);
+  PO_CHECK_PTR(text);
+  *text = mma->mma->history.c_str();
+  return PO_OK;
+}
+int po_mma_set_iteration_callback(po_mma mma, po_mma_iteration_fn fn, void *user) {
+  PO_CHECK_PTR(mma);
+  mma->mma->iter_cb = fn;
+  mma->mma->iter_cb_user = user;
   return PO_OK;
 }
 

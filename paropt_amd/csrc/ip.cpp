@@ -186,6 +186,45 @@ void Options::addTrustRegionDefaults() {
     {"least_squares_multipliers", "affine_step", "no_start_strategy", "default"});
 }
 
+void Options::addMMADefaults() {
+  auto F = [&](const char *n, double v, double lo, double hi) {
+    Entry x;
+    x.type = FLOAT;
+    x.f = v;
+    x.flo = lo;
+    x.fhi = hi;
+    e[n] = x;
+  };
+  Entry s;
+  s.type = STR;
+  s.s = "paropt.mma";
+  e["mma_output_file"] = s;
+  Entry it;
+  it.type = INT;
+  it.i = 200;
+  it.ilo = 0;
+  it.ihi = 1000000;
+  e["mma_max_iterations"] = it;
+  Entry lin;
+  lin.type = BOOL;
+  lin.i = 0;
+  lin.ilo = 0;
+  lin.ihi = 1;
+  e["mma_use_constraint_linearization"] = lin;
+  F("mma_l1_tol", 1e-6, 0.0, 1e20);
+  F("mma_linfty_tol", 1e-6, 0.0, 1e20);
+  F("mma_infeas_tol", 1e-5, 0.0, 1e20);
+  F("mma_asymptote_contract", 0.7, 0.0, 1.0);
+  F("mma_asymptote_relax", 1.2, 1.0, 1e20);
+  F("mma_init_asymptote_offset", 0.5, 0.0, 1.0);
+  F("mma_min_asymptote_offset", 0.01, 0.0, 1e20);
+  F("mma_max_asymptote_offset", 10.0, 0.0, 1e20);
+  F("mma_bound_relax", 0.0, 0.0, 1e20);
+  F("mma_eps_regularization", 1e-5, 0.0, 1e20);
+  F("mma_delta_regularization", 1e-3, 0.0, 1e20);
+  F("mma_move_limit", 0.2, 0.0, 1e20);
+}
+
 int Options::set(const char *name, const char *value) {
   auto it = e.find(name);
   if (it == e.end()) {
@@ -1341,8 +1380,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
   corrector_active = false;
   const bool use_hvec_product = options.integer("use_hvec_product");
   const bool use_diag_hessian = options.integer("use_diag_hessian");
-  if (has_w && (use_hvec_product || use_diag_hessian)) {
-    set_error("use_hvec_product / use_diag_hessian with sparse constraints are not implemented on the device path");
+  if (has_w && use_hvec_product) {
+    set_error("use_hvec_product with sparse constraints is not implemented on the device path");
     return PO_ERR_OPTION;
   }
   if (use_diag_hessian) PO_TRY(ensureHdiag());
@@ -1549,7 +1588,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
       }
     } else if (use_diag_hessian) {  // :4940-4948
       use_qn = false;
-      if (prob->evalHessianDiag(x, vars.z.data(), nullptr, hdiag) != 0) {
+      if (prob->evalHessianDiag(x, vars.z.data(), has_w ? wvar[0] : nullptr, hdiag) != 0) {
         fprintf(stderr, "ParOpt: Hessian diagonal evaluation failed\n");
         return PO_ERR_USER;
       }

@@ -27,6 +27,8 @@ class Options {
   Options();
   // ParOptTrustRegion::addDefaultOptions (src/ParOptTrustRegion.cpp:739-847) into the same registry
   void addTrustRegionDefaults();
+  // ParOptMMA::addDefaultOptions (src/ParOptMMA.cpp:234-289)
+  void addMMADefaults();
   int set(const char *name, const char *value);
   int set(const char *name, int value);
   int set(const char *name, double value);

@@ -200,9 +200,16 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
     double diag = options.real("qn_sigma");
-    std::vector<double> coef(mq + 1, 0.0);
+    std::vector<double> coef(mq + 2, 0.0);
     for (int i = 0; i < c; i++) coef[i] = step.z[i];
-    if (qn && !seq_lin) {
+    int mres = mq;
+    if (options.integer("use_diag_hessian") && hdiag) {
+      // -h o px replaces the whole quasi-Newton term, sigma included (:1464-1473)
+      diag = 0.0;
+      PO_TRY(k_mul(ctx, xt->d, 1.0, hdiag->d, px->d, n));
+      Pq.push_back(xt->d);
+      coef[mres++] = -1.0;
+    } else if (qn && !seq_lin) {
       diag += qn->diag();
       if (kq > 0) {
         std::vector<double> rz(dots.begin() + c, dots.begin() + c + kq);
@@ -214,9 +221,9 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
     PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
     if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
     Pq.push_back(tvec->d);
-    coef[mq] = 1.0;
+    coef[mres++] = 1.0;
     PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
-                      mq + 1, diag, beta_mu, n, d1v->d));
+                      mres, diag, beta_mu, n, d1v->d));
     // sparse rows (:1492-1527)
     PO_TRY(computeResidualW(mu));
     if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;

@@ -26,6 +26,7 @@ po_problem = C.c_void_p
 po_ip = C.c_void_p
 po_tr = C.c_void_p
 po_eig = C.c_void_p
+po_mma = C.c_void_p
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
 c_i64_p = C.POINTER(C.c_int64)
@@ -186,6 +187,19 @@ SIGNATURES = {
     "po_tr_get_quasi_newton": (C.c_int, [po_tr, C.POINTER(po_qn)]),
     "po_tr_get_model_vectors": (C.c_int, [po_tr, C.POINTER(po_vec), C.POINTER(po_vec)]),
     "po_tr_set_iteration_callback": (C.c_int, [po_tr, TR_ITER_FN, C.c_void_p]),
+    "po_mma_create": (C.c_int, [po_problem, C.POINTER(po_mma)]),
+    "po_mma_destroy": (C.c_int, [po_mma]),
+    "po_mma_set_option_str": (C.c_int, [po_mma, C.c_char_p, C.c_char_p]),
+    "po_mma_set_option_int": (C.c_int, [po_mma, C.c_char_p, C.c_int]),
+    "po_mma_set_option_float": (C.c_int, [po_mma, C.c_char_p, C.c_double]),
+    "po_mma_optimize": (C.c_int, [po_mma]),
+    "po_mma_get_optimized_point": (
+        C.c_int, [po_mma, C.POINTER(po_vec), C.POINTER(c_double_p)] + [C.POINTER(po_vec)] * 3),
+    "po_mma_get_asymptotes": (C.c_int, [po_mma, C.POINTER(po_vec), C.POINTER(po_vec)]),
+    "po_mma_get_state": (C.c_int, [po_mma, c_int_p, c_int_p, c_double_p, C.POINTER(c_double_p)]),
+    "po_mma_get_last_row": (C.c_int, [po_mma, C.POINTER(c_double_p)]),
+    "po_mma_get_history": (C.c_int, [po_mma, C.POINTER(C.c_char_p)]),
+    "po_mma_set_iteration_callback": (C.c_int, [po_mma, TR_ITER_FN, C.c_void_p]),
     "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
