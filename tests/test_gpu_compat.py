@@ -98,3 +98,17 @@ def test_reference_style_problem_ip_and_tr(tmp_path):
     assert len(cols[0]) == otr.iter_count
     # both drivers land on the same optimum of this convex problem
     np.testing.assert_allclose(x2[:], x[:], rtol=0, atol=1e-3)
+
+    # ... and through the method of moving asymptotes (algorithm = "mma")
+    from oracle import mma_oracle as mo
+
+    mfile = str(tmp_path / "paropt.mma")
+    opt3 = ParOpt.Optimizer(Quadratic(), {"algorithm": "mma", "mma_max_iterations": 12, "mma_output_file": mfile,
+                                         "output_file": None})
+    opt3.optimize()
+    x3, z3 = opt3.getOptimizedPoint()[:2]
+    omma = mo.MMA(OracleProblem(), {"mma_max_iterations": 12})
+    omma.optimize(po.InteriorPoint(omma, {}))
+    np.testing.assert_allclose(x3[:], omma.x, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(z3, omma.z, rtol=1e-5, atol=1e-7)
+    assert open(mfile).read().count("\n") >= 13
