@@ -173,6 +173,10 @@ int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, cons
 // computeCompStep :2825-2923 at (x + ax*px, zl + az*pzl, zu + az*pzu): out = {product, count}
 int k_comp_step(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 double ax, double az, int64_t n, double out[2]);
+// comp_step + merit0 (unscaled step) + max|px| in one pass: out = {comp product, count, pos log, neg log,
+// ppos, pneg, g.px, px.px, max|px|}
+int k_comp_merit(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu, double ax,
+                 double az, const double *g, int64_t n, double out[9]);
 // evalMeritInitDeriv :3652-3714 barrier part + the three design-space inner products:
 // out = {pos log, neg log, pos presult, neg presult, g.px, px.px}; px is scaled by sx.
 int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double *g, int64_t n,

@@ -313,6 +313,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   hdiag = nullptr;
   vA_valid = false;
   inexact_newton_step = false;
+  merit_cache_valid = false;
   nhvec = 0;
   nw = p->nwcon;
   has_w = false;
@@ -804,6 +805,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     ptpx[i] = refine_pass ? ptpx[i] + v : v;
   }
   ptpx_valid = true;
+  merit_cache_valid = false;  // the step is about to change
   // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
   // the axpy pass starts (A-part = p.z = alpha_A; Z-part = d0 M^-1 d0 Z^T px with Z^T px = ptpx),
   // so the same pass over P also emits the right-hand side t' of the refinement solve.
@@ -982,8 +984,15 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
       az = ax / max_bnd;
     }
   }
-  double out[2];
-  PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, n, out));
+  double out[9];
+  if (!has_w) {
+    // one pass also yields the merit pieces and the step norm the line search is about to ask for
+    PO_TRY(k_comp_merit(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, g->d, n, out));
+    for (int i = 0; i < 7; i++) merit_cache[i] = out[2 + i];
+    merit_cache_valid = true;
+  } else {
+    PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, n, out));
+  }
   double prod = out[0] / options.real("rel_bound_barrier"), count = out[1];
   if (has_w) {  // :2866-2889
     double wprod = 0.0;
@@ -1061,7 +1070,16 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
   const double frac = options.real("penalty_descent_fraction");
   const bool seq_lin = options.integer("sequential_linear_method");
   double out[6];
-  PO_TRY(k_merit0(ctx, bounds(), px->d, sx, g->d, n, out));
+  if (merit_cache_valid) {
+    out[0] = merit_cache[0];
+    out[1] = merit_cache[1];
+    out[2] = sx * merit_cache[2];
+    out[3] = sx * merit_cache[3];
+    out[4] = sx * merit_cache[4];
+    out[5] = sx * sx * merit_cache[5];
+  } else {
+    PO_TRY(k_merit0(ctx, bounds(), px->d, sx, g->d, n, out));
+  }
   double pos = out[0] * beta, neg = out[1] * beta, ppos = out[2] * beta, pneg = out[3] * beta;
   const double gpx = out[4], pxpx = out[5];
   int kq = 0;
@@ -1701,7 +1719,11 @@ int InteriorPoint::optimize(const char *checkpoint) {
           line_fail = LS_FAILURE;
         } else {
           double px_norm = 0.0;
-          PO_TRY(k_reduce1(ctx, RED_AMAX, px->d, nullptr, n, &px_norm));
+          if (merit_cache_valid) {
+            px_norm = merit_cache[6];
+          } else {
+            PO_TRY(k_reduce1(ctx, RED_AMAX, px->d, nullptr, n, &px_norm));
+          }
           px_norm *= fabs(sx);
           double alpha_min = 1.0;
           if (px_norm != 0.0) alpha_min = fprec / px_norm;

@@ -149,6 +149,10 @@ class InteriorPoint {
   std::vector<Vec *> gmresW;   // Krylov basis of computeKKTGMRESStep
   bool vA_valid;               // vA = A^T pz of the current step was maintained by the solves
   bool inexact_newton_step;    // the current step came from computeKKTGMRESStep
+  // merit pieces of the current (unscaled) step, produced together with the complementarity check of
+  // scaleKKTStep: {pos log, neg log, ppos, pneg, g.px, px.px, max|px|}
+  double merit_cache[7];
+  bool merit_cache_valid;
   int ensureHdiag();
   int solveKKTAlpha(const double *bx, double alpha, const Dense &b, double mu, bool use_qn, bool full,
                     double tau, Dense &out);

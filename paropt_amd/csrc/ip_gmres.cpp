@@ -68,6 +68,7 @@ int InteriorPoint::solveKKTAlpha(const double *bx, double alpha, const Dense &b,
     ptpx[i] = v;
   }
   ptpx_valid = true;
+  merit_cache_valid = false;  // the step is about to change
   tdots_valid = false;
   residual_fused = false;
   vA_valid = false;

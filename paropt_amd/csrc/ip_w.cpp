@@ -158,6 +158,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     ptpx[i] = refine_pass ? ptpx[i] + v : v;
   }
   ptpx_valid = true;
+  merit_cache_valid = false;  // the step is about to change
   tdots_valid = false;
   residual_fused = false;
   // (dx, dzw) = K0^-1 (d1 + P alpha, d2): by linearity the full solve minus the bx-only solve

@@ -1279,6 +1279,59 @@ int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double 
   return reduce_finish(c, grid, 6, 0, 0, out);
 }
 
+// comp_step + merit0 + max|px| in ONE pass over (x, lb, ub, zl, zu, px, pzl, pzu, g): the three
+// reductions scaleKKTStep / evalMeritInitDeriv / the line search's step norm need of the same step.
+// The merit pieces are taken for the UNSCALED step (the scaling sx > 0 is applied on the host:
+// the sign split of px is invariant, ppos/pneg/g.px are linear and px.px quadratic in sx).
+// sums {comp product, count, pos log, neg log, ppos, pneg, g.px, px.px}; max {|px|}
+__global__ void __launch_bounds__(kBlock)
+    comp_merit_kernel(Bounds b, const double *__restrict__ px, const double *__restrict__ pzl,
+                      const double *__restrict__ pzu, double ax, double az, const double *__restrict__ g,
+                      int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 8];
+  double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double mx[1] = {0.0};
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n), gv = ld2(g, q, n);
+    const double xn0 = _x.x + ax * p.x, xn1 = _x.y + ax * p.y;
+    if (e0.L) {
+      s[0] += (_zl.x + az * l.x) * (xn0 - _lb.x);
+      s[1] += 1.0;
+    }
+    if (e1.L) {
+      s[0] += (_zl.y + az * l.y) * (xn1 - _lb.y);
+      s[1] += 1.0;
+    }
+    if (e0.U) {
+      s[0] += (_zu.x + az * u.x) * (_ub.x - xn0);
+      s[1] += 1.0;
+    }
+    if (e1.U) {
+      s[0] += (_zu.y + az * u.y) * (_ub.y - xn1);
+      s[1] += 1.0;
+    }
+    barrier_elem(e0, s[2], s[3]);
+    barrier_elem(e1, s[2], s[3]);
+    if (e0.L) { if (p.x > 0.0) s[4] += p.x / e0.xl; else s[5] += p.x / e0.xl; }
+    if (e1.L) { if (p.y > 0.0) s[4] += p.y / e1.xl; else s[5] += p.y / e1.xl; }
+    if (e0.U) { if (p.x > 0.0) s[5] -= p.x / e0.xu; else s[4] -= p.x / e0.xu; }
+    if (e1.U) { if (p.y > 0.0) s[5] -= p.y / e1.xu; else s[4] -= p.y / e1.xu; }
+    s[6] += gv.x * p.x + gv.y * p.y;
+    s[7] += p.x * p.x + p.y * p.y;
+    mx[0] = fmax(mx[0], fmax(fabs(p.x), fabs(p.y)));
+  }
+  block_reduce_store<8, OP_SUM>(s, partials, 0, sm);
+  block_reduce_store<1, OP_MAX>(mx, partials, 8, sm);
+}
+int k_comp_merit(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu, double ax,
+                 double az, const double *g, int64_t n, double out[9]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 9));
+  PO_LAUNCH(comp_merit_kernel, grid, b, px, pzl, pzu, ax, az, g, n, c->d_partials);
+  return reduce_finish(c, grid, 8, 0, 1, out);
+}
+
 __device__ __forceinline__ double clamp_elem(double v, bool has_l, double lb, bool has_u, double ub,
                                              double eps) {
   if (has_l && v <= lb + eps) v = lb + eps;
