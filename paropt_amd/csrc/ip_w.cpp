@@ -60,18 +60,7 @@ int InteriorPoint::allocateW() {
 // (yx, yw) <- K0^-1 (bx, bw), ParOptQuasiDefBlockMat::apply (src/ParOptSparseMat.cpp:122-190);
 // bw == nullptr stands for a zero block.  bx must not alias yx->d.
 int InteriorPoint::applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw) {
-  PO_TRY(k_mul(ctx, yx->d, 1.0, Dinv->d, bx, n));
-  if (bw) {
-    PO_TRY(k_copy(ctx, yw->d, bw, nw));
-  } else {
-    PO_TRY(k_fill(ctx, yw->d, nw, 0.0));
-  }
-  if (prob->addSparseJacobian(-1.0, x, yx, yw) != 0) return PO_ERR_USER;
-  PO_TRY(k_mul(ctx, yw->d, 1.0, Cw->d, yw->d, nw));
-  PO_TRY(k_copy(ctx, yx->d, bx, n));
-  if (prob->addSparseJacobianTranspose(1.0, x, yw, yx) != 0) return PO_ERR_USER;
-  PO_TRY(k_mul(ctx, yx->d, 1.0, Dinv->d, yx->d, n));
-  return PO_OK;
+  return prob->sparseApplyK0(x, Dinv, Cw, bx, bw, yx, yw, wtmp);
 }
 
 // the w blocks of computeKKTRes (:1358-1398) and their norms

@@ -53,6 +53,10 @@ class MMA : public Problem {
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;
+  int sparseApplyK0(Vec *, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                    Vec *wwork) override {
+    return prob->sparseApplyK0(xvec, d, cw, bx, bw, yx, yw, wwork);
+  }
 
   Problem *prob;
   Options opts;

@@ -34,6 +34,12 @@ class Problem {
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
   virtual int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                                   Vec *work);
+  // (yx, yw) = K0^-1 (bx, bw) of ParOptQuasiDefBlockMat::apply (src/ParOptSparseMat.cpp:122-190) with
+  // the diagonal blocks d (n) and cw (w): yx = d o bx; yw = cw o (bw - Aw yx); yx = d o (bx + Aw^T yw).
+  // The default is that sequence through the Jacobian callbacks (11 n-sized passes); structured problems
+  // do it in 5.  bx must not alias yx; bw may be null (zero block); `wwork` is w-sized scratch.
+  virtual int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                            Vec *wwork);
 
   Ctx *ctx;
   int64_t nlocal, offset, nglobal;
@@ -87,6 +93,8 @@ class SeparableProblem : public Problem {
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;
+  int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                    Vec *wwork) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   GroupMap gmap;

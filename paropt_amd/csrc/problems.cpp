@@ -23,6 +23,23 @@ int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
   return PO_OK;
 }
 
+int Problem::sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                           Vec *) {
+  const int64_t n = nlocal, w = nwcon;
+  PO_TRY(k_mul(ctx, yx->d, 1.0, d->d, bx, n));
+  if (bw) {
+    PO_TRY(k_copy(ctx, yw->d, bw, w));
+  } else {
+    PO_TRY(k_fill(ctx, yw->d, w, 0.0));
+  }
+  if (addSparseJacobian(-1.0, x, yx, yw) != 0) return PO_ERR_USER;
+  PO_TRY(k_mul(ctx, yw->d, 1.0, cw->d, yw->d, w));
+  PO_TRY(k_copy(ctx, yx->d, bx, n));
+  if (addSparseJacobianTranspose(1.0, x, yw, yx) != 0) return PO_ERR_USER;
+  PO_TRY(k_mul(ctx, yx->d, 1.0, d->d, yx->d, n));
+  return PO_OK;
+}
+
 // ---- callbacks --------------------------------------------------------------------------------
 int CallbackProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
   if (!cb.get_vars_and_bounds) {
@@ -192,6 +209,15 @@ int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P
 }
 
 // the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
+// Aw = -(group indicator): u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx - yw[group])
+int SeparableProblem::sparseApplyK0(Vec *, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
+                                    Vec *yw, Vec *wwork) {
+  const double *P[1] = {bx};
+  double *U[1] = {wwork->d};
+  PO_TRY(k_group_panel(ctx, gmap, P, 1, d->d, -1.0, U));
+  PO_TRY(k_w_apply_mid(ctx, cw->d, bw, wwork->d, nwcon, yw->d));
+  return k_group_apply(ctx, gmap, d->d, bx, -1.0, yw->d, nlocal, yx->d);
+}
 int SeparableProblem::evalHvecProduct(Vec *x, const double *z, Vec *, Vec *px, Vec *hvec) {
   if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], px->d, nlocal, hvec->d) != PO_OK;
   return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, px->d, nlocal,

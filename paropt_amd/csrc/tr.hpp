@@ -85,6 +85,10 @@ class TrustRegionSubproblem : public Problem {
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;
+  int sparseApplyK0(Vec *, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                    Vec *wwork) override {
+    return prob->sparseApplyK0(xk, d, cw, bx, bw, yx, yw, wwork);
+  }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
 
   Problem *prob;
@@ -155,6 +159,10 @@ class InfeasSubproblem : public Problem {  // :468-650
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override {
     return sub->sparseJacobianPanel(x, d, P, nv, U, work);
+  }
+  int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
+                    Vec *wwork) override {
+    return sub->sparseApplyK0(x, d, cw, bx, bw, yx, yw, wwork);
   }
   TrustRegionSubproblem *sub;
   int objective, constraint;

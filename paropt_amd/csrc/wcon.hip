@@ -217,6 +217,40 @@ int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, con
   return PO_OK;
 }
 
+// second half of the structured K0^-1 apply: yx_g = d_g (bx_g + alpha * yw[i(g)]) inside a group,
+// yx_g = d_g bx_g outside
+__global__ void __launch_bounds__(kBlock)
+    group_apply_kernel(GroupMap m, const double *__restrict__ d, const double *__restrict__ bx, double alpha,
+                       const double *__restrict__ yw, int64_t n, double *__restrict__ yx) {
+  const int64_t period = m.nw + m.skip;
+  PO_W_LOOP(g, n) {
+    double v = bx[g];
+    const int64_t r = g - m.start;
+    if (r >= 0) {
+      const int64_t i = r / period;
+      if (i < m.nwcon && (r - i * period) < m.nw) v += alpha * yw[i];
+    }
+    yx[g] = d[g] * v;
+  }
+}
+int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, double alpha, const double *yw,
+                  int64_t n, double *yx) {
+  if (n <= 0) return PO_OK;
+  PO_WLAUNCH(group_apply_kernel, wgrid(c, n), m, d, bx, alpha, yw, n, yx);
+  return PO_OK;
+}
+// yw = cw * (bw - u)   (bw may be null)
+__global__ void __launch_bounds__(kBlock)
+    w_apply_mid_kernel(const double *__restrict__ cw, const double *__restrict__ bw, const double *__restrict__ u,
+                       int64_t w, double *__restrict__ yw) {
+  PO_W_LOOP(i, w) yw[i] = cw[i] * ((bw ? bw[i] : 0.0) - u[i]);
+}
+int k_w_apply_mid(Ctx *c, const double *cw, const double *bw, const double *u, int64_t w, double *yw) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_apply_mid_kernel, wgrid(c, w), cw, bw, u, w, yw);
+  return PO_OK;
+}
+
 // ---- small element-wise helpers ---------------------------------------------------------------------
 // y = a * x1 * x2   (x2 may be null -> y = a * x1)
 __global__ void __launch_bounds__(kBlock)

@@ -25,6 +25,9 @@ int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const 
 int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, const double *d,
                   double alpha, double *const *U);
 
+int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, double alpha, const double *yw,
+                  int64_t n, double *yx);
+int k_w_apply_mid(Ctx *c, const double *cw, const double *bw, const double *u, int64_t w, double *yw);
 int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n);
 int k_recip(Ctx *c, double *y, int64_t n);
 
