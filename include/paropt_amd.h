@@ -168,6 +168,10 @@ int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon,
 int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstart, int nwskip,
                              int64_t nwinequality);
 int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequality_local);
+/* useLowerBounds / useUpperBounds (src/ParOptProblem.h:140-150; CyParOptProblem::setVarBoundOptions):
+ * a problem that declares a side unused never has that side's bound multipliers formed.  Before
+ * po_ip_create. */
+int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper);
 int po_problem_destroy(po_problem p);
 int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon);
 int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons);

@@ -327,6 +327,11 @@ for tag, extra in (
         **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
                                   "opt.max_major_iters": 60}, **extra)),
     )
+# problems that declare no upper / no lower bounds (useUpperBounds() / useLowerBounds() = 0)
+case("ip_quadratic_noupper_n200_c2", "ip", problem="quadratic", n=200, c=2, use_upper=0, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 80}))
+case("ip_convex_nolower_n200_c2", "ip", problem="convex", n=200, c=2, use_lower=0, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 25}))
 # --- Hessian-vector products: inexact Newton-Krylov steps (computeKKTGMRESStep :5796-6191) and the
 # diagonal-Hessian variant.  nk_switch_tol / max_gmres_rtol are opened up so that
 # the GMRES branch is taken early and often.

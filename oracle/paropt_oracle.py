@@ -528,7 +528,8 @@ class InteriorPoint:
         w = getattr(prob, "nwcon", 0)
         self.w = w
         self.ninequality = c
-        self.use_lower = self.use_upper = True
+        self.use_lower = bool(getattr(prob, "use_lower", True))
+        self.use_upper = bool(getattr(prob, "use_upper", True))
         self.vars = Vars(n, c, w)
         self.res = Vars(n, c, w)
         self.step = Vars(n, c, w)

@@ -129,6 +129,7 @@ class SepProblem : public ParOptProblem {
     setNumInequalities(_ncon, _nwineq < 0 ? _nwcon : _nwineq);
     hook = NULL;
     tr_hook = NULL;
+    use_lower_flag = use_upper_flag = 1;
     beta.resize(_ncon);
     if (kind == QUADRATIC) {
       for (int j = 0; j < _ncon; j++) beta[j] = u01(seed, 4, j);
@@ -142,6 +143,9 @@ class SepProblem : public ParOptProblem {
     }
   }
   ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefBlockMat(this, 1); }
+  int useLowerBounds() { return use_lower_flag; }
+  int useUpperBounds() { return use_upper_flag; }
+  int use_lower_flag, use_upper_flag;
 
   void getVarsAndBounds(ParOptVec *xv, ParOptVec *lbv, ParOptVec *ubv) {
     double *x, *lb, *ub;
@@ -707,6 +711,8 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
                                     (int)geti(A, "nw", 0), (int)geti(A, "nwstart", 0),
                                     (int)geti(A, "nwskip", 0), (int)geti(A, "nwineq", -1));
   prob->incref();
+  prob->use_lower_flag = (int)geti(A, "use_lower", 1);
+  prob->use_upper_flag = (int)geti(A, "use_upper", 1);
   ParOptOptions *opt = new ParOptOptions(comm);
   opt->incref();
   ParOptInteriorPoint::addDefaultOptions(opt);

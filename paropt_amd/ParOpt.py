@@ -119,7 +119,8 @@ class Problem(_api.Problem):
             self.addSparseJacobian = lambda a, x, px, out: self._user["wjac"](a, _Host(x), _Host(px), _Host(out))
             self.addSparseJacobianTranspose = lambda a, x, p, out: self._user["wjact"](a, _Host(x), _Host(p), _Host(out))
             self.addSparseInnerProduct = lambda a, x, c, A: self._user["winner"](a, _Host(x), _Host(c), A)
-        super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq)
+        super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq,
+                         use_lower=kwargs.get("use_lower", True), use_upper=kwargs.get("use_upper", True))
 
     def _gvb(self, x, lb, ub):
         self._user["gvb"](_Host(x), _Host(lb), _Host(ub))
@@ -193,7 +194,8 @@ class InteriorPoint(_api.InteriorPoint):
     def getOptimizedPoint(self):
         x, z, zl, zu = super().getOptimizedPoint()
         w = self.getOptimizedSparse()
-        return PVec(x), z, (PVec(w[0]) if w else None), PVec(zl), PVec(zu)
+        return (PVec(x), z, (PVec(w[0]) if w else None), PVec(zl) if zl is not None else None,
+                PVec(zu) if zu is not None else None)
 
 
 class Optimizer:

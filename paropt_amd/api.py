@@ -274,7 +274,8 @@ class Problem:
     addSparseInnerProduct(alpha, x, cvec, A) (A is the w-sized diagonal), all in place on numpy views.
     """
 
-    def __init__(self, ctx, nvars, ncon, ninequality=-1, nwcon=0, nwinequality=0):
+    def __init__(self, ctx, nvars, ncon, ninequality=-1, nwcon=0, nwinequality=0, use_lower=True,
+                 use_upper=True):
         self.ctx = ctx
         self.nvars, self.ncon = int(nvars), int(ncon)
         self.nwcon = int(nwcon)
@@ -316,6 +317,8 @@ class Problem:
         self._h = L.po_problem()
         check(lib.po_problem_create_callbacks(ctx.handle, self.nvars, self.ncon, int(ninequality),
                                               C.byref(cb), C.byref(self._h)))
+        if not (use_lower and use_upper):
+            check(lib.po_problem_set_var_bound_options(self._h, int(bool(use_lower)), int(bool(use_upper))))
         # optional second-order callbacks (use_hvec_product / use_diag_hessian): evalHvecProduct(x, z, zw,
         # px, hvec) and evalHessianDiag(x, z, zw, hdiag) on numpy views, as in paropt.ParOpt
         has_hvec, has_hdiag = hasattr(self, "evalHvecProduct"), hasattr(self, "evalHessianDiag")
@@ -407,6 +410,10 @@ class SeparableProblem:
         self.nwcon = a.value
         return self
 
+    def setVarBoundOptions(self, use_lower=True, use_upper=True):
+        check(lib.po_problem_set_var_bound_options(self._h, int(bool(use_lower)), int(bool(use_upper))))
+        return self
+
     @property
     def handle(self):
         return self._h
@@ -488,8 +495,10 @@ class InteriorPoint:
         z = L.c_double_p()
         check(lib.po_ip_get_optimized_point(self._h, C.byref(x), C.byref(z), C.byref(zl), C.byref(zu)))
         c = self.problem.ncon
+        # zl / zu are None for a side the problem declares unused (as the reference returns NULL)
         return (PVec(self.ctx, handle=x, owned=False), np.array([z[i] for i in range(c)]),
-                PVec(self.ctx, handle=zl, owned=False), PVec(self.ctx, handle=zu, owned=False))
+                PVec(self.ctx, handle=zl, owned=False) if zl else None,
+                PVec(self.ctx, handle=zu, owned=False) if zu else None)
 
     def getOptimizedSlacks(self):
         ptrs = [L.c_double_p() for _ in range(4)]
@@ -562,7 +571,8 @@ class InteriorPoint:
         f, rho = self.getObjective()
         d = dict(mu=self.getBarrierParameter(), rho=rho, fobj=f, z=z, s=s, t=t, zs=zs, zt=zt,
                  counters=np.array([niter, neval, ngeval]),
-                 norms=np.array([x.norm(), zl.norm(), zu.norm()]))
+                 norms=np.array([x.norm(), zl.norm() if zl is not None else np.nan,
+                                 zu.norm() if zu is not None else np.nan]))
         wv = self.getOptimizedSparse()
         if wv is not None:
             d["wnorms"] = np.array([v.norm() for v in wv])

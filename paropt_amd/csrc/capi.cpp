@@ -376,6 +376,12 @@ int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequ
   if (nwinequality_local) *nwinequality_local = p->p->nwinequality;
   return PO_OK;
 }
+int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper) {
+  PO_CHECK_PTR(p);
+  p->p->use_lower = use_lower ? 1 : 0;
+  p->p->use_upper = use_upper ? 1 : 0;
+  return PO_OK;
+}
 int po_problem_destroy(po_problem p) {
   if (!p) return PO_OK;
   delete p->p;

@@ -20,8 +20,9 @@ class Problem {
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
   virtual int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) { return 0; }
   virtual int writeOutput(int iter, Vec *x) { return 0; }
-  virtual int useLowerBounds() { return 1; }
-  virtual int useUpperBounds() { return 1; }
+  virtual int useLowerBounds() { return use_lower; }
+  virtual int useUpperBounds() { return use_upper; }
+  int use_lower = 1, use_upper = 1;  // setVarBoundOptions of the reference's Cython problems
   // Hessian of the Lagrangian f - z^T c - zw^T cw (src/ParOptProblem.h:160-189); non-zero = not available
   virtual int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) { return 1; }
   virtual int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) { return 1; }

@@ -126,6 +126,7 @@ SIGNATURES = {
     "po_problem_set_hessian_callbacks": (C.c_int, [po_problem, HVEC_FN, HDIAG_FN]),
     "po_problem_set_weighting": (C.c_int, [po_problem, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64]),
     "po_problem_sparse_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p]),
+    "po_problem_set_var_bound_options": (C.c_int, [po_problem, C.c_int, C.c_int]),
     "po_problem_destroy": (C.c_int, [po_problem]),
     "po_problem_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p, c_int_p]),
     "po_problem_eval_obj_con": (C.c_int, [po_problem, po_vec, c_double_p, c_double_p]),

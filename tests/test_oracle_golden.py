@@ -104,6 +104,8 @@ def run_oracle_ip(case, nmax=None):
         nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
     )
+    prob.use_lower = bool(a.get("use_lower", 1))
+    prob.use_upper = bool(a.get("use_upper", 1))
     opts = ip_options_from_case(case)
     opts.pop("write_output_frequency", None)
     for k in ("use_line_search",):
