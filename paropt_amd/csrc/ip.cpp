@@ -1799,6 +1799,17 @@ int InteriorPoint::optimize(const char *checkpoint) {
 // :1297-1309, :4777-4805); here it is accumulated in `history` and written when optimize returns.
 void InteriorPoint::flushHistory() {
   const std::string fname = options.str("output_file");
+  // debugging aid: PAROPT_AMD_DUMP_LONG_SOLVES=<N> prints the head and tail of the iteration table of
+  // every solve that took at least N major iterations (e.g. a stalled trust-region subproblem)
+  if (ctx->rank == 0) {
+    const char *dbg = getenv("PAROPT_AMD_DUMP_LONG_SOLVES");
+    if (dbg && niter >= atoi(dbg)) {
+      const size_t len = history.size();
+      fprintf(stderr, "---- paropt_amd: solve with %d iterations ----\n%s\n   [...]\n%s\n", niter,
+              history.substr(0, std::min<size_t>(len, 6000)).c_str(),
+              history.substr(len > 4000 ? len - 4000 : 0).c_str());
+    }
+  }
   if (ctx->rank != 0 || fname.empty()) return;
   FILE *fp = fopen(fname.c_str(), "w");
   if (!fp) return;

@@ -26,7 +26,7 @@ def cpu_reference(a):
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
     cmd = [mpiexec, "-n", str(ranks), drv, "trbench", "problem=%s" % a.problem, "n=%d" % a.n, "c=%d" % a.ncon,
            "eig_N=%d" % a.eig_N, "eig_index=0", "eig_curv=%g" % a.curv, "opt.qn_subspace_size=%d" % a.qn_size,
-           "tr.tr_max_iterations=%d" % a.cpu_tr_iters]
+           "opt.max_major_iters=%d" % a.max_major_iters, "tr.tr_max_iterations=%d" % a.cpu_tr_iters]
     t0 = time.time()
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd="/tmp")
     for ln in out.stdout.splitlines():
@@ -48,6 +48,10 @@ def main():
     ap.add_argument("--curv", type=float, default=2.0)
     ap.add_argument("--qn-size", type=int, default=10)
     ap.add_argument("--tr-iters", type=int, default=10)
+    # interior-point iteration cap per subproblem solve, as the reference's trust-region examples set it
+    # (examples/topology_optimization/topo_optimization.py:560: 100); the degenerate steering LP can
+    # otherwise sit on a failed line search until the default cap of 5000 (same in the reference)
+    ap.add_argument("--max-major-iters", type=int, default=200)
     ap.add_argument("--cpu-tr-iters", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
@@ -55,7 +59,8 @@ def main():
 
     ctx = pa.Context(0)
     prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
-    tr = pa.TrustRegion(prob, {"qn_subspace_size": a.qn_size, "tr_max_iterations": a.tr_iters})
+    tr = pa.TrustRegion(prob, {"qn_subspace_size": a.qn_size, "tr_max_iterations": a.tr_iters,
+                               "max_major_iters": a.max_major_iters})
     tr.setEigenModelSynthetic(a.eig_N, 0, 0, a.curv)
     counts = []
 
@@ -78,8 +83,9 @@ def main():
            "seconds": dt, "inner_ip_iterations": ip_iters, "inner_ip_iterations_per_s": ip_iters / dt,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "config 5: ParOptEigenSubproblem under ParOptTrustRegion, separable random_%s "
-                                  "n=%d, m=%d, N=%d curvature directions, L-BFGS(%d), trust-region defaults" % (
-                                      a.problem, a.n, a.ncon, a.eig_N, a.qn_size)},
+                                  "n=%d, m=%d, N=%d curvature directions, L-BFGS(%d), trust-region defaults, "
+                                  "max_major_iters=%d per subproblem solve" % (
+                                      a.problem, a.n, a.ncon, a.eig_N, a.qn_size, a.max_major_iters)},
            "cpu_baseline": None if a.no_cpu_baseline else cpu_reference(a)}
     print(json.dumps(res), flush=True)
 
