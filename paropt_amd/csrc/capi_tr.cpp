@@ -58,13 +58,9 @@ struct po_tr_holder {
   EigCallback cb;
   EigSynthetic sy;
 };
-static std::vector<std::pair<po_tr, po_tr_holder *>> g_holders;
 static po_tr_holder *holder_of(po_tr tr) {
-  for (auto &p : g_holders)
-    if (p.first == tr) return p.second;
-  po_tr_holder *h = new po_tr_holder();
-  g_holders.push_back(std::make_pair(tr, h));
-  return h;
+  if (!tr->eig_holder) tr->eig_holder = new po_tr_holder();
+  return static_cast<po_tr_holder *>(tr->eig_holder);
 }
 
 extern "C" {
@@ -73,20 +69,15 @@ int po_tr_create(po_problem prob, po_tr *out) {
   PO_CHECK_PTR(prob);
   PO_CHECK_PTR(out);
   po_tr_s *h = new po_tr_s();
+  h->eig_holder = nullptr;
   h->tr = new TrustRegion(prob->p);
   *out = h;
   return PO_OK;
 }
 int po_tr_destroy(po_tr tr) {
   if (!tr) return PO_OK;
-  for (size_t i = 0; i < g_holders.size(); i++) {
-    if (g_holders[i].first == tr) {
-      delete g_holders[i].second;
-      g_holders.erase(g_holders.begin() + i);
-      break;
-    }
-  }
   delete tr->tr;
+  delete static_cast<po_tr_holder *>(tr->eig_holder);
   delete tr;
   return PO_OK;
 }

@@ -231,6 +231,7 @@ class TrustRegion {
 
 struct po_tr_s {
   po::TrustRegion *tr;
+  void *eig_holder;  // capi_tr.cpp: storage behind the eigenvalue-model callbacks, owned by the handle
 };
 struct po_eig_s {
   po::CompactEigenApprox *e;

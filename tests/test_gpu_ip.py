@@ -183,6 +183,61 @@ def test_ip_vs_oracle_large(ctx, problem, n, c, qn, m):
         info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)]
 
 
+SWEEP = [
+    # problem, n, c, qn, m, options, weighting (nwcon, nw, nwstart, nwskip, nwineq) or None
+    ("quadratic", 1, 1, "bfgs", 3, {}, None),
+    ("quadratic", 2, 1, "sr1", 2, {}, None),
+    ("convex", 127, 3, "bfgs", 4, {"barrier_strategy": "mehrotra"}, None),
+    ("convex", 129, 2, "bfgs", 4, {"barrier_strategy": "mehrotra_predictor_corrector"}, None),
+    ("quadratic", 511, 5, "bfgs", 7, {"norm_type": "l1"}, None),
+    ("quadratic", 513, 17, "bfgs", 6, {"barrier_strategy": "complementarity_fraction"}, None),
+    ("convex", 1025, 33, "bfgs", 12, {"use_line_search": False}, None),
+    ("rosenbrock", 255, 2, "bfgs", 5, {"abs_res_tol": 1e-6, "starting_point_strategy": "least_squares_multipliers"}, None),
+    ("convex", 513, 2, "bfgs", 5, {}, (51, 7, 3, 3, 51)),            # groups straddle the 512-variable tile
+    ("convex", 1200, 3, "bfgs", 4, {}, (2, 513, 10, 60, 1)),        # groups wider than a tile: untiled kernels
+    ("quadratic", 777, 4, "sr1", 5, {}, (97, 8, 1, 0, 40)),         # mixed inequality / equality groups
+    ("convex", 300, 2, "bfgs", 5, {"use_diag_hessian": True}, (60, 5, 0, 0, 60)),
+    ("convex", 640, 3, "bfgs", 6, {"use_hvec_product": True, "gmres_subspace_size": 8, "nk_switch_tol": 1e3,
+                                   "max_gmres_rtol": 1.0}, None),
+]
+
+
+@pytest.mark.parametrize("problem,n,c,qn,m,extra,wt", SWEEP)
+def test_ip_size_and_option_sweep(ctx, problem, n, c, qn, m, extra, wt):
+    """Awkward sizes (1, 2, odd, one off the tile sizes 128 / 512 / 1024, panels of 1..33 columns) and
+    option combinations without a golden, against the oracle: counters and info tokens exactly."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    opts = {"qn_subspace_size": m, "qn_type": qn, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 8 if qn == "sr1" else 14}
+    opts.update(extra)
+    wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
+    oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
+    osn = []
+    oip.hook = lambda s, k: osn.append(s.snapshot())
+    oip.optimize()
+    prob = pa.SeparableProblem(ctx, problem, n, c)
+    if wt:
+        prob.setWeighting(*wt)
+    ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
+    gsn = []
+    ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
+    ip.optimize()
+    ncmp = min(len(osn), len(gsn))
+    assert ncmp >= min(len(osn), 6)
+    for k in range(ncmp):
+        np.testing.assert_array_equal(gsn[k]["counters"], osn[k]["counters"], err_msg="counters @%d" % k)
+        assert gsn[k]["qn_size"] == osn[k]["qn_size"]
+        assert abs(gsn[k]["mu"] - osn[k]["mu"]) <= 1e-6 * abs(osn[k]["mu"]), k
+        assert abs(gsn[k]["fobj"] - osn[k]["fobj"]) <= 1e-6 * max(1.0, abs(osn[k]["fobj"])), k
+        np.testing.assert_allclose(gsn[k]["norms"], osn[k]["norms"], rtol=1e-6, atol=1e-12)
+        if wt:
+            np.testing.assert_allclose(gsn[k]["wnorms"], osn[k]["wnorms"], rtol=1e-6)
+    assert [t["info"].split() for t in oip.trace[1:ncmp]] == [
+        info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)]
+
+
 def test_python_callback_problem(ctx):
     """The drop-in boundary for user problems: a Python-implemented problem (host arrays via
     getArray, as the reference's examples do) driven by the device solver -- the 2-constraint
