@@ -103,9 +103,14 @@ int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, dou
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out);
 // launch-only variant for the roofline bench (no host sync); result stays in partials
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks);
-int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W);
+// W = V^T diag(d) V.  With kpend > 0 the first kpend (<= 12) columns are L-SR1 columns still to be
+// formed: V[j] = Y_j, S[j] = S_j, and Z_j = Y_j - b0 S_j is used for the Gram AND written to Zout[j].
+int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
+            const double *const *S = nullptr, double *const *Zout = nullptr, int kpend = 0,
+            double b0 = 0.0);
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
-                   int *nblocks, int *nslots);
+                   int *nblocks, int *nslots, const double *const *S = nullptr,
+                   double *const *Zout = nullptr, int kpend = 0, double b0 = 0.0);
 
 // ---- interior-point kernels -------------------------------------------------------------------
 struct Bounds {  // the per-element data every bound-aware kernel needs

@@ -705,11 +705,34 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDia
   const double b0 = (!use_hdiag && qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
   PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   int k = 0;
+  // L-SR1 leaves its columns Z_j = Y_j - b0 S_j unformed after an update; when this Gram pass is their
+  // first consumer they are formed on the fly (and written out for the later passes): the panel is
+  // ordered [Z | Ac] for that launch and the result permuted back to [Ac | Z]
+  std::vector<const double *> Yp, Sp;
+  std::vector<double *> Zo;
+  double b0z = 0.0;
+  const bool fuse_z = qn && use_qn && !diag_only && !has_w && qn->pendingZ(&Yp, &Sp, &Zo, &b0z) &&
+                      !Yp.empty() && Yp.size() <= 12 && c + (int)Yp.size() <= kWgramMaxVecs;
+  if (fuse_z) {
+    k = (int)Yp.size();
+    const int m2 = c + k;
+    std::vector<const double *> P2(Yp);
+    for (Vec *a : Ac) P2.push_back(a->d);
+    std::vector<double> W2((size_t)m2 * m2, 0.0);
+    PO_TRY(k_wgram(ctx, Dinv->d, P2.data(), m2, n, W2.data(), Sp.data(), Zo.data(), k, b0z));
+    qn->pendingZDone();
+    W.assign((size_t)m2 * m2, 0.0);
+    auto perm = [&](int i) { return i < c ? k + i : i - c; };  // index in [Ac | Z] -> index in [Z | Ac]
+    for (int j = 0; j < m2; j++)
+      for (int i = 0; i < m2; i++) W[i + (size_t)m2 * j] = W2[perm(i) + (size_t)m2 * perm(j)];
+  }
   std::vector<const double *> P = panel(use_qn && !diag_only, &k);
   const int m = c + k;
   wk = k;
-  W.assign((size_t)m * m, 0.0);
-  if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+  if (!fuse_z) {
+    W.assign((size_t)m * m, 0.0);
+    if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+  }
   if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930), then W -= U^T Cw U
     PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
     if (prob->addSparseInnerProduct(1.0, x, Dinv, Cw) != 0) return PO_ERR_USER;

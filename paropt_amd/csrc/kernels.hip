@@ -494,10 +494,13 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
 constexpr int kGramTile = 128;            // rows per LDS tile
 constexpr int kGramLd = kGramTile + 2;    // LDS row stride in doubles (== 2 mod 32)
 
-template <int MB>
+// ZP > 0: the first `kpend` (<= 4*ZP) columns are L-SR1 columns that have not been materialised yet:
+// V.p[j] = Y_j, S.p[j] = S_j and the staged value is Z_j = Y_j - b0 S_j, which is also written to
+// Zout.p[j] for the later panel passes of the iteration (saves the separate 3-pass rebuild of Z).
+template <int MB, int ZP>
 __global__ void __launch_bounds__(kBlock)
     wgram_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
-                 double *__restrict__ partials) {
+                 double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0) {
   constexpr int M = 16 * MB;
   constexpr int NBLK = MB * (MB + 1) / 2;
   constexpr int NPASS = 4 * MB;  // staging passes: 4 columns (one per wave) per pass
@@ -522,12 +525,25 @@ __global__ void __launch_bounds__(kBlock)
     const int j = wave + 4 * it;
     colp[it] = V.p[j < nv ? j : nv - 1];
   }
+  // unformed L-SR1 columns: the S_j streams, branch-free like the panel loads (lanes beyond kpend
+  // re-read the last pending column and ignore it)
+  const double *scol[ZP > 0 ? ZP : 1];
+  double *zcol[ZP > 0 ? ZP : 1];
+#pragma unroll
+  for (int it = 0; it < (ZP > 0 ? ZP : 1); it++) {
+    const int j = wave + 4 * it;
+    scol[it] = (ZP > 0 && kpend > 0) ? S.p[j < kpend ? j : kpend - 1] : nullptr;
+    zcol[it] = (ZP > 0 && j < kpend) ? Zout.p[j] : nullptr;
+  }
   const int64_t ilast = ((n - 1) >> 1) << 1;
   // Software pipeline: the global loads of the NEXT tile are issued (all of them, back to back)
   // before the current tile is multiplied, and are only waited for at the next LDS store.  Rows
   // past n are read from the zero pad when they fall in the last pair and clamped to the last
   // in-range pair otherwise; their weight is forced to zero, so they contribute nothing.
   f64x2 buf[NPASS];
+  f64x2 sbuf[ZP > 0 ? ZP : 1];
+  int64_t pre_i = 0;    // row of the prefetched pair, and whether it is in range (for the Z write-back)
+  bool pre_in = false;
   f64x2 dbuf = (f64x2){0.0, 0.0};
 #define PO_GRAM_PREFETCH(TILE)                                                             \
   {                                                                                        \
@@ -536,6 +552,11 @@ __global__ void __launch_bounds__(kBlock)
     if (!_in) _i = ilast;                                                                  \
     _Pragma("unroll") for (int it = 0; it < NPASS; it++) buf[it] =                         \
         ld_stream(colp[it] + _i);                                   \
+    if (ZP > 0) {                                                                          \
+      _Pragma("unroll") for (int it = 0; it < ZP; it++) sbuf[it] = ld_stream(scol[it] + _i); \
+      pre_i = _i;                                                                          \
+      pre_in = _in;                                                                        \
+    }                                                                                      \
     dbuf = *reinterpret_cast<const f64x2 *>(d + _i);                                       \
     if (!_in) dbuf = (f64x2){0.0, 0.0};                                                    \
     else if (_i + 1 >= n) dbuf.y = 0.0;                                                    \
@@ -546,6 +567,13 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int it = 0; it < NPASS; it++) {
       const int j = wave + 4 * it;
+      if (ZP > 0 && it < ZP && j < kpend) {
+        f64x2 z;
+        z.x = buf[it].x - b0 * sbuf[it].x;
+        z.y = buf[it].y - b0 * sbuf[it].y;
+        buf[it] = z;
+        if (pre_in) __builtin_nontemporal_store(z, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
+      }
       if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = buf[it];
     }
     if (wave == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = dbuf;
@@ -594,9 +622,9 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-template <int MB>
+template <int MB, int ZP>
 static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int grid,
-                          int64_t ntiles) {
+                          int64_t ntiles, const PtrTable &st, const PtrTableW &zt, int kpend, double b0) {
   constexpr int M = 16 * MB;
   constexpr int NBLK = MB * (MB + 1) / 2;
   size_t lds_stage = (size_t)(M * kGramLd + kGramTile) * sizeof(double);
@@ -604,19 +632,19 @@ static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, i
   size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
   static bool attr_set = false;
   if (!attr_set) {
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_kernel<MB>),
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_kernel<MB, ZP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgram_kernel<MB>, dim3(grid), dim3(kBlock), lds, c->stream, d, pt, nv, n,
-                     ntiles, c->d_partials);
+  hipLaunchKernelGGL((wgram_kernel<MB, ZP>), dim3(grid), dim3(kBlock), lds, c->stream, d, pt, nv, n,
+                     ntiles, c->d_partials, st, zt, kpend, b0);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   return PO_OK;
 }
 
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, int *nblocks,
-                   int *nslots) {
+                   int *nslots, const double *const *S, double *const *Zout, int kpend, double b0) {
   if (nv > kWgramMaxVecs || nv < 1) {
     set_error("wgram panel width %d outside 1..%d", nv, kWgramMaxVecs);
     return PO_ERR_ARG;
@@ -629,25 +657,40 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   if (g < 1) g = 1;
   const int grid = (int)g;
   PO_TRY(ensure_partials(c, (size_t)grid * NBLK * 256));
-  PtrTable pt;
+  PtrTable pt, st;
+  PtrTableW zt;
   CoefTable ct;
   fill_tables(nullptr, V, nv, &ct, &pt);
-  switch (MB) {
-    case 1: PO_TRY(wgram_launch_t<1>(c, d, pt, nv, n, grid, ntiles)); break;
-    case 2: PO_TRY(wgram_launch_t<2>(c, d, pt, nv, n, grid, ntiles)); break;
-    case 3: PO_TRY(wgram_launch_t<3>(c, d, pt, nv, n, grid, ntiles)); break;
-    case 4: PO_TRY(wgram_launch_t<4>(c, d, pt, nv, n, grid, ntiles)); break;
-    default: PO_TRY(wgram_launch_t<5>(c, d, pt, nv, n, grid, ntiles)); break;
+  fill_tables(nullptr, S, S ? kpend : 0, &ct, &st);
+  for (int j = 0; j < kMaxPanel; j++) zt.p[j] = (Zout && j < kpend) ? Zout[j] : nullptr;
+  if (kpend > 12 || kpend > nv || (kpend > 0 && (!S || !Zout))) {
+    set_error("wgram: %d pending columns cannot be materialised in the Gram pass", kpend);
+    return PO_ERR_ARG;
   }
+#define PO_WG(MBv)                                                                          \
+  if (kpend > 0) {                                                                          \
+    PO_TRY((wgram_launch_t<MBv, 3>(c, d, pt, nv, n, grid, ntiles, st, zt, kpend, b0)));     \
+  } else {                                                                                  \
+    PO_TRY((wgram_launch_t<MBv, 0>(c, d, pt, nv, n, grid, ntiles, st, zt, 0, 0.0)));        \
+  }
+  switch (MB) {
+    case 1: PO_WG(1) break;
+    case 2: PO_WG(2) break;
+    case 3: PO_WG(3) break;
+    case 4: PO_WG(4) break;
+    default: PO_WG(5) break;
+  }
+#undef PO_WG
   *nblocks = grid;
   *nslots = NBLK * 256;
   return PO_OK;
 }
 
-int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W) {
+int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
+            const double *const *S, double *const *Zout, int kpend, double b0) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
-  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots));
+  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0));
   std::vector<double> blocks(nslots);
   PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));
   const int MB = (nv + 15) / 16;

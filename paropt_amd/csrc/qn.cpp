@@ -78,12 +78,14 @@ void CompactQuasiNewton::reset() {  // :127-142 / :603-618
 }
 
 std::vector<const double *> CompactQuasiNewton::zPointers() const {
+  ensureZ();
   std::vector<const double *> p;
   for (Vec *v : Z) p.push_back(v->d);
   return p;
 }
 
 int CompactQuasiNewton::getCompactMat(double *b0_, const double **d0_, const double **M_, Vec ***Z_) {
+  if (Z_) ensureZ();
   if (b0_) *b0_ = b0;
   if (d0_) *d0_ = d0.data();
   if (M_) *M_ = M.data();
@@ -286,20 +288,44 @@ int LSR1::update(Vec *s, Vec *y, int *rc) {  // :636-747
     }
   }
   for (int i = 0; i < k; i++) M[(size_t)i * (k + 1)] -= D[i];
-  // Z_i = Y_i - b0 S_i re-materialised for every held pair (:730-735), one fused pass each
+  // Z_i = Y_i - b0 S_i for every held pair (:730-735): formed lazily -- by the interior point's
+  // weighted-Gram pass when it is the next consumer, by ensureZ() otherwise
   Z.clear();
   d0.assign(k, 1.0);
+  for (int i = 0; i < k; i++) Z.push_back(Zown[i]);
+  z_pending = true;
+  factorM();
+  return PO_OK;
+}
+
+bool LSR1::pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp,
+                    std::vector<double *> *Zout, double *b0_) const {
+  if (!z_pending) return false;
+  const int k = (int)Z.size();
+  Yp->clear();
+  Sp->clear();
+  Zout->clear();
+  for (int i = 0; i < k; i++) {
+    Yp->push_back(Y[i]->d);
+    Sp->push_back(S[i]->d);
+    Zout->push_back(Zown[i]->d);
+  }
+  *b0_ = b0;
+  return true;
+}
+
+int LSR1::ensureZ() const {
+  if (!z_pending) return PO_OK;
+  const int k = (int)Z.size();
   std::vector<double *> zd;
   std::vector<const double *> yp, sp;
   for (int i = 0; i < k; i++) {
     zd.push_back(Zown[i]->d);
     yp.push_back(Y[i]->d);
     sp.push_back(S[i]->d);
-    Z.push_back(Zown[i]);
   }
-  PO_TRY(k_panel_lincomb(ctx, zd.data(), 1.0, yp.data(), -b0, sp.data(), k, n));
-  factorM();
-  return PO_OK;
+  z_pending = false;
+  return k_panel_lincomb(ctx, zd.data(), 1.0, yp.data(), -b0, sp.data(), k, n);
 }
 
 }  // namespace po

@@ -36,6 +36,16 @@ class CompactQuasiNewton {
   virtual int size() const { return (int)Z.size(); }
   virtual double diag() const { return b0; }
   virtual std::vector<const double *> zPointers() const;
+  // L-SR1 only: after update() the columns Z_j = Y_j - b0 S_j are left unformed until somebody needs
+  // them.  A consumer that can form them on the fly (the weighted-Gram pass of the interior point)
+  // asks for the ingredients and then declares them materialised; everybody else goes through
+  // zPointers() / getCompactMat() / mult(), which form them first (one fused 3-pass launch).
+  virtual bool pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp,
+                        std::vector<double *> *Zout, double *b0_) const {
+    return false;
+  }
+  virtual void pendingZDone() {}
+  virtual int ensureZ() const { return PO_OK; }
 
   Ctx *ctx;
   int64_t n;
@@ -74,9 +84,20 @@ class LBFGS : public CompactQuasiNewton {
 
 class LSR1 : public CompactQuasiNewton {
  public:
-  LSR1(Ctx *ctx, int64_t n, int msub_max) : CompactQuasiNewton(ctx, n, msub_max, true) {}
+  LSR1(Ctx *ctx, int64_t n, int msub_max) : CompactQuasiNewton(ctx, n, msub_max, true), z_pending(false) {}
+  void reset() override {
+    z_pending = false;
+    CompactQuasiNewton::reset();
+  }
   int update(Vec *s, Vec *y, int *rc) override;
   int getMaxLimitedMemorySize() override { return msub_max; }
+  bool pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp, std::vector<double *> *Zout,
+                double *b0_) const override;
+  void pendingZDone() override { z_pending = false; }
+  int ensureZ() const override;
+
+ private:
+  mutable bool z_pending;
 };
 
 }  // namespace po
