@@ -112,3 +112,99 @@ def test_reference_style_problem_ip_and_tr(tmp_path):
     np.testing.assert_allclose(x3[:], omma.x, rtol=0, atol=1e-6)
     np.testing.assert_allclose(z3, omma.z, rtol=1e-5, atol=1e-7)
     assert open(mfile).read().count("\n") >= 13
+
+
+def test_sparse_rosenbrock_example_style():
+    """examples/sparse/sparse_rosenbrock.py in spirit: two variables, NO dense constraint, one sparse
+    constraint x0 + x1 + 5 >= 0 through the nwblock = 1 callbacks, solved by the interior point and by
+    the trust-region driver (the example's own options); checked against the oracle."""
+    from oracle import paropt_oracle as po
+    from oracle import tr_oracle as tro
+    from paropt_amd import ParOpt
+
+    x0 = np.array([-1.3, -0.4])
+
+    class Rosenbrock(ParOpt.Problem):
+        def __init__(self):
+            self.comm = None
+            self.nvars, self.ncon, self.nwcon, self.nwblock = 2, 0, 1, 1
+            super(Rosenbrock, self).__init__(self.comm, nvars=self.nvars, ncon=self.ncon, nwcon=self.nwcon,
+                                             nwblock=self.nwblock)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = x0
+            lb[:] = -2.0
+            ub[:] = 2.0
+
+        def evalObjCon(self, x):
+            return 0, 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2, np.zeros(1)
+
+        def evalObjConGradient(self, x, g, A):
+            g[0] = 200 * (x[1] - x[0] ** 2) * (-2 * x[0]) - 2 * (1 - x[0])
+            g[1] = 200 * (x[1] - x[0] ** 2)
+            return 0
+
+        def evalSparseCon(self, x, con):
+            con[0] = x[0] + x[1] + 5.0
+
+        def addSparseJacobian(self, alpha, x, px, con):
+            con[0] += alpha * (px[0] + px[1])
+
+        def addSparseJacobianTranspose(self, alpha, x, pz, out):
+            out[0] += alpha * pz[0]
+            out[1] += alpha * pz[0]
+
+        def addSparseInnerProduct(self, alpha, x, c, A):
+            A[0] += alpha * (c[0] + c[1])
+
+    class OracleRosen:
+        comm = po.SelfComm()
+        nlocal, c, nwcon, nwineq = 2, 0, 1, 1
+
+        def vars_and_bounds(self):
+            return x0.copy(), np.full(2, -2.0), np.full(2, 2.0)
+
+        def eval_obj_con(self, x):
+            return 0, 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2, np.zeros(0)
+
+        def eval_obj_con_gradient(self, x):
+            return 0, np.array([200 * (x[1] - x[0] ** 2) * (-2 * x[0]) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2)]), []
+
+        def eval_sparse_con(self, x):
+            return np.array([x[0] + x[1] + 5.0])
+
+        def add_sparse_jacobian(self, alpha, px, out):
+            out[0] += alpha * (px[0] + px[1])
+            return out
+
+        def add_sparse_jacobian_transpose(self, alpha, pzw, out):
+            out[:] += alpha * pzw[0]
+            return out
+
+        def add_sparse_inner_product(self, alpha, cvec, A):
+            A[0] += alpha * (cvec[0] + cvec[1])
+            return A
+
+    ip_opts = {"algorithm": "ip", "qn_subspace_size": 5, "abs_res_tol": 1e-8, "max_major_iters": 200, "output_file": None}
+    opt = ParOpt.Optimizer(Rosenbrock(), ip_opts)
+    opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+    oip = po.InteriorPoint(OracleRosen(), {"qn_subspace_size": 5, "abs_res_tol": 1e-8, "max_major_iters": 200})
+    oip.optimize()
+    assert opt.ip.getIterationCounters() == (oip.niter, oip.neval, oip.ngeval)
+    np.testing.assert_allclose(x[:], oip.vars.x, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(x[:], [1.0, 1.0], atol=1e-5)  # the unconstrained Rosenbrock minimum is feasible
+    np.testing.assert_allclose(zw[:], oip.vars.zw, rtol=0, atol=1e-7)
+
+    tr_opts = {"algorithm": "tr", "tr_init_size": 0.5, "tr_min_size": 1e-6, "tr_max_size": 10.0, "tr_eta": 0.1,
+               "tr_adaptive_gamma_update": True, "tr_max_iterations": 60, "tr_output_file": None, "output_file": None}
+    opt2 = ParOpt.Optimizer(Rosenbrock(), tr_opts)
+    opt2.optimize()
+    x2 = opt2.getOptimizedPoint()[0]
+    ops = po.VecOps(po.SelfComm())
+    sub = tro.QuadraticSubproblem(OracleRosen(), po.LBFGS(2, 10, ops, "skip_negative_curvature"))
+    otr = tro.TrustRegion(sub, po.InteriorPoint(sub, {}), {"tr_init_size": 0.5, "tr_min_size": 1e-6,
+                                                           "tr_max_size": 10.0, "tr_eta": 0.1, "tr_max_iterations": 60})
+    otr.optimize()
+    assert opt2.tr.getState()["iter_count"] == otr.iter_count
+    np.testing.assert_allclose(x2[:], sub.xk, rtol=0, atol=1e-6)
