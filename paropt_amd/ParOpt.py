@@ -122,6 +122,57 @@ class Problem(_api.Problem):
         super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq,
                          use_lower=kwargs.get("use_lower", True), use_upper=kwargs.get("use_upper", True))
 
+    def checkGradients(self, dh=1e-6, x=None, check_hvec_product=False):
+        """ParOptProblem::checkGradients (src/ParOptProblem.cpp:376-620) on the host: directional
+        finite differences of the objective and the dense constraints against the gradients, and for
+        sparse constraints the transpose-equivalence and inner-product identities.  Prints the
+        reference's report and returns the relative errors."""
+        n, m, w = self.nvars, self.ncon, self.nwcon
+        xa, lb, ub = np.zeros(n), np.zeros(n), np.zeros(n)
+        self._user["gvb"](_Host(xa), _Host(lb), _Host(ub))
+        if x is not None:
+            xa = np.array(x[:], dtype=float)
+        px = np.array([1.0 if i % 2 == 0 else -1.0 for i in range(n)])
+        g, A = np.zeros(n), [np.zeros(n) for _ in range(m)]
+        _, f0, c0 = self._user["eval"](_Host(xa.copy()))
+        c0 = np.array(c0[:m], dtype=float)
+        self._user["grad"](_Host(xa.copy()), _Host(g), [_Host(a) for a in A])
+        _, f1, c1 = self._user["eval"](_Host(xa + dh * px))
+        c1 = np.array(c1[:m], dtype=float)
+        out = {}
+        pobj, fd = float(g @ px), (f1 - f0) / dh
+        out["objective"] = abs(pobj - fd) / max(abs(fd), 1e-300)
+        print("Objective gradient test\nObjective FD: %15.8e  Actual: %15.8e  Err: %8.2e  Rel err: %8.2e" % (
+            fd, pobj, abs(fd - pobj), out["objective"]))
+        for i in range(m):
+            pc, fdc = float(A[i] @ px), (c1[i] - c0[i]) / dh
+            out["con%d" % i] = abs(pc - fdc) / max(abs(fdc), 1e-300)
+            print("Con[%3d]   FD: %15.8e  Actual: %15.8e  Err: %8.2e  Rel err: %8.2e" % (
+                i, fdc, pc, abs(fdc - pc), out["con%d" % i]))
+        if w > 0:
+            zw = np.array([1.05 + 0.25 * (i % 21) for i in range(w)])
+            cw = np.zeros(w)
+            self._user["wjac"](1.0, _Host(xa), _Host(px), _Host(cw))
+            gt = np.zeros(n)
+            self._user["wjact"](1.0, _Host(xa), _Host(zw), _Host(gt))
+            d1, d2 = float(zw @ cw), float(gt @ px)
+            out["transpose"] = abs(d1 - d2) / max(abs(d2), 1e-300)
+            print("\nTranspose-equivalence\nx^{T}*(J(x)*p): %8.2e  p*(J(x)^{T}*x): %8.2e  Err: %8.2e  Rel Err: %8.2e" % (
+                d1, d2, abs(d1 - d2), out["transpose"]))
+            cvec = np.array([0.05 + 0.25 * (i % 37) for i in range(n)])
+            Cw = np.zeros(w)
+            self._user["winner"](1.0, _Host(xa), _Host(cvec), Cw)
+            t = np.zeros(n)
+            self._user["wjact"](1.0, _Host(xa), _Host(zw), _Host(t))
+            t *= cvec
+            cw2 = np.zeros(w)
+            self._user["wjac"](1.0, _Host(xa), _Host(t), _Host(cw2))
+            d1, d2 = float(cw2 @ zw), float(np.sum(Cw * zw * zw))
+            out["inner_product"] = abs(d1 - d2) / max(abs(d2), 1e-300)
+            print("\nJ(x)*C^{-1}*J(x)^{T} test: \nProduct: %8.2e  Matrix: %8.2e  Err: %8.2e  Rel Err: %8.2e" % (
+                d1, d2, abs(d1 - d2), out["inner_product"]))
+        return out
+
     def _gvb(self, x, lb, ub):
         self._user["gvb"](_Host(x), _Host(lb), _Host(ub))
 

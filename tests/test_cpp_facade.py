@@ -78,3 +78,37 @@ def test_cpp_optimizer_trust_region(tmp_path):
     assert abs(out["fobj"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
     np.testing.assert_allclose(out["xnorm"], g["final/xnorm"][0], rtol=1e-6)
     np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-4, atol=1e-6)
+
+
+def build_c(tmp_path):
+    exe = str(tmp_path / "c_abi_quadratic")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "c_abi_quadratic.c"), "-L" + os.path.join(ROOT, "paropt_amd"),
+           "-lparopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "paropt_amd"), "-Wl,-rpath-link,/opt/rocm/lib",
+           "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_abi_header_is_c99_and_links(tmp_path):
+    """include/paropt_amd.h is plain C (no C++ in the boundary) and every call of the example links."""
+    import torch
+
+    exe = build_c(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    res = subprocess.run([exe, "1000"], capture_output=True, text=True)
+    assert res.returncode == 2 and "no MI355X available" in res.stderr
+
+
+@pytest.mark.gpu
+def test_c_abi_three_algorithms_agree(tmp_path):
+    """ip, tr and mma from plain C on the same convex quadratic reach the same optimum."""
+    exe = build_c(tmp_path)
+    res = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    f = out["ip"]["fobj"]
+    assert abs(out["tr"]["fobj"] - f) <= 1e-4 * max(1.0, abs(f))
+    assert abs(out["mma"]["fobj"] - f) <= 1e-3 * max(1.0, abs(f))
+    assert out["ip"]["niter"] > 5 and out["tr"]["iters"] > 3 and out["mma"]["sub_iters"] > out["mma"]["iters"]

@@ -185,6 +185,8 @@ def test_sparse_rosenbrock_example_style():
             A[0] += alpha * (cvec[0] + cvec[1])
             return A
 
+    errs = Rosenbrock().checkGradients()  # the example calls it before optimising
+    assert errs["objective"] < 1e-4 and errs["transpose"] < 1e-12 and errs["inner_product"] < 1e-12
     ip_opts = {"algorithm": "ip", "qn_subspace_size": 5, "abs_res_tol": 1e-8, "max_major_iters": 200, "output_file": None}
     opt = ParOpt.Optimizer(Rosenbrock(), ip_opts)
     opt.optimize()
