@@ -201,6 +201,15 @@ int po_ip_get_barrier_parameter(po_ip ip, double *mu);      /* .cpp:1110 */
 int po_ip_get_complementarity(po_ip ip, double *comp);      /* .cpp:1118-1120 */
 int po_ip_get_objective(po_ip ip, double *fobj, double *rho);
 int po_ip_set_penalty_gamma(po_ip ip, double gamma);        /* .cpp:1127-1151 */
+/* setPenaltyGamma(const double*) .cpp:1160-1172: one value per dense constraint (negative = keep) */
+int po_ip_set_penalty_gamma_array(po_ip ip, const double *gamma);
+/* setQuasiNewton .cpp:1193-1234: use a caller-owned approximation (NULL detaches it; the solver then
+ * needs sequential_linear_method or use_diag_hessian); resetProblemInstance .cpp:745-764: swap in a
+ * problem of identical sizes (the trust-region and MMA drivers do both) */
+int po_ip_set_quasi_newton(po_ip ip, po_qn qn);
+int po_ip_reset_problem_instance(po_ip ip, po_problem prob);
+/* number of Hessian-vector products of the last optimize (getIterationCounters' 4th output) */
+int po_ip_get_hvec_count(po_ip ip, int *nhvec);
 int po_ip_reset_design_and_bounds(po_ip ip);                /* .cpp:1249-1251 */
 int po_ip_reset_quasi_newton(po_ip ip);                     /* resetQuasiNewtonHessian .cpp:1241-1245 */
 int po_ip_get_quasi_newton(po_ip ip, po_qn *qn);            /* borrowed */

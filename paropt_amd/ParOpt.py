@@ -242,6 +242,12 @@ class InteriorPoint(_api.InteriorPoint):
         opts = {k: v for k, v in opts.items() if not k.startswith(_TR_ONLY + _MMA_ONLY)}
         super().__init__(problem, opts)
 
+    def getOptimizedSlacks(self):
+        """s, t, sw, tw as the reference returns them (ParOpt.pyx:1291-1322)."""
+        s, t, zs, zt = super().getOptimizedSlacks()
+        w = self.getOptimizedSparse()
+        return s, t, (PVec(w[1]) if w else None), (PVec(w[2]) if w else None)
+
     def getOptimizedPoint(self):
         x, z, zl, zu = super().getOptimizedPoint()
         w = self.getOptimizedSparse()

@@ -519,6 +519,34 @@ class InteriorPoint:
         check(lib.po_ip_get_counters(self._h, C.byref(a), C.byref(b), C.byref(d)))
         return a.value, b.value, d.value
 
+    def setPenaltyGamma(self, gamma):
+        check(lib.po_ip_set_penalty_gamma(self._h, float(gamma)))
+
+    def setMultiplePenaltyGamma(self, gamma):
+        arr = np.ascontiguousarray(gamma, dtype=np.float64)
+        assert len(arr) == self.problem.ncon
+        check(lib.po_ip_set_penalty_gamma_array(self._h, arr.ctypes.data_as(L.c_double_p)))
+
+    def setQuasiNewton(self, qn):
+        """Use a caller-owned LBFGS / LSR1 (kept alive by this object); None detaches it."""
+        self._qn_ref = qn
+        check(lib.po_ip_set_quasi_newton(self._h, qn._h if qn is not None else None))
+
+    def resetProblemInstance(self, problem):
+        self._prob_ref = problem
+        check(lib.po_ip_reset_problem_instance(self._h, problem.handle))
+
+    def resetQuasiNewtonHessian(self):
+        check(lib.po_ip_reset_quasi_newton(self._h))
+
+    def resetDesignAndBounds(self):
+        check(lib.po_ip_reset_design_and_bounds(self._h))
+
+    def getHvecCount(self):
+        v = C.c_int()
+        check(lib.po_ip_get_hvec_count(self._h, C.byref(v)))
+        return v.value
+
     def getBarrierParameter(self):
         v = C.c_double()
         check(lib.po_ip_get_barrier_parameter(self._h, C.byref(v)))

@@ -502,6 +502,27 @@ int po_ip_set_penalty_gamma(po_ip ip, double gamma) {
   ip->ip->setPenaltyGamma(gamma);
   return PO_OK;
 }
+int po_ip_set_penalty_gamma_array(po_ip ip, const double *gamma) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(gamma);
+  ip->ip->setPenaltyGammaArray(gamma);
+  return PO_OK;
+}
+int po_ip_set_quasi_newton(po_ip ip, po_qn qn) {
+  PO_CHECK_PTR(ip);
+  return ip->ip->setQuasiNewton(qn ? qn->qn : nullptr);
+}
+int po_ip_reset_problem_instance(po_ip ip, po_problem prob) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(prob);
+  return ip->ip->resetProblemInstance(prob->p);
+}
+int po_ip_get_hvec_count(po_ip ip, int *nhvec) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(nhvec);
+  *nhvec = ip->ip->nhvec;
+  return PO_OK;
+}
 int po_ip_reset_design_and_bounds(po_ip ip) {
   PO_CHECK_PTR(ip);
   return ip->ip->resetDesignAndBounds();

@@ -152,6 +152,10 @@ SIGNATURES = {
     "po_ip_get_complementarity": (C.c_int, [po_ip, c_double_p]),
     "po_ip_get_objective": (C.c_int, [po_ip, c_double_p, c_double_p]),
     "po_ip_set_penalty_gamma": (C.c_int, [po_ip, C.c_double]),
+    "po_ip_set_penalty_gamma_array": (C.c_int, [po_ip, c_double_p]),
+    "po_ip_set_quasi_newton": (C.c_int, [po_ip, po_qn]),
+    "po_ip_reset_problem_instance": (C.c_int, [po_ip, po_problem]),
+    "po_ip_get_hvec_count": (C.c_int, [po_ip, c_int_p]),
     "po_ip_reset_design_and_bounds": (C.c_int, [po_ip]),
     "po_ip_reset_quasi_newton": (C.c_int, [po_ip]),
     "po_ip_get_quasi_newton": (C.c_int, [po_ip, C.POINTER(po_qn)]),

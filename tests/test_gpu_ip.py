@@ -400,6 +400,45 @@ def test_python_hessian_callbacks(ctx):
             assert "iNK" in ip1.getHistory()
 
 
+def test_external_quasi_newton_and_penalties(ctx):
+    """setQuasiNewton / setPenaltyGamma(array) / getIterationCounters' nhvec (src/ParOptInteriorPoint.h:
+    157-185): a caller-owned L-BFGS gives the same trajectory as the solver's own, per-constraint penalties
+    equal to the scalar default change nothing, a detached approximation needs the sequential linear mode."""
+    import paropt_amd as pa
+
+    n, c = 3000, 3
+    opts = {"qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 25, "write_output_frequency": 0}
+    ip1 = pa.InteriorPoint(pa.SeparableProblem(ctx, "quadratic", n, c), opts)
+    ip1.optimize()
+    prob2 = pa.SeparableProblem(ctx, "quadratic", n, c)
+    ip2 = pa.InteriorPoint(prob2, opts)
+    qn = pa.LBFGS(ctx, prob2.nvars, 6)
+    ip2.setQuasiNewton(qn)
+    ip2.setMultiplePenaltyGamma([1000.0] * c)
+    ip2.optimize()
+    assert ip1.getIterationCounters() == ip2.getIterationCounters()
+    np.testing.assert_allclose(ip2.getOptimizedPoint()[0].to_numpy(), ip1.getOptimizedPoint()[0].to_numpy(),
+                               rtol=0, atol=1e-12)
+    k = C_int_size(qn)
+    assert k == 12  # the caller's object holds the pairs
+    assert ip2.getHvecCount() == 0
+    ip3 = pa.InteriorPoint(pa.SeparableProblem(ctx, "quadratic", n, c), dict(opts, max_major_iters=5))
+    ip3.setQuasiNewton(None)
+    with pytest.raises(pa.ParOptAMDError):
+        ip3.optimize()  # neither a quasi-Newton approximation nor a sequential linear method
+
+
+def C_int_size(qn):
+    import ctypes as C
+
+    from paropt_amd import lib as L
+
+    k, b0 = C.c_int(), C.c_double()
+    L.check(L.lib.po_qn_get_compact(qn._h, C.byref(k), C.byref(b0), None, None, None))
+    return k.value
+
+
 def test_option_errors(ctx):
     import paropt_amd as pa
 
