@@ -324,6 +324,7 @@ class ParOptCompactQuasiNewton : public ParOptBase {
     return k;
   }
   int getMaxLimitedMemorySize() { int k = 0; po_qn_max_size(h, &k); return k; }
+  po_qn handle() { return h; }
 
  protected:
   ParOptCompactQuasiNewton() : h(NULL) {}
@@ -411,11 +412,23 @@ class ParOptInteriorPoint : public ParOptBase {
   }
   void getIterationCounters(int *niter = NULL, int *neval = NULL, int *ngeval = NULL, int *nhvec = NULL) {
     po_ip_get_counters(ip, niter, neval, ngeval);
-    if (nhvec) *nhvec = 0;
+    if (nhvec) po_ip_get_hvec_count(ip, nhvec);
   }
   double getBarrierParameter() { double v = 0; po_ip_get_barrier_parameter(ip, &v); return v; }
   ParOptScalar getComplementarity() { double v = 0; po_ip_get_complementarity(ip, &v); return v; }
   void setPenaltyGamma(double gamma) { po_ip_set_penalty_gamma(ip, gamma); }
+  void setPenaltyGamma(const double *gamma) { po_ip_set_penalty_gamma_array(ip, gamma); }
+  // the caller keeps ownership of (and must keep alive) the approximation; NULL detaches it
+  void setQuasiNewton(ParOptCompactQuasiNewton *qn) { po_ip_set_quasi_newton(ip, qn ? qn->handle() : NULL); }
+  void resetProblemInstance(ParOptProblem *problem) {
+    if (po_ip_reset_problem_instance(ip, problem->handle()) == 0) {
+      problem->incref();
+      prob->decref();
+      prob = problem;
+    } else {
+      fprintf(stderr, "ParOpt: Incompatible problem instance\n");
+    }
+  }
   void resetQuasiNewtonHessian() { po_ip_reset_quasi_newton(ip); }
   void resetDesignAndBounds() { po_ip_reset_design_and_bounds(ip); }
   int writeSolutionFile(const char *filename) { return po_ip_write_solution_file(ip, filename); }
