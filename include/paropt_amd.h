@@ -40,7 +40,8 @@ enum {
   PO_ERR_COMM = 3,      /* RCCL / communicator failure */
   PO_ERR_NO_DEVICE = 4, /* no usable gfx950 device: the product has no CPU fallback */
   PO_ERR_OPTION = 5,    /* unknown option or wrong type (src/ParOptOptions.cpp:310-386) */
-  PO_ERR_USER = 6       /* a problem callback returned non-zero */
+  PO_ERR_USER = 6,      /* a problem callback returned non-zero */
+  PO_ERR_NUMERIC = 7    /* a factorization broke down (sparse Cholesky pivot <= 0) */
 };
 
 const char *po_last_error(void);
@@ -54,6 +55,10 @@ int po_ctx_synchronize(po_ctx ctx);
 int po_ctx_rank(po_ctx ctx, int *rank, int *size);
 /* The HIP stream every kernel of this context is launched on (a hipStream_t). */
 void *po_ctx_stream(po_ctx ctx);
+/* Copy between a host buffer and a raw device array this library handed out (the Jacobian entries of
+ * po_problem_set_sparse_jacobian_data), ordered with the context's stream; returns when the copy is done.
+ * to_device != 0: host -> device. */
+int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_device);
 /* RCCL over xGMI: rank 0 calls po_rccl_unique_id, ships the bytes to the other ranks by any
  * side channel (the Python harness uses the torch.distributed store), then every rank calls
  * po_ctx_comm_init_rccl.  Replaces the MPI_Allreduce/Reduce/Bcast sites of SURVEY.md 2.3. */
@@ -152,6 +157,47 @@ typedef struct po_problem_sparse_callbacks {
  * valid on a problem made by po_problem_create_callbacks, before po_ip_create */
 int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequality,
                                     const po_problem_sparse_callbacks *cb);
+/* CSR form of the sparse constraints: ParOptSparseProblem (src/ParOptProblem.h:301-395,
+ * src/ParOptProblem.cpp:624-816; Cython side src/CyParOptProblem.h:177-262).  The Jacobian Aw of the
+ * nwcon rank-local sparse constraints has a FIXED pattern (rowp[nwcon+1], cols[nnz], local column
+ * indices, any order within a row, no duplicates); rows may overlap, so S = C + Aw D^-1 Aw^T is a general
+ * sparse SPD matrix, factored on the device (ParOptQuasiDefSparseMat, src/ParOptSparseMat.cpp:234-450).
+ *   eval_sparse_obj_con          evalSparseObjCon :332: also writes sparse_con = cw(x) (w-sized device vector)
+ *   eval_sparse_obj_con_gradient evalSparseObjConGradient :335: also writes the nnz Jacobian entries, in the
+ *                                order of `cols`, to `data` - a DEVICE array (hipMemcpy or a kernel)
+ * Replaces the problem's eval_obj_con / eval_obj_con_gradient callbacks, as the reference's subclass does.
+ * Only on a problem made by po_problem_create_callbacks, before po_ip_create. */
+typedef int (*po_eval_sparse_obj_con_fn)(void *user, po_vec x, double *fobj, double *cons, po_vec sparse_con);
+typedef int (*po_eval_sparse_obj_con_gradient_fn)(void *user, po_vec x, po_vec g, po_vec *Ac, double *data,
+                                                  int64_t nnz);
+int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwinequality, const int *rowp,
+                                        const int *cols, po_eval_sparse_obj_con_fn eval_sparse_obj_con,
+                                        po_eval_sparse_obj_con_gradient_fn eval_sparse_obj_con_gradient);
+/* getSparseJacobianData (src/ParOptProblem.cpp:689-703): host pattern, device values; returns nnz in *nnz */
+int po_problem_get_sparse_jacobian_data(po_problem p, const int **rowp, const int **cols, double **data,
+                                        int64_t *nnz);
+/* ParOptQuasiDefMat (src/ParOptSparseMat.h:18-62) of any problem with sparse constraints, block or CSR form:
+ * factor: c holds the diagonal C on entry (the block form leaves 1/(C + diag(Aw dinv Aw^T)) in it);
+ * apply: [D Aw^T; Aw -C] [yx; -yw] = [bx; bw] with the factor of the last po_quasidef_factor, bw may be
+ * NULL (the three-argument apply :39).  bx must not alias yx. */
+int po_quasidef_factor(po_problem p, po_vec x, po_vec dinv, po_vec c);
+int po_quasidef_apply(po_problem p, po_vec x, po_vec dinv, po_vec c, po_vec bx, po_vec bw, po_vec yx, po_vec yw);
+/* getFactorInfo (src/ParOptSparseMat.cpp:433-450): one line about the sparse factor, NULL for the block form */
+const char *po_quasidef_factor_info(po_problem p);
+/* The one-time host analysis behind po_problem_set_sparse_jacobian_data, exposed so it can be inspected (and
+ * tested) without a device: column-sorted pattern, pattern of S = Aw Aw^T, nested-dissection ordering,
+ * elimination tree, pattern of L (CSR, diagonal last in each row) and the dependency level sets the device
+ * factorization and solves are scheduled by.  No context needed.
+ * info = {nnz(Aw), nnz(lower S), nnz(L), forward levels, backward levels, 1 if `cols` was already sorted}. */
+typedef struct po_csr_symbolic_s *po_csr_symbolic;
+int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const int *cols, po_csr_symbolic *out);
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[6]);
+/* borrowed host arrays: perm[new] = old (nwcon), parent (nwcon), Lrowp (nwcon+1), Lcols (nnz(L)),
+ * fwd_ptr (levels+1) / fwd_order (nwcon), bwd_ptr / bwd_order; any output pointer may be NULL */
+int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
+                           const int **Lcols, const int **fwd_ptr, const int **fwd_order, const int **bwd_ptr,
+                           const int **bwd_order);
+int po_csr_symbolic_destroy(po_csr_symbolic h);
 /* Second-order information (src/ParOptProblem.h:160-189) for use_hvec_product / use_diag_hessian:
  * evalHvecProduct: hvec = H(x, z, zw) px ; evalHessianDiag: hdiag = diag H(x, z, zw), with H the
  * Hessian of the Lagrangian f - z^T c - zw^T cw.  zw is NULL when nwcon = 0.  Either may be NULL. */
@@ -168,6 +214,11 @@ int po_problem_create_separable(po_ctx ctx, int kind, int64_t nglobal, int ncon,
 int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstart, int nwskip,
                              int64_t nwinequality);
 int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequality_local);
+/* Overlapping nonlinear sparse constraints on a built-in workload, in the CSR form above and rank-local like
+ * examples/rosenbrock/sparse_rosenbrock.cpp:38-118 (which is span 2, stride 1):
+ * cw_i = 1 - sum_{k<span} x[i*stride + k]^2 >= 0, i < (nlocal - span)/stride + 1.  reverse_cols stores each
+ * row's columns in descending order (exercises the unsorted-pattern path).  Before po_ip_create. */
+int po_problem_set_chain(po_problem p, int span, int stride, int reverse_cols);
 /* useLowerBounds / useUpperBounds (src/ParOptProblem.h:140-150; CyParOptProblem::setVarBoundOptions):
  * a problem that declares a side unused never has that side's bound multipliers formed.  Before
  * po_ip_create. */

@@ -327,6 +327,32 @@ for tag, extra in (
         **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
                                   "opt.max_major_iters": 60}, **extra)),
     )
+# --- CSR form of the sparse constraints: the reference's ParOptSparseProblem with the
+# overlapping chain constraints of examples/rosenbrock/sparse_rosenbrock.cpp generalised to span / stride;
+# the S-solve is oracle/ref_driver.cpp's dense LAPACK quasi-definite matrix (the reference's sparse Cholesky
+# needs METIS, absent here), everything else is the reference.
+case("ipcsr_rosenbrock_n100_chain2", "ip", problem="rosenbrock", n=100, chain_span=2, chain_stride=1,
+     dump_vecs_every=10,
+     **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-6,
+        "opt.barrier_strategy": "monotone", "opt.write_output_frequency": 1, "opt.max_major_iters": 150})
+case("ipcsr_convex_n240_c3_chain3s2_rev", "ip", problem="convex", n=240, c=3, chain_span=3, chain_stride=2,
+     chain_reverse=1, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 80}))
+case("ipcsr_quadratic_n200_c2_chain4s4", "ip", problem="quadratic", n=200, c=2, chain_span=4, chain_stride=4,
+     dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.qn_type": "bfgs", "opt.max_major_iters": 80}))
+for tag, extra in (
+    ("mpc", {"opt.barrier_strategy": "mehrotra_predictor_corrector"}),
+    ("sr1", {"opt.qn_type": "sr1"}),
+    ("l2_least_squares", {"opt.norm_type": "l2", "opt.starting_point_strategy": "least_squares_multipliers"}),
+):
+    case("ipcsr_convex_n200_c2_chain5s3_%s" % tag, "ip", problem="convex", n=200, c=2, chain_span=5,
+         chain_stride=3, dump_vecs_every=10,
+         **dict(ip_common, **dict({"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs",
+                                   "opt.max_major_iters": 60}, **extra)))
+case("ipcsr_convex_n240_c2_chain2_r2", "ip", ranks=2, problem="convex", n=240, c=2, chain_span=2, chain_stride=1,
+     dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
 # problems that declare no upper / no lower bounds (useUpperBounds() / useLowerBounds() = 0)
 case("ip_quadratic_noupper_n200_c2", "ip", problem="quadratic", n=200, c=2, use_upper=0, dump_vecs_every=10,
      **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 80}))

@@ -311,8 +311,12 @@ class SepProblem:
     """
 
     def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None, nwcon=0, nw=0,
-                 nwstart=0, nwskip=0, nwineq=-1):
+                 nwstart=0, nwskip=0, nwineq=-1, chain=None):
         self.comm = comm if comm is not None else SelfComm()
+        # chain = (span, stride): the CSR form (ParOptSparseProblem, src/ParOptProblem.cpp:624-816) with the
+        # rank-local overlapping constraints cw_i = 1 - sum_{k<span} x[i*stride+k]^2 >= 0 of
+        # oracle/ref_driver.cpp SepCsrProblem (examples/rosenbrock/sparse_rosenbrock.cpp:75-118 is (2, 1))
+        self.chain = tuple(chain) if chain else None
         # weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i*(nw+nwskip) + k] (the pattern of
         # examples/rosenbrock/rosenbrock.cpp:131-184); disjoint supports, nwblock = 1
         self.nwcon, self.nw, self.nwstart, self.nwskip = int(nwcon), int(nw), int(nwstart), int(nwskip)
@@ -323,6 +327,13 @@ class SepProblem:
         self.kind = kind
         self.nglobal = int(n)
         self.nlocal, self.offset = shard(n, self.comm.rank, self.comm.size)
+        if self.chain:
+            span, stride = self.chain
+            rows = (self.nlocal - span) // stride + 1 if self.nlocal >= span else 0
+            self.cidx = (np.arange(rows) * stride)[:, None] + np.arange(span)[None, :]
+            self.nwcon = self.nwineq = rows
+            self._cw = np.zeros(rows)
+            self._jac = np.zeros((rows, span))
         self.c = 2 if kind == "rosenbrock" else int(c)
         self.seed = seed
         idx = np.arange(self.offset, self.offset + self.nlocal, dtype=np.uint64)
@@ -348,9 +359,20 @@ class SepProblem:
             return 0.05 + 0.9 * u01(self.seed, 3, self.idx), np.zeros(n), np.ones(n)
         return np.full(n, -1.0), np.full(n, -2.0), np.full(n, 1.0)
 
+    def sparse_jacobian_dense(self):
+        """Aw as a dense (w, n) array from the stored entries (tests and the dense S of the oracle)."""
+        A = np.zeros((self.nwcon, self.nlocal))
+        if self.chain:
+            np.add.at(A, (np.arange(self.nwcon)[:, None], self.cidx), self._jac)
+        elif self.nwcon:
+            A[np.arange(self.nwcon)[:, None], self.widx] = -1.0
+        return A
+
     def eval_obj_con(self, x):
         c = self.c
         loc = np.zeros(c + 1)
+        if self.chain:  # evalSparseObjCon stores the sparse constraint values (.cpp:724-727)
+            self._cw = 1.0 - np.sum(x[self.cidx] ** 2, axis=1)
         if self.kind == "quadratic":
             loc[0] = np.sum(0.5 * self.q * x * x + self.b * x)
             for j in range(c):
@@ -376,20 +398,28 @@ class SepProblem:
     def eval_sparse_con(self, x):
         if self.nwcon == 0:
             return np.zeros(0)
+        if self.chain:  # the values of the LAST evaluation, whatever x is (.cpp:750-760)
+            return self._cw.copy()
         return 1.0 - np.sum(x[self.widx], axis=1)
 
     def add_sparse_jacobian(self, alpha, px, out):  # out += alpha * Aw px
-        if self.nwcon:
+        if self.chain:  # the entries of the LAST gradient evaluation (.cpp:762-788)
+            out += alpha * np.sum(self._jac * px[self.cidx], axis=1)
+        elif self.nwcon:
             out -= alpha * np.sum(px[self.widx], axis=1)
         return out
 
     def add_sparse_jacobian_transpose(self, alpha, pzw, out):  # out += alpha * Aw^T pzw
-        if self.nwcon:
+        if self.chain:
+            np.add.at(out, self.cidx, alpha * self._jac * pzw[:, None])
+        elif self.nwcon:
             out[self.widx] -= alpha * pzw[:, None]
         return out
 
     def add_sparse_inner_product(self, alpha, cvec, A):  # A += alpha * diag(Aw diag(cvec) Aw^T)
-        if self.nwcon:
+        if self.chain:
+            A += alpha * np.sum(self._jac ** 2 * cvec[self.cidx], axis=1)
+        elif self.nwcon:
             A += alpha * np.sum(cvec[self.widx], axis=1)
         return A
 
@@ -415,6 +445,8 @@ class SepProblem:
         return h
 
     def eval_obj_con_gradient(self, x):
+        if self.chain:  # evalSparseObjConGradient stores the Jacobian entries (.cpp:739-742)
+            self._jac = -2.0 * x[self.cidx]
         if self.kind == "quadratic":
             return 0, self.q * x + self.b, [a.copy() for a in self.A]
         if self.kind == "convex":
@@ -607,7 +639,13 @@ class InteriorPoint:
     # ---- quasi-definite block matrix (nwblock = 1): src/ParOptSparseMat.cpp:41-229 --------
     def _factor(self, v, Cdiag):
         """Cw = 1 / (Cdiag + Aw Dinv Aw^T) per constraint."""
-        if self.w:
+        if self.w and getattr(self.prob, "chain", None):
+            # ParOptQuasiDefSparseMat::factor (src/ParOptSparseMat.cpp:303-356): S = C + Aw D^-1 Aw^T, here
+            # dense (the factorization is a direct solve; its sparsity is an implementation matter)
+            Aw = self.prob.sparse_jacobian_dense()
+            self._Aw = Aw
+            self._Schol = sla.cho_factor(np.diag(Cdiag) + (Aw * self.Dinv) @ Aw.T, lower=True, check_finite=False)
+        elif self.w:
             A = Cdiag.copy()
             self.prob.add_sparse_inner_product(1.0, self.Dinv, A)
             self.Cw = 1.0 / A
@@ -619,7 +657,10 @@ class InteriorPoint:
             return yx, np.zeros(0)
         yw = np.zeros(self.w) if bw is None else bw.copy()
         self.prob.add_sparse_jacobian(-1.0, yx, yw)
-        yw = yw * self.Cw
+        if getattr(self.prob, "chain", None):  # :358-431
+            yw = sla.cho_solve(self._Schol, yw, check_finite=False)
+        else:
+            yw = yw * self.Cw
         yx = bx.copy()
         self.prob.add_sparse_jacobian_transpose(1.0, yw, yx)
         yx = yx * self.Dinv

@@ -39,6 +39,7 @@
 #include "ParOptTrustRegion.h"
 #include "ParOptCompactEigenvalueApprox.h"
 #include "ParOptMMA.h"
+#include "ParOptBlasLapack.h"
 #undef private
 #undef protected
 
@@ -351,6 +352,137 @@ class SepProblem : public ParOptProblem {
   std::vector<double> beta;
   DumpHook *hook;
   struct TrHook *tr_hook;
+};
+
+// ---------------------------------------------------------------------------
+// CSR form of the sparse constraints: the reference's ParOptSparseProblem (its own CSR products,
+// src/ParOptProblem.cpp:762-816) around a SepProblem for the objective and the dense constraints, with
+// the rank-local overlapping chain constraints of examples/rosenbrock/sparse_rosenbrock.cpp:75-118
+// generalised to a span and a stride:
+//     cw_i = 1 - sum_{k<span} x[i*stride + k]^2 >= 0,   i < (nvars - span)/stride + 1.
+// The reference's ParOptQuasiDefSparseMat needs ParOptSparseCholesky.cpp, which needs METIS (absent
+// here), so createQuasiDefMat() - a virtual extension point of ParOptProblem - returns DenseQuasiDef
+// below: the same factor/apply contract (src/ParOptSparseMat.h:18-62) with S = C + A D^-1 A^T formed
+// densely and factored by LAPACK dpptrf.  A direct solve is unique up to round-off, so trajectories
+// recorded this way pin every other piece of the CSR path against the reference.
+// ---------------------------------------------------------------------------
+class SepCsrProblem;
+class DenseQuasiDef : public ParOptQuasiDefMat {
+ public:
+  DenseQuasiDef(ParOptSparseProblem *p) : prob(p), Dinv(NULL) {
+    prob->getProblemSizes(&nvars, NULL, &nwcon);
+    S.resize((size_t)nwcon * (nwcon + 1) / 2);
+    rhs.resize(nvars);
+  }
+  int factor(ParOptVec *x, ParOptVec *Dinv0, ParOptVec *C) {
+    Dinv = Dinv0;
+    const int *rowp, *cols;
+    const ParOptScalar *data;
+    prob->getSparseJacobianData(&rowp, &cols, &data);
+    double *d, *c;
+    Dinv->getArray(&d);
+    C->getArray(&c);
+    std::vector<double> A((size_t)nwcon * nvars, 0.0);
+    for (int i = 0; i < nwcon; i++) {
+      for (int p = rowp[i]; p < rowp[i + 1]; p++) A[(size_t)i * nvars + cols[p]] += data[p];
+    }
+    // packed lower, column-major: S(i,j), i >= j, at i + j*(2n - j - 1)/2
+    for (int j = 0; j < nwcon; j++) {
+      for (int i = j; i < nwcon; i++) {
+        double v = (i == j) ? c[i] : 0.0;
+        for (int k = 0; k < nvars; k++) v += A[(size_t)i * nvars + k] * d[k] * A[(size_t)j * nvars + k];
+        S[i + (size_t)j * (2 * nwcon - j - 1) / 2] = v;
+      }
+    }
+    int info = 0, n = nwcon;
+    LAPACKdpptrf("L", &n, &S[0], &info);
+    return info;
+  }
+  void apply(ParOptVec *bx, ParOptVec *yx, ParOptVec *yw) { applyImpl(bx, NULL, yx, yw); }
+  void apply(ParOptVec *bx, ParOptVec *bw, ParOptVec *yx, ParOptVec *yw) { applyImpl(bx, bw, yx, yw); }
+
+ private:
+  void applyImpl(ParOptVec *bxv, ParOptVec *bwv, ParOptVec *yxv, ParOptVec *ywv) {
+    const int *rowp, *cols;
+    const ParOptScalar *data;
+    prob->getSparseJacobianData(&rowp, &cols, &data);
+    double *bx, *bw = NULL, *yx, *yw, *d;
+    bxv->getArray(&bx);
+    if (bwv) bwv->getArray(&bw);
+    yxv->getArray(&yx);
+    ywv->getArray(&yw);
+    Dinv->getArray(&d);
+    for (int i = 0; i < nwcon; i++) {
+      double v = bw ? bw[i] : 0.0;
+      for (int p = rowp[i]; p < rowp[i + 1]; p++) v -= data[p] * d[cols[p]] * bx[cols[p]];
+      yw[i] = v;
+    }
+    int info = 0, n = nwcon, one = 1;
+    LAPACKdpptrs("L", &n, &one, &S[0], yw, &n, &info);
+    for (int k = 0; k < nvars; k++) rhs[k] = 0.0;
+    for (int i = 0; i < nwcon; i++) {
+      for (int p = rowp[i]; p < rowp[i + 1]; p++) rhs[cols[p]] += data[p] * yw[i];
+    }
+    for (int k = 0; k < nvars; k++) yx[k] = d[k] * (bx[k] + rhs[k]);
+  }
+  ParOptSparseProblem *prob;
+  ParOptVec *Dinv;
+  int nvars, nwcon;
+  std::vector<double> S, rhs;
+};
+
+class SepCsrProblem : public ParOptSparseProblem {
+ public:
+  SepCsrProblem(MPI_Comm comm, SepProblem *_inner, int _span, int _stride, int _reverse)
+      : ParOptSparseProblem(comm), inner(_inner), span(_span), stride(_stride), reverse(_reverse) {
+    inner->incref();
+    int nv, nc;
+    inner->getProblemSizes(&nv, &nc, NULL);
+    const int rows = nv >= span ? (nv - span) / stride + 1 : 0;
+    setProblemSizes(nv, nc, rows);
+    setNumInequalities(nc, rows);
+    std::vector<int> rowp(rows + 1), cols((size_t)rows * span);
+    for (int i = 0; i < rows; i++) {
+      rowp[i] = i * span;
+      for (int k = 0; k < span; k++) cols[i * span + (reverse ? span - 1 - k : k)] = i * stride + k;
+    }
+    rowp[rows] = rows * span;
+    setSparseJacobianData(&rowp[0], &cols[0]);
+    inner->wn = rows;  // the hook dumps the sparse multipliers when wn > 0
+  }
+  ~SepCsrProblem() { inner->decref(); }
+  ParOptQuasiDefMat *createQuasiDefMat() { return new DenseQuasiDef(this); }
+  int useLowerBounds() { return inner->useLowerBounds(); }
+  int useUpperBounds() { return inner->useUpperBounds(); }
+  void getVarsAndBounds(ParOptVec *x, ParOptVec *lb, ParOptVec *ub) { inner->getVarsAndBounds(x, lb, ub); }
+  int evalSparseObjCon(ParOptVec *xv, ParOptScalar *fobj, ParOptScalar *cons, ParOptVec *sparse) {
+    int fail = inner->evalObjCon(xv, fobj, cons);
+    double *x, *c;
+    xv->getArray(&x);
+    sparse->getArray(&c);
+    for (int i = 0; i < nwcon; i++) {
+      double v = 1.0;
+      for (int k = 0; k < span; k++) v -= x[i * stride + k] * x[i * stride + k];
+      c[i] = v;
+    }
+    return fail;
+  }
+  int evalSparseObjConGradient(ParOptVec *xv, ParOptVec *g, ParOptVec **Ac, ParOptScalar *data) {
+    int fail = inner->evalObjConGradient(xv, g, Ac);
+    double *x;
+    xv->getArray(&x);
+    for (int i = 0; i < nwcon; i++) {
+      for (int k = 0; k < span; k++) {
+        data[i * span + (reverse ? span - 1 - k : k)] = -2.0 * x[i * stride + k];
+      }
+    }
+    return fail;
+  }
+  int evalHvecProduct(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *, ParOptVec *) { return 1; }
+  int evalHessianDiag(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *) { return 1; }
+  void writeOutput(int iter, ParOptVec *x) { inner->writeOutput(iter, x); }
+  SepProblem *inner;
+  int span, stride, reverse;
 };
 
 // state dumped at the top of every trust-region iteration (tr_write_output_frequency = 1)
@@ -713,6 +845,13 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   prob->incref();
   prob->use_lower_flag = (int)geti(A, "use_lower", 1);
   prob->use_upper_flag = (int)geti(A, "use_upper", 1);
+  ParOptProblem *top = prob;
+  const int chain_span = (int)geti(A, "chain_span", 0);
+  if (chain_span > 0) {
+    top = new SepCsrProblem(comm, prob, chain_span, (int)geti(A, "chain_stride", 1),
+                            (int)geti(A, "chain_reverse", 0));
+    top->incref();
+  }
   ParOptOptions *opt = new ParOptOptions(comm);
   opt->incref();
   ParOptInteriorPoint::addDefaultOptions(opt);
@@ -723,7 +862,7 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
     opt->setOption("output_file", "/dev/null");
   }
   set_options(opt, A);
-  ParOptInteriorPoint *ip = new ParOptInteriorPoint(prob, opt);
+  ParOptInteriorPoint *ip = new ParOptInteriorPoint(top, opt);
   ip->incref();
   RecFile R;
   DumpHook hook;

@@ -13,6 +13,10 @@ from .api import (  # noqa: F401
     SeparableProblem,
     TrustRegion,
     EigenApprox,
+    CsrSymbolic,
+    quasidef_factor,
+    quasidef_apply,
+    quasidef_factor_info,
     bench_mdot,
     bench_wgram,
     wgram,

@@ -272,13 +272,20 @@ class Problem:
     nwcon > 0 (sparse constraints, nwblock = 1) also override evalSparseCon(x, out),
     addSparseJacobian(alpha, x, px, out), addSparseJacobianTranspose(alpha, x, pzw, out) and
     addSparseInnerProduct(alpha, x, cvec, A) (A is the w-sized diagonal), all in place on numpy views.
+
+    With rowp / cols (the reference's CSR form, paropt/ParOpt.pyx:849-881) override instead
+    evalSparseObjCon(x, sparse_cons) -> (fail, fobj, con) and evalSparseObjConGradient(x, g, A, data) -> fail;
+    sparse_cons (nwcon) and data (nnz, in the order of cols) are filled in place.
     """
 
     def __init__(self, ctx, nvars, ncon, ninequality=-1, nwcon=0, nwinequality=0, use_lower=True,
-                 use_upper=True):
+                 use_upper=True, rowp=None, cols=None):
         self.ctx = ctx
         self.nvars, self.ncon = int(nvars), int(ncon)
         self.nwcon = int(nwcon)
+        self._csr = rowp is not None and cols is not None
+        if self._csr and len(rowp) != self.nwcon + 1:
+            raise ValueError("rowp is incorrect length")  # paropt/ParOpt.pyx:861-862
         cb = L.ProblemCallbacks()
 
         def _gvb(user, x, lb, ub):
@@ -348,7 +355,43 @@ class Problem:
 
             self._hcbs = (L.HVEC_FN(_hvec) if has_hvec else L.HVEC_FN(), L.HDIAG_FN(_hdiag) if has_hdiag else L.HDIAG_FN())
             check(lib.po_problem_set_hessian_callbacks(self._h, self._hcbs[0], self._hcbs[1]))
-        if self.nwcon > 0:
+        if self._csr:
+            self._rowp = np.ascontiguousarray(rowp, dtype=np.intc)
+            self._cols = np.ascontiguousarray(cols, dtype=np.intc)
+            nnz = int(self._rowp[-1])
+            if len(self._cols) != nnz:
+                raise ValueError("cols is incorrect length")
+            self._data_host = np.zeros(max(nnz, 1))
+
+            def _sobjcon(user, x, fobj, cons, sparse):
+                vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+                vs = PVec(ctx, handle=L.po_vec(sparse), owned=False)
+                asp = vs.getArray()
+                fail, f, con = self.evalSparseObjCon(vx.to_numpy(), asp)
+                vs.syncToDevice()
+                fobj[0] = float(f)
+                for j in range(self.ncon):
+                    cons[j] = float(con[j])
+                return int(fail or 0)
+
+            def _sgrad(user, x, g, Ac, data, nnz_):
+                vx = PVec(ctx, handle=L.po_vec(x), owned=False)
+                vg = PVec(ctx, handle=L.po_vec(g), owned=False)
+                va = [PVec(ctx, handle=L.po_vec(Ac[j]), owned=False) for j in range(self.ncon)]
+                ag = vg.getArray()
+                aa = [v.getArray() for v in va]
+                fail = self.evalSparseObjConGradient(vx.to_numpy(), ag, aa, self._data_host[:nnz])
+                vg.syncToDevice()
+                for v in va:
+                    v.syncToDevice()
+                check(lib.po_ctx_memcpy(ctx.handle, data, self._data_host.ctypes.data, 8 * nnz, 1))
+                return int(fail or 0)
+
+            self._csr_cbs = (L.SPARSE_OBJCON_FN(_sobjcon), L.SPARSE_GRAD_FN(_sgrad))
+            check(lib.po_problem_set_sparse_jacobian_data(
+                self._h, self.nwcon, int(nwinequality), self._rowp.ctypes.data_as(L.c_int_p),
+                self._cols.ctypes.data_as(L.c_int_p), self._csr_cbs[0], self._csr_cbs[1]))
+        elif self.nwcon > 0:
             def _wrap(method):
                 def _f(user, alpha, x, v, out):
                     vx = PVec(ctx, handle=L.po_vec(x), owned=False)
@@ -410,6 +453,15 @@ class SeparableProblem:
         self.nwcon = a.value
         return self
 
+    def setChain(self, span=2, stride=1, reverse_cols=False):
+        """Rank-local overlapping sparse constraints in CSR form: cw_i = 1 - sum_{k<span} x[i*stride+k]^2 >= 0
+        (examples/rosenbrock/sparse_rosenbrock.cpp is span 2, stride 1)."""
+        check(lib.po_problem_set_chain(self._h, int(span), int(stride), int(bool(reverse_cols))))
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.po_problem_sparse_sizes(self._h, C.byref(a), C.byref(b)))
+        self.nwcon = a.value
+        return self
+
     def setVarBoundOptions(self, use_lower=True, use_upper=True):
         check(lib.po_problem_set_var_bound_options(self._h, int(bool(use_lower)), int(bool(use_upper))))
         return self
@@ -430,6 +482,52 @@ class SeparableProblem:
                 lib.po_problem_destroy(self._h)
         except Exception:
             pass
+
+
+class CsrSymbolic:
+    """The one-time host analysis of a CSR sparse Jacobian pattern (no device needed): ordering,
+    elimination tree, pattern of the Cholesky factor of S = C + Aw D^-1 Aw^T, dependency level sets."""
+
+    def __init__(self, nvars, rowp, cols):
+        rowp = np.ascontiguousarray(rowp, dtype=np.intc)
+        cols = np.ascontiguousarray(cols, dtype=np.intc)
+        w = len(rowp) - 1
+        h = L.po_csr_symbolic()
+        check(lib.po_csr_symbolic_create(int(nvars), w, rowp.ctypes.data_as(L.c_int_p),
+                                         cols.ctypes.data_as(L.c_int_p), C.byref(h)))
+        try:
+            info = (C.c_int64 * 6)()
+            check(lib.po_csr_symbolic_info(h, info))
+            self.nnz, self.nnzS, self.nnzL, self.nlevels_fwd, self.nlevels_bwd = (int(v) for v in info[:5])
+            self.sorted_input = bool(info[5])
+            ptrs = [L.c_int_p() for _ in range(8)]
+            check(lib.po_csr_symbolic_arrays(h, *[C.byref(p) for p in ptrs]))
+
+            def arr(p, n):
+                return np.ctypeslib.as_array(p, shape=(n,)).copy() if n > 0 else np.zeros(0, dtype=np.intc)
+
+            self.perm, self.parent = arr(ptrs[0], w), arr(ptrs[1], w)
+            self.Lrowp, self.Lcols = arr(ptrs[2], w + 1), arr(ptrs[3], self.nnzL)
+            self.fwd_ptr, self.fwd_order = arr(ptrs[4], self.nlevels_fwd + 1), arr(ptrs[5], w)
+            self.bwd_ptr, self.bwd_order = arr(ptrs[6], self.nlevels_bwd + 1), arr(ptrs[7], w)
+        finally:
+            lib.po_csr_symbolic_destroy(h)
+
+
+def quasidef_factor(problem, x, dinv, c):
+    """ParOptQuasiDefMat::factor (src/ParOptSparseMat.h:25) of the problem's sparse constraints."""
+    check(lib.po_quasidef_factor(problem.handle, x.handle, dinv.handle, c.handle))
+
+
+def quasidef_apply(problem, x, dinv, c, bx, bw, yx, yw):
+    """ParOptQuasiDefMat::apply (:39-56); bw may be None."""
+    check(lib.po_quasidef_apply(problem.handle, x.handle, dinv.handle, c.handle, bx.handle,
+                                bw.handle if bw is not None else None, yx.handle, yw.handle))
+
+
+def quasidef_factor_info(problem):
+    s = lib.po_quasidef_factor_info(problem.handle)
+    return s.decode() if s else None
 
 
 class InteriorPoint:

@@ -58,6 +58,17 @@ int po_ctx_rank(po_ctx ctx, int *rank, int *size) {
   return PO_OK;
 }
 void *po_ctx_stream(po_ctx ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_device) {
+  PO_CHECK_PTR(ctx);
+  if (bytes <= 0) return PO_OK;
+  PO_CHECK_PTR(dst);
+  PO_CHECK_PTR(src);
+  PO_HIP(hipSetDevice(ctx->device));
+  PO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                        ctx->stream));
+  PO_HIP(hipStreamSynchronize(ctx->stream));
+  return PO_OK;
+}
 int po_rccl_unique_id(void *id128) {
   PO_CHECK_PTR(id128);
   return rccl_unique_id(id128);
@@ -349,6 +360,121 @@ int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequ
   q->nwinequality = nwinequality;
   return PO_OK;
 }
+int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwinequality, const int *rowp,
+                                        const int *cols, po_eval_sparse_obj_con_fn eval_sparse_obj_con,
+                                        po_eval_sparse_obj_con_gradient_fn eval_sparse_obj_con_gradient) {
+  PO_CHECK_PTR(p);
+  PO_CHECK_PTR(rowp);
+  CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);
+  if (!q) {
+    po::set_error("po_problem_set_sparse_jacobian_data needs a callback problem");
+    return PO_ERR_ARG;
+  }
+  if (!eval_sparse_obj_con || !eval_sparse_obj_con_gradient) {
+    po::set_error("po_problem_set_sparse_jacobian_data: both evaluation callbacks are required");
+    return PO_ERR_ARG;
+  }
+  PO_TRY(q->setSparseJacobianData(nwcon, nwinequality, rowp, cols));
+  q->csr_obj_con = eval_sparse_obj_con;
+  q->csr_gradient = eval_sparse_obj_con_gradient;
+  return PO_OK;
+}
+int po_problem_get_sparse_jacobian_data(po_problem p, const int **rowp, const int **cols, double **data,
+                                        int64_t *nnz) {
+  PO_CHECK_PTR(p);
+  po::CsrSparse *m = p->p->csr;
+  if (!m) {
+    po::set_error("the problem has no CSR sparse Jacobian");
+    return PO_ERR_ARG;
+  }
+  if (rowp) *rowp = m->user_rowp.data();
+  if (cols) *cols = m->user_cols.data();
+  if (data) *data = m->data;
+  if (nnz) *nnz = m->nnz;
+  return PO_OK;
+}
+int po_quasidef_factor(po_problem p, po_vec x, po_vec dinv, po_vec c) {
+  PO_CHECK_PTR(p);
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(dinv);
+  PO_CHECK_PTR(c);
+  if (p->p->nwcon <= 0 || c->n != p->p->nwcon || dinv->n != p->p->nlocal) {
+    po::set_error("po_quasidef_factor: the problem has no sparse constraints or the sizes do not match");
+    return PO_ERR_ARG;
+  }
+  return p->p->sparseFactor(x, dinv, c);
+}
+int po_quasidef_apply(po_problem p, po_vec x, po_vec dinv, po_vec c, po_vec bx, po_vec bw, po_vec yx,
+                      po_vec yw) {
+  PO_CHECK_PTR(p);
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(dinv);
+  PO_CHECK_PTR(c);
+  PO_CHECK_PTR(bx);
+  PO_CHECK_PTR(yx);
+  PO_CHECK_PTR(yw);
+  po::Problem *q = p->p;
+  if (q->nwcon <= 0 || c->n != q->nwcon || yw->n != q->nwcon || (bw && bw->n != q->nwcon) ||
+      dinv->n != q->nlocal || bx->n != q->nlocal || yx->n != q->nlocal || bx->d == yx->d) {
+    po::set_error("po_quasidef_apply: size mismatch (or bx aliases yx)");
+    return PO_ERR_ARG;
+  }
+  po::Vec *work = po::vec_new(q->ctx, q->nwcon);
+  if (!work) return PO_ERR_HIP;
+  int rc = q->sparseApplyK0(x, dinv, c, bx->d, bw ? bw->d : nullptr, yx, yw, work);
+  if (rc == PO_OK && hipStreamSynchronize(q->ctx->stream) != hipSuccess) rc = PO_ERR_HIP;
+  po::vec_decref(work);
+  return rc;
+}
+struct po_csr_symbolic_s {
+  po::CsrSymbolic s;
+};
+int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const int *cols, po_csr_symbolic *out) {
+  PO_CHECK_PTR(rowp);
+  PO_CHECK_PTR(out);
+  if (nwcon < 0 || nvars < 0 || (rowp[nwcon] > 0 && !cols)) {
+    po::set_error("po_csr_symbolic_create: bad arguments");
+    return PO_ERR_ARG;
+  }
+  po_csr_symbolic h = new po_csr_symbolic_s;
+  int rc = po::csr_analyse(nvars, nwcon, rowp, cols, &h->s);
+  if (rc != PO_OK) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return PO_OK;
+}
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[6]) {
+  PO_CHECK_PTR(h);
+  PO_CHECK_PTR(info);
+  info[0] = h->s.nnz;
+  info[1] = h->s.nnzS;
+  info[2] = h->s.nnzL;
+  info[3] = (int64_t)h->s.fwd_ptr.size() - 1;
+  info[4] = (int64_t)h->s.bwd_ptr.size() - 1;
+  info[5] = h->s.identity_src ? 1 : 0;
+  return PO_OK;
+}
+int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
+                           const int **Lcols, const int **fwd_ptr, const int **fwd_order, const int **bwd_ptr,
+                           const int **bwd_order) {
+  PO_CHECK_PTR(h);
+  if (perm) *perm = h->s.perm.data();
+  if (parent) *parent = h->s.parent.data();
+  if (Lrowp) *Lrowp = h->s.Lrowp.data();
+  if (Lcols) *Lcols = h->s.Lcols.data();
+  if (fwd_ptr) *fwd_ptr = h->s.fwd_ptr.data();
+  if (fwd_order) *fwd_order = h->s.fwd_order.data();
+  if (bwd_ptr) *bwd_ptr = h->s.bwd_ptr.data();
+  if (bwd_order) *bwd_order = h->s.bwd_order.data();
+  return PO_OK;
+}
+int po_csr_symbolic_destroy(po_csr_symbolic h) {
+  delete h;
+  return PO_OK;
+}
+const char *po_quasidef_factor_info(po_problem p) { return p && p->p ? p->p->sparseFactorInfo() : nullptr; }
 int po_problem_set_hessian_callbacks(po_problem p, po_hvec_fn hvec, po_hdiag_fn hdiag) {
   PO_CHECK_PTR(p);
   CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);
@@ -369,6 +495,15 @@ int po_problem_set_weighting(po_problem p, int64_t nwcon, int nw, int64_t nwstar
     return PO_ERR_ARG;
   }
   return q->setWeighting(nwcon, nw, nwstart, nwskip, nwinequality);
+}
+int po_problem_set_chain(po_problem p, int span, int stride, int reverse_cols) {
+  PO_CHECK_PTR(p);
+  SeparableProblem *q = dynamic_cast<SeparableProblem *>(p->p);
+  if (!q) {
+    po::set_error("po_problem_set_chain needs a built-in separable problem");
+    return PO_ERR_ARG;
+  }
+  return q->setChain(span, stride, reverse_cols);
 }
 int po_problem_sparse_sizes(po_problem p, int64_t *nwcon_local, int64_t *nwinequality_local) {
   PO_CHECK_PTR(p);

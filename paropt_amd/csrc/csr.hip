@@ -1,0 +1,398 @@
+// Device kernels of the general sparse-constraint path (csr.hpp): CSR / CSC products with the fixed
+// pattern of ParOptSparseProblem (reference src/ParOptProblem.cpp:762-816), the Schur complement
+// S = C + Aw D^-1 Aw^T of ParOptQuasiDefSparseMat::factor (src/ParOptSparseMat.cpp:303-356) assembled
+// straight into the factor's value array, and a level-scheduled sparse Cholesky with its triangular
+// solves.  Everything is gather-based and deterministic: each output element has exactly one writer
+// and a fixed summation order, so repeated runs are bit-identical.
+//
+// Rooflines: the products and the assembly are HBM/L2-gather bound (8-byte gathers over a fixed
+// pattern); the factorization and the solves are LATENCY bound by the number of dependency levels
+// (one launch per level, one wavefront per row) - the nested-dissection ordering on the host keeps
+// that number near log2(w) + the separator sizes.
+#include <math.h>
+
+#include "csr.hpp"
+#include "wcon.hpp"
+
+namespace po {
+
+#define PO_C_LOOP(i, n)                                                                   \
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n);               \
+       i += (int64_t)gridDim.x * blockDim.x)
+
+#define PO_CLAUNCH(kernel, grid, block, ...)                                              \
+  do {                                                                                    \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, c->stream, __VA_ARGS__);       \
+    c->n_launches++;                                                                      \
+    PO_HIP(hipGetLastError());                                                            \
+  } while (0)
+
+static int cgrid(Ctx *c, int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b > (int64_t)c->num_cu * 8) b = (int64_t)c->num_cu * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// dst[i] = src[idx[i]]
+__global__ void __launch_bounds__(kBlock)
+    csr_gather_kernel(double *__restrict__ dst, const double *__restrict__ src, const int *__restrict__ idx,
+                      int64_t n) {
+  PO_C_LOOP(i, n) dst[i] = src[idx[i]];
+}
+int k_csr_gather(Ctx *c, double *dst, const double *src, const int *idx, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_CLAUNCH(csr_gather_kernel, cgrid(c, n), kBlock, dst, src, idx, n);
+  return PO_OK;
+}
+
+// out[op(i)] = beta*b[i] + alpha * sum_q vals[q] * scale[c_q] * x[c_q]; G lanes share a row.
+// b may alias out (no restrict on either).
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+    csr_spmv_kernel(const int *__restrict__ rowp, const int *__restrict__ cols, const double *__restrict__ vals,
+                    int64_t w, double alpha, const double *__restrict__ x, const double *__restrict__ scale,
+                    double beta, const double *b, double *out, const int *__restrict__ outperm) {
+  const int sub = threadIdx.x % G;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / G);
+  for (int64_t i = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; i < w; i += stride) {
+    double acc = 0.0;
+    const int e = rowp[i + 1];
+    for (int q = rowp[i] + sub; q < e; q += G) {
+      const int k = cols[q];
+      acc += scale ? vals[q] * (scale[k] * x[k]) : vals[q] * x[k];
+    }
+    acc = group_sum<G>(acc);
+    if (sub == 0) {
+      const double base = beta != 0.0 ? beta * b[i] : 0.0;
+      out[outperm ? outperm[i] : i] = base + alpha * acc;
+    }
+  }
+}
+int k_csr_spmv(Ctx *c, int group, const int *rowp, const int *cols, const double *vals, int64_t w, double alpha,
+               const double *x, const double *scale, double beta, const double *b, double *out,
+               const int *outperm) {
+  if (w <= 0) return PO_OK;
+  const int grid = cgrid(c, w * group);
+  if (group == 1) {
+    PO_CLAUNCH(csr_spmv_kernel<1>, grid, kBlock, rowp, cols, vals, w, alpha, x, scale, beta, b, out, outperm);
+  } else if (group == 4) {
+    PO_CLAUNCH(csr_spmv_kernel<4>, grid, kBlock, rowp, cols, vals, w, alpha, x, scale, beta, b, out, outperm);
+  } else if (group == 16) {
+    PO_CLAUNCH(csr_spmv_kernel<16>, grid, kBlock, rowp, cols, vals, w, alpha, x, scale, beta, b, out, outperm);
+  } else {
+    PO_CLAUNCH(csr_spmv_kernel<64>, grid, kBlock, rowp, cols, vals, w, alpha, x, scale, beta, b, out, outperm);
+  }
+  return PO_OK;
+}
+
+// out[j] = dscale[j] * (bx[j] + alpha * sum_{p in column j} vals[srcT[p]] * y[rowsT[p]]); bx may alias out
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+    csr_spmvT_kernel(const int *__restrict__ colp, const int *__restrict__ rowsT, const int *__restrict__ srcT,
+                     const double *__restrict__ vals, int64_t n, double alpha, const double *__restrict__ y,
+                     const double *bx, const double *__restrict__ dscale, double *out) {
+  const int sub = threadIdx.x % G;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / G);
+  for (int64_t j = (int64_t)blockIdx.x * (kBlock / G) + threadIdx.x / G; j < n; j += stride) {
+    double acc = 0.0;
+    const int e = colp[j + 1];
+    for (int p = colp[j] + sub; p < e; p += G) acc += vals[srcT[p]] * y[rowsT[p]];
+    acc = group_sum<G>(acc);
+    if (sub == 0) {
+      const double v = (bx ? bx[j] : 0.0) + alpha * acc;
+      out[j] = dscale ? dscale[j] * v : v;
+    }
+  }
+}
+int k_csr_spmvT(Ctx *c, int group, const int *colp, const int *rowsT, const int *srcT, const double *vals,
+                int64_t n, double alpha, const double *y, const double *bx, const double *dscale, double *out) {
+  if (n <= 0) return PO_OK;
+  const int grid = cgrid(c, n * group);
+  if (group == 1) {
+    PO_CLAUNCH(csr_spmvT_kernel<1>, grid, kBlock, colp, rowsT, srcT, vals, n, alpha, y, bx, dscale, out);
+  } else if (group == 4) {
+    PO_CLAUNCH(csr_spmvT_kernel<4>, grid, kBlock, colp, rowsT, srcT, vals, n, alpha, y, bx, dscale, out);
+  } else if (group == 16) {
+    PO_CLAUNCH(csr_spmvT_kernel<16>, grid, kBlock, colp, rowsT, srcT, vals, n, alpha, y, bx, dscale, out);
+  } else {
+    PO_CLAUNCH(csr_spmvT_kernel<64>, grid, kBlock, colp, rowsT, srcT, vals, n, alpha, y, bx, dscale, out);
+  }
+  return PO_OK;
+}
+
+// out_i += alpha * sum_q vals[q]^2 cvec[c_q]   (the diagonal of Aw diag(cvec) Aw^T)
+__global__ void __launch_bounds__(kBlock)
+    csr_inner_kernel(const int *__restrict__ rowp, const int *__restrict__ cols, const double *__restrict__ vals,
+                     int64_t w, double alpha, const double *__restrict__ cvec, double *__restrict__ out) {
+  PO_C_LOOP(i, w) {
+    double acc = 0.0;
+    for (int q = rowp[i]; q < rowp[i + 1]; q++) acc += vals[q] * vals[q] * cvec[cols[q]];
+    out[i] += alpha * acc;
+  }
+}
+int k_csr_inner(Ctx *c, const int *rowp, const int *cols, const double *vals, int64_t w, double alpha,
+                const double *cvec, double *out) {
+  if (w <= 0) return PO_OK;
+  PO_CLAUNCH(csr_inner_kernel, cgrid(c, w), kBlock, rowp, cols, vals, w, alpha, cvec, out);
+  return PO_OK;
+}
+
+// U_r[op(i)] = sum_q vals[q] d[c_q] P_r[c_q], eight columns of the panel per sweep over the row
+constexpr int kPanelJB = 8;
+__global__ void __launch_bounds__(kBlock)
+    csr_panel_kernel(const int *__restrict__ rowp, const int *__restrict__ cols, const double *__restrict__ vals,
+                     int64_t w, const double *__restrict__ d, PtrTable P, int nv, PtrTableW U,
+                     const int *__restrict__ outperm) {
+  PO_C_LOOP(i, w) {
+    const int b = rowp[i], e = rowp[i + 1];
+    const int64_t o = outperm ? outperm[i] : i;
+    for (int r0 = 0; r0 < nv; r0 += kPanelJB) {
+      double acc[kPanelJB];
+#pragma unroll
+      for (int jj = 0; jj < kPanelJB; jj++) acc[jj] = 0.0;
+      for (int q = b; q < e; q++) {
+        const int k = cols[q];
+        const double a = vals[q] * d[k];
+#pragma unroll
+        for (int jj = 0; jj < kPanelJB; jj++) {
+          if (r0 + jj < nv) acc[jj] += a * P.p[r0 + jj][k];
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < kPanelJB; jj++) {
+        if (r0 + jj < nv) U.p[r0 + jj][o] = acc[jj];
+      }
+    }
+  }
+}
+int k_csr_panel(Ctx *c, const int *rowp, const int *cols, const double *vals, int64_t w, const double *d,
+                const double *const *P, int nv, double *const *U, const int *outperm) {
+  if (w <= 0 || nv <= 0) return PO_OK;
+  if (nv > kMaxPanel) {
+    set_error("sparse panel product: %d columns exceed the panel limit %d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  PtrTable pt;
+  PtrTableW ut;
+  for (int j = 0; j < kMaxPanel; j++) {
+    pt.p[j] = j < nv ? P[j] : P[0];
+    ut.p[j] = j < nv ? U[j] : U[0];
+  }
+  PO_CLAUNCH(csr_panel_kernel, cgrid(c, w), kBlock, rowp, cols, vals, w, d, pt, nv, ut, outperm);
+  return PO_OK;
+}
+
+// One thread per structural entry (a, b) of lower(P S P^T): the two column-sorted rows of Aw are merged,
+// Lvals[slot] = [a == b] cdiag[a] + sum_k Aw[a,k] dinv[k] Aw[b,k].  Fill entries were zeroed by the caller.
+__global__ void __launch_bounds__(kBlock)
+    csr_assemble_kernel(const int *__restrict__ rowp, const int *__restrict__ cols,
+                        const double *__restrict__ vals, const double *__restrict__ dinv,
+                        const double *__restrict__ cdiag, const int *__restrict__ ent_a,
+                        const int *__restrict__ ent_b, const int *__restrict__ ent_slot, int64_t nent,
+                        double *__restrict__ Lvals) {
+  PO_C_LOOP(e, nent) {
+    const int a = ent_a[e], b = ent_b[e];
+    double acc = 0.0;
+    if (a == b) {
+      for (int q = rowp[a]; q < rowp[a + 1]; q++) acc += vals[q] * vals[q] * dinv[cols[q]];
+      acc += cdiag[a];
+    } else {
+      int qa = rowp[a], qb = rowp[b];
+      const int ea = rowp[a + 1], eb = rowp[b + 1];
+      while (qa < ea && qb < eb) {
+        const int ka = cols[qa], kb = cols[qb];
+        if (ka == kb) {
+          acc += vals[qa] * dinv[ka] * vals[qb];
+          qa++;
+          qb++;
+        } else if (ka < kb) {
+          qa++;
+        } else {
+          qb++;
+        }
+      }
+    }
+    Lvals[ent_slot[e]] = acc;
+  }
+}
+int k_csr_assemble(Ctx *c, const int *rowp, const int *cols, const double *vals, const double *dinv,
+                   const double *cdiag, const int *ent_a, const int *ent_b, const int *ent_slot, int64_t nent,
+                   double *Lvals) {
+  if (nent <= 0) return PO_OK;
+  PO_CLAUNCH(csr_assemble_kernel, cgrid(c, nent), kBlock, rowp, cols, vals, dinv, cdiag, ent_a, ent_b, ent_slot,
+             nent, Lvals);
+  return PO_OK;
+}
+
+// built-in chain constraints (examples/rosenbrock/sparse_rosenbrock.cpp:75-118 is span 2, stride 1)
+__global__ void __launch_bounds__(kBlock)
+    chain_con_kernel(const double *__restrict__ x, int64_t w, int span, int stride, double *__restrict__ cw) {
+  PO_C_LOOP(i, w) {
+    double v = 1.0;
+    for (int k = 0; k < span; k++) {
+      const double xi = x[i * stride + k];
+      v -= xi * xi;
+    }
+    cw[i] = v;
+  }
+}
+int k_chain_con(Ctx *c, const double *x, int64_t w, int span, int stride, double *cw) {
+  if (w <= 0) return PO_OK;
+  PO_CLAUNCH(chain_con_kernel, cgrid(c, w), kBlock, x, w, span, stride, cw);
+  return PO_OK;
+}
+__global__ void __launch_bounds__(kBlock)
+    chain_jac_kernel(const double *__restrict__ x, int64_t w, int span, int stride, int reverse,
+                     double *__restrict__ data) {
+  PO_C_LOOP(e, w * span) {
+    const int64_t i = e / span;
+    const int s = (int)(e - i * span);
+    const int k = reverse ? span - 1 - s : s;
+    data[e] = -2.0 * x[i * stride + k];
+  }
+}
+int k_chain_jac(Ctx *c, const double *x, int64_t w, int span, int stride, int reverse, double *data) {
+  if (w <= 0) return PO_OK;
+  PO_CLAUNCH(chain_jac_kernel, cgrid(c, w * span), kBlock, x, w, span, stride, reverse, data);
+  return PO_OK;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Row Cholesky of one dependency level: one wavefront per row i, entries left to right,
+//   L_ij = (S_ij - sum_{k<j} L_ik L_jk) / L_jj,   L_ii = sqrt(S_ii - sum_k L_ik^2).
+// Row j (j < i) was finished by an earlier launch; the lanes stride over row j and look each column up
+// in the part of row i already computed (binary search on the sorted columns).
+__global__ void __launch_bounds__(64)
+    chol_level_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals,
+                      const int *__restrict__ rows, int nrows, int *flag) {
+  const int i = rows[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int p0 = Lrowp[i], pd = Lrowp[i + 1] - 1;
+  for (int p = p0; p <= pd; p++) {
+    double acc = 0.0;
+    double v;
+    if (p < pd) {
+      const int j = Lcols[p];
+      const int r0 = Lrowp[j], rd = Lrowp[j + 1] - 1;
+      for (int q = r0 + lane; q < rd; q += 64) {
+        const int k = Lcols[q];
+        int lo = p0, hi = p;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (Lcols[mid] < k) {
+            lo = mid + 1;
+          } else {
+            hi = mid;
+          }
+        }
+        if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+      }
+      acc = wave_sum(acc);
+      v = (Lvals[p] - acc) / Lvals[rd];
+    } else {
+      for (int q = p0 + lane; q < pd; q += 64) acc += Lvals[q] * Lvals[q];
+      acc = wave_sum(acc);
+      double a = Lvals[p] - acc;
+      if (!(a > 0.0)) {
+        if (lane == 0) {
+          flag[0] = 1;
+          flag[1] = i;
+        }
+        a = 1.0;
+      }
+      v = sqrt(a);
+    }
+    if (lane == 0) Lvals[p] = v;
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows,
+                 int *flag) {
+  if (nrows <= 0) return PO_OK;
+  PO_CLAUNCH(chol_level_kernel, nrows, 64, Lrowp, Lcols, Lvals, rows, nrows, flag);
+  return PO_OK;
+}
+
+// y_i = (y_i - sum_{j<i} L_ij y_j) / L_ii for the rows of one level; wavefront `wave` of the workgroup takes
+// the right-hand sides wave, wave+4, ...
+__global__ void __launch_bounds__(kBlock)
+    trsv_fwd_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols,
+                    const double *__restrict__ Lvals, const int *__restrict__ rows, int nrows, PtrTableW Y,
+                    int nv) {
+  const int i = rows[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = Lrowp[i], pd = Lrowp[i + 1] - 1;
+  const double diag = Lvals[pd];
+  for (int r = wave + 4 * blockIdx.y; r < nv; r += 4 * gridDim.y) {
+    double *y = Y.p[r];
+    double acc = 0.0;
+    for (int q = p0 + lane; q < pd; q += 64) acc += Lvals[q] * y[Lcols[q]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[i] = (y[i] - acc) / diag;
+  }
+}
+// x_i = (y_i - sum_{j>i} L_ji x_j) / L_ii through the column storage of L
+__global__ void __launch_bounds__(kBlock)
+    trsv_bwd_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Ltp, const int *__restrict__ Ltrows,
+                    const int *__restrict__ Ltsrc, const double *__restrict__ Lvals,
+                    const int *__restrict__ rows, int nrows, PtrTableW Y, int nv) {
+  const int i = rows[blockIdx.x];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = Ltp[i], p1 = Ltp[i + 1];
+  const double diag = Lvals[Lrowp[i + 1] - 1];
+  for (int r = wave + 4 * blockIdx.y; r < nv; r += 4 * gridDim.y) {
+    double *y = Y.p[r];
+    double acc = 0.0;
+    for (int q = p0 + lane; q < p1; q += 64) acc += Lvals[Ltsrc[q]] * y[Ltrows[q]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[i] = (y[i] - acc) / diag;
+  }
+}
+static int fill_table(PtrTableW &t, double *const *Y, int nv) {
+  if (nv > kMaxPanel) {
+    set_error("sparse triangular solve: %d right-hand sides exceed the panel limit %d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  for (int j = 0; j < kMaxPanel; j++) t.p[j] = j < nv ? Y[j] : Y[0];
+  return PO_OK;
+}
+int k_trsv_fwd_level(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, const int *rows, int nrows,
+                     double *const *Y, int nv) {
+  if (nrows <= 0 || nv <= 0) return PO_OK;
+  PtrTableW t;
+  PO_TRY(fill_table(t, Y, nv));
+  const int gy = nv > 4 ? (nrows < 1024 ? (nv + 3) / 4 : 1) : 1;
+  hipLaunchKernelGGL(trsv_fwd_kernel, dim3(nrows, gy), dim3(nv > 1 ? kBlock : 64), 0, c->stream, Lrowp, Lcols,
+                     Lvals, rows, nrows, t, nv);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  return PO_OK;
+}
+int k_trsv_bwd_level(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,
+                     const double *Lvals, const int *rows, int nrows, double *const *Y, int nv) {
+  if (nrows <= 0 || nv <= 0) return PO_OK;
+  PtrTableW t;
+  PO_TRY(fill_table(t, Y, nv));
+  const int gy = nv > 4 ? (nrows < 1024 ? (nv + 3) / 4 : 1) : 1;
+  hipLaunchKernelGGL(trsv_bwd_kernel, dim3(nrows, gy), dim3(nv > 1 ? kBlock : 64), 0, c->stream, Lrowp, Ltp,
+                     Ltrows, Ltsrc, Lvals, rows, nrows, t, nv);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  return PO_OK;
+}
+
+}  // namespace po

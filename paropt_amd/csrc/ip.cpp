@@ -735,8 +735,7 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDia
   }
   if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930), then W -= U^T Cw U
     PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
-    if (prob->addSparseInnerProduct(1.0, x, Dinv, Cw) != 0) return PO_ERR_USER;
-    PO_TRY(k_recip(ctx, Cw->d, nw));
+    PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:1930)
     PO_TRY(sparseGramCorrection(P, m));
   }
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)

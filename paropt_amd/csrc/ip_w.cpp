@@ -77,7 +77,7 @@ int InteriorPoint::wCompStep(double ax, double az, double *prod) {
   return k_w_comp_step(ctx, wv(), wp(), ax, az, nw, prod);
 }
 
-// W -= U^T Cw U with U_j = Aw (Dinv o P_j)
+// W -= U^T S^-1 U with U_j = Aw (Dinv o P_j), S = C + Aw Dinv Aw^T (diagonal for the block form: Cw = S^-1)
 int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m) {
   if (m <= 0) return PO_OK;
   while ((int)Uw.size() < m) {
@@ -92,8 +92,11 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
     Uc[j] = Uw[j]->d;
   }
   PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), tvec));
+  // block form: U^T Cw U.  CSR form: U <- L^-1 U with S = L L^T, then U^T U
+  const double *weights = Cw->d;
+  PO_TRY(prob->sparseHalfSolve(U.data(), m, Cw, &weights));
   std::vector<double> W2((size_t)m * m, 0.0);
-  PO_TRY(k_wgram(ctx, Cw->d, Uc.data(), m, nw, W2.data()));
+  PO_TRY(k_wgram(ctx, weights, Uc.data(), m, nw, W2.data()));
   for (size_t i = 0; i < W2.size(); i++) W[i] -= W2[i];
   return PO_OK;
 }
@@ -248,8 +251,7 @@ int InteriorPoint::initLeastSquaresMultipliersW() {
   const double small = 1e-4;
   PO_TRY(k_fill(ctx, Dinv->d, n, 1.0));
   PO_TRY(k_fill(ctx, Cw->d, nw, small));
-  if (prob->addSparseInnerProduct(1.0, x, Dinv, Cw) != 0) return PO_ERR_USER;
-  PO_TRY(k_recip(ctx, Cw->d, nw));
+  PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:5429)
   int k = 0;
   std::vector<const double *> A = panel(false, &k);
   W.assign((size_t)c * c, 0.0);

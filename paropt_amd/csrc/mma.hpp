@@ -57,6 +57,11 @@ class MMA : public Problem {
                     Vec *wwork) override {
     return prob->sparseApplyK0(xvec, d, cw, bx, bw, yx, yw, wwork);
   }
+  int sparseFactor(Vec *, Vec *d, Vec *cw) override { return prob->sparseFactor(xvec, d, cw); }
+  int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) override {
+    return prob->sparseHalfSolve(U, nv, cw, weights);
+  }
+  const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
 
   Problem *prob;
   Options opts;

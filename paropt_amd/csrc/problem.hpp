@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "core.hpp"
+#include "csr.hpp"
 #include "qn.hpp"
 #include "wcon.hpp"
 
@@ -14,7 +15,7 @@ class Problem {
  public:
   Problem(Ctx *c, int64_t nlocal_, int ncon_, int nineq_)
       : ctx(c), nlocal(nlocal_), offset(0), nglobal(nlocal_), ncon(ncon_), ninequality(nineq_) {}
-  virtual ~Problem() {}
+  virtual ~Problem() { delete csr; }
   virtual int getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) = 0;
   virtual int evalObjCon(Vec *x, double *fobj, double *cons) = 0;
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
@@ -26,11 +27,13 @@ class Problem {
   // Hessian of the Lagrangian f - z^T c - zw^T cw (src/ParOptProblem.h:160-189); non-zero = not available
   virtual int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) { return 1; }
   virtual int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) { return 1; }
-  // sparse constraints (src/ParOptProblem.h:215-262); out / pzw / A are w-sized device vectors
-  virtual int evalSparseCon(Vec *x, Vec *out) { return 0; }
-  virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) { return 0; }
-  virtual int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) { return 0; }
-  virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) { return 0; }
+  // sparse constraints (src/ParOptProblem.h:215-262); out / pzw / A are w-sized device vectors.  The
+  // defaults serve a problem with a CSR pattern (`csr`, the ParOptSparseProblem form) and are no-ops
+  // otherwise.
+  virtual int evalSparseCon(Vec *x, Vec *out);
+  virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out);
+  virtual int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
+  virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A);
   // U_j = Aw (d o P_j) for a whole panel; the default goes column by column through
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
   virtual int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
@@ -41,6 +44,20 @@ class Problem {
   // do it in 5.  bx must not alias yx; bw may be null (zero block); `wwork` is w-sized scratch.
   virtual int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
                             Vec *wwork);
+  // ParOptQuasiDefMat::factor (src/ParOptSparseMat.h:25): cw holds Cdiag on entry.  Block form
+  // (nwblock = 1): cw <- 1/(Cdiag + diag(Aw d Aw^T)).  CSR form: S = Cdiag + Aw d Aw^T is factored on the
+  // device and cw is left alone.
+  virtual int sparseFactor(Vec *x, Vec *d, Vec *cw);
+  // Second half of the Gram correction W -= U^T S^-1 U: turns the panel from sparseJacobianPanel into Y
+  // with U^T S^-1 U = Y^T diag(weights) Y.  Block form: Y = U, weights = cw.  CSR form: Y = L^-1 U in
+  // place, unit weights.
+  virtual int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights);
+  // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
+  virtual const char *sparseFactorInfo() { return csr ? csr->factorInfo() : nullptr; }
+  // fixed CSR pattern of the sparse Jacobian (ParOptSparseProblem::setSparseJacobianData, .cpp:632-677);
+  // owned.  Sets nwcon / nwinequality.
+  int setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols);
+  CsrSparse *csr = nullptr;
 
   Ctx *ctx;
   int64_t nlocal, offset, nglobal;
@@ -71,6 +88,10 @@ class CallbackProblem : public Problem {
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   po_problem_callbacks cb;
   SparseCallbacks sparse;
+  // CSR form (CyParOptSparseProblem, src/CyParOptProblem.h:177-262): the two evaluation callbacks also fill
+  // the sparse constraint values and the Jacobian entries
+  po_eval_sparse_obj_con_fn csr_obj_con = nullptr;
+  po_eval_sparse_obj_con_gradient_fn csr_gradient = nullptr;
   po_hvec_fn hvec_fn = nullptr;
   po_hdiag_fn hdiag_fn = nullptr;
 };
@@ -88,6 +109,11 @@ class SeparableProblem : public Problem {
   // weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i (nw + nwskip) + k] on GLOBAL indices;
   // groups must not straddle rank boundaries (checked)
   int setWeighting(int64_t nwcon_global, int nw, int64_t nwstart, int nwskip, int64_t nwineq_global);
+  // overlapping nonlinear sparse constraints in CSR form, rank-local like the reference's example
+  // (examples/rosenbrock/sparse_rosenbrock.cpp:38-118 is span = 2, stride = 1):
+  //   cw_i = 1 - sum_{k<span} x[i*stride + k]^2,  i < (nlocal - span)/stride + 1, all inequalities
+  int setChain(int span, int stride, int reverse_cols);
+  int chain_span = 0, chain_stride = 0, chain_reverse = 0;
   int evalSparseCon(Vec *x, Vec *out) override;
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;

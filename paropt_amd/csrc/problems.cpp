@@ -11,9 +11,58 @@ static void shard(int64_t n, int rank, int size, int64_t *nlocal, int64_t *offse
   *offset = rank * base + (rank < rem ? rank : rem);
 }
 
-// ---- generic sparse-panel fallback ------------------------------------------------------------
+// ---- CSR form (ParOptSparseProblem) and the generic fallbacks ------------------------------------
+int Problem::setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols) {
+  if (nwcon_ < 0 || nwineq_ < 0 || nwineq_ > nwcon_ || !rowp || (rowp[nwcon_] > 0 && !cols)) {
+    set_error("setSparseJacobianData: bad arguments");
+    return PO_ERR_ARG;
+  }
+  CsrSparse *m = new CsrSparse(ctx, nlocal, nwcon_);
+  int rc = m->setPattern(rowp, cols);
+  if (rc != PO_OK) {
+    delete m;
+    return rc;
+  }
+  delete csr;
+  csr = m;
+  nwcon = nwcon_;
+  nwinequality = nwineq_;
+  return PO_OK;
+}
+// ParOptSparseProblem::evalSparseCon copies the values the last evaluation stored (.cpp:750-760)
+int Problem::evalSparseCon(Vec *, Vec *out) {
+  if (!csr) return 0;
+  return k_copy(ctx, out->d, csr->cw->d, nwcon) != PO_OK;
+}
+int Problem::addSparseJacobian(double alpha, Vec *, Vec *px, Vec *out) {  // .cpp:762-788
+  if (!csr) return 0;
+  return csr->spmv(alpha, px->d, out->d) != PO_OK;
+}
+int Problem::addSparseJacobianTranspose(double alpha, Vec *, Vec *pzw, Vec *out) {  // .cpp:790-816
+  if (!csr) return 0;
+  return csr->spmvT(alpha, pzw->d, out->d) != PO_OK;
+}
+int Problem::addSparseInnerProduct(double alpha, Vec *, Vec *cvec, Vec *A) {
+  if (!csr) return 0;
+  return csr->innerProduct(alpha, cvec->d, A->d) != PO_OK;
+}
+int Problem::sparseFactor(Vec *x, Vec *d, Vec *cw) {
+  if (csr) return csr->factor(d->d, cw->d);
+  if (addSparseInnerProduct(1.0, x, d, cw) != 0) return PO_ERR_USER;
+  return k_recip(ctx, cw->d, nwcon);
+}
+int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) {
+  if (csr) {
+    *weights = csr->unitWeights();
+    return csr->halfSolve(U, nv);
+  }
+  *weights = cw->d;
+  return PO_OK;
+}
+
 int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                                  Vec *work) {
+  if (csr) return csr->panelPermuted(d->d, P, nv, U);
   for (int j = 0; j < nv; j++) {
     PO_TRY(k_mul(ctx, work->d, 1.0, d->d, P[j], nlocal));
     PO_TRY(k_fill(ctx, U[j], nwcon, 0.0));
@@ -25,6 +74,7 @@ int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
 
 int Problem::sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
                            Vec *) {
+  if (csr) return csr->applyK0(d->d, bx, bw, yx->d, yw->d);
   const int64_t n = nlocal, w = nwcon;
   PO_TRY(k_mul(ctx, yx->d, 1.0, d->d, bx, n));
   if (bw) {
@@ -51,11 +101,22 @@ int CallbackProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
   return rc;
 }
 int CallbackProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
+  if (csr) {  // ParOptSparseProblem::evalObjCon (.cpp:724-727)
+    if (!csr_obj_con) return 1;
+    return csr_obj_con(cb.user, static_cast<po_vec>(x), fobj, cons, static_cast<po_vec>(csr->cw));
+  }
   return cb.eval_obj_con(cb.user, static_cast<po_vec>(x), fobj, cons);
 }
 int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   std::vector<po_vec> h(ncon > 0 ? ncon : 1);
   for (int j = 0; j < ncon; j++) h[j] = static_cast<po_vec>(Ac[j]);
+  if (csr) {  // ParOptSparseProblem::evalObjConGradient (.cpp:739-742)
+    if (!csr_gradient) return 1;
+    int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data(), csr->data,
+                          csr->nnz);
+    if (rc != 0) return rc;
+    return csr->valuesChanged() != PO_OK;
+  }
   return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data());
 }
 int CallbackProblem::computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) {
@@ -69,20 +130,24 @@ int CallbackProblem::writeOutput(int iter, Vec *x) {
 }
 
 int CallbackProblem::evalSparseCon(Vec *x, Vec *out) {
+  if (csr) return Problem::evalSparseCon(x, out);
   if (!sparse.set || !sparse.cb.eval_sparse_con) return nwcon > 0 ? 1 : 0;
   return sparse.cb.eval_sparse_con(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(out));
 }
 int CallbackProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  if (csr) return Problem::addSparseJacobian(alpha, x, px, out);
   if (!sparse.set || !sparse.cb.add_sparse_jacobian) return nwcon > 0 ? 1 : 0;
   return sparse.cb.add_sparse_jacobian(cb.user, alpha, static_cast<po_vec>(x),
                                        static_cast<po_vec>(px), static_cast<po_vec>(out));
 }
 int CallbackProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  if (csr) return Problem::addSparseJacobianTranspose(alpha, x, pzw, out);
   if (!sparse.set || !sparse.cb.add_sparse_jacobian_transpose) return nwcon > 0 ? 1 : 0;
   return sparse.cb.add_sparse_jacobian_transpose(cb.user, alpha, static_cast<po_vec>(x),
                                                  static_cast<po_vec>(pzw), static_cast<po_vec>(out));
 }
 int CallbackProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
+  if (csr) return Problem::addSparseInnerProduct(alpha, x, cvec, A);
   if (!sparse.set || !sparse.cb.add_sparse_inner_product) return nwcon > 0 ? 1 : 0;
   return sparse.cb.add_sparse_inner_product(cb.user, alpha, static_cast<po_vec>(x),
                                             static_cast<po_vec>(cvec), static_cast<po_vec>(A));
@@ -191,27 +256,58 @@ int SeparableProblem::setWeighting(int64_t nwg, int nw, int64_t nwstart, int nws
   if (nwinequality > count) nwinequality = count;
   return PO_OK;
 }
+int SeparableProblem::setChain(int span, int stride, int reverse_cols) {
+  if (span < 1 || stride < 1) {
+    set_error("setChain: span and stride must be positive");
+    return PO_ERR_ARG;
+  }
+  const int64_t rows = nlocal >= span ? (nlocal - span) / stride + 1 : 0;
+  if (rows * span > 2000000000LL) {
+    set_error("setChain: more than 2e9 Jacobian entries on one rank");
+    return PO_ERR_ARG;
+  }
+  std::vector<int> rowp(rows + 1), cols((size_t)rows * span);
+  for (int64_t i = 0; i < rows; i++) {
+    rowp[i] = (int)(i * span);
+    for (int k = 0; k < span; k++) {
+      cols[i * span + (reverse_cols ? span - 1 - k : k)] = (int)(i * stride + k);
+    }
+  }
+  rowp[rows] = (int)(rows * span);
+  PO_TRY(setSparseJacobianData(rows, rows, rowp.data(), cols.data()));
+  chain_span = span;
+  chain_stride = stride;
+  chain_reverse = reverse_cols;
+  gmap = GroupMap();
+  return PO_OK;
+}
 int SeparableProblem::evalSparseCon(Vec *x, Vec *out) {
+  if (csr) return Problem::evalSparseCon(x, out);
   return k_group_sum(ctx, gmap, out->d, 0, 1.0, -1.0, x->d);
 }
 int SeparableProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  if (csr) return Problem::addSparseJacobian(alpha, x, px, out);
   return k_group_sum(ctx, gmap, out->d, 1, 0.0, -alpha, px->d);
 }
 int SeparableProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  if (csr) return Problem::addSparseJacobianTranspose(alpha, x, pzw, out);
   return k_group_scatter(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
 }
 int SeparableProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
+  if (csr) return Problem::addSparseInnerProduct(alpha, x, cvec, A);
   return k_group_sum(ctx, gmap, A->d, 1, 0.0, alpha, cvec->d);
 }
 int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
                                           double *const *U, Vec *work) {
+  if (csr) return Problem::sparseJacobianPanel(x, d, P, nv, U, work);
   return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
 }
 
 // the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
 // Aw = -(group indicator): u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx - yw[group])
-int SeparableProblem::sparseApplyK0(Vec *, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
+int SeparableProblem::sparseApplyK0(Vec *xv, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
                                     Vec *yw, Vec *wwork) {
+  if (csr) return Problem::sparseApplyK0(xv, d, cw, bx, bw, yx, yw, wwork);
   const double *P[1] = {bx};
   double *U[1] = {wwork->d};
   PO_TRY(k_group_panel(ctx, gmap, P, 1, d->d, -1.0, U));
@@ -219,11 +315,13 @@ int SeparableProblem::sparseApplyK0(Vec *, Vec *d, Vec *cw, const double *bx, co
   return k_group_apply(ctx, gmap, d->d, bx, -1.0, yw->d, nlocal, yx->d);
 }
 int SeparableProblem::evalHvecProduct(Vec *x, const double *z, Vec *, Vec *px, Vec *hvec) {
+  if (csr) return 1;  // the chain constraints are nonlinear; their Hessian is not provided
   if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], px->d, nlocal, hvec->d) != PO_OK;
   return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, px->d, nlocal,
                     hvec->d) != PO_OK;
 }
 int SeparableProblem::evalHessianDiag(Vec *x, const double *z, Vec *, Vec *hdiag) {
+  if (csr) return 1;
   if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], nullptr, nlocal, hdiag->d) != PO_OK;
   return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, nullptr, nlocal,
                     hdiag->d) != PO_OK;
@@ -249,6 +347,7 @@ int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
 
 int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
   const int64_t n = nlocal;
+  if (csr) PO_TRY(k_chain_con(ctx, x->d, nwcon, chain_span, chain_stride, csr->cw->d));
   if (kind == PO_PROBLEM_ROSENBROCK) {
     double out[3];
     PO_TRY(k_rosen_f(ctx, x->d, n, out));
@@ -273,6 +372,10 @@ int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
 
 int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   const int64_t n = nlocal;
+  if (csr) {
+    PO_TRY(k_chain_jac(ctx, x->d, nwcon, chain_span, chain_stride, chain_reverse, csr->data));
+    PO_TRY(csr->valuesChanged());
+  }
   if (kind == PO_PROBLEM_ROSENBROCK) {
     return k_rosen_g(ctx, x->d, n, g->d, Ac[0]->d, Ac[1]->d);
   }

@@ -89,6 +89,11 @@ class TrustRegionSubproblem : public Problem {
                     Vec *wwork) override {
     return prob->sparseApplyK0(xk, d, cw, bx, bw, yx, yw, wwork);
   }
+  int sparseFactor(Vec *, Vec *d, Vec *cw) override { return prob->sparseFactor(xk, d, cw); }
+  int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) override {
+    return prob->sparseHalfSolve(U, nv, cw, weights);
+  }
+  const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
 
   Problem *prob;
@@ -164,6 +169,11 @@ class InfeasSubproblem : public Problem {  // :468-650
                     Vec *wwork) override {
     return sub->sparseApplyK0(x, d, cw, bx, bw, yx, yw, wwork);
   }
+  int sparseFactor(Vec *x, Vec *d, Vec *cw) override { return sub->sparseFactor(x, d, cw); }
+  int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) override {
+    return sub->sparseHalfSolve(U, nv, cw, weights);
+  }
+  const char *sparseFactorInfo() override { return sub->sparseFactorInfo(); }
   TrustRegionSubproblem *sub;
   int objective, constraint;
   double obj_scale;

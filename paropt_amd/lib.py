@@ -45,6 +45,10 @@ EIG_UPDATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_eig)
 TR_ITER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
 SPARSE_CON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec)
 SPARSE_JAC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, po_vec, po_vec, po_vec)
+SPARSE_OBJCON_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p, po_vec)
+SPARSE_GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p, C.c_void_p, C.c_int64)
+po_csr_symbolic = C.c_void_p
+c_int_pp = C.POINTER(c_int_p)
 
 
 class ProblemCallbacks(C.Structure):
@@ -77,6 +81,7 @@ SIGNATURES = {
     "po_ctx_synchronize": (C.c_int, [po_ctx]),
     "po_ctx_rank": (C.c_int, [po_ctx, c_int_p, c_int_p]),
     "po_ctx_stream": (C.c_void_p, [po_ctx]),
+    "po_ctx_memcpy": (C.c_int, [po_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "po_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "po_ctx_comm_init_rccl": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_void_p]),
     "po_ctx_comm_init_callback": (C.c_int, [po_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
@@ -126,6 +131,20 @@ SIGNATURES = {
     "po_problem_set_hessian_callbacks": (C.c_int, [po_problem, HVEC_FN, HDIAG_FN]),
     "po_problem_set_weighting": (C.c_int, [po_problem, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int64]),
     "po_problem_sparse_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p]),
+    "po_problem_set_sparse_jacobian_data": (
+        C.c_int, [po_problem, C.c_int64, C.c_int64, c_int_p, c_int_p, SPARSE_OBJCON_FN, SPARSE_GRAD_FN]),
+    "po_problem_get_sparse_jacobian_data": (
+        C.c_int, [po_problem, c_int_pp, c_int_pp, C.POINTER(C.c_void_p), c_i64_p]),
+    "po_problem_set_chain": (C.c_int, [po_problem, C.c_int, C.c_int, C.c_int]),
+    "po_quasidef_factor": (C.c_int, [po_problem, po_vec, po_vec, po_vec]),
+    "po_quasidef_apply": (C.c_int, [po_problem, po_vec, po_vec, po_vec, po_vec, po_vec, po_vec, po_vec]),
+    "po_quasidef_factor_info": (C.c_char_p, [po_problem]),
+    "po_csr_symbolic_create": (C.c_int, [C.c_int64, C.c_int64, c_int_p, c_int_p, C.POINTER(po_csr_symbolic)]),
+    "po_csr_symbolic_info": (C.c_int, [po_csr_symbolic, c_i64_p]),
+    "po_csr_symbolic_arrays": (
+        C.c_int, [po_csr_symbolic, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp,
+                  c_int_pp]),
+    "po_csr_symbolic_destroy": (C.c_int, [po_csr_symbolic]),
     "po_problem_set_var_bound_options": (C.c_int, [po_problem, C.c_int, C.c_int]),
     "po_problem_destroy": (C.c_int, [po_problem]),
     "po_problem_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p, c_int_p]),

@@ -44,6 +44,8 @@ def run_gpu(ctx, case, want_vectors=False):
     if a.get("nwcon", 0) > 0:
         prob.setWeighting(a["nwcon"], a["nw"], a.get("nwstart", 0), a.get("nwskip", 0),
                           a.get("nwineq", a["nwcon"]))
+    if a.get("chain_span", 0) > 0:  # CSR form of the sparse constraints (device sparse Cholesky)
+        prob.setChain(a["chain_span"], a.get("chain_stride", 1), a.get("chain_reverse", 0))
     if not (a.get("use_lower", 1) and a.get("use_upper", 1)):
         prob.setVarBoundOptions(a.get("use_lower", 1), a.get("use_upper", 1))
     opts = ip_options_from_case(case)
@@ -69,7 +71,7 @@ def run_gpu(ctx, case, want_vectors=False):
     return ip, snaps
 
 
-IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_")
+IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_") + golden_names("ipcsr_")
             if not n.endswith("_r2") and "checkpoint" not in n]
 
 

@@ -103,6 +103,7 @@ def run_oracle_ip(case, nmax=None):
         eig_min=a.get("eig_min", 1.0), eig_max=a.get("eig_max", 100.0),
         nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
+        chain=(a["chain_span"], a.get("chain_stride", 1)) if a.get("chain_span", 0) else None,
     )
     prob.use_lower = bool(a.get("use_lower", 1))
     prob.use_upper = bool(a.get("use_upper", 1))
@@ -128,7 +129,7 @@ def info_tokens(paropt_out):
     return toks
 
 
-IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_") if not n.endswith("_r2") and "checkpoint" not in n]
+IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_") + golden_names("ipcsr_") if not n.endswith("_r2") and "checkpoint" not in n]
 
 
 @pytest.mark.parametrize("name", IP_CASES)
