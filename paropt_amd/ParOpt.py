@@ -101,26 +101,54 @@ class Problem(_api.Problem):
 
     def __init__(self, comm=None, **kwargs):
         nvars, ncon, nwcon, nineq, nwineq = _sizes(kwargs)
-        if kwargs.get("rowp") is not None or kwargs.get("cols") is not None:
-            raise NotImplementedError("the CSR sparse-constraint form is not available on the device path")
-        if nwcon > 0 and kwargs.get("nwblock", 1) not in (0, 1):
-            raise NotImplementedError("sparse constraints need nwblock = 1 on the device path")
+        rowp, cols = kwargs.get("rowp"), kwargs.get("cols")
+        csr = rowp is not None and cols is not None  # CyParOptSparseProblem (ParOpt.pyx:854-881)
+        if not csr and nwcon > 0 and kwargs.get("nwblock", 1) not in (0, 1):
+            raise NotImplementedError("sparse constraints need nwblock = 1 or the CSR form (rowp=, cols=) on the "
+                                      "device path")
         self.comm = comm
-        self._user = dict(gvb=self.getVarsAndBounds, eval=self.evalObjCon, grad=self.evalObjConGradient)
-        if nwcon > 0:
-            self._user.update(wcon=self.evalSparseCon, wjac=self.addSparseJacobian,
-                              wjact=self.addSparseJacobianTranspose, winner=self.addSparseInnerProduct)
-        # route the host-array protocol of the base class to the PVec protocol of the reference
+        self._user = dict(gvb=self.getVarsAndBounds)
         self.getVarsAndBounds = self._gvb
-        self.evalObjCon = self._eval
-        self.evalObjConGradient = self._grad
-        if nwcon > 0:
-            self.evalSparseCon = lambda x, out: self._user["wcon"](_Host(x), _Host(out))
-            self.addSparseJacobian = lambda a, x, px, out: self._user["wjac"](a, _Host(x), _Host(px), _Host(out))
-            self.addSparseJacobianTranspose = lambda a, x, p, out: self._user["wjact"](a, _Host(x), _Host(p), _Host(out))
-            self.addSparseInnerProduct = lambda a, x, c, A: self._user["winner"](a, _Host(x), _Host(c), A)
+        if csr:
+            rp = np.asarray(rowp, dtype=np.intc)
+            cl = np.asarray(cols, dtype=np.intc)
+            rows = np.repeat(np.arange(nwcon), np.diff(rp))
+            seval, sgrad = self.evalSparseObjCon, self.evalSparseObjConGradient
+            self._user.update(seval=seval, sgrad=sgrad)
+            self.evalSparseObjCon = lambda x, sp: seval(_Host(x), _Host(sp))
+            self.evalSparseObjConGradient = lambda x, g, A, data: sgrad(
+                _Host(x), _Host(g), [_Host(a) for a in A], data)
+            # host views of the same callbacks for checkGradients
+            chk = dict(data=np.zeros(len(cl)))
+
+            def _grad(x, g, A):
+                return sgrad(x, g, A, chk["data"])
+
+            def _wjac(alpha, x, px, out):
+                np.add.at(out._a, rows, alpha * chk["data"] * np.asarray(px[:])[cl])
+
+            def _wjact(alpha, x, pzw, out):
+                np.add.at(out._a, cl, alpha * chk["data"] * np.asarray(pzw[:])[rows])
+
+            # no inner-product check: Aw C Aw^T is not diagonal when rows overlap
+            self._user.update(eval=lambda x: seval(x, _Host(np.zeros(nwcon))), grad=_grad, wjac=_wjac,
+                              wjact=_wjact, winner=None)
+        else:
+            self._user.update(eval=self.evalObjCon, grad=self.evalObjConGradient)
+            if nwcon > 0:
+                self._user.update(wcon=self.evalSparseCon, wjac=self.addSparseJacobian,
+                                  wjact=self.addSparseJacobianTranspose, winner=self.addSparseInnerProduct)
+            # route the host-array protocol of the base class to the PVec protocol of the reference
+            self.evalObjCon = self._eval
+            self.evalObjConGradient = self._grad
+            if nwcon > 0:
+                self.evalSparseCon = lambda x, out: self._user["wcon"](_Host(x), _Host(out))
+                self.addSparseJacobian = lambda a, x, px, out: self._user["wjac"](a, _Host(x), _Host(px), _Host(out))
+                self.addSparseJacobianTranspose = lambda a, x, p, out: self._user["wjact"](a, _Host(x), _Host(p), _Host(out))
+                self.addSparseInnerProduct = lambda a, x, c, A: self._user["winner"](a, _Host(x), _Host(c), A)
         super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq,
-                         use_lower=kwargs.get("use_lower", True), use_upper=kwargs.get("use_upper", True))
+                         use_lower=kwargs.get("use_lower", True), use_upper=kwargs.get("use_upper", True),
+                         rowp=rowp if csr else None, cols=cols if csr else None)
 
     def checkGradients(self, dh=1e-6, x=None, check_hvec_product=False):
         """ParOptProblem::checkGradients (src/ParOptProblem.cpp:376-620) on the host: directional
@@ -159,6 +187,7 @@ class Problem(_api.Problem):
             out["transpose"] = abs(d1 - d2) / max(abs(d2), 1e-300)
             print("\nTranspose-equivalence\nx^{T}*(J(x)*p): %8.2e  p*(J(x)^{T}*x): %8.2e  Err: %8.2e  Rel Err: %8.2e" % (
                 d1, d2, abs(d1 - d2), out["transpose"]))
+        if w > 0 and self._user.get("winner") is not None:
             cvec = np.array([0.05 + 0.25 * (i % 37) for i in range(n)])
             Cw = np.zeros(w)
             self._user["winner"](1.0, _Host(xa), _Host(cvec), Cw)

@@ -92,3 +92,54 @@ def test_hash_data_is_sharding_invariant():
             nl, off = po.shard(1000, r, size)
             pieces.append(po.u01(7, 123, np.arange(off, off + nl, dtype=np.uint64)))
         np.testing.assert_array_equal(np.concatenate(pieces), full)
+
+
+def _worker_csr(rank, world, port, args, opts, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = po.TorchComm()
+    prob = po.SepProblem(args["problem"], args["n"], args["c"], comm=comm,
+                         chain=(args["chain_span"], args.get("chain_stride", 1)))
+    ip = po.InteriorPoint(prob, opts, comm=comm)
+    snaps = []
+    ip.hook = lambda s, k: snaps.append(s.snapshot())
+    ip.optimize()
+    if rank == 0:
+        q.put(([(tuple(s["counters"]), s["fobj"], s["mu"], tuple(s["norms"]), tuple(s["wnorms"])) for s in snaps],
+               (ip.niter, ip.neval, ip.ngeval), ip.fobj))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_oracle_csr_constraints_match_reference_on_two_ranks():
+    """Rank-local CSR sparse constraints (each rank owns the rows over its own variables and its own S):
+    the sharded oracle against the trajectory the reference produced on two MPI ranks."""
+    from conftest import ip_options_from_case, load_golden
+
+    g, case = load_golden("ipcsr_convex_n240_c2_chain2_r2")
+    opts = ip_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_csr, args=(r, 2, port, case["args"], opts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    snaps, counters, fobj = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nref = 1 + max(int(k[2:5]) for k in g if k.startswith("it") and k.endswith("/mu"))
+    for k in range(min(25, nref, len(snaps))):
+        pfx = "it%03d/" % k
+        cnt, f, mu, norms, wnorms = snaps[k]
+        np.testing.assert_array_equal(np.array(cnt), g[pfx + "counters"])
+        assert abs(f - g[pfx + "fobj"][0]) <= 1e-7 * max(1.0, abs(g[pfx + "fobj"][0]))
+        assert abs(mu - g[pfx + "mu"][0]) <= 1e-7 * abs(g[pfx + "mu"][0])
+        np.testing.assert_allclose(norms, g[pfx + "norms"], rtol=1e-7)
+        np.testing.assert_allclose(wnorms, g[pfx + "wnorms"], rtol=1e-6)
+    np.testing.assert_array_equal(np.array(counters), g["final/counters"])
+    assert abs(fobj - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))

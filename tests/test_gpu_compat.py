@@ -210,3 +210,62 @@ def test_sparse_rosenbrock_example_style():
     otr.optimize()
     assert opt2.tr.getState()["iter_count"] == otr.iter_count
     np.testing.assert_allclose(x2[:], sub.xk, rtol=0, atol=1e-6)
+
+
+def test_sparse_rosenbrock_csr_form():
+    """examples/rosenbrock/sparse_rosenbrock.cpp through the reference's PYTHON interface for the CSR form
+    (ParOpt.Problem(comm, ..., rowp=, cols=) with evalSparseObjCon / evalSparseObjConGradient,
+    paropt/ParOpt.pyx:579-625,849-881): two dense constraints, nvars - 1 overlapping sparse constraints
+    cw_i = 1 - x_i^2 - x_{i+1}^2 >= 0.  Checked against the numpy oracle (pinned to the reference on
+    tests/golden/ipcsr_rosenbrock_n100_chain2.npz, the same problem)."""
+    from conftest import ip_options_from_case, load_golden
+    from oracle import paropt_oracle as po
+    from paropt_amd import ParOpt
+
+    n = 100
+    rowp = [2 * i for i in range(n)]
+    cols = [j for i in range(n - 1) for j in (i, i + 1)]
+
+    class SparseRosenbrock(ParOpt.Problem):
+        def __init__(self):
+            super(SparseRosenbrock, self).__init__(None, nvars=n, ncon=2, nwcon=n - 1, ninequality=2,
+                                                   nwinequality=n - 1, rowp=rowp, cols=cols)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = -1.0
+            lb[:] = -2.0
+            ub[:] = 1.0
+
+        def evalSparseObjCon(self, x, sparse):
+            xa = np.array(x[:])
+            f = np.sum((1.0 - xa[:-1]) ** 2 + 100.0 * (xa[1:] - xa[:-1] ** 2) ** 2)
+            con = np.array([0.25 - np.sum(xa * xa), 10.0 + np.sum(xa[::2])])
+            sparse[:] = 1.0 - xa[:-1] ** 2 - xa[1:] ** 2
+            return 0, f, con
+
+        def evalSparseObjConGradient(self, x, g, A, data):
+            xa = np.array(x[:])
+            ga = np.zeros(n)
+            ga[:-1] += -2.0 * (1.0 - xa[:-1]) + 200.0 * (xa[1:] - xa[:-1] ** 2) * (-2.0 * xa[:-1])
+            ga[1:] += 200.0 * (xa[1:] - xa[:-1] ** 2)
+            g[:] = ga
+            A[0][:] = -2.0 * xa
+            A[1][:] = 0.0
+            A[1][::2] = 1.0
+            data[0::2] = -2.0 * xa[:-1]
+            data[1::2] = -2.0 * xa[1:]
+            return 0
+
+    errs = SparseRosenbrock().checkGradients(x=np.random.RandomState(0).uniform(-1.5, 0.5, size=n))
+    assert errs["objective"] < 1e-3 and errs["con0"] < 1e-4 and errs["con1"] < 1e-6 and errs["transpose"] < 1e-12
+    g, case = load_golden("ipcsr_rosenbrock_n100_chain2")
+    opts = ip_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    opt = ParOpt.Optimizer(SparseRosenbrock(), dict(opts, algorithm="ip", output_file=None))
+    opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+    np.testing.assert_array_equal(np.array(opt.ip.getIterationCounters()), g["final/counters"])
+    assert abs(opt.ip.getObjective()[0] - g["final/fobj"][0]) <= 1e-6 * abs(g["final/fobj"][0])
+    np.testing.assert_allclose(z, g["final/z"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x[:], g["final/x"], rtol=0, atol=1e-6)
+    assert len(zw) == n - 1

@@ -165,6 +165,65 @@ def test_two_ranks_weighting_constraints_match_single_rank():
     np.testing.assert_allclose(zw2, zw1, rtol=0, atol=1e-6 * max(1.0, np.abs(zw1).max()))
 
 
+def _worker_csr(rank, world, port, q, args, opts):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    prob = pa.SeparableProblem(ctx, args["problem"], args["n"], args["c"]).setChain(
+        args["chain_span"], args.get("chain_stride", 1), args.get("chain_reverse", 0))
+    ip = pa.InteriorPoint(prob, opts)
+    snaps = []
+    ip.setIterationCallback(lambda k: snaps.append(ip.snapshot()))
+    ip.optimize()
+    if rank == 0:
+        q.put(([(tuple(s["counters"]), s["qn_size"], s["fobj"], s["mu"], tuple(s["norms"]), tuple(s["wnorms"]),
+                 tuple(s["z"])) for s in snaps], tuple(ip.getIterationCounters()), ip.getObjective()[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_csr_constraints_match_reference_golden():
+    """The CSR form of the sparse constraints on two ranks (each rank factors its own S, no collective on the
+    sparse path) against the trajectory the reference produced on two MPI ranks."""
+    from conftest import ip_options_from_case, load_golden
+
+    g, case = load_golden("ipcsr_convex_n240_c2_chain2_r2")
+    assert case["ranks"] == 2
+    opts = ip_options_from_case(case)
+    opts["write_output_frequency"] = 0
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_csr, args=(r, 2, port, q, case["args"], opts)) for r in range(2)]
+    for p in procs:
+        p.start()
+    snaps, counters, fobj = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nref = 1 + max(int(k[2:5]) for k in g if k.startswith("it") and k.endswith("/mu"))
+    ncmp = min(25, nref, len(snaps))
+    assert ncmp >= min(25, nref)
+    for k in range(ncmp):
+        pfx = "it%03d/" % k
+        cnt, qs, f, mu, norms, wnorms, z = snaps[k]
+        np.testing.assert_array_equal(np.array(cnt), g[pfx + "counters"], err_msg="counters @%d" % k)
+        assert qs == int(g[pfx + "qn_size"][0])
+        assert abs(mu - g[pfx + "mu"][0]) <= 1e-6 * abs(g[pfx + "mu"][0])
+        assert abs(f - g[pfx + "fobj"][0]) <= 1e-6 * max(1.0, abs(g[pfx + "fobj"][0]))
+        np.testing.assert_allclose(norms, g[pfx + "norms"], rtol=1e-6)
+        np.testing.assert_allclose(wnorms, g[pfx + "wnorms"], rtol=1e-6)
+        np.testing.assert_allclose(z, g[pfx + "z"], rtol=1e-5, atol=1e-5 * max(1.0, np.abs(g[pfx + "z"]).max()))
+    np.testing.assert_array_equal(np.array(counters), g["final/counters"])
+    assert abs(fobj - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+
+
 def _worker_tr(rank, world, port, q):
     import torch.distributed as dist
 

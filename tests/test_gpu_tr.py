@@ -118,3 +118,27 @@ def test_tr_option_errors(ctx):
         pa.TrustRegion(prob, {"tr_accept_step_strategy": "no_such_strategy"})
     with pytest.raises(pa.ParOptAMDError):
         pa.TrustRegion(prob, {"tr_no_such_option": 1})
+
+
+def test_trust_region_over_csr_sparse_constraints(ctx):
+    """The trust-region driver over a problem in the CSR form: the quadratic subproblem forwards the
+    quasi-definite factor / half-solve to the wrapped problem, so the inner interior point runs the sparse
+    Cholesky path.  Checked against the oracle's driver on the same problem (the oracle mirrors the
+    reference's stored-value semantics of ParOptSparseProblem::evalSparseCon)."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+    from oracle import tr_oracle as tro
+
+    n, c = 120, 2
+    opts = {"tr_init_size": 0.1, "tr_max_iterations": 12, "qn_subspace_size": 5, "output_file": "",
+            "tr_output_file": ""}
+    tr = pa.TrustRegion(pa.SeparableProblem(ctx, "convex", n, c).setChain(3, 2), opts)
+    tr.optimize()
+    ops = po.VecOps(po.SelfComm())
+    sub = tro.QuadraticSubproblem(po.SepProblem("convex", n, c, chain=(3, 2)),
+                                  po.LBFGS(n, 5, ops, "skip_negative_curvature"))
+    otr = tro.TrustRegion(sub, po.InteriorPoint(sub, {}), {"tr_init_size": 0.1, "tr_max_iterations": 12})
+    otr.optimize()
+    st = tr.getState()
+    assert st["iter_count"] == otr.iter_count
+    np.testing.assert_allclose(tr.getOptimizedPoint()[0].to_numpy(), sub.xk, rtol=0, atol=1e-6)
