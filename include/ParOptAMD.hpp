@@ -179,16 +179,7 @@ class ParOptProblem : public ParOptBase {
       if (po_problem_create_callbacks(ctx, nvars, ncon, ninequality, &cb, &hprob) != 0) {
         fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
       }
-      if (hprob && nwcon > 0) {
-        po_problem_sparse_callbacks scb;
-        scb.eval_sparse_con = &ParOptProblem::tramp_wcon;
-        scb.add_sparse_jacobian = &ParOptProblem::tramp_wjac;
-        scb.add_sparse_jacobian_transpose = &ParOptProblem::tramp_wjact;
-        scb.add_sparse_inner_product = &ParOptProblem::tramp_winner;
-        if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0) {
-          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
-        }
-      }
+      if (hprob) attachSparse();
     }
     return hprob;
   }
@@ -196,9 +187,21 @@ class ParOptProblem : public ParOptBase {
  protected:
   po_ctx ctx;
   int nvars, ncon, nwcon, ninequality, nwinequality;
+  po_problem hprob;
+  // registers the sparse-constraint callbacks with the library; ParOptSparseProblem registers its CSR form
+  virtual void attachSparse() {
+    if (nwcon <= 0) return;
+    po_problem_sparse_callbacks scb;
+    scb.eval_sparse_con = &ParOptProblem::tramp_wcon;
+    scb.add_sparse_jacobian = &ParOptProblem::tramp_wjac;
+    scb.add_sparse_jacobian_transpose = &ParOptProblem::tramp_wjact;
+    scb.add_sparse_inner_product = &ParOptProblem::tramp_winner;
+    if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0) {
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    }
+  }
 
  private:
-  po_problem hprob;
   static int tramp_vars(void *self, po_vec x, po_vec lb, po_vec ub) {
     ParOptVec vx(x), vl(lb), vu(ub);
     double *p;
@@ -279,6 +282,77 @@ class ParOptProblem : public ParOptBase {
     ParOptVec vx(x);
     static_cast<ParOptProblem *>(self)->writeOutput(iter, &vx);
     return 0;
+  }
+};
+
+// ---- ParOptSparseProblem (src/ParOptProblem.h:301-395): fixed CSR pattern for the sparse Jacobian -------------
+// Overlapping rows are allowed; the quasi-definite system is solved with the device sparse Cholesky
+// (ParOptQuasiDefSparseMat of the reference).  `data` is a HOST array of nnz entries in the order of cols, as in
+// the reference; it is uploaded after the call.
+class ParOptSparseProblem : public ParOptProblem {
+ public:
+  explicit ParOptSparseProblem(po_ctx _ctx) : ParOptProblem(_ctx) {}
+  // after setProblemSizes(), as in the reference (:306-312)
+  void setSparseJacobianData(const int *_rowp, const int *_cols) {
+    rowp.assign(_rowp, _rowp + nwcon + 1);
+    cols.assign(_cols, _cols + rowp[nwcon]);
+    data.assign(cols.size() > 0 ? cols.size() : 1, 0.0);
+  }
+  int getSparseJacobianData(const int **_rowp, const int **_cols, const ParOptScalar **_data) {
+    if (_rowp) *_rowp = rowp.data();
+    if (_cols) *_cols = cols.data();
+    if (_data) *_data = data.data();
+    return (int)cols.size();
+  }
+  virtual int evalSparseObjCon(ParOptVec *x, ParOptScalar *fobj, ParOptScalar *cons, ParOptVec *sparse_con) = 0;
+  virtual int evalSparseObjConGradient(ParOptVec *x, ParOptVec *g, ParOptVec **Ac, ParOptScalar *data) = 0;
+  // the base-class evaluations are never reached: the library calls the sparse forms (:348-358)
+  int evalObjCon(ParOptVec *, ParOptScalar *, ParOptScalar *) { return 1; }
+  int evalObjConGradient(ParOptVec *, ParOptVec *, ParOptVec **) { return 1; }
+  // one line about the device factorization (ParOptQuasiDefMat::getFactorInfo)
+  const char *getFactorInfo() { return hprob ? po_quasidef_factor_info(hprob) : NULL; }
+
+ protected:
+  void attachSparse() {
+    if (po_problem_set_sparse_jacobian_data(hprob, nwcon, nwinequality, rowp.data(), cols.data(),
+                                            &ParOptSparseProblem::tramp_sobjcon,
+                                            &ParOptSparseProblem::tramp_sgrad) != 0) {
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    }
+  }
+
+ private:
+  std::vector<int> rowp, cols;
+  std::vector<ParOptScalar> data;
+  static int tramp_sobjcon(void *self, po_vec x, double *fobj, double *cons, po_vec sparse) {
+    ParOptVec vx(x), vs(sparse);
+    double *p;
+    vx.syncToHost();
+    vs.getArray(&p);
+    int fail = static_cast<ParOptSparseProblem *>(self)->evalSparseObjCon(&vx, fobj, cons, &vs);
+    vs.syncToDevice();
+    return fail;
+  }
+  static int tramp_sgrad(void *self, po_vec x, po_vec g, const po_vec *Ac, double *ddata, int64_t nnz) {
+    ParOptSparseProblem *me = static_cast<ParOptSparseProblem *>(self);
+    ParOptVec vx(x), vg(g);
+    vx.syncToHost();
+    std::vector<ParOptVec *> va(me->ncon > 0 ? me->ncon : 1, (ParOptVec *)NULL);
+    double *p;
+    vg.getArray(&p);
+    for (int j = 0; j < me->ncon; j++) {
+      va[j] = new ParOptVec(Ac[j]);
+      va[j]->incref();
+      va[j]->getArray(&p);
+    }
+    int fail = me->evalSparseObjConGradient(&vx, &vg, va.data(), me->data.data());
+    vg.syncToDevice();
+    for (int j = 0; j < me->ncon; j++) {
+      va[j]->syncToDevice();
+      va[j]->decref();
+    }
+    if (po_ctx_memcpy(me->ctx, ddata, me->data.data(), (int64_t)sizeof(double) * nnz, 1) != 0) return 1;
+    return fail;
   }
 };
 

@@ -168,8 +168,8 @@ int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequ
  * Replaces the problem's eval_obj_con / eval_obj_con_gradient callbacks, as the reference's subclass does.
  * Only on a problem made by po_problem_create_callbacks, before po_ip_create. */
 typedef int (*po_eval_sparse_obj_con_fn)(void *user, po_vec x, double *fobj, double *cons, po_vec sparse_con);
-typedef int (*po_eval_sparse_obj_con_gradient_fn)(void *user, po_vec x, po_vec g, po_vec *Ac, double *data,
-                                                  int64_t nnz);
+typedef int (*po_eval_sparse_obj_con_gradient_fn)(void *user, po_vec x, po_vec g, const po_vec *Ac,
+                                                  double *data, int64_t nnz);
 int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwinequality, const int *rowp,
                                         const int *cols, po_eval_sparse_obj_con_fn eval_sparse_obj_con,
                                         po_eval_sparse_obj_con_gradient_fn eval_sparse_obj_con_gradient);
@@ -188,15 +188,16 @@ const char *po_quasidef_factor_info(po_problem p);
  * tested) without a device: column-sorted pattern, pattern of S = Aw Aw^T, nested-dissection ordering,
  * elimination tree, pattern of L (CSR, diagonal last in each row) and the dependency level sets the device
  * factorization and solves are scheduled by.  No context needed.
- * info = {nnz(Aw), nnz(lower S), nnz(L), forward levels, backward levels, 1 if `cols` was already sorted}. */
+ * info = {nnz(Aw), nnz(lower S), nnz(L), dependency levels, 1 if `cols` was already sorted}. */
 typedef struct po_csr_symbolic_s *po_csr_symbolic;
 int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const int *cols, po_csr_symbolic *out);
-int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[6]);
-/* borrowed host arrays: perm[new] = old (nwcon), parent (nwcon), Lrowp (nwcon+1), Lcols (nnz(L)),
- * fwd_ptr (levels+1) / fwd_order (nwcon), bwd_ptr / bwd_order; any output pointer may be NULL */
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[5]);
+/* borrowed host arrays: perm[new] = old (nwcon), parent (nwcon), Lrowp (nwcon+1), Lcols (nnz(L)), level_ptr
+ * (levels+1): rows are numbered level by level, level l is the rows level_ptr[l] .. level_ptr[l+1]-1, processed
+ * in ascending order by the factorization and the forward solve and in descending order by the backward
+ * solve; any output pointer may be NULL */
 int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
-                           const int **Lcols, const int **fwd_ptr, const int **fwd_order, const int **bwd_ptr,
-                           const int **bwd_order);
+                           const int **Lcols, const int **level_ptr);
 int po_csr_symbolic_destroy(po_csr_symbolic h);
 /* Second-order information (src/ParOptProblem.h:160-189) for use_hvec_product / use_diag_hessian:
  * evalHvecProduct: hvec = H(x, z, zw) px ; evalHessianDiag: hdiag = diag H(x, z, zw), with H the

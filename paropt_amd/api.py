@@ -496,11 +496,11 @@ class CsrSymbolic:
         check(lib.po_csr_symbolic_create(int(nvars), w, rowp.ctypes.data_as(L.c_int_p),
                                          cols.ctypes.data_as(L.c_int_p), C.byref(h)))
         try:
-            info = (C.c_int64 * 6)()
+            info = (C.c_int64 * 5)()
             check(lib.po_csr_symbolic_info(h, info))
-            self.nnz, self.nnzS, self.nnzL, self.nlevels_fwd, self.nlevels_bwd = (int(v) for v in info[:5])
-            self.sorted_input = bool(info[5])
-            ptrs = [L.c_int_p() for _ in range(8)]
+            self.nnz, self.nnzS, self.nnzL, self.nlevels = (int(v) for v in info[:4])
+            self.sorted_input = bool(info[4])
+            ptrs = [L.c_int_p() for _ in range(5)]
             check(lib.po_csr_symbolic_arrays(h, *[C.byref(p) for p in ptrs]))
 
             def arr(p, n):
@@ -508,8 +508,7 @@ class CsrSymbolic:
 
             self.perm, self.parent = arr(ptrs[0], w), arr(ptrs[1], w)
             self.Lrowp, self.Lcols = arr(ptrs[2], w + 1), arr(ptrs[3], self.nnzL)
-            self.fwd_ptr, self.fwd_order = arr(ptrs[4], self.nlevels_fwd + 1), arr(ptrs[5], w)
-            self.bwd_ptr, self.bwd_order = arr(ptrs[6], self.nlevels_bwd + 1), arr(ptrs[7], w)
+            self.level_ptr = arr(ptrs[4], self.nlevels + 1)
         finally:
             lib.po_csr_symbolic_destroy(h)
 

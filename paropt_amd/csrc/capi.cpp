@@ -445,29 +445,24 @@ int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const 
   *out = h;
   return PO_OK;
 }
-int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[6]) {
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[5]) {
   PO_CHECK_PTR(h);
   PO_CHECK_PTR(info);
   info[0] = h->s.nnz;
   info[1] = h->s.nnzS;
   info[2] = h->s.nnzL;
   info[3] = (int64_t)h->s.fwd_ptr.size() - 1;
-  info[4] = (int64_t)h->s.bwd_ptr.size() - 1;
-  info[5] = h->s.identity_src ? 1 : 0;
+  info[4] = h->s.identity_src ? 1 : 0;
   return PO_OK;
 }
 int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
-                           const int **Lcols, const int **fwd_ptr, const int **fwd_order, const int **bwd_ptr,
-                           const int **bwd_order) {
+                           const int **Lcols, const int **level_ptr) {
   PO_CHECK_PTR(h);
   if (perm) *perm = h->s.perm.data();
   if (parent) *parent = h->s.parent.data();
   if (Lrowp) *Lrowp = h->s.Lrowp.data();
   if (Lcols) *Lcols = h->s.Lcols.data();
-  if (fwd_ptr) *fwd_ptr = h->s.fwd_ptr.data();
-  if (fwd_order) *fwd_order = h->s.fwd_order.data();
-  if (bwd_ptr) *bwd_ptr = h->s.bwd_ptr.data();
-  if (bwd_order) *bwd_order = h->s.bwd_order.data();
+  if (level_ptr) *level_ptr = h->s.fwd_ptr.data();
   return PO_OK;
 }
 int po_csr_symbolic_destroy(po_csr_symbolic h) {

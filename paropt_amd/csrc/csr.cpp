@@ -3,6 +3,7 @@
 #include "csr.hpp"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -12,7 +13,16 @@ namespace po {
 
 namespace {
 
-constexpr int kLeaf = 48;  // subsets this small are numbered as they come
+// subsets this small are numbered as they come (PAROPT_AMD_ND_LEAF overrides, for experiments)
+static int leaf_size() {
+  static int v = 0;
+  if (v == 0) {
+    const char *e = getenv("PAROPT_AMD_ND_LEAF");
+    v = e && atoi(e) > 0 ? atoi(e) : 8;
+  }
+  return v;
+}
+#define kLeaf leaf_size()
 
 // Nested dissection from BFS level structures (George's automatic nested dissection): the middle
 // level of a rooted level structure from a pseudo-peripheral vertex separates the graph; the two
@@ -240,22 +250,25 @@ int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrS
     nd.order(all, 0, 0, 0);
     s.perm.swap(nd.perm);
   }
-  s.iperm.assign(w, -1);
-  for (int i = 0; i < w; i++) {
-    if (s.perm[i] < 0 || s.perm[i] >= w || s.iperm[s.perm[i]] != -1) {
-      set_error("internal: ordering is not a permutation");
-      return PO_ERR_ARG;
+  // The dissection ordering fixes the elimination TREE; any topological order of that tree gives the same
+  // factor up to a relabelling.  Rows are renumbered level by level (a row's level = the height of its
+  // subtree), so the rows a launch works on - and their storage in L - are contiguous in memory.
+  auto invert = [&](const std::vector<int> &perm, std::vector<int> &iperm) -> bool {
+    iperm.assign(w, -1);
+    for (int i = 0; i < w; i++) {
+      if (perm[i] < 0 || perm[i] >= w || iperm[perm[i]] != -1) return false;
+      iperm[perm[i]] = i;
     }
-    s.iperm[s.perm[i]] = i;
-  }
-  // elimination tree (Liu, with path compression) and the row patterns of L (row subtrees)
-  s.parent.assign(w, -1);
-  {
+    return true;
+  };
+  // elimination tree (Liu, with path compression)
+  auto etree = [&](const std::vector<int> &perm, const std::vector<int> &iperm, std::vector<int> &parent) {
+    parent.assign(w, -1);
     std::vector<int> anc(w, -1);
     for (int i = 0; i < w; i++) {
-      const int old = s.perm[i];
+      const int old = perm[i];
       for (int p = adjp[old]; p < adjp[old + 1]; p++) {
-        int r = s.iperm[adj[p]];
+        int r = iperm[adj[p]];
         if (r >= i) continue;
         while (anc[r] != -1 && anc[r] != i) {
           const int nx = anc[r];
@@ -264,11 +277,37 @@ int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrS
         }
         if (anc[r] == -1) {
           anc[r] = i;
-          s.parent[r] = i;
+          parent[r] = i;
         }
       }
     }
+  };
+  auto levels_of = [&](const std::vector<int> &parent, std::vector<int> &lev) -> int {
+    lev.assign(w, 0);
+    int nlev = w > 0 ? 1 : 0;
+    for (int i = 0; i < w; i++) {
+      const int p = parent[i];
+      if (p >= 0 && lev[p] < lev[i] + 1) lev[p] = lev[i] + 1;
+      if (lev[i] + 1 > nlev) nlev = lev[i] + 1;
+    }
+    return nlev;
+  };
+  if (!invert(s.perm, s.iperm)) {
+    set_error("internal: ordering is not a permutation");
+    return PO_ERR_ARG;
   }
+  std::vector<int> lev;
+  {
+    etree(s.perm, s.iperm, s.parent);
+    const int nlev = levels_of(s.parent, lev);
+    std::vector<int> start((size_t)nlev + 1, 0), byLevel(w);
+    for (int i = 0; i < w; i++) start[lev[i] + 1]++;
+    for (int l = 0; l < nlev; l++) start[l + 1] += start[l];
+    for (int i = 0; i < w; i++) byLevel[start[lev[i]]++] = s.perm[i];
+    s.perm.swap(byLevel);
+    invert(s.perm, s.iperm);
+  }
+  etree(s.perm, s.iperm, s.parent);
   s.Lrowp.assign((size_t)w + 1, 0);
   s.Lcols.clear();
   {
@@ -337,36 +376,46 @@ int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrS
       s.ent_slot.push_back((int)(f - &s.Lcols[0]));
     }
   }
-  // dependency levels: a row needs every row in its pattern, all of them descendants in the tree
+  // assemble in the order of Aw's rows: the (many) reads of an entry walk Aw coalesced, its one write scatters
   {
-    std::vector<int> lev(w, 0);
-    int nlev = w > 0 ? 1 : 0;
-    for (int i = 0; i < w; i++) {
-      const int p = s.parent[i];
-      if (p >= 0 && lev[p] < lev[i] + 1) lev[p] = lev[i] + 1;
-      if (lev[i] + 1 > nlev) nlev = lev[i] + 1;
+    const size_t ne = s.ent_slot.size();
+    std::vector<int> idx(ne);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](int x, int y) {
+      return s.ent_a[x] != s.ent_a[y] ? s.ent_a[x] < s.ent_a[y] : s.ent_b[x] < s.ent_b[y];
+    });
+    std::vector<int> ta(ne), tb(ne), ts(ne);
+    for (size_t k = 0; k < ne; k++) {
+      ta[k] = s.ent_a[idx[k]];
+      tb[k] = s.ent_b[idx[k]];
+      ts[k] = s.ent_slot[idx[k]];
     }
+    s.ent_a.swap(ta);
+    s.ent_b.swap(tb);
+    s.ent_slot.swap(ts);
+  }
+  // dependency levels: a row needs every row in its pattern, all of them descendants in the tree.  The same
+  // sets in DESCENDING order schedule the backward solve (x_i needs x_j for the ancestors j in column i).
+  {
+    const int nlev = levels_of(s.parent, lev);
     s.fwd_ptr.assign((size_t)nlev + 1, 0);
     for (int i = 0; i < w; i++) s.fwd_ptr[lev[i] + 1]++;
     for (int l = 0; l < nlev; l++) s.fwd_ptr[l + 1] += s.fwd_ptr[l];
     s.fwd_order.resize(w);
     std::vector<int> fill(s.fwd_ptr.begin(), s.fwd_ptr.end() - 1);
     for (int i = 0; i < w; i++) s.fwd_order[fill[lev[i]]++] = i;
-  }
-  {
-    std::vector<int> dep(w, 0);
-    int nlev = w > 0 ? 1 : 0;
-    for (int i = w - 1; i >= 0; i--) {
-      const int p = s.parent[i];
-      dep[i] = p >= 0 ? dep[p] + 1 : 0;
-      if (dep[i] + 1 > nlev) nlev = dep[i] + 1;
+    s.fwd_maxlen.assign(nlev, 0);
+    s.bwd_maxlen.assign(nlev, 0);
+    for (int i = 0; i < w; i++) {
+      s.fwd_maxlen[lev[i]] = std::max(s.fwd_maxlen[lev[i]], s.Lrowp[i + 1] - s.Lrowp[i]);
+      s.bwd_maxlen[lev[i]] = std::max(s.bwd_maxlen[lev[i]], s.Ltp[i + 1] - s.Ltp[i]);
     }
-    s.bwd_ptr.assign((size_t)nlev + 1, 0);
-    for (int i = 0; i < w; i++) s.bwd_ptr[dep[i] + 1]++;
-    for (int l = 0; l < nlev; l++) s.bwd_ptr[l + 1] += s.bwd_ptr[l];
-    s.bwd_order.resize(w);
-    std::vector<int> fill(s.bwd_ptr.begin(), s.bwd_ptr.end() - 1);
-    for (int i = 0; i < w; i++) s.bwd_order[fill[dep[i]]++] = i;
+    for (int i = 0; i < w; i++) {
+      if (s.fwd_order[i] != i) {
+        set_error("internal: rows are not numbered level by level");
+        return PO_ERR_ARG;
+      }
+    }
   }
   return PO_OK;
 }
@@ -412,7 +461,6 @@ CsrSparse::~CsrSparse() {
   dfree(d_ent_b);
   dfree(d_ent_slot);
   dfree(d_fwd);
-  dfree(d_bwd);
   dfree(Lvals);
   dfree(ones);
   dfree(wwork);
@@ -462,7 +510,6 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   PO_TRY(upload(d_ent_b, sym.ent_b));
   PO_TRY(upload(d_ent_slot, sym.ent_slot));
   PO_TRY(upload(d_fwd, sym.fwd_order));
-  PO_TRY(upload(d_bwd, sym.bwd_order));
   dfree(Lvals);
   dfree(ones);
   dfree(wwork);
@@ -479,7 +526,6 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   cw = vec_new(ctx, w);
   if (!cw) return PO_ERR_HIP;
   nlevels_f = (int)sym.fwd_ptr.size() - 1;
-  nlevels_b = (int)sym.bwd_ptr.size() - 1;
   spmv_group = group_for(w > 0 ? (double)nnz / (double)w : 0.0);
   spmvT_group = group_for(n > 0 ? (double)nnz / (double)n : 0.0);
   return PO_OK;
@@ -506,6 +552,10 @@ int CsrSparse::panelPermuted(const double *d, const double *const *P, int nv, do
   return k_csr_panel(ctx, d_rowp, d_cols, vals, w, d, P, nv, U, d_iperm);
 }
 
+// one thread per row when the rows of a level are short, or when there are so many that even long rows keep
+// every lane busy; a wavefront per row otherwise
+static int thinLevel(int maxlen, int64_t work_items) { return maxlen <= 24 || (work_items >= 65536 && maxlen <= 96); }
+
 int CsrSparse::factor(const double *dinv, const double *cdiag) {
   if (w <= 0) return PO_OK;
   PO_HIP(hipMemsetAsync(Lvals, 0, ((size_t)sym.nnzL + 4) * sizeof(double), ctx->stream));
@@ -514,7 +564,7 @@ int CsrSparse::factor(const double *dinv, const double *cdiag) {
                         (int64_t)sym.ent_slot.size(), Lvals));
   for (int l = 0; l < nlevels_f; l++) {
     const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
-    PO_TRY(k_chol_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, d_flag));
+    PO_TRY(k_chol_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, d_flag, thinLevel(sym.fwd_maxlen[l], e - b)));
   }
   int flag[4] = {0, 0, 0, 0};
   PO_HIP(hipMemcpyAsync(flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
@@ -533,13 +583,15 @@ int CsrSparse::solveInPlace(double *const *Y, int nv, bool forward, bool backwar
   if (forward) {
     for (int l = 0; l < nlevels_f; l++) {
       const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
-      PO_TRY(k_trsv_fwd_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, Y, nv));
+      PO_TRY(k_trsv_fwd_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, Y, nv,
+                              thinLevel(sym.fwd_maxlen[l], (int64_t)(e - b) * nv)));
     }
   }
   if (backward) {
-    for (int l = 0; l < nlevels_b; l++) {
-      const int b = sym.bwd_ptr[l], e = sym.bwd_ptr[l + 1];
-      PO_TRY(k_trsv_bwd_level(ctx, d_Lrowp, d_Ltp, d_Ltrows, d_Ltsrc, Lvals, d_bwd + b, e - b, Y, nv));
+    for (int l = nlevels_f - 1; l >= 0; l--) {
+      const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
+      PO_TRY(k_trsv_bwd_level(ctx, d_Lrowp, d_Ltp, d_Ltrows, d_Ltsrc, Lvals, d_fwd + b, e - b, Y, nv,
+                              thinLevel(sym.bwd_maxlen[l], (int64_t)(e - b) * nv)));
     }
   }
   return PO_OK;

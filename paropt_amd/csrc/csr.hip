@@ -320,10 +320,46 @@ __global__ void __launch_bounds__(64)
     __syncthreads();
   }
 }
+// The same recurrence with ONE THREAD per row, for levels whose rows are short (the leaves of the
+// dissection tree: a wavefront per row would idle 60 of its 64 lanes and cost a workgroup launch per row).
+__global__ void __launch_bounds__(kBlock)
+    chol_level_thin_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals,
+                           const int *__restrict__ rows, int nrows, int *flag) {
+  PO_C_LOOP(t, nrows) {
+    const int i = rows[t];
+    const int p0 = Lrowp[i], pd = Lrowp[i + 1] - 1;
+    double dsum = 0.0;
+    for (int p = p0; p < pd; p++) {
+      const int j = Lcols[p];
+      const int r0 = Lrowp[j], rd = Lrowp[j + 1] - 1;
+      double acc = 0.0;
+      int lo = p0;  // both rows are sorted: a merge instead of a search
+      for (int q = r0; q < rd; q++) {
+        const int k = Lcols[q];
+        while (lo < p && Lcols[lo] < k) lo++;
+        if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+      }
+      const double v = (Lvals[p] - acc) / Lvals[rd];
+      Lvals[p] = v;
+      dsum += v * v;
+    }
+    double a = Lvals[pd] - dsum;
+    if (!(a > 0.0)) {
+      flag[0] = 1;
+      flag[1] = i;
+      a = 1.0;
+    }
+    Lvals[pd] = sqrt(a);
+  }
+}
 int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows,
-                 int *flag) {
+                 int *flag, int thin) {
   if (nrows <= 0) return PO_OK;
-  PO_CLAUNCH(chol_level_kernel, nrows, 64, Lrowp, Lcols, Lvals, rows, nrows, flag);
+  if (thin) {
+    PO_CLAUNCH(chol_level_thin_kernel, cgrid(c, nrows), kBlock, Lrowp, Lcols, Lvals, rows, nrows, flag);
+  } else {
+    PO_CLAUNCH(chol_level_kernel, nrows, 64, Lrowp, Lcols, Lvals, rows, nrows, flag);
+  }
   return PO_OK;
 }
 
@@ -362,6 +398,35 @@ __global__ void __launch_bounds__(kBlock)
     if (lane == 0) y[i] = (y[i] - acc) / diag;
   }
 }
+// thin variants: one thread per (row, right-hand side), consecutive threads on consecutive rows
+__global__ void __launch_bounds__(kBlock)
+    trsv_fwd_thin_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols,
+                         const double *__restrict__ Lvals, const int *__restrict__ rows, int nrows, PtrTableW Y,
+                         int nv) {
+  PO_C_LOOP(t, (int64_t)nrows * nv) {
+    const int r = (int)(t / nrows);
+    const int i = rows[t - (int64_t)r * nrows];
+    double *y = Y.p[r];
+    const int p0 = Lrowp[i], pd = Lrowp[i + 1] - 1;
+    double acc = 0.0;
+    for (int q = p0; q < pd; q++) acc += Lvals[q] * y[Lcols[q]];
+    y[i] = (y[i] - acc) / Lvals[pd];
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    trsv_bwd_thin_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Ltp,
+                         const int *__restrict__ Ltrows, const int *__restrict__ Ltsrc,
+                         const double *__restrict__ Lvals, const int *__restrict__ rows, int nrows, PtrTableW Y,
+                         int nv) {
+  PO_C_LOOP(t, (int64_t)nrows * nv) {
+    const int r = (int)(t / nrows);
+    const int i = rows[t - (int64_t)r * nrows];
+    double *y = Y.p[r];
+    double acc = 0.0;
+    for (int q = Ltp[i]; q < Ltp[i + 1]; q++) acc += Lvals[Ltsrc[q]] * y[Ltrows[q]];
+    y[i] = (y[i] - acc) / Lvals[Lrowp[i + 1] - 1];
+  }
+}
 static int fill_table(PtrTableW &t, double *const *Y, int nv) {
   if (nv > kMaxPanel) {
     set_error("sparse triangular solve: %d right-hand sides exceed the panel limit %d", nv, kMaxPanel);
@@ -371,10 +436,14 @@ static int fill_table(PtrTableW &t, double *const *Y, int nv) {
   return PO_OK;
 }
 int k_trsv_fwd_level(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, const int *rows, int nrows,
-                     double *const *Y, int nv) {
+                     double *const *Y, int nv, int thin) {
   if (nrows <= 0 || nv <= 0) return PO_OK;
   PtrTableW t;
   PO_TRY(fill_table(t, Y, nv));
+  if (thin) {
+    PO_CLAUNCH(trsv_fwd_thin_kernel, cgrid(c, (int64_t)nrows * nv), kBlock, Lrowp, Lcols, Lvals, rows, nrows, t, nv);
+    return PO_OK;
+  }
   const int gy = nv > 4 ? (nrows < 1024 ? (nv + 3) / 4 : 1) : 1;
   hipLaunchKernelGGL(trsv_fwd_kernel, dim3(nrows, gy), dim3(nv > 1 ? kBlock : 64), 0, c->stream, Lrowp, Lcols,
                      Lvals, rows, nrows, t, nv);
@@ -383,10 +452,15 @@ int k_trsv_fwd_level(Ctx *c, const int *Lrowp, const int *Lcols, const double *L
   return PO_OK;
 }
 int k_trsv_bwd_level(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,
-                     const double *Lvals, const int *rows, int nrows, double *const *Y, int nv) {
+                     const double *Lvals, const int *rows, int nrows, double *const *Y, int nv, int thin) {
   if (nrows <= 0 || nv <= 0) return PO_OK;
   PtrTableW t;
   PO_TRY(fill_table(t, Y, nv));
+  if (thin) {
+    PO_CLAUNCH(trsv_bwd_thin_kernel, cgrid(c, (int64_t)nrows * nv), kBlock, Lrowp, Ltp, Ltrows, Ltsrc, Lvals, rows,
+               nrows, t, nv);
+    return PO_OK;
+  }
   const int gy = nv > 4 ? (nrows < 1024 ? (nv + 3) / 4 : 1) : 1;
   hipLaunchKernelGGL(trsv_bwd_kernel, dim3(nrows, gy), dim3(nv > 1 ? kBlock : 64), 0, c->stream, Lrowp, Ltp,
                      Ltrows, Ltsrc, Lvals, rows, nrows, t, nv);

@@ -39,8 +39,11 @@ struct CsrSymbolic {
   std::vector<int> Lrowp, Lcols;        // rows of L (lower, columns ascending, diagonal last)
   std::vector<int> Ltp, Ltrows, Ltsrc;  // columns of L below the diagonal, Ltsrc = slot in the row storage
   std::vector<int> ent_a, ent_b, ent_slot;  // structural entries of lower(P S P^T): rows a,b of A -> slot in L
-  std::vector<int> fwd_order, fwd_ptr;  // rows grouped by dependency level (factor + forward solve)
-  std::vector<int> bwd_order, bwd_ptr;  // rows grouped by depth in the tree (backward solve)
+  // rows grouped by dependency level: ascending for the factorization and the forward solve, descending for
+  // the backward solve.  Rows are NUMBERED level by level, so fwd_order is the identity and each level is a
+  // contiguous range of rows (and of L's storage).
+  std::vector<int> fwd_order, fwd_ptr;
+  std::vector<int> fwd_maxlen, bwd_maxlen;  // longest row / column of each level (kernel variant choice)
   int64_t nnzS = 0, nnzL = 0;
   bool identity_src = true;
 };
@@ -74,7 +77,7 @@ class CsrSparse {
   CsrSymbolic sym;
   Ctx *ctx;
   int64_t n, w, nnz;
-  int nlevels_f = 0, nlevels_b = 0;
+  int nlevels_f = 0;
 
  private:
   int solveInPlace(double *const *Y, int nv, bool forward, bool backward);
@@ -85,7 +88,7 @@ class CsrSparse {
   int *d_Lrowp = nullptr, *d_Lcols = nullptr;
   int *d_Ltp = nullptr, *d_Ltrows = nullptr, *d_Ltsrc = nullptr;
   int *d_ent_a = nullptr, *d_ent_b = nullptr, *d_ent_slot = nullptr;
-  int *d_fwd = nullptr, *d_bwd = nullptr;
+  int *d_fwd = nullptr;
   double *Lvals = nullptr, *ones = nullptr, *wwork = nullptr;
   int *d_flag = nullptr;
   std::string info;
@@ -105,11 +108,12 @@ int k_csr_panel(Ctx *c, const int *rowp, const int *cols, const double *vals, in
 int k_csr_assemble(Ctx *c, const int *rowp, const int *cols, const double *vals, const double *dinv,
                    const double *cdiag, const int *ent_a, const int *ent_b, const int *ent_slot, int64_t nent,
                    double *Lvals);
-int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows, int *flag);
+int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows, int *flag,
+                 int thin);
 int k_trsv_fwd_level(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, const int *rows, int nrows,
-                     double *const *Y, int nv);
+                     double *const *Y, int nv, int thin);
 int k_trsv_bwd_level(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,
-                     const double *Lvals, const int *rows, int nrows, double *const *Y, int nv);
+                     const double *Lvals, const int *rows, int nrows, double *const *Y, int nv, int thin);
 // built-in chain constraints cw_i = 1 - sum_{k<span} x[i*stride + k]^2 and their Jacobian entries
 int k_chain_con(Ctx *c, const double *x, int64_t w, int span, int stride, double *cw);
 int k_chain_jac(Ctx *c, const double *x, int64_t w, int span, int stride, int reverse, double *data);

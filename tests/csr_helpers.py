@@ -62,8 +62,8 @@ def emulate_factor(sym, S):
     Lp, Lc = sym.Lrowp, sym.Lcols
     L = np.zeros((w, w))
     done = np.zeros(w, dtype=bool)
-    for lev in range(sym.nlevels_fwd):
-        rows = sym.fwd_order[sym.fwd_ptr[lev]:sym.fwd_ptr[lev + 1]]
+    for lev in range(sym.nlevels):
+        rows = np.arange(sym.level_ptr[lev], sym.level_ptr[lev + 1])
         for i in rows:
             for p in range(Lp[i], Lp[i + 1]):
                 j = Lc[p]

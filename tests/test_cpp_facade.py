@@ -14,10 +14,10 @@ import pytest
 from conftest import ROOT, load_golden
 
 
-def build(tmp_path):
-    exe = str(tmp_path / "rosenbrock_amd")
+def build(tmp_path, name="rosenbrock_amd"):
+    exe = str(tmp_path / name)
     cmd = ["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "rosenbrock_amd.cpp"), "-L" + os.path.join(ROOT, "paropt_amd"),
+           os.path.join(ROOT, "examples", name + ".cpp"), "-L" + os.path.join(ROOT, "paropt_amd"),
            "-lparopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "paropt_amd"), "-Wl,-rpath-link,/opt/rocm/lib",
            "-o", exe]
     subprocess.check_call(cmd)
@@ -78,6 +78,33 @@ def test_cpp_optimizer_trust_region(tmp_path):
     assert abs(out["fobj"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
     np.testing.assert_allclose(out["xnorm"], g["final/xnorm"][0], rtol=1e-6)
     np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-4, atol=1e-6)
+
+
+def test_sparse_facade_compiles(tmp_path):
+    import torch
+
+    exe = build(tmp_path, "sparse_rosenbrock_amd")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 2 and "no MI355X available" in res.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_sparse_rosenbrock_csr_matches_reference(tmp_path):
+    """examples/rosenbrock/sparse_rosenbrock.cpp on the facade's ParOptSparseProblem: the reference's own
+    trajectory on the same problem (golden ipcsr_rosenbrock_n100_chain2, reference interior point on
+    ParOptSparseProblem) ends at the same point with the same counters."""
+    exe = build(tmp_path, "sparse_rosenbrock_amd")
+    res = subprocess.run([exe, "nvars=100"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    g, _ = load_golden("ipcsr_rosenbrock_n100_chain2")
+    np.testing.assert_array_equal(np.array([out["niter"], out["neval"], out["ngeval"]]), g["final/counters"])
+    assert abs(out["fobj"] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+    np.testing.assert_allclose(out["xnorm"], g["final/norms"][0], rtol=1e-7)
+    np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-5, atol=1e-6)
+    assert "nnz(L)" in out["factor_info"]
 
 
 def build_c(tmp_path):

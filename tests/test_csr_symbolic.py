@@ -49,12 +49,13 @@ def test_symbolic_structure(name):
         mask[i, sym.Lcols[sym.Lrowp[i]:sym.Lrowp[i + 1]]] = True
     assert np.all(np.abs(Lref[~mask]) < 1e-13)
     np.testing.assert_allclose(L, Lref, rtol=1e-10, atol=1e-12)
-    # backward levels: every row below the diagonal in column i sits in an earlier backward level
-    depth = np.zeros(w, dtype=int)
-    for lev in range(sym.nlevels_bwd):
-        depth[sym.bwd_order[sym.bwd_ptr[lev]:sym.bwd_ptr[lev + 1]]] = lev
+    # the same level sets, descending, schedule the backward solve: every row below the diagonal in column j
+    # sits in a LATER level than j
+    level = np.zeros(w, dtype=int)
+    for lev in range(sym.nlevels):
+        level[sym.level_ptr[lev]:sym.level_ptr[lev + 1]] = lev
     ii, jj = np.nonzero(np.tril(mask, -1))
-    assert np.all(depth[ii] < depth[jj])
+    assert np.all(level[ii] > level[jj])
 
 
 def test_nested_dissection_keeps_chains_shallow():
@@ -62,14 +63,14 @@ def test_nested_dissection_keeps_chains_shallow():
     n = 20000
     rowp, cols = chain_pattern(n, 2, 1)
     sym = CsrSymbolic(n, rowp, cols)
-    assert sym.nlevels_fwd < 120, sym.nlevels_fwd
+    assert sym.nlevels < 40, sym.nlevels
     assert sym.nnzL < 3 * sym.nnzS
 
 
 def test_block_diagonal_has_no_fill():
     rowp, cols = chain_pattern(4000, 4, 4)
     sym = CsrSymbolic(4000, rowp, cols)
-    assert sym.nnzL == sym.nnzS == 1000 and sym.nlevels_fwd == 1 and sym.sorted_input
+    assert sym.nnzL == sym.nnzS == 1000 and sym.nlevels == 1 and sym.sorted_input
 
 
 def test_bad_patterns_are_rejected():
