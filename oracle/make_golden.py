@@ -353,6 +353,25 @@ for tag, extra in (
 case("ipcsr_convex_n240_c2_chain2_r2", "ip", ranks=2, problem="convex", n=240, c=2, chain_span=2, chain_stride=1,
      dump_vecs_every=10,
      **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
+# second-order branches WITH sparse constraints: block form (weighting, linear) and CSR form (chain, the
+# constraint Hessian 2 zw_i enters the Lagrangian)
+hvw = {"opt.use_hvec_product": 1, "opt.gmres_subspace_size": 15, "opt.nk_switch_tol": 1e3, "opt.max_gmres_rtol": 1.0}
+case("ipw_quadratic_hvec_n300_c3_w40", "ip", problem="quadratic", n=300, c=3, nwcon=40, nw=5, nwstart=2, nwskip=1,
+     dump_vecs_every=10,
+     **dict(ip_common, **dict(hvw, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80})))
+case("ipw_rosenbrock_hvec_n100_w5", "ip", problem="rosenbrock", n=100, nwcon=5, nw=5, nwstart=1, nwskip=1,
+     dump_vecs_every=10,
+     **dict({"opt.qn_subspace_size": 10, "opt.abs_res_tol": 1e-6, "opt.write_output_frequency": 1,
+             "opt.max_major_iters": 150}, **dict(hvw, **{"opt.nk_switch_tol": 1.0, "opt.max_gmres_rtol": 0.5})))
+case("ipcsr_convex_hvec_n200_c2_chain3s2", "ip", problem="convex", n=200, c=2, chain_span=3, chain_stride=2,
+     dump_vecs_every=10,
+     **dict(ip_common, **dict(hvw, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80})))
+case("ipcsr_quadratic_hvec_n150_c2_chain2", "ip", problem="quadratic", n=150, c=2, chain_span=2, chain_stride=1,
+     dump_vecs_every=10,
+     **dict(ip_common, **dict(hvw, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 80})))
+case("ipcsr_convex_diaghess_n200_c2_chain3s2", "ip", problem="convex", n=200, c=2, chain_span=3, chain_stride=2,
+     dump_vecs_every=10,
+     **dict(ip_common, **{"opt.use_diag_hessian": 1, "opt.qn_subspace_size": 6, "opt.max_major_iters": 80}))
 # problems that declare no upper / no lower bounds (useUpperBounds() / useLowerBounds() = 0)
 case("ip_quadratic_noupper_n200_c2", "ip", problem="quadratic", n=200, c=2, use_upper=0, dump_vecs_every=10,
      **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 80}))

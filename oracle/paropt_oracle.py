@@ -423,25 +423,35 @@ class SepProblem:
             A += alpha * np.sum(cvec[self.widx], axis=1)
         return A
 
-    def hessian_diag(self, x, z):  # oracle/ref_driver.cpp evalHessianDiag
-        if self.kind == "quadratic":
-            return self.q.copy()
-        if self.kind == "convex":
-            d = 1e-3 + x
-            return 2.0 * self.b * self.b / (d * d * d)
-        h = np.full(len(x), 2.0 * z[0])
-        r = x[1:] - x[:-1] ** 2
-        h[:-1] += 2.0 - 400.0 * r + 800.0 * x[:-1] ** 2
-        h[1:] += 200.0
+    def _chain_hessian_diag(self, zw):
+        """2 zw_i on the diagonal entries of every chain constraint's variables (Lagrangian f - z.c - zw.cw)."""
+        h = np.zeros(self.nlocal)
+        if self.chain and zw is not None and len(zw):
+            np.add.at(h, self.cidx, 2.0 * np.asarray(zw)[:, None] * np.ones(self.cidx.shape[1])[None, :])
         return h
 
-    def hvec_product(self, x, z, px):  # oracle/ref_driver.cpp evalHvecProduct
+    def hessian_diag(self, x, z, zw=None):  # oracle/ref_driver.cpp evalHessianDiag
+        if self.kind == "quadratic":
+            h = self.q.copy()
+        elif self.kind == "convex":
+            d = 1e-3 + x
+            h = 2.0 * self.b * self.b / (d * d * d)
+        else:
+            h = np.full(len(x), 2.0 * z[0])
+            r = x[1:] - x[:-1] ** 2
+            h[:-1] += 2.0 - 400.0 * r + 800.0 * x[:-1] ** 2
+            h[1:] += 200.0
+        return h + self._chain_hessian_diag(zw) if self.chain else h
+
+    def hvec_product(self, x, z, px, zw=None):  # oracle/ref_driver.cpp evalHvecProduct
         if self.kind in ("quadratic", "convex"):
-            return self.hessian_diag(x, z) * px
+            return self.hessian_diag(x, z, zw) * px
         h = 2.0 * z[0] * px
         r = x[1:] - x[:-1] ** 2
         h[:-1] += (2.0 - 400.0 * r + 800.0 * x[:-1] ** 2) * px[:-1] - 400.0 * x[:-1] * px[1:]
         h[1:] += -400.0 * x[:-1] * px[:-1] + 200.0 * px[1:]
+        if self.chain:
+            h += self._chain_hessian_diag(zw) * px
         return h
 
     def eval_obj_con_gradient(self, x):
@@ -726,7 +736,7 @@ class InteriorPoint:
         o = self.opt
         L, U = self._masks()
         if inexact_newton_step:
-            r.x += -1.0 * self.prob.hvec_product(v.x, v.z, p.x)
+            r.x += -1.0 * self.prob.hvec_product(v.x, v.z, p.x, v.zw if self.w else None)
         elif o["use_diag_hessian"]:
             r.x -= p.x * self.hdiag
         else:
@@ -900,14 +910,17 @@ class InteriorPoint:
             d1 += yz[i] * self.Ac[i]
         return self._apply(d1)[0]
 
-    def solve_kkt_diag_alpha(self, v, bx, alpha, b, y):  # :2441-2614 (w = 0)
+    def solve_kkt_diag_alpha(self, v, bx, alpha, b, y):  # :2441-2614
         L, U = self._masks()
         xl = np.where(L, v.x - self.lb, 1.0)
         xu = np.where(U, self.ub - v.x, 1.0)
         d1 = bx.copy()
         d1 += alpha * np.where(L, b.zl / xl, 0.0)
         d1 -= alpha * np.where(U, b.zu / xu, 0.0)
-        yx, _ = self._apply(d1)
+        d2 = None
+        if self.w:  # :2482-2508
+            d2 = alpha * (b.zw + (b.zsw + v.sw * b.sw) / v.zsw - (b.ztw + v.tw * b.tw) / v.ztw)
+        yx, _ = self._apply(d1, d2)
         yz = self.ops.mdot(yx, self.Ac)
         yz = alpha * (b.z + (b.zs + v.s * b.s) / v.zs - (b.zt + v.t * b.t) / v.zt) - yz
         yz = self._gsolve(yz)
@@ -918,8 +931,14 @@ class InteriorPoint:
         y.t[:] = (alpha * b.zt - v.t * y.zt) / v.zt
         for i in range(self.c):
             d1 += yz[i] * self.Ac[i]
-        yx, _ = self._apply(d1)
+        yx, yw = self._apply(d1, d2)
         y.x[:] = yx
+        if self.w:  # :2557-2585
+            y.zw[:] = yw
+            y.zsw[:] = yw - alpha * b.sw
+            y.ztw[:] = -alpha * b.tw - yw
+            y.sw[:] = (alpha * b.zsw - v.sw * y.zsw) / v.zsw
+            y.tw[:] = (alpha * b.ztw - v.tw * y.ztw) / v.ztw
         y.zl[:] = np.where(L, (alpha * b.zl - v.zl * y.x) / xl, 0.0)
         y.zu[:] = np.where(U, (alpha * b.zu + v.zu * y.x) / xu, 0.0)
 
@@ -931,6 +950,11 @@ class InteriorPoint:
         qu = np.where(U, px / du, 0.0)
         ppos = beta * float(np.sum(np.where(L & (px > 0.0), ql, 0.0)) - np.sum(np.where(U & ~(px > 0.0), qu, 0.0)))
         pneg = beta * float(np.sum(np.where(L & ~(px > 0.0), ql, 0.0)) - np.sum(np.where(U & (px > 0.0), qu, 0.0)))
+        if self.w:  # :5711-5730
+            for val, pv in ((v.sw, p.sw), (v.tw, p.tw)):
+                q = pv / val
+                ppos += float(np.sum(q[pv > 0.0]))
+                pneg += float(np.sum(q[~(pv > 0.0)]))
         out = self.comm.allreduce([ppos, pneg])
         ppos, pneg = float(out[0]), float(out[1])
         for i in range(self.c):
@@ -942,6 +966,8 @@ class InteriorPoint:
         pmerit = self.ops.dot(self.g, p.x) - self.barrier_param * (ppos + pneg)
         for i in range(self.c):
             pmerit += self.gamma_s[i] * p.s[i] + self.gamma_t[i] * p.t[i]
+        if self.w:  # :5767
+            pmerit += self.ops.dot(self.gamma_sw, p.sw) + self.ops.dot(self.gamma_tw, p.tw)
         return pmerit
 
     def _smw_correct(self, v, p, scratch, use_qn):
@@ -957,7 +983,7 @@ class InteriorPoint:
             return scratch
         return None
 
-    def compute_kkt_gmres_step(self, v, r, p, rtol, atol, use_qn):  # :5796-6191 (w = 0)
+    def compute_kkt_gmres_step(self, v, r, p, rtol, atol, use_qn):  # :5796-6191
         m = self.opt["gmres_subspace_size"]
         if m <= 0:
             return 0
@@ -975,6 +1001,9 @@ class InteriorPoint:
             beta += self.ops.dot(r.zl, r.zl)
         if self.use_upper:
             beta += self.ops.dot(r.zu, r.zu)
+        if self.w:  # :5846-5852
+            for k in ("zw", "sw", "tw", "zsw", "ztw"):
+                beta += self.ops.dot(getattr(r, k), getattr(r, k))
         bnorm = math.sqrt(self.ops.dot(r.x, r.x) + beta)
         beta *= 1.0 / (bnorm * bnorm)
         cinfeas = float(np.sum((self.cvals - v.s + v.t) ** 2))
@@ -982,6 +1011,12 @@ class InteriorPoint:
         if cinfeas != 0.0:
             cinfeas = math.sqrt(cinfeas)
             cscale = 1.0 / cinfeas
+        cwinfeas, cwscale = 0.0, 0.0
+        if self.w:  # :5884-5890
+            cwinfeas = math.sqrt(self.ops.dot(r.zw, r.zw))
+            if cwinfeas != 0.0:
+                cwscale = 1.0 / cwinfeas
+        awproj = np.zeros(m)
         gres[0] = bnorm
         W[0] = r.x / gres[0]
         alpha[0] = 1.0
@@ -997,7 +1032,13 @@ class InteriorPoint:
             for j in range(c):
                 cj = self.ops.dot(self.Ac[j], p.x) - p.s[j] + p.t[j]
                 aproj[i] -= cscale * r.z[j] * cj
-            W[i + 1] = self.prob.hvec_product(v.x, v.z, p.x)
+            if self.w:  # :5963-5973
+                xt = np.zeros(self.n)
+                self.prob.add_sparse_jacobian_transpose(1.0, r.zw, xt)
+                awproj[i] = -cwscale * self.ops.dot(p.x, xt)
+                awproj[i] += cwscale * self.ops.dot(r.zw, p.sw)
+                awproj[i] -= cwscale * self.ops.dot(r.zw, p.tw)
+            W[i + 1] = self.prob.hvec_product(v.x, v.z, p.x, v.zw if self.w else None)
             self.nhvec += 1
             if self.qn is not None and use_qn:
                 self.qn.mult_add(-1.0, p.x, W[i + 1])
@@ -1032,8 +1073,8 @@ class InteriorPoint:
                 hp = (j + 1) * (j + 2) // 2 - 1
                 y[j] = y[j] / H[j + hp]
             fpr = float(np.dot(y[:niters], fproj[:niters]))
-            cpr = float(np.dot(y[:niters], aproj[:niters]))
-            constraint_descent = 1 if cpr <= -0.01 * cinfeas else 0
+            cpr = float(np.dot(y[:niters], aproj[:niters] + awproj[:niters]))
+            constraint_descent = 1 if cpr <= -0.01 * (cinfeas + cwinfeas) else 0
             if fpr < 0.0 or constraint_descent:
                 if abs(gres[i + 1]) < atol or abs(gres[i + 1]) < rtol * bnorm:
                     break
@@ -1050,7 +1091,7 @@ class InteriorPoint:
             gamma += gres[i] * alpha[i]
         gamma /= bnorm
         r.x[:] = W[0]
-        for k in ("z", "s", "t", "zs", "zt", "zl", "zu"):
+        for k in ("z", "s", "t", "zs", "zt", "zl", "zu") + (("zw", "sw", "tw", "zsw", "ztw") if self.w else ()):
             getattr(r, k)[...] *= gamma
         self.solve_kkt_diag_full(v, r, p)
         corr = self._smw_correct(v, p, scratch, use_qn)
@@ -1061,7 +1102,14 @@ class InteriorPoint:
         for i in range(c):
             deriv = self.ops.dot(self.Ac[i], p.x) - p.s[i] + p.t[i]
             cpr += cscale * (self.cvals[i] - v.s[i] + v.t[i]) * deriv
-        if fpr < 0.0 or cpr < -0.01 * cinfeas:
+        if self.w:  # :6163-6174 (both slack terms are SUBTRACTED here, unlike the loop above)
+            rzw = self.prob.eval_sparse_con(v.x) - v.sw + v.tw
+            xt = np.zeros(self.n)
+            self.prob.add_sparse_jacobian_transpose(1.0, rzw, xt)
+            cpr += cwscale * self.ops.dot(p.x, xt)
+            cpr -= cwscale * self.ops.dot(p.sw, rzw)
+            cpr -= cwscale * self.ops.dot(p.tw, rzw)
+        if fpr < 0.0 or cpr < -0.01 * (cinfeas + cwinfeas):
             return niters
         return -niters
 
@@ -1709,7 +1757,7 @@ class InteriorPoint:
                     diagonal_qn_step = 1
             elif o["use_diag_hessian"]:  # :4940-4948
                 use_qn = 0
-                self.hdiag = self.prob.hessian_diag(v.x, v.z)
+                self.hdiag = self.prob.hessian_diag(v.x, v.z, v.zw if self.w else None)
             mu_for_res = self.barrier_param
             if not inexact_newton_step and barrier_strategy in mehrotra_names:  # affine residual :4958-4964
                 mu_for_res = 0.0

@@ -478,8 +478,29 @@ class SepCsrProblem : public ParOptSparseProblem {
     }
     return fail;
   }
-  int evalHvecProduct(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *, ParOptVec *) { return 1; }
-  int evalHessianDiag(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *) { return 1; }
+  // Hessian of the Lagrangian f - z^T c - zw^T cw: the inner problem's part plus 2 zw_i on the diagonal
+  // entries of every chain constraint's variables
+  int evalHvecProduct(ParOptVec *x, ParOptScalar *z, ParOptVec *zwv, ParOptVec *pxv, ParOptVec *hv) {
+    int fail = inner->evalHvecProduct(x, z, zwv, pxv, hv);
+    double *zw, *px, *h;
+    zwv->getArray(&zw);
+    pxv->getArray(&px);
+    hv->getArray(&h);
+    for (int i = 0; i < nwcon; i++) {
+      for (int k = 0; k < span; k++) h[i * stride + k] += 2.0 * zw[i] * px[i * stride + k];
+    }
+    return fail;
+  }
+  int evalHessianDiag(ParOptVec *x, ParOptScalar *z, ParOptVec *zwv, ParOptVec *hv) {
+    int fail = inner->evalHessianDiag(x, z, zwv, hv);
+    double *zw, *h;
+    zwv->getArray(&zw);
+    hv->getArray(&h);
+    for (int i = 0; i < nwcon; i++) {
+      for (int k = 0; k < span; k++) h[i * stride + k] += 2.0 * zw[i];
+    }
+    return fail;
+  }
   void writeOutput(int iter, ParOptVec *x) { inner->writeOutput(iter, x); }
   SepProblem *inner;
   int span, stride, reverse;

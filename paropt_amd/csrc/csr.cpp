@@ -548,6 +548,10 @@ int CsrSparse::innerProduct(double alpha, const double *cvec, double *out) {
   return k_csr_inner(ctx, d_rowp, d_cols, vals, w, alpha, cvec, out);
 }
 
+int CsrSparse::colSum(double scale, const double *y, double *out) {
+  return k_csr_colsum(ctx, d_colp, d_rowsT, n, scale, y, out);
+}
+
 int CsrSparse::panelPermuted(const double *d, const double *const *P, int nv, double *const *U) {
   return k_csr_panel(ctx, d_rowp, d_cols, vals, w, d, P, nv, U, d_iperm);
 }

@@ -128,6 +128,23 @@ int k_csr_spmvT(Ctx *c, int group, const int *colp, const int *rowsT, const int 
   return PO_OK;
 }
 
+// out[j] = scale * sum_{rows i touching column j} y[i]   (pattern only)
+__global__ void __launch_bounds__(kBlock)
+    csr_colsum_kernel(const int *__restrict__ colp, const int *__restrict__ rowsT, int64_t n, double scale,
+                      const double *__restrict__ y, double *__restrict__ out) {
+  PO_C_LOOP(j, n) {
+    double acc = 0.0;
+    for (int p = colp[j]; p < colp[j + 1]; p++) acc += y[rowsT[p]];
+    out[j] = scale * acc;
+  }
+}
+int k_csr_colsum(Ctx *c, const int *colp, const int *rowsT, int64_t n, double scale, const double *y,
+                 double *out) {
+  if (n <= 0) return PO_OK;
+  PO_CLAUNCH(csr_colsum_kernel, cgrid(c, n), kBlock, colp, rowsT, n, scale, y, out);
+  return PO_OK;
+}
+
 // out_i += alpha * sum_q vals[q]^2 cvec[c_q]   (the diagonal of Aw diag(cvec) Aw^T)
 __global__ void __launch_bounds__(kBlock)
     csr_inner_kernel(const int *__restrict__ rowp, const int *__restrict__ cols, const double *__restrict__ vals,

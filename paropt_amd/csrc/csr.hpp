@@ -64,6 +64,7 @@ class CsrSparse {
   int spmv(double alpha, const double *px, double *out);     // out += alpha Aw px        (w)
   int spmvT(double alpha, const double *pzw, double *out);   // out += alpha Aw^T pzw     (n)
   int innerProduct(double alpha, const double *cvec, double *out);  // out_i += alpha sum_k a_ik^2 c_k
+  int colSum(double scale, const double *y, double *out);    // out_j = scale * sum of y over the rows touching j
   // U_j = Aw (d o P_j), rows in the factor's elimination order (only the Gram correction reads them)
   int panelPermuted(const double *d, const double *const *P, int nv, double *const *U);
   int factor(const double *dinv, const double *cdiag);       // S = diag(cdiag) + Aw diag(dinv) Aw^T = L L^T
@@ -101,6 +102,7 @@ int k_csr_spmv(Ctx *c, int group, const int *rowp, const int *cols, const double
                const double *x, const double *scale, double beta, const double *b, double *out, const int *outperm);
 int k_csr_spmvT(Ctx *c, int group, const int *colp, const int *rowsT, const int *srcT, const double *vals,
                 int64_t n, double alpha, const double *y, const double *bx, const double *dscale, double *out);
+int k_csr_colsum(Ctx *c, const int *colp, const int *rowsT, int64_t n, double scale, const double *y, double *out);
 int k_csr_inner(Ctx *c, const int *rowp, const int *cols, const double *vals, int64_t w, double alpha,
                 const double *cvec, double *out);
 int k_csr_panel(Ctx *c, const int *rowp, const int *cols, const double *vals, int64_t w, const double *d,

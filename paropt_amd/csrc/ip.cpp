@@ -319,7 +319,8 @@ InteriorPoint::InteriorPoint(Problem *p)
   has_w = false;
   nw_global = 0.0;
   gsw = gtw = Cw = wd2 = wyw = wtmp = wtmp2 = d1v = nullptr;
-  for (int i = 0; i < 5; i++) wvar[i] = wresv[i] = wstepv[i] = nullptr;
+  for (int i = 0; i < 5; i++) wvar[i] = wresv[i] = wstepv[i] = wscalev[i] = nullptr;
+  for (int i = 0; i < 10; i++) w_merit_last[i] = 0.0;
   for (int i = 0; i < 7; i++) w_sums[i] = 0.0;
   for (int i = 0; i < 5; i++) w_maxs[i] = 0.0;
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
@@ -367,6 +368,7 @@ InteriorPoint::~InteriorPoint() {
     vec_decref(wvar[i]);
     vec_decref(wresv[i]);
     vec_decref(wstepv[i]);
+    vec_decref(wscalev[i]);
   }
   for (Vec *v : Uw) vec_decref(v);
   for (Vec *v : gmresW) vec_decref(v);
@@ -1421,8 +1423,10 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const bool use_hvec_product = options.integer("use_hvec_product");
   const bool use_diag_hessian = options.integer("use_diag_hessian");
   if (has_w && use_hvec_product) {
-    set_error("use_hvec_product with sparse constraints is not implemented on the device path");
-    return PO_ERR_OPTION;
+    for (int i = 0; i < 5; i++) {
+      if (!wscalev[i]) wscalev[i] = vec_new(ctx, nw);
+      if (!wscalev[i]) return PO_ERR_HIP;
+    }
   }
   if (use_diag_hessian) PO_TRY(ensureHdiag());
   inexact_newton_step = false;

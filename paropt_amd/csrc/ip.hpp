@@ -157,6 +157,11 @@ class InteriorPoint {
   int solveKKTAlpha(const double *bx, double alpha, const Dense &b, double mu, bool use_qn, bool full,
                     double tau, Dense &out);
   int evalObjBarrierDeriv(const Dense &p, double *pmerit);
+  // sparse-constraint variants of the two above (ip_gmres.cpp); wscalev = alpha-scaled copy of the w residual
+  int solveKKTAlphaW(const double *bx, double alpha, const Dense &b, double mu, bool use_qn, bool full,
+                     double tau, Dense &out);
+  Vec *wscalev[5];
+  double w_merit_last[10];  // k_w_merit sums of the last evalObjBarrierDeriv (sparse part)
   int computeKKTGMRESStep(double rtol, double atol, bool use_qn, double tau, int *gmres_iters);
 
   // ---- sparse-constraint path (ip_w.cpp) ----

@@ -1703,7 +1703,7 @@ __global__ void __launch_bounds__(kBlock)
                double beta_mu, int64_t n, double *__restrict__ t) {
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 r = ld2(bx, q, n), dv = ld2(dinv, q, n);
+    const double2 r = ld2(bx, q, n), dv = dinv ? ld2(dinv, q, n) : make_double2(1.0, 1.0);  // null: raw d1
     double d0 = r.x, d1 = r.y;
     if (e0.L) d0 += alpha * (-(e0.xl * e0.zl - beta_mu)) / e0.xl;
     if (e0.U) d0 -= alpha * (-(e0.xu * e0.zu - beta_mu)) / e0.xu;

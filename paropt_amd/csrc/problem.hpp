@@ -114,6 +114,8 @@ class SeparableProblem : public Problem {
   //   cw_i = 1 - sum_{k<span} x[i*stride + k]^2,  i < (nlocal - span)/stride + 1, all inequalities
   int setChain(int span, int stride, int reverse_cols);
   int chain_span = 0, chain_stride = 0, chain_reverse = 0;
+  Vec *chain_tmp = nullptr;
+  int chainHessian(Vec *zw, Vec *px, Vec *h);
   int evalSparseCon(Vec *x, Vec *out) override;
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;

@@ -174,6 +174,7 @@ SeparableProblem::SeparableProblem(Ctx *c, int kind_, int64_t nglobal_, int ncon
 }
 
 SeparableProblem::~SeparableProblem() {
+  vec_decref(chain_tmp);
   vec_decref(q);
   vec_decref(b);
   for (Vec *v : A) vec_decref(v);
@@ -314,17 +315,33 @@ int SeparableProblem::sparseApplyK0(Vec *xv, Vec *d, Vec *cw, const double *bx, 
   PO_TRY(k_w_apply_mid(ctx, cw->d, bw, wwork->d, nwcon, yw->d));
   return k_group_apply(ctx, gmap, d->d, bx, -1.0, yw->d, nlocal, yx->d);
 }
-int SeparableProblem::evalHvecProduct(Vec *x, const double *z, Vec *, Vec *px, Vec *hvec) {
-  if (csr) return 1;  // the chain constraints are nonlinear; their Hessian is not provided
-  if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], px->d, nlocal, hvec->d) != PO_OK;
-  return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, px->d, nlocal,
-                    hvec->d) != PO_OK;
+// Hessian of the Lagrangian f - z^T c - zw^T cw.  The weighting constraints are linear; a chain constraint
+// cw_i = 1 - sum x^2 adds 2 zw_i on the diagonal entries of its variables.
+int SeparableProblem::chainHessian(Vec *zw, Vec *px, Vec *h) {
+  if (!csr || !zw) return PO_OK;
+  if (!chain_tmp) chain_tmp = vec_new(ctx, nlocal);
+  if (!chain_tmp) return PO_ERR_HIP;
+  PO_TRY(csr->colSum(2.0, zw->d, chain_tmp->d));
+  if (px) PO_TRY(k_mul(ctx, chain_tmp->d, 1.0, chain_tmp->d, px->d, nlocal));
+  return k_axpy(ctx, h->d, 1.0, chain_tmp->d, nlocal);
 }
-int SeparableProblem::evalHessianDiag(Vec *x, const double *z, Vec *, Vec *hdiag) {
-  if (csr) return 1;
-  if (kind == PO_PROBLEM_ROSENBROCK) return k_rosen_hess(ctx, x->d, z[0], nullptr, nlocal, hdiag->d) != PO_OK;
-  return k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, nullptr, nlocal,
-                    hdiag->d) != PO_OK;
+int SeparableProblem::evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) {
+  if (kind == PO_PROBLEM_ROSENBROCK) {
+    if (k_rosen_hess(ctx, x->d, z[0], px->d, nlocal, hvec->d) != PO_OK) return 1;
+  } else if (k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, px->d, nlocal,
+                        hvec->d) != PO_OK) {
+    return 1;
+  }
+  return chainHessian(zw, px, hvec) != PO_OK;
+}
+int SeparableProblem::evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) {
+  if (kind == PO_PROBLEM_ROSENBROCK) {
+    if (k_rosen_hess(ctx, x->d, z[0], nullptr, nlocal, hdiag->d) != PO_OK) return 1;
+  } else if (k_sep_hess(ctx, kind == PO_PROBLEM_QUADRATIC ? 0 : 1, q ? q->d : nullptr, b->d, x->d, nullptr,
+                        nlocal, hdiag->d) != PO_OK) {
+    return 1;
+  }
+  return chainHessian(zw, nullptr, hdiag) != PO_OK;
 }
 
 int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {

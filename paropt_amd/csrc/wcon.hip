@@ -318,6 +318,41 @@ int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const dou
   return reduce_finish(c, grid, 7, 0, 5, out);
 }
 
+// dst blocks = alpha * src blocks (the alpha-scaled right-hand side of solveKKTDiagSystem :2441-2614)
+__global__ void __launch_bounds__(kBlock) w_scale5_kernel(WVars dst, WVars src, double alpha, int64_t w) {
+  PO_W_LOOP(i, w) {
+    dst.zw[i] = alpha * src.zw[i];
+    dst.sw[i] = alpha * src.sw[i];
+    dst.tw[i] = alpha * src.tw[i];
+    dst.zsw[i] = alpha * src.zsw[i];
+    dst.ztw[i] = alpha * src.ztw[i];
+  }
+}
+int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t w) {
+  if (w <= 0) return PO_OK;
+  PO_WLAUNCH(w_scale5_kernel, wgrid(c, w), dst, src, alpha, w);
+  return PO_OK;
+}
+// sums of squares of the five residual blocks (the sparse part of |b| in computeKKTGMRESStep :5846-5852)
+__global__ void __launch_bounds__(kBlock) w_sumsq5_kernel(WVars r, int64_t w, double *__restrict__ partials) {
+  __shared__ double sm[4 * 5];
+  double s[5] = {0, 0, 0, 0, 0};
+  PO_W_LOOP(i, w) {
+    s[0] += r.zw[i] * r.zw[i];
+    s[1] += r.sw[i] * r.sw[i];
+    s[2] += r.tw[i] * r.tw[i];
+    s[3] += r.zsw[i] * r.zsw[i];
+    s[4] += r.ztw[i] * r.ztw[i];
+  }
+  w_block_reduce<5, 0>(s, partials, 0, sm);
+}
+int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]) {
+  const int grid = wgrid(c, w);
+  PO_TRY(ensure_partials(c, (size_t)grid * 5));
+  PO_WLAUNCH(w_sumsq5_kernel, grid, r, w, c->d_partials);
+  return reduce_finish(c, grid, 5, 0, 0, out);
+}
+
 // Cdiag = sw/zsw + tw/ztw (setUpKKTDiagSystem :1912-1927)
 __global__ void __launch_bounds__(kBlock) w_cdiag_kernel(WVars v, int64_t w, double *__restrict__ cd) {
   PO_W_LOOP(i, w) cd[i] = v.sw[i] / v.zsw[i] + v.tw[i] / v.ztw[i];

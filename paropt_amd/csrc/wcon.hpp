@@ -33,6 +33,8 @@ int k_recip(Ctx *c, double *y, int64_t n);
 
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
             int64_t w, double out[12]);
+int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t w);
+int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]);
 int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd);
 int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2);
 int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,

@@ -114,6 +114,9 @@ def test_ip_trajectory_golden(ctx, name):
     if "sr1" not in name and name not in GOLDEN_WINDOWS:
         np.testing.assert_array_equal(np.array(ip.getIterationCounters()), g["final/counters"])
         assert abs(ip.getObjective()[0] - g["final/fobj"][0]) <= 1e-6 * max(1.0, abs(g["final/fobj"][0]))
+        if "hvec" in name:  # total Hessian-vector products = total GMRES iterations (nhvc column)
+            rows = [ln.split() for ln in str(g["paropt_out"]).splitlines() if ln[:5].strip().isdigit()]
+            assert ip.getHvecCount() == int(rows[-1][3])
 
 
 KAT_CASES = ["ip_quadratic_n257_c3_bfgs", "ip_quadratic_n1000_c8_bfgs20", "ip_convex_n300_c5_bfgs",
