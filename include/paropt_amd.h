@@ -177,7 +177,10 @@ int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwi
 int po_problem_get_sparse_jacobian_data(po_problem p, const int **rowp, const int **cols, double **data,
                                         int64_t *nnz);
 /* ParOptQuasiDefMat (src/ParOptSparseMat.h:18-62) of any problem with sparse constraints, block or CSR form:
- * factor: c holds the diagonal C on entry (the block form leaves 1/(C + diag(Aw dinv Aw^T)) in it);
+ * factor: c holds the diagonal C on entry (the block form leaves 1/(C + diag(Aw dinv Aw^T)) in it); returns
+ * PO_ERR_NUMERIC when the sparse Cholesky met a non-positive pivot (D^-1 or C not positive) - inside the
+ * interior point the same event is counted, warned about once and survived, as the reference ignores
+ * LAPACK's info there (src/ParOptSparseCholesky.cpp:631);
  * apply: [D Aw^T; Aw -C] [yx; -yw] = [bx; bw] with the factor of the last po_quasidef_factor, bw may be
  * NULL (the three-argument apply :39).  bx must not alias yx. */
 int po_quasidef_factor(po_problem p, po_vec x, po_vec dinv, po_vec c);

@@ -192,7 +192,7 @@ class MMA:
             Ac = [a.copy() for a in self.A]
         return 0, g, Ac
 
-    def hessian_diag(self, xv, z):  # :967-1010
+    def hessian_diag(self, xv, z, zw=None):  # :967-1010
         Uinv, Linv = 1.0 / (self.U - xv), 1.0 / (xv - self.L)
         h = 2.0 * (Uinv**3 * self.p0 + Linv**3 * self.q0)
         if self.use_true_mma:
@@ -200,7 +200,7 @@ class MMA:
                 h += 2.0 * z[i] * (Uinv**3 * self.pi[i] + Linv**3 * self.qi[i])
         return h
 
-    def hvec_product(self, xv, z, px):  # :929-962 (objective part only, as the reference)
+    def hvec_product(self, xv, z, px, zw=None):  # :929-962 (objective part only, as the reference)
         Uinv, Linv = 1.0 / (self.U - xv), 1.0 / (xv - self.L)
         return 2.0 * (Uinv**3 * self.p0 + Linv**3 * self.q0) * px
 

@@ -402,7 +402,9 @@ int po_quasidef_factor(po_problem p, po_vec x, po_vec dinv, po_vec c) {
     po::set_error("po_quasidef_factor: the problem has no sparse constraints or the sizes do not match");
     return PO_ERR_ARG;
   }
-  return p->p->sparseFactor(x, dinv, c);
+  const long before = p->p->sparseFactorBreakdowns();
+  PO_TRY(p->p->sparseFactor(x, dinv, c));
+  return p->p->sparseFactorBreakdowns() != before ? PO_ERR_NUMERIC : PO_OK;  // the text is already set
 }
 int po_quasidef_apply(po_problem p, po_vec x, po_vec dinv, po_vec c, po_vec bx, po_vec bw, po_vec yx,
                       po_vec yw) {

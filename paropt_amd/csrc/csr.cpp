@@ -574,10 +574,33 @@ int CsrSparse::factor(const double *dinv, const double *cdiag) {
   PO_HIP(hipMemcpyAsync(flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
   PO_HIP(hipStreamSynchronize(ctx->stream));
   if (flag[0] != 0) {
-    // the reference's factor() reports the failure and the caller carries on (src/ParOptInteriorPoint.cpp:1930);
-    // a non-positive pivot here means S is not numerically SPD, which the algorithm cannot survive
-    set_error("sparse Cholesky: non-positive pivot in row %d of the permuted Schur complement", flag[1]);
-    return PO_ERR_NUMERIC;
+    // S is not numerically SPD: D^-1 or C has a non-positive entry (an indefinite diagonal Hessian, say).
+    // The reference ignores LAPACK's info in the same situation (ParOptSparseCholesky.cpp:631, and the return
+    // value of mat->factor at ParOptInteriorPoint.cpp:1930) and carries on with whatever the factor holds;
+    // here the offending pivots were replaced by 1 so the factor stays finite, the event is counted, the text
+    // is kept for po_last_error() and the interior point carries on too.  po_quasidef_factor reports it.
+    std::vector<double> hd((size_t)n), hc((size_t)w);
+    double dmin = 0.0, cmin = 0.0;
+    long bad = 0;
+    if (hipMemcpy(hd.data(), dinv, hd.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(hc.data(), cdiag, hc.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+      dmin = hd.empty() ? 0.0 : hd[0];
+      cmin = hc.empty() ? 0.0 : hc[0];
+      for (double v : hd) {
+        if (!(v == v) || v - v != 0.0) bad++;
+        if (v < dmin) dmin = v;
+      }
+      for (double v : hc) {
+        if (!(v == v) || v - v != 0.0) bad++;
+        if (v < cmin) cmin = v;
+      }
+    }
+    set_error("sparse Cholesky: non-positive pivot in row %d of the permuted Schur complement "
+              "(min D^-1 %.3e, min C %.3e, %ld non-finite inputs)", flag[1], dmin, cmin, bad);
+    if (breakdowns++ == 0 && ctx->rank == 0) {
+      fprintf(stderr, "ParOpt warning: sparse Cholesky breakdown, the quasi-definite matrix is not positive "
+                      "definite (min D^-1 %.3e, min C %.3e); continuing as the reference does\n", dmin, cmin);
+    }
   }
   return PO_OK;
 }

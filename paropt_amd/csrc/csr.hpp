@@ -79,6 +79,7 @@ class CsrSparse {
   Ctx *ctx;
   int64_t n, w, nnz;
   int nlevels_f = 0;
+  long breakdowns = 0;  // factorizations that met a non-positive pivot (see factor())
 
  private:
   int solveInPlace(double *const *Y, int nv, bool forward, bool backward);

@@ -62,6 +62,7 @@ class MMA : public Problem {
     return prob->sparseHalfSolve(U, nv, cw, weights);
   }
   const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
+  long sparseFactorBreakdowns() override { return prob->sparseFactorBreakdowns(); }
 
   Problem *prob;
   Options opts;

@@ -54,6 +54,8 @@ class Problem {
   virtual int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights);
   // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
   virtual const char *sparseFactorInfo() { return csr ? csr->factorInfo() : nullptr; }
+  // number of factorizations so far that met a non-positive pivot (CSR form; 0 otherwise)
+  virtual long sparseFactorBreakdowns() { return csr ? csr->breakdowns : 0; }
   // fixed CSR pattern of the sparse Jacobian (ParOptSparseProblem::setSparseJacobianData, .cpp:632-677);
   // owned.  Sets nwcon / nwinequality.
   int setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols);

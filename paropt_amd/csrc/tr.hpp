@@ -94,6 +94,7 @@ class TrustRegionSubproblem : public Problem {
     return prob->sparseHalfSolve(U, nv, cw, weights);
   }
   const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
+  long sparseFactorBreakdowns() override { return prob->sparseFactorBreakdowns(); }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
 
   Problem *prob;
@@ -174,6 +175,7 @@ class InfeasSubproblem : public Problem {  // :468-650
     return sub->sparseHalfSolve(U, nv, cw, weights);
   }
   const char *sparseFactorInfo() override { return sub->sparseFactorInfo(); }
+  long sparseFactorBreakdowns() override { return sub->sparseFactorBreakdowns(); }
   TrustRegionSubproblem *sub;
   int objective, constraint;
   double obj_scale;
