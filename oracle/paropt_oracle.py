@@ -646,10 +646,15 @@ class InteriorPoint:
                     self.gamma_s[i] = 0.0 if i < self.ninequality else gamma[i]
                     self.gamma_t[i] = gamma[i]
 
+    def _csr_form(self):
+        """The problem is a ParOptSparseProblem (general sparse S): the built-in chain constraints, or any
+        problem object that sets csr_form = True and provides sparse_jacobian_dense()."""
+        return bool(getattr(self.prob, "chain", None)) or bool(getattr(self.prob, "csr_form", False))
+
     # ---- quasi-definite block matrix (nwblock = 1): src/ParOptSparseMat.cpp:41-229 --------
     def _factor(self, v, Cdiag):
         """Cw = 1 / (Cdiag + Aw Dinv Aw^T) per constraint."""
-        if self.w and getattr(self.prob, "chain", None):
+        if self.w and self._csr_form():
             # ParOptQuasiDefSparseMat::factor (src/ParOptSparseMat.cpp:303-356): S = C + Aw D^-1 Aw^T, here
             # dense (the factorization is a direct solve; its sparsity is an implementation matter)
             Aw = self.prob.sparse_jacobian_dense()
@@ -667,7 +672,7 @@ class InteriorPoint:
             return yx, np.zeros(0)
         yw = np.zeros(self.w) if bw is None else bw.copy()
         self.prob.add_sparse_jacobian(-1.0, yx, yw)
-        if getattr(self.prob, "chain", None):  # :358-431
+        if self._csr_form():  # :358-431
             yw = sla.cho_solve(self._Schol, yw, check_finite=False)
         else:
             yw = yw * self.Cw

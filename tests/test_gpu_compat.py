@@ -269,3 +269,98 @@ def test_sparse_rosenbrock_csr_form():
     np.testing.assert_allclose(z, g["final/z"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(x[:], g["final/x"], rtol=0, atol=1e-6)
     assert len(zw) == n - 1
+
+
+def test_electron_style_sparse_equalities_csr():
+    """The shape of the reference's examples/COPS/electron/electron.py: NO dense constraint, one sparse EQUALITY
+    per electron (x_i^2 + y_i^2 + z_i^2 = 1, num_sparse_inequalities = 0) declared through rowp / cols with the
+    reference's keyword names, a dense (non-separable) objective, least-squares multiplier start and damped BFGS.
+    Checked against the numpy oracle (dense S) on the same data."""
+    from oracle import paropt_oracle as po
+    from paropt_amd import ParOpt
+
+    ne = 8
+    n = 3 * ne
+    rng = np.random.RandomState(0)
+    alpha, beta = rng.uniform(0.0, 2 * np.pi, ne), rng.uniform(-np.pi, np.pi, ne)
+    x0 = np.concatenate([np.cos(beta) * np.cos(alpha), np.cos(beta) * np.sin(alpha), np.sin(beta)])
+    rowp = [3 * i for i in range(ne + 1)]
+    cols = [j for i in range(ne) for j in (i, ne + i, 2 * ne + i)]
+
+    def fobj_grad(x):
+        P = x.reshape(3, ne)
+        d = P[:, :, None] - P[:, None, :]
+        dsq = np.sum(d * d, axis=0) + np.eye(ne)
+        iu = np.triu_indices(ne, 1)
+        f = float(np.sum(dsq[iu] ** -0.5))
+        fact = dsq ** -1.5
+        np.fill_diagonal(fact, 0.0)
+        g = -np.sum(d * fact[None, :, :], axis=2)
+        return f, g.reshape(-1)
+
+    class Electron(ParOpt.Problem):
+        def __init__(self):
+            super(Electron, self).__init__(None, nvars=n, num_sparse_constraints=ne, num_sparse_inequalities=0,
+                                           rowp=rowp, cols=cols)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = x0
+            lb[:] = -10.0
+            ub[:] = 10.0
+
+        def evalSparseObjCon(self, x, sparse_cons):
+            xa = np.array(x[:])
+            sparse_cons[:] = 1.0 - np.sum(xa.reshape(3, ne) ** 2, axis=0)
+            return 0, fobj_grad(xa)[0], []
+
+        def evalSparseObjConGradient(self, x, g, A, data):
+            xa = np.array(x[:])
+            g[:] = fobj_grad(xa)[1]
+            data[:] = (-2.0 * xa.reshape(3, ne)).T.reshape(-1)
+            return 0
+
+    class OracleElectron:
+        comm = po.SelfComm()
+        nlocal, c, nwcon, nwineq, csr_form = n, 0, ne, 0, True
+
+        def vars_and_bounds(self):
+            return x0.copy(), np.full(n, -10.0), np.full(n, 10.0)
+
+        def eval_obj_con(self, x):
+            self._cw = 1.0 - np.sum(x.reshape(3, ne) ** 2, axis=0)
+            return 0, fobj_grad(x)[0], np.zeros(0)
+
+        def eval_obj_con_gradient(self, x):
+            self._A = np.zeros((ne, n))
+            for i in range(ne):
+                self._A[i, [i, ne + i, 2 * ne + i]] = -2.0 * x[[i, ne + i, 2 * ne + i]]
+            return 0, fobj_grad(x)[1], []
+
+        def eval_sparse_con(self, x):
+            return self._cw.copy()
+
+        def sparse_jacobian_dense(self):
+            return self._A
+
+        def add_sparse_jacobian(self, alpha, px, out):
+            out += alpha * (self._A @ px)
+            return out
+
+        def add_sparse_jacobian_transpose(self, alpha, pzw, out):
+            out += alpha * (self._A.T @ pzw)
+            return out
+
+    opts = {"norm_type": "infinity", "qn_type": "bfgs", "qn_subspace_size": 10,
+            "starting_point_strategy": "least_squares_multipliers", "qn_update_type": "damped_update",
+            "abs_res_tol": 1e-6, "barrier_strategy": "monotone", "armijo_constant": 1e-5, "penalty_gamma": 100.0,
+            "max_major_iters": 200}
+    opt = ParOpt.Optimizer(Electron(), dict(opts, algorithm="ip", output_file=None))
+    opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+    oip = po.InteriorPoint(OracleElectron(), dict(opts))
+    oip.optimize()
+    assert opt.ip.getIterationCounters() == (oip.niter, oip.neval, oip.ngeval)
+    xa = np.array(x[:])
+    np.testing.assert_allclose(np.sum(xa.reshape(3, ne) ** 2, axis=0), 1.0, atol=1e-6)  # on the sphere
+    np.testing.assert_allclose(xa, oip.vars.x, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.array(zw[:]), oip.vars.zw, rtol=0, atol=1e-5 * max(1.0, np.abs(oip.vars.zw).max()))
