@@ -191,16 +191,20 @@ const char *po_quasidef_factor_info(po_problem p);
  * tested) without a device: column-sorted pattern, pattern of S = Aw Aw^T, nested-dissection ordering,
  * elimination tree, pattern of L (CSR, diagonal last in each row) and the dependency level sets the device
  * factorization and solves are scheduled by.  No context needed.
- * info = {nnz(Aw), nnz(lower S), nnz(L), dependency levels, 1 if `cols` was already sorted}. */
+ * info = {nnz(Aw), nnz(lower S), nnz(L), dependency levels, 1 if `cols` was already sorted, number of fronts,
+ * rows of the largest front}. */
 typedef struct po_csr_symbolic_s *po_csr_symbolic;
 int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const int *cols, po_csr_symbolic *out);
-int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[5]);
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[7]);
 /* borrowed host arrays: perm[new] = old (nwcon), parent (nwcon), Lrowp (nwcon+1), Lcols (nnz(L)), level_ptr
- * (levels+1): rows are numbered level by level, level l is the rows level_ptr[l] .. level_ptr[l+1]-1, processed
- * in ascending order by the factorization and the forward solve and in descending order by the backward
- * solve; any output pointer may be NULL */
+ * (levels+1), front_of (nwcon).  Rows are numbered level by level; level l is the rows level_ptr[l] ..
+ * level_ptr[l+1]-1, processed in ascending order by the factorization and the forward solve and in descending
+ * order by the backward solve.  Inside a level come first the ordinary rows (front_of = -1), which depend on
+ * earlier levels only, then its FRONTS: dense separator cliques whose rows are contiguous, front_of = first row
+ * of the front, row f0 + r ending with the columns f0 .. f0 + r (the part left of f0 depends on earlier levels
+ * only; the triangle inside is factored / solved by one workgroup).  Any output pointer may be NULL. */
 int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
-                           const int **Lcols, const int **level_ptr);
+                           const int **Lcols, const int **level_ptr, const int **front_of);
 int po_csr_symbolic_destroy(po_csr_symbolic h);
 /* Second-order information (src/ParOptProblem.h:160-189) for use_hvec_product / use_diag_hessian:
  * evalHvecProduct: hvec = H(x, z, zw) px ; evalHessianDiag: hdiag = diag H(x, z, zw), with H the

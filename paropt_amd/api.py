@@ -496,11 +496,12 @@ class CsrSymbolic:
         check(lib.po_csr_symbolic_create(int(nvars), w, rowp.ctypes.data_as(L.c_int_p),
                                          cols.ctypes.data_as(L.c_int_p), C.byref(h)))
         try:
-            info = (C.c_int64 * 5)()
+            info = (C.c_int64 * 7)()
             check(lib.po_csr_symbolic_info(h, info))
             self.nnz, self.nnzS, self.nnzL, self.nlevels = (int(v) for v in info[:4])
             self.sorted_input = bool(info[4])
-            ptrs = [L.c_int_p() for _ in range(5)]
+            self.nfronts, self.max_front = int(info[5]), int(info[6])
+            ptrs = [L.c_int_p() for _ in range(6)]
             check(lib.po_csr_symbolic_arrays(h, *[C.byref(p) for p in ptrs]))
 
             def arr(p, n):
@@ -509,6 +510,7 @@ class CsrSymbolic:
             self.perm, self.parent = arr(ptrs[0], w), arr(ptrs[1], w)
             self.Lrowp, self.Lcols = arr(ptrs[2], w + 1), arr(ptrs[3], self.nnzL)
             self.level_ptr = arr(ptrs[4], self.nlevels + 1)
+            self.front_of = arr(ptrs[5], w)
         finally:
             lib.po_csr_symbolic_destroy(h)
 

@@ -447,7 +447,7 @@ int po_csr_symbolic_create(int64_t nvars, int64_t nwcon, const int *rowp, const 
   *out = h;
   return PO_OK;
 }
-int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[5]) {
+int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[7]) {
   PO_CHECK_PTR(h);
   PO_CHECK_PTR(info);
   info[0] = h->s.nnz;
@@ -455,16 +455,19 @@ int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[5]) {
   info[2] = h->s.nnzL;
   info[3] = (int64_t)h->s.fwd_ptr.size() - 1;
   info[4] = h->s.identity_src ? 1 : 0;
+  info[5] = (int64_t)h->s.front_start.size();
+  info[6] = h->s.max_front;
   return PO_OK;
 }
 int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
-                           const int **Lcols, const int **level_ptr) {
+                           const int **Lcols, const int **level_ptr, const int **front_of) {
   PO_CHECK_PTR(h);
   if (perm) *perm = h->s.perm.data();
   if (parent) *parent = h->s.parent.data();
   if (Lrowp) *Lrowp = h->s.Lrowp.data();
   if (Lcols) *Lcols = h->s.Lcols.data();
   if (level_ptr) *level_ptr = h->s.fwd_ptr.data();
+  if (front_of) *front_of = h->s.front_of.data();
   return PO_OK;
 }
 int po_csr_symbolic_destroy(po_csr_symbolic h) {

@@ -13,6 +13,13 @@ namespace po {
 
 namespace {
 
+constexpr int kFrontMin = 16;  // shortest chain scheduled as a front
+
+int internal_error(const char *what) {
+  set_error("internal: sparse Cholesky analysis: %s", what);
+  return PO_ERR_ARG;
+}
+
 // subsets this small are numbered as they come (PAROPT_AMD_ND_LEAF overrides, for experiments)
 static int leaf_size() {
   static int v = 0;
@@ -147,7 +154,21 @@ struct Dissector {
 
 }  // namespace
 
-int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrSymbolic *out) {
+static int csr_analyse_impl(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrSymbolic *out,
+                            bool allow_fronts);
+
+int csr_analyse(int64_t n, int64_t w, const int *rowp, const int *cols, CsrSymbolic *out) {
+  const char *e = getenv("PAROPT_AMD_NO_FRONTS");
+  int rc = csr_analyse_impl(n, w, rowp, cols, out, !(e && atoi(e) > 0));
+  if (rc == PO_ERR_NUMERIC) {  // a chain that is not a dense front after all: schedule row by row
+    *out = CsrSymbolic();
+    rc = csr_analyse_impl(n, w, rowp, cols, out, false);
+  }
+  return rc;
+}
+
+static int csr_analyse_impl(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrSymbolic *out,
+                            bool allow_fronts) {
   CsrSymbolic &s = *out;
   if (w64 < 0 || n64 < 0 || w64 > 2000000000LL || n64 > 2000000000LL) {
     set_error("sparse Jacobian: sizes out of range (nwcon %lld, nvars %lld)", (long long)w64, (long long)n64);
@@ -296,15 +317,71 @@ int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrS
     set_error("internal: ordering is not a permutation");
     return PO_ERR_ARG;
   }
-  std::vector<int> lev;
+  // Fronts.  A separator of the dissection is a clique, i.e. a chain j -> j+1 -> ... of the tree whose
+  // columns have nested structures (a fundamental supernode): row by row it would cost one level per
+  // vertex.  Chains of at least kFrontMin rows become FRONTS: one scheduling unit whose rows are numbered
+  // consecutively; the part of those rows left of the front is computed for all rows at once, the dense
+  // lower triangle inside the front (the tails of the rows) by one workgroup.  Levels are heights in the
+  // tree of units.
+  std::vector<int> lev(w, 0), front_of(w, -1);
   {
     etree(s.perm, s.iperm, s.parent);
-    const int nlev = levels_of(s.parent, lev);
-    std::vector<int> start((size_t)nlev + 1, 0), byLevel(w);
-    for (int i = 0; i < w; i++) start[lev[i] + 1]++;
-    for (int l = 0; l < nlev; l++) start[l + 1] += start[l];
-    for (int i = 0; i < w; i++) byLevel[start[lev[i]]++] = s.perm[i];
+    const std::vector<int> &parent = s.parent;
+    std::vector<int> colcount(w, 1), nchild(w, 0), head(w);
+    {
+      std::vector<int> mark(w, -1);
+      for (int i = 0; i < w; i++) {
+        const int old = s.perm[i];
+        mark[i] = i;
+        for (int p = adjp[old]; p < adjp[old + 1]; p++) {
+          int j = s.iperm[adj[p]];
+          if (j >= i) continue;
+          while (mark[j] != i) {
+            colcount[j]++;
+            mark[j] = i;
+            j = parent[j];
+          }
+        }
+      }
+    }
+    for (int i = 0; i < w; i++) {
+      if (parent[i] >= 0) nchild[parent[i]]++;
+    }
+    std::iota(head.begin(), head.end(), 0);
+    if (allow_fronts) {
+      for (int j = 0; j + 1 < w; j++) {
+        if (parent[j] == j + 1 && nchild[j + 1] == 1 && colcount[j] == colcount[j + 1] + 1) head[j + 1] = head[j];
+      }
+    }
+    std::vector<int> fsize(w, 0), ulev(w, 0);
+    for (int i = 0; i < w; i++) fsize[head[i]]++;
+    auto unit = [&](int i) { return fsize[head[i]] >= kFrontMin ? head[i] : i; };
+    int nlev = w > 0 ? 1 : 0;
+    for (int i = 0; i < w; i++) {
+      const int u = unit(i), p = parent[i];
+      if (ulev[u] + 1 > nlev) nlev = ulev[u] + 1;
+      if (p >= 0) {
+        const int up = unit(p);
+        if (up != u && ulev[up] < ulev[u] + 1) ulev[up] = ulev[u] + 1;
+      }
+    }
+    // bucket (level, ordinary | front), rows ascending inside a bucket: a front stays contiguous
+    std::vector<int> start((size_t)2 * nlev + 1, 0), byLevel(w), newlev(w), newfront(w, -1);
+    for (int i = 0; i < w; i++) start[2 * ulev[unit(i)] + (fsize[head[i]] >= kFrontMin ? 1 : 0) + 1]++;
+    for (int b = 0; b < 2 * nlev; b++) start[b + 1] += start[b];
+    std::vector<int> newpos(w);
+    for (int i = 0; i < w; i++) {
+      const int u = unit(i);
+      const bool in_front = fsize[head[i]] >= kFrontMin;
+      const int pos = start[2 * ulev[u] + (in_front ? 1 : 0)]++;
+      newpos[i] = pos;
+      byLevel[pos] = s.perm[i];
+      newlev[pos] = ulev[u];
+      if (in_front) newfront[pos] = newpos[head[i]];
+    }
     s.perm.swap(byLevel);
+    lev.swap(newlev);
+    front_of.swap(newfront);
     invert(s.perm, s.iperm);
   }
   etree(s.perm, s.iperm, s.parent);
@@ -394,27 +471,58 @@ int csr_analyse(int64_t n64, int64_t w64, const int *rowp, const int *cols, CsrS
     s.ent_b.swap(tb);
     s.ent_slot.swap(ts);
   }
-  // dependency levels: a row needs every row in its pattern, all of them descendants in the tree.  The same
-  // sets in DESCENDING order schedule the backward solve (x_i needs x_j for the ancestors j in column i).
+  // Levels.  An ordinary row needs every row in its pattern, all of them in earlier levels; the rows of a
+  // front need earlier levels for the columns left of the front and each other inside it.  The same sets in
+  // DESCENDING order schedule the backward solve (x_i needs x_j for the ancestors j in column i).
   {
-    const int nlev = levels_of(s.parent, lev);
+    int nlev = 0;
+    for (int i = 0; i < w; i++) nlev = std::max(nlev, lev[i] + 1);
     s.fwd_ptr.assign((size_t)nlev + 1, 0);
     for (int i = 0; i < w; i++) s.fwd_ptr[lev[i] + 1]++;
     for (int l = 0; l < nlev; l++) s.fwd_ptr[l + 1] += s.fwd_ptr[l];
     s.fwd_order.resize(w);
-    std::vector<int> fill(s.fwd_ptr.begin(), s.fwd_ptr.end() - 1);
-    for (int i = 0; i < w; i++) s.fwd_order[fill[lev[i]]++] = i;
+    std::iota(s.fwd_order.begin(), s.fwd_order.end(), 0);
     s.fwd_maxlen.assign(nlev, 0);
     s.bwd_maxlen.assign(nlev, 0);
-    for (int i = 0; i < w; i++) {
-      s.fwd_maxlen[lev[i]] = std::max(s.fwd_maxlen[lev[i]], s.Lrowp[i + 1] - s.Lrowp[i]);
-      s.bwd_maxlen[lev[i]] = std::max(s.bwd_maxlen[lev[i]], s.Ltp[i + 1] - s.Ltp[i]);
-    }
-    for (int i = 0; i < w; i++) {
-      if (s.fwd_order[i] != i) {
-        set_error("internal: rows are not numbered level by level");
-        return PO_ERR_ARG;
+    s.ord_end.assign(nlev, 0);
+    s.front_ptr.assign((size_t)nlev + 1, 0);
+    s.front_maxdesc.assign(nlev, 0);
+    s.front_start.clear();
+    s.front_size.clear();
+    s.front_of = front_of;
+    for (int l = 0; l < nlev; l++) {
+      int i = s.fwd_ptr[l];
+      const int e = s.fwd_ptr[l + 1];
+      while (i < e && front_of[i] < 0) {
+        if (lev[i] != l) return internal_error("rows are not numbered level by level");
+        s.fwd_maxlen[l] = std::max(s.fwd_maxlen[l], s.Lrowp[i + 1] - s.Lrowp[i]);
+        s.bwd_maxlen[l] = std::max(s.bwd_maxlen[l], s.Ltp[i + 1] - s.Ltp[i]);
+        for (int p = s.Lrowp[i]; p < s.Lrowp[i + 1] - 1; p++) {
+          if (lev[s.Lcols[p]] >= l) return internal_error("a row depends on a row of its own level");
+        }
+        i++;
       }
+      s.ord_end[l] = i;
+      while (i < e) {
+        const int f0 = i;
+        if (front_of[i] != f0) return internal_error("front rows are not contiguous");
+        int sz = 0;
+        while (i < e && front_of[i] == f0) {
+          // the tail of row f0 + sz must be exactly the columns f0 .. f0 + sz
+          const int len = s.Lrowp[i + 1] - s.Lrowp[i];
+          if (lev[i] != l || len < sz + 1 || s.Lcols[s.Lrowp[i + 1] - 1 - sz] != f0) return PO_ERR_NUMERIC;
+          for (int p = s.Lrowp[i]; p < s.Lrowp[i + 1] - 1 - sz; p++) {
+            if (lev[s.Lcols[p]] >= l) return internal_error("a front depends on a row of its own level");
+          }
+          s.front_maxdesc[l] = std::max(s.front_maxdesc[l], len - sz - 1);
+          sz++;
+          i++;
+        }
+        s.front_start.push_back(f0);
+        s.front_size.push_back(sz);
+        s.max_front = std::max(s.max_front, sz);
+      }
+      s.front_ptr[l + 1] = (int)s.front_start.size();
     }
   }
   return PO_OK;
@@ -461,6 +569,10 @@ CsrSparse::~CsrSparse() {
   dfree(d_ent_b);
   dfree(d_ent_slot);
   dfree(d_fwd);
+  dfree(d_front_of);
+  dfree(d_front_end);
+  dfree(d_fstart);
+  dfree(d_fsize);
   dfree(Lvals);
   dfree(ones);
   dfree(wwork);
@@ -510,6 +622,16 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   PO_TRY(upload(d_ent_b, sym.ent_b));
   PO_TRY(upload(d_ent_slot, sym.ent_slot));
   PO_TRY(upload(d_fwd, sym.fwd_order));
+  {
+    std::vector<int> front_end(sym.front_of.size(), -1);
+    for (size_t f = 0; f < sym.front_start.size(); f++) {
+      for (int r = 0; r < sym.front_size[f]; r++) front_end[sym.front_start[f] + r] = sym.front_start[f] + sym.front_size[f];
+    }
+    PO_TRY(upload(d_front_of, sym.front_of));
+    PO_TRY(upload(d_front_end, front_end));
+    PO_TRY(upload(d_fstart, sym.front_start));
+    PO_TRY(upload(d_fsize, sym.front_size));
+  }
   dfree(Lvals);
   dfree(ones);
   dfree(wwork);
@@ -568,7 +690,11 @@ int CsrSparse::factor(const double *dinv, const double *cdiag) {
                         (int64_t)sym.ent_slot.size(), Lvals));
   for (int l = 0; l < nlevels_f; l++) {
     const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
-    PO_TRY(k_chol_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, d_flag, thinLevel(sym.fwd_maxlen[l], e - b)));
+    const int oe = sym.ord_end[l], f0 = sym.front_ptr[l], nf = sym.front_ptr[l + 1] - f0;
+    PO_TRY(k_chol_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, oe - b, d_flag,
+                        thinLevel(sym.fwd_maxlen[l], oe - b)));
+    PO_TRY(k_chol_fronts(ctx, d_Lrowp, d_Lcols, Lvals, oe, e - oe, d_front_of, d_fstart + f0, d_fsize + f0, nf,
+                         sym.front_maxdesc[l], d_flag));
   }
   int flag[4] = {0, 0, 0, 0};
   PO_HIP(hipMemcpyAsync(flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
@@ -610,15 +736,21 @@ int CsrSparse::solveInPlace(double *const *Y, int nv, bool forward, bool backwar
   if (forward) {
     for (int l = 0; l < nlevels_f; l++) {
       const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
-      PO_TRY(k_trsv_fwd_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, e - b, Y, nv,
-                              thinLevel(sym.fwd_maxlen[l], (int64_t)(e - b) * nv)));
+      const int oe = sym.ord_end[l], f0 = sym.front_ptr[l], nf = sym.front_ptr[l + 1] - f0;
+      PO_TRY(k_trsv_fwd_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, oe - b, Y, nv,
+                              thinLevel(sym.fwd_maxlen[l], (int64_t)(oe - b) * nv)));
+      PO_TRY(k_trsv_fronts_fwd(ctx, d_Lrowp, d_Lcols, Lvals, oe, e - oe, d_front_of, d_fstart + f0, d_fsize + f0,
+                               nf, Y, nv));
     }
   }
   if (backward) {
     for (int l = nlevels_f - 1; l >= 0; l--) {
       const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
-      PO_TRY(k_trsv_bwd_level(ctx, d_Lrowp, d_Ltp, d_Ltrows, d_Ltsrc, Lvals, d_fwd + b, e - b, Y, nv,
-                              thinLevel(sym.bwd_maxlen[l], (int64_t)(e - b) * nv)));
+      const int oe = sym.ord_end[l], f0 = sym.front_ptr[l], nf = sym.front_ptr[l + 1] - f0;
+      PO_TRY(k_trsv_fronts_bwd(ctx, d_Lrowp, d_Ltp, d_Ltrows, d_Ltsrc, Lvals, oe, e - oe, d_front_of, d_front_end,
+                               d_fstart + f0, d_fsize + f0, nf, Y, nv));
+      PO_TRY(k_trsv_bwd_level(ctx, d_Lrowp, d_Ltp, d_Ltrows, d_Ltsrc, Lvals, d_fwd + b, oe - b, Y, nv,
+                              thinLevel(sym.bwd_maxlen[l], (int64_t)(oe - b) * nv)));
     }
   }
   return PO_OK;

@@ -380,6 +380,230 @@ int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, cons
   return PO_OK;
 }
 
+// ---- fronts: dense separator cliques (csr.hpp) ----------------------------------------------------------
+// Row f0 + r of a front ends with the columns f0 .. f0 + r: T(r, q) = Lvals[Lrowp[f0 + r + 1] - 1 - r + q].
+// Step 1 (all rows of all fronts of a level at once): the entries LEFT of the front, the recurrence of
+// chol_level_kernel stopped at column f0.
+// The columns of row i left of the front are staged in LDS (when they fit in `cap` ints) so that the binary
+// searches never leave the CU.
+__device__ __forceinline__ int front_search(const int *__restrict__ Lcols, const int *scol, bool cached, int p0,
+                                            int lo, int hi, int k) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const int cm = cached ? scol[mid - p0] : Lcols[mid];
+    if (cm < k) {
+      lo = mid + 1;
+    } else {
+      hi = mid;
+    }
+  }
+  return lo;
+}
+__global__ void __launch_bounds__(64)
+    chol_front_rows_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals, int row0,
+                           const int *__restrict__ front_of, int cap) {
+  extern __shared__ int scol[];
+  const int i = row0 + blockIdx.x;
+  const int lane = threadIdx.x;
+  const int f0 = front_of[i];
+  const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - f0);
+  const bool cached = pe - p0 <= cap;
+  if (cached) {
+    for (int q = p0 + lane; q < pe; q += 64) scol[q - p0] = Lcols[q];
+  }
+  __syncthreads();
+  for (int p = p0; p < pe; p++) {
+    double acc = 0.0;
+    const int j = cached ? scol[p - p0] : Lcols[p];
+    const int r0 = Lrowp[j], rd = Lrowp[j + 1] - 1;
+    for (int q = r0 + lane; q < rd; q += 64) {
+      const int k = Lcols[q];
+      const int lo = front_search(Lcols, scol, cached, p0, p0, p, k);
+      if (lo < p && (cached ? scol[lo - p0] : Lcols[lo]) == k) acc += Lvals[q] * Lvals[lo];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) Lvals[p] = (Lvals[p] - acc) / Lvals[rd];
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+// Step 2: T(i, j) -= sum over the columns left of the front of L_ik L_jk, one wavefront per pair, four
+// wavefronts share a row i.
+__global__ void __launch_bounds__(kBlock)
+    chol_front_syrk_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals, int row0,
+                           const int *__restrict__ front_of, int cap) {
+  extern __shared__ int scol[];
+  const int i = row0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f0 = front_of[i];
+  const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - f0);
+  const bool cached = pe - p0 <= cap;
+  if (cached) {
+    for (int q = p0 + (int)threadIdx.x; q < pe; q += kBlock) scol[q - p0] = Lcols[q];
+  }
+  __syncthreads();
+  for (int j = f0 + wave; j <= i; j += 4) {
+    const int r0 = Lrowp[j], re = Lrowp[j + 1] - 1 - (j - f0);
+    double acc = 0.0;
+    for (int q = r0 + lane; q < re; q += 64) {
+      const int k = Lcols[q];
+      const int lo = front_search(Lcols, scol, cached, p0, p0, pe, k);
+      if (lo < pe && (cached ? scol[lo - p0] : Lcols[lo]) == k) acc += Lvals[q] * Lvals[lo];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) Lvals[pe + (j - f0)] -= acc;
+  }
+}
+// Step 3: dense right-looking Cholesky of the triangle, one workgroup of 1024 per front.
+constexpr int kFrontThreads = 1024;
+__global__ void __launch_bounds__(kFrontThreads)
+    chol_front_dense_kernel(const int *__restrict__ Lrowp, double *Lvals, const int *__restrict__ fstart,
+                            const int *__restrict__ fsize, int *flag) {
+  const int f0 = fstart[blockIdx.x], s = fsize[blockIdx.x];
+  const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+#define PO_T(r, q) Lvals[Lrowp[f0 + (r) + 1] - 1 - (r) + (q)]
+  for (int k = 0; k < s; k++) {
+    if (tid == 0) {
+      double a = PO_T(k, k);
+      if (!(a > 0.0)) {
+        flag[0] = 1;
+        flag[1] = f0 + k;
+        a = 1.0;
+      }
+      PO_T(k, k) = sqrt(a);
+    }
+    __threadfence_block();
+    __syncthreads();
+    const double d = PO_T(k, k);
+    for (int r = k + 1 + tid; r < s; r += kFrontThreads) PO_T(r, k) /= d;
+    __threadfence_block();
+    __syncthreads();
+    for (int r = k + 1 + ty; r < s; r += 32) {
+      const int base = Lrowp[f0 + r + 1] - 1 - r;
+      const double lrk = Lvals[base + k];
+      for (int q = k + 1 + tx; q <= r; q += 32) Lvals[base + q] -= lrk * PO_T(q, k);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+int k_chol_fronts(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, int row0, int nrows,
+                  const int *front_of, const int *fstart, const int *fsize, int nfronts, int maxdesc, int *flag) {
+  if (nrows <= 0 || nfronts <= 0) return PO_OK;
+  const int cap = maxdesc < 12288 ? (maxdesc > 0 ? maxdesc : 1) : 12288;  // ints of LDS per workgroup (<= 48 KB)
+  hipLaunchKernelGGL(chol_front_rows_kernel, dim3(nrows), dim3(64), cap * sizeof(int), c->stream, Lrowp, Lcols,
+                     Lvals, row0, front_of, cap);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  hipLaunchKernelGGL(chol_front_syrk_kernel, dim3(nrows), dim3(kBlock), cap * sizeof(int), c->stream, Lrowp, Lcols,
+                     Lvals, row0, front_of, cap);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  PO_CLAUNCH(chol_front_dense_kernel, nfronts, kFrontThreads, Lrowp, Lvals, fstart, fsize, flag);
+  return PO_OK;
+}
+
+// Solves on a front.  Forward: first y_i -= sum over the columns left of the front (all rows at once), then the
+// dense forward substitution by one workgroup.  Backward: first y_i -= sum over the rows BELOW the front in
+// column i (the ancestors, through the column storage), then the dense backward substitution.
+__global__ void __launch_bounds__(kBlock)
+    trsv_front_fwd_rows_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols,
+                               const double *__restrict__ Lvals, int row0, const int *__restrict__ front_of,
+                               PtrTableW Y, int nv) {
+  const int i = row0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - front_of[i]);
+  for (int r = wave; r < nv; r += 4) {
+    double *y = Y.p[r];
+    double acc = 0.0;
+    for (int q = p0 + lane; q < pe; q += 64) acc += Lvals[q] * y[Lcols[q]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[i] -= acc;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+    trsv_front_bwd_cols_kernel(const int *__restrict__ Ltp, const int *__restrict__ Ltrows,
+                               const int *__restrict__ Ltsrc, const double *__restrict__ Lvals, int row0,
+                               const int *__restrict__ front_of, const int *__restrict__ front_end, PtrTableW Y,
+                               int nv) {
+  const int i = row0 + blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the first entries of column i are the rows of the front below i
+  const int q0 = Ltp[i] + (front_end[i] - 1 - i), q1 = Ltp[i + 1];
+  for (int r = wave; r < nv; r += 4) {
+    double *y = Y.p[r];
+    double acc = 0.0;
+    for (int q = q0 + lane; q < q1; q += 64) acc += Lvals[Ltsrc[q]] * y[Ltrows[q]];
+    acc = wave_sum(acc);
+    if (lane == 0) y[i] -= acc;
+  }
+}
+__global__ void __launch_bounds__(kFrontThreads)
+    trsv_front_fwd_dense_kernel(const int *__restrict__ Lrowp, const double *__restrict__ Lvals,
+                                const int *__restrict__ fstart, const int *__restrict__ fsize, PtrTableW Y,
+                                int nv) {
+  const int f0 = fstart[blockIdx.x], s = fsize[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < s; k++) {
+    if (tid < nv) Y.p[tid][f0 + k] /= PO_T(k, k);
+    __threadfence_block();
+    __syncthreads();
+    const int64_t items = (int64_t)(s - k - 1) * nv;
+    for (int64_t t = tid; t < items; t += kFrontThreads) {
+      const int r = (int)(t / (s - k - 1));
+      const int i = k + 1 + (int)(t - (int64_t)r * (s - k - 1));
+      double *y = Y.p[r];
+      y[f0 + i] -= PO_T(i, k) * y[f0 + k];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(kFrontThreads)
+    trsv_front_bwd_dense_kernel(const int *__restrict__ Lrowp, const double *__restrict__ Lvals,
+                                const int *__restrict__ fstart, const int *__restrict__ fsize, PtrTableW Y,
+                                int nv) {
+  const int f0 = fstart[blockIdx.x], s = fsize[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int k = s - 1; k >= 0; k--) {
+    if (tid < nv) Y.p[tid][f0 + k] /= PO_T(k, k);
+    __threadfence_block();
+    __syncthreads();
+    const int64_t items = (int64_t)k * nv;
+    for (int64_t t = tid; t < items; t += kFrontThreads) {
+      const int r = (int)(t / k);
+      const int i = (int)(t - (int64_t)r * k);
+      double *y = Y.p[r];
+      y[f0 + i] -= PO_T(k, i) * y[f0 + k];
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+#undef PO_T
+static int fill_table(PtrTableW &t, double *const *Y, int nv);
+int k_trsv_fronts_fwd(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, int row0, int nrows,
+                      const int *front_of, const int *fstart, const int *fsize, int nfronts, double *const *Y,
+                      int nv) {
+  if (nrows <= 0 || nfronts <= 0 || nv <= 0) return PO_OK;
+  PtrTableW t;
+  PO_TRY(fill_table(t, Y, nv));
+  PO_CLAUNCH(trsv_front_fwd_rows_kernel, nrows, nv > 1 ? kBlock : 64, Lrowp, Lcols, Lvals, row0, front_of, t, nv);
+  PO_CLAUNCH(trsv_front_fwd_dense_kernel, nfronts, kFrontThreads, Lrowp, Lvals, fstart, fsize, t, nv);
+  return PO_OK;
+}
+int k_trsv_fronts_bwd(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,
+                      const double *Lvals, int row0, int nrows, const int *front_of, const int *front_end,
+                      const int *fstart, const int *fsize, int nfronts, double *const *Y, int nv) {
+  if (nrows <= 0 || nfronts <= 0 || nv <= 0) return PO_OK;
+  PtrTableW t;
+  PO_TRY(fill_table(t, Y, nv));
+  PO_CLAUNCH(trsv_front_bwd_cols_kernel, nrows, nv > 1 ? kBlock : 64, Ltp, Ltrows, Ltsrc, Lvals, row0, front_of,
+             front_end, t, nv);
+  PO_CLAUNCH(trsv_front_bwd_dense_kernel, nfronts, kFrontThreads, Lrowp, Lvals, fstart, fsize, t, nv);
+  return PO_OK;
+}
+
 // y_i = (y_i - sum_{j<i} L_ij y_j) / L_ii for the rows of one level; wavefront `wave` of the workgroup takes
 // the right-hand sides wave, wave+4, ...
 __global__ void __launch_bounds__(kBlock)

@@ -43,7 +43,13 @@ struct CsrSymbolic {
   // the backward solve.  Rows are NUMBERED level by level, so fwd_order is the identity and each level is a
   // contiguous range of rows (and of L's storage).
   std::vector<int> fwd_order, fwd_ptr;
-  std::vector<int> fwd_maxlen, bwd_maxlen;  // longest row / column of each level (kernel variant choice)
+  std::vector<int> fwd_maxlen, bwd_maxlen;  // longest ordinary row / column of each level (kernel variant choice)
+  // Each level = ordinary rows [fwd_ptr[l], ord_end[l]) followed by the rows of its FRONTS (dense separator
+  // cliques, front_ptr[l] .. front_ptr[l+1]-1 in front_start / front_size): row front_start + r ends with the
+  // columns front_start .. front_start + r, so the front's lower triangle is the tails of its rows.
+  std::vector<int> ord_end, front_ptr, front_start, front_size, front_of;
+  std::vector<int> front_maxdesc;  // per level: longest part of a front row left of its front
+  int max_front = 0;
   int64_t nnzS = 0, nnzL = 0;
   bool identity_src = true;
 };
@@ -91,6 +97,7 @@ class CsrSparse {
   int *d_Ltp = nullptr, *d_Ltrows = nullptr, *d_Ltsrc = nullptr;
   int *d_ent_a = nullptr, *d_ent_b = nullptr, *d_ent_slot = nullptr;
   int *d_fwd = nullptr;
+  int *d_front_of = nullptr, *d_front_end = nullptr, *d_fstart = nullptr, *d_fsize = nullptr;
   double *Lvals = nullptr, *ones = nullptr, *wwork = nullptr;
   int *d_flag = nullptr;
   std::string info;
@@ -113,6 +120,14 @@ int k_csr_assemble(Ctx *c, const int *rowp, const int *cols, const double *vals,
                    double *Lvals);
 int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows, int *flag,
                  int thin);
+int k_chol_fronts(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, int row0, int nrows,
+                  const int *front_of, const int *fstart, const int *fsize, int nfronts, int maxdesc, int *flag);
+int k_trsv_fronts_fwd(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, int row0, int nrows,
+                      const int *front_of, const int *fstart, const int *fsize, int nfronts, double *const *Y,
+                      int nv);
+int k_trsv_fronts_bwd(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,
+                      const double *Lvals, int row0, int nrows, const int *front_of, const int *front_end,
+                      const int *fstart, const int *fsize, int nfronts, double *const *Y, int nv);
 int k_trsv_fwd_level(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, const int *rows, int nrows,
                      double *const *Y, int nv, int thin);
 int k_trsv_bwd_level(Ctx *c, const int *Lrowp, const int *Ltp, const int *Ltrows, const int *Ltsrc,

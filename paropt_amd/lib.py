@@ -141,7 +141,8 @@ SIGNATURES = {
     "po_quasidef_factor_info": (C.c_char_p, [po_problem]),
     "po_csr_symbolic_create": (C.c_int, [C.c_int64, C.c_int64, c_int_p, c_int_p, C.POINTER(po_csr_symbolic)]),
     "po_csr_symbolic_info": (C.c_int, [po_csr_symbolic, c_i64_p]),
-    "po_csr_symbolic_arrays": (C.c_int, [po_csr_symbolic, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp]),
+    "po_csr_symbolic_arrays": (
+        C.c_int, [po_csr_symbolic, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp]),
     "po_csr_symbolic_destroy": (C.c_int, [po_csr_symbolic]),
     "po_problem_set_var_bound_options": (C.c_int, [po_problem, C.c_int, C.c_int]),
     "po_problem_destroy": (C.c_int, [po_problem]),

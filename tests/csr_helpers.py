@@ -55,7 +55,9 @@ def dense_jacobian(n, rowp, cols, data):
 
 
 def emulate_factor(sym, S):
-    """Row Cholesky on the symbolic pattern in level order; returns L (dense, permuted space)."""
+    """Row Cholesky on the symbolic pattern in the device's schedule; returns L (dense, permuted space).
+    Ordinary rows of a level may only read earlier levels; the rows of a front may also read the earlier rows of
+    the same front, and only through the dense tail of the row."""
     w = len(sym.perm)
     P = sym.perm
     Sp = S[np.ix_(P, P)]
@@ -65,10 +67,14 @@ def emulate_factor(sym, S):
     for lev in range(sym.nlevels):
         rows = np.arange(sym.level_ptr[lev], sym.level_ptr[lev + 1])
         for i in rows:
+            f0 = sym.front_of[i]
             for p in range(Lp[i], Lp[i + 1]):
                 j = Lc[p]
                 if j < i:
-                    assert done[j], "row %d needs row %d which is not in an earlier level" % (i, j)
+                    in_front = f0 >= 0 and j >= f0
+                    assert done[j] or in_front, "row %d needs row %d which is not in an earlier level" % (i, j)
+                    if in_front:  # dense tail: columns f0 .. i, contiguous at the end of the row
+                        assert p == Lp[i + 1] - 1 - (i - j)
                     L[i, j] = (Sp[i, j] - L[i, :j] @ L[j, :j]) / L[j, j]
                 else:
                     assert j == i and p == Lp[i + 1] - 1

@@ -15,6 +15,7 @@ CASES = {
     "chain5_rev": lambda: (257, *chain_pattern(257, 5, 2, reverse=True)),
     "block_diag": lambda: (240, *chain_pattern(240, 4, 4)),
     "grid": lambda: (12 * 11, *grid_pattern(12, 11)),
+    "grid_fronts": lambda: (26 * 24, *grid_pattern(26, 24)),
     "random_local": lambda: (400, *random_pattern(400, 250, 5, 1, local=12)),
     "random_global": lambda: (150, *random_pattern(150, 90, 3, 2)),
     "empty_rows": lambda: (50, np.array([0, 0, 2, 2, 3, 3], dtype=np.intc), np.array([4, 1, 4], dtype=np.intc)),
@@ -55,7 +56,10 @@ def test_symbolic_structure(name):
     for lev in range(sym.nlevels):
         level[sym.level_ptr[lev]:sym.level_ptr[lev + 1]] = lev
     ii, jj = np.nonzero(np.tril(mask, -1))
-    assert np.all(level[ii] > level[jj])
+    same_front = (sym.front_of[ii] >= 0) & (sym.front_of[ii] == sym.front_of[jj])
+    assert np.all((level[ii] > level[jj]) | same_front)
+    if name == "grid_fronts":
+        assert sym.nfronts > 0 and sym.max_front >= 16
 
 
 def test_nested_dissection_keeps_chains_shallow():
@@ -65,6 +69,16 @@ def test_nested_dissection_keeps_chains_shallow():
     sym = CsrSymbolic(n, rowp, cols)
     assert sym.nlevels < 40, sym.nlevels
     assert sym.nnzL < 3 * sym.nnzS
+
+
+def test_fronts_flatten_grid_like_patterns(monkeypatch):
+    # a 2-D pattern: without fronts every separator vertex is a level of its own
+    rowp, cols = grid_pattern(60, 60)
+    sym = CsrSymbolic(3600, rowp, cols)
+    monkeypatch.setenv("PAROPT_AMD_NO_FRONTS", "1")
+    ref = CsrSymbolic(3600, rowp, cols)
+    assert ref.nfronts == 0 and sym.nfronts > 10
+    assert sym.nnzL == ref.nnzL and sym.nlevels * 4 < ref.nlevels, (sym.nlevels, ref.nlevels)
 
 
 def test_block_diagonal_has_no_fill():

@@ -73,6 +73,8 @@ PATTERNS = {
     "chain5_rev": lambda: (257, *chain_pattern(257, 5, 2, reverse=True)),
     "block_diag": lambda: (240, *chain_pattern(240, 4, 4)),
     "grid": lambda: (12 * 11, *grid_pattern(12, 11)),
+    "grid_fronts": lambda: (26 * 24, *grid_pattern(26, 24)),
+    "grid_fronts_big": lambda: (40 * 40, *grid_pattern(40, 40)),
     "random_local": lambda: (400, *random_pattern(400, 250, 5, 1, local=12)),
     "random_global": lambda: (150, *random_pattern(150, 90, 3, 2)),
     "long_rows": lambda: (600, *random_pattern(600, 40, 150, 3)),
@@ -104,6 +106,8 @@ def test_quasidef_solve_matches_dense(ctx, name):
     np.testing.assert_array_equal(cv.to_numpy(), c)  # the CSR form leaves C alone
     info = pa.quasidef_factor_info(prob)
     assert info and "nnz(L)" in info
+    if name.startswith("grid_fronts"):
+        assert pa.CsrSymbolic(n, rowp, cols).nfronts > 0
     for with_bw in (True, False):
         bx = rng.standard_normal(n)
         bw = rng.standard_normal(w) if with_bw else None
