@@ -771,12 +771,12 @@ int CsrSparse::applyK0(const double *dinv, const double *bx, const double *bw, d
 
 const char *CsrSparse::factorInfo() {
   // the fields of ParOptQuasiDefSparseMat::getFactorInfo (src/ParOptSparseMat.cpp:433-450); this factor has
-  // no supernodes, the level counts take that column
+  // the level and front counts take the supernode column
   char buf[192];
   const double tri = 0.5 * (double)w * ((double)w + 1.0);
   snprintf(buf, sizeof(buf),
-           "n %5lld nlevels %5d nnz(K) %7lld nnz(L) %7lld nnz(L) / nnz(K) %8.4f sparsity(L) %8.2e",
-           (long long)w, nlevels_f, (long long)sym.nnzS, (long long)sym.nnzL,
+           "n %5lld nlevels %5d nfronts %5d nnz(K) %7lld nnz(L) %7lld nnz(L) / nnz(K) %8.4f sparsity(L) %8.2e",
+           (long long)w, nlevels_f, (int)sym.front_start.size(), (long long)sym.nnzS, (long long)sym.nnzL,
            sym.nnzS > 0 ? (double)sym.nnzL / (double)sym.nnzS : 0.0, tri > 0 ? (double)sym.nnzL / tri : 0.0);
   info = buf;
   return info.c_str();

@@ -1551,6 +1551,10 @@ int InteriorPoint::optimize(const char *checkpoint) {
     phaseEnd("residual");
 
     if (ctx->rank == 0) {  // iteration table :4777-4801
+      if (k == 0 || options.integer("output_level") > 0) {  // :4767-4774
+        const char *inform = has_w ? prob->sparseFactorInfo() : nullptr;
+        if (inform) history += std::string("MatInfo: ") + inform + "\n";
+      }
       if (k % 10 == 0) {
         snprintf(line, sizeof(line),
                  "\n%4s %4s %4s %4s %7s %7s %7s %12s %7s %7s %7s %7s %7s %8s %7s info\n", "iter",

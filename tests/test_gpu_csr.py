@@ -190,6 +190,7 @@ def test_callback_csr_problem_matches_builtin_and_oracle(ctx, kind, n, c, span, 
     ip2 = pa.InteriorPoint(built, OPTS)
     ip2.optimize()
     assert ip1.getIterationCounters() == ip2.getIterationCounters()
+    assert "MatInfo: n " in ip2.getHistory()  # the factor line of the reference's output file (:4767-4774)
     x1, z1 = ip1.getOptimizedPoint()[:2]
     x2, z2 = ip2.getOptimizedPoint()[:2]
     np.testing.assert_allclose(x1.to_numpy(), x2.to_numpy(), rtol=0, atol=1e-9)
