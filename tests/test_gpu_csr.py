@@ -346,3 +346,91 @@ def test_solution_file_with_csr_constraints(ctx, tmp_path):
     ip2.readSolutionFile(f)
     np.testing.assert_array_equal(ip2.getOptimizedSparse()[0].to_numpy(), zw)
     np.testing.assert_array_equal(ip2.getOptimizedPoint()[0].to_numpy(), ip.getOptimizedPoint()[0].to_numpy())
+
+
+def test_interior_point_on_grid_pattern_with_fronts(ctx):
+    """A full interior-point solve whose sparse Schur complement has dense separator fronts (one linear
+    inequality per grid edge) against the numpy oracle with a dense S on the same data."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    nx, ny = 26, 24
+    n = nx * ny
+    rowp, cols = grid_pattern(nx, ny)
+    w = len(rowp) - 1
+    assert pa.CsrSymbolic(n, rowp, cols).nfronts > 0
+    rng = np.random.default_rng(11)
+    data = rng.uniform(0.5, 1.5, size=int(rowp[-1]))
+    A = dense_jacobian(n, rowp, cols, data)
+    xt = rng.uniform(0.2, 0.8, size=n)
+    b = A @ rng.uniform(0.3, 0.6, size=n) + 0.05  # cw = b - A x >= 0 is feasible
+    a0 = rng.uniform(0.5, 1.0, size=n)
+
+    def f_g(x):
+        return float(np.sum((x - xt) ** 2)), 2.0 * (x - xt)
+
+    class P(pa.Problem):
+        def __init__(self):
+            super().__init__(ctx, n, 1, 1, nwcon=w, nwinequality=w, rowp=rowp, cols=cols)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = 0.5, 0.0, 1.0
+
+        def evalSparseObjCon(self, x, sparse):
+            sparse[:] = b - A @ x
+            return 0, f_g(x)[0], np.array([0.45 * np.sum(a0) - a0 @ x])
+
+        def evalSparseObjConGradient(self, x, g, Ac, d):
+            g[:] = f_g(x)[1]
+            Ac[0][:] = -a0
+            d[:] = data
+            return 0
+
+    class O:
+        comm = po.SelfComm()
+        nlocal, c, nwcon, nwineq, csr_form = n, 1, w, w, True
+
+        def vars_and_bounds(self):
+            return np.full(n, 0.5), np.zeros(n), np.ones(n)
+
+        def eval_obj_con(self, x):
+            self._cw = b - A @ x
+            return 0, f_g(x)[0], np.array([0.45 * np.sum(a0) - a0 @ x])
+
+        def eval_obj_con_gradient(self, x):
+            return 0, f_g(x)[1], [-a0.copy()]
+
+        def eval_sparse_con(self, x):
+            return self._cw.copy()
+
+        def sparse_jacobian_dense(self):
+            return -A
+
+        def add_sparse_jacobian(self, alpha, px, out):
+            out -= alpha * (A @ px)
+            return out
+
+        def add_sparse_jacobian_transpose(self, alpha, pzw, out):
+            out -= alpha * (A.T @ pzw)
+            return out
+
+    opts = dict(OPTS, max_major_iters=60)
+    # the Jacobian of cw = b - A x is -A: hand the device the entries of -A
+    data_dev = -data
+
+    class P2(P):
+        def evalSparseObjConGradient(self, x, g, Ac, d):
+            g[:] = f_g(x)[1]
+            Ac[0][:] = -a0
+            d[:] = data_dev
+            return 0
+
+    ip = pa.InteriorPoint(P2(), opts)
+    ip.optimize()
+    oip = po.InteriorPoint(O(), dict(opts))
+    oip.optimize()
+    assert tuple(ip.getIterationCounters()) == (oip.niter, oip.neval, oip.ngeval)
+    assert abs(ip.getObjective()[0] - oip.fobj) <= 1e-8 * max(1.0, abs(oip.fobj))
+    np.testing.assert_allclose(ip.getOptimizedPoint()[0].to_numpy(), oip.vars.x, rtol=0, atol=1e-7)
+    zw = ip.getOptimizedSparse()[0].to_numpy()
+    np.testing.assert_allclose(zw, oip.vars.zw, rtol=0, atol=1e-6 * max(1.0, np.abs(oip.vars.zw).max()))
