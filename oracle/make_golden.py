@@ -420,6 +420,12 @@ case("tr_quadratic_n150_c2_fixedgamma", "tr", problem="quadratic", n=150, c=2, d
      **dict(tr_common, **{"tr.tr_adaptive_gamma_update": 0, "opt.penalty_gamma": 50.0}))
 case("tr_convex_n200_c2_w40", "tr", problem="convex", n=200, c=2, nwcon=40, nw=5, nwstart=0, nwskip=0,
      dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05}))
+# the trust-region driver over a problem in the CSR form: pins the stored-value semantics of
+# ParOptSparseProblem::evalSparseCon / addSparseJacobian under trial-point evaluations
+case("tr_csr_convex_n120_c2_chain3s2", "tr", problem="convex", n=120, c=2, chain_span=3, chain_stride=2,
+     dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05, "tr.tr_max_iterations": 40}))
+case("tr_csr_rosenbrock_n60_chain2", "tr", problem="rosenbrock", n=60, chain_span=2, chain_stride=1,
+     dump_vecs_every=10, **dict(tr_common, **{"opt.qn_subspace_size": 10, "tr.tr_max_iterations": 60}))
 # filter globalisation (filterOptimize :1690-2210)
 case("tr_filter_quadratic_n200_c3", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10,
      **dict(tr_common, **{"tr.tr_accept_step_strategy": "filter_method"}))

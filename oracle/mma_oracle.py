@@ -218,3 +218,11 @@ class MMA:
 
     def add_sparse_inner_product(self, alpha, cvec, A):
         return self.prob.add_sparse_inner_product(alpha, cvec, A)
+
+    # ParOptMMA::createQuasiDefMat forwards to the wrapped problem (src/ParOptMMA.cpp:776-777)
+    @property
+    def csr_form(self):
+        return bool(getattr(self.prob, "chain", None)) or bool(getattr(self.prob, "csr_form", False))
+
+    def sparse_jacobian_dense(self):
+        return self.prob.sparse_jacobian_dense()

@@ -977,6 +977,12 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
                                     (int)geti(A, "nw", 0), (int)geti(A, "nwstart", 0),
                                     (int)geti(A, "nwskip", 0), (int)geti(A, "nwineq", -1));
   prob->incref();
+  ParOptProblem *top = prob;  // the problem the optimizer sees: the CSR wrapper when chain_span > 0
+  if ((int)geti(A, "chain_span", 0) > 0) {
+    top = new SepCsrProblem(comm, prob, (int)geti(A, "chain_span", 0), (int)geti(A, "chain_stride", 1),
+                            (int)geti(A, "chain_reverse", 0));
+    top->incref();
+  }
   ParOptOptions *opt = new ParOptOptions(comm);
   opt->incref();
   ParOptInteriorPoint::addDefaultOptions(opt);
@@ -1003,12 +1009,12 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   std::string qt = opt->getEnumOption("qn_type");
   int msub = opt->getIntOption("qn_subspace_size");
   if (qt == "bfgs") {
-    ParOptLBFGS *b = new ParOptLBFGS(prob, msub);
+    ParOptLBFGS *b = new ParOptLBFGS(top, msub);
     std::string ut = opt->getEnumOption("qn_update_type");
     b->setBFGSUpdateType(ut == "damped_update" ? PAROPT_DAMPED_UPDATE : PAROPT_SKIP_NEGATIVE_CURVATURE);
     qn = b;
   } else if (qt == "sr1") {
-    qn = new ParOptLSR1(prob, msub);
+    qn = new ParOptLSR1(top, msub);
   }
   if (qn) {
     qn->incref();
@@ -1019,9 +1025,9 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   ParOptTrustRegionSubproblem *sub = NULL;
   EigData E;
   if (eigN > 0) {
-    ParOptCompactEigenApprox *eigh = new ParOptCompactEigenApprox(prob, eigN);
+    ParOptCompactEigenApprox *eigh = new ParOptCompactEigenApprox(top, eigN);
     ParOptEigenQuasiNewton *eqn = new ParOptEigenQuasiNewton(qn, eigh, (int)geti(A, "eig_index", 0));
-    ParOptEigenSubproblem *es = new ParOptEigenSubproblem(prob, eqn);
+    ParOptEigenSubproblem *es = new ParOptEigenSubproblem(top, eqn);
     E.N = eigN;
     E.seed = seed;
     E.offset = offset;
@@ -1029,7 +1035,7 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
     es->setEigenModelUpdate(&E, eig_update);
     sub = es;
   } else {
-    sub = new ParOptQuadraticSubproblem(prob, qn);
+    sub = new ParOptQuadraticSubproblem(top, qn);
   }
   sub->incref();
   ParOptInteriorPoint *ip = new ParOptInteriorPoint(sub, opt);

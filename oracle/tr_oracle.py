@@ -95,6 +95,15 @@ class _SubproblemBase:
     def add_sparse_inner_product(self, alpha, cvec, A):
         return self.prob.add_sparse_inner_product(alpha, cvec, A)
 
+    # createQuasiDefMat() forwards to the wrapped problem (src/ParOptTrustRegion.cpp:257-258,513-514): a CSR-form
+    # problem keeps its general sparse quasi-definite matrix under the subproblem
+    @property
+    def csr_form(self):
+        return bool(getattr(self.prob, "chain", None)) or bool(getattr(self.prob, "csr_form", False))
+
+    def sparse_jacobian_dense(self):
+        return self.prob.sparse_jacobian_dense()
+
     def _lagrangian_gradient_difference(self, z, zw):
         """t = [gt - At^T z - Aw^T zw] - [gk - Ak^T z - Aw^T zw]  (:187-205 / eigen :492-510)."""
         t = self.gt.copy()
@@ -221,6 +230,15 @@ class InfeasSubproblem:
 
     def add_sparse_inner_product(self, alpha, cvec, A):
         return self.sub.add_sparse_inner_product(alpha, cvec, A)
+
+    # createQuasiDefMat() forwards to the wrapped problem (src/ParOptTrustRegion.cpp:257-258,513-514): a CSR-form
+    # problem keeps its general sparse quasi-definite matrix under the subproblem
+    @property
+    def csr_form(self):
+        return bool(getattr(self.sub, "chain", None)) or bool(getattr(self.sub, "csr_form", False))
+
+    def sparse_jacobian_dense(self):
+        return self.sub.sparse_jacobian_dense()
 
 
 # ---- compact eigenvalue approximation -------------------------------------------------------------

@@ -33,6 +33,8 @@ def run_gpu_tr(ctx, case, python_eig_callback=False):
     if a.get("nwcon", 0) > 0:
         prob.setWeighting(a["nwcon"], a["nw"], a.get("nwstart", 0), a.get("nwskip", 0),
                           a.get("nwineq", a["nwcon"]))
+    if a.get("chain_span", 0) > 0:
+        prob.setChain(a["chain_span"], a.get("chain_stride", 1), a.get("chain_reverse", 0))
     opts, tropts = tr_options_from_case(case)
     opts.pop("write_output_frequency", None)
     tr = pa.TrustRegion(prob, dict(opts, **tropts))

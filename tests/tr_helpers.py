@@ -43,7 +43,8 @@ def run_oracle_tr(case, nmax=None):
     prob = po.SepProblem(a["problem"], a["n"], a.get("c", 2), seed=a.get("seed", 0),
                          eig_min=a.get("eig_min", 1.0), eig_max=a.get("eig_max", 100.0),
                          nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
-                         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1))
+                         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
+                         chain=(a["chain_span"], a.get("chain_stride", 1)) if a.get("chain_span", 0) else None)
     opts, tropts = tr_options_from_case(case)
     if "penalty_gamma" in opts:
         tropts["penalty_gamma"] = opts["penalty_gamma"]
