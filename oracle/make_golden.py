@@ -404,6 +404,8 @@ case("mma_convex_n200_c2_linearized", "mma", problem="convex", n=200, c=2,
      **{"mma.mma_max_iterations": 25, "mma.mma_use_constraint_linearization": 1, "mma.mma_bound_relax": 1e-4})
 case("mma_convex_n200_c2_w40", "mma", problem="convex", n=200, c=2, nwcon=40, nw=5, nwstart=0, nwskip=0,
      **{"mma.mma_max_iterations": 20})
+case("mma_csr_convex_n150_c2_chain2s2", "mma", problem="convex", n=150, c=2, chain_span=2, chain_stride=2,
+     **{"mma.mma_max_iterations": 15})
 # --- trust-region driver: ParOptOptimizer's algorithm="tr" set-up ---
 tr_common = {"opt.qn_subspace_size": 5, "tr.tr_max_iterations": 60}
 case("tr_quadratic_n200_c3_bfgs", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10, **tr_common)

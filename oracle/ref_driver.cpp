@@ -1121,7 +1121,13 @@ static int mode_mma(std::map<std::string, std::string> &A, MPI_Comm comm, int ra
       opt->setOption(name.c_str(), it->second.c_str());
     }
   }
-  ParOptMMA *mma = new ParOptMMA(prob, opt);
+  ParOptProblem *top = prob;  // the CSR wrapper when chain_span > 0
+  if ((int)geti(A, "chain_span", 0) > 0) {
+    top = new SepCsrProblem(comm, prob, (int)geti(A, "chain_span", 0), (int)geti(A, "chain_stride", 1),
+                            (int)geti(A, "chain_reverse", 0));
+    top->incref();
+  }
+  ParOptMMA *mma = new ParOptMMA(top, opt);
   mma->incref();
   ParOptInteriorPoint *ip = new ParOptInteriorPoint(mma, opt);
   ip->incref();

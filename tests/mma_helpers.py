@@ -28,7 +28,8 @@ def run_oracle_mma(case):
     a = case["args"]
     prob = po.SepProblem(a["problem"], a["n"], a.get("c", 2), seed=a.get("seed", 0),
                          nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
-                         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1))
+                         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
+                         chain=(a["chain_span"], a.get("chain_stride", 1)) if a.get("chain_span", 0) else None)
     opts, mopts = mma_options_from_case(case)
     mma = mo.MMA(prob, mopts)
     ip = po.InteriorPoint(mma, opts)

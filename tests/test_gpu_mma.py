@@ -28,6 +28,8 @@ def run_gpu_mma(ctx, case):
     prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), a.get("seed", 0))
     if a.get("nwcon", 0) > 0:
         prob.setWeighting(a["nwcon"], a["nw"], a.get("nwstart", 0), a.get("nwskip", 0), a.get("nwineq", a["nwcon"]))
+    if a.get("chain_span", 0) > 0:
+        prob.setChain(a["chain_span"], a.get("chain_stride", 1), a.get("chain_reverse", 0))
     opts, mopts = mma_options_from_case(case)
     mma = pa.MMA(prob, dict(opts, **mopts))
     rows = []
