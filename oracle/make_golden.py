@@ -260,6 +260,14 @@ case(
     checkpoint=1,
     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}),
 )
+# the same file written by TWO MPI ranks (MPI_File_write_at_all at var_range / wcon_range offsets, :929-968):
+# one file in the layout of the concatenated problem; the CSR case has rank-local sparse constraints
+case("ip_quadratic_checkpoint_n131_c3_r2", "ip", ranks=2, problem="quadratic", n=131, c=3, dump_vecs_every=10,
+     checkpoint=1,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}))
+case("ipcsr_convex_checkpoint_n121_c2_chain2_r2", "ip", ranks=2, problem="convex", n=121, c=2, chain_span=2,
+     chain_stride=1, dump_vecs_every=10, checkpoint=1,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.write_output_frequency": 10, "opt.max_major_iters": 12}))
 # --- weighting (sparse, block-diagonal) constraints: SURVEY 8f rank 1 / config 4 ---
 # the reference example itself: examples/rosenbrock/rosenbrock.cpp:219-222 (nwcon=5, nw=5, start 1, skip 1)
 case(

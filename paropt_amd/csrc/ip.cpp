@@ -1848,97 +1848,161 @@ void InteriorPoint::flushHistory() {
   fclose(fp);
 }
 
-// rank-local shard of the reference's checkpoint layout (:883-972); rank r writes
-// "<filename>" (size 1) or "<filename>.<r>" (size > 1)
-int InteriorPoint::writeSolutionFile(const char *filename) {
-  std::string name = filename;
-  if (ctx->size > 1) name += "." + std::to_string(ctx->rank);
-  FILE *fp = fopen(name.c_str(), "wb");
-  if (!fp) {
-    set_error("cannot open checkpoint file %s", name.c_str());
+// writeSolutionFile (:883-972): ONE file in the reference's layout whatever the number of ranks -
+//   int32 {total nvars, total nwcon, ncon}, mu, s, t, z, zs, zt (ncon each, written by rank 0), then x, zl, zu
+//   as global arrays (each rank writes its block at its offset, as MPI_File_write_at_all does there), then zw
+//   and sw likewise when there are sparse constraints.
+// A file written by N ranks is byte-for-byte the file of the concatenated problem and can be read by any
+// number of ranks (shared file system, like MPI-IO).
+int InteriorPoint::gatherCounts(int64_t mine, std::vector<int64_t> *all) {
+  // all[r] = the count of rank r, through the one collective the context has: a dot product of the
+  // 1-vector [mine] with unit vectors that are 1 only on their own rank
+  all->assign(ctx->size, mine);
+  if (ctx->size == 1) return PO_OK;
+  if (ctx->size > kMaxPanel) {
+    set_error("solution files support at most %d ranks", kMaxPanel);
     return PO_ERR_ARG;
   }
-  int sizes[3] = {(int)prob->nglobal, (int)nw_global, c};
-  fwrite(sizes, sizeof(int), 3, fp);
-  fwrite(&barrier_param, sizeof(double), 1, fp);
-  fwrite(vars.s.data(), sizeof(double), c, fp);
-  fwrite(vars.t.data(), sizeof(double), c, fp);
-  fwrite(vars.z.data(), sizeof(double), c, fp);
-  fwrite(vars.zs.data(), sizeof(double), c, fp);
-  fwrite(vars.zt.data(), sizeof(double), c, fp);
-  std::vector<double> host((size_t)(n > 0 ? n : 1));
-  Vec *vs[3] = {x, zl, zu};
-  for (Vec *v : vs) {
-    if (hipMemcpyAsync(host.data(), v->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost,
-                       ctx->stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->stream) != hipSuccess) {
-      fclose(fp);
-      set_error("checkpoint download failed");
-      return PO_ERR_HIP;
+  Vec *v = vec_new(ctx, 1), *one = vec_new(ctx, 1), *zero = vec_new(ctx, 1);
+  if (!v || !one || !zero) return PO_ERR_HIP;
+  int rc = k_fill(ctx, v->d, 1, (double)mine);
+  if (rc == PO_OK) rc = k_fill(ctx, one->d, 1, 1.0);
+  if (rc == PO_OK) rc = k_fill(ctx, zero->d, 1, 0.0);
+  std::vector<const double *> V(ctx->size, zero->d);
+  V[ctx->rank] = one->d;
+  std::vector<double> out(ctx->size, 0.0);
+  if (rc == PO_OK) rc = k_mdot(ctx, v->d, V.data(), ctx->size, 1, out.data());
+  for (int r = 0; r < ctx->size; r++) (*all)[r] = (int64_t)(out[r] + 0.5);
+  vec_decref(v);
+  vec_decref(one);
+  vec_decref(zero);
+  return rc;
+}
+
+int InteriorPoint::solutionFileOffsets(int64_t *nvars_total, int64_t *var_off, int64_t *nw_total, int64_t *w_off) {
+  std::vector<int64_t> nv, nwv;
+  PO_TRY(gatherCounts(n, &nv));
+  PO_TRY(gatherCounts(nw, &nwv));
+  *nvars_total = *nw_total = *var_off = *w_off = 0;
+  for (int r = 0; r < ctx->size; r++) {
+    if (r < ctx->rank) {
+      *var_off += nv[r];
+      *w_off += nwv[r];
     }
-    fwrite(host.data(), sizeof(double), (size_t)n, fp);
+    *nvars_total += nv[r];
+    *nw_total += nwv[r];
   }
-  if (has_w) {  // zw then sw, as the reference (:951-968)
-    std::vector<double> hw((size_t)(nw > 0 ? nw : 1));
-    for (int i = 0; i < 2; i++) {
-      if (hipMemcpyAsync(hw.data(), wvar[i]->d, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost,
-                         ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) {
-        fclose(fp);
-        set_error("checkpoint download failed");
-        return PO_ERR_HIP;
-      }
-      fwrite(hw.data(), sizeof(double), (size_t)nw, fp);
-    }
-  }
-  fclose(fp);
   return PO_OK;
 }
 
-// readSolutionFile (:983-1104): restart state written by writeSolutionFile (same layout)
-int InteriorPoint::readSolutionFile(const char *filename) {
-  std::string name = filename;
-  if (ctx->size > 1) name += "." + std::to_string(ctx->rank);
-  FILE *fp = fopen(name.c_str(), "rb");
-  if (!fp) {
-    set_error("cannot open solution file %s", name.c_str());
-    return PO_ERR_ARG;
-  }
-  int sizes[3] = {0, 0, 0};
-  bool ok = fread(sizes, sizeof(int), 3, fp) == 3;
-  if (!ok || sizes[0] != (int)prob->nglobal || sizes[1] != (int)nw_global || sizes[2] != c) {
-    fclose(fp);
-    set_error("ParOpt: Problem size incompatible with solution file");
-    return PO_ERR_ARG;
-  }
-  ok = ok && fread(&barrier_param, sizeof(double), 1, fp) == 1;
-  std::vector<double> *blocks[5] = {&vars.s, &vars.t, &vars.z, &vars.zs, &vars.zt};
-  for (auto *b : blocks) ok = ok && fread(b->data(), sizeof(double), c, fp) == (size_t)c;
-  std::vector<double> host((size_t)(n > 0 ? n : 1));
-  Vec *vs[3] = {x, zl, zu};
-  for (Vec *v : vs) {
-    ok = ok && fread(host.data(), sizeof(double), (size_t)n, fp) == (size_t)n;
-    if (ok && (hipMemcpyAsync(v->d, host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
-                              ctx->stream) != hipSuccess ||
-               hipStreamSynchronize(ctx->stream) != hipSuccess)) {
-      ok = false;
+static bool file_block(FILE *fp, bool writing, int64_t byte_offset, double *host, size_t count) {
+  if (fseeko(fp, (off_t)byte_offset, SEEK_SET) != 0) return false;
+  if (count == 0) return true;
+  return (writing ? fwrite(host, sizeof(double), count, fp) : fread(host, sizeof(double), count, fp)) == count;
+}
+
+int InteriorPoint::writeSolutionFile(const char *filename) {
+  int64_t N = 0, off = 0, Wt = 0, woff = 0;
+  PO_TRY(solutionFileOffsets(&N, &off, &Wt, &woff));  // collective
+  int ok = 1;
+  if (ctx->rank == 0) {
+    FILE *fp = fopen(filename, "wb");
+    if (fp) {
+      int sizes[3] = {(int)N, (int)Wt, c};
+      ok = fwrite(sizes, sizeof(int), 3, fp) == 3 && fwrite(&barrier_param, sizeof(double), 1, fp) == 1;
+      const std::vector<double> *blocks[5] = {&vars.s, &vars.t, &vars.z, &vars.zs, &vars.zt};
+      for (auto *b : blocks) ok = ok && fwrite(b->data(), sizeof(double), c, fp) == (size_t)c;
+      fclose(fp);
+    } else {
+      ok = 0;
     }
   }
-  if (has_w) {
-    std::vector<double> hw((size_t)(nw > 0 ? nw : 1));
-    for (int i = 0; i < 2; i++) {
-      ok = ok && fread(hw.data(), sizeof(double), (size_t)nw, fp) == (size_t)nw;
-      if (ok && (hipMemcpyAsync(wvar[i]->d, hw.data(), sizeof(double) * (size_t)nw,
-                                hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                 hipStreamSynchronize(ctx->stream) != hipSuccess)) {
-        ok = false;
+  // every rank learns whether the header is there (and waits for it)
+  std::vector<int64_t> flags;
+  PO_TRY(gatherCounts(ok, &flags));
+  if (flags[0] == 0) {
+    set_error("cannot open checkpoint file %s", filename);
+    return PO_ERR_ARG;
+  }
+  FILE *fp = fopen(filename, "r+b");
+  if (!fp) {
+    ok = 0;
+  } else {
+    const int64_t base = 3 * (int64_t)sizeof(int) + (5 * (int64_t)c + 1) * (int64_t)sizeof(double);
+    std::vector<double> host((size_t)std::max<int64_t>(std::max(n, nw), 1));
+    Vec *vs[3] = {x, zl, zu};
+    for (int b = 0; b < 3 && ok; b++) {
+      ok = hipMemcpyAsync(host.data(), vs[b]->d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream) ==
+               hipSuccess &&
+           hipStreamSynchronize(ctx->stream) == hipSuccess &&
+           file_block(fp, true, base + 8 * (b * N + off), host.data(), (size_t)n);
+    }
+    if (Wt > 0) {  // zw then sw, as the reference (:951-968)
+      for (int b = 0; b < 2 && ok; b++) {
+        ok = (nw == 0 || (hipMemcpyAsync(host.data(), wvar[b]->d, sizeof(double) * (size_t)nw,
+                                         hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                          hipStreamSynchronize(ctx->stream) == hipSuccess)) &&
+             file_block(fp, true, base + 8 * (3 * N + b * Wt + woff), host.data(), (size_t)nw);
       }
     }
+    fclose(fp);
   }
-  fclose(fp);
-  if (!ok) {
-    set_error("short read or upload failure on solution file %s", name.c_str());
-    return PO_ERR_ARG;
+  PO_TRY(gatherCounts(ok, &flags));  // completion barrier + agreement on the outcome
+  for (int r = 0; r < ctx->size; r++) {
+    if (flags[r] == 0) {
+      set_error("writing the checkpoint file %s failed on rank %d", filename, r);
+      return PO_ERR_ARG;
+    }
+  }
+  return PO_OK;
+}
+
+// readSolutionFile (:983-1104): restart state written by writeSolutionFile (same layout, any rank count)
+int InteriorPoint::readSolutionFile(const char *filename) {
+  int64_t N = 0, off = 0, Wt = 0, woff = 0;
+  PO_TRY(solutionFileOffsets(&N, &off, &Wt, &woff));  // collective
+  FILE *fp = fopen(filename, "rb");
+  int ok = fp != nullptr;
+  int sizes[3] = {0, 0, 0};
+  bool size_ok = true;
+  if (ok) {
+    ok = fread(sizes, sizeof(int), 3, fp) == 3;
+    size_ok = ok && sizes[0] == (int)N && sizes[1] == (int)Wt && sizes[2] == c;
+    ok = ok && size_ok && fread(&barrier_param, sizeof(double), 1, fp) == 1;
+    std::vector<double> *blocks[5] = {&vars.s, &vars.t, &vars.z, &vars.zs, &vars.zt};
+    for (auto *b : blocks) ok = ok && fread(b->data(), sizeof(double), c, fp) == (size_t)c;
+    const int64_t base = 3 * (int64_t)sizeof(int) + (5 * (int64_t)c + 1) * (int64_t)sizeof(double);
+    std::vector<double> host((size_t)std::max<int64_t>(std::max(n, nw), 1));
+    Vec *vs[3] = {x, zl, zu};
+    for (int b = 0; b < 3 && ok; b++) {
+      ok = file_block(fp, false, base + 8 * (b * N + off), host.data(), (size_t)n) &&
+           hipMemcpyAsync(vs[b]->d, host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream) ==
+               hipSuccess &&
+           hipStreamSynchronize(ctx->stream) == hipSuccess;
+    }
+    if (Wt > 0) {
+      for (int b = 0; b < 2 && ok; b++) {
+        ok = file_block(fp, false, base + 8 * (3 * N + b * Wt + woff), host.data(), (size_t)nw) &&
+             (nw == 0 || (hipMemcpyAsync(wvar[b]->d, host.data(), sizeof(double) * (size_t)nw,
+                                         hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                          hipStreamSynchronize(ctx->stream) == hipSuccess));
+      }
+    }
+    fclose(fp);
+  }
+  std::vector<int64_t> flags;
+  PO_TRY(gatherCounts(ok, &flags));  // every rank takes the same decision
+  for (int r = 0; r < ctx->size; r++) {
+    if (flags[r] == 0) {
+      if (!fp) {
+        set_error("cannot open solution file %s", filename);
+      } else if (!size_ok) {
+        set_error("ParOpt: Problem size incompatible with solution file");
+      } else {
+        set_error("short read or upload failure on solution file %s (rank %d)", filename, r);
+      }
+      return PO_ERR_ARG;
+    }
   }
   return PO_OK;
 }

@@ -153,6 +153,8 @@ class InteriorPoint {
   // scaleKKTStep: {pos log, neg log, ppos, pneg, g.px, px.px, max|px|}
   double merit_cache[7];
   bool merit_cache_valid;
+  int gatherCounts(int64_t mine, std::vector<int64_t> *all);
+  int solutionFileOffsets(int64_t *nvars_total, int64_t *var_off, int64_t *nw_total, int64_t *w_off);
   int ensureHdiag();
   int solveKKTAlpha(const double *bx, double alpha, const Dense &b, double mu, bool use_qn, bool full,
                     double tau, Dense &out);

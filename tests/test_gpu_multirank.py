@@ -312,3 +312,85 @@ def test_rccl_plumbing_single_rank(monkeypatch):
         outs[-1] += (ip.getObjective()[0],)
     for a, b in zip(*outs):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def _worker_ckpt(rank, world, port, q, args, opts, path):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+
+    def make():
+        p = pa.SeparableProblem(ctx, args["problem"], args["n"], args["c"])
+        if args.get("chain_span", 0):
+            p.setChain(args["chain_span"], args.get("chain_stride", 1))
+        return p
+
+    ip = pa.InteriorPoint(make(), opts)
+    ip.optimize(checkpoint=path)  # the file left behind is the last multiple of write_output_frequency
+    # a second file with the FINAL state, re-read on the same two ranks: bit-exact round trip of every block
+    ip.writeSolutionFile(path + ".final")
+    ip2 = pa.InteriorPoint(make(), opts)
+    ip2.readSolutionFile(path + ".final")
+    same = True
+    for a, b in zip(ip.getOptimizedPoint(), ip2.getOptimizedPoint()):
+        a = a.to_numpy() if hasattr(a, "to_numpy") else np.asarray(a)
+        b = b.to_numpy() if hasattr(b, "to_numpy") else np.asarray(b)
+        same = same and np.array_equal(a, b)
+    if ip.getOptimizedSparse() is not None:
+        for a, b in zip(ip.getOptimizedSparse()[:2], ip2.getOptimizedSparse()[:2]):
+            same = same and np.array_equal(a.to_numpy(), b.to_numpy())
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(same))
+    if rank == 0:
+        q.put(all(flags))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ip_quadratic_checkpoint_n131_c3_r2", "ipcsr_convex_checkpoint_n121_c2_chain2_r2"])
+def test_two_rank_solution_file_is_the_references_single_file(name, tmp_path):
+    """writeSolutionFile on two ranks: ONE file in the layout of the concatenated problem, as the reference's
+    MPI-IO code writes it (src/ParOptInteriorPoint.cpp:883-972) - compared with the file the reference left
+    behind on two MPI ranks (header bit-exact, payload to 1e-6), re-read on two ranks (bit-exact), and, where
+    the single-rank problem is the same problem, read by ONE rank."""
+    import struct
+
+    from conftest import ip_options_from_case, load_golden
+
+    g, case = load_golden(name)
+    ref = g["checkpoint_bytes"].tobytes()
+    a = case["args"]
+    opts = ip_options_from_case(case)
+    path = str(tmp_path / "ckpt.bin")
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_ckpt, args=(r, 2, port, q, a, opts, path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    roundtrip = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert roundtrip
+    mine = open(path, "rb").read()
+    assert not os.path.exists(path + ".0")
+    assert len(mine) == len(ref) and mine[:12] == ref[:12]
+    nv, nwc, c = struct.unpack("<3i", mine[:12])
+    assert len(mine) == 12 + (5 * c + 1) * 8 + 3 * nv * 8 + 2 * nwc * 8
+    pm = np.frombuffer(mine[12:], dtype="<f8")
+    pr = np.frombuffer(ref[12:], dtype="<f8")
+    np.testing.assert_allclose(pm, pr, rtol=1e-6, atol=1e-6 * np.abs(pr).max())
+    if nwc == 0:
+        import paropt_amd as pa
+
+        ctx = pa.Context(0)
+        ip = pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"], a["c"]), opts)
+        ip.readSolutionFile(path)
+        np.testing.assert_array_equal(ip.getOptimizedPoint()[0].to_numpy(), pm[1 + 5 * c: 1 + 5 * c + nv])
