@@ -692,7 +692,7 @@ int CsrSparse::factor(const double *dinv, const double *cdiag) {
     const int b = sym.fwd_ptr[l], e = sym.fwd_ptr[l + 1];
     const int oe = sym.ord_end[l], f0 = sym.front_ptr[l], nf = sym.front_ptr[l + 1] - f0;
     PO_TRY(k_chol_level(ctx, d_Lrowp, d_Lcols, Lvals, d_fwd + b, oe - b, d_flag,
-                        thinLevel(sym.fwd_maxlen[l], oe - b)));
+                        thinLevel(sym.fwd_maxlen[l], oe - b), sym.fwd_maxlen[l]));
     PO_TRY(k_chol_fronts(ctx, d_Lrowp, d_Lcols, Lvals, oe, e - oe, d_front_of, d_fstart + f0, d_fsize + f0, nf,
                          sym.front_maxdesc[l], d_flag));
   }

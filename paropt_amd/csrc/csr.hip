@@ -288,24 +288,114 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// An LDS hash table column -> value of the part of row i computed so far (open addressing, linear probing,
+// capacity a power of two >= twice the row length): a lookup is one or two LDS probes instead of a binary
+// search through L2.  Layout in dynamic LDS: tcap ints of keys, then tcap doubles of values.
+struct RowTable {
+  int *key;
+  double *val;
+  int mask;
+  __device__ __forceinline__ int slot(int k) const { return (int)(((unsigned)k * 2654435761u) >> 7) & mask; }
+  __device__ __forceinline__ void insert(int k, double v) {  // one inserting thread at a time
+    int h = slot(k);
+    while (key[h] != -1) h = (h + 1) & mask;
+    key[h] = k;
+    val[h] = v;
+  }
+  __device__ __forceinline__ void insert_shared(int k, double v) {  // concurrent inserts of distinct keys
+    int h = slot(k);
+    while (atomicCAS(&key[h], -1, k) != -1) h = (h + 1) & mask;
+    val[h] = v;
+  }
+  __device__ __forceinline__ double find(int k) const {  // 0 when absent
+    int h = slot(k);
+    int kk;
+    while ((kk = key[h]) != -1) {
+      if (kk == k) return val[h];
+      h = (h + 1) & mask;
+    }
+    return 0.0;
+  }
+};
+__device__ __forceinline__ RowTable row_table(int *lds, int tcap) {
+  RowTable t;
+  t.key = lds;
+  t.val = reinterpret_cast<double *>(lds + tcap);
+  t.mask = tcap - 1;
+  return t;
+}
+constexpr int kMaxTable = 4096;  // 16 KB of keys + 32 KB of values
+static int table_cap(int maxlen) {  // 0: the rows are too long, use the search kernels
+  int cap = 64;
+  while (cap < 2 * maxlen) cap <<= 1;
+  return cap <= kMaxTable ? cap : 0;
+}
+
 // Row Cholesky of one dependency level: one wavefront per row i, entries left to right,
 //   L_ij = (S_ij - sum_{k<j} L_ik L_jk) / L_jj,   L_ii = sqrt(S_ii - sum_k L_ik^2).
-// Row j (j < i) was finished by an earlier launch; the lanes stride over row j and look each column up
-// in the part of row i already computed (binary search on the sorted columns).
+// Row j (j < i) was finished by an earlier launch; the lanes stride over row j and look each column up in the
+// part of row i already computed: in the LDS table (TABLE) or by binary search on the sorted columns.
+template <int TABLE>
 __global__ void __launch_bounds__(64)
     chol_level_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals,
-                      const int *__restrict__ rows, int nrows, int *flag) {
+                      const int *__restrict__ rows, int nrows, int *flag, int tcap) {
+  extern __shared__ int lds[];
   const int i = rows[blockIdx.x];
   const int lane = threadIdx.x;
   const int p0 = Lrowp[i], pd = Lrowp[i + 1] - 1;
-  for (int p = p0; p <= pd; p++) {
+  RowTable tab = row_table(lds, TABLE ? tcap : 1);
+  if (TABLE) {
+    for (int h = lane; h < tcap; h += 64) tab.key[h] = -1;
+    __syncthreads();
+  }
+  double dsum = 0.0;
+  // 64 entries at a time: lane l fetches what entry pc + l needs from row j (its extent, its diagonal) and
+  // the entry's own assembled value, so that none of those loads sits on the sequential chain
+  for (int pc = p0; pc < pd; pc += 64) {
+  int mj = 0, mr0 = 0, mrd = 0;
+  double mdiag = 1.0, mval = 0.0;
+  if (pc + lane < pd) {
+    mj = Lcols[pc + lane];
+    mr0 = Lrowp[mj];
+    mrd = Lrowp[mj + 1] - 1;
+    mdiag = Lvals[mrd];
+    mval = Lvals[pc + lane];
+  }
+  const int cnt = pd - pc < 64 ? pd - pc : 64;
+  int nk = -1;
+  double nv = 0.0;
+  if (TABLE && cnt > 0) {
+    const int q = __shfl(mr0, 0, 64) + lane;
+    if (q < __shfl(mrd, 0, 64)) {
+      nk = Lcols[q];
+      nv = Lvals[q];
+    }
+  }
+  for (int e = 0; e < cnt; e++) {
+    const int p = pc + e;
     double acc = 0.0;
-    double v;
-    if (p < pd) {
-      const int j = Lcols[p];
-      const int r0 = Lrowp[j], rd = Lrowp[j + 1] - 1;
-      for (int q = r0 + lane; q < rd; q += 64) {
-        const int k = Lcols[q];
+    const int j = __shfl(mj, e, 64);
+    const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
+    const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
+    if (TABLE) {
+      // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
+      // the next entry start now, before this entry's arithmetic: they do not depend on it
+      const int ck = nk;
+      const double cv = nv;
+      nk = -1;
+      if (e + 1 < cnt) {
+        const int q = __shfl(mr0, e + 1, 64) + lane;
+        if (q < __shfl(mrd, e + 1, 64)) {
+          nk = Lcols[q];
+          nv = Lvals[q];
+        }
+      }
+      if (ck >= 0) acc = cv * tab.find(ck);
+      for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
+    }
+    for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
+      const int k = Lcols[q];
+      {
         int lo = p0, hi = p;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
@@ -317,25 +407,34 @@ __global__ void __launch_bounds__(64)
         }
         if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
       }
-      acc = wave_sum(acc);
-      v = (Lvals[p] - acc) / Lvals[rd];
-    } else {
-      for (int q = p0 + lane; q < pd; q += 64) acc += Lvals[q] * Lvals[q];
-      acc = wave_sum(acc);
-      double a = Lvals[p] - acc;
-      if (!(a > 0.0)) {
-        if (lane == 0) {
-          flag[0] = 1;
-          flag[1] = i;
-        }
-        a = 1.0;
-      }
-      v = sqrt(a);
     }
-    if (lane == 0) Lvals[p] = v;
-    __threadfence_block();
-    __syncthreads();
+    acc = wave_sum(acc);
+    const double v = (sval - acc) / jdiag;
+    dsum += v * v;
+    if (lane == 0) {
+      Lvals[p] = v;
+      if (TABLE) tab.insert(j, v);
+    }
+    if (TABLE) {
+      // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
+      // insert without a barrier (which would also wait for the loads just started); the fence only keeps
+      // the compiler from reordering
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    } else {
+      __threadfence_block();
+      __syncthreads();
+    }
   }
+  }
+  double a = Lvals[pd] - dsum;
+  if (!(a > 0.0)) {
+    if (lane == 0) {
+      flag[0] = 1;
+      flag[1] = i;
+    }
+    a = 1.0;
+  }
+  if (lane == 0) Lvals[pd] = sqrt(a);
 }
 // The same recurrence with ONE THREAD per row, for levels whose rows are short (the leaves of the
 // dissection tree: a wavefront per row would idle 60 of its 64 lanes and cost a workgroup launch per row).
@@ -370,12 +469,21 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows,
-                 int *flag, int thin) {
+                 int *flag, int thin, int maxlen) {
   if (nrows <= 0) return PO_OK;
   if (thin) {
     PO_CLAUNCH(chol_level_thin_kernel, cgrid(c, nrows), kBlock, Lrowp, Lcols, Lvals, rows, nrows, flag);
   } else {
-    PO_CLAUNCH(chol_level_kernel, nrows, 64, Lrowp, Lcols, Lvals, rows, nrows, flag);
+    const int tcap = table_cap(maxlen);
+    if (tcap > 0) {
+      hipLaunchKernelGGL(chol_level_kernel<1>, dim3(nrows), dim3(64), (size_t)tcap * 12, c->stream, Lrowp, Lcols,
+                         Lvals, rows, nrows, flag, tcap);
+    } else {
+      hipLaunchKernelGGL(chol_level_kernel<0>, dim3(nrows), dim3(64), 16, c->stream, Lrowp, Lcols, Lvals, rows,
+                         nrows, flag, 1);
+    }
+    c->n_launches++;
+    PO_HIP(hipGetLastError());
   }
   return PO_OK;
 }
@@ -384,71 +492,181 @@ int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, cons
 // Row f0 + r of a front ends with the columns f0 .. f0 + r: T(r, q) = Lvals[Lrowp[f0 + r + 1] - 1 - r + q].
 // Step 1 (all rows of all fronts of a level at once): the entries LEFT of the front, the recurrence of
 // chol_level_kernel stopped at column f0.
-// The columns of row i left of the front are staged in LDS (when they fit in `cap` ints) so that the binary
-// searches never leave the CU.
-__device__ __forceinline__ int front_search(const int *__restrict__ Lcols, const int *scol, bool cached, int p0,
-                                            int lo, int hi, int k) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const int cm = cached ? scol[mid - p0] : Lcols[mid];
-    if (cm < k) {
-      lo = mid + 1;
-    } else {
-      hi = mid;
-    }
-  }
-  return lo;
-}
+template <int TABLE>
 __global__ void __launch_bounds__(64)
     chol_front_rows_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals, int row0,
-                           const int *__restrict__ front_of, int cap) {
-  extern __shared__ int scol[];
+                           const int *__restrict__ front_of, int tcap) {
+  extern __shared__ int lds[];
   const int i = row0 + blockIdx.x;
   const int lane = threadIdx.x;
   const int f0 = front_of[i];
   const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - f0);
-  const bool cached = pe - p0 <= cap;
-  if (cached) {
-    for (int q = p0 + lane; q < pe; q += 64) scol[q - p0] = Lcols[q];
+  RowTable tab = row_table(lds, TABLE ? tcap : 1);
+  if (TABLE) {
+    for (int h = lane; h < tcap; h += 64) tab.key[h] = -1;
+    __syncthreads();
   }
-  __syncthreads();
-  for (int p = p0; p < pe; p++) {
+  for (int pc = p0; pc < pe; pc += 64) {  // metadata of 64 entries at a time, off the sequential chain
+  int mj = 0, mr0 = 0, mrd = 0;
+  double mdiag = 1.0, mval = 0.0;
+  if (pc + lane < pe) {
+    mj = Lcols[pc + lane];
+    mr0 = Lrowp[mj];
+    mrd = Lrowp[mj + 1] - 1;
+    mdiag = Lvals[mrd];
+    mval = Lvals[pc + lane];
+  }
+  const int cnt = pe - pc < 64 ? pe - pc : 64;
+  int nk = -1;
+  double nv = 0.0;
+  if (TABLE && cnt > 0) {
+    const int q = __shfl(mr0, 0, 64) + lane;
+    if (q < __shfl(mrd, 0, 64)) {
+      nk = Lcols[q];
+      nv = Lvals[q];
+    }
+  }
+  for (int e = 0; e < cnt; e++) {
+    const int p = pc + e;
     double acc = 0.0;
-    const int j = cached ? scol[p - p0] : Lcols[p];
-    const int r0 = Lrowp[j], rd = Lrowp[j + 1] - 1;
-    for (int q = r0 + lane; q < rd; q += 64) {
+    const int j = __shfl(mj, e, 64);
+    const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
+    const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
+    if (TABLE) {
+      // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
+      // the next entry start now, before this entry's arithmetic: they do not depend on it
+      const int ck = nk;
+      const double cv = nv;
+      nk = -1;
+      if (e + 1 < cnt) {
+        const int q = __shfl(mr0, e + 1, 64) + lane;
+        if (q < __shfl(mrd, e + 1, 64)) {
+          nk = Lcols[q];
+          nv = Lvals[q];
+        }
+      }
+      if (ck >= 0) acc = cv * tab.find(ck);
+      for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
+    }
+    for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
       const int k = Lcols[q];
-      const int lo = front_search(Lcols, scol, cached, p0, p0, p, k);
-      if (lo < p && (cached ? scol[lo - p0] : Lcols[lo]) == k) acc += Lvals[q] * Lvals[lo];
+      {
+        int lo = p0, hi = p;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (Lcols[mid] < k) {
+            lo = mid + 1;
+          } else {
+            hi = mid;
+          }
+        }
+        if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+      }
     }
     acc = wave_sum(acc);
-    if (lane == 0) Lvals[p] = (Lvals[p] - acc) / Lvals[rd];
-    __threadfence_block();
-    __syncthreads();
+    const double v = (sval - acc) / jdiag;
+    if (lane == 0) {
+      Lvals[p] = v;
+      if (TABLE) tab.insert(j, v);
+    }
+    if (TABLE) {
+      // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
+      // insert without a barrier (which would also wait for the loads just started); the fence only keeps
+      // the compiler from reordering
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    } else {
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  }
+}
+// The same step for levels whose front rows are LONG (the top separators: thousands of entries, each a dot with a
+// row of hundreds): NW wavefronts share a row, every entry's dot is split over all of them and combined through
+// LDS.  Two barriers per entry, but 1/NW of the arithmetic on the sequential chain.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+    chol_front_rows_wide_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals,
+                                int row0, const int *__restrict__ front_of, int tcap) {
+  extern __shared__ int lds[];
+  __shared__ double red[NW];
+  __shared__ double vbroadcast;
+  const int i = row0 + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f0 = front_of[i];
+  const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - f0);
+  RowTable tab = row_table(lds, tcap);
+  for (int h = tid; h < tcap; h += 64 * NW) tab.key[h] = -1;
+  __syncthreads();
+  for (int pc = p0; pc < pe; pc += 64) {
+    int mj = 0, mr0 = 0, mrd = 0;
+    double mdiag = 1.0, mval = 0.0;
+    if (pc + lane < pe) {  // every wavefront keeps its own copy of the chunk's metadata
+      mj = Lcols[pc + lane];
+      mr0 = Lrowp[mj];
+      mrd = Lrowp[mj + 1] - 1;
+      mdiag = Lvals[mrd];
+      mval = Lvals[pc + lane];
+    }
+    const int cnt = pe - pc < 64 ? pe - pc : 64;
+    for (int e = 0; e < cnt; e++) {
+      const int j = __shfl(mj, e, 64);
+      const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
+      const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
+      double acc = 0.0;
+      for (int q = r0 + tid; q < rd; q += 64 * NW) acc += Lvals[q] * tab.find(Lcols[q]);
+      acc = wave_sum(acc);
+      if (lane == 0) red[wave] = acc;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) tot += red[k];
+        const double v = (sval - tot) / jdiag;
+        Lvals[pc + e] = v;
+        tab.insert(j, v);
+      }
+      __syncthreads();
+    }
   }
 }
 // Step 2: T(i, j) -= sum over the columns left of the front of L_ik L_jk, one wavefront per pair, four
-// wavefronts share a row i.
+// wavefronts share a row i (whose left part sits in the LDS table).
+template <int TABLE>
 __global__ void __launch_bounds__(kBlock)
     chol_front_syrk_kernel(const int *__restrict__ Lrowp, const int *__restrict__ Lcols, double *Lvals, int row0,
-                           const int *__restrict__ front_of, int cap) {
-  extern __shared__ int scol[];
+                           const int *__restrict__ front_of, int tcap) {
+  extern __shared__ int lds[];
   const int i = row0 + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int f0 = front_of[i];
   const int p0 = Lrowp[i], pe = Lrowp[i + 1] - 1 - (i - f0);
-  const bool cached = pe - p0 <= cap;
-  if (cached) {
-    for (int q = p0 + (int)threadIdx.x; q < pe; q += kBlock) scol[q - p0] = Lcols[q];
+  RowTable tab = row_table(lds, TABLE ? tcap : 1);
+  if (TABLE) {
+    for (int h = threadIdx.x; h < tcap; h += kBlock) tab.key[h] = -1;
+    __syncthreads();
+    for (int q = p0 + (int)threadIdx.x; q < pe; q += kBlock) tab.insert_shared(Lcols[q], Lvals[q]);
+    __syncthreads();
   }
-  __syncthreads();
   for (int j = f0 + wave; j <= i; j += 4) {
     const int r0 = Lrowp[j], re = Lrowp[j + 1] - 1 - (j - f0);
     double acc = 0.0;
     for (int q = r0 + lane; q < re; q += 64) {
       const int k = Lcols[q];
-      const int lo = front_search(Lcols, scol, cached, p0, p0, pe, k);
-      if (lo < pe && (cached ? scol[lo - p0] : Lcols[lo]) == k) acc += Lvals[q] * Lvals[lo];
+      if (TABLE) {
+        acc += Lvals[q] * tab.find(k);
+      } else {
+        int lo = p0, hi = pe;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (Lcols[mid] < k) {
+            lo = mid + 1;
+          } else {
+            hi = mid;
+          }
+        }
+        if (lo < pe && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+      }
     }
     acc = wave_sum(acc);
     if (lane == 0) Lvals[pe + (j - f0)] -= acc;
@@ -490,13 +708,26 @@ __global__ void __launch_bounds__(kFrontThreads)
 int k_chol_fronts(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, int row0, int nrows,
                   const int *front_of, const int *fstart, const int *fsize, int nfronts, int maxdesc, int *flag) {
   if (nrows <= 0 || nfronts <= 0) return PO_OK;
-  const int cap = maxdesc < 12288 ? (maxdesc > 0 ? maxdesc : 1) : 12288;  // ints of LDS per workgroup (<= 48 KB)
-  hipLaunchKernelGGL(chol_front_rows_kernel, dim3(nrows), dim3(64), cap * sizeof(int), c->stream, Lrowp, Lcols,
-                     Lvals, row0, front_of, cap);
+  const int tcap = table_cap(maxdesc);
+  if (tcap > 0 && maxdesc >= 256) {
+    hipLaunchKernelGGL(chol_front_rows_wide_kernel<8>, dim3(nrows), dim3(512), (size_t)tcap * 12, c->stream, Lrowp,
+                       Lcols, Lvals, row0, front_of, tcap);
+  } else if (tcap > 0) {
+    hipLaunchKernelGGL(chol_front_rows_kernel<1>, dim3(nrows), dim3(64), (size_t)tcap * 12, c->stream, Lrowp, Lcols,
+                       Lvals, row0, front_of, tcap);
+  } else {
+    hipLaunchKernelGGL(chol_front_rows_kernel<0>, dim3(nrows), dim3(64), 16, c->stream, Lrowp, Lcols, Lvals, row0,
+                       front_of, 1);
+  }
   c->n_launches++;
   PO_HIP(hipGetLastError());
-  hipLaunchKernelGGL(chol_front_syrk_kernel, dim3(nrows), dim3(kBlock), cap * sizeof(int), c->stream, Lrowp, Lcols,
-                     Lvals, row0, front_of, cap);
+  if (tcap > 0) {
+    hipLaunchKernelGGL(chol_front_syrk_kernel<1>, dim3(nrows), dim3(kBlock), (size_t)tcap * 12, c->stream, Lrowp,
+                       Lcols, Lvals, row0, front_of, tcap);
+  } else {
+    hipLaunchKernelGGL(chol_front_syrk_kernel<0>, dim3(nrows), dim3(kBlock), 16, c->stream, Lrowp, Lcols, Lvals,
+                       row0, front_of, 1);
+  }
   c->n_launches++;
   PO_HIP(hipGetLastError());
   PO_CLAUNCH(chol_front_dense_kernel, nfronts, kFrontThreads, Lrowp, Lvals, fstart, fsize, flag);

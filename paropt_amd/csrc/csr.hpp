@@ -119,7 +119,7 @@ int k_csr_assemble(Ctx *c, const int *rowp, const int *cols, const double *vals,
                    const double *cdiag, const int *ent_a, const int *ent_b, const int *ent_slot, int64_t nent,
                    double *Lvals);
 int k_chol_level(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, const int *rows, int nrows, int *flag,
-                 int thin);
+                 int thin, int maxlen);
 int k_chol_fronts(Ctx *c, const int *Lrowp, const int *Lcols, double *Lvals, int row0, int nrows,
                   const int *front_of, const int *fstart, const int *fsize, int nfronts, int maxdesc, int *flag);
 int k_trsv_fronts_fwd(Ctx *c, const int *Lrowp, const int *Lcols, const double *Lvals, int row0, int nrows,
