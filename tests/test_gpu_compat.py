@@ -364,3 +364,154 @@ def test_electron_style_sparse_equalities_csr():
     np.testing.assert_allclose(np.sum(xa.reshape(3, ne) ** 2, axis=0), 1.0, atol=1e-6)  # on the sphere
     np.testing.assert_allclose(xa, oip.vars.x, rtol=0, atol=1e-6)
     np.testing.assert_allclose(np.array(zw[:]), oip.vars.zw, rtol=0, atol=1e-5 * max(1.0, np.abs(oip.vars.zw).max()))
+
+
+def test_polygon_style_dense_vs_sparse_forms():
+    """The shape of the reference's examples/COPS/polygon/polygon.py (largest small polygon): MORE sparse
+    constraints than variables (nv-1 ordering rows of 2 entries, nv(nv-1)/2 distance rows of 4), every row
+    overlapping many others, so S = C + Aw D^-1 Aw^T is essentially dense (one big front).  The same problem is
+    posed (a) with all constraints dense (c = 54 columns in the Gram panel) and (b) in the CSR form; (b) is
+    checked against the numpy oracle over the first 60 iterations, (a) and (b) against each other at the end."""
+    from oracle import paropt_oracle as po
+    from paropt_amd import ParOpt
+
+    nv = 10
+    n = 2 * nv
+    pairs = [(i, j) for i in range(nv - 1) for j in range(i + 1, nv)]
+    nc1, nc2 = nv - 1, len(pairs)
+    w = nc1 + nc2
+    rng = np.random.RandomState(0)
+    x0 = np.concatenate([rng.uniform(0.1, 0.9, nv), np.linspace(0.1 * np.pi, 0.9 * np.pi, nv)])
+    lbv = np.zeros(n)
+    ubv = np.concatenate([np.full(nv, 10.0), np.full(nv, np.pi)])
+    rowp, cols = [0], []
+    for i in range(nv - 1):
+        cols += [nv + i, nv + i + 1]
+        rowp.append(len(cols))
+    for i, j in pairs:
+        cols += [i, j, nv + i, nv + j]
+        rowp.append(len(cols))
+    pi_, pj_ = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+
+    def fobj_grad(x):
+        r, t = x[:nv], x[nv:]
+        s, c = np.sin(t[1:] - t[:-1]), np.cos(t[1:] - t[:-1])
+        f = -0.5 * np.sum(r[:-1] * r[1:] * s)
+        g = np.zeros(n)
+        g[:nv - 1] -= 0.5 * r[1:] * s
+        g[1:nv] -= 0.5 * r[:-1] * s
+        g[nv:n - 1] += 0.5 * r[:-1] * r[1:] * c
+        g[nv + 1:] -= 0.5 * r[:-1] * r[1:] * c
+        return f, g
+
+    def cons_jac(x):
+        r, t = x[:nv], x[nv:]
+        cval = np.concatenate([t[1:] - t[:-1],
+                               1.0 - r[pi_] ** 2 - r[pj_] ** 2 + 2.0 * r[pi_] * r[pj_] * np.cos(t[pi_] - t[pj_])])
+        cc, sc = np.cos(t[pi_] - t[pj_]), np.sin(t[pi_] - t[pj_])
+        d2 = np.stack([-2.0 * r[pi_] + 2.0 * r[pj_] * cc, -2.0 * r[pj_] + 2.0 * r[pi_] * cc,
+                       -2.0 * r[pi_] * r[pj_] * sc, 2.0 * r[pi_] * r[pj_] * sc], axis=1)
+        data = np.concatenate([np.tile([-1.0, 1.0], nc1), d2.reshape(-1)])
+        return cval, data
+
+    def dense_rows(data):
+        A = np.zeros((w, n))
+        for i in range(w):
+            A[i, cols[rowp[i]:rowp[i + 1]]] = data[rowp[i]:rowp[i + 1]]
+        return A
+
+    class SparsePolygon(ParOpt.Problem):
+        def __init__(self):
+            super(SparsePolygon, self).__init__(None, nvars=n, num_sparse_constraints=w, rowp=rowp, cols=cols)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = x0, lbv, ubv
+
+        def evalSparseObjCon(self, x, sparse_cons):
+            xa = np.array(x[:])
+            sparse_cons[:] = cons_jac(xa)[0]
+            return 0, fobj_grad(xa)[0], []
+
+        def evalSparseObjConGradient(self, x, g, A, data):
+            xa = np.array(x[:])
+            g[:] = fobj_grad(xa)[1]
+            data[:] = cons_jac(xa)[1]
+            return 0
+
+    class DensePolygon(ParOpt.Problem):
+        def __init__(self):
+            super(DensePolygon, self).__init__(None, nvars=n, num_dense_constraints=w)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = x0, lbv, ubv
+
+        def evalObjCon(self, x):
+            xa = np.array(x[:])
+            return 0, fobj_grad(xa)[0], cons_jac(xa)[0]
+
+        def evalObjConGradient(self, x, g, A):
+            xa = np.array(x[:])
+            g[:] = fobj_grad(xa)[1]
+            J = dense_rows(cons_jac(xa)[1])
+            for i in range(w):
+                A[i][:] = J[i]
+            return 0
+
+    class OraclePolygon:
+        comm = po.SelfComm()
+        nlocal, c, nwcon, nwineq, csr_form = n, 0, w, w, True
+
+        def vars_and_bounds(self):
+            return x0.copy(), lbv.copy(), ubv.copy()
+
+        def eval_obj_con(self, x):
+            self._cw = cons_jac(x)[0]
+            return 0, fobj_grad(x)[0], np.zeros(0)
+
+        def eval_obj_con_gradient(self, x):
+            self._A = dense_rows(cons_jac(x)[1])
+            return 0, fobj_grad(x)[1], []
+
+        def eval_sparse_con(self, x):
+            return self._cw.copy()
+
+        def sparse_jacobian_dense(self):
+            return self._A
+
+        def add_sparse_jacobian(self, alpha, px, out):
+            out += alpha * (self._A @ px)
+            return out
+
+        def add_sparse_jacobian_transpose(self, alpha, pzw, out):
+            out += alpha * (self._A.T @ pzw)
+            return out
+
+    opts = {"norm_type": "infinity", "qn_type": "bfgs", "qn_subspace_size": 10,
+            "starting_point_strategy": "least_squares_multipliers", "qn_update_type": "damped_update",
+            "abs_res_tol": 1e-6, "barrier_strategy": "monotone", "armijo_constant": 1e-5, "penalty_gamma": 100.0,
+            "max_major_iters": 400}
+    # (b) against the oracle over the first 60 iterations (the run needs several hundred, as the reference
+    # example's own max_major_iters = 500 says; long trajectories part by round-off)
+    short = dict(opts, max_major_iters=60)
+    sp = ParOpt.Optimizer(SparsePolygon(), dict(short, algorithm="ip", output_file=None))
+    sp.optimize()
+    xs = np.array(sp.getOptimizedPoint()[0][:])
+    oip = po.InteriorPoint(OraclePolygon(), dict(short))
+    oip.optimize()
+    assert sp.ip.getIterationCounters() == (oip.niter, oip.neval, oip.ngeval)
+    np.testing.assert_allclose(xs, oip.vars.x, rtol=0, atol=1e-6)
+    # (a) and (b) to the end
+    opts["max_major_iters"] = 500
+    sp = ParOpt.Optimizer(SparsePolygon(), dict(opts, algorithm="ip", output_file=None))
+    sp.optimize()
+    xs = np.array(sp.getOptimizedPoint()[0][:])
+    dn = ParOpt.Optimizer(DensePolygon(), dict(opts, algorithm="ip", output_file=None))
+    dn.optimize()
+    xd = np.array(dn.getOptimizedPoint()[0][:])
+    # (the example does not pin a vertex at the origin, so the "area" is that of the fan from the origin and the
+    # optimum sits at large radii; what matters here is that both forms stay feasible and agree)
+    for xx in (xs, xd):
+        assert cons_jac(xx)[0].min() >= -1e-5  # ordered angles, all pairwise distances <= 1
+        assert fobj_grad(xx)[0] < fobj_grad(x0)[0]
+    print("polygon objective: sparse form %.8f, dense form %.8f" % (fobj_grad(xs)[0], fobj_grad(xd)[0]))
+    assert abs(fobj_grad(xs)[0] - fobj_grad(xd)[0]) <= 1e-2 * abs(fobj_grad(xd)[0])
