@@ -272,7 +272,9 @@ int po_ip_get_hvec_count(po_ip ip, int *nhvec);
 int po_ip_reset_design_and_bounds(po_ip ip);                /* .cpp:1249-1251 */
 int po_ip_reset_quasi_newton(po_ip ip);                     /* resetQuasiNewtonHessian .cpp:1241-1245 */
 int po_ip_get_quasi_newton(po_ip ip, po_qn *qn);            /* borrowed */
-int po_ip_write_solution_file(po_ip ip, const char *filename); /* .cpp:883-972 (rank-local shard) */
+/* collective: ONE file in the reference's MPI-IO layout whatever the rank count (rank 0 writes the header and
+ * the dense blocks, every rank its block of x, zl, zu, zw, sw at its global offset) */
+int po_ip_write_solution_file(po_ip ip, const char *filename); /* .cpp:883-972 */
 int po_ip_read_solution_file(po_ip ip, const char *filename);  /* .cpp:983-1104 (restart) */
 /* Per-iteration observer, called at the point the reference calls prob->writeOutput
  * (.cpp:4620-4630); used by the parity tests to snapshot the state. */
