@@ -672,15 +672,48 @@ __global__ void __launch_bounds__(kBlock)
     if (lane == 0) Lvals[pe + (j - f0)] -= acc;
   }
 }
-// Step 3: dense right-looking Cholesky of the triangle, one workgroup of 1024 per front.
+// Step 3: dense right-looking Cholesky of the triangle, one workgroup of 1024 per front.  Per column: the
+// scaled column goes to LDS (and back to L), then the trailing triangle is updated from LDS - two barriers.
 constexpr int kFrontThreads = 1024;
+constexpr int kFrontLds = 2048;  // fronts up to this many rows keep their row offsets and the column in LDS
+#define PO_T(r, q) Lvals[Lrowp[f0 + (r) + 1] - 1 - (r) + (q)]
 __global__ void __launch_bounds__(kFrontThreads)
     chol_front_dense_kernel(const int *__restrict__ Lrowp, double *Lvals, const int *__restrict__ fstart,
                             const int *__restrict__ fsize, int *flag) {
+  __shared__ int tb[kFrontLds];
+  __shared__ double colk[kFrontLds];
   const int f0 = fstart[blockIdx.x], s = fsize[blockIdx.x];
   const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
-#define PO_T(r, q) Lvals[Lrowp[f0 + (r) + 1] - 1 - (r) + (q)]
-  for (int k = 0; k < s; k++) {
+  if (s <= kFrontLds) {
+    for (int r = tid; r < s; r += kFrontThreads) tb[r] = Lrowp[f0 + r + 1] - 1 - r;
+    __syncthreads();
+    for (int k = 0; k < s; k++) {
+      double a = Lvals[tb[k] + k];  // final since the previous trailing update
+      if (!(a > 0.0)) {
+        if (tid == 0) {
+          flag[0] = 1;
+          flag[1] = f0 + k;
+        }
+        a = 1.0;
+      }
+      const double d = sqrt(a);
+      for (int r = k + tid; r < s; r += kFrontThreads) {
+        const double v = r == k ? d : Lvals[tb[r] + k] / d;
+        colk[r] = v;
+        Lvals[tb[r] + k] = v;
+      }
+      __syncthreads();
+      for (int r = k + 1 + ty; r < s; r += 32) {
+        const int base = tb[r];
+        const double lrk = colk[r];
+        for (int q = k + 1 + tx; q <= r; q += 32) Lvals[base + q] -= lrk * colk[q];
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    return;
+  }
+  for (int k = 0; k < s; k++) {  // very large fronts: the same through global memory
     if (tid == 0) {
       double a = PO_T(k, k);
       if (!(a > 0.0)) {
