@@ -94,3 +94,28 @@ def test_bad_patterns_are_rejected():
         CsrSymbolic(5, np.array([0, 1], dtype=np.intc), np.array([5], dtype=np.intc))  # out of range
     with pytest.raises(ParOptAMDError):
         CsrSymbolic(5, np.array([0, 2, 1], dtype=np.intc), np.array([0, 1], dtype=np.intc))  # rowp decreasing
+
+
+def test_symbolic_random_soak():
+    """Twenty random patterns (grids with extra random rows, local and global random rows): the schedule's
+    dependency rules hold and the emulated factorization reproduces S."""
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        if trial % 2 == 0:
+            nx, ny = int(rng.integers(4, 26)), int(rng.integers(4, 26))
+            n = nx * ny
+            rowp, cols = grid_pattern(nx, ny)
+            ep, ec = random_pattern(n, int(rng.integers(0, 20)), 6, int(rng.integers(1 << 30)))
+            rowp = np.concatenate([rowp, rowp[-1] + ep[1:]]).astype(np.intc)
+            cols = np.concatenate([cols, ec]).astype(np.intc)
+        else:
+            n = int(rng.integers(20, 300))
+            rowp, cols = random_pattern(n, int(rng.integers(1, 250)), int(rng.integers(1, 12)),
+                                        int(rng.integers(1 << 30)), local=int(rng.integers(4, 50)))
+        w = len(rowp) - 1
+        sym = CsrSymbolic(n, rowp, cols)
+        data = rng.uniform(0.5, 1.5, size=int(rowp[-1]))
+        A = dense_jacobian(n, rowp, cols, data)
+        S = np.diag(rng.uniform(0.1, 1.0, size=w)) + (A * rng.uniform(0.5, 2.0, size=n)) @ A.T
+        L, Sp = emulate_factor(sym, S)
+        np.testing.assert_allclose(L @ L.T, Sp, rtol=1e-11, atol=1e-11)

@@ -436,3 +436,54 @@ def test_interior_point_on_grid_pattern_with_fronts(ctx):
     np.testing.assert_allclose(ip.getOptimizedPoint()[0].to_numpy(), oip.vars.x, rtol=0, atol=1e-7)
     zw = ip.getOptimizedSparse()[0].to_numpy()
     np.testing.assert_allclose(zw, oip.vars.zw, rtol=0, atol=1e-6 * max(1.0, np.abs(oip.vars.zw).max()))
+
+
+def test_quasidef_solve_random_soak(ctx):
+    """Thirty random patterns (row lengths, locality, grids with random extra rows) against dense solves: guards
+    the corner cases of the scheduler (levels without ordinary rows, fronts next to thin rows, table capacity at
+    its limits, empty rows)."""
+    import paropt_amd as pa
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for trial in range(30):
+        kind = trial % 3
+        if kind == 0:
+            n = int(rng.integers(20, 400))
+            w = int(rng.integers(1, 300))
+            rowp, cols = random_pattern(n, w, int(rng.integers(1, 9)), int(rng.integers(1 << 30)),
+                                        local=int(rng.integers(4, 40)))
+        elif kind == 1:
+            n = int(rng.integers(20, 200))
+            w = int(rng.integers(1, 120))
+            rowp, cols = random_pattern(n, w, int(rng.integers(1, 40)), int(rng.integers(1 << 30)))
+        else:
+            nx, ny = int(rng.integers(4, 30)), int(rng.integers(4, 30))
+            n = nx * ny
+            rowp, cols = grid_pattern(nx, ny)
+            extra_p, extra_c = random_pattern(n, int(rng.integers(0, 30)), 6, int(rng.integers(1 << 30)))
+            rowp = np.concatenate([rowp, rowp[-1] + extra_p[1:]]).astype(np.intc)
+            cols = np.concatenate([cols, extra_c]).astype(np.intc)
+        w = len(rowp) - 1
+        if rowp[-1] == 0:
+            continue
+        data = rng.uniform(-1.5, 1.5, size=int(rowp[-1]))
+        prob = PatternProblem(ctx, n, rowp, cols, data)
+        pa.InteriorPoint(prob, {"max_major_iters": 0}).optimize()
+        A = dense_jacobian(n, rowp, cols, data)
+        d = rng.uniform(0.2, 3.0, size=n)
+        c = rng.uniform(0.05, 2.0, size=w)
+        S = np.diag(c) + (A * d) @ A.T
+        x = _vec(ctx, np.full(n, 0.5))
+        dv, cv = _vec(ctx, d), _vec(ctx, c)
+        pa.quasidef_factor(prob, x, dv, cv)
+        bx, bw = rng.standard_normal(n), rng.standard_normal(w)
+        yx, yw = pa.PVec(ctx, n), pa.PVec(ctx, w)
+        pa.quasidef_apply(prob, x, dv, cv, _vec(ctx, bx), _vec(ctx, bw), yx, yw)
+        yw_ref = np.linalg.solve(S, bw - A @ (d * bx))
+        err = np.abs(yw.to_numpy() - yw_ref).max() / max(1.0, np.abs(yw_ref).max())
+        worst = max(worst, err)
+        assert err <= 1e-9, (trial, kind, n, w, err)
+        yx_ref = d * (bx + A.T @ yw_ref)
+        np.testing.assert_allclose(yx.to_numpy(), yx_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(yx_ref).max()))
+    assert worst <= 1e-9
