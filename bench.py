@@ -156,6 +156,7 @@ def main():
     def cb(k):
         if k == W:
             barrier_sync()
+            stamp["counters0"] = ctx.counters()
             stamp["t0"] = time.perf_counter()
 
     ip.setIterationCallback(cb)
@@ -164,6 +165,9 @@ def main():
     barrier_sync()
     t1 = time.perf_counter()
     elapsed = t1 - stamp["t0"]
+    red1, lau1 = ctx.counters()
+    red_per_iter = (red1 - stamp["counters0"][0]) / float(a.steps)
+    launches_per_iter = (lau1 - stamp["counters0"][1]) / float(a.steps)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,7 +220,8 @@ def main():
                                        if a.nwcon > 0 else ("config 3" if a.problem == "convex" else "config 2"),
                                        a.problem, a.n, a.ncon, a.qn.upper(), a.qn_size, world),
                        "n_global": a.n, "ncon": a.ncon, "nwcon": a.nwcon, "qn": a.qn, "evals_per_iter": (neval - 1) / float(niter),
-                       "collective": comm_kind},
+                       "collective": comm_kind, "reductions_per_iter": red_per_iter,
+                       "launches_per_iter": launches_per_iter},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "phase_ms_per_iter": {k: 1e3 * v / niter for k, v in phases.items()},

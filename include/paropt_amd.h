@@ -55,6 +55,9 @@ int po_ctx_synchronize(po_ctx ctx);
 int po_ctx_rank(po_ctx ctx, int *rank, int *size);
 /* The HIP stream every kernel of this context is launched on (a hipStream_t). */
 void *po_ctx_stream(po_ctx ctx);
+/* Diagnostics: host-synchronising reductions (= collectives when there is more than one rank) and kernel launches
+ * issued on this context so far. */
+int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
 /* Copy between a host buffer and a raw device array this library handed out (the Jacobian entries of
  * po_problem_set_sparse_jacobian_data), ordered with the context's stream; returns when the copy is done.
  * to_device != 0: host -> device. */

@@ -32,6 +32,12 @@ class Context:
     def synchronize(self):
         check(lib.po_ctx_synchronize(self._h))
 
+    def counters(self):
+        """(host-synchronising reductions, kernel launches) issued on this context so far."""
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.po_ctx_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def init_rccl_from_torch(self):
         """One process per GPU: ship the RCCL unique id over torch.distributed, then init."""
         import torch.distributed as dist

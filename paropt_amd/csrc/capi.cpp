@@ -58,6 +58,12 @@ int po_ctx_rank(po_ctx ctx, int *rank, int *size) {
   return PO_OK;
 }
 void *po_ctx_stream(po_ctx ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
+  PO_CHECK_PTR(ctx);
+  if (reductions) *reductions = ctx->n_reductions;
+  if (launches) *launches = ctx->n_launches;
+  return PO_OK;
+}
 int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_device) {
   PO_CHECK_PTR(ctx);
   if (bytes <= 0) return PO_OK;
