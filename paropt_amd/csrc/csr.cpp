@@ -21,7 +21,7 @@ int internal_error(const char *what) {
 }
 
 // subsets this small are numbered as they come (PAROPT_AMD_ND_LEAF overrides, for experiments)
-static int leaf_size() {
+int leaf_size() {
   static int v = 0;
   if (v == 0) {
     const char *e = getenv("PAROPT_AMD_ND_LEAF");
@@ -29,7 +29,6 @@ static int leaf_size() {
   }
   return v;
 }
-#define kLeaf leaf_size()
 
 // Nested dissection from BFS level structures (George's automatic nested dissection): the middle
 // level of a rooted level structure from a pseudo-peripheral vertex separates the graph; the two
@@ -75,7 +74,7 @@ struct Dissector {
 
   // number the vertices of `verts` (all carrying region id `reg`) into positions [lo, lo + |verts|)
   void order(std::vector<int> &verts, int reg, int lo, int depth) {
-    if ((int)verts.size() <= kLeaf || depth > 96) {
+    if ((int)verts.size() <= leaf_size() || depth > 96) {
       number(verts, lo);
       return;
     }
@@ -88,7 +87,7 @@ struct Dissector {
       if (region[verts[s]] != reg) continue;
       const int r = next_region++;
       bfs(verts[s], reg, comp, r);
-      if ((int)comp.size() <= kLeaf) {
+      if ((int)comp.size() <= leaf_size()) {
         small.insert(small.end(), comp.begin(), comp.end());
       } else {
         big.push_back(comp);

@@ -352,79 +352,79 @@ __global__ void __launch_bounds__(64)
   // 64 entries at a time: lane l fetches what entry pc + l needs from row j (its extent, its diagonal) and
   // the entry's own assembled value, so that none of those loads sits on the sequential chain
   for (int pc = p0; pc < pd; pc += 64) {
-  int mj = 0, mr0 = 0, mrd = 0;
-  double mdiag = 1.0, mval = 0.0;
-  if (pc + lane < pd) {
-    mj = Lcols[pc + lane];
-    mr0 = Lrowp[mj];
-    mrd = Lrowp[mj + 1] - 1;
-    mdiag = Lvals[mrd];
-    mval = Lvals[pc + lane];
-  }
-  const int cnt = pd - pc < 64 ? pd - pc : 64;
-  int nk = -1;
-  double nv = 0.0;
-  if (TABLE && cnt > 0) {
-    const int q = __shfl(mr0, 0, 64) + lane;
-    if (q < __shfl(mrd, 0, 64)) {
-      nk = Lcols[q];
-      nv = Lvals[q];
+    int mj = 0, mr0 = 0, mrd = 0;
+    double mdiag = 1.0, mval = 0.0;
+    if (pc + lane < pd) {
+      mj = Lcols[pc + lane];
+      mr0 = Lrowp[mj];
+      mrd = Lrowp[mj + 1] - 1;
+      mdiag = Lvals[mrd];
+      mval = Lvals[pc + lane];
     }
-  }
-  for (int e = 0; e < cnt; e++) {
-    const int p = pc + e;
-    double acc = 0.0;
-    const int j = __shfl(mj, e, 64);
-    const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
-    const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
-    if (TABLE) {
-      // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
-      // the next entry start now, before this entry's arithmetic: they do not depend on it
-      const int ck = nk;
-      const double cv = nv;
-      nk = -1;
-      if (e + 1 < cnt) {
-        const int q = __shfl(mr0, e + 1, 64) + lane;
-        if (q < __shfl(mrd, e + 1, 64)) {
-          nk = Lcols[q];
-          nv = Lvals[q];
-        }
+    const int cnt = pd - pc < 64 ? pd - pc : 64;
+    int nk = -1;
+    double nv = 0.0;
+    if (TABLE && cnt > 0) {
+      const int q = __shfl(mr0, 0, 64) + lane;
+      if (q < __shfl(mrd, 0, 64)) {
+        nk = Lcols[q];
+        nv = Lvals[q];
       }
-      if (ck >= 0) acc = cv * tab.find(ck);
-      for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
     }
-    for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
-      const int k = Lcols[q];
-      {
-        int lo = p0, hi = p;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (Lcols[mid] < k) {
-            lo = mid + 1;
-          } else {
-            hi = mid;
+    for (int e = 0; e < cnt; e++) {
+      const int p = pc + e;
+      double acc = 0.0;
+      const int j = __shfl(mj, e, 64);
+      const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
+      const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
+      if (TABLE) {
+        // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
+        // the next entry start now, before this entry's arithmetic: they do not depend on it
+        const int ck = nk;
+        const double cv = nv;
+        nk = -1;
+        if (e + 1 < cnt) {
+          const int q = __shfl(mr0, e + 1, 64) + lane;
+          if (q < __shfl(mrd, e + 1, 64)) {
+            nk = Lcols[q];
+            nv = Lvals[q];
           }
         }
-        if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+        if (ck >= 0) acc = cv * tab.find(ck);
+        for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
+      }
+      for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
+        const int k = Lcols[q];
+        {
+          int lo = p0, hi = p;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (Lcols[mid] < k) {
+              lo = mid + 1;
+            } else {
+              hi = mid;
+            }
+          }
+          if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+        }
+      }
+      acc = wave_sum(acc);
+      const double v = (sval - acc) / jdiag;
+      dsum += v * v;
+      if (lane == 0) {
+        Lvals[p] = v;
+        if (TABLE) tab.insert(j, v);
+      }
+      if (TABLE) {
+        // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
+        // insert without a barrier (which would also wait for the loads just started); the fence only keeps
+        // the compiler from reordering
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      } else {
+        __threadfence_block();
+        __syncthreads();
       }
     }
-    acc = wave_sum(acc);
-    const double v = (sval - acc) / jdiag;
-    dsum += v * v;
-    if (lane == 0) {
-      Lvals[p] = v;
-      if (TABLE) tab.insert(j, v);
-    }
-    if (TABLE) {
-      // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
-      // insert without a barrier (which would also wait for the loads just started); the fence only keeps
-      // the compiler from reordering
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    } else {
-      __threadfence_block();
-      __syncthreads();
-    }
-  }
   }
   double a = Lvals[pd] - dsum;
   if (!(a > 0.0)) {
@@ -507,78 +507,78 @@ __global__ void __launch_bounds__(64)
     __syncthreads();
   }
   for (int pc = p0; pc < pe; pc += 64) {  // metadata of 64 entries at a time, off the sequential chain
-  int mj = 0, mr0 = 0, mrd = 0;
-  double mdiag = 1.0, mval = 0.0;
-  if (pc + lane < pe) {
-    mj = Lcols[pc + lane];
-    mr0 = Lrowp[mj];
-    mrd = Lrowp[mj + 1] - 1;
-    mdiag = Lvals[mrd];
-    mval = Lvals[pc + lane];
-  }
-  const int cnt = pe - pc < 64 ? pe - pc : 64;
-  int nk = -1;
-  double nv = 0.0;
-  if (TABLE && cnt > 0) {
-    const int q = __shfl(mr0, 0, 64) + lane;
-    if (q < __shfl(mrd, 0, 64)) {
-      nk = Lcols[q];
-      nv = Lvals[q];
+    int mj = 0, mr0 = 0, mrd = 0;
+    double mdiag = 1.0, mval = 0.0;
+    if (pc + lane < pe) {
+      mj = Lcols[pc + lane];
+      mr0 = Lrowp[mj];
+      mrd = Lrowp[mj + 1] - 1;
+      mdiag = Lvals[mrd];
+      mval = Lvals[pc + lane];
     }
-  }
-  for (int e = 0; e < cnt; e++) {
-    const int p = pc + e;
-    double acc = 0.0;
-    const int j = __shfl(mj, e, 64);
-    const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
-    const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
-    if (TABLE) {
-      // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
-      // the next entry start now, before this entry's arithmetic: they do not depend on it
-      const int ck = nk;
-      const double cv = nv;
-      nk = -1;
-      if (e + 1 < cnt) {
-        const int q = __shfl(mr0, e + 1, 64) + lane;
-        if (q < __shfl(mrd, e + 1, 64)) {
-          nk = Lcols[q];
-          nv = Lvals[q];
-        }
+    const int cnt = pe - pc < 64 ? pe - pc : 64;
+    int nk = -1;
+    double nv = 0.0;
+    if (TABLE && cnt > 0) {
+      const int q = __shfl(mr0, 0, 64) + lane;
+      if (q < __shfl(mrd, 0, 64)) {
+        nk = Lcols[q];
+        nv = Lvals[q];
       }
-      if (ck >= 0) acc = cv * tab.find(ck);
-      for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
     }
-    for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
-      const int k = Lcols[q];
-      {
-        int lo = p0, hi = p;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (Lcols[mid] < k) {
-            lo = mid + 1;
-          } else {
-            hi = mid;
+    for (int e = 0; e < cnt; e++) {
+      const int p = pc + e;
+      double acc = 0.0;
+      const int j = __shfl(mj, e, 64);
+      const int r0 = __shfl(mr0, e, 64), rd = __shfl(mrd, e, 64);
+      const double jdiag = __shfl(mdiag, e, 64), sval = __shfl(mval, e, 64);
+      if (TABLE) {
+        // the first 64 entries of row j were fetched while the previous entry was being finished; the loads of
+        // the next entry start now, before this entry's arithmetic: they do not depend on it
+        const int ck = nk;
+        const double cv = nv;
+        nk = -1;
+        if (e + 1 < cnt) {
+          const int q = __shfl(mr0, e + 1, 64) + lane;
+          if (q < __shfl(mrd, e + 1, 64)) {
+            nk = Lcols[q];
+            nv = Lvals[q];
           }
         }
-        if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+        if (ck >= 0) acc = cv * tab.find(ck);
+        for (int q = r0 + 64 + lane; q < rd; q += 64) acc += Lvals[q] * tab.find(Lcols[q]);
+      }
+      for (int q = r0 + lane; !TABLE && q < rd; q += 64) {
+        const int k = Lcols[q];
+        {
+          int lo = p0, hi = p;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (Lcols[mid] < k) {
+              lo = mid + 1;
+            } else {
+              hi = mid;
+            }
+          }
+          if (lo < p && Lcols[lo] == k) acc += Lvals[q] * Lvals[lo];
+        }
+      }
+      acc = wave_sum(acc);
+      const double v = (sval - acc) / jdiag;
+      if (lane == 0) {
+        Lvals[p] = v;
+        if (TABLE) tab.insert(j, v);
+      }
+      if (TABLE) {
+        // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
+        // insert without a barrier (which would also wait for the loads just started); the fence only keeps
+        // the compiler from reordering
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      } else {
+        __threadfence_block();
+        __syncthreads();
       }
     }
-    acc = wave_sum(acc);
-    const double v = (sval - acc) / jdiag;
-    if (lane == 0) {
-      Lvals[p] = v;
-      if (TABLE) tab.insert(j, v);
-    }
-    if (TABLE) {
-      // one wavefront per workgroup: its LDS operations execute in program order, so the other lanes see the
-      // insert without a barrier (which would also wait for the loads just started); the fence only keeps
-      // the compiler from reordering
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    } else {
-      __threadfence_block();
-      __syncthreads();
-    }
-  }
   }
 }
 // The same step for levels whose front rows are LONG (the top separators: thousands of entries, each a dot with a
