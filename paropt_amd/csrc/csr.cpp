@@ -757,6 +757,14 @@ int CsrSparse::solveInPlace(double *const *Y, int nv, bool forward, bool backwar
 
 int CsrSparse::halfSolve(double *const *U, int nv) { return solveInPlace(U, nv, true, false); }
 
+int CsrSparse::correction(const double *const *Yp, int nv, const double *alpha, double *out) {
+  PO_TRY(k_panel_axpy(ctx, wwork, 0.0, nullptr, 0.0, alpha, Yp, nv, w));
+  double *Y[1] = {wwork};
+  PO_TRY(solveInPlace(Y, 1, false, true));
+  PO_TRY(k_csr_gather(ctx, out, wwork, d_iperm, w));
+  return k_scale(ctx, out, w, -1.0);
+}
+
 int CsrSparse::applyK0(const double *dinv, const double *bx, const double *bw, double *yx, double *yw) {
   // wwork (elimination order) = bw - Aw (dinv o bx)
   PO_TRY(k_csr_spmv(ctx, spmv_group, d_rowp, d_cols, vals, w, -1.0, bx, dinv, bw ? 1.0 : 0.0, bw, wwork,

@@ -75,6 +75,8 @@ class CsrSparse {
   int panelPermuted(const double *d, const double *const *P, int nv, double *const *U);
   int factor(const double *dinv, const double *cdiag);       // S = diag(cdiag) + Aw diag(dinv) Aw^T = L L^T
   int halfSolve(double *const *U, int nv);                   // U_j <- L^-1 U_j (elimination order, in place)
+  // out (natural order) = -S^-1 (U alpha) from the half-solved panel Y = L^-1 U: -L^-T (Y alpha)
+  int correction(const double *const *Y, int nv, const double *alpha, double *out);
   // (yx, yw) = K0^-1 (bx, bw); bw may be null; bx must not alias yx
   int applyK0(const double *dinv, const double *bx, const double *bw, double *yx, double *yw);
   const double *unitWeights() const { return ones; }

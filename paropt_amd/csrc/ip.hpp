@@ -170,6 +170,7 @@ class InteriorPoint {
   Vec *gsw, *gtw, *Cw, *wd2, *wyw, *wtmp, *wtmp2;
   Vec *d1v;                 // n-sized: raw d1, then v = d1 + P alpha
   std::vector<Vec *> Uw;    // U_j = Aw (Dinv o P_j)
+  bool panel_valid = false;  // Uw matches the current setUpKKTSystem (consumed by solveKKTW)
   double w_sums[7], w_maxs[5];  // reductions of the last w residual (k_w_res layout)
   WVars wv() const;
   WVars wr() const;

@@ -98,6 +98,7 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
   std::vector<double> W2((size_t)m * m, 0.0);
   PO_TRY(k_wgram(ctx, weights, Uc.data(), m, nw, W2.data()));
   for (size_t i = 0; i < W2.size(); i++) W[i] -= W2[i];
+  panel_valid = true;  // Uw holds the (half-solved) panel of the CURRENT Dinv, factor and panel columns
   return PO_OK;
 }
 
@@ -153,13 +154,30 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   merit_cache_valid = false;  // the step is about to change
   tdots_valid = false;
   residual_fused = false;
-  // (dx, dzw) = K0^-1 (d1 + P alpha, d2): by linearity the full solve minus the bx-only solve
-  if (m > 0) PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, alpha.data(), P.data(), m, n));
-  PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+  // (dx, dzw) = K0^-1 (d1 + P alpha, d2) = K0^-1 (d1, d2) + K0^-1 (P alpha, 0), and the second term comes from
+  // the panel the Gram correction already holds: dzw += -S^-1 (U alpha), dx += Dinv (P alpha + Aw^T of that) -
+  // no second quasi-definite apply, and P alpha rides in the same pass that forms the bound multipliers
   double mins_x[2], mins_w[2];
-  PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, nullptr, nullptr, 0, beta_mu, refine_pass ? 1 : 0,
-                  tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
-                  cu));
+  if (m > 0 && (int)Uw.size() >= m && panel_valid) {
+    std::vector<const double *> Uc(m);
+    for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
+    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
+    PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
+    PO_TRY(k_fill(ctx, d1v->d, n, 0.0));
+    if (prob->addSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    std::vector<const double *> P1(P);
+    std::vector<double> a1(alpha.begin(), alpha.begin() + m);
+    P1.push_back(d1v->d);
+    a1.push_back(1.0);
+    PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, a1.data(), P1.data(), m + 1, beta_mu, refine_pass ? 1 : 0,
+                    tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl, cu));
+  } else {
+    if (m > 0) PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, alpha.data(), P.data(), m, n));
+    PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+    PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, nullptr, nullptr, 0, beta_mu, refine_pass ? 1 : 0,
+                    tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
+                    cu));
+  }
   PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
   step_mins[0] = std::min(mins_x[0], mins_w[0]);
   step_mins[1] = std::min(mins_x[1], mins_w[1]);
@@ -280,6 +298,7 @@ int InteriorPoint::initLeastSquaresMultipliersW() {
     vars.z[i] = (z[i] < -gam || z[i] > gam) ? 0.0 : z[i];
   }
   PO_TRY(k_w_clip(ctx, wvar[0]->d, wyw->d, gsw->d, gtw->d, nw));
+  panel_valid = false;  // Uw was built with Dinv = 1 and the constraint columns only
   return PO_OK;
 }
 

@@ -52,6 +52,10 @@ class Problem {
   // with U^T S^-1 U = Y^T diag(weights) Y.  Block form: Y = U, weights = cw.  CSR form: Y = L^-1 U in
   // place, unit weights.
   virtual int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights);
+  // out = -S^-1 (U alpha) for the panel as sparseHalfSolve left it (nv columns, w-sized, `out` w-sized):
+  // K0^-1 (P alpha, 0) = (Dinv (P alpha + Aw^T out), out), which turns the second quasi-definite apply of a
+  // bordered solve into a correction of the first.  Block form: -cw o (U alpha).  CSR form: -L^-T (Y alpha).
+  virtual int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out);
   // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
   virtual const char *sparseFactorInfo() { return csr ? csr->factorInfo() : nullptr; }
   // number of factorizations so far that met a non-positive pivot (CSR form; 0 otherwise)

@@ -60,6 +60,12 @@ int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **w
   return PO_OK;
 }
 
+int Problem::sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) {
+  if (csr) return csr->correction(U, nv, alpha, out->d);
+  PO_TRY(k_panel_axpy(ctx, out->d, 0.0, nullptr, 0.0, alpha, U, nv, nwcon));
+  return k_mul(ctx, out->d, -1.0, cw->d, out->d, nwcon);
+}
+
 int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                                  Vec *work) {
   if (csr) return csr->panelPermuted(d->d, P, nv, U);

@@ -95,6 +95,9 @@ class TrustRegionSubproblem : public Problem {
   }
   const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
   long sparseFactorBreakdowns() override { return prob->sparseFactorBreakdowns(); }
+  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) override {
+    return prob->sparseCorrection(U, nv, alpha, cw, out);
+  }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
 
   Problem *prob;
@@ -176,6 +179,9 @@ class InfeasSubproblem : public Problem {  // :468-650
   }
   const char *sparseFactorInfo() override { return sub->sparseFactorInfo(); }
   long sparseFactorBreakdowns() override { return sub->sparseFactorBreakdowns(); }
+  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) override {
+    return sub->sparseCorrection(U, nv, alpha, cw, out);
+  }
   TrustRegionSubproblem *sub;
   int objective, constraint;
   double obj_scale;
