@@ -157,6 +157,7 @@ def main():
         if k == W:
             barrier_sync()
             stamp["counters0"] = ctx.counters()
+            ctx.time_mdot(a.ncon)  # HIP events around every mdot<ncon> launch of the timed region
             stamp["t0"] = time.perf_counter()
 
     ip.setIterationCallback(cb)
@@ -166,6 +167,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - stamp["t0"]
     red1, lau1 = ctx.counters()
+    mdot_ms_run, mdot_launches_run = ctx.time_mdot_result()
+    ctx.time_mdot(0)
     red_per_iter = (red1 - stamp["counters0"][0]) / float(a.steps)
     launches_per_iter = (lau1 - stamp["counters0"][1]) / float(a.steps)
     if dist is not None:
@@ -182,7 +185,10 @@ def main():
     x_c, z_c, zl_c, zu_c = ip.getOptimizedPoint()
     # the dense-constraint panel the solver itself streams: reuse fresh hash vectors of the same shape
     V = [pa.PVec(ctx, nl).fill_hash(1, 20 + j, prob.offset, 2.0, -1.0) for j in range(a.ncon)]
-    ms, _ = pa.bench_mdot(x, V, 20)
+    ms_isolated, _ = pa.bench_mdot(x, V, 20)
+    # the figure of record: the mdot<ncon> launches the solver itself issued in the timed region (the constraint
+    # evaluations of the line search), HIP events on the launch stream; the isolated loop is kept beside it
+    ms = mdot_ms_run / mdot_launches_run if mdot_launches_run > 0 else ms_isolated
     alg_bytes = 8.0 * (a.ncon + 1) * nl
     achieved = alg_bytes / (ms * 1e-3) * 1e-9
     traffic = None
@@ -195,7 +201,8 @@ def main():
         pass
     roofline = {"bound": "hbm", "kernel": "mdot_kernel<32> (ParOptVec::mdot, nvecs=%d, n_local=%d)" % (a.ncon, nl),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "avg_launch_ms": ms, "algorithmic_bytes": alg_bytes}
+                "traffic": traffic, "avg_launch_ms": ms, "launches_timed_in_run": mdot_launches_run,
+                "avg_launch_ms_isolated_loop": ms_isolated, "algorithmic_bytes": alg_bytes}
 
     if rank == 0:
         cpu = None

@@ -58,6 +58,12 @@ void *po_ctx_stream(po_ctx ctx);
 /* Diagnostics: host-synchronising reductions (= collectives when there is more than one rank) and kernel launches
  * issued on this context so far. */
 int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
+/* Live timing of the headline kernel inside a run: after po_ctx_time_mdot(ctx, nvecs) every ParOptVec::mdot
+ * launch with exactly `nvecs` vectors on this context is bracketed by HIP events on the context's stream
+ * (nvecs = 0 switches it off; every call resets the accumulators); the result call returns the accumulated
+ * kernel milliseconds and the number of launches. */
+int po_ctx_time_mdot(po_ctx ctx, int nvecs);
+int po_ctx_time_mdot_result(po_ctx ctx, double *ms_total, int64_t *launches);
 /* Copy between a host buffer and a raw device array this library handed out (the Jacobian entries of
  * po_problem_set_sparse_jacobian_data), ordered with the context's stream; returns when the copy is done.
  * to_device != 0: host -> device. */

@@ -32,6 +32,16 @@ class Context:
     def synchronize(self):
         check(lib.po_ctx_synchronize(self._h))
 
+    def time_mdot(self, nvecs):
+        """Bracket every mdot launch of exactly `nvecs` vectors with HIP events (0: off); resets the totals."""
+        check(lib.po_ctx_time_mdot(self._h, int(nvecs)))
+
+    def time_mdot_result(self):
+        """(accumulated kernel milliseconds, launches) since time_mdot()."""
+        ms, cnt = C.c_double(), C.c_int64()
+        check(lib.po_ctx_time_mdot_result(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def counters(self):
         """(host-synchronising reductions, kernel launches) issued on this context so far."""
         a, b = C.c_int64(), C.c_int64()

@@ -64,6 +64,19 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   if (launches) *launches = ctx->n_launches;
   return PO_OK;
 }
+int po_ctx_time_mdot(po_ctx ctx, int nvecs) {
+  PO_CHECK_PTR(ctx);
+  ctx->time_mdot_nv = nvecs > 0 ? nvecs : 0;
+  ctx->mdot_ms = 0.0;
+  ctx->mdot_count = 0;
+  return PO_OK;
+}
+int po_ctx_time_mdot_result(po_ctx ctx, double *ms_total, int64_t *launches) {
+  PO_CHECK_PTR(ctx);
+  if (ms_total) *ms_total = ctx->mdot_ms;
+  if (launches) *launches = ctx->mdot_count;
+  return PO_OK;
+}
 int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_device) {
   PO_CHECK_PTR(ctx);
   if (bytes <= 0) return PO_OK;

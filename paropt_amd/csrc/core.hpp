@@ -60,6 +60,10 @@ struct Ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long n_reductions = 0;  // statistics: host-synchronising reductions issued
   long n_launches = 0;
+  // live timing of the headline kernel: mdot launches of exactly this many vectors are bracketed by ev0/ev1
+  int time_mdot_nv = 0;
+  double mdot_ms = 0.0;
+  long mdot_count = 0;
 };
 
 struct Vec {

@@ -473,8 +473,18 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out) {
   if (nv <= 0) return PO_OK;
   int grid = 0;
+  const bool timed = c->time_mdot_nv == nv;  // po_ctx_time_mdot: HIP events on the launch stream
+  if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_mdot_launch(c, x, V, nv, n, &grid));
-  return reduce_finish(c, grid, nv, 0, 0, out);
+  if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
+  PO_TRY(reduce_finish(c, grid, nv, 0, 0, out));  // synchronises the stream: ev1 has completed
+  if (timed) {
+    float ms = 0.0f;
+    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->mdot_ms += ms;
+    c->mdot_count++;
+  }
+  return PO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -143,3 +143,23 @@ def test_wgram_vs_numpy(ctx, n, nv):
     W = pa.wgram(d, V)
     np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
     np.testing.assert_array_equal(W, W.T)
+
+
+def test_live_mdot_timing_hook(ctx):
+    """po_ctx_time_mdot: launches of exactly the requested width are timed with HIP events, others are not."""
+    import paropt_amd as pa
+
+    n = 100_000
+    x = pa.PVec(ctx, n).fill_hash(0, 1, 0, 1.0, 0.0)
+    V = [pa.PVec(ctx, n).fill_hash(0, 10 + j, 0, 1.0, 0.0) for j in range(5)]
+    ctx.time_mdot(5)
+    ref = x.mdot(V)
+    x.mdot(V[:3])
+    x.mdot(V)
+    ms, cnt = ctx.time_mdot_result()
+    assert cnt == 2 and ms > 0.0
+    ctx.time_mdot(0)
+    np.testing.assert_array_equal(x.mdot(V), ref)
+    assert ctx.time_mdot_result() == (0.0, 0)
+    red, launches = ctx.counters()
+    assert red > 0 and launches > 0
