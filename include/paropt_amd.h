@@ -58,6 +58,11 @@ void *po_ctx_stream(po_ctx ctx);
 /* Diagnostics: host-synchronising reductions (= collectives when there is more than one rank) and kernel launches
  * issued on this context so far. */
 int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
+/* Leak check: device vectors currently alive in this process (every ParOptVec, the panels of the quasi-Newton
+ * objects, the work vectors of the solvers) and the HBM bytes behind them.  The reference's intrusive
+ * reference counts (src/ParOptVec.h:28-47) are kept, so after the last decref / destroy both return to their
+ * values before the objects were made. */
+int po_live_objects(int64_t *vectors, int64_t *bytes);
 /* Live timing of the headline kernel inside a run: after po_ctx_time_mdot(ctx, nvecs) every ParOptVec::mdot
  * launch with exactly `nvecs` vectors on this context is bracketed by HIP events on the context's stream
  * (nvecs = 0 switches it off; every call resets the accumulators); the result call returns the accumulated

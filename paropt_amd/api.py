@@ -12,6 +12,13 @@ from . import lib as L
 from .lib import check, lib
 
 
+def live_objects():
+    """(device vectors alive in this process, HBM bytes behind them): the leak check of the C ABI."""
+    a, b = C.c_int64(), C.c_int64()
+    check(lib.po_live_objects(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 class Context:
     """One per process / GPU: HIP stream + communicator (replaces the MPI communicator)."""
 

@@ -64,6 +64,14 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   if (launches) *launches = ctx->n_launches;
   return PO_OK;
 }
+int po_live_objects(int64_t *vectors, int64_t *bytes) {
+  long v = 0;
+  long long b = 0;
+  po::live_objects(&v, &b);
+  if (vectors) *vectors = v;
+  if (bytes) *bytes = b;
+  return PO_OK;
+}
 int po_ctx_time_mdot(po_ctx ctx, int nvecs) {
   PO_CHECK_PTR(ctx);
   ctx->time_mdot_nv = nvecs > 0 ? nvecs : 0;

@@ -9,11 +9,21 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+
 namespace po {
 
 // Device vectors are allocated with an even element count plus slack and zero-filled, so the
 // kernels can always use full 16-byte accesses on the last pair (kernels.hip::ld2/st2).
 static size_t padded_elems(int64_t n) { return (size_t)(((n + 1) >> 1) << 1) + 2; }
+
+// live-object accounting (po_live_objects): every device vector alive and the bytes behind them
+static std::atomic<long> g_live_vecs(0);
+static std::atomic<long long> g_live_bytes(0);
+void live_objects(long *vecs, long long *bytes) {
+  if (vecs) *vecs = g_live_vecs.load();
+  if (bytes) *bytes = g_live_bytes.load();
+}
 
 Vec *vec_new(Ctx *c, int64_t n) {
   po_vec_s *v = new po_vec_s();
@@ -31,6 +41,8 @@ Vec *vec_new(Ctx *c, int64_t n) {
   if (hipMemsetAsync(v->d, 0, bytes, c->stream) != hipSuccess) {
     set_error("hipMemsetAsync failed");
   }
+  g_live_vecs++;
+  g_live_bytes += (long long)bytes;
   return v;
 }
 
@@ -40,6 +52,8 @@ void vec_decref(Vec *v) {
     (void)hipStreamSynchronize(v->ctx->stream);
     if (v->d) (void)hipFree(v->d);
     if (v->h) (void)hipHostFree(v->h);
+    g_live_vecs--;
+    g_live_bytes -= (long long)(sizeof(double) * padded_elems(v->n));
     delete static_cast<po_vec_s *>(v);
   }
 }

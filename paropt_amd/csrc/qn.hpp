@@ -12,6 +12,7 @@ namespace po {
 
 Vec *vec_new(Ctx *c, int64_t n);
 void vec_decref(Vec *v);
+void live_objects(long *vecs, long long *bytes);
 
 class CompactQuasiNewton {
  public:
