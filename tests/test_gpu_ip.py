@@ -588,3 +588,71 @@ def test_output_file_table(ctx, tmp_path):
         assert abs(float(mine[k][7]) - float(ref[k][7])) <= 2e-5 * max(1.0, abs(float(ref[k][7])))  # fobj
         assert mine[k][11] == ref[k][11]                      # mu
         assert mine[k][15:] == ref[k][15:]                    # info tokens
+
+
+@pytest.mark.parametrize("problem,qn", [("quadratic", "bfgs"), ("convex", "sr1"), ("rosenbrock", "bfgs")])
+def test_check_kkt_step_residual(ctx, problem, qn):
+    """The reference's checkKKTStep (src/ParOptInteriorPoint.cpp:6212-6360) without the reference: at an interior
+    iteration the fused device step p must satisfy the linearised KKT system K p = r assembled DENSELY in numpy from
+    the state, the problem data and the compact quasi-Newton matrix B = b0 I - Z d0 M^-1 d0 Z^T (no oracle code
+    on either side of the comparison)."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po  # only for the problem data (hash-seeded vectors)
+
+    n, c = 200, 3
+    data = po.SepProblem(problem, n, c)
+    c = data.c
+    prob = pa.SeparableProblem(ctx, problem, n, c)
+    ip = pa.InteriorPoint(prob, {"qn_type": qn, "qn_subspace_size": 5, "max_major_iters": 9, "abs_res_tol": 1e-30})
+    got = {}
+
+    def cb(k):
+        if k != 8:
+            return
+        mu = ip.getBarrierParameter()
+        x, z, zl, zu = ip.getOptimizedPoint()
+        s, t, zs, zt = ip.getOptimizedSlacks()
+        b0, d0, M, Z = ip.getQuasiNewton().getCompactMat()
+        got.update(mu=mu, x=x.to_numpy(), z=np.array(z), zl=zl.to_numpy(), zu=zu.to_numpy(), s=np.array(s),
+                   t=np.array(t), zs=np.array(zs), zt=np.array(zt), b0=b0, d0=d0, M=M,
+                   Z=[v.to_numpy() for v in Z], p=ip.debugKKTStep(mu))
+
+    ip.setIterationCallback(cb)
+    ip.optimize()
+    g = got
+    x, p = g["x"], g["p"]
+    _, grad, A = data.eval_obj_con_gradient(x)
+    _, _, cons = data.eval_obj_con(x)
+    A = np.array(A)
+    _, lb, ub = data.vars_and_bounds()
+    beta, mu = 1.0, g["mu"]  # rel_bound_barrier = 1
+    gam = 1000.0
+    # residual of the perturbed KKT conditions (computeKKTRes :1337-1446); all constraints are inequalities
+    rx = g["zl"] - g["zu"] - grad + A.T @ g["z"]
+    rz = -(cons - g["s"] + g["t"])
+    rs = -(0.0 - g["zs"] + g["z"])
+    rt = -(gam - g["zt"] - g["z"])
+    rzs = -(g["s"] * g["zs"] - mu)
+    rzt = -(g["t"] * g["zt"] - mu)
+    rzl = -((x - lb) * g["zl"] - beta * mu)
+    rzu = -((ub - x) * g["zu"] - beta * mu)
+    k = len(g["Z"])
+    B = g["b0"] * np.eye(n)
+    if k > 0:
+        Zm = np.array(g["Z"]).T
+        if qn == "bfgs":
+            B -= (Zm * g["d0"]) @ np.linalg.solve(g["M"], (Zm * g["d0"]).T)
+        else:
+            B -= Zm @ np.linalg.solve(g["M"], Zm.T)
+    # the step must zero the linearised residual (addKKTResStep :1451-1583)
+    ex = rx - B @ p["x"] + A.T @ p["z"] + p["zl"] - p["zu"]
+    ez = rz - (A @ p["x"] - p["s"] + p["t"])
+    es = rs + (p["zs"] - p["z"])
+    et = rt + (p["zt"] + p["z"])
+    ezs = rzs - (p["s"] * g["zs"] + g["s"] * p["zs"])
+    ezt = rzt - (p["t"] * g["zt"] + g["t"] * p["zt"])
+    ezl = rzl - ((x - lb) * p["zl"] + p["x"] * g["zl"])
+    ezu = rzu - ((ub - x) * p["zu"] - p["x"] * g["zu"])
+    scale = max(1.0, np.abs(rx).max(), np.abs(rz).max(), np.abs(rzl).max(), np.abs(rzu).max())
+    for name, e in (("x", ex), ("z", ez), ("s", es), ("t", et), ("zs", ezs), ("zt", ezt), ("zl", ezl), ("zu", ezu)):
+        assert np.abs(e).max() <= 1e-9 * scale, (name, np.abs(e).max(), scale)
