@@ -307,6 +307,8 @@ int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, 
 int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,
                          const double **pz, const double **ps, const double **pt,
                          const double **pzs, const double **pzt);
+/* the sparse blocks of that step (borrowed; NULL handles when the problem has no sparse constraints) */
+int po_ip_debug_kkt_step_sparse(po_ip ip, po_vec *pzw, po_vec *psw, po_vec *ptw, po_vec *pzsw, po_vec *pztw);
 
 /* ---- standalone hot kernels for the roofline bench ----------------------------------------- */
 /* W = P^T diag(d) P, P = [vecs], column-major nvecs x nvecs on the host (MFMA fp64). */

@@ -711,6 +711,11 @@ class InteriorPoint:
                    zu=PVec(self.ctx, handle=pzu, owned=False).to_numpy())
         for name, p in zip(("z", "s", "t", "zs", "zt"), d):
             out[name] = np.array([p[i] for i in range(c)])
+        wh = [L.po_vec() for _ in range(5)]
+        check(lib.po_ip_debug_kkt_step_sparse(self._h, *[C.byref(h) for h in wh]))
+        if wh[0]:
+            for name, h in zip(("zw", "sw", "tw", "zsw", "ztw"), wh):
+                out[name] = PVec(self.ctx, handle=h, owned=False).to_numpy()
         return out
 
     def snapshot(self):

@@ -751,6 +751,16 @@ int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *p
   return PO_OK;
 }
 
+int po_ip_debug_kkt_step_sparse(po_ip ip, po_vec *pzw, po_vec *psw, po_vec *ptw, po_vec *pzsw, po_vec *pztw) {
+  PO_CHECK_PTR(ip);
+  InteriorPoint *p = ip->ip;
+  po_vec *out[5] = {pzw, psw, ptw, pzsw, pztw};
+  for (int i = 0; i < 5; i++) {
+    if (out[i]) *out[i] = p->has_w ? static_cast<po_vec>(p->wstepv[i]) : nullptr;
+  }
+  return PO_OK;
+}
+
 // ---- standalone hot kernels -----------------------------------------------------------------------
 static int gather_ptrs(po_vec ref, const po_vec *vecs, int nvecs, std::vector<const double *> &p) {
   p.resize(nvecs > 0 ? nvecs : 1);

@@ -191,6 +191,7 @@ SIGNATURES = {
         [po_ip, C.c_double, C.POINTER(po_vec), C.POINTER(po_vec), C.POINTER(po_vec)]
         + [C.POINTER(c_double_p)] * 5,
     ),
+    "po_ip_debug_kkt_step_sparse": (C.c_int, [po_ip] + [C.POINTER(po_vec)] * 5),
     "po_tr_create": (C.c_int, [po_problem, C.POINTER(po_tr)]),
     "po_tr_destroy": (C.c_int, [po_tr]),
     "po_tr_set_option_str": (C.c_int, [po_tr, C.c_char_p, C.c_char_p]),

@@ -656,3 +656,70 @@ def test_check_kkt_step_residual(ctx, problem, qn):
     scale = max(1.0, np.abs(rx).max(), np.abs(rz).max(), np.abs(rzl).max(), np.abs(rzu).max())
     for name, e in (("x", ex), ("z", ez), ("s", es), ("t", et), ("zs", ezs), ("zt", ezt), ("zl", ezl), ("zu", ezu)):
         assert np.abs(e).max() <= 1e-9 * scale, (name, np.abs(e).max(), scale)
+
+
+@pytest.mark.parametrize("form", ["weighting", "chain"])
+def test_check_kkt_step_residual_sparse(ctx, form):
+    """checkKKTStep with sparse constraints, block form (nwblock = 1) and CSR form (device sparse Cholesky): the
+    fused step, including its five w-sized blocks, against the dense linearised KKT system in numpy."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po  # problem data only
+
+    n, c = 240, 2
+    if form == "weighting":
+        data = po.SepProblem("convex", n, c, nwcon=39, nw=5, nwstart=3, nwskip=1)
+        prob = pa.SeparableProblem(ctx, "convex", n, c).setWeighting(39, 5, 3, 1)
+    else:
+        data = po.SepProblem("convex", n, c, chain=(3, 2))
+        prob = pa.SeparableProblem(ctx, "convex", n, c).setChain(3, 2)
+    ip = pa.InteriorPoint(prob, {"qn_type": "bfgs", "qn_subspace_size": 5, "max_major_iters": 7, "abs_res_tol": 1e-30,
+                                 "penalty_gamma": 1000.0})
+    g = {}
+
+    def cb(k):
+        if k != 6:
+            return
+        mu = ip.getBarrierParameter()
+        x, z, zl, zu = ip.getOptimizedPoint()
+        s, t, zs, zt = ip.getOptimizedSlacks()
+        wv = [v.to_numpy() for v in ip.getOptimizedSparse()]
+        b0, d0, M, Z = ip.getQuasiNewton().getCompactMat()
+        g.update(mu=mu, x=x.to_numpy(), z=np.array(z), zl=zl.to_numpy(), zu=zu.to_numpy(), s=np.array(s),
+                 t=np.array(t), zs=np.array(zs), zt=np.array(zt), w=wv, b0=b0, d0=d0, M=M,
+                 Z=[v.to_numpy() for v in Z], p=ip.debugKKTStep(mu))
+
+    ip.setIterationCallback(cb)
+    ip.optimize()
+    x, p = g["x"], g["p"]
+    _, _, cons = data.eval_obj_con(x)
+    _, grad, A = data.eval_obj_con_gradient(x)
+    A = np.array(A)
+    cw = data.eval_sparse_con(x)
+    Aw = data.sparse_jacobian_dense()
+    zw, sw, tw, zsw, ztw = g["w"]
+    _, lb, ub = data.vars_and_bounds()
+    mu, gam = g["mu"], 1000.0
+    rx = g["zl"] - g["zu"] - grad + A.T @ g["z"] + Aw.T @ zw
+    rz = -(cons - g["s"] + g["t"])
+    rs, rt = -(0.0 - g["zs"] + g["z"]), -(gam - g["zt"] - g["z"])
+    rzs, rzt = -(g["s"] * g["zs"] - mu), -(g["t"] * g["zt"] - mu)
+    rzl, rzu = -((x - lb) * g["zl"] - mu), -((ub - x) * g["zu"] - mu)
+    rzw = -(cw - sw + tw)
+    rsw, rtw = zsw - 0.0 - zw, ztw - gam + zw  # all sparse constraints are inequalities: gamma_sw = 0
+    rzsw, rztw = mu - sw * zsw, mu - tw * ztw
+    Zm = np.array(g["Z"]).T
+    B = g["b0"] * np.eye(n) - (Zm * g["d0"]) @ np.linalg.solve(g["M"], (Zm * g["d0"]).T)
+    errs = {
+        "x": rx - B @ p["x"] + A.T @ p["z"] + Aw.T @ p["zw"] + p["zl"] - p["zu"],
+        "z": rz - (A @ p["x"] - p["s"] + p["t"]),
+        "s": rs + (p["zs"] - p["z"]), "t": rt + (p["zt"] + p["z"]),
+        "zs": rzs - (p["s"] * g["zs"] + g["s"] * p["zs"]), "zt": rzt - (p["t"] * g["zt"] + g["t"] * p["zt"]),
+        "zl": rzl - ((x - lb) * p["zl"] + p["x"] * g["zl"]), "zu": rzu - ((ub - x) * p["zu"] - p["x"] * g["zu"]),
+        # sparse rows (:1492-1527)
+        "zw": rzw - (Aw @ p["x"] - p["sw"] + p["tw"]),
+        "sw": rsw + (p["zsw"] - p["zw"]), "tw": rtw + (p["ztw"] + p["zw"]),
+        "zsw": rzsw - (p["sw"] * zsw + sw * p["zsw"]), "ztw": rztw - (p["tw"] * ztw + tw * p["ztw"]),
+    }
+    scale = max(1.0, np.abs(rx).max(), np.abs(rzw).max(), np.abs(rz).max(), np.abs(rtw).max())
+    for name, e in errs.items():
+        assert np.abs(e).max() <= 1e-9 * scale, (form, name, np.abs(e).max(), scale)
