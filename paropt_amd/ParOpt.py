@@ -329,6 +329,33 @@ LBFGS = _api.LBFGS
 LSR1 = _api.LSR1
 
 
+def unpack_checkpoint(filename, full=False):
+    """Decode a solution file of writeSolutionFile (src/ParOptInteriorPoint.cpp:883-972): returns
+    ``barrier, s, z, x, zl, zu`` like paropt.ParOpt.unpack_checkpoint (paropt/ParOpt.pyx:318-354) - whose offsets
+    predate the t, zs, zt blocks of the file and therefore misread everything after ``s``; this one follows the
+    layout the C++ side writes.  With ``full=True`` a dict with every block (t, zs, zt, zw, sw too)."""
+    raw = open(filename, "rb").read()
+    nvars, nwcon, ncon = (int(v) for v in np.frombuffer(raw[:12], dtype="<i4"))
+    pay = np.frombuffer(raw[12:], dtype="<f8")
+    need = 1 + 5 * ncon + 3 * nvars + 2 * nwcon
+    if len(pay) < need:
+        raise ValueError("solution file %s is too short for its header (%d < %d doubles)" % (filename, len(pay), need))
+    out = {"barrier": float(pay[0]), "nvars": nvars, "nwcon": nwcon, "ncon": ncon}
+    off = 1
+    for key in ("s", "t", "z", "zs", "zt"):
+        out[key] = pay[off:off + ncon].copy()
+        off += ncon
+    for key in ("x", "zl", "zu"):
+        out[key] = pay[off:off + nvars].copy()
+        off += nvars
+    for key in ("zw", "sw"):
+        out[key] = pay[off:off + nwcon].copy()
+        off += nwcon
+    if full:
+        return out
+    return out["barrier"], out["s"], out["z"], out["x"], out["zl"], out["zu"]
+
+
 def unpack_output(filename):
     """Columns of an interior-point output file (ParOpt.pyx:61-133): (names, list of arrays)."""
     args = ["iter", "nobj", "ngrd", "nhvc", "alpha", "alphx", "alphz", "fobj", "|opt|", "|infes|", "|dual|", "mu",
