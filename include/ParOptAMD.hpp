@@ -131,7 +131,10 @@ class ParOptOptions : public ParOptBase {
 class ParOptProblem : public ParOptBase {
  public:
   explicit ParOptProblem(po_ctx _ctx)
-      : ctx(_ctx), nvars(0), ncon(0), nwcon(0), ninequality(-1), nwinequality(-1), hprob(NULL) {}
+      : ctx(_ctx), nvars(0), ncon(0), nwcon(0), ninequality(-1), nwinequality(-1), nwblock(1), hprob(NULL) {}
+  // the nwblock of the reference's `new ParOptQuasiDefBlockMat(this, nwblock)` in createQuasiDefMat(): with
+  // nwblock > 1 addSparseInnerProduct fills packed upper nwblock x nwblock blocks (before the first handle())
+  void setSparseBlockSize(int _nwblock) { nwblock = _nwblock; }
   virtual ~ParOptProblem() {
     if (hprob) po_problem_destroy(hprob);
   }
@@ -186,7 +189,7 @@ class ParOptProblem : public ParOptBase {
 
  protected:
   po_ctx ctx;
-  int nvars, ncon, nwcon, ninequality, nwinequality;
+  int nvars, ncon, nwcon, ninequality, nwinequality, nwblock;
   po_problem hprob;
   // registers the sparse-constraint callbacks with the library; ParOptSparseProblem registers its CSR form
   virtual void attachSparse() {
@@ -196,7 +199,8 @@ class ParOptProblem : public ParOptBase {
     scb.add_sparse_jacobian = &ParOptProblem::tramp_wjac;
     scb.add_sparse_jacobian_transpose = &ParOptProblem::tramp_wjact;
     scb.add_sparse_inner_product = &ParOptProblem::tramp_winner;
-    if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0) {
+    if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0 ||
+        (nwblock > 1 && po_problem_set_sparse_block_size(hprob, nwblock) != 0)) {
       fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     }
   }

@@ -220,6 +220,12 @@ int po_csr_symbolic_info(po_csr_symbolic h, int64_t info[7]);
 int po_csr_symbolic_arrays(po_csr_symbolic h, const int **perm, const int **parent, const int **Lrowp,
                            const int **Lcols, const int **level_ptr, const int **front_of);
 int po_csr_symbolic_destroy(po_csr_symbolic h);
+/* nwblock of ParOptQuasiDefBlockMat (src/ParOptSparseMat.cpp:11-229) for the callback form: consecutive blocks of
+ * nwblock (1..16) sparse constraints may share variables inside a block.  add_sparse_inner_product then receives,
+ * instead of the w-sized diagonal, the packed upper triangles of the nwblock x nwblock blocks - entry (i, j),
+ * i <= j, of block b at b nwblock (nwblock+1)/2 + i + j (j+1)/2, nwcon (nwblock+1)/2 entries in all - as the
+ * reference passes them (src/ParOptProblem.h:252-262).  After po_problem_set_sparse_callbacks. */
+int po_problem_set_sparse_block_size(po_problem p, int nwblock);
 /* Second-order information (src/ParOptProblem.h:160-189) for use_hvec_product / use_diag_hessian:
  * evalHvecProduct: hvec = H(x, z, zw) px ; evalHessianDiag: hdiag = diag H(x, z, zw), with H the
  * Hessian of the Lagrangian f - z^T c - zw^T cw.  zw is NULL when nwcon = 0.  Either may be NULL. */

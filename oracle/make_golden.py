@@ -297,6 +297,14 @@ case(
     dump_vecs_every=10,
     **dict(ip_common, **{"opt.qn_subspace_size": 8, "opt.qn_type": "bfgs", "opt.max_major_iters": 100}),
 )
+# nwblock > 1: blocks of three constraints on the same group of six variables with different weights
+# (oracle/ref_driver.cpp SepProblem::wgt), so that Aw D^-1 Aw^T has dense 3 x 3 diagonal blocks
+case("ipw_rosenbrock_n240_w60_nwblock3", "ip", problem="rosenbrock", n=240, nwcon=60, nw=6, nwstart=0, nwskip=2,
+     nwblock=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 120}))
+case("ipw_quadratic_n240_c2_w60_nwblock3", "ip", problem="quadratic", n=240, c=2, nwcon=60, nw=6, nwstart=0,
+     nwskip=2, nwblock=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "bfgs", "opt.max_major_iters": 120}))
 # equality weighting constraints (sum of each group = 1), partial coverage with gaps
 case(
     "ipw_convex_n300_c2_w30_eq",

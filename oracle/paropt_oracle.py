@@ -311,7 +311,7 @@ class SepProblem:
     """
 
     def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None, nwcon=0, nw=0,
-                 nwstart=0, nwskip=0, nwineq=-1, chain=None):
+                 nwstart=0, nwskip=0, nwineq=-1, chain=None, nwblock=1):
         self.comm = comm if comm is not None else SelfComm()
         # chain = (span, stride): the CSR form (ParOptSparseProblem, src/ParOptProblem.cpp:624-816) with the
         # rank-local overlapping constraints cw_i = 1 - sum_{k<span} x[i*stride+k]^2 >= 0 of
@@ -321,9 +321,20 @@ class SepProblem:
         # examples/rosenbrock/rosenbrock.cpp:131-184); disjoint supports, nwblock = 1
         self.nwcon, self.nw, self.nwstart, self.nwskip = int(nwcon), int(nw), int(nwstart), int(nwskip)
         self.nwineq = self.nwcon if nwineq < 0 else int(nwineq)
+        # nwblock > 1 (oracle/ref_driver.cpp SepProblem::wgt): blocks of nwblock constraints share one group of
+        # nw variables with different weights; Aw D^-1 Aw^T then has dense diagonal blocks, handled through
+        # the general (dense S) quasi-definite solve of this oracle
+        self.nwblock = int(nwblock)
+        self.wwgt = None
         if self.nwcon > 0:
-            j0 = self.nwstart + np.arange(self.nwcon) * (self.nw + self.nwskip)
+            blk = np.arange(self.nwcon) // self.nwblock
+            j0 = self.nwstart + blk * (self.nw + self.nwskip)
             self.widx = (j0[:, None] + np.arange(self.nw)[None, :])  # (w, nw) variable indices
+            if self.nwblock > 1:
+                k = (np.arange(self.nwcon) % self.nwblock)[:, None]
+                j = np.arange(self.nw)[None, :]
+                self.wwgt = 1.0 + 0.5 * ((k * (j + 1) + j) % 3)
+                self.csr_form = True
         self.kind = kind
         self.nglobal = int(n)
         self.nlocal, self.offset = shard(n, self.comm.rank, self.comm.size)
@@ -365,7 +376,7 @@ class SepProblem:
         if self.chain:
             np.add.at(A, (np.arange(self.nwcon)[:, None], self.cidx), self._jac)
         elif self.nwcon:
-            A[np.arange(self.nwcon)[:, None], self.widx] = -1.0
+            A[np.arange(self.nwcon)[:, None], self.widx] = -1.0 if self.wwgt is None else -self.wwgt
         return A
 
     def eval_obj_con(self, x):
@@ -400,11 +411,15 @@ class SepProblem:
             return np.zeros(0)
         if self.chain:  # the values of the LAST evaluation, whatever x is (.cpp:750-760)
             return self._cw.copy()
+        if self.wwgt is not None:
+            return 1.0 - np.sum(self.wwgt * x[self.widx], axis=1)
         return 1.0 - np.sum(x[self.widx], axis=1)
 
     def add_sparse_jacobian(self, alpha, px, out):  # out += alpha * Aw px
         if self.chain:  # the entries of the LAST gradient evaluation (.cpp:762-788)
             out += alpha * np.sum(self._jac * px[self.cidx], axis=1)
+        elif self.nwcon and self.wwgt is not None:
+            out -= alpha * np.sum(self.wwgt * px[self.widx], axis=1)
         elif self.nwcon:
             out -= alpha * np.sum(px[self.widx], axis=1)
         return out
@@ -412,6 +427,8 @@ class SepProblem:
     def add_sparse_jacobian_transpose(self, alpha, pzw, out):  # out += alpha * Aw^T pzw
         if self.chain:
             np.add.at(out, self.cidx, alpha * self._jac * pzw[:, None])
+        elif self.nwcon and self.wwgt is not None:
+            np.add.at(out, self.widx, -alpha * self.wwgt * pzw[:, None])
         elif self.nwcon:
             out[self.widx] -= alpha * pzw[:, None]
         return out

@@ -120,6 +120,7 @@ class SepProblem : public ParOptProblem {
     nw = _nw;
     nwstart = _nwstart;
     nwskip = _nwskip;
+    nwblock = 1;
     kind = _kind;
     offset = _offset;
     nglobal = _nglobal;
@@ -143,7 +144,12 @@ class SepProblem : public ParOptProblem {
       }
     }
   }
-  ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefBlockMat(this, 1); }
+  ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefBlockMat(this, nwblock); }
+  // nwblock > 1: the wn constraints come in blocks of nwblock consecutive ones that act on the SAME group of nw
+  // variables with different weights, cw_{b,k} = 1 - sum_j wgt(k,j) x[nwstart + b (nw+nwskip) + j], so that
+  // Aw D^-1 Aw^T is block diagonal with dense nwblock x nwblock blocks (src/ParOptSparseMat.cpp:41-229)
+  int nwblock;
+  static double wgt(int k, int j) { return 1.0 + 0.5 * ((k * (j + 1) + j) % 3); }
   int useLowerBounds() { return use_lower_flag; }
   int useUpperBounds() { return use_upper_flag; }
   int use_lower_flag, use_upper_flag;
@@ -263,8 +269,9 @@ class SepProblem : public ParOptProblem {
     outv->getArray(&out);
     for (int i = 0; i < wn; i++) {
       double s = 1.0;
-      const int j0 = nwstart + i * (nw + nwskip);
-      for (int k = 0; k < nw; k++) s -= x[j0 + k];
+      const int b = i / nwblock, k = i % nwblock;
+      const int j0 = nwstart + b * (nw + nwskip);
+      for (int j = 0; j < nw; j++) s -= (nwblock > 1 ? wgt(k, j) : 1.0) * x[j0 + j];
       out[i] = s;
     }
   }
@@ -273,8 +280,9 @@ class SepProblem : public ParOptProblem {
     pxv->getArray(&px);
     outv->getArray(&out);
     for (int i = 0; i < wn; i++) {
-      const int j0 = nwstart + i * (nw + nwskip);
-      for (int k = 0; k < nw; k++) out[i] -= alpha * px[j0 + k];
+      const int b = i / nwblock, k = i % nwblock;
+      const int j0 = nwstart + b * (nw + nwskip);
+      for (int j = 0; j < nw; j++) out[i] -= alpha * (nwblock > 1 ? wgt(k, j) : 1.0) * px[j0 + j];
     }
   }
   void addSparseJacobianTranspose(ParOptScalar alpha, ParOptVec *, ParOptVec *pzwv, ParOptVec *outv) {
@@ -282,16 +290,32 @@ class SepProblem : public ParOptProblem {
     pzwv->getArray(&pzw);
     outv->getArray(&out);
     for (int i = 0; i < wn; i++) {
-      const int j0 = nwstart + i * (nw + nwskip);
-      for (int k = 0; k < nw; k++) out[j0 + k] -= alpha * pzw[i];
+      const int b = i / nwblock, k = i % nwblock;
+      const int j0 = nwstart + b * (nw + nwskip);
+      for (int j = 0; j < nw; j++) out[j0 + j] -= alpha * (nwblock > 1 ? wgt(k, j) : 1.0) * pzw[i];
     }
   }
   void addSparseInnerProduct(ParOptScalar alpha, ParOptVec *, ParOptVec *cvecv, ParOptScalar *A) {
     double *cv;
     cvecv->getArray(&cv);
-    for (int i = 0; i < wn; i++) {
-      const int j0 = nwstart + i * (nw + nwskip);
-      for (int k = 0; k < nw; k++) A[i] += alpha * cv[j0 + k];
+    if (nwblock == 1) {
+      for (int i = 0; i < wn; i++) {
+        const int j0 = nwstart + i * (nw + nwskip);
+        for (int k = 0; k < nw; k++) A[i] += alpha * cv[j0 + k];
+      }
+      return;
+    }
+    // packed upper triangle per block, column by column: (i, j), i <= j, at i + j (j+1)/2
+    const int incr = nwblock * (nwblock + 1) / 2;
+    for (int b = 0; b < wn / nwblock; b++) {
+      const int j0 = nwstart + b * (nw + nwskip);
+      for (int jj = 0; jj < nwblock; jj++) {
+        for (int ii = 0; ii <= jj; ii++) {
+          double v = 0.0;
+          for (int j = 0; j < nw; j++) v += wgt(ii, j) * wgt(jj, j) * cv[j0 + j];
+          A[b * incr + ii + jj * (jj + 1) / 2] += alpha * v;
+        }
+      }
     }
   }
 
@@ -866,6 +890,7 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   prob->incref();
   prob->use_lower_flag = (int)geti(A, "use_lower", 1);
   prob->use_upper_flag = (int)geti(A, "use_upper", 1);
+  prob->nwblock = (int)geti(A, "nwblock", 1);
   ParOptProblem *top = prob;
   const int chain_span = (int)geti(A, "chain_span", 0);
   if (chain_span > 0) {

@@ -103,9 +103,8 @@ class Problem(_api.Problem):
         nvars, ncon, nwcon, nineq, nwineq = _sizes(kwargs)
         rowp, cols = kwargs.get("rowp"), kwargs.get("cols")
         csr = rowp is not None and cols is not None  # CyParOptSparseProblem (ParOpt.pyx:854-881)
-        if not csr and nwcon > 0 and kwargs.get("nwblock", 1) not in (0, 1):
-            raise NotImplementedError("sparse constraints need nwblock = 1 or the CSR form (rowp=, cols=) on the "
-                                      "device path")
+        nwblock = max(1, int(kwargs.get("nwblock", 1) or 1))
+        self._nwblock = 1 if csr else nwblock
         self.comm = comm
         self._user = dict(gvb=self.getVarsAndBounds)
         self.getVarsAndBounds = self._gvb
@@ -148,7 +147,7 @@ class Problem(_api.Problem):
                 self.addSparseInnerProduct = lambda a, x, c, A: self._user["winner"](a, _Host(x), _Host(c), A)
         super().__init__(getContext(), nvars, ncon, nineq, nwcon=nwcon, nwinequality=nwineq,
                          use_lower=kwargs.get("use_lower", True), use_upper=kwargs.get("use_upper", True),
-                         rowp=rowp if csr else None, cols=cols if csr else None)
+                         rowp=rowp if csr else None, cols=cols if csr else None, nwblock=1 if csr else nwblock)
 
     def checkGradients(self, dh=1e-6, x=None, check_hvec_product=False):
         """ParOptProblem::checkGradients (src/ParOptProblem.cpp:376-620) on the host: directional
@@ -189,14 +188,24 @@ class Problem(_api.Problem):
                 d1, d2, abs(d1 - d2), out["transpose"]))
         if w > 0 and self._user.get("winner") is not None:
             cvec = np.array([0.05 + 0.25 * (i % 37) for i in range(n)])
-            Cw = np.zeros(w)
+            B = getattr(self, "_nwblock", 1)
+            Cw = np.zeros(w * (B + 1) // 2)
             self._user["winner"](1.0, _Host(xa), _Host(cvec), Cw)
             t = np.zeros(n)
             self._user["wjact"](1.0, _Host(xa), _Host(zw), _Host(t))
             t *= cvec
             cw2 = np.zeros(w)
             self._user["wjac"](1.0, _Host(xa), _Host(t), _Host(cw2))
-            d1, d2 = float(cw2 @ zw), float(np.sum(Cw * zw * zw))
+            if B == 1:
+                quad = float(np.sum(Cw * zw * zw))
+            else:  # packed upper blocks: (i, j), i <= j, of block b at b B (B+1)/2 + i + j (j+1)/2
+                quad, incr = 0.0, B * (B + 1) // 2
+                for b in range(w // B):
+                    for j in range(B):
+                        for i in range(j + 1):
+                            v = Cw[b * incr + i + j * (j + 1) // 2] * zw[b * B + i] * zw[b * B + j]
+                            quad += v if i == j else 2.0 * v
+            d1, d2 = float(cw2 @ zw), quad
             out["inner_product"] = abs(d1 - d2) / max(abs(d2), 1e-300)
             print("\nJ(x)*C^{-1}*J(x)^{T} test: \nProduct: %8.2e  Matrix: %8.2e  Err: %8.2e  Rel Err: %8.2e" % (
                 d1, d2, abs(d1 - d2), out["inner_product"]))

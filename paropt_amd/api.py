@@ -294,7 +294,8 @@ class Problem:
     (fail, fobj, con) and evalObjConGradient(x, g, A) -> fail, all on numpy views.  With
     nwcon > 0 (sparse constraints, nwblock = 1) also override evalSparseCon(x, out),
     addSparseJacobian(alpha, x, px, out), addSparseJacobianTranspose(alpha, x, pzw, out) and
-    addSparseInnerProduct(alpha, x, cvec, A) (A is the w-sized diagonal), all in place on numpy views.
+    addSparseInnerProduct(alpha, x, cvec, A) (A is the w-sized diagonal; with nwblock > 1 the packed upper
+    triangles of the nwblock x nwblock blocks, nwcon (nwblock+1)/2 entries), all in place on numpy views.
 
     With rowp / cols (the reference's CSR form, paropt/ParOpt.pyx:849-881) override instead
     evalSparseObjCon(x, sparse_cons) -> (fail, fobj, con) and evalSparseObjConGradient(x, g, A, data) -> fail;
@@ -302,7 +303,7 @@ class Problem:
     """
 
     def __init__(self, ctx, nvars, ncon, ninequality=-1, nwcon=0, nwinequality=0, use_lower=True,
-                 use_upper=True, rowp=None, cols=None):
+                 use_upper=True, rowp=None, cols=None, nwblock=1):
         self.ctx = ctx
         self.nvars, self.ncon = int(nvars), int(ncon)
         self.nwcon = int(nwcon)
@@ -443,6 +444,8 @@ class Problem:
              scb.add_sparse_inner_product) = self._scbs
             self._scb_struct = scb
             check(lib.po_problem_set_sparse_callbacks(self._h, self.nwcon, int(nwinequality), C.byref(scb)))
+            if int(nwblock) > 1:  # addSparseInnerProduct then fills packed upper nwblock x nwblock blocks
+                check(lib.po_problem_set_sparse_block_size(self._h, int(nwblock)))
 
     @property
     def handle(self):

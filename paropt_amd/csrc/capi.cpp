@@ -502,6 +502,15 @@ int po_csr_symbolic_destroy(po_csr_symbolic h) {
   return PO_OK;
 }
 const char *po_quasidef_factor_info(po_problem p) { return p && p->p ? p->p->sparseFactorInfo() : nullptr; }
+int po_problem_set_sparse_block_size(po_problem p, int nwblock) {
+  PO_CHECK_PTR(p);
+  CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);
+  if (!q || !q->sparse.set) {
+    po::set_error("po_problem_set_sparse_block_size needs a callback problem with sparse callbacks");
+    return PO_ERR_ARG;
+  }
+  return q->setSparseBlockSize(nwblock);
+}
 int po_problem_set_hessian_callbacks(po_problem p, po_hvec_fn hvec, po_hdiag_fn hdiag) {
   PO_CHECK_PTR(p);
   CallbackProblem *q = dynamic_cast<CallbackProblem *>(p->p);

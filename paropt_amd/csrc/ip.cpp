@@ -1552,7 +1552,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
 
     if (ctx->rank == 0) {  // iteration table :4777-4801
       if (k == 0 || options.integer("output_level") > 0) {  // :4767-4774
-        const char *inform = has_w ? prob->sparseFactorInfo() : nullptr;
+        const char *inform = prob->sparseFactorInfo();
         if (inform) history += std::string("MatInfo: ") + inform + "\n";
       }
       if (k % 10 == 0) {

@@ -15,7 +15,7 @@ class Problem {
  public:
   Problem(Ctx *c, int64_t nlocal_, int ncon_, int nineq_)
       : ctx(c), nlocal(nlocal_), offset(0), nglobal(nlocal_), ncon(ncon_), ninequality(nineq_) {}
-  virtual ~Problem() { delete csr; }
+  virtual ~Problem();
   virtual int getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) = 0;
   virtual int evalObjCon(Vec *x, double *fobj, double *cons) = 0;
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
@@ -57,13 +57,22 @@ class Problem {
   // bordered solve into a correction of the first.  Block form: -cw o (U alpha).  CSR form: -L^-T (Y alpha).
   virtual int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out);
   // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
-  virtual const char *sparseFactorInfo() { return csr ? csr->factorInfo() : nullptr; }
+  virtual const char *sparseFactorInfo();
   // number of factorizations so far that met a non-positive pivot (CSR form; 0 otherwise)
   virtual long sparseFactorBreakdowns() { return csr ? csr->breakdowns : 0; }
   // fixed CSR pattern of the sparse Jacobian (ParOptSparseProblem::setSparseJacobianData, .cpp:632-677);
   // owned.  Sets nwcon / nwinequality.
   int setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols);
   CsrSparse *csr = nullptr;
+  // block form with nwblock > 1 (ParOptQuasiDefBlockMat, src/ParOptSparseMat.cpp:11-229): consecutive blocks of
+  // nwblock constraints may share variables inside a block; addSparseInnerProduct then fills the packed upper
+  // triangles of the nwblock x nwblock blocks (nwcon (nwblock+1)/2 entries)
+  int setSparseBlockSize(int nwblock_);
+  int nwblock = 1;
+  Vec *blk = nullptr;    // packed blocks: C + Aw D^-1 Aw^T, then its Cholesky factor U (A = U^T U)
+  Vec *wones = nullptr;  // unit weights for the Gram of the half-solved panel
+  int *blk_flag = nullptr;
+  std::string factor_info;
 
   Ctx *ctx;
   int64_t nlocal, offset, nglobal;

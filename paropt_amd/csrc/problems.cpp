@@ -1,5 +1,8 @@
 // Problem implementations: the C-callback problem and the device-resident separable workloads.
 #include <math.h>
+#include <stdio.h>
+
+#include <string>
 
 #include "problem.hpp"
 
@@ -29,6 +32,36 @@ int Problem::setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *r
   nwinequality = nwineq_;
   return PO_OK;
 }
+Problem::~Problem() {
+  delete csr;
+  vec_decref(blk);
+  vec_decref(wones);
+  if (blk_flag) (void)hipFree(blk_flag);
+}
+const char *Problem::sparseFactorInfo() {
+  if (csr) return csr->factorInfo();
+  factor_info = "nblock: " + std::to_string(nwblock);  // ParOptQuasiDefBlockMat::getFactorInfo (:218-221)
+  return factor_info.c_str();
+}
+int Problem::setSparseBlockSize(int nwblock_) {
+  if (nwblock_ < 1 || nwblock_ > 16 || (nwcon % nwblock_) != 0 || csr) {
+    set_error("sparse block size %d: must be 1..16, divide the %lld local sparse constraints, and the problem must "
+              "not be in the CSR form", nwblock_, (long long)nwcon);
+    return PO_ERR_ARG;
+  }
+  vec_decref(blk);
+  vec_decref(wones);
+  blk = wones = nullptr;
+  nwblock = nwblock_;
+  if (nwblock > 1) {
+    blk = vec_new(ctx, nwcon * (nwblock + 1) / 2);
+    wones = vec_new(ctx, nwcon);
+    if (!blk || !wones) return PO_ERR_HIP;
+    PO_TRY(k_fill(ctx, wones->d, nwcon, 1.0));
+    if (!blk_flag) PO_HIP(hipMalloc((void **)&blk_flag, 4 * sizeof(int)));
+  }
+  return PO_OK;
+}
 // ParOptSparseProblem::evalSparseCon copies the values the last evaluation stored (.cpp:750-760)
 int Problem::evalSparseCon(Vec *, Vec *out) {
   if (!csr) return 0;
@@ -48,6 +81,21 @@ int Problem::addSparseInnerProduct(double alpha, Vec *, Vec *cvec, Vec *A) {
 }
 int Problem::sparseFactor(Vec *x, Vec *d, Vec *cw) {
   if (csr) return csr->factor(d->d, cw->d);
+  if (nwblock > 1) {  // :60-112
+    const int64_t nb = nwcon / nwblock;
+    PO_TRY(k_blk_init(ctx, cw->d, nb, nwblock, blk->d));
+    if (addSparseInnerProduct(1.0, x, d, blk) != 0) return PO_ERR_USER;
+    PO_HIP(hipMemsetAsync(blk_flag, 0, 4 * sizeof(int), ctx->stream));
+    PO_TRY(k_blk_factor(ctx, blk->d, nb, nwblock, blk_flag));
+    int flag[4] = {0, 0, 0, 0};
+    PO_HIP(hipMemcpyAsync(flag, blk_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
+    PO_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag[0] != 0 && ctx->rank == 0) {  // the reference returns dpptrf's info, which its caller ignores (:1930)
+      fprintf(stderr, "ParOpt warning: block %d of the sparse constraint matrix is not positive definite\n",
+              flag[1] / nwblock);
+    }
+    return PO_OK;
+  }
   if (addSparseInnerProduct(1.0, x, d, cw) != 0) return PO_ERR_USER;
   return k_recip(ctx, cw->d, nwcon);
 }
@@ -56,6 +104,10 @@ int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **w
     *weights = csr->unitWeights();
     return csr->halfSolve(U, nv);
   }
+  if (nwblock > 1) {  // S = U^T U per block: U_panel^T S^-1 U_panel = (U^-T P)^T (U^-T P)
+    *weights = wones->d;
+    return k_blk_solve(ctx, blk->d, nwcon / nwblock, nwblock, U, nv, 1);
+  }
   *weights = cw->d;
   return PO_OK;
 }
@@ -63,6 +115,11 @@ int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **w
 int Problem::sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) {
   if (csr) return csr->correction(U, nv, alpha, out->d);
   PO_TRY(k_panel_axpy(ctx, out->d, 0.0, nullptr, 0.0, alpha, U, nv, nwcon));
+  if (nwblock > 1) {  // -U^-1 (Y alpha)
+    double *Y[1] = {out->d};
+    PO_TRY(k_blk_solve(ctx, blk->d, nwcon / nwblock, nwblock, Y, 1, 2));
+    return k_scale(ctx, out->d, nwcon, -1.0);
+  }
   return k_mul(ctx, out->d, -1.0, cw->d, out->d, nwcon);
 }
 
@@ -89,7 +146,12 @@ int Problem::sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const doub
     PO_TRY(k_fill(ctx, yw->d, w, 0.0));
   }
   if (addSparseJacobian(-1.0, x, yx, yw) != 0) return PO_ERR_USER;
-  PO_TRY(k_mul(ctx, yw->d, 1.0, cw->d, yw->d, w));
+  if (nwblock > 1) {  // applyFactor (:192-216)
+    double *Y[1] = {yw->d};
+    PO_TRY(k_blk_solve(ctx, blk->d, w / nwblock, nwblock, Y, 1, 0));
+  } else {
+    PO_TRY(k_mul(ctx, yw->d, 1.0, cw->d, yw->d, w));
+  }
   PO_TRY(k_copy(ctx, yx->d, bx, n));
   if (addSparseJacobianTranspose(1.0, x, yw, yx) != 0) return PO_ERR_USER;
   PO_TRY(k_mul(ctx, yx->d, 1.0, d->d, yx->d, n));

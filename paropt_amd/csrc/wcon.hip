@@ -251,6 +251,96 @@ int k_w_apply_mid(Ctx *c, const double *cw, const double *bw, const double *u, i
   return PO_OK;
 }
 
+// ---- nwblock > 1: block-diagonal Cw with dense nwblock x nwblock blocks (ParOptQuasiDefBlockMat, reference
+// src/ParOptSparseMat.cpp:41-229), LAPACK's packed upper storage per block: (i, j), i <= j, at i + j (j+1)/2.
+// One thread per block (the blocks are a handful of entries); kMaxBlock bounds the unrolled local arrays.
+constexpr int kMaxBlock = 16;
+// blocks <- diag(cdiag) (:60-76), before the problem's addSparseInnerProduct adds Aw D^-1 Aw^T
+__global__ void __launch_bounds__(kBlock)
+    blk_init_kernel(const double *__restrict__ cdiag, int64_t nblocks, int B, double *__restrict__ blk) {
+  const int incr = B * (B + 1) / 2;
+  PO_W_LOOP(b, nblocks) {
+    double *a = blk + b * incr;
+    for (int t = 0; t < incr; t++) a[t] = 0.0;
+    for (int j = 0; j < B; j++) a[j + j * (j + 1) / 2] = cdiag[b * B + j];
+  }
+}
+int k_blk_init(Ctx *c, const double *cdiag, int64_t nblocks, int B, double *blk) {
+  if (nblocks <= 0) return PO_OK;
+  PO_WLAUNCH(blk_init_kernel, wgrid(c, nblocks), cdiag, nblocks, B, blk);
+  return PO_OK;
+}
+// A = U^T U in place (dpptrf "U", :104-112)
+__global__ void __launch_bounds__(kBlock) blk_factor_kernel(double *__restrict__ blk, int64_t nblocks, int B, int *flag) {
+  const int incr = B * (B + 1) / 2;
+  PO_W_LOOP(b, nblocks) {
+    double *a = blk + b * incr;
+    for (int j = 0; j < B; j++) {
+      const int cj = j * (j + 1) / 2;
+      for (int i = 0; i < j; i++) {
+        const int ci = i * (i + 1) / 2;
+        double v = a[i + cj];
+        for (int k = 0; k < i; k++) v -= a[k + ci] * a[k + cj];
+        a[i + cj] = v / a[i + ci];
+      }
+      double d = a[j + cj];
+      for (int k = 0; k < j; k++) d -= a[k + cj] * a[k + cj];
+      if (!(d > 0.0)) {
+        flag[0] = 1;
+        flag[1] = (int)(b * B + j);
+        d = 1.0;
+      }
+      a[j + cj] = sqrt(d);
+    }
+  }
+}
+int k_blk_factor(Ctx *c, double *blk, int64_t nblocks, int B, int *flag) {
+  if (nblocks <= 0) return PO_OK;
+  PO_WLAUNCH(blk_factor_kernel, wgrid(c, nblocks), blk, nblocks, B, flag);
+  return PO_OK;
+}
+// mode 0: y <- (U^T U)^-1 y (dpptrs, :199-216); mode 1: y <- U^-T y; mode 2: y <- U^-1 y.  One thread per
+// (block, right-hand side).
+__global__ void __launch_bounds__(kBlock)
+    blk_solve_kernel(const double *__restrict__ blk, int64_t nblocks, int B, PtrTableW Y, int nv, int mode) {
+  const int incr = B * (B + 1) / 2;
+  PO_W_LOOP(t, nblocks * nv) {
+    const int r = (int)(t / nblocks);
+    const int64_t b = t - (int64_t)r * nblocks;
+    const double *a = blk + b * incr;
+    double *y = Y.p[r] + b * B;
+    double v[kMaxBlock];
+    for (int j = 0; j < B; j++) v[j] = y[j];
+    if (mode != 2) {  // U^T z = y, forward
+      for (int j = 0; j < B; j++) {
+        const int cj = j * (j + 1) / 2;
+        double s = v[j];
+        for (int i = 0; i < j; i++) s -= a[i + cj] * v[i];
+        v[j] = s / a[j + cj];
+      }
+    }
+    if (mode != 1) {  // U x = z, backward
+      for (int j = B - 1; j >= 0; j--) {
+        double s = v[j];
+        for (int k = j + 1; k < B; k++) s -= a[j + k * (k + 1) / 2] * v[k];
+        v[j] = s / a[j + j * (j + 1) / 2];
+      }
+    }
+    for (int j = 0; j < B; j++) y[j] = v[j];
+  }
+}
+int k_blk_solve(Ctx *c, const double *blk, int64_t nblocks, int B, double *const *Y, int nv, int mode) {
+  if (nblocks <= 0 || nv <= 0) return PO_OK;
+  if (B > kMaxBlock || nv > kMaxPanel) {
+    set_error("block solve: nwblock %d (max %d) or %d right-hand sides (max %d)", B, kMaxBlock, nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  PtrTableW t;
+  for (int j = 0; j < kMaxPanel; j++) t.p[j] = j < nv ? Y[j] : Y[0];
+  PO_WLAUNCH(blk_solve_kernel, wgrid(c, nblocks * nv), blk, nblocks, B, t, nv, mode);
+  return PO_OK;
+}
+
 // ---- small element-wise helpers ---------------------------------------------------------------------
 // y = a * x1 * x2   (x2 may be null -> y = a * x1)
 __global__ void __launch_bounds__(kBlock)

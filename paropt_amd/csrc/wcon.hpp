@@ -28,6 +28,10 @@ int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, con
 int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, double alpha, const double *yw,
                   int64_t n, double *yx);
 int k_w_apply_mid(Ctx *c, const double *cw, const double *bw, const double *u, int64_t w, double *yw);
+// nwblock > 1: packed upper blocks of Cw (wcon.hip)
+int k_blk_init(Ctx *c, const double *cdiag, int64_t nblocks, int B, double *blk);
+int k_blk_factor(Ctx *c, double *blk, int64_t nblocks, int B, int *flag);
+int k_blk_solve(Ctx *c, const double *blk, int64_t nblocks, int B, double *const *Y, int nv, int mode);
 int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n);
 int k_recip(Ctx *c, double *y, int64_t n);
 

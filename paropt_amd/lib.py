@@ -140,6 +140,7 @@ SIGNATURES = {
     "po_problem_get_sparse_jacobian_data": (
         C.c_int, [po_problem, c_int_pp, c_int_pp, C.POINTER(C.c_void_p), c_i64_p]),
     "po_problem_set_chain": (C.c_int, [po_problem, C.c_int, C.c_int, C.c_int]),
+    "po_problem_set_sparse_block_size": (C.c_int, [po_problem, C.c_int]),
     "po_quasidef_factor": (C.c_int, [po_problem, po_vec, po_vec, po_vec]),
     "po_quasidef_apply": (C.c_int, [po_problem, po_vec, po_vec, po_vec, po_vec, po_vec, po_vec, po_vec]),
     "po_quasidef_factor_info": (C.c_char_p, [po_problem]),

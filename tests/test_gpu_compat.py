@@ -515,3 +515,68 @@ def test_polygon_style_dense_vs_sparse_forms():
         assert fobj_grad(xx)[0] < fobj_grad(x0)[0]
     print("polygon objective: sparse form %.8f, dense form %.8f" % (fobj_grad(xs)[0], fobj_grad(xd)[0]))
     assert abs(fobj_grad(xs)[0] - fobj_grad(xd)[0]) <= 1e-2 * abs(fobj_grad(xd)[0])
+
+
+@pytest.mark.parametrize("name", ["ipw_rosenbrock_n240_w60_nwblock3", "ipw_quadratic_n240_c2_w60_nwblock3"])
+def test_nwblock_three_matches_reference_golden(name):
+    """Sparse constraints in the callback block form with nwblock = 3 (ParOptQuasiDefBlockMat, packed 3 x 3 blocks
+    from addSparseInnerProduct) through the reference's Python interface, against the trajectories the reference
+    produced on the same problems (tests/golden/ipw_*_nwblock3.npz)."""
+    from conftest import ip_options_from_case, load_golden
+    from oracle import paropt_oracle as po  # problem data only
+    from paropt_amd import ParOpt
+
+    g, case = load_golden(name)
+    a = case["args"]
+    n, w, B, nw = a["n"], a["nwcon"], a["nwblock"], a["nw"]
+    data = po.SepProblem(a["problem"], n, a.get("c", 2), nwcon=w, nw=nw, nwstart=a["nwstart"], nwskip=a["nwskip"],
+                         nwblock=B)
+    nc = data.c
+    Aw = data.sparse_jacobian_dense()  # constant: the constraints are linear
+
+    class Blocked(ParOpt.Problem):
+        def __init__(self):
+            super(Blocked, self).__init__(None, nvars=n, ncon=nc, nwcon=w, nwblock=B)
+
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:], lb[:], ub[:] = data.vars_and_bounds()
+
+        def evalObjCon(self, x):
+            return data.eval_obj_con(np.array(x[:]))
+
+        def evalObjConGradient(self, x, g_, A):
+            fail, gg, AA = data.eval_obj_con_gradient(np.array(x[:]))
+            g_[:] = gg
+            for j in range(nc):
+                A[j][:] = AA[j]
+            return fail
+
+        def evalSparseCon(self, x, con):
+            con[:] = 1.0 + Aw @ np.array(x[:])
+
+        def addSparseJacobian(self, alpha, x, px, con):
+            con[:] = np.array(con[:]) + alpha * (Aw @ np.array(px[:]))
+
+        def addSparseJacobianTranspose(self, alpha, x, pz, out):
+            out[:] = np.array(out[:]) + alpha * (Aw.T @ np.array(pz[:]))
+
+        def addSparseInnerProduct(self, alpha, x, c, A):
+            S = (Aw * np.array(c[:])) @ Aw.T
+            incr = B * (B + 1) // 2
+            for b in range(w // B):
+                for j in range(B):
+                    for i in range(j + 1):
+                        A[b * incr + i + j * (j + 1) // 2] += alpha * S[b * B + i, b * B + j]
+
+    errs = Blocked().checkGradients(x=np.random.RandomState(1).uniform(-1.5, 0.5, size=n))
+    assert errs["transpose"] < 1e-12 and errs["inner_product"] < 1e-12
+    opts = ip_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    opt = ParOpt.Optimizer(Blocked(), dict(opts, algorithm="ip", output_file=None))
+    opt.optimize()
+    x, z, zw, zl, zu = opt.getOptimizedPoint()
+    np.testing.assert_array_equal(np.array(opt.ip.getIterationCounters()), g["final/counters"])
+    assert abs(opt.ip.getObjective()[0] - g["final/fobj"][0]) <= 1e-6 * abs(g["final/fobj"][0])
+    np.testing.assert_allclose(x[:], g["final/x"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(z, g["final/z"], rtol=1e-5, atol=1e-6)
+    assert "MatInfo: nblock: 3" in opt.ip.getHistory()

@@ -72,7 +72,7 @@ def run_gpu(ctx, case, want_vectors=False):
 
 
 IP_CASES = [n for n in golden_names("ip_") + golden_names("ipw_") + golden_names("ipcsr_")
-            if not n.endswith("_r2") and "checkpoint" not in n]
+            if not n.endswith("_r2") and "checkpoint" not in n and "nwblock" not in n]  # nwblock: test_gpu_compat
 
 
 @pytest.mark.parametrize("name", IP_CASES)

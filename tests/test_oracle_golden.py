@@ -104,6 +104,7 @@ def run_oracle_ip(case, nmax=None):
         nwcon=a.get("nwcon", 0), nw=a.get("nw", 0), nwstart=a.get("nwstart", 0),
         nwskip=a.get("nwskip", 0), nwineq=a.get("nwineq", -1),
         chain=(a["chain_span"], a.get("chain_stride", 1)) if a.get("chain_span", 0) else None,
+        nwblock=a.get("nwblock", 1),
     )
     prob.use_lower = bool(a.get("use_lower", 1))
     prob.use_upper = bool(a.get("use_upper", 1))
