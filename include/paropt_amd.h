@@ -69,6 +69,15 @@ int po_live_objects(int64_t *vectors, int64_t *bytes);
  * kernel milliseconds and the number of launches. */
 int po_ctx_time_mdot(po_ctx ctx, int nvecs);
 int po_ctx_time_mdot_result(po_ctx ctx, double *ms_total, int64_t *launches);
+/* The same for the weighted-Gram launches of setUpKKTDiagSystem/setUpKKTSystem (src/ParOptInteriorPoint.cpp:
+ * 1935-1950, 2648-2654): which = 0 the plain launches, 1 the launches that also form the L-SR1 columns;
+ * ncols = panel width of the last timed launch, alg_bytes_total = algorithmic HBM bytes of the timed launches. */
+int po_ctx_time_wgram(po_ctx ctx, int on);
+int po_ctx_time_wgram_result(po_ctx ctx, int which, double *ms_total, int64_t *launches, int *ncols,
+                             double *alg_bytes_total);
+/* Communicator in use (0 self, 1 RCCL, 2 host callback) and the collectives issued so far: pure-sum
+ * reductions go through ncclAllReduce, mixed SUM/MIN/MAX payloads through one rank-ordered ncclAllGather. */
+int po_ctx_comm_info(po_ctx ctx, int *kind, int64_t *allreduces, int64_t *allgathers);
 /* Copy between a host buffer and a raw device array this library handed out (the Jacobian entries of
  * po_problem_set_sparse_jacobian_data), ordered with the context's stream; returns when the copy is done.
  * to_device != 0: host -> device. */
@@ -251,6 +260,12 @@ int po_problem_set_chain(po_problem p, int span, int stride, int reverse_cols);
  * a problem that declares a side unused never has that side's bound multipliers formed.  Before
  * po_ip_create. */
 int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper);
+/* Declares that the DENSE constraints are linear in x (their Jacobian is constant).  The reference's contract
+ * (src/ParOptProblem.h:146-158) has evalObjConGradient rewrite all ncon gradient vectors at every call; with this
+ * flag the solver keeps the Jacobian of the first evaluation of each optimize() call and afterwards invokes the
+ * gradient callback with Ac == NULL ("objective gradient only").  Off by default: without it Ac is never NULL.
+ * Rejected (PO_ERR_ARG) for the built-in Rosenbrock problem, whose constraints are not linear. */
+int po_problem_set_linear_constraints(po_problem p, int flag);
 int po_problem_destroy(po_problem p);
 int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon);
 int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons);
@@ -323,6 +338,9 @@ int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W);
  * time in milliseconds measured with HIP events on that stream (bench.py's roofline leg). */
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out);
 int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *avg_ms);
+/* Same-run stream ceilings on the context stream: kind 0 = read-only (x.y, 16 B per element),
+ * kind 1 = copy y <- x (8 B read + 8 B written per element); average kernel milliseconds over `reps`. */
+int po_bench_stream(po_vec x, po_vec y, int kind, int reps, double *avg_ms);
 
 /* ---- ParOptTrustRegion over the quadratic / compact-eigenvalue subproblem ------------------------
  * src/ParOptTrustRegion.h:376-480, set up as ParOptOptimizer does for algorithm = "tr"

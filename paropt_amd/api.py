@@ -49,6 +49,24 @@ class Context:
         check(lib.po_ctx_time_mdot_result(self._h, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
+    def time_wgram(self, on):
+        """Bracket every weighted-Gram launch with HIP events (resets the totals)."""
+        check(lib.po_ctx_time_wgram(self._h, int(bool(on))))
+
+    def time_wgram_result(self, which):
+        """(kernel ms, launches, panel width, algorithmic bytes) of the timed weighted-Gram launches;
+        which = 0 plain launches, 1 launches that also form the L-SR1 columns."""
+        ms, cnt, cols, byt = C.c_double(), C.c_int64(), C.c_int(), C.c_double()
+        check(lib.po_ctx_time_wgram_result(self._h, int(which), C.byref(ms), C.byref(cnt), C.byref(cols),
+                                           C.byref(byt)))
+        return ms.value, cnt.value, cols.value, byt.value
+
+    def comm_info(self):
+        """(communicator kind: 0 self / 1 RCCL / 2 host callback, ncclAllReduce calls, ncclAllGather calls)."""
+        k, a, b = C.c_int(), C.c_int64(), C.c_int64()
+        check(lib.po_ctx_comm_info(self._h, C.byref(k), C.byref(a), C.byref(b)))
+        return k.value, a.value, b.value
+
     def counters(self):
         """(host-synchronising reductions, kernel launches) issued on this context so far."""
         a, b = C.c_int64(), C.c_int64()
@@ -330,9 +348,10 @@ class Problem:
         def _grad(user, x, g, Ac):
             vx = PVec(ctx, handle=L.po_vec(x), owned=False)
             vg = PVec(ctx, handle=L.po_vec(g), owned=False)
-            va = [PVec(ctx, handle=L.po_vec(Ac[j]), owned=False) for j in range(self.ncon)]
+            # Ac is NULL when the problem declared linear constraints and only the objective gradient is wanted
+            va = [PVec(ctx, handle=L.po_vec(Ac[j]), owned=False) for j in range(self.ncon)] if Ac else []
             ag = vg.getArray()
-            aa = [v.getArray() for v in va]
+            aa = [v.getArray() for v in va] if Ac else None
             fail = self.evalObjConGradient(vx.to_numpy(), ag, aa)
             vg.syncToDevice()
             for v in va:
@@ -490,6 +509,12 @@ class SeparableProblem:
 
     def setVarBoundOptions(self, use_lower=True, use_upper=True):
         check(lib.po_problem_set_var_bound_options(self._h, int(bool(use_lower)), int(bool(use_upper))))
+        return self
+
+    def setLinearConstraints(self, flag=True):
+        """The dense constraints are linear: the solver keeps the Jacobian of the first gradient evaluation
+        of each optimize() and asks for the objective gradient only afterwards (po_problem_set_linear_constraints)."""
+        check(lib.po_problem_set_linear_constraints(self._h, int(bool(flag))))
         return self
 
     @property
@@ -980,6 +1005,13 @@ def bench_mdot(x, vecs, reps=10):
     out = np.zeros(max(nv, 1))
     check(lib.po_bench_mdot(x.handle, arr, nv, int(reps), C.byref(ms), out.ctypes.data_as(L.c_double_p)))
     return ms.value, out[:nv]
+
+
+def bench_stream(x, y, kind, reps=10):
+    """Average kernel ms of a read-only stream (kind 0: x.y) or a copy (kind 1: y <- x), HIP events."""
+    ms = C.c_double()
+    check(lib.po_bench_stream(x.handle, y.handle, int(kind), int(reps), C.byref(ms)))
+    return ms.value
 
 
 def bench_wgram(d, vecs, reps=10):

@@ -85,6 +85,34 @@ int po_ctx_time_mdot_result(po_ctx ctx, double *ms_total, int64_t *launches) {
   if (launches) *launches = ctx->mdot_count;
   return PO_OK;
 }
+int po_ctx_time_wgram(po_ctx ctx, int on) {
+  PO_CHECK_PTR(ctx);
+  ctx->time_wgram = on ? 1 : 0;
+  for (int i = 0; i < 2; i++) {
+    ctx->wgram_ms[i] = 0.0;
+    ctx->wgram_count[i] = 0;
+    ctx->wgram_cols[i] = 0;
+    ctx->wgram_bytes[i] = 0.0;
+  }
+  return PO_OK;
+}
+int po_ctx_time_wgram_result(po_ctx ctx, int which, double *ms_total, int64_t *launches, int *ncols,
+                             double *alg_bytes_total) {
+  PO_CHECK_PTR(ctx);
+  if (which < 0 || which > 1) return PO_ERR_ARG;
+  if (ms_total) *ms_total = ctx->wgram_ms[which];
+  if (launches) *launches = ctx->wgram_count[which];
+  if (ncols) *ncols = ctx->wgram_cols[which];
+  if (alg_bytes_total) *alg_bytes_total = ctx->wgram_bytes[which];
+  return PO_OK;
+}
+int po_ctx_comm_info(po_ctx ctx, int *kind, int64_t *allreduces, int64_t *allgathers) {
+  PO_CHECK_PTR(ctx);
+  if (kind) *kind = (int)ctx->comm_kind;
+  if (allreduces) *allreduces = ctx->n_allreduce;
+  if (allgathers) *allgathers = ctx->n_allgather;
+  return PO_OK;
+}
 int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_device) {
   PO_CHECK_PTR(ctx);
   if (bytes <= 0) return PO_OK;
@@ -553,6 +581,16 @@ int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper)
   p->p->use_upper = use_upper ? 1 : 0;
   return PO_OK;
 }
+int po_problem_set_linear_constraints(po_problem p, int flag) {
+  PO_CHECK_PTR(p);
+  SeparableProblem *sp = dynamic_cast<SeparableProblem *>(p->p);
+  if (flag && sp && sp->kind == PO_PROBLEM_ROSENBROCK) {
+    set_error("the Rosenbrock problem's constraints are not linear");
+    return PO_ERR_ARG;
+  }
+  p->p->linear_constraints = flag ? 1 : 0;
+  return PO_OK;
+}
 int po_problem_destroy(po_problem p) {
   if (!p) return PO_OK;
   delete p->p;
@@ -804,6 +842,23 @@ int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg
   PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *avg_ms = (double)ms / (reps > 0 ? reps : 1);
   if (out) PO_TRY(reduce_finish(c, grid, nvecs, 0, 0, out));
+  return PO_OK;
+}
+int po_bench_stream(po_vec x, po_vec y, int kind, int reps, double *avg_ms) {
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(y);
+  PO_CHECK_PTR(avg_ms);
+  if (x->n != y->n || x->ctx != y->ctx) return PO_ERR_ARG;
+  Ctx *c = x->ctx;
+  PO_TRY(k_stream_launch(c, kind, x->d, y->d, x->n));  // warm-up
+  PO_HIP(hipStreamSynchronize(c->stream));
+  PO_HIP(hipEventRecord(c->ev0, c->stream));
+  for (int r = 0; r < reps; r++) PO_TRY(k_stream_launch(c, kind, x->d, y->d, x->n));
+  PO_HIP(hipEventRecord(c->ev1, c->stream));
+  PO_HIP(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *avg_ms = (double)ms / (reps > 0 ? reps : 1);
   return PO_OK;
 }
 int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *avg_ms) {

@@ -33,6 +33,7 @@ struct RcclApi {
   int (*GetUniqueId)(void *) = nullptr;
   int (*CommInitRank)(void **, int, Id128, int) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
@@ -54,9 +55,12 @@ static int load_rccl() {
   g_rccl.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(h, "ncclCommInitRank");
   g_rccl.AllGather =
       (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(h, "ncclAllGather");
+  g_rccl.AllReduce =
+      (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce ||
+      !g_rccl.CommDestroy) {
     set_error("librccl.so lacks an expected symbol");
     dlclose(h);
     return PO_ERR_COMM;
@@ -103,6 +107,9 @@ int comm_init_rccl(Ctx *c, int rank, int size, const void *id128) {
   }
   c->rccl_comm = comm;
   c->comm_kind = COMM_RCCL;
+  // PAROPT_AMD_RCCL_ALLGATHER=1: every reduction through the rank-ordered all-gather (bit-identical across
+  // rank-to-GPU placements); default: pure-sum payloads use ncclAllReduce, mixed SUM/MIN/MAX the all-gather
+  c->rccl_allreduce = getenv("PAROPT_AMD_RCCL_ALLGATHER") ? 0 : 1;
   // gather buffers sized for the communicator
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -193,7 +200,21 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
   const size_t bytes = sizeof(double) * (size_t)nslots;
   int nparts = 1;
   const double *parts = c->h_red;
-  if (c->comm_kind == COMM_RCCL) {
+  if (c->comm_kind == COMM_RCCL && c->rccl_allreduce && nmin == 0 && nmax == 0) {
+    // the MPI_Allreduce(SUM) sites of the reference (dot/mdot/Gram entries, src/ParOptVec.cpp:124-170,
+    // src/ParOptInteriorPoint.cpp:1957) -> ONE ncclAllReduce over xGMI on the solver's stream, in place in d_red;
+    // every rank receives the same bits (the reduced value is produced once per chunk and broadcast)
+    int rc = g_rccl.AllReduce(c->d_red, c->d_red, (size_t)nslots, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm,
+                              c->stream);
+    if (rc != 0) {
+      set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+      return PO_ERR_COMM;
+    }
+    c->n_allreduce++;
+    PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
+    PO_HIP(hipStreamSynchronize(c->stream));
+  } else if (c->comm_kind == COMM_RCCL) {
+    c->n_allgather++;
     int rc = g_rccl.AllGather(c->d_red, c->d_gather, (size_t)nslots, /*ncclDouble*/ 8, c->rccl_comm,
                               c->stream);
     if (rc != 0) {

@@ -49,6 +49,8 @@ struct Ctx {
   int rank = 0, size = 1;
   CommKind comm_kind = COMM_SELF;
   void *rccl_comm = nullptr;
+  int rccl_allreduce = 1;  // pure-sum reductions through ncclAllReduce (else everything through the all-gather)
+  long n_allreduce = 0, n_allgather = 0;
   po_allgather_fn cb_allgather = nullptr;
   void *cb_user = nullptr;
   // reduction plumbing
@@ -64,6 +66,12 @@ struct Ctx {
   int time_mdot_nv = 0;
   double mdot_ms = 0.0;
   long mdot_count = 0;
+  // the same for the weighted-Gram launches (po_ctx_time_wgram): [0] plain, [1] with L-SR1 columns formed in the pass
+  int time_wgram = 0;
+  double wgram_ms[2] = {0.0, 0.0};
+  long wgram_count[2] = {0, 0};
+  int wgram_cols[2] = {0, 0};
+  double wgram_bytes[2] = {0.0, 0.0};  // algorithmic bytes of the timed launches
 };
 
 struct Vec {
@@ -106,6 +114,7 @@ enum Red1 { RED_DOT = 0, RED_SUMSQ = 1, RED_ASUM = 2, RED_AMAX = 3 };
 int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out);
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out);
 // launch-only variant for the roofline bench (no host sync); result stays in partials
+int k_stream_launch(Ctx *c, int kind, double *x, double *y, int64_t n);  // bench: 0 = x.y, 1 = y <- x
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks);
 // W = V^T diag(d) V.  With kpend > 0 the first kpend (<= 12) columns are L-SR1 columns still to be
 // formed: V[j] = Y_j, S[j] = S_j, and Z_j = Y_j - b0 S_j is used for the Gram AND written to Zout[j].

@@ -374,6 +374,8 @@ InteriorPoint::~InteriorPoint() {
   for (Vec *v : gmresW) vec_decref(v);
   vec_decref(hdiag);
   if (qn_owned) delete qn;
+  if (user_events_ready)
+    for (int i = 0; i < 2 * kUserRing; i++) (void)hipEventDestroy(user_ev[i]);
 }
 
 void InteriorPoint::setPenaltyGamma(double gamma) {  // :1127-1151
@@ -400,6 +402,7 @@ int InteriorPoint::resetProblemInstance(Problem *p) {  // :745-764
     return PO_ERR_ARG;
   }
   prob = p;
+  ac_valid = false;
   return PO_OK;
 }
 
@@ -477,6 +480,30 @@ void InteriorPoint::phaseEnd(const char *name) {
   phase_names.push_back(name);
   phase_seconds.push_back(t1 - phase_t0);
   phase_t0 = t1;
+}
+
+void InteriorPoint::userBegin() {
+  if (!user_events_ready) {
+    for (int i = 0; i < 2 * kUserRing; i++)
+      if (hipEventCreate(&user_ev[i]) != hipSuccess) return;
+    user_events_ready = true;
+  }
+  if (user_pending == kUserRing) userHarvest();
+  (void)hipEventRecord(user_ev[2 * user_pending], ctx->stream);
+}
+void InteriorPoint::userEnd() {
+  if (!user_events_ready) return;
+  (void)hipEventRecord(user_ev[2 * user_pending + 1], ctx->stream);
+  user_pending++;
+}
+void InteriorPoint::userHarvest() {
+  for (int i = 0; i < user_pending; i++) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(user_ev[2 * i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, user_ev[2 * i], user_ev[2 * i + 1]) == hipSuccess)
+      user_seconds += 1e-3 * ms;
+  }
+  user_pending = 0;
 }
 
 // ================================================================================================
@@ -1230,7 +1257,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
     clampStepDense(rs, vars.s, alpha, step.s, eps, true);
     clampStepDense(rt, vars.t, alpha, step.t, eps, true);
+    userBegin();
     int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
+    userEnd();
     neval++;
     if (fail_obj) {
       fprintf(stderr, "ParOpt: Evaluation failed during line search, trying new point\n");
@@ -1353,7 +1382,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
       return PO_ERR_USER;
     }
   }
-  int fail_g = prob->evalObjConGradient(x, g, Ac.data());
+  // a problem with linear dense constraints keeps the Jacobian of the first evaluation (Ac == nullptr)
+  userBegin();
+  int fail_g = prob->evalObjConGradient(x, g, (prob->linear_constraints && ac_valid) ? nullptr : Ac.data());
+  userEnd();
   ngeval++;
   if (fail_g) fprintf(stderr, "ParOpt: Gradient evaluation failed at final line search\n");
   if (do_qn) {
@@ -1445,6 +1477,9 @@ int InteriorPoint::optimize(const char *checkpoint) {
   history.clear();
   phase_names.clear();
   phase_seconds.clear();
+  user_seconds = 0.0;
+  user_pending = 0;
+  ac_valid = false;
   if (!seq_lin && !qn && !use_diag_hessian) {
     if (ctx->rank == 0)
       fprintf(stderr,
@@ -1454,18 +1489,23 @@ int InteriorPoint::optimize(const char *checkpoint) {
   }
   phaseBegin();
   PO_TRY(initAndCheckDesignAndBounds());
+  userBegin();
   int fail_obj = prob->evalObjCon(x, &fobj, cvals.data());
+  userEnd();
   neval++;
   if (fail_obj) {
     fprintf(stderr, "ParOpt: Initial function and constraint evaluation failed\n");
     return fail_obj;
   }
+  userBegin();
   int fail_g = prob->evalObjConGradient(x, g, Ac.data());
+  userEnd();
   ngeval++;
   if (fail_g) {
     fprintf(stderr, "ParOpt: Initial gradient evaluation failed\n");
     return fail_g;
   }
+  ac_valid = true;
   if (start == "affine_step") {
     PO_TRY(initAffineStepMultipliers());
   } else if (start == "least_squares_multipliers") {
@@ -1828,6 +1868,9 @@ int InteriorPoint::optimize(const char *checkpoint) {
 // The reference streams the iteration table to `output_file` on the root rank (setOutputFile
 // :1297-1309, :4777-4805); here it is accumulated in `history` and written when optimize returns.
 void InteriorPoint::flushHistory() {
+  userHarvest();
+  phase_names.push_back("user_eval");
+  phase_seconds.push_back(user_seconds);
   const std::string fname = options.str("output_file");
   // debugging aid: PAROPT_AMD_DUMP_LONG_SOLVES=<N> prints the head and tail of the iteration table of
   // every solve that took at least N major iterations (e.g. a stalled trust-region subproblem)

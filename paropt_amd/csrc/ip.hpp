@@ -212,6 +212,17 @@ class InteriorPoint {
   void phaseBegin();
   void phaseEnd(const char *name);
   double phase_t0;
+  // HIP-event time of the user's problem callbacks (evalObjCon / evalObjConGradient): reported as the phase
+  // "user_eval", a SUBSET of the init / line_search / step_update phases that contain the calls
+  static const int kUserRing = 16;
+  hipEvent_t user_ev[2 * kUserRing];
+  int user_pending = 0;
+  bool user_events_ready = false;
+  double user_seconds = 0.0;
+  void userBegin();
+  void userEnd();
+  void userHarvest();
+  bool ac_valid = false;  // Ac holds the Jacobian of a problem with linear_constraints
 };
 
 }  // namespace po

@@ -358,6 +358,23 @@ int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X
   return PO_OK;
 }
 
+// stream ceilings for the bench line (po_bench_stream): read-only x.y and copy y <- x, no host sync
+template <int KIND>
+__global__ void __launch_bounds__(kBlock)
+    reduce1_kernel(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
+                   double *__restrict__ partials);
+int k_stream_launch(Ctx *c, int kind, double *x, double *y, int64_t n) {
+  if (n <= 0) return PO_OK;
+  if (kind == 0) {
+    const int grid = grid_for(c, n, 5);
+    PO_TRY(ensure_partials(c, (size_t)grid));
+    PO_LAUNCH(reduce1_kernel<RED_DOT>, grid, x, y, n, c->d_partials);
+  } else {
+    PO_LAUNCH(copy_kernel, grid_for(c, n), y, x, n);
+  }
+  return PO_OK;
+}
+
 // dot / sum of squares / asum / amax
 template <int KIND>
 __global__ void __launch_bounds__(kBlock)
@@ -700,9 +717,21 @@ int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, 
             const double *const *S, double *const *Zout, int kpend, double b0) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
+  const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream
+  if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0));
+  if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
   std::vector<double> blocks(nslots);
-  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));  // synchronises the stream
+  if (timed) {
+    float ms = 0.0f;
+    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const int w = kpend > 0 ? 1 : 0;
+    c->wgram_ms[w] += ms;
+    c->wgram_count[w]++;
+    c->wgram_cols[w] = nv;
+    c->wgram_bytes[w] += 8.0 * (double)n * (nv + 1 + 2 * kpend);  // panel + weights (+ S read, Z written)
+  }
   const int MB = (nv + 15) / 16;
   int b = 0;
   for (int rb = 0; rb < MB; rb++) {

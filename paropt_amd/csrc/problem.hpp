@@ -18,7 +18,12 @@ class Problem {
   virtual ~Problem();
   virtual int getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) = 0;
   virtual int evalObjCon(Vec *x, double *fobj, double *cons) = 0;
+  // Ac == nullptr: only the objective gradient is wanted.  The solver passes nullptr after the first full
+  // evaluation of an optimize() call when the problem has declared `linear_constraints` (the dense constraint
+  // Jacobian does not depend on x, po_problem_set_linear_constraints), and never otherwise -- the reference's
+  // contract (src/ParOptProblem.h:146-158) is unchanged for problems that do not set the flag.
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
+  int linear_constraints = 0;
   virtual int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) { return 0; }
   virtual int writeOutput(int iter, Vec *x) { return 0; }
   virtual int useLowerBounds() { return use_lower; }

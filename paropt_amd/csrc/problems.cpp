@@ -177,7 +177,7 @@ int CallbackProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
 }
 int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   std::vector<po_vec> h(ncon > 0 ? ncon : 1);
-  for (int j = 0; j < ncon; j++) h[j] = static_cast<po_vec>(Ac[j]);
+  for (int j = 0; j < ncon; j++) h[j] = Ac ? static_cast<po_vec>(Ac[j]) : nullptr;
   if (csr) {  // ParOptSparseProblem::evalObjConGradient (.cpp:739-742)
     if (!csr_gradient) return 1;
     int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data(), csr->data,
@@ -462,6 +462,7 @@ int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
     PO_TRY(csr->valuesChanged());
   }
   if (kind == PO_PROBLEM_ROSENBROCK) {
+    if (!Ac) return 1;  // nonlinear constraints: the flag must not be set
     return k_rosen_g(ctx, x->d, n, g->d, Ac[0]->d, Ac[1]->d);
   }
   if (kind == PO_PROBLEM_QUADRATIC) {
@@ -473,11 +474,11 @@ int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   // problems do (examples/random_convex/random_convex.py:67-71): Ac_j = +-a_j, one launch
   std::vector<double *> dst;
   std::vector<const double *> src;
-  for (int j = 0; j < ncon; j++) {
+  for (int j = 0; j < ncon && Ac; j++) {
     dst.push_back(Ac[j]->d);
     src.push_back(A[j]->d);
   }
-  if (ncon > 0) {
+  if (ncon > 0 && Ac) {
     PO_TRY(k_panel_lincomb(ctx, dst.data(), kind == PO_PROBLEM_QUADRATIC ? 1.0 : -1.0, src.data(), 0.0,
                            nullptr, ncon, n));
   }

@@ -86,6 +86,9 @@ SIGNATURES = {
     "po_live_objects": (C.c_int, [c_i64_p, c_i64_p]),
     "po_ctx_time_mdot": (C.c_int, [po_ctx, C.c_int]),
     "po_ctx_time_mdot_result": (C.c_int, [po_ctx, c_double_p, c_i64_p]),
+    "po_ctx_time_wgram": (C.c_int, [po_ctx, C.c_int]),
+    "po_ctx_time_wgram_result": (C.c_int, [po_ctx, C.c_int, c_double_p, c_i64_p, c_int_p, c_double_p]),
+    "po_ctx_comm_info": (C.c_int, [po_ctx, c_int_p, c_i64_p, c_i64_p]),
     "po_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "po_ctx_comm_init_rccl": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_void_p]),
     "po_ctx_comm_init_callback": (C.c_int, [po_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
@@ -149,6 +152,7 @@ SIGNATURES = {
     "po_csr_symbolic_arrays": (
         C.c_int, [po_csr_symbolic, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp]),
     "po_csr_symbolic_destroy": (C.c_int, [po_csr_symbolic]),
+    "po_problem_set_linear_constraints": (C.c_int, [po_problem, C.c_int]),
     "po_problem_set_var_bound_options": (C.c_int, [po_problem, C.c_int, C.c_int]),
     "po_problem_destroy": (C.c_int, [po_problem]),
     "po_problem_sizes": (C.c_int, [po_problem, c_i64_p, c_i64_p, c_int_p]),
@@ -232,6 +236,7 @@ SIGNATURES = {
     "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
+    "po_bench_stream": (C.c_int, [po_vec, po_vec, C.c_int, C.c_int, c_double_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,76 @@
+"""bench.py --gpus N: the N-rank job is started as a child process (torchrun) by bench.py itself when it is
+not already running under one; the line it prints reports the ranks the job really had."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                         text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines
+
+
+def test_self_launch_plumbing_cpu():
+    """No GPU: PAROPT_BENCH_STUB=1 replaces the solver by a gloo all-reduce, everything else (argument relay,
+    torchrun child, rank-0 line relay, exit code) is the real launcher."""
+    out, lines = _run(["--gpus", "2", "--steps", "3", "--warmup", "2"], {"PAROPT_BENCH_STUB": "1"}, 300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["gpus_arg"] == 2 and r["steps"] == 3 and r["warmup"] == 2
+
+
+def test_single_rank_does_not_spawn_cpu():
+    out, lines = _run(["--gpus", "1", "--steps", "1"], {"PAROPT_BENCH_STUB": "1"}, 120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(lines[0])["n_gpus"] == 1
+    assert "launching" not in out.stderr
+
+
+def test_child_failure_is_reported_cpu():
+    """A job whose ranks fail must not look like a result: non-zero exit, no line."""
+    out, lines = _run(["--gpus", "2", "--steps", "1", "--problem", "nonsense"], {"PAROPT_BENCH_STUB": "1"}, 300)
+    assert out.returncode != 0
+    assert not lines
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_shared_gpu():
+    """`python bench.py --gpus 2` (the shape of the driver's command) on a 1-GPU box: both ranks share GPU 0 and
+    reduce through the host-callback communicator; the line must say n_gpus == 2 and carry the contract fields."""
+    out, lines = _run(["--gpus", "2", "--nglobal", "2000000", "--steps", "3", "--warmup", "3", "--repeats", "2",
+                       "--no-cpu-baseline", "--qn-size", "3"], {"PAROPT_BENCH_SHARE_GPU": "1"}, 900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2
+    assert r["steps"] == 3 and r["warmup"] == 5  # clamped to qn_size + 2
+    assert r["repeats"] == 2 and r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
+    assert r["config"]["collective"].startswith("gloo callback")
+    assert set(r["variants"]) == {"constant_jacobian", "jacobian_rewritten_every_gradient_call"}
+    assert r["roofline"]["stream_ceiling"]["read_only_GBps"] > 0
+    assert r["roofline"]["second"] is not None and r["roofline"]["second"]["hbm"]["frac"] > 0
+    assert r["user_eval_ms_per_iter"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line():
+    out, lines = _run(["--nglobal", "1000000", "--steps", "3", "--warmup", "3", "--repeats", "1",
+                       "--no-cpu-baseline", "--qn-size", "3"], {}, 900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["metric"].startswith("IP iterations/sec") and "n=1M vars m=32" in r["metric"]
+    assert r["roofline"]["traffic"] is None  # the committed PMC profile is for n = 50 M only
+    v = r["variants"]
+    assert v["constant_jacobian"]["user_eval_ms_per_iter"] < v["jacobian_rewritten_every_gradient_call"]["user_eval_ms_per_iter"]

@@ -1,36 +1,93 @@
-// Measures the issue rate of v_mfma_f64_16x16x4_f64 on one SIMD (independent accumulators).
+// Issue-rate sweep of the fp64 matrix instructions of gfx950 against the fp64 vector FMA:
+//   kind 0: v_mfma_f64_16x16x4_f64 (2048 flop / instruction / wave)
+//   kind 1: v_mfma_f64_4x4x4_4b_f64 (4 blocks x 4x4x4, 512 flop / instruction / wave)
+//   kind 2: v_fma_f64 (128 flop / instruction / wave)
+// NACC independent accumulators per wave, 1..8 waves per SIMD (256-thread workgroups, wpc per CU).
+// The shader clock during the run is estimated from s_memtime (core clock) over s_memrealtime (100 MHz).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_f64_rate.hip -o tools/mfma_f64_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int NACC>
-__global__ void __launch_bounds__(256) k(double* out, int iters, double a, double b) {
-  f64x4 acc[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; i++) acc[i] = (f64x4){0, 0, 0, 0};
+
+template <int KIND, int NACC>
+__global__ void __launch_bounds__(256) k(double *out, unsigned long long *clk, int iters, double a, double b) {
   double av = a + threadIdx.x * 1e-9, bv = b - threadIdx.x * 1e-9;
-  for (int it = 0; it < iters; it++) {
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
-  }
   double s = 0;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  if (KIND == 0) {
+    f64x4 acc[NACC];
 #pragma unroll
-  for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; i++) acc[i] = (f64x4){0, 0, 0, 0};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else if (KIND == 1) {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += acc[i];
+  } else {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 1e-3 * i;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_fma(av, acc[i], bv);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += acc[i];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    clk[0] = t1 - t0;
+    clk[1] = r1 - r0;
+  }
 }
-template <int NACC> void run(int wpc) {
-  double* out; hipMalloc(&out, 256 * 256 * wpc * 8);
-  int iters = 20000;
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<NACC>, dim3(256 * wpc), dim3(256), 0, 0, out, 100, 1.0, 2.0);
+
+template <int KIND, int NACC>
+void run(int wpc) {
+  double *out;
+  unsigned long long *clk, h[2];
+  hipMalloc(&out, 256 * 256 * wpc * 8);
+  hipMalloc(&clk, 16);
+  const int iters = KIND == 0 ? 6000 : 20000;
+  const double flop = KIND == 0 ? 2048.0 : (KIND == 1 ? 512.0 : 128.0);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, 100, 1.0, 2.0);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<NACC>, dim3(256 * wpc), dim3(256), 0, 0, out, iters, 1.0, 2.0);
-  hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
-  double nmfma_per_simd = (double)iters * NACC * wpc;  // one wave per SIMD per block, wpc blocks per CU
-  double tflops = (double)iters * NACC * 2048.0 * 4 * 256 * wpc / (ms * 1e-3) * 1e-12;
-  printf("NACC=%d blocks/CU=%d: %.3f ms, %.1f TFLOP/s, %.1f ns per MFMA per SIMD (%.1f cycles @2.4GHz)\n", NACC, wpc, ms, tflops,
-         ms * 1e6 / nmfma_per_simd, ms * 1e6 / nmfma_per_simd * 2.4);
+  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, iters, 1.0, 2.0);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+  const double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+  const double n_per_simd = (double)iters * NACC * wpc;  // one wave per SIMD per workgroup
+  const double tflops = (double)iters * NACC * flop * 4 * 256 * wpc / (ms * 1e-3) * 1e-12;
+  const double ns = ms * 1e6 / n_per_simd;
+  printf("kind=%s NACC=%d waves/SIMD=%d: %.3f ms, %.1f TFLOP/s, %.2f ns per instr per SIMD (%.1f cycles @2.4GHz; "
+         "memtime/realtime -> %.0f MHz -> %.1f cycles)\n",
+         KIND == 0 ? "mfma16x16x4" : (KIND == 1 ? "mfma4x4x4" : "v_fma_f64"), NACC, wpc, ms, tflops, ns, ns * 2.4, mhz,
+         ns * mhz * 1e-3);
   hipFree(out);
+  hipFree(clk);
 }
-int main() { run<1>(1); run<2>(1); run<4>(1); run<6>(1); run<8>(1); run<6>(2); run<6>(3); return 0; }
+
+int main() {
+  run<0, 1>(1); run<0, 6>(1); run<0, 6>(2); run<0, 6>(3); run<0, 4>(4); run<0, 4>(8);
+  run<1, 1>(1); run<1, 8>(1); run<1, 16>(1); run<1, 16>(2); run<1, 16>(3); run<1, 16>(4); run<1, 8>(8);
+  run<2, 8>(1); run<2, 8>(2); run<2, 8>(4); run<2, 8>(8);
+  return 0;
+}
