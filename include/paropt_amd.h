@@ -334,6 +334,10 @@ int po_ip_debug_kkt_step_sparse(po_ip ip, po_vec *pzw, po_vec *psw, po_vec *ptw,
 /* ---- standalone hot kernels for the roofline bench ----------------------------------------- */
 /* W = P^T diag(d) P, P = [vecs], column-major nvecs x nvecs on the host (MFMA fp64). */
 int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W);
+/* The same pass with the LAST vector t pre-weighted: W[i][nvecs-1] = W[nvecs-1][i] = vecs[i] . t for i < nvecs-1
+ * (the panel dots P^T t of the bordered solve that follows setUpKKTSystem ride in the Gram pass,
+ * src/ParOptInteriorPoint.cpp:2139-2147); W[nvecs-1][nvecs-1] = t . t. */
+int po_wgram_with_rhs(po_vec d, const po_vec *vecs, int nvecs, double *W);
 /* Launch mdot `reps` times back to back on the context stream and return the average kernel
  * time in milliseconds measured with HIP events on that stream (bench.py's roofline leg). */
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out);
@@ -341,6 +345,10 @@ int po_bench_wgram(po_vec d, const po_vec *vecs, int nvecs, int reps, double *av
 /* Same-run stream ceilings on the context stream: kind 0 = read-only (x.y, 16 B per element),
  * kind 1 = copy y <- x (8 B read + 8 B written per element); average kernel milliseconds over `reps`. */
 int po_bench_stream(po_vec x, po_vec y, int kind, int reps, double *avg_ms);
+/* Every hot kernel of one interior-point iteration (n local variables, c dense constraints, k <= 12
+ * quasi-Newton columns) timed in isolation on synthetic vectors; `report` receives a JSON array of
+ * {kernel, avg_ms, min_ms, alg_GB, GBps, frac_hbm_8TBps, TFLOPs} (tools/microbench.py). */
+int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, char *report, int report_len);
 
 /* ---- ParOptTrustRegion over the quadratic / compact-eigenvalue subproblem ------------------------
  * src/ParOptTrustRegion.h:376-480, set up as ParOptOptimizer does for algorithm = "tr"

@@ -19,6 +19,7 @@ from .api import (  # noqa: F401
     quasidef_apply,
     quasidef_factor_info,
     bench_mdot,
+    bench_kernels,
     bench_stream,
     bench_wgram,
     wgram,

@@ -990,11 +990,13 @@ class MMA:
         return t.value.decode()
 
 
-def wgram(d, vecs):
+def wgram(d, vecs, rhs_last=False):
+    """W = P^T diag(d) P; rhs_last: the last vector is pre-weighted (its row / column are plain dots)."""
     nv = len(vecs)
     W = np.zeros((nv, nv))
     arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
-    check(lib.po_wgram(d.handle, arr, nv, W.ctypes.data_as(L.c_double_p)))
+    fn = lib.po_wgram_with_rhs if rhs_last else lib.po_wgram
+    check(fn(d.handle, arr, nv, W.ctypes.data_as(L.c_double_p)))
     return W.T  # column-major symmetric
 
 
@@ -1005,6 +1007,15 @@ def bench_mdot(x, vecs, reps=10):
     out = np.zeros(max(nv, 1))
     check(lib.po_bench_mdot(x.handle, arr, nv, int(reps), C.byref(ms), out.ctypes.data_as(L.c_double_p)))
     return ms.value, out[:nv]
+
+
+def bench_kernels(ctx, n, c, k, reps=5):
+    """Every hot kernel of an interior-point iteration timed in isolation (po_bench_kernels): list of dicts."""
+    import json
+
+    buf = C.create_string_buffer(16384)
+    check(lib.po_bench_kernels(ctx.handle, int(n), int(c), int(k), int(reps), buf, len(buf)))
+    return json.loads(buf.value.decode())
 
 
 def bench_stream(x, y, kind, reps=10):

@@ -825,6 +825,13 @@ int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W) {
   PO_TRY(gather_ptrs(d, vecs, nvecs, p));
   return k_wgram(d->ctx, d->d, p.data(), nvecs, d->n, W);
 }
+int po_wgram_with_rhs(po_vec d, const po_vec *vecs, int nvecs, double *W) {
+  PO_CHECK_PTR(d);
+  PO_CHECK_PTR(W);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(d, vecs, nvecs, p));
+  return k_wgram(d->ctx, d->d, p.data(), nvecs, d->n, W, nullptr, nullptr, 0, 0.0, 1);
+}
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(avg_ms);

@@ -118,12 +118,16 @@ int k_stream_launch(Ctx *c, int kind, double *x, double *y, int64_t n);  // benc
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks);
 // W = V^T diag(d) V.  With kpend > 0 the first kpend (<= 12) columns are L-SR1 columns still to be
 // formed: V[j] = Y_j, S[j] = S_j, and Z_j = Y_j - b0 S_j is used for the Gram AND written to Zout[j].
+// preweighted_last != 0: the last column V[nv-1] = t already carries its weight (t = Dinv o d1), so that
+// W[i][nv-1] = V_i . t for i < nv-1 -- the panel dots P^T t of the following bordered solve ride in the same
+// pass over P (the entry W[nv-1][nv-1] is sum t^2, unused).
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
             const double *const *S = nullptr, double *const *Zout = nullptr, int kpend = 0,
-            double b0 = 0.0);
+            double b0 = 0.0, int preweighted_last = 0);
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
                    int *nblocks, int *nslots, const double *const *S = nullptr,
-                   double *const *Zout = nullptr, int kpend = 0, double b0 = 0.0);
+                   double *const *Zout = nullptr, int kpend = 0, double b0 = 0.0,
+                   int preweighted_last = 0);
 
 // ---- interior-point kernels -------------------------------------------------------------------
 struct Bounds {  // the per-element data every bound-aware kernel needs

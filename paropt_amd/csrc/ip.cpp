@@ -326,6 +326,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   // debugging / test switch: re-measure P^T px with explicit mdot passes instead of W-based algebra
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
+  fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
   use_lower = prob->useLowerBounds();
   use_upper = prob->useUpperBounds();
   vars.resize(c);
@@ -727,12 +728,21 @@ int InteriorPoint::getComplementarity(double *comp) {
 // ================================================================================================
 // the KKT system
 // ================================================================================================
-int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDiagSystem + setUpKKTSystem
+int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs_mu) {  // setUpKKTDiagSystem + setUpKKTSystem
   ptpx_valid = false;
+  t0_valid = false;
   const double sigma = options.real("qn_sigma");
   const bool use_hdiag = options.integer("use_diag_hessian") && hdiag;  // h_i replaces b0 (:1840-1842)
   const double b0 = (!use_hdiag && qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
   PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
+  // The right-hand side of the solve that follows is known already (rx, the bounds and mu): t = Dinv o d1 is
+  // built now and rides through the Gram pass as one more, pre-weighted, column, so that P^T t -- the mdot pass
+  // at the head of solveKKT -- comes out of the pass over P that the Schur complements need anyway.
+  const bool fuse_t = rhs_mu && fused_tdots && !has_w && c + (qn && use_qn && !diag_only ? qn->size() : 0) > 0;
+  if (fuse_t) {
+    PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, options.real("rel_bound_barrier") * (*rhs_mu), n, tvec->d, nullptr,
+                nullptr));
+  }
   int k = 0;
   // L-SR1 leaves its columns Z_j = Y_j - b0 S_j unformed after an update; when this Gram pass is their
   // first consumer they are formed on the fly (and written out for the later passes): the panel is
@@ -741,26 +751,48 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only) {  // setUpKKTDia
   std::vector<double *> Zo;
   double b0z = 0.0;
   const bool fuse_z = qn && use_qn && !diag_only && !has_w && qn->pendingZ(&Yp, &Sp, &Zo, &b0z) &&
-                      !Yp.empty() && Yp.size() <= 12 && c + (int)Yp.size() <= kWgramMaxVecs;
+                      !Yp.empty() && Yp.size() <= 12 && c + (int)Yp.size() + (fuse_t ? 1 : 0) <= kWgramMaxVecs;
   if (fuse_z) {
     k = (int)Yp.size();
-    const int m2 = c + k;
+    const int m2 = c + k, mt = m2 + (fuse_t ? 1 : 0);
     std::vector<const double *> P2(Yp);
     for (Vec *a : Ac) P2.push_back(a->d);
-    std::vector<double> W2((size_t)m2 * m2, 0.0);
-    PO_TRY(k_wgram(ctx, Dinv->d, P2.data(), m2, n, W2.data(), Sp.data(), Zo.data(), k, b0z));
+    if (fuse_t) P2.push_back(tvec->d);
+    std::vector<double> W2((size_t)mt * mt, 0.0);
+    PO_TRY(k_wgram(ctx, Dinv->d, P2.data(), mt, n, W2.data(), Sp.data(), Zo.data(), k, b0z, fuse_t ? 1 : 0));
     qn->pendingZDone();
     W.assign((size_t)m2 * m2, 0.0);
     auto perm = [&](int i) { return i < c ? k + i : i - c; };  // index in [Ac | Z] -> index in [Z | Ac]
     for (int j = 0; j < m2; j++)
-      for (int i = 0; i < m2; i++) W[i + (size_t)m2 * j] = W2[perm(i) + (size_t)m2 * perm(j)];
+      for (int i = 0; i < m2; i++) W[i + (size_t)m2 * j] = W2[perm(i) + (size_t)mt * perm(j)];
+    if (fuse_t) {
+      t0dots.assign(m2, 0.0);
+      for (int i = 0; i < m2; i++) t0dots[i] = W2[perm(i) + (size_t)mt * m2];
+    }
   }
   std::vector<const double *> P = panel(use_qn && !diag_only, &k);
   const int m = c + k;
   wk = k;
   if (!fuse_z) {
     W.assign((size_t)m * m, 0.0);
-    if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+    if (m > 0 && fuse_t && m + 1 <= kWgramMaxVecs) {
+      std::vector<const double *> Pt(P);
+      Pt.push_back(tvec->d);
+      const int mt = m + 1;
+      std::vector<double> Wt((size_t)mt * mt, 0.0);
+      PO_TRY(k_wgram(ctx, Dinv->d, Pt.data(), mt, n, Wt.data(), nullptr, nullptr, 0, 0.0, 1));
+      for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) W[i + (size_t)m * j] = Wt[i + (size_t)mt * j];
+      t0dots.assign(m, 0.0);
+      for (int i = 0; i < m; i++) t0dots[i] = Wt[i + (size_t)mt * m];
+    } else {
+      if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+      t0dots.clear();
+    }
+  }
+  if (fuse_t && m > 0 && (int)t0dots.size() == m) {
+    t0_valid = true;
+    t0_mu = *rhs_mu;
   }
   if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930), then W -= U^T Cw U
     PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
@@ -815,13 +847,18 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   const int m = c + k;
   const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
   const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
-  if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
+  // t = Dinv o d1 and P^T t were produced by setUpKKTSystem's Gram pass when the right-hand side was known then
+  const bool have_t0 = !refine_pass && t0_valid && t0_mu == mu && !cl && (int)t0dots.size() == m;
+  if (!refine_pass && !have_t0) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
   std::vector<double> dots(m > 0 ? m : 1, 0.0);
-  if (refine_pass && tdots_valid && (int)tdots.size() == m) {
+  if (have_t0) {
+    for (int i = 0; i < m; i++) dots[i] = t0dots[i];
+  } else if (refine_pass && tdots_valid && (int)tdots.size() == m) {
     dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
   } else if (m > 0) {
     PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
   }
+  if (!refine_pass) t0_valid = false;  // tvec is overwritten by the passes below
   tdots_valid = false;
   // yz = G^-1 (d3 - A yx0)   (:2150-2159)
   std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
@@ -1685,7 +1722,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
     if (inexact_newton_step) {
       // nothing to do: computeKKTGMRESStep left the step in (px, pzl, pzu, step)
     } else {
-    PO_TRY(setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0));
+    const double rhs_mu = mehrotra ? 0.0 : barrier_param;  // of the solve that follows
+    PO_TRY(setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0, &rhs_mu));
     phaseEnd("setup_kkt");
     if (!mehrotra) {
       PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
@@ -1778,7 +1816,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
           PO_TRY(computeResidual(barrier_param, true));
           denseResidual(barrier_param, res);
           resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
-          PO_TRY(setUpKKTSystem(true));
+          PO_TRY(setUpKKTSystem(true, false, &barrier_param));
           PO_TRY(computeKKTStepWithRefinement(barrier_param, true, tau));
           PO_TRY(scaleKKTStep(tau, comp, &alpha_x, &alpha_z, &ceq_step));
           PO_TRY(evalMeritInitDeriv(alpha_x, &m0, &dm0));

@@ -198,7 +198,7 @@ class InteriorPoint {
   double compFromSums(double prod, double count, const Dense &v, double wprod = 0.0) const;
   // diag_only: keep b0 of the quasi-Newton approximation in Dinv but leave its low-rank part out
   // (the "diagonal quasi-Newton step" of :4923-4980)
-  int setUpKKTSystem(bool use_qn, bool diag_only = false);
+  int setUpKKTSystem(bool use_qn, bool diag_only = false, const double *rhs_mu = nullptr);
   int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                bool fuse_residual = false);
   int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);
@@ -222,7 +222,11 @@ class InteriorPoint {
   void userBegin();
   void userEnd();
   void userHarvest();
-  bool ac_valid = false;  // Ac holds the Jacobian of a problem with linear_constraints
+  bool ac_valid = false;
+  // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
+  bool fused_tdots = true, t0_valid = false;
+  double t0_mu = 0.0;
+  std::vector<double> t0dots;  // Ac holds the Jacobian of a problem with linear_constraints
 };
 
 }  // namespace po

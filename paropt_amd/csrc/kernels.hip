@@ -504,260 +504,7 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
   return PO_OK;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Weighted Gram  W = P^T diag(d) P  on the fp64 matrix cores.
-//
-// Replaces the reference's c(c+1)/2 dots of setUpKKTDiagSystem (src/ParOptInteriorPoint.cpp:
-// 1935-1950) AND the k diagonal-KKT solves + k mdots of setUpKKTSystem (:2648-2654) by one pass
-// over the panel.  Algorithmic traffic 8*(m+1)*n bytes, m(m+1)n flops.
-//
-// Mapping: one workgroup stages a tile of TILE rows of all m (padded to 16*MB) columns in LDS
-// ([column][row], row stride TILE+2 doubles so that the ds_read_b64 operand fetches of a
-// 16-column x 4-row fragment hit 32 distinct 8-byte slots); the 4 wavefronts split the tile's
-// rows (K split) and each accumulates all MB(MB+1)/2 upper-triangular 16x16 blocks with
-// v_mfma_f64_16x16x4_f64:  A fragment = P[16r + (lane&15)][row0 + (lane>>4)],
-//                          B fragment = d[row] * P[16s + (lane&15)][row]          (r <= s).
-// ---------------------------------------------------------------------------------------------
-constexpr int kGramTile = 128;            // rows per LDS tile
-constexpr int kGramLd = kGramTile + 2;    // LDS row stride in doubles (== 2 mod 32)
-
-// ZP > 0: the first `kpend` (<= 4*ZP) columns are L-SR1 columns that have not been materialised yet:
-// V.p[j] = Y_j, S.p[j] = S_j and the staged value is Z_j = Y_j - b0 S_j, which is also written to
-// Zout.p[j] for the later panel passes of the iteration (saves the separate 3-pass rebuild of Z).
-template <int MB, int ZP>
-__global__ void __launch_bounds__(kBlock)
-    wgram_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
-                 double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0) {
-  constexpr int M = 16 * MB;
-  constexpr int NBLK = MB * (MB + 1) / 2;
-  constexpr int NPASS = 4 * MB;  // staging passes: 4 columns (one per wave) per pass
-  extern __shared__ double lds[];  // [M][kGramLd] panel tile, then [kGramTile] weights
-  double *pt = lds;
-  double *dw = lds + M * kGramLd;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  f64x4 acc[NBLK];
-#pragma unroll
-  for (int b = 0; b < NBLK; b++) acc[b] = (f64x4){0.0, 0.0, 0.0, 0.0};
-
-  // zero the padded columns once (they are never written by the staging loop)
-  for (int idx = tid; idx < (M - nv) * kGramLd; idx += kBlock) pt[nv * kGramLd + idx] = 0.0;
-
-  // wave w stages columns w, w+4, ...; lane l holds rows 2l, 2l+1 of the 128-row tile.
-  // Columns beyond nv re-read the last column (never written to LDS), so that the loads carry
-  // no branch and are all issued before the first wait.
-  const double *colp[NPASS];
-#pragma unroll
-  for (int it = 0; it < NPASS; it++) {
-    const int j = wave + 4 * it;
-    colp[it] = V.p[j < nv ? j : nv - 1];
-  }
-  // unformed L-SR1 columns: the S_j streams, branch-free like the panel loads (lanes beyond kpend
-  // re-read the last pending column and ignore it)
-  const double *scol[ZP > 0 ? ZP : 1];
-  double *zcol[ZP > 0 ? ZP : 1];
-#pragma unroll
-  for (int it = 0; it < (ZP > 0 ? ZP : 1); it++) {
-    const int j = wave + 4 * it;
-    scol[it] = (ZP > 0 && kpend > 0) ? S.p[j < kpend ? j : kpend - 1] : nullptr;
-    zcol[it] = (ZP > 0 && j < kpend) ? Zout.p[j] : nullptr;
-  }
-  const int64_t ilast = ((n - 1) >> 1) << 1;
-  // Software pipeline: the global loads of the NEXT tile are issued (all of them, back to back)
-  // before the current tile is multiplied, and are only waited for at the next LDS store.  Rows
-  // past n are read from the zero pad when they fall in the last pair and clamped to the last
-  // in-range pair otherwise; their weight is forced to zero, so they contribute nothing.
-  f64x2 buf[NPASS];
-  f64x2 sbuf[ZP > 0 ? ZP : 1];
-  int64_t pre_i = 0;    // row of the prefetched pair, and whether it is in range (for the Z write-back)
-  bool pre_in = false;
-  f64x2 dbuf = (f64x2){0.0, 0.0};
-#define PO_GRAM_PREFETCH(TILE)                                                             \
-  {                                                                                        \
-    int64_t _i = (TILE) * kGramTile + 2 * lane;                                            \
-    const bool _in = (_i < n);                                                             \
-    if (!_in) _i = ilast;                                                                  \
-    _Pragma("unroll") for (int it = 0; it < NPASS; it++) buf[it] =                         \
-        ld_stream(colp[it] + _i);                                   \
-    if (ZP > 0) {                                                                          \
-      _Pragma("unroll") for (int it = 0; it < ZP; it++) sbuf[it] = ld_stream(scol[it] + _i); \
-      pre_i = _i;                                                                          \
-      pre_in = _in;                                                                        \
-    }                                                                                      \
-    dbuf = *reinterpret_cast<const f64x2 *>(d + _i);                                       \
-    if (!_in) dbuf = (f64x2){0.0, 0.0};                                                    \
-    else if (_i + 1 >= n) dbuf.y = 0.0;                                                    \
-  }
-  if ((int64_t)blockIdx.x < ntiles) PO_GRAM_PREFETCH((int64_t)blockIdx.x);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();  // previous tile fully consumed
-#pragma unroll
-    for (int it = 0; it < NPASS; it++) {
-      const int j = wave + 4 * it;
-      if (ZP > 0 && it < ZP && j < kpend) {
-        f64x2 z;
-        z.x = buf[it].x - b0 * sbuf[it].x;
-        z.y = buf[it].y - b0 * sbuf[it].y;
-        buf[it] = z;
-        if (pre_in) __builtin_nontemporal_store(z, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
-      }
-      if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = buf[it];
-    }
-    if (wave == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = dbuf;
-    __syncthreads();
-    if (tile + gridDim.x < ntiles) PO_GRAM_PREFETCH(tile + gridDim.x);
-    // ---- compute: wave w owns rows [32w, 32w+32) of the tile: 8 k-steps of 4 rows ----
-    const int colq = lane & 15, rowq = lane >> 4;
-#pragma unroll 2
-    for (int ks = 0; ks < kGramTile / 16; ks++) {
-      const int r = wave * (kGramTile / 4) + ks * 4 + rowq;
-      const double w = dw[r];
-      double a[MB], bw[MB];
-#pragma unroll
-      for (int m = 0; m < MB; m++) {
-        a[m] = pt[(16 * m + colq) * kGramLd + r];
-        bw[m] = a[m] * w;
-      }
-      int b = 0;
-#pragma unroll
-      for (int rb = 0; rb < MB; rb++) {
-#pragma unroll
-        for (int sb = rb; sb < MB; sb++) {
-          acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[rb], bw[sb], acc[b], 0, 0, 0);
-          b++;
-        }
-      }
-    }
-  }
-#undef PO_GRAM_PREFETCH
-  // ---- cross-wave (K split) reduction through LDS, then one partial per workgroup ----
-  __syncthreads();
-  double *red = lds;  // reuse: [4 waves][NBLK*256]
-  // each lane holds 4 values of each block: element (row = rowq + 4*e, col = colq)
-#pragma unroll
-  for (int b = 0; b < NBLK; b++) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int row = (lane >> 4) + 4 * e, col = lane & 15;
-      red[(wave * NBLK + b) * 256 + row * 16 + col] = acc[b][e];
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < NBLK * 256; idx += kBlock) {
-    const double v = (red[idx] + red[NBLK * 256 + idx]) + (red[2 * NBLK * 256 + idx] + red[3 * NBLK * 256 + idx]);
-    partials[(size_t)idx * gridDim.x + blockIdx.x] = v;
-  }
-}
-
-template <int MB, int ZP>
-static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int grid,
-                          int64_t ntiles, const PtrTable &st, const PtrTableW &zt, int kpend, double b0) {
-  constexpr int M = 16 * MB;
-  constexpr int NBLK = MB * (MB + 1) / 2;
-  size_t lds_stage = (size_t)(M * kGramLd + kGramTile) * sizeof(double);
-  size_t lds_red = (size_t)4 * NBLK * 256 * sizeof(double);
-  size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_kernel<MB, ZP>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((wgram_kernel<MB, ZP>), dim3(grid), dim3(kBlock), lds, c->stream, d, pt, nv, n,
-                     ntiles, c->d_partials, st, zt, kpend, b0);
-  c->n_launches++;
-  PO_HIP(hipGetLastError());
-  return PO_OK;
-}
-
-int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, int *nblocks,
-                   int *nslots, const double *const *S, double *const *Zout, int kpend, double b0) {
-  if (nv > kWgramMaxVecs || nv < 1) {
-    set_error("wgram panel width %d outside 1..%d", nv, kWgramMaxVecs);
-    return PO_ERR_ARG;
-  }
-  const int MB = (nv + 15) / 16;
-  const int NBLK = MB * (MB + 1) / 2;
-  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
-  int64_t g = c->num_cu * (MB <= 3 ? 3 : 2);
-  if (g > ntiles) g = ntiles;
-  if (g < 1) g = 1;
-  const int grid = (int)g;
-  PO_TRY(ensure_partials(c, (size_t)grid * NBLK * 256));
-  PtrTable pt, st;
-  PtrTableW zt;
-  CoefTable ct;
-  fill_tables(nullptr, V, nv, &ct, &pt);
-  fill_tables(nullptr, S, S ? kpend : 0, &ct, &st);
-  for (int j = 0; j < kMaxPanel; j++) zt.p[j] = (Zout && j < kpend) ? Zout[j] : nullptr;
-  if (kpend > 12 || kpend > nv || (kpend > 0 && (!S || !Zout))) {
-    set_error("wgram: %d pending columns cannot be materialised in the Gram pass", kpend);
-    return PO_ERR_ARG;
-  }
-#define PO_WG(MBv)                                                                          \
-  if (kpend > 0) {                                                                          \
-    PO_TRY((wgram_launch_t<MBv, 3>(c, d, pt, nv, n, grid, ntiles, st, zt, kpend, b0)));     \
-  } else {                                                                                  \
-    PO_TRY((wgram_launch_t<MBv, 0>(c, d, pt, nv, n, grid, ntiles, st, zt, 0, 0.0)));        \
-  }
-  switch (MB) {
-    case 1: PO_WG(1) break;
-    case 2: PO_WG(2) break;
-    case 3: PO_WG(3) break;
-    case 4: PO_WG(4) break;
-    default: PO_WG(5) break;
-  }
-#undef PO_WG
-  *nblocks = grid;
-  *nslots = NBLK * 256;
-  return PO_OK;
-}
-
-int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
-            const double *const *S, double *const *Zout, int kpend, double b0) {
-  if (nv <= 0) return PO_OK;
-  int grid = 0, nslots = 0;
-  const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream
-  if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
-  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0));
-  if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
-  std::vector<double> blocks(nslots);
-  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));  // synchronises the stream
-  if (timed) {
-    float ms = 0.0f;
-    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    const int w = kpend > 0 ? 1 : 0;
-    c->wgram_ms[w] += ms;
-    c->wgram_count[w]++;
-    c->wgram_cols[w] = nv;
-    c->wgram_bytes[w] += 8.0 * (double)n * (nv + 1 + 2 * kpend);  // panel + weights (+ S read, Z written)
-  }
-  const int MB = (nv + 15) / 16;
-  int b = 0;
-  for (int rb = 0; rb < MB; rb++) {
-    for (int sb = rb; sb < MB; sb++, b++) {
-      for (int r = 0; r < 16; r++) {
-        for (int s = 0; s < 16; s++) {
-          const int i = 16 * rb + r, j = 16 * sb + s;
-          if (i < nv && j < nv) {
-            const double v = blocks[(size_t)b * 256 + r * 16 + s];
-            if (rb == sb) {
-              // diagonal block: both triangles were computed; symmetrise exactly
-              if (r <= s) {
-                W[i + (size_t)nv * j] = v;
-                W[j + (size_t)nv * i] = v;
-              }
-            } else {
-              W[i + (size_t)nv * j] = v;
-              W[j + (size_t)nv * i] = v;
-            }
-          }
-        }
-      }
-    }
-  }
-  return PO_OK;
-}
+// (the weighted Gram W = P^T diag(d) P lives in wgram.hip)
 
 // ---------------------------------------------------------------------------------------------
 // interior-point element kernels

@@ -1,0 +1,309 @@
+// Weighted Gram  W = P^T diag(d) P  on the fp64 matrix cores of gfx950.
+//
+// Replaces the reference's c(c+1)/2 dots of setUpKKTDiagSystem (src/ParOptInteriorPoint.cpp:1935-1950)
+// AND the k diagonal-KKT solves + k mdots of setUpKKTSystem (:2648-2654) by one pass over the panel
+// P = [Ac | Z]; with a pre-weighted last column t = Dinv o d1 the same pass also yields the
+// panel dots P^T t of the bordered solve that follows (:2139-2147).  Algorithmic traffic 8(m+1)n bytes,
+// m(m+1)n useful flops.
+//
+// Instruction choice (tools/mfma_f64_rate.hip on MI355X, profiles/r02_mfma_f64_rate.txt):
+//   v_mfma_f64_16x16x4_f64     2048 flop in ~105 cycles/SIMD  -> 47 TFLOP/s sustained
+//   v_mfma_f64_4x4x4_4b_f64     512 flop in 16.6 cycles/SIMD -> 75.8 TFLOP/s (96 % of the 78.6 spec)
+// and the 4-column granularity of the second form wastes far less of a symmetric product: for m = 43 columns
+// 66 blocks of 4x4 (1056 products per row, 946 useful) against 6 blocks of 16x16 (1536 per row).
+//
+// Mapping.  A workgroup (4 wavefronts) stages a tile of 128 rows of all columns (padded to groups of 4) in LDS,
+// [column][row] with a row stride of 136 doubles (== 8 mod 32: the ds_read_b64 operand fetch below touches 32
+// distinct 8-byte bank pairs per half wave).  v_mfma_f64_4x4x4_4b multiplies four independent 4x4x4 blocks;
+// measured operand layout (tools/mfma_f64_layout.hip): A lane = i + 4 b + 16 k, B lane = j + 4 b + 16 k,
+// D lane = j + 4 b + 16 i.  The four blocks b are four row chunks of the tile (16 rows per instruction:
+// row = 16 s + b + 4 k), so one instruction accumulates one 4x4 block pair (I, J) of W over 16 rows, and every
+// lane fetches ONE operand per column group: a_g = P[row][4 g + (lane & 3)], used as A for the pairs (g, .)
+// and, multiplied by the row weight, as B for the pairs (., g).  The NG (NG + 1) / 2 block pairs are dealt
+// round-robin to the four wavefronts (OUTPUT split: every wavefront sees all rows, owns a quarter of W), so
+// there is no cross-wave reduction; the four row-chunk partials of a block are summed with two lane shuffles
+// at the very end.  The loads of the next tile are issued into registers before the current tile is
+// multiplied.
+#include "core.hpp"
+
+#include <math.h>
+#include <stdlib.h>
+
+namespace po {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kGramTile = 128;          // rows per LDS tile
+constexpr int kGramLd = kGramTile + 8;  // LDS row stride in doubles (== 8 mod 32)
+
+struct PtrTableW {
+  double *p[kMaxPanel];
+};
+
+__device__ __forceinline__ f64x2 ld_nt(const double *p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
+}
+
+// the pairs p = W, W + 4, ... of the row-major enumeration of {(I, J): I <= J < NG}
+template <int NG, int W>
+__device__ __forceinline__ void gram_step(const double (&a)[NG], const double (&bw)[NG],
+                                          double (&acc)[(NG * (NG + 1) / 2 + 3) / 4]) {
+  int p = 0;
+#pragma unroll
+  for (int I = 0; I < NG; I++) {
+#pragma unroll
+    for (int J = I; J < NG; J++) {
+      if ((p & 3) == W) acc[p >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], bw[J], acc[p >> 2], 0, 0, 0);
+      p++;
+    }
+  }
+}
+
+template <int NG, int W>
+__device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const double *__restrict__ dw, int lane,
+                                          int tcol, double (&acc)[(NG * (NG + 1) / 2 + 3) / 4]) {
+  const int ci = lane & 3;                              // column within the group
+  const int rowoff = ((lane >> 2) & 3) + 4 * (lane >> 4);  // row within the 16-row step: b + 4 k
+  const double *base = pt + ci * kGramLd + rowoff;
+#pragma unroll 1
+  for (int s = 0; s < kGramTile / 16; s++) {
+    const double w = dw[16 * s + rowoff];
+    double a[NG], bw[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      a[g] = base[(4 * g) * kGramLd + 16 * s];
+      // column `tcol` (if any) already carries its weight: its products with the panel are the plain dots P^T t
+      bw[g] = a[g] * ((4 * g + ci == tcol) ? 1.0 : w);
+    }
+    gram_step<NG, W>(a, bw, acc);
+  }
+}
+
+template <int NG, int W>
+__device__ __forceinline__ void gram_store(const double (&acc)[(NG * (NG + 1) / 2 + 3) / 4], int lane,
+                                           double *__restrict__ partials) {
+  constexpr int NP = NG * (NG + 1) / 2;
+#pragma unroll
+  for (int q = 0; q < (NP + 3) / 4; q++) {
+    const int p = 4 * q + W;
+    if (p < NP) {
+      double v = acc[q];
+      v += __shfl_xor(v, 4, 64);  // the four row chunks b of the block
+      v += __shfl_xor(v, 8, 64);
+      if (((lane >> 2) & 3) == 0) {
+        const int slot = p * 16 + (lane >> 4) * 4 + (lane & 3);  // element (i, j) of block pair p
+        partials[(size_t)slot * gridDim.x + blockIdx.x] = v;
+      }
+    }
+  }
+}
+
+// ZP > 0: the first `kpend` (<= 4 * ZP) columns are L-SR1 columns that have not been materialised yet:
+// V.p[j] = Y_j, S.p[j] = S_j, the staged value is Z_j = Y_j - b0 S_j, which is also written to Zout.p[j] for the
+// later panel passes of the iteration (saves the separate 3-pass rebuild of Z).
+template <int NG, int ZP, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+    wgram_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
+                 double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol) {
+  constexpr int M = 4 * NG;
+  constexpr int NQ = (NG * (NG + 1) / 2 + 3) / 4;
+  extern __shared__ double lds[];  // [M][kGramLd] panel tile, then [kGramTile] weights
+  double *pt = lds;
+  double *dw = lds + M * kGramLd;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: pointers stay in SGPRs
+
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+
+  // zero the padded columns once (they are never written by the staging loop)
+  for (int idx = tid; idx < (M - nv) * kGramLd; idx += kBlock) pt[nv * kGramLd + idx] = 0.0;
+
+  // wave w stages columns w, w+4, ...; lane l holds rows 2l, 2l+1 of the 128-row tile.  Columns beyond nv
+  // re-read the last column (never written to LDS), so that the loads carry no branch and are all issued
+  // before the first wait.
+  const double *colp[NG];
+#pragma unroll
+  for (int it = 0; it < NG; it++) {
+    const int j = wave + 4 * it;
+    colp[it] = V.p[j < nv ? j : nv - 1];
+  }
+  const double *scol[ZP > 0 ? ZP : 1];
+  double *zcol[ZP > 0 ? ZP : 1];
+#pragma unroll
+  for (int it = 0; it < (ZP > 0 ? ZP : 1); it++) {
+    const int j = wave + 4 * it;
+    scol[it] = (ZP > 0 && kpend > 0) ? S.p[j < kpend ? j : kpend - 1] : nullptr;
+    zcol[it] = (ZP > 0 && j < kpend) ? Zout.p[j] : nullptr;
+  }
+  const int64_t ilast = ((n - 1) >> 1) << 1;
+  // Software pipeline: the global loads of the NEXT tile are issued (all of them, back to back) before the
+  // current tile is multiplied, and are only waited for at the next LDS store.  Row pairs past n are clamped to
+  // the last in-range pair for the load and staged as zeros (the pad element of an odd-length vector is 0.0).
+  f64x2 buf[NG];
+  f64x2 sbuf[ZP > 0 ? ZP : 1];
+  int64_t pre_i = 0;
+  bool pre_in = false;
+  f64x2 dbuf = (f64x2){0.0, 0.0};
+#define PO_GRAM_PREFETCH(TILE)                                                               \
+  {                                                                                          \
+    int64_t _i = (TILE) * kGramTile + 2 * lane;                                              \
+    pre_in = (_i < n);                                                                       \
+    if (!pre_in) _i = ilast;                                                                 \
+    pre_i = _i;                                                                              \
+    _Pragma("unroll") for (int it = 0; it < NG; it++) buf[it] = ld_nt(colp[it] + _i);        \
+    if (ZP > 0) {                                                                            \
+      _Pragma("unroll") for (int it = 0; it < ZP; it++) sbuf[it] = ld_nt(scol[it] + _i);     \
+    }                                                                                        \
+    dbuf = *reinterpret_cast<const f64x2 *>(d + _i);                                         \
+  }
+  if ((int64_t)blockIdx.x < ntiles) PO_GRAM_PREFETCH((int64_t)blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int it = 0; it < NG; it++) {
+      const int j = wave + 4 * it;
+      f64x2 v = buf[it];
+      if (ZP > 0 && it < ZP && j < kpend) {
+        v.x -= b0 * sbuf[it].x;
+        v.y -= b0 * sbuf[it].y;
+        if (pre_in) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
+      }
+      if (!pre_in) v = (f64x2){0.0, 0.0};
+      if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;
+    }
+    if (wave == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = pre_in ? dbuf : (f64x2){0.0, 0.0};
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) PO_GRAM_PREFETCH(tile + gridDim.x);
+    switch (wave) {
+      case 0: gram_tile<NG, 0>(pt, dw, lane, tcol, acc); break;
+      case 1: gram_tile<NG, 1>(pt, dw, lane, tcol, acc); break;
+      case 2: gram_tile<NG, 2>(pt, dw, lane, tcol, acc); break;
+      default: gram_tile<NG, 3>(pt, dw, lane, tcol, acc); break;
+    }
+  }
+#undef PO_GRAM_PREFETCH
+  switch (wave) {
+    case 0: gram_store<NG, 0>(acc, lane, partials); break;
+    case 1: gram_store<NG, 1>(acc, lane, partials); break;
+    case 2: gram_store<NG, 2>(acc, lane, partials); break;
+    default: gram_store<NG, 3>(acc, lane, partials); break;
+  }
+}
+
+template <int NG, int ZP, int OCC>
+static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int64_t ntiles,
+                          const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out) {
+  const size_t lds = (size_t)(4 * NG * kGramLd + kGramTile) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_kernel<NG, ZP, OCC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > OCC) per_cu = OCC;  // one wavefront of every resident workgroup per SIMD
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)c->num_cu * per_cu;
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
+  hipLaunchKernelGGL((wgram_kernel<NG, ZP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, d, pt, nv, n, ntiles,
+                     c->d_partials, st, zt, kpend, b0, tcol);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  *grid_out = (int)g;
+  return PO_OK;
+}
+
+static int wgram_groups(int nv) { return (nv + 3) / 4; }
+
+int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, int *nblocks,
+                   int *nslots, const double *const *S, double *const *Zout, int kpend, double b0,
+                   int preweighted_last) {
+  if (nv > kWgramMaxVecs || nv < 1) {
+    set_error("wgram panel width %d outside 1..%d", nv, kWgramMaxVecs);
+    return PO_ERR_ARG;
+  }
+  if (kpend > 12 || kpend > nv || (kpend > 0 && (!S || !Zout))) {
+    set_error("wgram: %d pending columns cannot be materialised in the Gram pass", kpend);
+    return PO_ERR_ARG;
+  }
+  const int tcol = preweighted_last ? nv - 1 : -1;
+  const int NG = wgram_groups(nv);
+  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
+  PtrTable pt, st;
+  PtrTableW zt;
+  for (int j = 0; j < kMaxPanel; j++) {
+    pt.p[j] = j < nv ? V[j] : nullptr;
+    st.p[j] = (S && j < kpend) ? S[j] : nullptr;
+    zt.p[j] = (Zout && j < kpend) ? Zout[j] : nullptr;
+  }
+  int grid = 0;
+  // resident wavefronts per SIMD the kernel is compiled for (register budget 512 / OCC per lane)
+  static const int occ_env = getenv("PAROPT_AMD_WGRAM_OCC") ? atoi(getenv("PAROPT_AMD_WGRAM_OCC")) : 0;
+#define PO_WG(NGv)                                                                                     \
+  case NGv: {                                                                                          \
+    constexpr int OCCD = NGv <= 8 ? 4 : (NGv <= 11 ? 3 : (NGv <= 14 ? 2 : 1));                         \
+    constexpr int OCCA = NGv <= 8 ? 3 : (NGv <= 11 ? 2 : (NGv <= 14 ? 1 : 1));                         \
+    const bool alt = occ_env > 0 && occ_env == OCCA;                                                   \
+    if (kpend > 0) {                                                                                   \
+      if (alt) PO_TRY((wgram_launch_t<NGv, 3, OCCA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+      else PO_TRY((wgram_launch_t<NGv, 3, OCCD>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));     \
+    } else {                                                                                           \
+      if (alt) PO_TRY((wgram_launch_t<NGv, 0, OCCA>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));    \
+      else PO_TRY((wgram_launch_t<NGv, 0, OCCD>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));        \
+    }                                                                                                  \
+  } break;
+  switch (NG) {
+    PO_WG(1) PO_WG(2) PO_WG(3) PO_WG(4) PO_WG(5) PO_WG(6) PO_WG(7) PO_WG(8) PO_WG(9) PO_WG(10)
+    PO_WG(11) PO_WG(12) PO_WG(13) PO_WG(14) PO_WG(15) PO_WG(16) PO_WG(17) PO_WG(18) PO_WG(19) PO_WG(20)
+  }
+#undef PO_WG
+  *nblocks = grid;
+  *nslots = (NG * (NG + 1) / 2) * 16;
+  return PO_OK;
+}
+
+int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
+            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last) {
+  if (nv <= 0) return PO_OK;
+  int grid = 0, nslots = 0;
+  const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream
+  if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
+  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last));
+  if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
+  std::vector<double> blocks(nslots);
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));  // synchronises the stream
+  if (timed) {
+    float ms = 0.0f;
+    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const int w = kpend > 0 ? 1 : 0;
+    c->wgram_ms[w] += ms;
+    c->wgram_count[w]++;
+    c->wgram_cols[w] = nv;
+    c->wgram_bytes[w] += 8.0 * (double)n * (nv + 1 + 2 * kpend);  // panel + weights (+ S read, Z written)
+  }
+  const int NG = wgram_groups(nv);
+  int p = 0;
+  for (int I = 0; I < NG; I++) {
+    for (int J = I; J < NG; J++, p++) {
+      for (int i = 0; i < 4; i++) {
+        for (int j = 0; j < 4; j++) {
+          const int r = 4 * I + i, s = 4 * J + j;
+          // upper entries only: a diagonal block pair computes both triangles, and with a pre-weighted last
+          // column only W[r][last] = P_r . t is meaningful
+          if (r < nv && s < nv && r <= s) {
+            const double v = blocks[(size_t)p * 16 + i * 4 + j];
+            W[r + (size_t)nv * s] = v;
+            W[s + (size_t)nv * r] = v;
+          }
+        }
+      }
+    }
+  }
+  return PO_OK;
+}
+
+}  // namespace po

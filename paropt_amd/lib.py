@@ -234,8 +234,10 @@ SIGNATURES = {
     "po_mma_get_history": (C.c_int, [po_mma, C.POINTER(C.c_char_p)]),
     "po_mma_set_iteration_callback": (C.c_int, [po_mma, TR_ITER_FN, C.c_void_p]),
     "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
+    "po_wgram_with_rhs": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
+    "po_bench_kernels": (C.c_int, [po_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "po_bench_stream": (C.c_int, [po_vec, po_vec, C.c_int, C.c_int, c_double_p]),
 }
 

@@ -145,6 +145,24 @@ def test_wgram_vs_numpy(ctx, n, nv):
     np.testing.assert_array_equal(W, W.T)
 
 
+@pytest.mark.parametrize("n", [1, 129, 1000, 70001])
+@pytest.mark.parametrize("nv", [2, 9, 16, 17, 33, 43, 48, 49, 80])
+def test_wgram_with_preweighted_rhs_column(ctx, n, nv):
+    """The last column t is pre-weighted: its row/column hold the plain dots P^T t, the rest is the weighted Gram."""
+    import paropt_amd as pa
+
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)]
+    dn = hnp(n, 9, scale=1.0, shift=0.5)
+    P = np.stack([hnp(n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)], axis=1)
+    ref = P.T @ (dn[:, None] * P)
+    ref[:, nv - 1] = P.T @ P[:, nv - 1]
+    ref[nv - 1, :] = ref[:, nv - 1]
+    W = pa.wgram(d, V, rhs_last=True)
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
+    np.testing.assert_array_equal(W, W.T)
+
+
 def test_live_mdot_timing_hook(ctx):
     """po_ctx_time_mdot: launches of exactly the requested width are timed with HIP events, others are not."""
     import paropt_amd as pa
