@@ -20,7 +20,8 @@
 // row = 16 s + b + 4 k), so one instruction accumulates one 4x4 block pair (I, J) of W over 16 rows, and every
 // lane fetches ONE operand per column group: a_g = P[row][4 g + (lane & 3)], used as A for the pairs (g, .)
 // and, multiplied by the row weight, as B for the pairs (., g).  The NG (NG + 1) / 2 block pairs are dealt
-// round-robin to the four wavefronts (OUTPUT split: every wavefront sees all rows, owns a quarter of W), so
+// to the four wavefronts by column group J (OUTPUT split: every wavefront sees all rows, owns about a quarter
+// of W and weights only its own B operands), so
 // there is no cross-wave reduction; the four row-chunk partials of a block are summed with two lane shuffles
 // at the very end.  The loads of the next tile are issued into registers before the current tile is
 // multiplied.
@@ -44,55 +45,102 @@ __device__ __forceinline__ f64x2 ld_nt(const double *p) {
   return __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p));
 }
 
-// the pairs p = W, W + 4, ... of the row-major enumeration of {(I, J): I <= J < NG}
+// Block pairs (I <= J) are dealt to the four wavefronts by COLUMN group J (the B side): a wavefront then weights
+// only the few operands b_J = w a_J of its own column groups instead of all of them.  Longest-processing-time
+// assignment of the column groups (column group J carries J + 1 pairs), fixed at compile time.
+template <int NG>
+struct GramPlan {
+  int owner[NG];
+  int load[4];
+  constexpr GramPlan() : owner{}, load{0, 0, 0, 0} {
+    for (int J = NG - 1; J >= 0; J--) {
+      int best = 0;
+      for (int w = 1; w < 4; w++)
+        if (load[w] < load[best]) best = w;
+      owner[J] = best;
+      load[best] += J + 1;
+    }
+  }
+  constexpr int max_load() const {
+    int m = load[0];
+    for (int w = 1; w < 4; w++)
+      if (load[w] > m) m = load[w];
+    return m;
+  }
+};
+template <int NG>
+struct GramPlanHolder {
+  static constexpr GramPlan<NG> plan = GramPlan<NG>();
+  static constexpr int NQ = plan.max_load();
+};
+
+// operands of one 16-row step: a[g] = P[row][4 g + (lane & 3)] for every column group, w = the row weight
+template <int NG>
+__device__ __forceinline__ void gram_fetch(const double *__restrict__ base, const double *__restrict__ dwl, int s,
+                                           double (&a)[NG], double &w) {
+  w = dwl[16 * s];
+#pragma unroll
+  for (int g = 0; g < NG; g++) a[g] = base[(4 * g) * kGramLd + 16 * s];
+}
+
 template <int NG, int W>
-__device__ __forceinline__ void gram_step(const double (&a)[NG], const double (&bw)[NG],
-                                          double (&acc)[(NG * (NG + 1) / 2 + 3) / 4]) {
-  int p = 0;
+__device__ __forceinline__ void gram_step(const double (&a)[NG], double w, bool tsel,
+                                          double (&acc)[GramPlanHolder<NG>::NQ]) {
+  constexpr GramPlan<NG> plan = GramPlanHolder<NG>::plan;
+  int q = 0;
 #pragma unroll
-  for (int I = 0; I < NG; I++) {
+  for (int J = 0; J < NG; J++) {
+    if (plan.owner[J] == W) {
+      // the pre-weighted column t (if any) is the last column: its products with the panel are plain dots
+      const double bw = a[J] * ((J == NG - 1 && tsel) ? 1.0 : w);
 #pragma unroll
-    for (int J = I; J < NG; J++) {
-      if ((p & 3) == W) acc[p >> 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], bw[J], acc[p >> 2], 0, 0, 0);
-      p++;
+      for (int I = 0; I <= J; I++) {
+        acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], bw, acc[q], 0, 0, 0);
+        q++;
+      }
     }
   }
 }
 
 template <int NG, int W>
 __device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const double *__restrict__ dw, int lane,
-                                          int tcol, double (&acc)[(NG * (NG + 1) / 2 + 3) / 4]) {
-  const int ci = lane & 3;                              // column within the group
+                                          int tcol, double (&acc)[GramPlanHolder<NG>::NQ]) {
+  const int ci = lane & 3;                                 // column within the group
   const int rowoff = ((lane >> 2) & 3) + 4 * (lane >> 4);  // row within the 16-row step: b + 4 k
   const double *base = pt + ci * kGramLd + rowoff;
+  const double *dwl = dw + rowoff;
+  const bool tsel = (4 * (NG - 1) + ci == tcol);
+  // the operand fetch of step s + 1 is issued before the matrix instructions of step s
+  double a0[NG], a1[NG], w0, w1;
+  gram_fetch<NG>(base, dwl, 0, a0, w0);
 #pragma unroll 1
-  for (int s = 0; s < kGramTile / 16; s++) {
-    const double w = dw[16 * s + rowoff];
-    double a[NG], bw[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      a[g] = base[(4 * g) * kGramLd + 16 * s];
-      // column `tcol` (if any) already carries its weight: its products with the panel are the plain dots P^T t
-      bw[g] = a[g] * ((4 * g + ci == tcol) ? 1.0 : w);
-    }
-    gram_step<NG, W>(a, bw, acc);
+  for (int s = 0; s < kGramTile / 16; s += 2) {
+    gram_fetch<NG>(base, dwl, s + 1, a1, w1);
+    gram_step<NG, W>(a0, w0, tsel, acc);
+    if (s + 2 < kGramTile / 16) gram_fetch<NG>(base, dwl, s + 2, a0, w0);
+    gram_step<NG, W>(a1, w1, tsel, acc);
   }
 }
 
 template <int NG, int W>
-__device__ __forceinline__ void gram_store(const double (&acc)[(NG * (NG + 1) / 2 + 3) / 4], int lane,
+__device__ __forceinline__ void gram_store(const double (&acc)[GramPlanHolder<NG>::NQ], int lane,
                                            double *__restrict__ partials) {
-  constexpr int NP = NG * (NG + 1) / 2;
+  constexpr GramPlan<NG> plan = GramPlanHolder<NG>::plan;
+  int q = 0;
 #pragma unroll
-  for (int q = 0; q < (NP + 3) / 4; q++) {
-    const int p = 4 * q + W;
-    if (p < NP) {
-      double v = acc[q];
-      v += __shfl_xor(v, 4, 64);  // the four row chunks b of the block
-      v += __shfl_xor(v, 8, 64);
-      if (((lane >> 2) & 3) == 0) {
-        const int slot = p * 16 + (lane >> 4) * 4 + (lane & 3);  // element (i, j) of block pair p
-        partials[(size_t)slot * gridDim.x + blockIdx.x] = v;
+  for (int J = 0; J < NG; J++) {
+    if (plan.owner[J] == W) {
+#pragma unroll
+      for (int I = 0; I <= J; I++) {
+        const int p = I * NG - (I * (I - 1)) / 2 + (J - I);  // row-major index of (I, J) among the upper pairs
+        double v = acc[q];
+        v += __shfl_xor(v, 4, 64);  // the four row chunks b of the block
+        v += __shfl_xor(v, 8, 64);
+        if (((lane >> 2) & 3) == 0) {
+          const int slot = p * 16 + (lane >> 4) * 4 + (lane & 3);  // element (i, j) of block pair p
+          partials[(size_t)slot * gridDim.x + blockIdx.x] = v;
+        }
+        q++;
       }
     }
   }
@@ -104,9 +152,10 @@ __device__ __forceinline__ void gram_store(const double (&acc)[(NG * (NG + 1) / 
 template <int NG, int ZP, int OCC>
 __global__ void __launch_bounds__(kBlock, OCC)
     wgram_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
-                 double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol) {
+                 double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol,
+                 int ablate) {
   constexpr int M = 4 * NG;
-  constexpr int NQ = (NG * (NG + 1) / 2 + 3) / 4;
+  constexpr int NQ = GramPlanHolder<NG>::NQ;
   extern __shared__ double lds[];  // [M][kGramLd] panel tile, then [kGramTile] weights
   double *pt = lds;
   double *dw = lds + M * kGramLd;
@@ -171,11 +220,14 @@ __global__ void __launch_bounds__(kBlock, OCC)
         if (pre_in) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
       }
       if (!pre_in) v = (f64x2){0.0, 0.0};
-      if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;
+      if (ablate == 2) {  // tuning: no LDS staging
+        if (v.x == 1.2345e301) acc[0] += v.y;
+      } else if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;
     }
     if (wave == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = pre_in ? dbuf : (f64x2){0.0, 0.0};
     __syncthreads();
-    if (tile + gridDim.x < ntiles) PO_GRAM_PREFETCH(tile + gridDim.x);
+    if (tile + gridDim.x < ntiles && ablate != 3) PO_GRAM_PREFETCH(tile + gridDim.x);
+    if (ablate == 1 || ablate == 2) continue;  // tuning: no matrix work
     switch (wave) {
       case 0: gram_tile<NG, 0>(pt, dw, lane, tcol, acc); break;
       case 1: gram_tile<NG, 1>(pt, dw, lane, tcol, acc); break;
@@ -202,6 +254,7 @@ static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, i
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  static const int ablate = getenv("PAROPT_AMD_WGRAM_ABLATE") ? atoi(getenv("PAROPT_AMD_WGRAM_ABLATE")) : 0;
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > OCC) per_cu = OCC;  // one wavefront of every resident workgroup per SIMD
   if (per_cu < 1) per_cu = 1;
@@ -210,7 +263,7 @@ static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, i
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
   hipLaunchKernelGGL((wgram_kernel<NG, ZP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, d, pt, nv, n, ntiles,
-                     c->d_partials, st, zt, kpend, b0, tcol);
+                     c->d_partials, st, zt, kpend, b0, tcol, ablate);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -245,15 +298,18 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   static const int occ_env = getenv("PAROPT_AMD_WGRAM_OCC") ? atoi(getenv("PAROPT_AMD_WGRAM_OCC")) : 0;
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
-    constexpr int OCCD = NGv <= 8 ? 4 : (NGv <= 11 ? 3 : (NGv <= 14 ? 2 : 1));                         \
-    constexpr int OCCA = NGv <= 8 ? 3 : (NGv <= 11 ? 2 : (NGv <= 14 ? 1 : 1));                         \
-    const bool alt = occ_env > 0 && occ_env == OCCA;                                                   \
+    /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \
+       that also forms the L-SR1 columns for 2 (its extra prefetch registers spill at 3) */                     \
+    constexpr int OCC0 = NGv <= 8 ? 4 : (NGv <= 11 ? 3 : (NGv <= 14 ? 2 : 1));                         \
+    constexpr int OCC0A = OCC0 > 1 ? OCC0 - 1 : 1;                                                     \
+    constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
+    constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
     if (kpend > 0) {                                                                                   \
-      if (alt) PO_TRY((wgram_launch_t<NGv, 3, OCCA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
-      else PO_TRY((wgram_launch_t<NGv, 3, OCCD>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));     \
+      if (occ_env == OCCZA) PO_TRY((wgram_launch_t<NGv, 3, OCCZA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+      else PO_TRY((wgram_launch_t<NGv, 3, OCCZ>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));     \
     } else {                                                                                           \
-      if (alt) PO_TRY((wgram_launch_t<NGv, 0, OCCA>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));    \
-      else PO_TRY((wgram_launch_t<NGv, 0, OCCD>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));        \
+      if (occ_env == OCC0A) PO_TRY((wgram_launch_t<NGv, 0, OCC0A>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));    \
+      else PO_TRY((wgram_launch_t<NGv, 0, OCC0>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));        \
     }                                                                                                  \
   } break;
   switch (NG) {
