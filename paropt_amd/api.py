@@ -466,6 +466,12 @@ class Problem:
             if int(nwblock) > 1:  # addSparseInnerProduct then fills packed upper nwblock x nwblock blocks
                 check(lib.po_problem_set_sparse_block_size(self._h, int(nwblock)))
 
+    def setLinearConstraints(self, flag=True):
+        """Declare the dense constraints linear: after the first gradient evaluation of an optimize() call
+        evalObjConGradient is called with A = None (objective gradient only)."""
+        check(lib.po_problem_set_linear_constraints(self._h, int(bool(flag))))
+        return self
+
     @property
     def handle(self):
         return self._h

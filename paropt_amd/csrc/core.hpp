@@ -184,7 +184,7 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,
-                      double az, int64_t n, double *yqn);
+                      double az, int64_t n, double *yqn, double *acz = nullptr);
 // Residual of the linearised KKT system for iterative refinement, already folded into the next
 // solve's right-hand side:  r'x = rx - diag*px + sum coef_j P_j + [L]pzl - [U]pzu ;
 // r'zl, r'zu as above ; t' = Dinv*(r'x + [L] r'zl/(x-lb) - [U] r'zu/(ub-x)).

@@ -327,6 +327,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
+  use_acz = !getenv("PAROPT_AMD_NO_ACZ");
   use_lower = prob->useLowerBounds();
   use_upper = prob->useUpperBounds();
   vars.resize(c);
@@ -360,7 +361,7 @@ int InteriorPoint::allocate() {
 }
 
 InteriorPoint::~InteriorPoint() {
-  Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn, vA};
+  Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn, vA, acz};
   for (Vec *v : all) vec_decref(v);
   for (Vec *v : Ac) vec_decref(v);
   Vec *wall[] = {gsw, gtw, Cw, wd2, wyw, wtmp, wtmp2, d1v};
@@ -404,6 +405,7 @@ int InteriorPoint::resetProblemInstance(Problem *p) {  // :745-764
   }
   prob = p;
   ac_valid = false;
+  acz_valid = false;
   return PO_OK;
 }
 
@@ -538,6 +540,7 @@ void InteriorPoint::resetQuasiNewtonHessian() {
 }
 
 int InteriorPoint::initLeastSquaresMultipliers() {  // :5366-5534 (w = 0)
+  acz_valid = false;
   const double mu0 = options.real("init_barrier_param");
   PO_TRY(k_fill(ctx, zl->d, n, mu0));
   PO_TRY(k_fill(ctx, zu->d, n, mu0));
@@ -585,6 +588,7 @@ int InteriorPoint::initAffineStepMultipliers() {  // :5536-5656
   } else {
     PO_TRY(solveKKT(res, 0.0, use_qn, false, 1.0, step));
   }
+  acz_valid = false;
   for (int i = 0; i < c; i++) {
     vars.z[i] = vars.z[i] + step.z[i];
     vars.s[i] = std::max(amin, fabs(vars.s[i] + step.s[i]));
@@ -618,8 +622,27 @@ int InteriorPoint::computeResidual(double mu, bool vectors) {
   if (has_w) PO_TRY(computeResidualW(mu));
   if (vectors) {
     std::vector<const double *> A;
-    for (Vec *a : Ac) A.push_back(a->d);
-    std::vector<double> zc(vars.z);
+    std::vector<double> zc;
+    // A problem that declared its dense constraints linear (constant Jacobian): A^T z is kept in `acz` and
+    // follows the multiplier steps (computeStepAndUpdate), so the residual does not stream the c constraint
+    // gradients; it is rebuilt from the gradients every kAczRefresh uses to bound the round-off drift.
+    if (prob->linear_constraints && ac_valid && c > 0 && use_acz) {
+      if (!acz) acz = vec_new(ctx, n);
+      if (!acz) return PO_ERR_HIP;
+      if (!acz_valid || acz_age >= kAczRefresh) {
+        std::vector<const double *> Ap;
+        for (Vec *a : Ac) Ap.push_back(a->d);
+        PO_TRY(k_panel_axpy(ctx, acz->d, 0.0, nullptr, 0.0, vars.z.data(), Ap.data(), c, n));
+        acz_valid = true;
+        acz_age = 0;
+      }
+      acz_age++;
+      A.push_back(acz->d);
+      zc.push_back(1.0);
+    } else {
+      for (Vec *a : Ac) A.push_back(a->d);
+      zc = vars.z;
+    }
     if (has_w) {  // + Aw^T zw as one more panel column (:1358-1361)
       PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
       if (prob->addSparseJacobianTranspose(1.0, x, wvar[0], tvec) != 0) return PO_ERR_USER;
@@ -1381,12 +1404,16 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // reused at the top of the loop.
   const bool fast_yqn = do_qn && analytic_panel_dots && !has_w && vA_valid;
   if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
+  // acz = A^T z follows z += alpha*sz*pz through va = A^T pz when the solves kept va; otherwise it is rebuilt
+  const bool acz_follow = acz && acz_valid && vA_valid;
   if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
-                             rx->d, vA->d, alpha * sz, n, y_qn->d));
+                             rx->d, vA->d, alpha * sz, n, y_qn->d, acz_follow ? acz->d : nullptr));
   } else {
     PO_TRY(k_update_mult(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper, n));
+    if (acz_follow) PO_TRY(k_axpy(ctx, acz->d, alpha * sz, vA->d, n));
   }
+  if (!acz_follow) acz_valid = false;
   for (int i = 0; i < c; i++) {
     double v = vars.s[i] + alpha * step.s[i];
     vars.s[i] = (v <= eps) ? eps : v;
@@ -1517,6 +1544,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   user_seconds = 0.0;
   user_pending = 0;
   ac_valid = false;
+  acz_valid = false;
   if (!seq_lin && !qn && !use_diag_hessian) {
     if (ctx->rank == 0)
       fprintf(stderr,
@@ -2040,6 +2068,7 @@ int InteriorPoint::writeSolutionFile(const char *filename) {
 
 // readSolutionFile (:983-1104): restart state written by writeSolutionFile (same layout, any rank count)
 int InteriorPoint::readSolutionFile(const char *filename) {
+  acz_valid = false;
   int64_t N = 0, off = 0, Wt = 0, woff = 0;
   PO_TRY(solutionFileOffsets(&N, &off, &Wt, &woff));  // collective
   FILE *fp = fopen(filename, "rb");

@@ -223,6 +223,11 @@ class InteriorPoint {
   void userEnd();
   void userHarvest();
   bool ac_valid = false;
+  // A^T z of a problem with linear dense constraints, kept by recurrence (computeResidual / computeStepAndUpdate)
+  static const int kAczRefresh = 16;
+  Vec *acz = nullptr;
+  bool acz_valid = false, use_acz = true;
+  int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fused_tdots = true, t0_valid = false;
   double t0_mu = 0.0;

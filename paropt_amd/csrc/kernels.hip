@@ -13,6 +13,7 @@
 #include "core.hpp"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace po {
 
@@ -30,9 +31,18 @@ namespace po {
 __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t q, int64_t n) {
   return *reinterpret_cast<const double2 *>(p + 2 * q);
 }
+#ifndef PO_ST2_PLAIN
+#define PO_ST2_NT 1
+#endif
+typedef double f64x2s __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st2(double *__restrict__ p, int64_t q, int64_t n, double2 v) {
   if (2 * q + 1 >= n) v.y = 0.0;
+#ifdef PO_ST2_NT
+  // every n-sized output is consumed by a later kernel, gigabytes of other traffic away: streaming store
+  __builtin_nontemporal_store((f64x2s){v.x, v.y}, reinterpret_cast<f64x2s *>(p + 2 * q));
+#else
   *reinterpret_cast<double2 *>(p + 2 * q) = v;
+#endif
 }
 
 // native vector types: register arrays of HIP's double2 class get demoted to scratch across barriers
@@ -118,6 +128,10 @@ int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin) {
 // 3-6 resident workgroups per CU stream at 6.2-6.5 TB/s; 8 per CU with ~6 resident leaves a
 // 1.33-wave tail and drops to 5.5 TB/s), fewer when n is small.
 int grid_for(Ctx *c, int64_t n, int bpc) {
+  static const int bpc3 = getenv("PAROPT_AMD_BPC3") ? atoi(getenv("PAROPT_AMD_BPC3")) : 0;  // tuning aid
+  static const int bpc4 = getenv("PAROPT_AMD_BPC4") ? atoi(getenv("PAROPT_AMD_BPC4")) : 0;
+  if (bpc == 3 && bpc3 > 0) bpc = bpc3;
+  if (bpc == 4 && bpc4 > 0) bpc = bpc4;
   const int64_t npairs = (n + 1) >> 1;
   int64_t blocks = (npairs + kBlock - 1) / kBlock;
   const int64_t cap = (int64_t)c->num_cu * bpc;
@@ -524,9 +538,8 @@ __device__ __forceinline__ BE bound_elem(double x, double lb, double ub, double 
   e.zu = zu;
   return e;
 }
-#define PO_LOAD_BOUNDS(b, q, n)                                                         \
-  const double2 _x = ld2((b).x, q, n), _lb = ld2((b).lb, q, n), _ub = ld2((b).ub, q, n), \
-                _zl = ld2((b).zl, q, n), _zu = ld2((b).zu, q, n);                        \
+// e0 / e1 from the five loaded pairs _x, _lb, _ub, _zl, _zu (double2) of row pair q
+#define PO_MAKE_BOUNDS(b, q, n)                                                          \
   const bool _has2 = (2 * q + 1 < n);                                                    \
   const BE e0 = bound_elem(_x.x, _lb.x, _ub.x, _zl.x, _zu.x, (b).max_bound, (b).use_lower, \
                            (b).use_upper);                                               \
@@ -538,6 +551,10 @@ __device__ __forceinline__ BE bound_elem(double x, double lb, double ub, double 
     e1.xl = 1.0;                                                                         \
     e1.xu = 1.0;                                                                         \
   }
+#define PO_LOAD_BOUNDS(b, q, n)                                                         \
+  const double2 _x = ld2((b).x, q, n), _lb = ld2((b).lb, q, n), _ub = ld2((b).ub, q, n), \
+                _zl = ld2((b).zl, q, n), _zu = ld2((b).zu, q, n);                        \
+  PO_MAKE_BOUNDS(b, q, n)
 
 // rx, complementarity, residual norms -----------------------------------------------------------
 // sums: {comp product, active count, l1|rx|, l1|rzl|, l1|rzu|, l2 rx, l2 rzl, l2 rzu}; maxs: {rx, rzl, rzu}
@@ -861,48 +878,81 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
 // -------------------------------------------------------------------------------------------------
 // First solve pass with the refinement residual AND its panel dots fused (one pass over P instead
 // of three: solve2 + res_step + mdot).  Mapping: a workgroup owns tiles of 128 rows; wave w owns the
-// panel columns j = w (mod 4), lane l the rows 2l, 2l+1 of the tile.  Each wave keeps its column
-// slice of the tile in registers (buf), contributes partial row sums  sum_j alpha_j P_j  through
-// 12 KB of LDS, wave 0 runs the element epilogue (px, pzl, pzu, t' = Dinv*d1'), t' is broadcast back
-// through 1 KB of LDS and every wave accumulates  P_j^T t'  for its own columns from registers.
+// panel columns j = w (mod 4), lane l the rows 2l, 2l+1 of the tile.  Per tile:
+//   (1) every wave forms the partial row sums  sum_j alpha_j P_j  over its own columns straight from the
+//       prefetch registers, posts them (6 KB of LDS) and parks its column slice of the tile in LDS;
+//   (2) the prefetch registers are free again: the loads of the NEXT tile are issued now and stay in flight
+//       through the rest of the tile;
+//   (3) wave 0 runs the element epilogue (px, pzl, pzu, t' = Dinv*d1') on operands it prefetched one tile
+//       ahead, broadcasts t' through 1 KB of LDS and prefetches its operands of the next tile;
+//   (4) every wave accumulates  P_j^T t'  for its own columns from its LDS slice.
+// Each wave reads back only the LDS columns it wrote itself, so two barriers per tile suffice.
 // -------------------------------------------------------------------------------------------------
-template <int NPASS>
-__global__ void __launch_bounds__(kBlock)
+constexpr int kS2Tile = 128;
+template <int NPASS, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
     solve2_dots_kernel(Bounds b, const double *t, const double *__restrict__ dinv, CoefTable alpha,
                        CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                        double *tout, double *__restrict__ va, int nca, double *__restrict__ partials) {
-  __shared__ double sacc[4 * 64 * 6];
-  __shared__ double stp[128];
-  __shared__ double sm[4 * 2];
+  extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
+  double *pt = s2lds;
+  double *sacc = s2lds + 4 * NPASS * kS2Tile;
+  double *stp = sacc + 4 * 64 * 6;
+  double *sm = stp + kS2Tile;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform on purpose: keeps the column pointers and coefficients in scalar registers
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *myslice = pt + (size_t)wave * NPASS * kS2Tile + 2 * lane;
   double dotacc[NPASS];
 #pragma unroll
   for (int it = 0; it < NPASS; it++) dotacc[it] = 0.0;
   double mins[2] = {1.0, 1.0};
   const int64_t qlast = (n - 1) >> 1;
+  f64x2 buf[NPASS];
+  f64x2 eb[8];  // wave 0: x, lb, ub, zl, zu, t, dinv, rx of the tile
+  int64_t q = 0;
+  bool in = false;
+#define PO_S2_PREFETCH(TILE)                                                                 \
+  {                                                                                          \
+    q = (TILE) * 64 + lane;                                                                  \
+    in = (2 * q < n);                                                                        \
+    if (!in) q = qlast;                                                                      \
+    _Pragma("unroll") for (int it = 0; it < NPASS; it++) {                                   \
+      const int j = wave + 4 * it;                                                           \
+      buf[it] = ld_stream(P.p[j < nv ? j : 0] + 2 * q);                                      \
+    }                                                                                        \
+  }
+#define PO_S2_PREFETCH_E(Q)                                                                  \
+  {                                                                                          \
+    eb[0] = *reinterpret_cast<const f64x2 *>(b.x + 2 * (Q));                                 \
+    eb[1] = *reinterpret_cast<const f64x2 *>(b.lb + 2 * (Q));                                \
+    eb[2] = *reinterpret_cast<const f64x2 *>(b.ub + 2 * (Q));                                \
+    eb[3] = *reinterpret_cast<const f64x2 *>(b.zl + 2 * (Q));                                \
+    eb[4] = *reinterpret_cast<const f64x2 *>(b.zu + 2 * (Q));                                \
+    eb[5] = *reinterpret_cast<const f64x2 *>(t + 2 * (Q));                                   \
+    eb[6] = *reinterpret_cast<const f64x2 *>(dinv + 2 * (Q));                                \
+    eb[7] = *reinterpret_cast<const f64x2 *>(rx + 2 * (Q));                                  \
+  }
+  if ((int64_t)blockIdx.x < ntiles) {
+    PO_S2_PREFETCH((int64_t)blockIdx.x);
+    if (wave == 0) PO_S2_PREFETCH_E(q);
+  }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int64_t q = tile * 64 + lane;  // pair index
-    const bool in = (2 * q < n);
-    if (!in) q = qlast;
-    f64x2 buf[NPASS];
-#pragma unroll
-    for (int it = 0; it < NPASS; it++) {
-      const int j = wave + 4 * it;
-      buf[it] = ld_stream(P.p[j < nv ? j : 0] + 2 * q);
-    }
+    const int64_t qc = q;  // row pair of this lane in the current tile
+    const bool inc = in;
     f64x2 a1 = (f64x2){0.0, 0.0}, a2 = a1, aA = a1;
 #pragma unroll
     for (int it = 0; it < NPASS; it++) {
       const int j = wave + 4 * it;  // coefficient tables are zero beyond nv
-      if (!in) buf[it] = (f64x2){0.0, 0.0};
+      f64x2 v = buf[it];
+      if (!inc) v = (f64x2){0.0, 0.0};
       const double ca = alpha.a[j], cb = coef2.a[j], cA = j < nca ? ca : 0.0;
-      a1 += ca * buf[it];
-      a2 += cb * buf[it];
-      aA += cA * buf[it];
+      a1 += ca * v;
+      a2 += cb * v;
+      aA += cA * v;
+      *reinterpret_cast<f64x2 *>(myslice + it * kS2Tile) = v;
     }
     double *sa = sacc + (wave * 64 + lane) * 6;
     sa[0] = a1.x;
@@ -912,6 +962,10 @@ __global__ void __launch_bounds__(kBlock)
     sa[4] = aA.x;
     sa[5] = aA.y;
     __syncthreads();
+    const bool more = tile + gridDim.x < ntiles;
+    // wave 0 issues its share of the next tile after the epilogue (keeps the prefetch registers out of the
+    // epilogue's register peak)
+    if (more && wave != 0) PO_S2_PREFETCH(tile + gridDim.x);
     if (wave == 0) {
       double2 acc = make_double2(0.0, 0.0), acc2 = acc, accA = acc;
 #pragma unroll
@@ -925,9 +979,14 @@ __global__ void __launch_bounds__(kBlock)
         accA.y += sp[5];
       }
       double2 tp = make_double2(0.0, 0.0);
-      if (in) {
-        PO_LOAD_BOUNDS(b, q, n);
-        const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n), r = ld2(rx, q, n);
+      if (inc) {
+        const double2 _x = make_double2(eb[0].x, eb[0].y), _lb = make_double2(eb[1].x, eb[1].y),
+                      _ub = make_double2(eb[2].x, eb[2].y), _zl = make_double2(eb[3].x, eb[3].y),
+                      _zu = make_double2(eb[4].x, eb[4].y);
+        const int64_t q = qc;
+        PO_MAKE_BOUNDS(b, q, n);
+        const double2 tv = make_double2(eb[5].x, eb[5].y), dv = make_double2(eb[6].x, eb[6].y),
+                      r = make_double2(eb[7].x, eb[7].y);
         if (va) st2(va, q, n, accA);
         const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
         Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
@@ -946,12 +1005,21 @@ __global__ void __launch_bounds__(kBlock)
       }
       stp[2 * lane] = tp.x;
       stp[2 * lane + 1] = tp.y;
+      if (more) {
+        PO_S2_PREFETCH(tile + gridDim.x);
+        PO_S2_PREFETCH_E(q);  // operands of the next tile (q was advanced by the prefetch above)
+      }
     }
     __syncthreads();
-    const double t0 = stp[2 * lane], t1 = stp[2 * lane + 1];
+    const f64x2 tt = *reinterpret_cast<const f64x2 *>(stp + 2 * lane);
 #pragma unroll
-    for (int it = 0; it < NPASS; it++) dotacc[it] = fma(buf[it].x, t0, fma(buf[it].y, t1, dotacc[it]));
+    for (int it = 0; it < NPASS; it++) {
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(myslice + it * kS2Tile);
+      dotacc[it] = fma(v.x, tt.x, fma(v.y, tt.y, dotacc[it]));
+    }
   }
+#undef PO_S2_PREFETCH
+#undef PO_S2_PREFETCH_E
   // dots: wave w holds columns w + 4*it; slots 0..nv-1 (sums), then the two minima
 #pragma unroll
   for (int it = 0; it < NPASS; it++) {
@@ -959,14 +1027,47 @@ __global__ void __launch_bounds__(kBlock)
     const int j = wave + 4 * it;
     if (lane == 0 && j < nv) partials[(size_t)j * gridDim.x + blockIdx.x] = v;
   }
+  __syncthreads();
   block_reduce_store<2, OP_MIN>(mins, partials, nv, sm);
 }
 
-#define PO_S2D_CASE(NP)                                                                          \
-  case NP:                                                                                       \
-    PO_LAUNCH(solve2_dots_kernel<NP>, grid, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, \
-              ntiles, px, pzl, pzu, tout, va, nca, c->d_partials);                               \
-    break;
+template <int NP, int OCC>
+static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const double *t, const double *dinv,
+                              const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
+                              double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
+                              double *pzl, double *pzu, double *tout, double *va, int nca, int *grid_out) {
+  const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(solve2_dots_kernel<NP, OCC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > OCC) per_cu = OCC;
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)c->num_cu * per_cu;
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
+  hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
+                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, c->d_partials);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  *grid_out = (int)g;
+  return PO_OK;
+}
+
+#define PO_S2D_CASE(NP)                                                                                    \
+  case NP: {                                                                                               \
+    constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
+    if (occ_env == OA)                                                                                     \
+      PO_TRY((solve2_dots_launch<NP, OA>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
+                                         pzl, pzu, tout, va, nca, &grid)));                                \
+    else                                                                                                   \
+      PO_TRY((solve2_dots_launch<NP, OD>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
+                                         pzl, pzu, tout, va, nca, &grid)));                                \
+  } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
@@ -978,11 +1079,8 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
     return PO_ERR_ARG;
   }
   const int64_t ntiles = (((n + 1) >> 1) + 63) / 64;
-  int64_t g = (int64_t)c->num_cu * 4;
-  if (g > ntiles) g = ntiles;
-  if (g < 1) g = 1;
-  const int grid = (int)g;
-  PO_TRY(ensure_partials(c, (size_t)grid * (nv + 2)));
+  int grid = 0;
+  static const int occ_env = getenv("PAROPT_AMD_S2D_OCC") ? atoi(getenv("PAROPT_AMD_S2D_OCC")) : 0;
   PtrTable pt;
   CoefTable ct, ct2;
   fill_tables(alpha, P, nv, &ct, &pt);
@@ -1232,10 +1330,14 @@ __global__ void __launch_bounds__(kBlock)
                            double *__restrict__ zu, const double *__restrict__ pzu, double a,
                            double eps, int use_lower, int use_upper, const double *__restrict__ rx,
                            const double *__restrict__ va, double az, int64_t n,
-                           double *__restrict__ yqn) {
+                           double *__restrict__ yqn, double *__restrict__ acz) {
   PO_PAIR_LOOP(q, n) {
     const double2 r = ld2(rx, q, n), w = ld2(va, q, n);
     double2 y = make_double2(r.x + az * w.x, r.y + az * w.y);
+    if (acz) {  // A^T z of a problem with a constant Jacobian follows the multiplier step: += az * A^T pz
+      const double2 c0 = ld2(acz, q, n);
+      st2(acz, q, n, make_double2(c0.x + az * w.x, c0.y + az * w.y));
+    }
     if (use_lower) {
       const double2 z = ld2(zl, q, n), p = ld2(pzl, q, n);
       y.x -= z.x;
@@ -1257,10 +1359,10 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,
-                      double az, int64_t n, double *yqn) {
+                      double az, int64_t n, double *yqn, double *acz) {
   if (n <= 0) return PO_OK;
   PO_LAUNCH(update_mult_yqn_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, rx,
-            va, az, n, yqn);
+            va, az, n, yqn, acz);
   return PO_OK;
 }
 

@@ -487,6 +487,82 @@ def test_explicit_and_analytic_panel_dots_agree(ctx, monkeypatch):
     np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("problem,qn,strategy", [("convex", "sr1", "monotone"), ("quadratic", "bfgs", "monotone"),
+                                                 ("convex", "bfgs", "mehrotra_predictor_corrector")])
+def test_linear_constraint_declaration_changes_nothing(ctx, problem, qn, strategy):
+    """po_problem_set_linear_constraints: the Jacobian of the first gradient evaluation is kept, the gradient
+    callback is asked for the objective gradient only, and A^T z follows the multiplier steps by recurrence
+    (rebuilt every 16 iterations) instead of streaming the constraint gradients: same trajectory as the plain
+    contract (counters / tokens bit-exact, state to 1e-8)."""
+    import paropt_amd as pa
+
+    opts = {"qn_type": qn, "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 45, "write_output_frequency": 0, "barrier_strategy": strategy}
+    runs = []
+    for flag in (False, True):
+        prob = pa.SeparableProblem(ctx, problem, 20011, 7)
+        prob.setLinearConstraints(flag)
+        ip = pa.InteriorPoint(prob, opts)
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        ip.optimize()
+        runs.append((sn, ip.getHistory(), ip.getOptimizedPoint()[0].to_numpy(), ip.getPhaseTimes()))
+    a, b = runs
+    assert len(a[0]) == len(b[0]) and len(a[0]) > 20
+    for sa, sb in zip(a[0], b[0]):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["qn_size"] == sb["qn_size"]
+        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-8 * max(1.0, abs(sb["fobj"]))
+        np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-8)
+        np.testing.assert_allclose(sa["z"], sb["z"], rtol=1e-6, atol=1e-9)
+    assert info_tokens(a[1]) == info_tokens(b[1])
+    np.testing.assert_allclose(a[2], b[2], rtol=0, atol=1e-8)
+
+
+def test_linear_constraints_python_callback_gets_no_jacobian(ctx):
+    """With the declaration, a callback problem sees Ac = None after the first gradient evaluation of an
+    optimize() call (and never without it)."""
+    import paropt_amd as pa
+
+    n, c = 500, 2
+    rng = np.random.default_rng(3)
+    A = rng.uniform(0.0, 1.0, size=(c, n))
+    q = rng.uniform(1.0, 5.0, size=n)
+    calls = []
+
+    class P(pa.Problem):
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = 0.5
+            lb[:] = 0.0
+            ub[:] = 1.0
+
+        def evalObjCon(self, x):
+            return 0, float(0.5 * np.dot(q * x, x)), (A @ x - 0.1 * A.sum(axis=1))
+
+        def evalObjConGradient(self, x, g, Ac):
+            calls.append(Ac is None)
+            g[:] = q * x
+            if Ac is not None:
+                for j in range(c):
+                    Ac[j][:] = A[j]
+            return 0
+
+    opts = {"qn_subspace_size": 4, "abs_res_tol": 1e-7, "max_major_iters": 12, "write_output_frequency": 0}
+    res = []
+    for flag in (False, True):
+        calls.clear()
+        prob = P(ctx, n, c)
+        if flag:
+            prob.setLinearConstraints(True)
+        ip = pa.InteriorPoint(prob, opts)
+        ip.optimize()
+        res.append((list(calls), ip.getOptimizedPoint()[0].to_numpy(), ip.getIterationCounters()))
+    assert not any(res[0][0])
+    assert res[1][0][0] is False and all(res[1][0][1:]) and len(res[1][0]) > 3
+    assert res[0][2] == res[1][2]
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
+
+
 def test_solution_file_format(ctx, tmp_path):
     """The binary checkpoint of writeSolutionFile (src/ParOptInteriorPoint.cpp:883-972): same
     layout as the file the reference left behind (header ints bit-exact, payload to 1e-6), and a
