@@ -230,15 +230,16 @@ class ParOptProblem : public ParOptBase {
     std::vector<ParOptVec *> va(me->ncon > 0 ? me->ncon : 1, (ParOptVec *)NULL);
     double *p;
     vg.getArray(&p);
-    for (int j = 0; j < me->ncon; j++) {
+    // Ac == NULL: the problem declared linear constraints (setLinearConstraints) and only g is wanted
+    for (int j = 0; Ac && j < me->ncon; j++) {
       va[j] = new ParOptVec(Ac[j]);
       va[j]->incref();
       // the reference hands out zero-initialised Ac that the problem may fill sparsely
       va[j]->getArray(&p);
     }
-    int fail = me->evalObjConGradient(&vx, &vg, va.data());
+    int fail = me->evalObjConGradient(&vx, &vg, Ac ? va.data() : NULL);
     vg.syncToDevice();
-    for (int j = 0; j < me->ncon; j++) {
+    for (int j = 0; Ac && j < me->ncon; j++) {
       va[j]->syncToDevice();
       va[j]->decref();
     }

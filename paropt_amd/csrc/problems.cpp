@@ -180,12 +180,13 @@ int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   for (int j = 0; j < ncon; j++) h[j] = Ac ? static_cast<po_vec>(Ac[j]) : nullptr;
   if (csr) {  // ParOptSparseProblem::evalObjConGradient (.cpp:739-742)
     if (!csr_gradient) return 1;
-    int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data(), csr->data,
-                          csr->nnz);
+    int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), Ac ? h.data() : nullptr,
+                          csr->data, csr->nnz);
     if (rc != 0) return rc;
     return csr->valuesChanged() != PO_OK;
   }
-  return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), h.data());
+  return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g),
+                                  Ac ? h.data() : nullptr);
 }
 int CallbackProblem::computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) {
   if (!cb.qn_update_correction) return 0;
