@@ -486,6 +486,57 @@ for nt in ("l1", "l2"):
         **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.norm_type": nt, "opt.max_major_iters": 80}),
     )
 
+# --- SURVEY 8a' integer bookkeeping: bound repairs of initAndCheckDesignAndBounds (check_flag bits, :4290-4344)
+# and clamp events (:3150-3190, 4177-4195).  bounds_mode: see oracle/ref_driver.cpp SepProblem.
+case("ip_convex_badbounds7_n300_c3", "ip", problem="convex", n=300, c=3, bounds_mode=7, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 60}))
+case("ip_quadratic_badbounds2_n200_c2", "ip", problem="quadratic", n=200, c=2, bounds_mode=2, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 60}))
+case("ip_convex_badbounds5_n201_c2_r2", "ip", ranks=2, problem="convex", n=201, c=2, bounds_mode=5, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 60}))
+# a coarse design_precision makes the clamps of the trial point and of the multipliers fire every few iterations
+case("ip_convex_clamp_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=5,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 40, "opt.design_precision": 3e-2}))
+case("ip_convex_clamp1e1_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=5,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 40, "opt.design_precision": 1e-1}))
+case("ip_quadratic_clamp_n200_c2", "ip", problem="quadratic", n=200, c=2, dump_vecs_every=5,
+     **dict(ip_common, **{"opt.qn_subspace_size": 5, "opt.max_major_iters": 40, "opt.design_precision": 5e-2}))
+# --- option branches with real control flow: backtracking line search (:4078), periodic Hessian
+# reset (:4611), relative function test (:4644), qn_sigma (:1477, 1871), no starting-point strategy, sequential
+# linear method without a quasi-Newton object, abs_step_tol (only ever stored, :4587, 4880, 4996)
+case("ip_rosenbrock_backtrack_n100", "ip", problem="rosenbrock", n=100, dump_vecs_every=10,
+     **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-6, "opt.write_output_frequency": 1,
+        "opt.max_major_iters": 150, "opt.use_backtracking_alpha": 1})
+case("ip_convex_backtrack_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 60, "opt.use_backtracking_alpha": 1}))
+case("ip_quadratic_resetfreq7_n300_c3", "ip", problem="quadratic", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80, "opt.hessian_reset_freq": 7}))
+case("ip_quadratic_relfunc_n300_c3", "ip", problem="quadratic", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80, "opt.rel_func_tol": 1e-6}))
+case("ip_quadratic_sigma_n300_c3", "ip", problem="quadratic", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80, "opt.qn_sigma": 0.5}))
+case("ip_convex_sigma_sr1_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs_every=5,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.qn_type": "sr1", "opt.max_major_iters": 25,
+                          "opt.qn_sigma": 2.0}))
+case("ip_quadratic_nostart_n300_c3", "ip", problem="quadratic", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80,
+                          "opt.starting_point_strategy": "no_start_strategy"}))
+case("ip_quadratic_slp_noqn_n200_c2", "ip", problem="quadratic", n=200, c=2, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_type": "none", "opt.sequential_linear_method": 1, "opt.max_major_iters": 40}))
+case("ip_quadratic_absstep_n300_c3", "ip", problem="quadratic", n=300, c=3, dump_vecs_every=10,
+     **dict(ip_common, **{"opt.qn_subspace_size": 6, "opt.max_major_iters": 80, "opt.abs_step_tol": 1e-4}))
+# --- the metric's configurations at n = 1e5 on FOUR MPI ranks (state of rank 0's shard, every 25th
+# element, every 5th iteration): config-2 shape, config-3 shape with the convergent L-BFGS variant, and the L-SR1
+# variant over a short window
+case("ip_quadratic_n100000_c8_bfgs20_r4", "ip", ranks=4, problem="quadratic", n=100000, c=8, dump_vecs_every=5,
+     vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 20, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
+case("ip_convex_n100000_c32_bfgs10_r4", "ip", ranks=4, problem="convex", n=100000, c=32, dump_vecs_every=5,
+     vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
+case("ip_convex_n100000_c32_sr1_r4", "ip", ranks=4, problem="convex", n=100000, c=32, dump_vecs_every=5,
+     vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 20}))
+case("ip_convex_n100000_c32_bfgs10_r1", "ip", ranks=1, problem="convex", n=100000, c=32, dump_vecs_every=5,
+     vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -518,6 +569,17 @@ def main():
             if mode == "ip":
                 with open(dargs["text"]) as f:
                     lines = [ln.rstrip("\n") for ln in f]
+                # check_flag of initAndCheckDesignAndBounds (:4290-4344) is a local of the reference: recovered
+                # from the three warnings it prints (the checks run in the constructor and again in optimize())
+                flag = 0
+                for ln in lines:
+                    if "Variable bounds are inconsistent" in ln:
+                        flag |= 1
+                    if "too close to lower bound" in ln:
+                        flag |= 2
+                    if "too close to upper bound" in ln:
+                        flag |= 4
+                d["check_flag"] = np.array([flag], dtype=np.int32)
                 # keep only the iteration table (drop the options echo)
                 start = next((i for i, ln in enumerate(lines) if ln.startswith("iter ")), 0)
                 d["paropt_out"] = np.array("\n".join(lines[start:]))

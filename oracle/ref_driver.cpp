@@ -63,7 +63,7 @@ static inline double u01(uint64_t seed, uint64_t aid, uint64_t i) {
 // ---------------------------------------------------------------------------
 struct RecFile {
   FILE *fp;
-  RecFile() : fp(NULL) {}
+  RecFile() : fp(NULL), stride(1) {}
   void open(const char *name) { fp = fopen(name, "wb"); }
   void close() {
     if (fp) fclose(fp);
@@ -83,10 +83,17 @@ struct RecFile {
   void f64s(const char *name, double v) { put(name, 0, 1, &v); }
   void i32(const char *name, const int *v, int64_t n) { put(name, 1, n, v); }
   void i32s(const char *name, int v) { put(name, 1, 1, &v); }
+  int stride;  // > 1: vectors are stored as every stride-th local element (large-n goldens)
   void vec(const char *name, ParOptVec *v) {
     double *a;
     int n = v->getArray(&a);
-    f64(name, a, n);
+    if (stride > 1) {
+      std::vector<double> sub;
+      for (int i = 0; i < n; i += stride) sub.push_back(a[i]);
+      f64(name, sub.data(), (int64_t)sub.size());
+    } else {
+      f64(name, a, n);
+    }
   }
 };
 
@@ -132,6 +139,7 @@ class SepProblem : public ParOptProblem {
     hook = NULL;
     tr_hook = NULL;
     use_lower_flag = use_upper_flag = 1;
+    bounds_mode = 0;
     beta.resize(_ncon);
     if (kind == QUADRATIC) {
       for (int j = 0; j < _ncon; j++) beta[j] = u01(seed, 4, j);
@@ -153,6 +161,10 @@ class SepProblem : public ParOptProblem {
   int useLowerBounds() { return use_lower_flag; }
   int useUpperBounds() { return use_upper_flag; }
   int use_lower_flag, use_upper_flag;
+  // bounds_mode (test data for initAndCheckDesignAndBounds, src/ParOptInteriorPoint.cpp:4277-4361), by GLOBAL
+  // index gi:  bit 1: gi % 7 == 3 -> lb = ub = midpoint (inconsistent bounds);  bit 2: gi % 11 == 5 -> x = lb
+  // (too close to the lower bound);  bit 4: gi % 13 == 6 -> x = ub (too close to the upper bound)
+  int bounds_mode;
 
   void getVarsAndBounds(ParOptVec *xv, ParOptVec *lbv, ParOptVec *ubv) {
     double *x, *lb, *ub;
@@ -173,6 +185,10 @@ class SepProblem : public ParOptProblem {
         lb[i] = -2.0;
         ub[i] = 1.0;
       }
+      const int64_t gi = offset + i;
+      if ((bounds_mode & 1) && gi % 7 == 3) lb[i] = ub[i] = 0.5 * (lb[i] + ub[i]);
+      if ((bounds_mode & 2) && gi % 11 == 5) x[i] = lb[i];
+      if ((bounds_mode & 4) && gi % 13 == 6) x[i] = ub[i];
     }
   }
 
@@ -602,6 +618,49 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
       R.f64((p + "qn_M").c_str(), M, (int64_t)k * k);
     }
   }
+  // Integer bookkeeping of SURVEY 8a': LU pivot rows of the last Schur-complement factorization (LAPACK dgetrf,
+  // 1-based; src/ParOptInteriorPoint.cpp:1968-1969) and of the compact quasi-Newton matrix
+  // (src/ParOptQuasiNewton.cpp:375, 743), valid from the iteration after they were computed
+  if (iter > 0) {
+    R.i32((p + "gpiv").c_str(), ip->gpiv, c);
+    if (ip->qn) {
+      ParOptLBFGS *lb_ = dynamic_cast<ParOptLBFGS *>(ip->qn);
+      ParOptLSR1 *sr_ = dynamic_cast<ParOptLSR1 *>(ip->qn);
+      if (lb_ && lb_->msub > 0) R.i32((p + "mfpiv").c_str(), lb_->mfpiv, 2 * lb_->msub);
+      if (sr_ && sr_->msub > 0) R.i32((p + "mfpiv").c_str(), sr_->mfpiv, sr_->msub);
+    }
+  }
+  {
+    // clamp events (computeStepVec :3150-3190, computeStepAndUpdate :4177-4195): variables / multipliers that
+    // sit exactly at their clamp value lb + eps, ub - eps, eps after the step
+    const double eps = ip->options->getFloatOption("design_precision");
+    double *xa, *la, *ua, *zla, *zua;
+    int nl = ip->variables.x->getArray(&xa);
+    ip->lb->getArray(&la);
+    ip->ub->getArray(&ua);
+    ip->variables.zl->getArray(&zla);
+    ip->variables.zu->getArray(&zua);
+    int loc[4] = {0, 0, 0, 0}, tot[4];
+    for (int i = 0; i < nl; i++) {
+      if (xa[i] == la[i] + eps) loc[0]++;
+      if (xa[i] == ua[i] - eps) loc[1]++;
+      if (zla[i] == eps) loc[2]++;
+      if (zua[i] == eps) loc[3]++;
+    }
+    MPI_Allreduce(loc, tot, 4, MPI_INT, MPI_SUM, ip->comm);
+    int cl[8] = {tot[0], tot[1], tot[2], tot[3], 0, 0, 0, 0};
+    for (int i = 0; i < c; i++) {
+      if (ip->variables.s[i] == eps) cl[4]++;
+      if (ip->variables.t[i] == eps) cl[5]++;
+      if (ip->variables.zs[i] == eps) cl[6]++;
+      if (ip->variables.zt[i] == eps) cl[7]++;
+    }
+    R.i32((p + "clamped").c_str(), cl, 8);
+  }
+  if (iter == 0 && hook->dump_vecs_every > 0) {
+    R.vec((p + "lb").c_str(), ip->lb);
+    R.vec((p + "ub").c_str(), ip->ub);
+  }
   // Scalar fingerprints of the distributed vectors (collective calls)
   double nx = ip->variables.x->norm(), nzl = ip->variables.zl->norm(),
          nzu = ip->variables.zu->norm();
@@ -891,6 +950,7 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   prob->use_lower_flag = (int)geti(A, "use_lower", 1);
   prob->use_upper_flag = (int)geti(A, "use_upper", 1);
   prob->nwblock = (int)geti(A, "nwblock", 1);
+  prob->bounds_mode = (int)geti(A, "bounds_mode", 0);
   ParOptProblem *top = prob;
   const int chain_span = (int)geti(A, "chain_span", 0);
   if (chain_span > 0) {
@@ -918,6 +978,7 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
   if (!bench) {
     if (rank == 0) R.open(gets(A, "out", "ip.rec").c_str());
+    R.stride = (int)geti(A, "vec_stride", 1);
     prob->hook = &hook;
     R.i32s("n", (int)n);
     R.i32s("c", c);
