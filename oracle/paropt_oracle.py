@@ -311,8 +311,11 @@ class SepProblem:
     """
 
     def __init__(self, kind, n, c, seed=0, eig_min=1.0, eig_max=100.0, comm=None, nwcon=0, nw=0,
-                 nwstart=0, nwskip=0, nwineq=-1, chain=None, nwblock=1):
+                 nwstart=0, nwskip=0, nwineq=-1, chain=None, nwblock=1, bounds_mode=0):
         self.comm = comm if comm is not None else SelfComm()
+        # test data for initAndCheckDesignAndBounds (oracle/ref_driver.cpp SepProblem::bounds_mode), by global index
+        # gi: bit 1: gi % 7 == 3 -> lb = ub = midpoint; bit 2: gi % 11 == 5 -> x = lb; bit 4: gi % 13 == 6 -> x = ub
+        self.bounds_mode = int(bounds_mode)
         # chain = (span, stride): the CSR form (ParOptSparseProblem, src/ParOptProblem.cpp:624-816) with the
         # rank-local overlapping constraints cw_i = 1 - sum_{k<span} x[i*stride+k]^2 >= 0 of
         # oracle/ref_driver.cpp SepCsrProblem (examples/rosenbrock/sparse_rosenbrock.cpp:75-118 is (2, 1))
@@ -365,10 +368,23 @@ class SepProblem:
     def vars_and_bounds(self):
         n = self.nlocal
         if self.kind == "quadratic":
-            return -2.0 + u01(self.seed, 3, self.idx), np.full(n, -5.0), np.full(n, 5.0)
-        if self.kind == "convex":
-            return 0.05 + 0.9 * u01(self.seed, 3, self.idx), np.zeros(n), np.ones(n)
-        return np.full(n, -1.0), np.full(n, -2.0), np.full(n, 1.0)
+            x, lb, ub = -2.0 + u01(self.seed, 3, self.idx), np.full(n, -5.0), np.full(n, 5.0)
+        elif self.kind == "convex":
+            x, lb, ub = 0.05 + 0.9 * u01(self.seed, 3, self.idx), np.zeros(n), np.ones(n)
+        else:
+            x, lb, ub = np.full(n, -1.0), np.full(n, -2.0), np.full(n, 1.0)
+        if self.bounds_mode:
+            gi = self.idx.astype(np.int64)
+            if self.bounds_mode & 1:
+                m = gi % 7 == 3
+                mid = 0.5 * (lb + ub)
+                lb = np.where(m, mid, lb)
+                ub = np.where(m, mid, ub)
+            if self.bounds_mode & 2:
+                x = np.where(gi % 11 == 5, lb, x)
+            if self.bounds_mode & 4:
+                x = np.where(gi % 13 == 6, ub, x)
+        return x, lb, ub
 
     def sparse_jacobian_dense(self):
         """Aw as a dense (w, n) array from the stored entries (tests and the dense S of the oracle)."""
@@ -708,20 +724,30 @@ class InteriorPoint:
         x, lb, ub = self.prob.vars_and_bounds()
         x, lb, ub = x.copy(), lb.copy(), ub.copy()
         rel_bound = 0.001 * self.barrier_param
+        flag = 0
         if self.use_lower and self.use_upper:
             L = lb > -mb
             U = ub < mb
             both = L & U
             bad = both & (lb >= ub)
             if np.any(bad):
+                flag |= 1
                 lbn = 0.5 * (lb[bad] + ub[bad]) - 0.5 * rel_bound
                 lb[bad] = lbn
                 ub[bad] = lbn + rel_bound
             delta = np.where(both, ub - lb, 1.0)
             lo = L & (x < lb + rel_bound * delta)
+            if np.any(lo):
+                flag |= 2
             x = np.where(lo, lb + rel_bound * delta, x)
             hi = U & (x > ub - rel_bound * delta)
+            if np.any(hi):
+                flag |= 4
             x = np.where(hi, ub - rel_bound * delta, x)
+        # MPI_Allreduce(MPI_BOR) of the reference (:4326-4327), accumulated over the calls like the warnings are
+        fl = np.array([float(flag & 1), float(flag & 2), float(flag & 4)])
+        fl = self.comm.allreduce(fl, op="max") if hasattr(self.comm, "allreduce") else fl
+        self.check_flag = getattr(self, "check_flag", 0) | (1 if fl[0] else 0) | (2 if fl[1] else 0) | (4 if fl[2] else 0)
         self.vars.x[:] = x
         self.lb, self.ub = lb, ub
         self.vars.zl[lb <= -mb] = 0.0
@@ -1919,6 +1945,19 @@ class InteriorPoint:
             d["wnorms"] = np.array([self.ops.norm(getattr(v, k)) for k in ("zw", "sw", "tw", "zsw", "ztw")])
             for k in ("zw", "sw", "tw", "zsw", "ztw"):
                 d[k] = getattr(v, k).copy()
+        # integer bookkeeping of SURVEY 8a' in the layout of oracle/ref_driver.cpp: LAPACK (1-based) pivot rows of
+        # the last factorizations, and the number of entries sitting exactly at their clamp values
+        if getattr(self, "Glu", None) is not None:
+            d["gpiv"] = np.asarray(self.Glu[1], dtype=np.int64) + 1
+        if self.qn is not None and getattr(self.qn, "lu", None) is not None and len(self.qn.Z) > 0:
+            d["mfpiv"] = np.asarray(self.qn.lu[1], dtype=np.int64) + 1
+        eps = self.opt["design_precision"]
+        loc = np.array([np.sum(v.x == self.lb + eps), np.sum(v.x == self.ub - eps), np.sum(v.zl == eps),
+                        np.sum(v.zu == eps)], dtype=float)
+        tot = self.comm.allreduce(loc)
+        d["clamped"] = np.array([int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), int(np.sum(v.s == eps)),
+                                 int(np.sum(v.t == eps)), int(np.sum(v.zs == eps)), int(np.sum(v.zt == eps))])
+        d["check_flag"] = getattr(self, "check_flag", 0)
         if self.qn is not None:
             b0, d0, M, Z = self.qn.get_compact()
             d["qn_size"] = len(Z)

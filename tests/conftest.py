@@ -36,6 +36,15 @@ def ip_options_from_case(case):
     return opts
 
 
+def golden_vec_view(full, case):
+    """The part of a GLOBAL design-sized vector a golden holds: rank 0's shard of the reference run
+    (contiguous blocks, oracle/ref_driver.cpp shard()), every vec_stride-th element."""
+    n = int(case["args"]["n"])
+    ranks = int(case.get("ranks", 1))
+    nloc0 = n // ranks + (1 if n % ranks > 0 else 0)
+    return np.asarray(full)[:nloc0:int(case["args"].get("vec_stride", 1))]
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN_DIR
