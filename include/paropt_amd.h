@@ -142,6 +142,9 @@ int po_qn_mult_add(po_qn qn, double alpha, po_vec x, po_vec y); /* multAdd .cpp:
 int po_qn_get_compact(po_qn qn, int *size, double *b0, const double **d0, const double **M,
                       const po_vec **Z);
 int po_qn_max_size(po_qn qn, int *size);                    /* getMaxLimitedMemorySize */
+/* 0-based pivot rows of the LU factorization of the compact matrix M (the reference's LAPACK mfpiv,
+ * src/ParOptQuasiNewton.cpp:375, 743, is 1-based); borrowed, valid until the next update / reset. */
+int po_qn_get_pivots(po_qn qn, const int **mfpiv, int *n);
 
 /* ---- ParOptProblem: src/ParOptProblem.h:42-296 -------------------------------------------- */
 /* User problems are bound the way the reference's own FFI binds them: a table of C callbacks
@@ -266,6 +269,10 @@ int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper)
  * gradient callback with Ac == NULL ("objective gradient only").  Off by default: without it Ac is never NULL.
  * Rejected (PO_ERR_ARG) for the built-in Rosenbrock problem, whose constraints are not linear. */
 int po_problem_set_linear_constraints(po_problem p, int flag);
+/* Test data for initAndCheckDesignAndBounds on the built-in problems (oracle/ref_driver.cpp SepProblem::bounds_mode),
+ * by global index gi: bit 1: gi % 7 == 3 -> lb = ub = midpoint; bit 2: gi % 11 == 5 -> x = lb; bit 4: gi % 13 == 6 ->
+ * x = ub. */
+int po_problem_set_bounds_mode(po_problem p, int mode);
 int po_problem_destroy(po_problem p);
 int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon);
 int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons);
@@ -325,6 +332,17 @@ int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, 
  * computeKKTRes/setUpKKTDiagSystem/setUpKKTSystem/computeKKTStep, .cpp:1337, 1832, 2634, 2700):
  * computes the KKT step at the current state with barrier mu into internal step storage and
  * returns borrowed handles / pointers to it. */
+/* Integer bookkeeping of the iteration (SURVEY 8a'), for bit-exact comparison with the reference:
+ *   gpiv[ngpiv]   0-based pivot rows of the LU factorization of the dense Schur complement G of the last
+ *                 setUpKKTDiagSystem (the reference's LAPACK gpiv, src/ParOptInteriorPoint.cpp:1968-1969, is 1-based;
+ *                 cpiv is not comparable: the product factors Ce from one Gram matrix);
+ *   check_flag    OR of the bound-repair bits of initAndCheckDesignAndBounds (:4290-4344): 1 inconsistent bounds,
+ *                 2 / 4 variables moved away from the lower / upper bound;
+ *   clamped[8]    entries sitting exactly at their clamp values (:3150-3190, 4177-4195): x == lb + eps,
+ *                 x == ub - eps, zl == eps, zu == eps (global counts), then s, t, zs, zt == eps. Collective. */
+int po_ip_get_debug_ints(po_ip ip, const int **gpiv, int *ngpiv, int *check_flag, int64_t clamped[8]);
+/* borrowed lb / ub vectors as repaired by initAndCheckDesignAndBounds */
+int po_ip_get_bounds(po_ip ip, po_vec *lb, po_vec *ub);
 int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,
                          const double **pz, const double **ps, const double **pt,
                          const double **pzs, const double **pzt);

@@ -517,6 +517,11 @@ class SeparableProblem:
         check(lib.po_problem_set_var_bound_options(self._h, int(bool(use_lower)), int(bool(use_upper))))
         return self
 
+    def setBoundsMode(self, mode):
+        """Deliberately broken bounds for the bound-repair tests (po_problem_set_bounds_mode)."""
+        check(lib.po_problem_set_bounds_mode(self._h, int(mode)))
+        return self
+
     def setLinearConstraints(self, flag=True):
         """The dense constraints are linear: the solver keeps the Jacobian of the first gradient evaluation
         of each optimize() and asks for the objective gradient only afterwards (po_problem_set_linear_constraints)."""
@@ -771,7 +776,25 @@ class InteriorPoint:
             check(lib.po_qn_get_compact(qn._h, C.byref(k), C.byref(b0), None, None, None))
             d["qn_size"] = k.value
             d["qn_b0"] = b0.value
+            pp, pn = L.c_int_p(), C.c_int()
+            check(lib.po_qn_get_pivots(qn._h, C.byref(pp), C.byref(pn)))
+            d["mfpiv"] = np.array([pp[i] for i in range(pn.value)], dtype=np.int64) + 1  # LAPACK numbering
+        d.update(self.getDebugInts())
         return d
+
+    def getDebugInts(self):
+        """SURVEY 8a' integers in the reference's numbering: gpiv (1-based LAPACK rows), check_flag, clamped[8]."""
+        pp, pn, fl = L.c_int_p(), C.c_int(), C.c_int()
+        cl = (C.c_int64 * 8)()
+        check(lib.po_ip_get_debug_ints(self._h, C.byref(pp), C.byref(pn), C.byref(fl), cl))
+        return dict(gpiv=np.array([pp[i] for i in range(pn.value)], dtype=np.int64) + 1, check_flag=fl.value,
+                    clamped=np.array(list(cl), dtype=np.int64))
+
+    def getBounds(self):
+        """(lb, ub) as repaired by initAndCheckDesignAndBounds (borrowed)."""
+        a, b = L.po_vec(), L.po_vec()
+        check(lib.po_ip_get_bounds(self._h, C.byref(a), C.byref(b)))
+        return PVec(self.ctx, handle=a, owned=False), PVec(self.ctx, handle=b, owned=False)
 
 
 class EigenApprox:

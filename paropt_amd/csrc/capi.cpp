@@ -355,6 +355,12 @@ int po_qn_get_compact(po_qn qn, int *size, double *b0, const double **d0, const 
   }
   return PO_OK;
 }
+int po_qn_get_pivots(po_qn qn, const int **mfpiv, int *n) {
+  PO_CHECK_PTR(qn);
+  if (mfpiv) *mfpiv = qn->qn->pivots().data();
+  if (n) *n = (int)qn->qn->pivots().size();
+  return PO_OK;
+}
 int po_qn_max_size(po_qn qn, int *size) {
   PO_CHECK_PTR(qn);
   *size = qn->qn->getMaxLimitedMemorySize();
@@ -581,6 +587,16 @@ int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper)
   p->p->use_upper = use_upper ? 1 : 0;
   return PO_OK;
 }
+int po_problem_set_bounds_mode(po_problem p, int mode) {
+  PO_CHECK_PTR(p);
+  SeparableProblem *sp = dynamic_cast<SeparableProblem *>(p->p);
+  if (!sp || mode < 0 || mode > 7) {
+    set_error("po_problem_set_bounds_mode: built-in problems only, mode 0..7");
+    return PO_ERR_ARG;
+  }
+  sp->bounds_mode = mode;
+  return PO_OK;
+}
 int po_problem_set_linear_constraints(po_problem p, int flag) {
   PO_CHECK_PTR(p);
   SeparableProblem *sp = dynamic_cast<SeparableProblem *>(p->p);
@@ -779,6 +795,25 @@ int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, 
   if (names) *names = p->phase_names_joined.c_str();
   if (seconds) *seconds = p->phase_seconds.data();
   if (count) *count = (int)p->phase_seconds.size();
+  return PO_OK;
+}
+int po_ip_get_debug_ints(po_ip ip, const int **gpiv, int *ngpiv, int *check_flag, int64_t clamped[8]) {
+  PO_CHECK_PTR(ip);
+  InteriorPoint *p = ip->ip;
+  if (gpiv) *gpiv = p->gPivots().data();
+  if (ngpiv) *ngpiv = (int)p->gPivots().size();
+  if (check_flag) *check_flag = p->checkFlag();
+  if (clamped) {
+    double out[8];
+    PO_TRY(p->clampCounts(out));
+    for (int i = 0; i < 8; i++) clamped[i] = (int64_t)(out[i] + 0.5);
+  }
+  return PO_OK;
+}
+int po_ip_get_bounds(po_ip ip, po_vec *lb, po_vec *ub) {
+  PO_CHECK_PTR(ip);
+  if (lb) *lb = static_cast<po_vec>(ip->ip->lowerBounds());
+  if (ub) *ub = static_cast<po_vec>(ip->ip->upperBounds());
   return PO_OK;
 }
 int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,

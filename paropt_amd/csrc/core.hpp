@@ -216,6 +216,10 @@ int k_affine_mult(Ctx *c, const Bounds &b, double *zl, const double *pzl, double
 // initAndCheckDesignAndBounds :4290-4360; out flag bits 1/2/4; zl/zu zeroed on inactive bounds
 int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double *zu,
                    double max_bound, double rel_bound, int both, int64_t n, int *flag);
+int k_bounds_mode(Ctx *c, double *x, double *lb, double *ub, int mode, int64_t offset, int64_t n);
+// entries at their clamp values: out = {#x == lb + eps, #x == ub - eps, #zl == eps, #zu == eps} (global sums)
+int k_clamp_count(Ctx *c, const double *x, const double *lb, const double *ub, const double *zl, const double *zu,
+                  double eps, int64_t n, double out[4]);
 int k_zero_inactive(Ctx *c, const double *lb, const double *ub, double *zl, double *zu,
                     double max_bound, int64_t n);
 

@@ -522,10 +522,25 @@ int InteriorPoint::initAndCheckDesignAndBounds() {  // :4277-4361
   int flag = 0;
   PO_TRY(k_check_bounds(ctx, x->d, lb->d, ub->d, zl->d, zu->d, options.real("max_bound_value"),
                         rel_bound, use_lower && use_upper, n, &flag));
+  check_flag |= flag;
   if (ctx->rank == 0) {
     if (flag & 1) history += "ParOpt Warning: Variable bounds are inconsistent\n";
     if (flag & 2) history += "ParOpt Warning: Variables may be too close to lower bound\n";
     if (flag & 4) history += "ParOpt Warning: Variables may be too close to upper bound\n";
+  }
+  return PO_OK;
+}
+
+int InteriorPoint::clampCounts(double out[8]) {
+  const double eps = options.real("design_precision");
+  PO_TRY(k_clamp_count(ctx, x->d, lb->d, ub->d, use_lower ? zl->d : nullptr, use_upper ? zu->d : nullptr, eps, n,
+                       out));
+  for (int j = 4; j < 8; j++) out[j] = 0.0;
+  for (int i = 0; i < c; i++) {
+    if (vars.s[i] == eps) out[4] += 1.0;
+    if (vars.t[i] == eps) out[5] += 1.0;
+    if (vars.zs[i] == eps) out[6] += 1.0;
+    if (vars.zt[i] == eps) out[7] += 1.0;
   }
   return PO_OK;
 }

@@ -57,6 +57,12 @@ class InteriorPoint {
   InteriorPoint(Problem *prob);
   ~InteriorPoint();
   int allocate();  // device storage (fails with PO_ERR_HIP when HBM is exhausted)
+  // SURVEY 8a' bookkeeping (po_ip_get_debug_ints)
+  const std::vector<int> &gPivots() const { return gpiv; }
+  Vec *lowerBounds() { return lb; }
+  Vec *upperBounds() { return ub; }
+  int checkFlag() const { return check_flag; }
+  int clampCounts(double out[8]);
 
   Options options;
   int optimize(const char *checkpoint);
@@ -222,6 +228,7 @@ class InteriorPoint {
   void userBegin();
   void userEnd();
   void userHarvest();
+  int check_flag = 0;  // OR of the bound-repair bits of every initAndCheckDesignAndBounds call (:4290-4344)
   bool ac_valid = false;
   // A^T z of a problem with linear dense constraints, kept by recurrence (computeResidual / computeStepAndUpdate)
   static const int kAczRefresh = 16;

@@ -1437,6 +1437,51 @@ int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double
   return PO_OK;
 }
 
+// test data for initAndCheckDesignAndBounds (po_problem_set_bounds_mode; oracle/ref_driver.cpp SepProblem), by
+// GLOBAL index gi: bit 1: gi % 7 == 3 -> lb = ub = midpoint; bit 2: gi % 11 == 5 -> x = lb; bit 4: gi % 13 == 6 -> x = ub
+__global__ void __launch_bounds__(kBlock)
+    bounds_mode_kernel(double *__restrict__ x, double *__restrict__ lb, double *__restrict__ ub, int mode,
+                       int64_t offset, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t gi = offset + i;
+    if ((mode & 1) && gi % 7 == 3) lb[i] = ub[i] = 0.5 * (lb[i] + ub[i]);
+    if ((mode & 2) && gi % 11 == 5) x[i] = lb[i];
+    if ((mode & 4) && gi % 13 == 6) x[i] = ub[i];
+  }
+}
+int k_bounds_mode(Ctx *c, double *x, double *lb, double *ub, int mode, int64_t offset, int64_t n) {
+  if (n <= 0 || mode == 0) return PO_OK;
+  PO_LAUNCH(bounds_mode_kernel, grid_for(c, n), x, lb, ub, mode, offset, n);
+  return PO_OK;
+}
+
+// clamp bookkeeping (SURVEY 8a'): entries sitting exactly at the clamp values lb + eps, ub - eps, eps that
+// computeStepVec / computeStepAndUpdate (src/ParOptInteriorPoint.cpp:3150-3190, 4177-4195) leave behind;
+// counts are summed as exact doubles
+__global__ void __launch_bounds__(kBlock)
+    clamp_count_kernel(const double *__restrict__ x, const double *__restrict__ lb, const double *__restrict__ ub,
+                       const double *__restrict__ zl, const double *__restrict__ zu, double eps, int64_t n,
+                       double *__restrict__ partials) {
+  __shared__ double sm[4 * 4];
+  double cnt[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (x[i] == lb[i] + eps) cnt[0] += 1.0;
+    if (x[i] == ub[i] - eps) cnt[1] += 1.0;
+    if (zl && zl[i] == eps) cnt[2] += 1.0;
+    if (zu && zu[i] == eps) cnt[3] += 1.0;
+  }
+  block_reduce_store<4, OP_SUM>(cnt, partials, 0, sm);
+}
+int k_clamp_count(Ctx *c, const double *x, const double *lb, const double *ub, const double *zl, const double *zu,
+                  double eps, int64_t n, double out[4]) {
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 4));
+  PO_LAUNCH(clamp_count_kernel, grid, x, lb, ub, zl, zu, eps, n, c->d_partials);
+  return reduce_finish(c, grid, 4, 0, 0, out);
+}
+
 __global__ void __launch_bounds__(kBlock)
     zero_inactive_kernel(const double *__restrict__ lb, const double *__restrict__ ub,
                          double *__restrict__ zl, double *__restrict__ zu, double maxb, int64_t n) {

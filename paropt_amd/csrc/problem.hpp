@@ -147,6 +147,7 @@ class SeparableProblem : public Problem {
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   GroupMap gmap;
+  int bounds_mode = 0;  // po_problem_set_bounds_mode: deliberately broken bounds (k_bounds_mode)
 
   int kind;
   uint64_t seed;

@@ -428,7 +428,7 @@ int SeparableProblem::getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) {
     PO_TRY(k_fill(ctx, lb->d, n, -2.0));
     PO_TRY(k_fill(ctx, ub->d, n, 1.0));
   }
-  return PO_OK;
+  return k_bounds_mode(ctx, x->d, lb->d, ub->d, bounds_mode, offset, n);
 }
 
 int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {

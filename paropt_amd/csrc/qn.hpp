@@ -57,6 +57,11 @@ class CompactQuasiNewton {
   int storePair(Vec *s, Vec *y, const double *sS, const double *sY, double sTs, double sTy);
   void factorM();
 
+ public:
+  const std::vector<int> &pivots() const { return piv; }  // 0-based LU pivot rows of M (po_qn_get_pivots)
+
+ protected:
+
   int msub_max, msub;
   double b0;
   int diag_type;

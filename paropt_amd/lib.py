@@ -152,6 +152,7 @@ SIGNATURES = {
     "po_csr_symbolic_arrays": (
         C.c_int, [po_csr_symbolic, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp, c_int_pp]),
     "po_csr_symbolic_destroy": (C.c_int, [po_csr_symbolic]),
+    "po_problem_set_bounds_mode": (C.c_int, [po_problem, C.c_int]),
     "po_problem_set_linear_constraints": (C.c_int, [po_problem, C.c_int]),
     "po_problem_set_var_bound_options": (C.c_int, [po_problem, C.c_int, C.c_int]),
     "po_problem_destroy": (C.c_int, [po_problem]),
@@ -237,6 +238,9 @@ SIGNATURES = {
     "po_wgram_with_rhs": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
+    "po_qn_get_pivots": (C.c_int, [po_qn, c_int_pp, c_int_p]),
+    "po_ip_get_debug_ints": (C.c_int, [po_ip, c_int_pp, c_int_p, c_int_p, c_i64_p]),
+    "po_ip_get_bounds": (C.c_int, [po_ip, C.POINTER(po_vec), C.POINTER(po_vec)]),
     "po_bench_kernels": (C.c_int, [po_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "po_bench_stream": (C.c_int, [po_vec, po_vec, C.c_int, C.c_int, c_double_p]),
 }
