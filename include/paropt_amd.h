@@ -63,6 +63,8 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
  * reference counts (src/ParOptVec.h:28-47) are kept, so after the last decref / destroy both return to their
  * values before the objects were made. */
 int po_live_objects(int64_t *vectors, int64_t *bytes);
+/* pinned host mirrors (po_vec_get_array) currently alive in this process */
+int po_live_host_mirrors(int64_t *mirrors);
 /* Live timing of the headline kernel inside a run: after po_ctx_time_mdot(ctx, nvecs) every ParOptVec::mdot
  * launch with exactly `nvecs` vectors on this context is bracketed by HIP events on the context's stream
  * (nvecs = 0 switches it off; every call resets the accumulators); the result call returns the accumulated

@@ -19,6 +19,13 @@ def live_objects():
     return a.value, b.value
 
 
+def live_host_mirrors():
+    """Pinned host mirrors (getArray) alive in this process."""
+    a = C.c_int64()
+    check(lib.po_live_host_mirrors(C.byref(a)))
+    return a.value
+
+
 class Context:
     """One per process / GPU: HIP stream + communicator (replaces the MPI communicator)."""
 
@@ -329,14 +336,31 @@ class Problem:
         if self._csr and len(rowp) != self.nwcon + 1:
             raise ValueError("rowp is incorrect length")  # paropt/ParOpt.pyx:861-862
         cb = L.ProblemCallbacks()
+        self._pending_exc = None
 
+        def _guard(fn):
+            # A Python exception must not look like success to the solver: it is kept (the first one), the
+            # callback reports failure through its non-zero return code, and optimize() re-raises it.
+            def _g(*args):
+                if self._pending_exc is not None:
+                    return 1  # fail fast until optimize() has re-raised the first exception
+                try:
+                    return fn(*args)
+                except BaseException as e:  # noqa: BLE001 - re-raised by _raise_pending()
+                    if self._pending_exc is None:
+                        self._pending_exc = e
+                    return 1
+            return _g
+
+        @_guard
         def _gvb(user, x, lb, ub):
             vx, vl, vu = (PVec(ctx, handle=L.po_vec(h), owned=False) for h in (x, lb, ub))
             ax, al, au = vx.getArray(), vl.getArray(), vu.getArray()
-            self.getVarsAndBounds(ax, al, au)
+            fail = self.getVarsAndBounds(ax, al, au)
             vx.syncToDevice(), vl.syncToDevice(), vu.syncToDevice()
-            return 0
+            return int(fail or 0)
 
+        @_guard
         def _eval(user, x, fobj, cons):
             vx = PVec(ctx, handle=L.po_vec(x), owned=False)
             fail, f, con = self.evalObjCon(vx.to_numpy())
@@ -345,6 +369,7 @@ class Problem:
                 cons[j] = float(con[j])
             return int(fail)
 
+        @_guard
         def _grad(user, x, g, Ac):
             vx = PVec(ctx, handle=L.po_vec(x), owned=False)
             vg = PVec(ctx, handle=L.po_vec(g), owned=False)
@@ -379,6 +404,7 @@ class Problem:
                 zwa = PVec(ctx, handle=L.po_vec(zw), owned=False).to_numpy() if zw else None
                 return vx.to_numpy(), za, zwa
 
+            @_guard
             def _hvec(user, x, z, zw, px, hvec):
                 xa, za, zwa = _views(x, z, zw)
                 vp = PVec(ctx, handle=L.po_vec(px), owned=False)
@@ -388,6 +414,7 @@ class Problem:
                 vh.syncToDevice()
                 return int(fail or 0)
 
+            @_guard
             def _hdiag(user, x, z, zw, hdiag):
                 xa, za, zwa = _views(x, z, zw)
                 vh = PVec(ctx, handle=L.po_vec(hdiag), owned=False)
@@ -406,6 +433,7 @@ class Problem:
                 raise ValueError("cols is incorrect length")
             self._data_host = np.zeros(max(nnz, 1))
 
+            @_guard
             def _sobjcon(user, x, fobj, cons, sparse):
                 vx = PVec(ctx, handle=L.po_vec(x), owned=False)
                 vs = PVec(ctx, handle=L.po_vec(sparse), owned=False)
@@ -417,6 +445,7 @@ class Problem:
                     cons[j] = float(con[j])
                 return int(fail or 0)
 
+            @_guard
             def _sgrad(user, x, g, Ac, data, nnz_):
                 vx = PVec(ctx, handle=L.po_vec(x), owned=False)
                 vg = PVec(ctx, handle=L.po_vec(g), owned=False)
@@ -436,24 +465,26 @@ class Problem:
                 self._cols.ctypes.data_as(L.c_int_p), self._csr_cbs[0], self._csr_cbs[1]))
         elif self.nwcon > 0:
             def _wrap(method):
+                @_guard
                 def _f(user, alpha, x, v, out):
                     vx = PVec(ctx, handle=L.po_vec(x), owned=False)
                     vv = PVec(ctx, handle=L.po_vec(v), owned=False)
                     vo = PVec(ctx, handle=L.po_vec(out), owned=False)
                     ao = vo.getArray()
                     vo.syncToHost()
-                    method(float(alpha), vx.to_numpy(), vv.to_numpy(), ao)
+                    fail = method(float(alpha), vx.to_numpy(), vv.to_numpy(), ao)
                     vo.syncToDevice()
-                    return 0
+                    return int(fail or 0)
                 return _f
 
+            @_guard
             def _wcon(user, x, out):
                 vx = PVec(ctx, handle=L.po_vec(x), owned=False)
                 vo = PVec(ctx, handle=L.po_vec(out), owned=False)
                 ao = vo.getArray()
-                self.evalSparseCon(vx.to_numpy(), ao)
+                fail = self.evalSparseCon(vx.to_numpy(), ao)
                 vo.syncToDevice()
-                return 0
+                return int(fail or 0)
 
             scb = L.ProblemSparseCallbacks()
             self._scbs = (L.SPARSE_CON_FN(_wcon), L.SPARSE_JAC_FN(_wrap(self.addSparseJacobian)),
@@ -465,6 +496,20 @@ class Problem:
             check(lib.po_problem_set_sparse_callbacks(self._h, self.nwcon, int(nwinequality), C.byref(scb)))
             if int(nwblock) > 1:  # addSparseInnerProduct then fills packed upper nwblock x nwblock blocks
                 check(lib.po_problem_set_sparse_block_size(self._h, int(nwblock)))
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib.po_problem_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _raise_pending(self):
+        """Re-raise the first exception a callback threw during the last solver call."""
+        e, self._pending_exc = self._pending_exc, None
+        if e is not None:
+            raise e
 
     def setLinearConstraints(self, flag=True):
         """Declare the dense constraints linear: after the first gradient evaluation of an optimize() call
@@ -641,6 +686,8 @@ class InteriorPoint:
 
     def optimize(self, checkpoint=None):
         rc = lib.po_ip_optimize(self._h, checkpoint.encode() if checkpoint else None)
+        if hasattr(self.problem, "_raise_pending"):
+            self.problem._raise_pending()  # an exception thrown inside a problem callback
         if rc not in (0,):
             raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
         return rc
@@ -884,6 +931,8 @@ class TrustRegion:
 
     def optimize(self):
         rc = lib.po_tr_optimize(self._h)
+        if hasattr(self.problem, "_raise_pending"):
+            self.problem._raise_pending()
         if rc != 0:
             raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
         return rc
@@ -986,6 +1035,8 @@ class MMA:
 
     def optimize(self):
         rc = lib.po_mma_optimize(self._h)
+        if hasattr(self.problem, "_raise_pending"):
+            self.problem._raise_pending()
         if rc != 0:
             raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
         return rc

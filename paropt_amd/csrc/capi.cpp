@@ -72,6 +72,10 @@ int po_live_objects(int64_t *vectors, int64_t *bytes) {
   if (bytes) *bytes = b;
   return PO_OK;
 }
+int po_live_host_mirrors(int64_t *mirrors) {
+  if (mirrors) *mirrors = po::live_mirrors();
+  return PO_OK;
+}
 int po_ctx_time_mdot(po_ctx ctx, int nvecs) {
   PO_CHECK_PTR(ctx);
   ctx->time_mdot_nv = nvecs > 0 ? nvecs : 0;
@@ -238,6 +242,7 @@ int po_vec_get_array(po_vec v, double **host) {
   PO_CHECK_PTR(host);
   if (!v->h) {
     PO_HIP(hipHostMalloc((void **)&v->h, sizeof(double) * (size_t)(v->n > 0 ? v->n : 1), hipHostMallocDefault));
+    po::mirror_created();
     PO_TRY(po_vec_sync_to_host(v));
   }
   *host = v->h;
@@ -417,8 +422,20 @@ int po_problem_set_sparse_callbacks(po_problem p, int64_t nwcon, int64_t nwinequ
   }
   q->sparse.cb = *cb;
   q->sparse.set = true;
+  const bool resized = q->nwcon != nwcon;
   q->nwcon = nwcon;
   q->nwinequality = nwinequality;
+  // packed-block buffers sized for the previous constraint count are stale: rebuild them for the new one
+  if (resized && q->nwblock > 1) {
+    const int nb = q->nwblock;
+    if (nwcon % nb != 0) {
+      q->setSparseBlockSize(1);
+      po::set_error("the new sparse constraint count %lld is not a multiple of the block size %d: block size reset "
+                    "to 1", (long long)nwcon, nb);
+      return PO_ERR_ARG;
+    }
+    return q->setSparseBlockSize(nb);
+  }
   return PO_OK;
 }
 int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwinequality, const int *rowp,

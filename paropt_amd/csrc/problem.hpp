@@ -64,7 +64,9 @@ class Problem {
   // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
   virtual const char *sparseFactorInfo();
   // number of factorizations so far that met a non-positive pivot (CSR form; 0 otherwise)
-  virtual long sparseFactorBreakdowns() { return csr ? csr->breakdowns : 0; }
+  virtual long sparseFactorBreakdowns() { return csr ? csr->breakdowns : blk_breakdowns; }
+  long blk_breakdowns = 0;   // block form with nwblock > 1: factorizations that replaced a non-positive pivot
+  int64_t blk_nwcon = 0;     // nwcon the packed-block buffers were sized for
   // fixed CSR pattern of the sparse Jacobian (ParOptSparseProblem::setSparseJacobianData, .cpp:632-677);
   // owned.  Sets nwcon / nwinequality.
   int setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols);

@@ -49,17 +49,25 @@ int Problem::setSparseBlockSize(int nwblock_) {
               "not be in the CSR form", nwblock_, (long long)nwcon);
     return PO_ERR_ARG;
   }
+  // allocate first, commit on success: a failure leaves the problem in its previous (consistent) state
+  Vec *nblk = nullptr, *nones = nullptr;
+  if (nwblock_ > 1) {
+    nblk = vec_new(ctx, nwcon * (nwblock_ + 1) / 2);
+    nones = vec_new(ctx, nwcon);
+    int rc = (nblk && nones) ? k_fill(ctx, nones->d, nwcon, 1.0) : PO_ERR_HIP;
+    if (rc == PO_OK && !blk_flag && hipMalloc((void **)&blk_flag, 4 * sizeof(int)) != hipSuccess) rc = PO_ERR_HIP;
+    if (rc != PO_OK) {
+      vec_decref(nblk);
+      vec_decref(nones);
+      return rc;
+    }
+  }
   vec_decref(blk);
   vec_decref(wones);
-  blk = wones = nullptr;
+  blk = nblk;
+  wones = nones;
   nwblock = nwblock_;
-  if (nwblock > 1) {
-    blk = vec_new(ctx, nwcon * (nwblock + 1) / 2);
-    wones = vec_new(ctx, nwcon);
-    if (!blk || !wones) return PO_ERR_HIP;
-    PO_TRY(k_fill(ctx, wones->d, nwcon, 1.0));
-    if (!blk_flag) PO_HIP(hipMalloc((void **)&blk_flag, 4 * sizeof(int)));
-  }
+  blk_nwcon = nwcon;
   return PO_OK;
 }
 // ParOptSparseProblem::evalSparseCon copies the values the last evaluation stored (.cpp:750-760)
@@ -85,14 +93,19 @@ int Problem::sparseFactor(Vec *x, Vec *d, Vec *cw) {
     const int64_t nb = nwcon / nwblock;
     PO_TRY(k_blk_init(ctx, cw->d, nb, nwblock, blk->d));
     if (addSparseInnerProduct(1.0, x, d, blk) != 0) return PO_ERR_USER;
-    PO_HIP(hipMemsetAsync(blk_flag, 0, 4 * sizeof(int), ctx->stream));
+    const int flag0[4] = {0, 0x7fffffff, 0, 0};
+    PO_HIP(hipMemcpyAsync(blk_flag, flag0, sizeof(flag0), hipMemcpyHostToDevice, ctx->stream));
     PO_TRY(k_blk_factor(ctx, blk->d, nb, nwblock, blk_flag));
     int flag[4] = {0, 0, 0, 0};
     PO_HIP(hipMemcpyAsync(flag, blk_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
     PO_HIP(hipStreamSynchronize(ctx->stream));
-    if (flag[0] != 0 && ctx->rank == 0) {  // the reference returns dpptrf's info, which its caller ignores (:1930)
-      fprintf(stderr, "ParOpt warning: block %d of the sparse constraint matrix is not positive definite\n",
-              flag[1] / nwblock);
+    if (flag[0] != 0) {  // the reference returns dpptrf's info, which its caller ignores (:1930)
+      if (blk_breakdowns == 0 && ctx->rank == 0) {  // warn once, like the CSR form
+        fprintf(stderr,
+                "ParOpt warning: the sparse constraint matrix is not positive definite (first failing row %d, block "
+                "%d; %d pivots replaced)\n", flag[1], flag[1] / nwblock, flag[0]);
+      }
+      blk_breakdowns++;
     }
     return PO_OK;
   }
@@ -129,8 +142,21 @@ int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
   for (int j = 0; j < nv; j++) {
     PO_TRY(k_mul(ctx, work->d, 1.0, d->d, P[j], nlocal));
     PO_TRY(k_fill(ctx, U[j], nwcon, 0.0));
-    Vec u{ctx, nwcon, U[j], 1, nullptr};
-    if (addSparseJacobian(1.0, x, work, &u) != 0) return PO_ERR_USER;
+    // a real po_vec handle that borrows the panel column: host-side callbacks may ask it for a pinned mirror
+    // (po_vec_get_array), which is released here -- the handle never reaches vec_decref
+    po_vec_s u;
+    u.ctx = ctx;
+    u.n = nwcon;
+    u.d = U[j];
+    u.ref = 1;
+    u.h = nullptr;
+    const int fail = addSparseJacobian(1.0, x, work, &u);
+    if (u.h) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipHostFree(u.h);
+      mirror_freed();
+    }
+    if (fail != 0) return PO_ERR_USER;
   }
   return PO_OK;
 }
@@ -177,16 +203,19 @@ int CallbackProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
 }
 int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   std::vector<po_vec> h(ncon > 0 ? ncon : 1);
+  // Ac == nullptr with ncon > 0: objective gradient only (linear_constraints); with ncon == 0 the callback still
+  // receives a valid (empty) array
+  const bool only_g = (Ac == nullptr && ncon > 0);
   for (int j = 0; j < ncon; j++) h[j] = Ac ? static_cast<po_vec>(Ac[j]) : nullptr;
   if (csr) {  // ParOptSparseProblem::evalObjConGradient (.cpp:739-742)
     if (!csr_gradient) return 1;
-    int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), Ac ? h.data() : nullptr,
+    int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), only_g ? nullptr : h.data(),
                           csr->data, csr->nnz);
     if (rc != 0) return rc;
     return csr->valuesChanged() != PO_OK;
   }
   return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g),
-                                  Ac ? h.data() : nullptr);
+                                  only_g ? nullptr : h.data());
 }
 int CallbackProblem::computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) {
   if (!cb.qn_update_correction) return 0;

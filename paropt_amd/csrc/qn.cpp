@@ -20,6 +20,10 @@ static size_t padded_elems(int64_t n) { return (size_t)(((n + 1) >> 1) << 1) + 2
 // live-object accounting (po_live_objects): every device vector alive and the bytes behind them
 static std::atomic<long> g_live_vecs(0);
 static std::atomic<long long> g_live_bytes(0);
+static std::atomic<long> g_live_mirrors(0);  // pinned host mirrors behind po_vec_get_array
+void mirror_created() { g_live_mirrors++; }
+void mirror_freed() { g_live_mirrors--; }
+long live_mirrors() { return g_live_mirrors.load(); }
 void live_objects(long *vecs, long long *bytes) {
   if (vecs) *vecs = g_live_vecs.load();
   if (bytes) *bytes = g_live_bytes.load();
@@ -51,7 +55,10 @@ void vec_decref(Vec *v) {
   if (--v->ref == 0) {
     (void)hipStreamSynchronize(v->ctx->stream);
     if (v->d) (void)hipFree(v->d);
-    if (v->h) (void)hipHostFree(v->h);
+    if (v->h) {
+      (void)hipHostFree(v->h);
+      mirror_freed();
+    }
     g_live_vecs--;
     g_live_bytes -= (long long)(sizeof(double) * padded_elems(v->n));
     delete static_cast<po_vec_s *>(v);

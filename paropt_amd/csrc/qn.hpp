@@ -13,6 +13,9 @@ namespace po {
 Vec *vec_new(Ctx *c, int64_t n);
 void vec_decref(Vec *v);
 void live_objects(long *vecs, long long *bytes);
+void mirror_created();
+void mirror_freed();
+long live_mirrors();
 
 class CompactQuasiNewton {
  public:

@@ -286,8 +286,11 @@ __global__ void __launch_bounds__(kBlock) blk_factor_kernel(double *__restrict__
       double d = a[j + cj];
       for (int k = 0; k < j; k++) d -= a[k + cj] * a[k + cj];
       if (!(d > 0.0)) {
-        flag[0] = 1;
-        flag[1] = (int)(b * B + j);
+        // flag[0]: number of non-positive pivots of this factorization; flag[1]: the FIRST failing row (flag[1]
+        // starts at INT_MAX); the pivot is replaced by 1 so that the solves stay finite -- dpptrf stops here and
+        // the reference ignores its info (src/ParOptSparseMat.cpp:104-112, ParOptInteriorPoint.cpp:1930)
+        atomicAdd(&flag[0], 1);
+        atomicMin(&flag[1], (int)(b * B + j));
         d = 1.0;
       }
       a[j + cj] = sqrt(d);

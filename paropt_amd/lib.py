@@ -84,6 +84,7 @@ SIGNATURES = {
     "po_ctx_memcpy": (C.c_int, [po_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "po_ctx_counters": (C.c_int, [po_ctx, c_i64_p, c_i64_p]),
     "po_live_objects": (C.c_int, [c_i64_p, c_i64_p]),
+    "po_live_host_mirrors": (C.c_int, [c_i64_p]),
     "po_ctx_time_mdot": (C.c_int, [po_ctx, C.c_int]),
     "po_ctx_time_mdot_result": (C.c_int, [po_ctx, c_double_p, c_i64_p]),
     "po_ctx_time_wgram": (C.c_int, [po_ctx, C.c_int]),

@@ -299,6 +299,37 @@ def test_python_callback_problem(ctx):
     np.testing.assert_array_equal(np.array(ip1.getIterationCounters()), g["final/counters"])
 
 
+def test_python_callback_exception_is_not_swallowed(ctx):
+    """An exception thrown inside a problem callback stops the solve (non-zero callback return) and is re-raised
+    by optimize() -- it must not be reported as a successful evaluation."""
+    import paropt_amd as pa
+
+    n = 50
+    calls = {"n": 0}
+
+    class P(pa.Problem):
+        def getVarsAndBounds(self, x, lb, ub):
+            x[:] = 0.5
+            lb[:] = 0.0
+            ub[:] = 1.0
+
+        def evalObjCon(self, x):
+            calls["n"] += 1
+            if calls["n"] == 3:
+                raise ZeroDivisionError("user bug")
+            return 0, float(np.dot(x - 0.3, x - 0.3)), np.array([x.sum() - 5.0])
+
+        def evalObjConGradient(self, x, g, A):
+            g[:] = 2.0 * (x - 0.3)
+            A[0][:] = 1.0
+            return 0
+
+    ip = pa.InteriorPoint(P(ctx, n, 1), {"max_major_iters": 20, "write_output_frequency": 0})
+    with pytest.raises(ZeroDivisionError):
+        ip.optimize()
+    assert calls["n"] == 3  # no user code ran after the exception
+
+
 def test_python_callback_sparse_constraints(ctx):
     """Sparse (weighting) constraints through the callback boundary: the reference's own example
     (examples/rosenbrock/rosenbrock.cpp: nwcon=5, nw=5, start 1, skip 1) implemented in Python on

@@ -79,7 +79,46 @@ def _scenarios(ctx):
         m.optimize()
         m.getAsymptotes()
 
-    return [vectors, quasi_newton, interior_point, sparse_forms, callbacks, trust_region, mma]
+    def sparse_callbacks():
+        # host-side sparse callbacks (block form, nwblock 1 and 2): the panel columns handed to addSparseJacobian
+        # borrow solver memory and get a pinned mirror each time -- none may outlive the call
+        for nwblock in (1, 2):
+            class W(pa.Problem):
+                def __init__(self):
+                    super().__init__(ctx, 40, 1, 1, nwcon=8, nwinequality=8, nwblock=nwblock)
+
+                def getVarsAndBounds(self, x, lb, ub):
+                    x[:], lb[:], ub[:] = 0.1, 0.0, 1.0
+
+                def evalObjCon(self, x):
+                    return 0, float(np.sum((x - 0.4) ** 2)), np.array([np.sum(x) - 2.0])
+
+                def evalObjConGradient(self, x, g, A):
+                    g[:] = 2.0 * (x - 0.4)
+                    A[0][:] = 1.0
+                    return 0
+
+                def evalSparseCon(self, x, out):
+                    out[:] = 1.0 - x.reshape(8, 5).sum(axis=1)
+
+                def addSparseJacobian(self, alpha, x, px, out):
+                    out[:] -= alpha * px.reshape(8, 5).sum(axis=1)
+
+                def addSparseJacobianTranspose(self, alpha, x, pzw, out):
+                    out[:] -= alpha * np.repeat(pzw, 5)
+
+                def addSparseInnerProduct(self, alpha, x, cvec, A):
+                    d = cvec.reshape(8, 5).sum(axis=1)
+                    if nwblock == 1:
+                        A[:] += alpha * d
+                    else:  # packed upper 2 x 2 blocks: constraints 2b and 2b+1 do not share variables
+                        A[0::3] += alpha * d[0::2]
+                        A[2::3] += alpha * d[1::2]
+
+            ip = pa.InteriorPoint(W(), {"max_major_iters": 6, "qn_subspace_size": 3})
+            ip.optimize()
+
+    return [vectors, quasi_newton, interior_point, sparse_forms, callbacks, sparse_callbacks, trust_region, mma]
 
 
 def test_every_object_gives_its_memory_back():
@@ -88,11 +127,13 @@ def test_every_object_gives_its_memory_back():
     ctx = pa.Context(0)
     gc.collect()
     base = pa.live_objects()
+    base_mirrors = pa.live_host_mirrors()
     for scenario in _scenarios(ctx):
         scenario()
         gc.collect()
         ctx.synchronize()
         assert pa.live_objects() == base, (scenario.__name__, pa.live_objects(), base)
+        assert pa.live_host_mirrors() == base_mirrors, (scenario.__name__, pa.live_host_mirrors(), base_mirrors)
     # and while objects are alive the counters do move
     v = pa.PVec(ctx, 1000)
     assert pa.live_objects()[0] == base[0] + 1 and pa.live_objects()[1] > base[1]
