@@ -92,6 +92,76 @@ def test_ip_invariants_fullsize(ctx, problem, n, c, qn, m, iters):
         np.testing.assert_array_equal(a["z"], b["z"])
 
 
+def test_config4_fullsize_weighting(ctx):
+    """BASELINE config 4 at full size on one GPU: n = 20 M, 4 dense + 1 M weighting constraints (groups of 20),
+    L-BFGS(10): invariants of the sparse blocks, feasibility of the weighting constraints along the run and
+    bitwise run-to-run determinism."""
+    import paropt_amd as pa
+
+    n, nwcon, nw, iters = 20_000_000, 1_000_000, 20, 12
+    opts = {"qn_type": "bfgs", "qn_subspace_size": 10, "abs_res_tol": 1e-30, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": iters, "write_output_frequency": 0}
+
+    def run():
+        prob = pa.SeparableProblem(ctx, "convex", n, 4)
+        prob.setWeighting(nwcon, nw, 0, 0)
+        ip = pa.InteriorPoint(prob, opts)
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        ip.optimize()
+        return ip, sn
+
+    ip, sn = run()
+    assert ip.getIterationCounters()[0] == iters
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    assert x.min() > 0.0 and x.max() < 1.0
+    zw, sw, tw, zsw, ztw = (v.to_numpy() for v in ip.getOptimizedSparse())
+    assert min(sw.min(), tw.min(), zsw.min(), ztw.min()) > 0.0
+    assert zw.shape == (nwcon,)
+    # infeasibility (the |infes| column: dense and weighting constraints in slack form) does not grow over the run
+    rows = [ln.split() for ln in ip.getHistory().splitlines() if ln[:5].strip().isdigit()]
+    assert len(rows) == iters and float(rows[-1][9]) <= float(rows[0][9])
+    for a, b in zip(sn, sn[1:]):
+        assert b["counters"][0] == a["counters"][0] + 1
+        assert np.all(np.isfinite(b["norms"])) and np.all(np.isfinite(b["wnorms"])) and np.isfinite(b["fobj"])
+    ip2, sn2 = run()
+    for a, b in zip(sn, sn2):
+        assert a["fobj"] == b["fobj"] and a["mu"] == b["mu"]
+        np.testing.assert_array_equal(a["wnorms"], b["wnorms"])
+
+
+def test_config5_fullsize_trust_region_eigen(ctx):
+    """BASELINE config 5 at full size: the trust-region driver over the compact-eigenvalue subproblem at
+    n = 5 M (4 constraints, N = 10 curvature directions, L-BFGS(10)): radius within its limits, finite table,
+    monotone acceptance bookkeeping, and bitwise determinism of the whole run."""
+    import paropt_amd as pa
+
+    n = 5_000_000
+
+    def run():
+        tr = pa.TrustRegion(pa.SeparableProblem(ctx, "quadratic", n, 4),
+                            {"tr_max_iterations": 5, "qn_subspace_size": 10, "max_major_iters": 200,
+                             "tr_output_file": "", "output_file": ""})
+        tr.setEigenModelSynthetic(10, 0, 0, 2.0)
+        sn = []
+        tr.setIterationCallback(lambda k: sn.append(tr.snapshot()))
+        tr.optimize()
+        return tr, sn
+
+    tr, sn = run()
+    assert len(sn) >= 5
+    for k, s in enumerate(sn):
+        assert 1e-3 <= s["tr_size"] <= 1.0 + 1e-12       # tr_min_size <= radius <= tr_max_size
+        assert np.isfinite(s["fk"]) and np.all(np.isfinite(s["ck"])) and np.all(np.isfinite(s["norms"]))
+        assert k == 0 or s["iters"][1] > 0                # every iteration solved a subproblem
+    x = tr.getOptimizedPoint()[0].to_numpy()
+    assert x.min() >= -5.0 and x.max() <= 5.0
+    tr2, sn2 = run()
+    for a, b in zip(sn, sn2):
+        assert a["fk"] == b["fk"] and a["tr_size"] == b["tr_size"]
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+
+
 def test_ip_vs_oracle_n1M(ctx):
     """Oracle parity at the largest size the numpy oracle finishes in about a minute."""
     import paropt_amd as pa

@@ -312,6 +312,10 @@ def test_rccl_plumbing_single_rank(monkeypatch):
         outs[-1] += (ip.getObjective()[0],)
     for a, b in zip(*outs):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    # pure-sum payloads (dot, mdot, Gram) went through ncclAllReduce, mixed SUM/MIN/MAX ones through ncclAllGather
+    kind, nred, ngat = ctx.comm_info()
+    assert kind == 1 and nred > 10 and ngat > 10
+    assert ref.comm_info() == (0, 0, 0)
 
 
 def _worker_ckpt(rank, world, port, q, args, opts, path):
