@@ -132,7 +132,6 @@ int main(int argc, char *argv[]) {
     ParOptScalar *zt;
     optimizer->getOptimizedPoint(&xt, &zt, NULL, NULL, NULL);
     ParOptScalar ft, ct[2];
-    xt->syncToHost();
     rosen->evalObjCon(xt, &ft, ct);
     int ntr = 0;
     for (const char *h = optimizer->getTrustRegionHistory(); *h; h++) ntr += (*h == '\n');
@@ -153,7 +152,6 @@ int main(int argc, char *argv[]) {
   ParOptScalar *z;
   opt->getOptimizedPoint(&x, &z, &zw, NULL, NULL);
   ParOptScalar fobj, cons[2];
-  x->syncToHost();
   rosen->evalObjCon(x, &fobj, cons);
   printf("{\"rc\": %d, \"niter\": %d, \"neval\": %d, \"ngeval\": %d, \"fobj\": %.15e, \"xnorm\": %.15e, "
          "\"z0\": %.15e, \"z1\": %.15e, \"zwnorm\": %.15e}\n", rc, niter, neval, ngeval, fobj, x->norm(),

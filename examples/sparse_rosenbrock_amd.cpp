@@ -106,8 +106,7 @@ int main(int argc, char *argv[]) {
   ParOptScalar *z;
   opt->getOptimizedPoint(&x, &z, &zw, NULL, NULL);
   ParOptScalar fobj, cons[2];
-  x->syncToHost();
-  ParOptVec *cw = new ParOptVec(ctx, nvars - 1);
+  ParOptVec *cw = new ParOptBasicVec(ctx, nvars - 1);
   cw->incref();
   rosen->evalSparseObjCon(x, &fobj, cons, cw);
   const char *info = rosen->getFactorInfo();

@@ -14,11 +14,12 @@
 //   * user callbacks return int fail (0 = ok); optimize() returns 0, 1 (mis-configuration) or the
 //     initial evaluation's fail code; options are set by name with typed setOption overloads that
 //     return non-zero for unknown names / wrong types (src/ParOptOptions.cpp:310-386).
-// Only dense constraints (nwcon = 0) are supported this round.
 #ifndef PAROPT_AMD_HPP
 #define PAROPT_AMD_HPP
 
+#include <math.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <map>
 #include <string>
@@ -29,6 +30,56 @@ extern "C" {
 }
 
 typedef double ParOptScalar;
+#define ParOptRealPart(x) (x)
+
+// ---- the communicator -----------------------------------------------------------------------------
+// PAROPT_AMD_USE_MPI (set by the headers under include/paropt_compat/, which carry the reference's file names):
+// the classes take the reference's MPI_Comm, one po_ctx per communicator is created on first use (device = rank
+// within the node, modulo the visible devices) and reductions across ranks go through MPI_Allgather on the host
+// (po_ctx_comm_init_callback) -- a maintainer's MPI program recompiles unchanged.  Without it the "communicator" is
+// the po_ctx itself.
+#ifdef PAROPT_AMD_USE_MPI
+#include <mpi.h>
+typedef MPI_Comm ParOptComm;
+#define PAROPT_MPI_TYPE MPI_DOUBLE
+struct ParOptAMDCommEntry {
+  MPI_Comm comm;
+  po_ctx ctx;
+};
+inline int paropt_amd_allgather(const double *in, double *out, int count, void *user) {
+  MPI_Comm comm = static_cast<ParOptAMDCommEntry *>(user)->comm;
+  return MPI_Allgather(in, count, MPI_DOUBLE, out, count, MPI_DOUBLE, comm) == MPI_SUCCESS ? 0 : 1;
+}
+inline po_ctx paropt_amd_context(MPI_Comm comm) {
+  static std::vector<ParOptAMDCommEntry *> reg;  // lives as long as the process
+  for (ParOptAMDCommEntry *e : reg) {
+    int cmp = MPI_UNEQUAL;
+    MPI_Comm_compare(e->comm, comm, &cmp);
+    if (cmp == MPI_IDENT || cmp == MPI_CONGRUENT) return e->ctx;
+  }
+  int rank = 0, size = 1, local = 0, ndev = 0;
+  MPI_Comm_rank(comm, &rank);
+  MPI_Comm_size(comm, &size);
+  MPI_Comm node;
+  if (MPI_Comm_split_type(comm, MPI_COMM_TYPE_SHARED, rank, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
+    MPI_Comm_rank(node, &local);
+    MPI_Comm_free(&node);
+  }
+  po_device_count(&ndev);
+  ParOptAMDCommEntry *e = new ParOptAMDCommEntry();
+  e->comm = comm;
+  e->ctx = NULL;
+  if (po_ctx_create(ndev > 0 ? local % ndev : 0, &e->ctx) != 0 ||
+      (size > 1 && po_ctx_comm_init_callback(e->ctx, rank, size, &paropt_amd_allgather, e) != 0)) {
+    fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  reg.push_back(e);
+  return e->ctx;
+}
+#else
+typedef po_ctx ParOptComm;
+inline po_ctx paropt_amd_context(po_ctx ctx) { return ctx; }
+#endif
 
 class ParOptBase {
  public:
@@ -44,100 +95,398 @@ class ParOptBase {
   int ref_count;
 };
 
-// ---- ParOptVec -----------------------------------------------------------------------------------
+// ---- ParOptVec: the 11 pure virtuals of src/ParOptVec.h:53-70 ---------------------------------------
 class ParOptVec : public ParOptBase {
  public:
-  // a new zero-filled vector of n local components (ParOptBasicVec ctor)
-  ParOptVec(po_ctx ctx, int n) : owner(true), h(NULL) { po_vec_create(ctx, n, &h); }
+  virtual ~ParOptVec() {}
+  virtual void set(ParOptScalar alpha) = 0;
+  virtual void zeroEntries() = 0;
+  virtual void copyValues(ParOptVec *vec) = 0;
+  virtual double norm() = 0;
+  virtual double maxabs() = 0;
+  virtual double l1norm() = 0;
+  virtual ParOptScalar dot(ParOptVec *vec) = 0;
+  virtual void mdot(ParOptVec **vecs, int nvecs, ParOptScalar *output) = 0;
+  virtual void scale(ParOptScalar alpha) = 0;
+  virtual void axpy(ParOptScalar alpha, ParOptVec *x) = 0;
+  virtual int getArray(ParOptScalar **array) = 0;
+  // facade additions (no-ops for vectors that do not live in HBM): the device handle, and explicit control of
+  // the pinned host mirror behind getArray (not needed for correctness: the mirror is kept coherent, see
+  // po_vec_get_array)
+  virtual po_vec handle() { return NULL; }
+  virtual void syncToDevice() {}
+  virtual void syncToHost() {}
+  virtual void releaseArray(int) {}
+};
+
+// ParOptBasicVec (src/ParOptVec.h:75-96): the design vector in HBM
+class ParOptBasicVec : public ParOptVec {
+ public:
+  // a new zero-filled vector of n local components
+  ParOptBasicVec(ParOptComm comm, int n) : owner(true), h(NULL) { po_vec_create(paropt_amd_context(comm), n, &h); }
   // adapter over a vector owned by the library (callback arguments, solver state)
-  explicit ParOptVec(po_vec borrowed) : owner(false), h(borrowed) {}
-  ~ParOptVec() {
+  explicit ParOptBasicVec(po_vec borrowed) : owner(false), h(borrowed) {}
+  ~ParOptBasicVec() {
     if (owner && h) po_vec_decref(h);
   }
   void set(ParOptScalar alpha) { po_vec_set(h, alpha); }
   void zeroEntries() { po_vec_zero(h); }
-  void copyValues(ParOptVec *vec) { po_vec_copy(h, vec->h); }
+  void copyValues(ParOptVec *vec) { po_vec_copy(h, vec->handle()); }
   double norm() { double v = 0; po_vec_norm(h, &v); return v; }
   double maxabs() { double v = 0; po_vec_maxabs(h, &v); return v; }
   double l1norm() { double v = 0; po_vec_l1norm(h, &v); return v; }
-  ParOptScalar dot(ParOptVec *vec) { double v = 0; po_vec_dot(h, vec->h, &v); return v; }
+  ParOptScalar dot(ParOptVec *vec) { double v = 0; po_vec_dot(h, vec->handle(), &v); return v; }
   void mdot(ParOptVec **vecs, int nvecs, ParOptScalar *output) {
     std::vector<po_vec> hs(nvecs > 0 ? nvecs : 1);
-    for (int i = 0; i < nvecs; i++) hs[i] = vecs[i]->h;
+    for (int i = 0; i < nvecs; i++) hs[i] = vecs[i]->handle();
     po_vec_mdot(h, hs.data(), nvecs, output);
   }
   void scale(ParOptScalar alpha) { po_vec_scale(h, alpha); }
-  void axpy(ParOptScalar alpha, ParOptVec *x) { po_vec_axpy(h, alpha, x->h); }
+  void axpy(ParOptScalar alpha, ParOptVec *x) { po_vec_axpy(h, alpha, x->handle()); }
+  // the reference's contract (src/ParOptVec.cpp:212-217): the pointer is the vector's data -- writes are seen by
+  // the operations above without any call in between, results of those operations show up behind the pointer
   int getArray(ParOptScalar **array) {
     int64_t n = 0;
     po_vec_size(h, &n);
     if (array) po_vec_get_array(h, array);
     return (int)n;
   }
-  // explicit mirror control for code that writes through getArray outside of a problem callback
+  po_vec handle() { return h; }
   void syncToDevice() { po_vec_sync_to_device(h); }
   void syncToHost() { po_vec_sync_to_host(h); }
-  po_vec handle() { return h; }
+  void releaseArray(int upload) { po_vec_release_array(h, upload); }
 
  private:
   bool owner;
   po_vec h;
 };
 
-// ---- ParOptOptions --------------------------------------------------------------------------------
+// ---- ParOptOptions (src/ParOptOptions.h:9-61, .cpp:80-470): typed registry with immediate validation ---------
 class ParOptOptions : public ParOptBase {
  public:
-  int setOption(const char *name, const char *value) { s[name] = value ? value : ""; return 0; }
-  int setOption(const char *name, int value) { i[name] = value; return 0; }
-  int setOption(const char *name, double value) { f[name] = value; return 0; }
-  // forwarded (and validated) when the solver is created
-  int apply(po_ip ip) {
-    int bad = 0;
-    for (auto &kv : s) bad |= po_ip_set_option_str(ip, kv.first.c_str(), kv.second.c_str());
-    for (auto &kv : i) bad |= po_ip_set_option_int(ip, kv.first.c_str(), kv.second);
-    for (auto &kv : f) bad |= po_ip_set_option_float(ip, kv.first.c_str(), kv.second);
-    return bad;
+  static const int PAROPT_STRING_OPTION = 1;
+  static const int PAROPT_BOOLEAN_OPTION = 2;
+  static const int PAROPT_INT_OPTION = 3;
+  static const int PAROPT_FLOAT_OPTION = 4;
+  static const int PAROPT_ENUM_OPTION = 5;
+
+#ifdef PAROPT_AMD_USE_MPI
+  ParOptOptions(MPI_Comm _comm = MPI_COMM_WORLD) : comm(_comm), iter_pos(0) {}
+#else
+  ParOptOptions() : iter_pos(0) {}
+#endif
+  // the add* calls return 1 when the name is taken (the entry is then left alone), else 0
+  int addStringOption(const char *name, const char *value, const char *descript) {
+    Entry x;
+    x.type = PAROPT_STRING_OPTION;
+    x.has_str = value != NULL;
+    x.s = x.s_default = value ? value : "";
+    return add(name, x, descript);
   }
-  // the same, into a trust-region driver (one registry for both option sets); `algorithm` is
-  // ParOptOptimizer's own switch and is not forwarded
-  int apply(po_tr tr) {
-    int bad = 0;
-    for (auto &kv : s)
-      if (kv.first != "algorithm") bad |= po_tr_set_option_str(tr, kv.first.c_str(), kv.second.c_str());
-    for (auto &kv : i) bad |= po_tr_set_option_int(tr, kv.first.c_str(), kv.second);
-    for (auto &kv : f) bad |= po_tr_set_option_float(tr, kv.first.c_str(), kv.second);
-    return bad;
+  int addBoolOption(const char *name, int value, const char *descript) {
+    Entry x;
+    x.type = PAROPT_BOOLEAN_OPTION;
+    x.i = x.i_default = value ? 1 : 0;
+    x.ilo = 0;
+    x.ihi = 1;
+    return add(name, x, descript);
   }
-  int apply(po_mma mma) {
-    int bad = 0;
-    for (auto &kv : s)
-      if (kv.first != "algorithm") bad |= po_mma_set_option_str(mma, kv.first.c_str(), kv.second.c_str());
-    for (auto &kv : i) bad |= po_mma_set_option_int(mma, kv.first.c_str(), kv.second);
-    for (auto &kv : f) bad |= po_mma_set_option_float(mma, kv.first.c_str(), kv.second);
-    return bad;
+  int addIntOption(const char *name, int value, int low, int high, const char *descript) {
+    Entry x;
+    x.type = PAROPT_INT_OPTION;
+    x.i = x.i_default = value;
+    x.ilo = low;
+    x.ihi = high;
+    return add(name, x, descript);
   }
-  const char *getStringOption(const char *name, const char *def) {
-    std::map<std::string, std::string>::iterator it = s.find(name);
-    return it == s.end() ? def : it->second.c_str();
+  int addFloatOption(const char *name, double value, double low, double high, const char *descript) {
+    Entry x;
+    x.type = PAROPT_FLOAT_OPTION;
+    x.f = x.f_default = value;
+    x.flo = low;
+    x.fhi = high;
+    return add(name, x, descript);
+  }
+  int addEnumOption(const char *name, const char *value, int size, const char *options[], const char *descript) {
+    Entry x;
+    x.type = PAROPT_ENUM_OPTION;
+    x.s = x.s_default = value ? value : "";
+    x.has_str = true;
+    for (int k = 0; k < size; k++) x.choices.push_back(options[k]);
+    return add(name, x, descript);
+  }
+  int isOption(const char *name) { return e.count(name) ? 1 : 0; }
+
+  // setOption returns 0 on success; unknown names, wrong types, values outside the range and strings that are
+  // not a member of the enumeration are refused with a message on stderr (:310-386) and leave the entry unchanged
+  int setOption(const char *name, const char *value) {
+    Entry *x = find(name);
+    if (!x) return 1;
+    if (x->type == PAROPT_STRING_OPTION) {
+      x->has_str = value != NULL;
+      x->s = value ? value : "";
+      x->is_set = 1;
+      return 0;
+    }
+    if (x->type == PAROPT_ENUM_OPTION) {
+      for (const std::string &c : x->choices) {
+        if (value && c == value) {
+          x->s = value;
+          x->is_set = 1;
+          return 0;
+        }
+      }
+      fprintf(stderr, "ParOptOptions Warning: Enum option %s not set: %s is not one of its values\n", name,
+              value ? value : "(null)");
+      return 1;
+    }
+    fprintf(stderr, "ParOptOptions Warning: Option %s is not a string or enum option\n", name);
+    return 1;
+  }
+  int setOption(const char *name, int value) {
+    Entry *x = find(name);
+    if (!x) return 1;
+    if (x->type == PAROPT_BOOLEAN_OPTION) {
+      x->i = value ? 1 : 0;
+      x->is_set = 1;
+      return 0;
+    }
+    if (x->type == PAROPT_INT_OPTION) {
+      if (value < x->ilo || value > x->ihi) {
+        fprintf(stderr, "ParOptOptions Warning: Integer option %s = %d out of range [%d, %d]\n", name, value, x->ilo,
+                x->ihi);
+        return 1;
+      }
+      x->i = value;
+      x->is_set = 1;
+      return 0;
+    }
+    fprintf(stderr, "ParOptOptions Warning: Option %s is not a boolean or integer option\n", name);
+    return 1;
+  }
+  int setOption(const char *name, double value) {
+    Entry *x = find(name);
+    if (!x) return 1;
+    if (x->type != PAROPT_FLOAT_OPTION) {
+      fprintf(stderr, "ParOptOptions Warning: Option %s is not a float option\n", name);
+      return 1;
+    }
+    if (value < x->flo || value > x->fhi) {
+      fprintf(stderr, "ParOptOptions Warning: Float option %s = %g out of range [%g, %g]\n", name, value, x->flo,
+              x->fhi);
+      return 1;
+    }
+    x->f = value;
+    x->is_set = 1;
+    return 0;
+  }
+  // typed getters: NULL / 0 / 0.0 for a missing name or the wrong type, like the reference (:391-440)
+  const char *getStringOption(const char *name) {
+    Entry *x = get(name, PAROPT_STRING_OPTION);
+    return (x && x->has_str) ? x->s.c_str() : NULL;
+  }
+  int getBoolOption(const char *name) {
+    Entry *x = get(name, PAROPT_BOOLEAN_OPTION);
+    return x ? x->i : 0;
+  }
+  int getIntOption(const char *name) {
+    Entry *x = get(name, PAROPT_INT_OPTION);
+    return x ? x->i : 0;
+  }
+  double getFloatOption(const char *name) {
+    Entry *x = get(name, PAROPT_FLOAT_OPTION);
+    return x ? x->f : 0.0;
+  }
+  const char *getEnumOption(const char *name) {
+    Entry *x = get(name, PAROPT_ENUM_OPTION);
+    return x ? x->s.c_str() : NULL;
+  }
+  int getOptionType(const char *name) {
+    std::map<std::string, Entry>::iterator it = e.find(name);
+    return it == e.end() ? 0 : it->second.type;
+  }
+  const char *getDescription(const char *name) {
+    std::map<std::string, Entry>::iterator it = e.find(name);
+    return it == e.end() ? NULL : it->second.descript.c_str();
+  }
+  int getIntRange(const char *name, int *low, int *high) {
+    Entry *x = get(name, PAROPT_INT_OPTION);
+    if (!x) return 1;
+    if (low) *low = x->ilo;
+    if (high) *high = x->ihi;
+    return 0;
+  }
+  int getFloatRange(const char *name, double *low, double *high) {
+    Entry *x = get(name, PAROPT_FLOAT_OPTION);
+    if (!x) return 1;
+    if (low) *low = x->flo;
+    if (high) *high = x->fhi;
+    return 0;
+  }
+  int getEnumRange(const char *name, int *size, const char *const **values) {
+    Entry *x = get(name, PAROPT_ENUM_OPTION);
+    if (!x) return 1;
+    x->cptr.clear();
+    for (const std::string &c : x->choices) x->cptr.push_back(c.c_str());
+    if (size) *size = (int)x->cptr.size();
+    if (values) *values = x->cptr.data();
+    return 0;
+  }
+  // one line per option; output_level > 0 also prints the ranges (:443-470)
+  void printSummary(FILE *fp, int output_level) {
+    if (!fp) return;
+    for (std::map<std::string, Entry>::iterator it = e.begin(); it != e.end(); ++it) {
+      const Entry &x = it->second;
+      if (x.type == PAROPT_STRING_OPTION) {
+        fprintf(fp, "%-40s %-15s\n", it->first.c_str(), x.has_str ? x.s.c_str() : "(null)");
+      } else if (x.type == PAROPT_ENUM_OPTION) {
+        fprintf(fp, "%-40s %-15s\n", it->first.c_str(), x.s.c_str());
+        if (output_level > 0) {
+          fprintf(fp, "%-40s", "  values:");
+          for (const std::string &c : x.choices) fprintf(fp, " %s", c.c_str());
+          fprintf(fp, "\n");
+        }
+      } else if (x.type == PAROPT_FLOAT_OPTION) {
+        fprintf(fp, "%-40s %-15g\n", it->first.c_str(), x.f);
+        if (output_level > 0) fprintf(fp, "%-40s [%g, %g]\n", "  range:", x.flo, x.fhi);
+      } else {
+        fprintf(fp, "%-40s %-15d\n", it->first.c_str(), x.i);
+        if (output_level > 0 && x.type == PAROPT_INT_OPTION) fprintf(fp, "%-40s [%d, %d]\n", "  range:", x.ilo, x.ihi);
+      }
+    }
+  }
+  // iteration over the names (:472-495)
+  void begin() { iter_pos = 0; names.clear(); for (auto &kv : e) names.push_back(kv.first); }
+  const char *getName() { return iter_pos < names.size() ? names[iter_pos].c_str() : NULL; }
+  int next() { iter_pos++; return iter_pos < names.size() ? 1 : 0; }
+
+  // facade plumbing: the registries of the library's drivers (po_options_visit_defaults), and the hand-over of
+  // every entry a driver knows to that driver
+  void addLibraryDefaults(int which) { po_options_visit_defaults(which, &ParOptOptions::visit, this); }
+  template <class SetStr, class SetInt, class SetFloat>
+  int forward(int which, SetStr sstr, SetInt sint, SetFloat sfloat) {
+    std::vector<std::string> known;
+    po_options_visit_defaults(which, &ParOptOptions::collect, &known);
+    if (which != 0) po_options_visit_defaults(0, &ParOptOptions::collect, &known);  // tr / mma share the ip registry
+    int bad = 0;
+    for (const std::string &nm : known) {
+      std::map<std::string, Entry>::iterator it = e.find(nm);
+      if (it == e.end()) continue;
+      const Entry &x = it->second;
+      if (x.type == PAROPT_STRING_OPTION || x.type == PAROPT_ENUM_OPTION) {
+        bad |= sstr(nm.c_str(), (x.type == PAROPT_STRING_OPTION && !x.has_str) ? "" : x.s.c_str());
+      } else if (x.type == PAROPT_FLOAT_OPTION) {
+        bad |= sfloat(nm.c_str(), x.f);
+      } else {
+        bad |= sint(nm.c_str(), x.i);
+      }
+    }
+    return bad;
   }
 
  private:
-  std::map<std::string, std::string> s;
-  std::map<std::string, int> i;
-  std::map<std::string, double> f;
+  struct Entry {
+    int type = 0, is_set = 0;
+    bool has_str = false;
+    std::string s, s_default, descript;
+    int i = 0, i_default = 0, ilo = 0, ihi = 0;
+    double f = 0.0, f_default = 0.0, flo = 0.0, fhi = 0.0;
+    std::vector<std::string> choices;
+    std::vector<const char *> cptr;
+  };
+  int add(const char *name, Entry &x, const char *descript) {
+    if (e.count(name)) return 1;
+    x.descript = descript ? descript : "";
+    e[name] = x;
+    return 0;
+  }
+  Entry *find(const char *name) {
+    std::map<std::string, Entry>::iterator it = e.find(name);
+    if (it == e.end()) {
+      fprintf(stderr, "ParOptOptions Warning: %s is not an option\n", name);
+      return NULL;
+    }
+    return &it->second;
+  }
+  Entry *get(const char *name, int type) {
+    std::map<std::string, Entry>::iterator it = e.find(name);
+    return (it == e.end() || it->second.type != type) ? NULL : &it->second;
+  }
+  static void visit(void *user, const char *name, int type, const char *sval, int ival, int ilo, int ihi, double fval,
+                    double flo, double fhi, int nenum, const char *const *enumvals) {
+    ParOptOptions *o = static_cast<ParOptOptions *>(user);
+    if (type == PAROPT_STRING_OPTION) {
+      o->addStringOption(name, sval, "");
+    } else if (type == PAROPT_BOOLEAN_OPTION) {
+      o->addBoolOption(name, ival, "");
+    } else if (type == PAROPT_INT_OPTION) {
+      o->addIntOption(name, ival, ilo, ihi, "");
+    } else if (type == PAROPT_FLOAT_OPTION) {
+      o->addFloatOption(name, fval, flo, fhi, "");
+    } else {
+      std::vector<const char *> ch(enumvals, enumvals + nenum);
+      o->addEnumOption(name, sval, nenum, ch.data(), "");
+    }
+  }
+  static void collect(void *user, const char *name, int, const char *, int, int, int, double, double, double, int,
+                      const char *const *) {
+    static_cast<std::vector<std::string> *>(user)->push_back(name);
+  }
+#ifdef PAROPT_AMD_USE_MPI
+  MPI_Comm comm;
+#endif
+  std::map<std::string, Entry> e;
+  std::vector<std::string> names;
+  size_t iter_pos;
 };
 
-// ---- ParOptProblem --------------------------------------------------------------------------------
+// ---- ParOptQuasiDefMat: what createQuasiDefMat() returns (src/ParOptSparseMat.h:18-120) ------------------
+// In the reference these objects factor and apply the quasi-definite matrix on the host.  Here the library does
+// that on the device; the objects only say WHICH form the problem asks for: block diagonal with nwblock x nwblock
+// blocks (ParOptQuasiDefBlockMat) or a general sparse matrix from the CSR pattern (ParOptQuasiDefSparseMat).
+class ParOptProblem;
+class ParOptSparseProblem;
+class ParOptQuasiDefMat : public ParOptBase {
+ public:
+  virtual ~ParOptQuasiDefMat() {}
+  virtual int getBlockSize() { return 1; }
+  virtual int isSparse() { return 0; }
+};
+class ParOptQuasiDefBlockMat : public ParOptQuasiDefMat {
+ public:
+  ParOptQuasiDefBlockMat(ParOptProblem *, int _nwblock) : nwblock(_nwblock < 1 ? 1 : _nwblock) {}
+  int getBlockSize() { return nwblock; }
+
+ private:
+  int nwblock;
+};
+class ParOptQuasiDefSparseMat : public ParOptQuasiDefMat {
+ public:
+  explicit ParOptQuasiDefSparseMat(ParOptSparseProblem *) {}
+  int isSparse() { return 1; }
+};
+
+// ---- ParOptProblem (src/ParOptProblem.h:42-296) -------------------------------------------------------
 class ParOptProblem : public ParOptBase {
  public:
-  explicit ParOptProblem(po_ctx _ctx)
-      : ctx(_ctx), nvars(0), ncon(0), nwcon(0), ninequality(-1), nwinequality(-1), nwblock(1), hprob(NULL) {}
-  // the nwblock of the reference's `new ParOptQuasiDefBlockMat(this, nwblock)` in createQuasiDefMat(): with
-  // nwblock > 1 addSparseInnerProduct fills packed upper nwblock x nwblock blocks (before the first handle())
+  explicit ParOptProblem(ParOptComm _comm)
+      : comm(_comm), ctx(paropt_amd_context(_comm)), nvars(0), ncon(0), ninequality(-1), nwcon(0), nwinequality(-1),
+        nwblock(1), linear_constraints(0), hprob(NULL) {}
+  ParOptProblem(ParOptComm _comm, int _nvars, int _ncon, int _ninequality, int _nwcon, int _nwinequality)
+      : comm(_comm), ctx(paropt_amd_context(_comm)), nvars(_nvars), ncon(_ncon), ninequality(_ninequality),
+        nwcon(_nwcon), nwinequality(_nwinequality), nwblock(1), linear_constraints(0), hprob(NULL) {}
+  // the nwblock of `new ParOptQuasiDefBlockMat(this, nwblock)` when createQuasiDefMat() is not overridden
   void setSparseBlockSize(int _nwblock) { nwblock = _nwblock; }
+  // facade extension (po_problem_set_linear_constraints): the dense constraints are linear, evalObjConGradient is
+  // called with Ac == NULL after the first evaluation of each optimize()
+  void setLinearConstraints(int flag) {
+    linear_constraints = flag;
+    if (hprob) po_problem_set_linear_constraints(hprob, flag);
+  }
   virtual ~ParOptProblem() {
     if (hprob) po_problem_destroy(hprob);
   }
+  ParOptComm getMPIComm() { return comm; }
   po_ctx getContext() { return ctx; }
   void setProblemSizes(int _nvars, int _ncon, int _nwcon) {
     nvars = _nvars;
@@ -155,23 +504,51 @@ class ParOptProblem : public ParOptBase {
     if (_ncon) *_ncon = ncon;
     if (_nwcon) *_nwcon = nwcon;
   }
-  virtual ParOptVec *createDesignVec() { return new ParOptVec(ctx, nvars); }
+  void getNumInequalities(int *_ninequality, int *_nwinequality) {
+    if (_ninequality) *_ninequality = ninequality < 0 ? ncon : ninequality;
+    if (_nwinequality) *_nwinequality = nwinequality < 0 ? nwcon : nwinequality;
+  }
+  virtual ParOptVec *createDesignVec() { return new ParOptBasicVec(comm, nvars); }
+  virtual ParOptVec *createConstraintVec() { return new ParOptBasicVec(comm, nwcon); }
+  // the reference makes this pure virtual (:72); here the default is the block form with setSparseBlockSize()
+  virtual ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefBlockMat(this, nwblock); }
+  virtual int isSparseInequality() { return 1; }
+  virtual int useLowerBounds() { return 1; }
+  virtual int useUpperBounds() { return 1; }
 
   virtual void getVarsAndBounds(ParOptVec *x, ParOptVec *lb, ParOptVec *ub) = 0;
   virtual int evalObjCon(ParOptVec *x, ParOptScalar *fobj, ParOptScalar *cons) = 0;
   virtual int evalObjConGradient(ParOptVec *x, ParOptVec *g, ParOptVec **Ac) = 0;
+  // Hessian of the Lagrangian (:160-196); non-zero = not available
+  virtual int evalHvecProduct(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *, ParOptVec *) { return 1; }
+  virtual int evalHessianDiag(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *) { return 1; }
   virtual void computeQuasiNewtonUpdateCorrection(ParOptVec *, ParOptScalar *, ParOptVec *, ParOptVec *,
                                                   ParOptVec *) {}
   virtual void writeOutput(int, ParOptVec *) {}
-  // sparse constraints, nwblock = 1 (src/ParOptProblem.h:215-262); `out` / `pzw` are w-sized
+  // sparse constraints (src/ParOptProblem.h:215-262); `out` / `pzw` are w-sized
   virtual void evalSparseCon(ParOptVec *, ParOptVec *) {}
   virtual void addSparseJacobian(ParOptScalar, ParOptVec *, ParOptVec *, ParOptVec *) {}
   virtual void addSparseJacobianTranspose(ParOptScalar, ParOptVec *, ParOptVec *, ParOptVec *) {}
   virtual void addSparseInnerProduct(ParOptScalar, ParOptVec *, ParOptVec *, ParOptScalar *) {}
+  virtual int getSparseJacobianBlockSize() { return -1; }
+
+  // Finite-difference check of the gradients the problem provides (src/ParOptProblem.cpp:225-622): the step
+  // direction is +-1 by the sign of the objective gradient, forward differences with step dh; prints the
+  // projected derivatives, their finite-difference estimates and the relative errors on rank 0, and (with
+  // check_hvec_product) does the same for the Hessian-vector product against differences of the Lagrangian's
+  // gradient, and for the sparse Jacobian products against differences of evalSparseCon.  Returns the largest
+  // relative error seen (the reference returns nothing).
+  double checkGradients(double dh, ParOptVec *xvec = NULL, int check_hvec_product = 0);
 
   // the C-callback problem handed to the library (created on first use)
   po_problem handle() {
     if (!hprob) {
+      ParOptQuasiDefMat *qd = createQuasiDefMat();
+      if (qd) {
+        qd->incref();
+        if (!qd->isSparse()) nwblock = qd->getBlockSize();
+        qd->decref();
+      }
       po_problem_callbacks cb;
       cb.user = this;
       cb.get_vars_and_bounds = &ParOptProblem::tramp_vars;
@@ -179,17 +556,25 @@ class ParOptProblem : public ParOptBase {
       cb.eval_obj_con_gradient = &ParOptProblem::tramp_grad;
       cb.qn_update_correction = NULL;
       cb.write_output = &ParOptProblem::tramp_write;
-      if (po_problem_create_callbacks(ctx, nvars, ncon, ninequality, &cb, &hprob) != 0) {
+      if (po_problem_create_callbacks(ctx, nvars, ncon, ninequality < 0 ? ncon : ninequality, &cb, &hprob) != 0) {
         fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
       }
-      if (hprob) attachSparse();
+      if (hprob) {
+        attachSparse();
+        po_problem_set_hessian_callbacks(hprob, &ParOptProblem::tramp_hvec, &ParOptProblem::tramp_hdiag);
+        if (!(useLowerBounds() && useUpperBounds()))
+          po_problem_set_var_bound_options(hprob, useLowerBounds(), useUpperBounds());
+        if (linear_constraints) po_problem_set_linear_constraints(hprob, 1);
+      }
     }
     return hprob;
   }
 
  protected:
+  ParOptComm comm;
   po_ctx ctx;
-  int nvars, ncon, nwcon, ninequality, nwinequality, nwblock;
+  int nvars, ncon, ninequality, nwcon, nwinequality;
+  int nwblock, linear_constraints;
   po_problem hprob;
   // registers the sparse-constraint callbacks with the library; ParOptSparseProblem registers its CSR form
   virtual void attachSparse() {
@@ -199,93 +584,89 @@ class ParOptProblem : public ParOptBase {
     scb.add_sparse_jacobian = &ParOptProblem::tramp_wjac;
     scb.add_sparse_jacobian_transpose = &ParOptProblem::tramp_wjact;
     scb.add_sparse_inner_product = &ParOptProblem::tramp_winner;
-    if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality, &scb) != 0 ||
+    if (po_problem_set_sparse_callbacks(hprob, nwcon, nwinequality < 0 ? nwcon : nwinequality, &scb) != 0 ||
         (nwblock > 1 && po_problem_set_sparse_block_size(hprob, nwblock) != 0)) {
       fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     }
   }
+  // Callback arguments are vectors the SOLVER owns: whatever the user's code did with their getArray pointers is
+  // uploaded (outputs) or dropped (inputs) when the callback returns (po_vec_release_array).
+  struct Arg {
+    ParOptBasicVec v;
+    int upload;
+    Arg(po_vec h, int _upload) : v(h), upload(_upload) { v.incref(); }
+    ~Arg() { v.releaseArray(upload); }
+    ParOptVec *p() { return &v; }
+  };
 
  private:
   static int tramp_vars(void *self, po_vec x, po_vec lb, po_vec ub) {
-    ParOptVec vx(x), vl(lb), vu(ub);
-    double *p;
-    vx.getArray(&p);
-    vl.getArray(&p);
-    vu.getArray(&p);
-    static_cast<ParOptProblem *>(self)->getVarsAndBounds(&vx, &vl, &vu);
-    vx.syncToDevice();
-    vl.syncToDevice();
-    vu.syncToDevice();
+    Arg vx(x, 1), vl(lb, 1), vu(ub, 1);
+    static_cast<ParOptProblem *>(self)->getVarsAndBounds(vx.p(), vl.p(), vu.p());
     return 0;
   }
   static int tramp_eval(void *self, po_vec x, double *fobj, double *cons) {
-    ParOptVec vx(x);
-    vx.syncToHost();
-    return static_cast<ParOptProblem *>(self)->evalObjCon(&vx, fobj, cons);
+    Arg vx(x, 0);
+    return static_cast<ParOptProblem *>(self)->evalObjCon(vx.p(), fobj, cons);
   }
   static int tramp_grad(void *self, po_vec x, po_vec g, const po_vec *Ac) {
     ParOptProblem *me = static_cast<ParOptProblem *>(self);
-    ParOptVec vx(x), vg(g);
-    vx.syncToHost();
+    Arg vx(x, 0), vg(g, 1);
+    std::vector<Arg *> args;
     std::vector<ParOptVec *> va(me->ncon > 0 ? me->ncon : 1, (ParOptVec *)NULL);
-    double *p;
-    vg.getArray(&p);
     // Ac == NULL: the problem declared linear constraints (setLinearConstraints) and only g is wanted
     for (int j = 0; Ac && j < me->ncon; j++) {
-      va[j] = new ParOptVec(Ac[j]);
-      va[j]->incref();
-      // the reference hands out zero-initialised Ac that the problem may fill sparsely
-      va[j]->getArray(&p);
+      args.push_back(new Arg(Ac[j], 1));
+      va[j] = args.back()->p();
     }
-    int fail = me->evalObjConGradient(&vx, &vg, Ac ? va.data() : NULL);
-    vg.syncToDevice();
-    for (int j = 0; Ac && j < me->ncon; j++) {
-      va[j]->syncToDevice();
-      va[j]->decref();
-    }
+    int fail = me->evalObjConGradient(vx.p(), vg.p(), (Ac || me->ncon == 0) ? va.data() : NULL);
+    for (Arg *a : args) delete a;
+    return fail;
+  }
+  static int tramp_hvec(void *self, po_vec x, const double *z, po_vec zw, po_vec px, po_vec hvec) {
+    ParOptProblem *me = static_cast<ParOptProblem *>(self);
+    Arg vx(x, 0), vp(px, 0), vh(hvec, 1);
+    Arg *vzw = zw ? new Arg(zw, 0) : NULL;
+    std::vector<double> zc(z, z + (me->ncon > 0 ? me->ncon : 0));
+    int fail = me->evalHvecProduct(vx.p(), zc.data(), vzw ? vzw->p() : NULL, vp.p(), vh.p());
+    delete vzw;
+    return fail;
+  }
+  static int tramp_hdiag(void *self, po_vec x, const double *z, po_vec zw, po_vec hdiag) {
+    ParOptProblem *me = static_cast<ParOptProblem *>(self);
+    Arg vx(x, 0), vh(hdiag, 1);
+    Arg *vzw = zw ? new Arg(zw, 0) : NULL;
+    std::vector<double> zc(z, z + (me->ncon > 0 ? me->ncon : 0));
+    int fail = me->evalHessianDiag(vx.p(), zc.data(), vzw ? vzw->p() : NULL, vh.p());
+    delete vzw;
     return fail;
   }
   static int tramp_wcon(void *self, po_vec x, po_vec out) {
-    ParOptVec vx(x), vo(out);
-    double *p;
-    vx.syncToHost();
-    vo.getArray(&p);
-    static_cast<ParOptProblem *>(self)->evalSparseCon(&vx, &vo);
-    vo.syncToDevice();
+    Arg vx(x, 0), vo(out, 1);
+    static_cast<ParOptProblem *>(self)->evalSparseCon(vx.p(), vo.p());
     return 0;
   }
   static int tramp_wjac(void *self, double alpha, po_vec x, po_vec px, po_vec out) {
-    ParOptVec vx(x), vp(px), vo(out);
-    vx.syncToHost();
-    vp.syncToHost();
-    vo.syncToHost();
-    static_cast<ParOptProblem *>(self)->addSparseJacobian(alpha, &vx, &vp, &vo);
-    vo.syncToDevice();
+    Arg vx(x, 0), vp(px, 0), vo(out, 1);
+    static_cast<ParOptProblem *>(self)->addSparseJacobian(alpha, vx.p(), vp.p(), vo.p());
     return 0;
   }
   static int tramp_wjact(void *self, double alpha, po_vec x, po_vec pzw, po_vec out) {
-    ParOptVec vx(x), vp(pzw), vo(out);
-    vx.syncToHost();
-    vp.syncToHost();
-    vo.syncToHost();
-    static_cast<ParOptProblem *>(self)->addSparseJacobianTranspose(alpha, &vx, &vp, &vo);
-    vo.syncToDevice();
+    Arg vx(x, 0), vp(pzw, 0), vo(out, 1);
+    static_cast<ParOptProblem *>(self)->addSparseJacobianTranspose(alpha, vx.p(), vp.p(), vo.p());
     return 0;
   }
   static int tramp_winner(void *self, double alpha, po_vec x, po_vec cvec, po_vec A) {
-    ParOptVec vx(x), vc(cvec), va(A);
-    vx.syncToHost();
-    vc.syncToHost();
-    va.syncToHost();
-    double *a;
-    va.getArray(&a);
-    static_cast<ParOptProblem *>(self)->addSparseInnerProduct(alpha, &vx, &vc, a);
-    va.syncToDevice();
+    // the reference hands `A` over as a raw array (packed upper blocks for nwblock > 1)
+    Arg vx(x, 0), vc(cvec, 0), va(A, 1);
+    double *a = NULL;
+    va.p()->getArray(&a);
+    static_cast<ParOptProblem *>(self)->addSparseInnerProduct(alpha, vx.p(), vc.p(), a);
     return 0;
   }
   static int tramp_write(void *self, int iter, po_vec x) {
-    ParOptVec vx(x);
-    static_cast<ParOptProblem *>(self)->writeOutput(iter, &vx);
+    Arg vx(x, 0);
+    static_cast<ParOptProblem *>(self)->writeOutput(iter, vx.p());
     return 0;
   }
 };
@@ -296,7 +677,8 @@ class ParOptProblem : public ParOptBase {
 // the reference; it is uploaded after the call.
 class ParOptSparseProblem : public ParOptProblem {
  public:
-  explicit ParOptSparseProblem(po_ctx _ctx) : ParOptProblem(_ctx) {}
+  explicit ParOptSparseProblem(ParOptComm _comm) : ParOptProblem(_comm) {}
+  ParOptQuasiDefMat *createQuasiDefMat() { return new ParOptQuasiDefSparseMat(this); }
   // after setProblemSizes(), as in the reference (:306-312)
   void setSparseJacobianData(const int *_rowp, const int *_cols) {
     rowp.assign(_rowp, _rowp + nwcon + 1);
@@ -330,31 +712,22 @@ class ParOptSparseProblem : public ParOptProblem {
   std::vector<int> rowp, cols;
   std::vector<ParOptScalar> data;
   static int tramp_sobjcon(void *self, po_vec x, double *fobj, double *cons, po_vec sparse) {
-    ParOptVec vx(x), vs(sparse);
-    double *p;
-    vx.syncToHost();
-    vs.getArray(&p);
-    int fail = static_cast<ParOptSparseProblem *>(self)->evalSparseObjCon(&vx, fobj, cons, &vs);
-    vs.syncToDevice();
-    return fail;
+    Arg vx(x, 0), vs(sparse, 1);
+    return static_cast<ParOptSparseProblem *>(self)->evalSparseObjCon(vx.p(), fobj, cons, vs.p());
   }
   static int tramp_sgrad(void *self, po_vec x, po_vec g, const po_vec *Ac, double *ddata, int64_t nnz) {
     ParOptSparseProblem *me = static_cast<ParOptSparseProblem *>(self);
-    ParOptVec vx(x), vg(g);
-    vx.syncToHost();
-    std::vector<ParOptVec *> va(me->ncon > 0 ? me->ncon : 1, (ParOptVec *)NULL);
-    double *p;
-    vg.getArray(&p);
-    for (int j = 0; j < me->ncon; j++) {
-      va[j] = new ParOptVec(Ac[j]);
-      va[j]->incref();
-      va[j]->getArray(&p);
-    }
-    int fail = me->evalSparseObjConGradient(&vx, &vg, va.data(), me->data.data());
-    vg.syncToDevice();
-    for (int j = 0; j < me->ncon; j++) {
-      va[j]->syncToDevice();
-      va[j]->decref();
+    int fail = 0;
+    {
+      Arg vx(x, 0), vg(g, 1);
+      std::vector<Arg *> args;
+      std::vector<ParOptVec *> va(me->ncon > 0 ? me->ncon : 1, (ParOptVec *)NULL);
+      for (int j = 0; Ac && j < me->ncon; j++) {
+        args.push_back(new Arg(Ac[j], 1));
+        va[j] = args.back()->p();
+      }
+      fail = me->evalSparseObjConGradient(vx.p(), vg.p(), (Ac || me->ncon == 0) ? va.data() : NULL, me->data.data());
+      for (Arg *a : args) delete a;
     }
     if (po_ctx_memcpy(me->ctx, ddata, me->data.data(), (int64_t)sizeof(double) * nnz, 1) != 0) return 1;
     return fail;
@@ -395,7 +768,7 @@ class ParOptCompactQuasiNewton : public ParOptBase {
       for (ParOptVec *v : zwrap) v->decref();
       zwrap.clear();
       for (int i = 0; i < k; i++) {
-        zwrap.push_back(new ParOptVec(zs[i]));
+        zwrap.push_back(new ParOptBasicVec(zs[i]));
         zwrap.back()->incref();
       }
       *Z = zwrap.data();
@@ -435,12 +808,25 @@ class ParOptLSR1 : public ParOptCompactQuasiNewton {
 // ---- ParOptInteriorPoint ------------------------------------------------------------------------
 class ParOptInteriorPoint : public ParOptBase {
  public:
+  // the option set of ParOptInteriorPoint::addDefaultOptions (src/ParOptInteriorPoint.cpp:536-727)
+  static void addDefaultOptions(ParOptOptions *options) { options->addLibraryDefaults(0); }
   ParOptInteriorPoint(ParOptProblem *_prob, ParOptOptions *_options = NULL)
       : prob(_prob), options(_options), ip(NULL), x(NULL), zl(NULL), zu(NULL), zw(NULL), sw(NULL), tw(NULL) {
     prob->incref();
     if (options) options->incref();
     if (po_ip_create(prob->handle(), &ip) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
-    if (ip && options && options->apply(ip) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    applyOptions();
+  }
+  ParOptOptions *getOptions() { return options; }
+  // the options object is shared and may change between the constructor and optimize(), as in the reference
+  void applyOptions() {
+    if (!ip || !options) return;
+    po_ip h = ip;
+    int bad = options->forward(
+        0, [h](const char *n, const char *v) { return po_ip_set_option_str(h, n, v); },
+        [h](const char *n, int v) { return po_ip_set_option_int(h, n, v); },
+        [h](const char *n, double v) { return po_ip_set_option_float(h, n, v); });
+    if (bad) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
   }
   ~ParOptInteriorPoint() {
     if (x) x->decref();
@@ -454,7 +840,10 @@ class ParOptInteriorPoint : public ParOptBase {
     prob->decref();
   }
   ParOptProblem *getOptProblem() { return prob; }
-  int optimize(const char *checkpoint = NULL) { return ip ? po_ip_optimize(ip, checkpoint) : 1; }
+  int optimize(const char *checkpoint = NULL) {
+    applyOptions();
+    return ip ? po_ip_optimize(ip, checkpoint) : 1;
+  }
   void getProblemSizes(int *nvars, int *ncon, int *nwcon) { prob->getProblemSizes(nvars, ncon, nwcon); }
   // borrowed internals, as in the reference (src/ParOptInteriorPoint.cpp:793-826)
   void getOptimizedPoint(ParOptVec **_x, ParOptScalar **_z, ParOptVec **_zw, ParOptVec **_zl, ParOptVec **_zu) {
@@ -519,7 +908,7 @@ class ParOptInteriorPoint : public ParOptBase {
     if (*slot) (*slot)->decref();
     *slot = NULL;
     if (h) {
-      *slot = new ParOptVec(h);
+      *slot = new ParOptBasicVec(h);
       (*slot)->incref();
     }
   }
@@ -534,6 +923,17 @@ class ParOptInteriorPoint : public ParOptBase {
 // subproblem, the interior-point sub-solver and the trust-region driver exactly as :108-183 does.
 class ParOptOptimizer : public ParOptBase {
  public:
+  // src/ParOptOptimizer.cpp:38-49: "algorithm", "ip_checkpoint_file" and the three drivers' option sets
+  static void addDefaultOptions(ParOptOptions *options) {
+    const char *optimizers[3] = {"ip", "tr", "mma"};
+    options->addEnumOption("algorithm", "tr", 3, optimizers, "optimization algorithm");
+    options->addStringOption("ip_checkpoint_file", NULL, "checkpoint file of the interior-point method");
+    options->addLibraryDefaults(0);
+    options->addLibraryDefaults(1);
+    options->addLibraryDefaults(2);
+  }
+  ParOptOptions *getOptions() { return options; }
+  ParOptProblem *getProblem() { return prob; }
   ParOptOptimizer(ParOptProblem *_prob, ParOptOptions *_options)
       : prob(_prob), options(_options), ip(NULL), tr(NULL), mma(NULL), x(NULL) {
     prob->incref();
@@ -548,28 +948,40 @@ class ParOptOptimizer : public ParOptBase {
     prob->decref();
   }
   void optimize() {
-    const std::string algorithm = options->getStringOption("algorithm", "tr");
+    const char *alg = options->getEnumOption("algorithm");
+    const std::string algorithm = alg ? alg : "tr";
     if (algorithm == "ip") {
       if (!ip) {
-        ParOptOptions *o = options;
-        ip = new ParOptInteriorPoint(prob, o);
+        ip = new ParOptInteriorPoint(prob, options);
         ip->incref();
       }
-      ip->optimize();
+      ip->optimize(options->getStringOption("ip_checkpoint_file"));
     } else if (algorithm == "tr") {
-      if (!tr) {
-        if (po_tr_create(prob->handle(), &tr) != 0 || options->apply(tr) != 0) {
-          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
-          return;
-        }
+      if (!tr && po_tr_create(prob->handle(), &tr) != 0) {
+        fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        return;
+      }
+      po_tr h = tr;
+      if (options->forward(
+              1, [h](const char *n, const char *v) { return po_tr_set_option_str(h, n, v); },
+              [h](const char *n, int v) { return po_tr_set_option_int(h, n, v); },
+              [h](const char *n, double v) { return po_tr_set_option_float(h, n, v); }) != 0) {
+        fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        return;
       }
       if (po_tr_optimize(tr) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     } else if (algorithm == "mma") {
-      if (!mma) {
-        if (po_mma_create(prob->handle(), &mma) != 0 || options->apply(mma) != 0) {
-          fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
-          return;
-        }
+      if (!mma && po_mma_create(prob->handle(), &mma) != 0) {
+        fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        return;
+      }
+      po_mma h = mma;
+      if (options->forward(
+              2, [h](const char *n, const char *v) { return po_mma_set_option_str(h, n, v); },
+              [h](const char *n, int v) { return po_mma_set_option_int(h, n, v); },
+              [h](const char *n, double v) { return po_mma_set_option_float(h, n, v); }) != 0) {
+        fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        return;
       }
       if (po_mma_optimize(mma) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     } else {
@@ -587,7 +999,7 @@ class ParOptOptimizer : public ParOptBase {
         po_mma_get_optimized_point(mma, &hx, &z, NULL, NULL, NULL);
       }
       if (x) x->decref();
-      x = new ParOptVec(hx);
+      x = new ParOptBasicVec(hx);
       x->incref();
       if (_x) *_x = x;
       if (_z) *_z = const_cast<double *>(z);
@@ -612,5 +1024,119 @@ class ParOptOptimizer : public ParOptBase {
   po_mma mma;
   ParOptVec *x;
 };
+
+// ---- ParOptProblem::checkGradients -------------------------------------------------------------------
+inline double ParOptProblem::checkGradients(double dh, ParOptVec *xvec, int check_hvec_product) {
+  int rank = 0;
+  po_ctx_rank(ctx, &rank, NULL);
+  ParOptVec *x = xvec ? xvec : createDesignVec();
+  x->incref();
+  ParOptVec *px = createDesignVec(), *g = createDesignVec(), *xt = createDesignVec(), *gt = createDesignVec();
+  px->incref();
+  g->incref();
+  xt->incref();
+  gt->incref();
+  std::vector<ParOptVec *> Ac(ncon > 0 ? ncon : 1, (ParOptVec *)NULL), At(ncon > 0 ? ncon : 1, (ParOptVec *)NULL);
+  for (int i = 0; i < ncon; i++) {
+    Ac[i] = createDesignVec();
+    Ac[i]->incref();
+    At[i] = createDesignVec();
+    At[i]->incref();
+  }
+  if (!xvec) getVarsAndBounds(x, g, px);  // the bounds land in g and px and are discarded
+  ParOptScalar fobj = 0.0, ft = 0.0;
+  std::vector<ParOptScalar> c(ncon > 0 ? ncon : 1, 0.0), ct(ncon > 0 ? ncon : 1, 0.0), Apx(ncon > 0 ? ncon : 1, 0.0);
+  evalObjCon(x, &fobj, c.data());
+  evalObjConGradient(x, g, Ac.data());
+  ParOptScalar *pxv, *gv;
+  px->getArray(&pxv);
+  g->getArray(&gv);
+  for (int i = 0; i < nvars; i++) pxv[i] = gv[i] >= 0.0 ? 1.0 : -1.0;
+  const ParOptScalar pobj = g->dot(px);
+  if (ncon > 0) px->mdot(Ac.data(), ncon, Apx.data());
+  // forward difference along px
+  xt->copyValues(x);
+  xt->axpy(dh, px);
+  evalObjCon(xt, &ft, ct.data());
+  double worst = 0.0;
+  auto report = [&](const char *what, int idx, double actual, double fd) {
+    const double err = fabs(actual - fd), rel = err / (fabs(actual) > 1e-300 ? fabs(actual) : 1.0);
+    if (rel > worst) worst = rel;
+    if (rank == 0) {
+      if (idx < 0) {
+        printf("%s\n%15s %15s %15s %15s\n%15.6e %15.6e %15.4e %15.4e\n", what, "Actual", "FD", "Err", "Rel err", actual,
+               fd, err, rel);
+      } else {
+        printf("%s[%d]\n%15.6e %15.6e %15.4e %15.4e\n", what, idx, actual, fd, err, rel);
+      }
+    }
+  };
+  report("Objective gradient test", -1, pobj, (ft - fobj) / dh);
+  for (int i = 0; i < ncon; i++) report("Constraint gradient test", i, Apx[i], (ct[i] - c[i]) / dh);
+  ParOptVec *zw = NULL;
+  if (nwcon > 0) {
+    zw = createConstraintVec();
+    zw->incref();
+    ParOptScalar *zwv;
+    zw->getArray(&zwv);
+    for (int i = 0; i < nwcon; i++) zwv[i] = 1.05 + 0.25 * (i % 21);
+    // sparse Jacobian: Aw px against differences of evalSparseCon, and (Aw px).zw against px.(Aw^T zw)
+    ParOptVec *cw = createConstraintVec(), *cwt = createConstraintVec(), *jp = createConstraintVec();
+    cw->incref();
+    cwt->incref();
+    jp->incref();
+    evalSparseCon(x, cw);
+    evalSparseCon(xt, cwt);
+    jp->zeroEntries();
+    addSparseJacobian(1.0, x, px, jp);
+    cwt->axpy(-1.0, cw);
+    cwt->scale(1.0 / dh);
+    report("Sparse Jacobian-vector product test (zw^T Aw px)", -1, jp->dot(zw), cwt->dot(zw));
+    gt->zeroEntries();
+    addSparseJacobianTranspose(1.0, x, zw, gt);
+    report("Sparse Jacobian transpose test (px^T Aw^T zw vs zw^T Aw px)", -1, gt->dot(px), jp->dot(zw));
+    cw->decref();
+    cwt->decref();
+    jp->decref();
+  }
+  if (check_hvec_product) {
+    // gradient of the Lagrangian g - sum z_i Ac_i - Aw^T zw at x and at x + dh px, against H px
+    std::vector<ParOptScalar> z(ncon > 0 ? ncon : 1, 0.0);
+    for (int i = 0; i < ncon; i++) z[i] = 2.3 - 0.15 * (i % 5);
+    ParOptVec *hvec = createDesignVec();
+    hvec->incref();
+    auto lagr = [&](ParOptVec *xp, ParOptVec *gp, std::vector<ParOptVec *> &Ap) {
+      evalObjConGradient(xp, gp, Ap.data());
+      for (int i = 0; i < ncon; i++) gp->axpy(-z[i], Ap[i]);
+      if (nwcon > 0) addSparseJacobianTranspose(-1.0, xp, zw, gp);
+    };
+    lagr(x, g, Ac);
+    lagr(xt, gt, At);
+    const int fail = evalHvecProduct(x, z.data(), zw, px, hvec);
+    if (fail == 0) {
+      gt->axpy(-1.0, g);
+      gt->scale(1.0 / dh);
+      report("Hessian-vector product test (px^T H px)", -1, hvec->dot(px), gt->dot(px));
+      gt->axpy(-1.0, hvec);
+      const double nrm = hvec->norm(), en = gt->norm();
+      if (rank == 0) printf("|H px - FD|: %15.4e   |H px|: %15.4e\n", en, nrm);
+      if (nrm > 0.0 && en / nrm > worst) worst = en / nrm;
+    } else if (rank == 0) {
+      printf("Hessian-vector products are not implemented by this problem\n");
+    }
+    hvec->decref();
+  }
+  if (zw) zw->decref();
+  for (int i = 0; i < ncon; i++) {
+    Ac[i]->decref();
+    At[i]->decref();
+  }
+  px->decref();
+  g->decref();
+  xt->decref();
+  gt->decref();
+  x->decref();
+  return worst;
+}
 
 #endif  // PAROPT_AMD_HPP

@@ -65,6 +65,17 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
 int po_live_objects(int64_t *vectors, int64_t *bytes);
 /* pinned host mirrors (po_vec_get_array) currently alive in this process */
 int po_live_host_mirrors(int64_t *mirrors);
+/* number of visible HIP devices (0 when there is none) */
+int po_device_count(int *count);
+/* Default option registries, for host-side ParOptOptions objects (src/ParOptOptions.h:9-61): the visitor is called
+ * once per option of ParOptInteriorPoint::addDefaultOptions (which = 0, src/ParOptInteriorPoint.cpp:536-727),
+ * ParOptTrustRegion::addDefaultOptions (1, src/ParOptTrustRegion.cpp:739-847) or ParOptMMA::addDefaultOptions
+ * (2, src/ParOptMMA.cpp:234-289) with type 1 string / 2 boolean / 3 int / 4 float / 5 enum (the reference's
+ * PAROPT_*_OPTION codes), the default and the admissible range / enum values. */
+typedef void (*po_option_visitor)(void *user, const char *name, int type, const char *sval, int ival, int ilo,
+                                  int ihi, double fval, double flo, double fhi, int nenum,
+                                  const char *const *enumvals);
+int po_options_visit_defaults(int which, po_option_visitor fn, void *user);
 /* Live timing of the headline kernel inside a run: after po_ctx_time_mdot(ctx, nvecs) every ParOptVec::mdot
  * launch with exactly `nvecs` vectors on this context is bracketed by HIP events on the context's stream
  * (nvecs = 0 switches it off; every call resets the accumulators); the result call returns the accumulated
@@ -110,10 +121,20 @@ int po_vec_mdot(po_vec x, const po_vec *vecs, int nvecs, double *out); /* mdot :
 int po_vec_norm(po_vec x, double *out);                     /* norm         :63-80 */
 int po_vec_maxabs(po_vec x, double *out);                   /* maxabs       :87-99 */
 int po_vec_l1norm(po_vec x, double *out);                   /* l1norm       :106-116 */
-/* getArray :212-217 -- a pinned HOST mirror; the first call downloads the device data.  Writes
- * made through the pointer reach the device at po_vec_sync_to_device.  The solver itself never
- * uses host mirrors. */
+/* getArray :212-217 -- in the reference the pointer IS the data.  Here it is a pinned HOST mirror of the HBM
+ * data that stays coherent through this ABI: po_vec_get_array downloads the vector (unless the mirror is already
+ * live) and marks the mirror LIVE; while it is live every po_* call that reads the vector uploads the mirror
+ * first and every po_* call that writes it downloads the result, so host writes are seen without an explicit
+ * sync and the pointer stays valid for the life of the vector.  po_vec_release_array ends the live state (with
+ * a final upload when `upload` != 0): REQUIRED for vectors the solver owns (callback arguments, optimized
+ * points) before the solver runs on, because the solver's own kernels do not look at mirrors; optional for
+ * vectors the caller created.  po_vec_sync_to_host is a plain download that does not make the mirror live;
+ * po_vec_sync_to_device a plain upload.  The solver itself never uses host mirrors. */
 int po_vec_get_array(po_vec v, double **host);
+int po_vec_release_array(po_vec v, int upload);
+/* the mirror after a fresh download, WITHOUT making it live (a read-only look, or a buffer for a write that is
+ * followed by po_vec_sync_to_device) */
+int po_vec_peek_array(po_vec v, double **host);
 int po_vec_sync_to_device(po_vec v);
 int po_vec_sync_to_host(po_vec v);
 /* Device-resident problems use the raw HBM pointer instead. */

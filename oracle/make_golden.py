@@ -538,6 +538,34 @@ case("ip_convex_n100000_c32_bfgs10_r1", "ip", ranks=1, problem="convex", n=10000
      vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
 
 
+def parse_tr_table(text):
+    """Rows of the trust-region iteration table (paropt.tr): 13 numeric columns without the wall time, + info."""
+    rows, infos = [], []
+    for ln in text.splitlines():
+        parts = ln.split()
+        if len(parts) >= 14 and parts[0].isdigit():
+            rows.append([float(v) for v in parts[:13]])
+            infos.append(" ".join(parts[14:]))
+    return np.array(rows), infos
+
+
+def example_golden():
+    """The reference's own example program (examples/rosenbrock/rosenbrock.cpp, built UNCHANGED against the
+    reference library by oracle/Makefile) run here; its trust-region table is the golden for the same source file
+    built against the product (oracle/_ref/rosenbrock_example_amd, tests/test_cpp_facade.py)."""
+    exe = os.path.join(HERE, "_ref", "rosenbrock_example")
+    env = dict(os.environ, MKL_NUM_THREADS="1", PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([exe], env=env, cwd=td, check=True, capture_output=True)
+        tr_text = open(os.path.join(td, "paropt.tr")).read()
+    rows, infos = parse_tr_table(tr_text)
+    path = os.path.join(GOLDEN, "example_rosenbrock.npz")
+    np.savez_compressed(path, table=rows, info=np.array(infos),
+                        case_json=np.array(json.dumps(dict(mode="example", ranks=1, args={}))))
+    print("%-40s %8d bytes  %d table rows" % ("example_rosenbrock", os.path.getsize(path), len(rows)))
+    return dict(mode="example", ranks=1, args={}, bytes=os.path.getsize(path))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -546,6 +574,8 @@ def main():
         subprocess.check_call(["make", "-C", HERE])
     os.makedirs(GOLDEN, exist_ok=True)
     manifest = {}
+    if not a.only or a.only in "example_rosenbrock":
+        manifest["example_rosenbrock"] = example_golden()
     for name, (mode, ranks, args) in sorted(CASES.items()):
         if a.only and a.only not in name:
             continue

@@ -219,13 +219,26 @@ class PVec:
         check(lib.po_vec_maxpy(self._h, float(beta), a.ctypes.data_as(L.c_double_p), arr, nv))
 
     def getArray(self):
-        """Host mirror as a numpy view (call syncToDevice after writing)."""
+        """The vector's data as a numpy view of its pinned host mirror, LIVE as in the reference (ParOptVec::getArray):
+        writes through the view are seen by every later operation on the vector and results of operations show
+        up in the view (po_vec_get_array); releaseArray() ends that state."""
         p = L.c_double_p()
         check(lib.po_vec_get_array(self._h, C.byref(p)))
         n = len(self)
         if n == 0:
             return np.zeros(0)
         return np.ctypeslib.as_array(p, shape=(n,))
+
+    def _peek(self):
+        p = L.c_double_p()
+        check(lib.po_vec_peek_array(self._h, C.byref(p)))
+        n = len(self)
+        return np.ctypeslib.as_array(p, shape=(n,)) if n else np.zeros(0)
+
+    def releaseArray(self, upload=True):
+        """End the live state of the host mirror getArray() handed out (final upload unless upload=False).
+        Required for vectors the solver owns before the solver runs on (po_vec_release_array)."""
+        check(lib.po_vec_release_array(self._h, int(bool(upload))))
 
     def syncToDevice(self):
         check(lib.po_vec_sync_to_device(self._h))
@@ -235,12 +248,10 @@ class PVec:
 
     # -- conveniences --------------------------------------------------------------------------
     def to_numpy(self):
-        a = self.getArray()
-        self.syncToHost()
-        return np.array(a, copy=True)
+        return np.array(self._peek(), copy=True)
 
     def from_numpy(self, arr):
-        a = self.getArray()
+        a = self._peek()
         a[:] = arr
         self.syncToDevice()
         return self
@@ -357,7 +368,7 @@ class Problem:
             vx, vl, vu = (PVec(ctx, handle=L.po_vec(h), owned=False) for h in (x, lb, ub))
             ax, al, au = vx.getArray(), vl.getArray(), vu.getArray()
             fail = self.getVarsAndBounds(ax, al, au)
-            vx.syncToDevice(), vl.syncToDevice(), vu.syncToDevice()
+            vx.releaseArray(True), vl.releaseArray(True), vu.releaseArray(True)
             return int(fail or 0)
 
         @_guard
@@ -378,9 +389,9 @@ class Problem:
             ag = vg.getArray()
             aa = [v.getArray() for v in va] if Ac else None
             fail = self.evalObjConGradient(vx.to_numpy(), ag, aa)
-            vg.syncToDevice()
+            vg.releaseArray(True)
             for v in va:
-                v.syncToDevice()
+                v.releaseArray(True)
             return int(fail or 0)
 
         self._cbs = (L.GET_VARS_FN(_gvb), L.EVAL_FN(_eval), L.GRAD_FN(_grad))
@@ -411,7 +422,7 @@ class Problem:
                 vh = PVec(ctx, handle=L.po_vec(hvec), owned=False)
                 ah = vh.getArray()
                 fail = self.evalHvecProduct(xa, za, zwa, vp.to_numpy(), ah)
-                vh.syncToDevice()
+                vh.releaseArray(True)
                 return int(fail or 0)
 
             @_guard
@@ -420,7 +431,7 @@ class Problem:
                 vh = PVec(ctx, handle=L.po_vec(hdiag), owned=False)
                 ah = vh.getArray()
                 fail = self.evalHessianDiag(xa, za, zwa, ah)
-                vh.syncToDevice()
+                vh.releaseArray(True)
                 return int(fail or 0)
 
             self._hcbs = (L.HVEC_FN(_hvec) if has_hvec else L.HVEC_FN(), L.HDIAG_FN(_hdiag) if has_hdiag else L.HDIAG_FN())
@@ -439,7 +450,7 @@ class Problem:
                 vs = PVec(ctx, handle=L.po_vec(sparse), owned=False)
                 asp = vs.getArray()
                 fail, f, con = self.evalSparseObjCon(vx.to_numpy(), asp)
-                vs.syncToDevice()
+                vs.releaseArray(True)
                 fobj[0] = float(f)
                 for j in range(self.ncon):
                     cons[j] = float(con[j])
@@ -453,9 +464,9 @@ class Problem:
                 ag = vg.getArray()
                 aa = [v.getArray() for v in va]
                 fail = self.evalSparseObjConGradient(vx.to_numpy(), ag, aa, self._data_host[:nnz])
-                vg.syncToDevice()
+                vg.releaseArray(True)
                 for v in va:
-                    v.syncToDevice()
+                    v.releaseArray(True)
                 check(lib.po_ctx_memcpy(ctx.handle, data, self._data_host.ctypes.data, 8 * nnz, 1))
                 return int(fail or 0)
 
@@ -471,9 +482,8 @@ class Problem:
                     vv = PVec(ctx, handle=L.po_vec(v), owned=False)
                     vo = PVec(ctx, handle=L.po_vec(out), owned=False)
                     ao = vo.getArray()
-                    vo.syncToHost()
                     fail = method(float(alpha), vx.to_numpy(), vv.to_numpy(), ao)
-                    vo.syncToDevice()
+                    vo.releaseArray(True)
                     return int(fail or 0)
                 return _f
 
@@ -483,7 +493,7 @@ class Problem:
                 vo = PVec(ctx, handle=L.po_vec(out), owned=False)
                 ao = vo.getArray()
                 fail = self.evalSparseCon(vx.to_numpy(), ao)
-                vo.syncToDevice()
+                vo.releaseArray(True)
                 return int(fail or 0)
 
             scb = L.ProblemSparseCallbacks()

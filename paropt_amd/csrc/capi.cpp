@@ -72,6 +72,22 @@ int po_live_objects(int64_t *vectors, int64_t *bytes) {
   if (bytes) *bytes = b;
   return PO_OK;
 }
+int po_device_count(int *count) {
+  PO_CHECK_PTR(count);
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return PO_OK;
+}
+int po_options_visit_defaults(int which, po_option_visitor fn, void *user) {
+  PO_CHECK_PTR(fn);
+  po::Options o;  // the interior-point registry
+  po::Options base;
+  if (which == 1) o.addTrustRegionDefaults();
+  if (which == 2) o.addMMADefaults();
+  if (which < 0 || which > 2) return PO_ERR_ARG;
+  return o.visit(which == 0 ? nullptr : &base, fn, user);
+}
 int po_live_host_mirrors(int64_t *mirrors) {
   if (mirrors) *mirrors = po::live_mirrors();
   return PO_OK;
@@ -142,6 +158,19 @@ int po_ctx_comm_init_callback(po_ctx ctx, int rank, int size, po_allgather_fn fn
 }
 
 // ---- vectors ------------------------------------------------------------------------------------
+// getArray contract (src/ParOptVec.cpp:212-217: the pointer IS the data).  While a mirror is live, reads through
+// the ABI see what the host wrote and results of ABI operations are visible through the pointer at once.
+static int mirror_up(Vec *v) {
+  if (!v || !v->h_live || !v->h || v->n <= 0) return PO_OK;
+  PO_HIP(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->n, hipMemcpyHostToDevice, v->ctx->stream));
+  return PO_OK;  // stream-ordered before the kernels that follow
+}
+static int mirror_down(Vec *v) {
+  if (!v || !v->h_live || !v->h || v->n <= 0) return PO_OK;
+  PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
+  PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  return PO_OK;
+}
 int po_vec_create(po_ctx ctx, int64_t nlocal, po_vec *out) {
   PO_CHECK_PTR(ctx);
   PO_CHECK_PTR(out);
@@ -170,33 +199,44 @@ int po_vec_size(po_vec v, int64_t *nlocal) {
 }
 int po_vec_set(po_vec v, double alpha) {
   PO_CHECK_PTR(v);
-  return k_fill(v->ctx, v->d, v->n, alpha);
+  PO_TRY(k_fill(v->ctx, v->d, v->n, alpha));
+  return mirror_down(v);
 }
 int po_vec_zero(po_vec v) {
   PO_CHECK_PTR(v);
-  return k_fill(v->ctx, v->d, v->n, 0.0);
+  PO_TRY(k_fill(v->ctx, v->d, v->n, 0.0));
+  return mirror_down(v);
 }
 int po_vec_copy(po_vec dst, po_vec src) {
   PO_CHECK_PTR(dst);
   PO_CHECK_PTR(src);
   PO_TRY(same_layout(dst, src));
-  return k_copy(dst->ctx, dst->d, src->d, dst->n);
+  PO_TRY(mirror_up(src));
+  PO_TRY(k_copy(dst->ctx, dst->d, src->d, dst->n));
+  return mirror_down(dst);
 }
 int po_vec_scale(po_vec v, double alpha) {
   PO_CHECK_PTR(v);
-  return k_scale(v->ctx, v->d, v->n, alpha);
+  PO_TRY(mirror_up(v));
+  PO_TRY(k_scale(v->ctx, v->d, v->n, alpha));
+  return mirror_down(v);
 }
 int po_vec_axpy(po_vec y, double alpha, po_vec x) {
   PO_CHECK_PTR(y);
   PO_CHECK_PTR(x);
   PO_TRY(same_layout(y, x));
-  return k_axpy(y->ctx, y->d, alpha, x->d, y->n);
+  PO_TRY(mirror_up(x));
+  PO_TRY(mirror_up(y));
+  PO_TRY(k_axpy(y->ctx, y->d, alpha, x->d, y->n));
+  return mirror_down(y);
 }
 int po_vec_dot(po_vec x, po_vec y, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(y);
   PO_CHECK_PTR(out);
   PO_TRY(same_layout(x, y));
+  PO_TRY(mirror_up(x));
+  PO_TRY(mirror_up(y));
   return k_reduce1(x->ctx, RED_DOT, x->d, y->d, x->n, out);
 }
 int po_vec_mdot(po_vec x, const po_vec *vecs, int nvecs, double *out) {
@@ -208,8 +248,10 @@ int po_vec_mdot(po_vec x, const po_vec *vecs, int nvecs, double *out) {
   for (int j = 0; j < nvecs; j++) {
     PO_CHECK_PTR(vecs[j]);
     PO_TRY(same_layout(x, vecs[j]));
+    PO_TRY(mirror_up(vecs[j]));
     p[j] = vecs[j]->d;
   }
+  PO_TRY(mirror_up(x));
   // wider panels than one kernel accepts are processed in slabs
   int j0 = 0;
   while (j0 < nvecs) {
@@ -223,6 +265,7 @@ int po_vec_norm(po_vec x, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(out);
   double ss = 0.0;
+  PO_TRY(mirror_up(x));
   PO_TRY(k_reduce1(x->ctx, RED_SUMSQ, x->d, nullptr, x->n, &ss));
   *out = sqrt(ss);
   return PO_OK;
@@ -230,22 +273,52 @@ int po_vec_norm(po_vec x, double *out) {
 int po_vec_maxabs(po_vec x, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(out);
+  PO_TRY(mirror_up(x));
   return k_reduce1(x->ctx, RED_AMAX, x->d, nullptr, x->n, out);
 }
 int po_vec_l1norm(po_vec x, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(out);
+  PO_TRY(mirror_up(x));
   return k_reduce1(x->ctx, RED_ASUM, x->d, nullptr, x->n, out);
+}
+static int ensure_mirror(po_vec v) {
+  if (!v->h) {
+    PO_HIP(hipHostMalloc((void **)&v->h, sizeof(double) * (size_t)(v->n > 0 ? v->n : 1), hipHostMallocDefault));
+    po::mirror_created();
+  }
+  return PO_OK;
 }
 int po_vec_get_array(po_vec v, double **host) {
   PO_CHECK_PTR(v);
   PO_CHECK_PTR(host);
-  if (!v->h) {
-    PO_HIP(hipHostMalloc((void **)&v->h, sizeof(double) * (size_t)(v->n > 0 ? v->n : 1), hipHostMallocDefault));
-    po::mirror_created();
-    PO_TRY(po_vec_sync_to_host(v));
+  PO_TRY(ensure_mirror(v));
+  if (!v->h_live) {  // first hand-out since the last release: bring the mirror up to date, then it is live
+    PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
+    PO_HIP(hipStreamSynchronize(v->ctx->stream));
+    v->h_live = 1;
   }
   *host = v->h;
+  return PO_OK;
+}
+int po_vec_peek_array(po_vec v, double **host) {
+  PO_CHECK_PTR(v);
+  PO_CHECK_PTR(host);
+  PO_TRY(ensure_mirror(v));
+  if (!v->h_live) {
+    PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
+    PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  }
+  *host = v->h;
+  return PO_OK;
+}
+int po_vec_release_array(po_vec v, int upload) {
+  PO_CHECK_PTR(v);
+  if (v->h_live && upload) {
+    PO_HIP(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->n, hipMemcpyHostToDevice, v->ctx->stream));
+    PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  }
+  v->h_live = 0;
   return PO_OK;
 }
 int po_vec_sync_to_device(po_vec v) {
@@ -255,12 +328,9 @@ int po_vec_sync_to_device(po_vec v) {
   PO_HIP(hipStreamSynchronize(v->ctx->stream));
   return PO_OK;
 }
-int po_vec_sync_to_host(po_vec v) {
+int po_vec_sync_to_host(po_vec v) {  // a read-only download: does not make the mirror live
   PO_CHECK_PTR(v);
-  if (!v->h) {
-    double *h;
-    return po_vec_get_array(v, &h);
-  }
+  PO_TRY(ensure_mirror(v));
   PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
   PO_HIP(hipStreamSynchronize(v->ctx->stream));
   return PO_OK;
@@ -281,14 +351,18 @@ int po_vec_maxpy(po_vec y, double beta, const double *alpha, const po_vec *vecs,
   for (int j = 0; j < nvecs; j++) {
     PO_CHECK_PTR(vecs[j]);
     PO_TRY(same_layout(y, vecs[j]));
+    PO_TRY(mirror_up(vecs[j]));
     p[j] = vecs[j]->d;
   }
-  return k_panel_axpy(y->ctx, y->d, 0.0, nullptr, beta, alpha, p.data(), nvecs, y->n);
+  PO_TRY(mirror_up(y));
+  PO_TRY(k_panel_axpy(y->ctx, y->d, 0.0, nullptr, beta, alpha, p.data(), nvecs, y->n));
+  return mirror_down(y);
 }
 int po_vec_fill_hash(po_vec v, uint64_t seed, uint64_t array_id, int64_t offset, double scale,
                      double shift) {
   PO_CHECK_PTR(v);
-  return k_fill_hash(v->ctx, v->d, v->n, seed, array_id, offset, scale, shift);
+  PO_TRY(k_fill_hash(v->ctx, v->d, v->n, seed, array_id, offset, scale, shift));
+  return mirror_down(v);
 }
 
 // ---- quasi-Newton -------------------------------------------------------------------------------
@@ -335,17 +409,28 @@ int po_qn_update(po_qn qn, po_vec s, po_vec y, int *rc) {
   PO_CHECK_PTR(s);
   PO_CHECK_PTR(y);
   int r = 0;
+  PO_TRY(mirror_up(s));
+  PO_TRY(mirror_up(y));
   PO_TRY(qn->qn->update(s, y, &r));
   if (rc) *rc = r;
   return PO_OK;
 }
 int po_qn_mult(po_qn qn, po_vec x, po_vec y) {
   PO_CHECK_PTR(qn);
-  return qn->qn->mult(x, y);
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(y);
+  PO_TRY(mirror_up(x));
+  PO_TRY(qn->qn->mult(x, y));
+  return mirror_down(y);
 }
 int po_qn_mult_add(po_qn qn, double alpha, po_vec x, po_vec y) {
   PO_CHECK_PTR(qn);
-  return qn->qn->multAdd(alpha, x, y);
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(y);
+  PO_TRY(mirror_up(x));
+  PO_TRY(mirror_up(y));
+  PO_TRY(qn->qn->multAdd(alpha, x, y));
+  return mirror_down(y);
 }
 int po_qn_get_compact(po_qn qn, int *size, double *b0, const double **d0, const double **M,
                       const po_vec **Z) {
@@ -639,17 +724,29 @@ int po_problem_sizes(po_problem p, int64_t *nlocal, int64_t *offset, int *ncon) 
 }
 int po_problem_eval_obj_con(po_problem p, po_vec x, double *fobj, double *cons) {
   PO_CHECK_PTR(p);
+  PO_CHECK_PTR(x);
+  PO_TRY(mirror_up(x));
   return p->p->evalObjCon(x, fobj, cons);
 }
 int po_problem_eval_obj_con_gradient(po_problem p, po_vec x, po_vec g, const po_vec *Ac) {
   PO_CHECK_PTR(p);
+  PO_CHECK_PTR(x);
+  PO_CHECK_PTR(g);
   std::vector<Vec *> a(p->p->ncon > 0 ? p->p->ncon : 1);
   for (int j = 0; j < p->p->ncon; j++) a[j] = Ac[j];
-  return p->p->evalObjConGradient(x, g, a.data());
+  PO_TRY(mirror_up(x));
+  int rc = p->p->evalObjConGradient(x, g, a.data());
+  PO_TRY(mirror_down(g));
+  for (int j = 0; j < p->p->ncon; j++) PO_TRY(mirror_down(a[j]));
+  return rc;
 }
 int po_problem_get_vars_and_bounds(po_problem p, po_vec x, po_vec lb, po_vec ub) {
   PO_CHECK_PTR(p);
-  return p->p->getVarsAndBounds(x, lb, ub);
+  int rc = p->p->getVarsAndBounds(x, lb, ub);
+  PO_TRY(mirror_down(x));
+  PO_TRY(mirror_down(lb));
+  PO_TRY(mirror_down(ub));
+  return rc;
 }
 
 // ---- interior point -----------------------------------------------------------------------------

@@ -79,7 +79,9 @@ struct Vec {
   int64_t n;
   double *d;
   int ref;
-  double *h;  // pinned host mirror (lazy)
+  double *h;       // pinned host mirror (lazy)
+  int h_live = 0;  // the mirror has been handed out (po_vec_get_array) and is the authoritative copy: every
+                   // C-ABI operation on the vector uploads it first / downloads the result (po_vec_release_array)
 };
 
 // A small table of raw device pointers passed by value as a kernel argument.

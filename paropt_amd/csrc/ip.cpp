@@ -1244,6 +1244,13 @@ void InteriorPoint::getIterationCounters(int *a, int *b, int *d) {
 }
 
 int InteriorPoint::optimize(const char *checkpoint) {
+  // host mirrors a caller obtained for the solver's vectors (getOptimizedPoint + getArray) stop being live here:
+  // the kernels below do not look at mirrors (po_vec_get_array)
+  {
+    Vec *mine[] = {x, zl, zu, wvar[0], wvar[1], wvar[2], wvar[3], wvar[4]};
+    for (Vec *v : mine)
+      if (v) v->h_live = 0;
+  }
   PO_TRY(createQuasiNewton());
   const double abs_res_tol = options.real("abs_res_tol");
   const double rel_func_tol = options.real("rel_func_tol");

@@ -36,6 +36,8 @@ class Options {
   int integer(const char *name) const;
   double real(const char *name) const;
   bool has(const char *name) const { return e.count(name) > 0; }
+  // calls fn for every entry that `skip` (may be null) does not hold: po_options_visit_defaults
+  int visit(const Options *skip, po_option_visitor fn, void *user) const;
 
  private:
   std::map<std::string, Entry> e;

@@ -277,6 +277,17 @@ int Options::set(const char *name, double value) {
   x.f = value;
   return PO_OK;
 }
+int Options::visit(const Options *skip, po_option_visitor fn, void *user) const {
+  for (const auto &kv : e) {
+    if (skip && skip->has(kv.first.c_str())) continue;
+    const Entry &x = kv.second;
+    std::vector<const char *> ch;
+    for (const std::string &c : x.choices) ch.push_back(c.c_str());
+    fn(user, kv.first.c_str(), (int)x.type, x.s.c_str(), x.i, x.ilo, x.ihi, x.f, x.flo, x.fhi, (int)ch.size(),
+       ch.empty() ? nullptr : ch.data());
+  }
+  return PO_OK;
+}
 const char *Options::str(const char *name) const { return e.at(name).s.c_str(); }
 int Options::integer(const char *name) const { return e.at(name).i; }
 double Options::real(const char *name) const { return e.at(name).f; }

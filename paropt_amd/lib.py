@@ -85,6 +85,10 @@ SIGNATURES = {
     "po_ctx_counters": (C.c_int, [po_ctx, c_i64_p, c_i64_p]),
     "po_live_objects": (C.c_int, [c_i64_p, c_i64_p]),
     "po_live_host_mirrors": (C.c_int, [c_i64_p]),
+    "po_device_count": (C.c_int, [c_int_p]),
+    "po_options_visit_defaults": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "po_vec_release_array": (C.c_int, [po_vec, C.c_int]),
+    "po_vec_peek_array": (C.c_int, [po_vec, C.POINTER(c_double_p)]),
     "po_ctx_time_mdot": (C.c_int, [po_ctx, C.c_int]),
     "po_ctx_time_mdot_result": (C.c_int, [po_ctx, c_double_p, c_i64_p]),
     "po_ctx_time_wgram": (C.c_int, [po_ctx, C.c_int]),

@@ -24,6 +24,172 @@ def build(tmp_path, name="rosenbrock_amd"):
     return exe
 
 
+REF_EXAMPLE = "/root/reference/examples/rosenbrock/rosenbrock.cpp"
+EXAMPLE_AMD = os.path.join(ROOT, "oracle", "_ref", "rosenbrock_example_amd")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXAMPLE), reason="the reference tree is only present in the build container")
+def test_reference_example_recompiles_unchanged(tmp_path):
+    """The reference's own example program -- /root/reference/examples/rosenbrock/rosenbrock.cpp, not a copy and not
+    edited -- compiles with -Werror-free g++ against include/paropt_compat/ (the reference's header names, MPI_Comm
+    communicators) and links against libparopt_amd.so + MPI: the problem class (getArray-style host code, MPI
+    reductions, sparse constraints, createQuasiDefMat), ParOptOptions, ParOptOptimizer::addDefaultOptions and the
+    whole main() are used as they are."""
+    exe = str(tmp_path / "rosenbrock_example_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-w", "-I" + os.path.join(ROOT, "include", "paropt_compat"),
+           "-I/opt/conda/include", REF_EXAMPLE, "-o", exe, "-static-libstdc++", "-static-libgcc",
+           "-L" + os.path.join(ROOT, "paropt_amd"), "-lparopt_amd", "-Wl,-rpath," + os.path.join(ROOT, "paropt_amd"),
+           "/opt/conda/lib/libmpi.so", "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath,/opt/conda/lib"]
+    subprocess.check_call(cmd)
+    import torch
+
+    if not torch.cuda.is_available():  # no GPU here: the program must say so instead of computing on the CPU
+        res = subprocess.run([exe], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+        assert "no CPU fallback" in res.stderr or "no HIP device" in res.stderr
+
+
+def parse_tr_table(text):
+    rows, infos = [], []
+    for ln in text.splitlines():
+        parts = ln.split()
+        if len(parts) >= 14 and parts[0].isdigit():
+            rows.append([float(v) for v in parts[:13]])
+            infos.append(" ".join(parts[14:]))
+    return np.array(rows), infos
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(EXAMPLE_AMD), reason="prebuilt by oracle/Makefile in the build container")
+def test_reference_example_program_reproduces_reference_run(tmp_path):
+    """The unchanged reference example built against the product (oracle/Makefile target rosenbrock_example_amd)
+    runs on the GPU under MPI_Init / MPI_COMM_WORLD and writes the same trust-region table as the same source file
+    built against the reference library (tests/golden/example_rosenbrock.npz): iteration count, accept/reject
+    pattern and the printed columns to print precision."""
+    res = subprocess.run([EXAMPLE_AMD], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "ParOpt time" in res.stdout
+    rows, infos = parse_tr_table(open(str(tmp_path / "paropt.tr")).read())
+    g = np.load(os.path.join(ROOT, "tests", "golden", "example_rosenbrock.npz"))
+    ref = g["table"]
+    assert rows.shape == ref.shape, (rows.shape, ref.shape)
+    # iter, fobj, infeas, l1, linfty, |x - xk|, tr, rho, mod red., avg z, max z, avg pen., max pen.
+    np.testing.assert_array_equal(rows[:, 0], ref[:, 0])
+    np.testing.assert_allclose(rows[:, 1], ref[:, 1], rtol=2e-5)            # fobj, 6 printed digits
+    np.testing.assert_allclose(rows[:, 6], ref[:, 6], rtol=1e-2)            # trust-region radius
+    np.testing.assert_allclose(rows[:, 9:13], ref[:, 9:13], rtol=2e-2, atol=1e-2)
+    for col in (2, 3, 4, 5, 7, 8):  # three printed digits; tiny late values are round-off
+        np.testing.assert_allclose(rows[:, col], ref[:, col], rtol=3e-2, atol=1e-5)
+    assert os.path.exists(str(tmp_path / "paropt.out"))
+
+
+def test_getarray_pointer_is_the_data(tmp_path):
+    """src/ParOptVec.cpp:212-217: no sync call between writes through the getArray pointer and the vector
+    operations, in either direction (compile-time check of the abstract ParOptVec interface as well)."""
+    src = tmp_path / "live.cpp"
+    src.write_text(r"""
+#include "ParOptAMD.hpp"
+struct P : public ParOptProblem {
+  P(po_ctx c) : ParOptProblem(c) { setProblemSizes(1000, 0, 0); }
+  void getVarsAndBounds(ParOptVec *, ParOptVec *, ParOptVec *) {}
+  int evalObjCon(ParOptVec *, ParOptScalar *, ParOptScalar *) { return 0; }
+  int evalObjConGradient(ParOptVec *, ParOptVec *, ParOptVec **) { return 0; }
+};
+int main() {
+  po_ctx ctx = NULL;
+  if (po_ctx_create(0, &ctx) != 0) return 2;
+  P *p = new P(ctx);
+  p->incref();
+  ParOptVec *x = p->createDesignVec(), *y = p->createDesignVec();  // the abstract type with its 11 virtuals
+  x->incref();
+  y->incref();
+  ParOptScalar *xa, *ya;
+  int n = x->getArray(&xa);
+  y->getArray(&ya);
+  for (int i = 0; i < n; i++) xa[i] = 1.0 + i;          // written through the pointer ...
+  double s = 0.0;
+  for (int i = 0; i < n; i++) s += (1.0 + i) * (1.0 + i);
+  int bad = 0;
+  bad |= fabs(x->norm() - sqrt(s)) > 1e-9;              // ... seen by the device reduction without a sync
+  y->copyValues(x);                                      // device result ...
+  bad |= (ya[10] != 11.0) << 1;                          // ... visible through the pointer taken before
+  y->scale(2.0);
+  xa[0] = 100.0;
+  y->axpy(1.0, x);
+  bad |= (ya[0] != 102.0 || ya[999] != 3000.0) << 2;
+  x->zeroEntries();
+  bad |= (xa[5] != 0.0) << 3;
+  ParOptVec *vs[2] = {x, y};
+  ParOptScalar d[2];
+  xa[1] = 1.0;
+  y->mdot(vs, 2, d);
+  bad |= (d[0] != ya[1]) << 4;
+  printf("bad=%d\n", bad);
+  return bad;
+}
+""")
+    exe = str(tmp_path / "live")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-L" + os.path.join(ROOT, "paropt_amd"), "-lparopt_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "paropt_amd"), "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    import torch
+
+    if torch.cuda.is_available():
+        res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stdout + res.stderr
+
+
+def test_options_registry_semantics(tmp_path):
+    """ParOptOptions of the facade (src/ParOptOptions.h:9-61): typed getters, immediate validation, ranges, the
+    three addDefaultOptions entry points -- host only, runs without a GPU."""
+    src = tmp_path / "opts.cpp"
+    src.write_text(r"""
+#include "ParOptAMD.hpp"
+int main() {
+  ParOptOptions *o = new ParOptOptions();
+  o->incref();
+  ParOptOptimizer::addDefaultOptions(o);
+  int bad = 0, k = 0;
+  bad |= (o->getOptionType("algorithm") != ParOptOptions::PAROPT_ENUM_OPTION) << k++;
+  bad |= (strcmp(o->getEnumOption("algorithm"), "tr") != 0) << k++;
+  bad |= (o->getStringOption("ip_checkpoint_file") != NULL) << k++;
+  bad |= (o->getIntOption("qn_subspace_size") != 10) << k++;
+  bad |= (o->getFloatOption("abs_res_tol") != 1e-6) << k++;
+  bad |= (o->getBoolOption("use_line_search") != 1) << k++;
+  bad |= (o->setOption("qn_subspace_size", 100000) == 0) << k++;      // out of range: refused at once
+  bad |= (o->getIntOption("qn_subspace_size") != 10) << k++;
+  bad |= (o->setOption("abs_res_tol", 3) == 0) << k++;                // wrong type
+  bad |= (o->setOption("qn_type", "newton") == 0) << k++;             // not in the enumeration
+  bad |= (o->setOption("no_such_option", 1.0) == 0) << k++;
+  bad |= (o->setOption("qn_type", "sr1") != 0 || strcmp(o->getEnumOption("qn_type"), "sr1") != 0) << k++;
+  bad |= (o->setOption("tr_max_size", 2.0) != 0 || o->getFloatOption("tr_max_size") != 2.0) << k++;
+  bad |= (o->setOption("mma_max_iterations", 7) != 0 || o->getIntOption("mma_max_iterations") != 7) << k++;
+  int lo = 0, hi = 0, ne = 0;
+  const char *const *vals = NULL;
+  bad |= (o->getIntRange("max_line_iters", &lo, &hi) != 0 || lo != 1 || hi != 100) << k++;
+  bad |= (o->getEnumRange("barrier_strategy", &ne, &vals) != 0 || ne != 4) << k++;
+  bad |= (o->isOption("penalty_gamma") != 1 || o->isOption("nope") != 0) << k++;
+  int count = 0;
+  o->begin();
+  do { count += o->getName() != NULL; } while (o->next());
+  bad |= (count < 80) << k++;
+  ParOptOptions *ip = new ParOptOptions();
+  ip->incref();
+  ParOptInteriorPoint::addDefaultOptions(ip);
+  bad |= (ip->isOption("tr_max_size") != 0 || ip->isOption("barrier_strategy") != 1) << k++;
+  printf("bad=%d count=%d\n", bad, count);
+  ip->decref();
+  o->decref();
+  return bad != 0;
+}
+""")
+    exe = str(tmp_path / "opts")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src),
+                           "-L" + os.path.join(ROOT, "paropt_amd"), "-lparopt_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "paropt_amd"), "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+
+
 def test_facade_compiles_and_fails_loudly_without_gpu(tmp_path):
     import torch
 
