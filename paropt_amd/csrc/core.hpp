@@ -104,6 +104,7 @@ int k_fill(Ctx *c, double *y, int64_t n, double alpha);
 int k_fill_hash(Ctx *c, double *y, int64_t n, uint64_t seed, uint64_t aid, int64_t offset,
                 double scale, double shift);
 int k_copy(Ctx *c, double *y, const double *x, int64_t n);
+int k_sign(Ctx *c, double *y, const double *x, int64_t n);  // y_i = x_i >= 0 ? 1 : -1
 int k_scale(Ctx *c, double *y, int64_t n, double alpha);
 int k_axpy(Ctx *c, double *y, double alpha, const double *x, int64_t n);
 // y <- a*x + b*y + sum_j alpha[j]*V[j]   (x may be null when a == 0; b == 0 never reads y)
@@ -194,6 +195,10 @@ int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const d
 int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
                const double *pzu, const double *dinv, const double *coef, const double *const *P,
                int nv, double diag, double beta_mu, int64_t n, double *tprime);
+// checkKKTStep :6212-6360: out = {max|r'x|, max|r'zl|, max|r'zu|} of the linearised KKT residual at the step
+int k_step_check(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl, const double *pzu,
+                 const double *coef, const double *const *P, int nv, double diag, double beta_mu, int64_t n,
+                 double out[3]);
 // computeCompStep :2825-2923 at (x + ax*px, zl + az*pzl, zu + az*pzu): out = {product, count}
 int k_comp_step(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 double ax, double az, int64_t n, double out[2]);

@@ -779,6 +779,63 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
   return PO_OK;
 }
 
+int InteriorPoint::checkKKTStep(int iteration, double mu) {
+  const double beta_mu = options.real("rel_bound_barrier") * mu;
+  const bool seq_lin = options.integer("sequential_linear_method");
+  int kq = 0;
+  std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
+  const int mq = c + kq;
+  std::vector<double> dots(mq > 0 ? mq : 1, 0.0), coef(mq > 0 ? mq : 1, 0.0);
+  if (mq > 0) PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));  // explicit: this is a check
+  for (int i = 0; i < c; i++) coef[i] = step.z[i];
+  double diag = options.real("qn_sigma");
+  if (qn && !seq_lin && !options.integer("use_diag_hessian")) {
+    diag += qn->diag();
+    if (kq > 0) {
+      std::vector<double> rz(dots.begin() + c, dots.begin() + c + kq);
+      qn->applyCompactInverse(rz.data());
+      for (int j = 0; j < kq; j++) coef[c + j] = rz[j];
+    }
+  }
+  if (has_w) {  // the sparse multiplier step enters r'x through Aw^T pzw: one more column
+    PO_TRY(k_fill(ctx, xt->d, n, 0.0));
+    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
+    Pq.push_back(xt->d);
+    coef.push_back(1.0);
+  }
+  double mx[3];
+  PO_TRY(computeResidual(mu, true));  // fresh rx, as the reference recomputes it (:6216)
+  PO_TRY(k_step_check(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, coef.data(), Pq.data(), (int)Pq.size(), diag,
+                      beta_mu, n, mx));
+  Dense r;
+  r.resize(c);
+  denseResidual(mu, r);
+  double mz = 0.0, ms = 0.0, mt = 0.0, mzs = 0.0, mzt = 0.0;
+  for (int i = 0; i < c; i++) {  // addKKTResStep dense rows :1529-1535
+    mz = std::max(mz, fabs(r.z[i] - (dots[i] - step.s[i] + step.t[i])));
+    ms = std::max(ms, fabs(r.s[i] + (step.zs[i] - step.z[i])));
+    mt = std::max(mt, fabs(r.t[i] + (step.zt[i] + step.z[i])));
+    mzs = std::max(mzs, fabs(r.zs[i] - (step.s[i] * vars.zs[i] + vars.s[i] * step.zs[i])));
+    mzt = std::max(mzt, fabs(r.zt[i] - (step.t[i] * vars.zt[i] + vars.t[i] * step.zt[i])));
+  }
+  if (ctx->rank == 0) {
+    char line[640];
+    snprintf(line, sizeof(line),
+             "\nResidual step check for iteration %d:\n"
+             "max |stationarity (x block)|:             %10.4e\n"
+             "max |dense constraints (z block)|:        %10.4e\n"
+             "max |slack duals (s block)|:              %10.4e\n"
+             "max |slack duals (t block)|:              %10.4e\n"
+             "max |slack complementarity (zs block)|:   %10.4e\n"
+             "max |slack complementarity (zt block)|:   %10.4e\n"
+             "max |lower-bound complementarity (zl)|:   %10.4e\n"
+             "max |upper-bound complementarity (zu)|:   %10.4e\n",
+             iteration, mx[0], mz, ms, mt, mzs, mzt, mx[1], mx[2]);
+    history += line;
+  }
+  return PO_OK;
+}
+
 int InteriorPoint::debugKKTStep(double mu) {
   PO_TRY(createQuasiNewton());
   PO_TRY(computeResidual(mu, true));
@@ -1286,6 +1343,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const double min_frac = options.real("min_fraction_to_boundary");
   const bool use_line_search = options.integer("use_line_search");
   const int write_freq = options.integer("write_output_frequency");
+  const int step_verification_frequency = options.integer("step_verification_frequency");
+  const int gradient_verification_frequency = options.integer("gradient_verification_frequency");
   const std::string start = options.str("starting_point_strategy");
   niter = neval = ngeval = nhvec = 0;
   residual_cached = false;
@@ -1354,6 +1413,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
       prob->writeOutput(k, x);
     }
     if (iter_cb) iter_cb(iter_cb_user, k);
+    // gradient_verification_frequency (:4522-4525, 4635-4639): finite-difference check of the user's gradients
+    if (gradient_verification_frequency > 0 && (k % gradient_verification_frequency) == 0) {
+      std::string rep;
+      PO_TRY(prob->checkGradients(options.real("gradient_check_step_length"), x, use_hvec_product, xt, tvec, &rep));
+      if (ctx->rank == 0) history += rep;
+    }
 
     const bool rel_function_test =
         (alpha_xprev == 1.0 && alpha_zprev == 1.0 && (fabs(fobj - fobj_prev) < rel_func_tol * fabs(fobj_prev)));
@@ -1563,6 +1628,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
     }
     }
     phaseEnd("kkt_step");
+    // step_verification_frequency (:5056-5073): block maxima of the linearised KKT residual at the step
+    if (step_verification_frequency > 0 && (k % step_verification_frequency) == 0 && !inexact_newton_step) {
+      if (barrier_strategy == B_MPC && ctx->rank == 0)
+        history += "Note: the step check is inconsistent with the predictor-corrector step (corrector terms)\n";
+      PO_TRY(checkKKTStep(k, barrier_param));
+    }
 
     double alpha_x = 1.0, alpha_z = 1.0;
     int ceq_step = 0;

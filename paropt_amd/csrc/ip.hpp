@@ -65,6 +65,9 @@ class InteriorPoint {
   Vec *upperBounds() { return ub; }
   int checkFlag() const { return check_flag; }
   int clampCounts(double out[8]);
+  // checkKKTStep (:6212-6360), step_verification_frequency: appends the block maxima of the linearised KKT
+  // residual at the current (unscaled) step to the iteration history
+  int checkKKTStep(int iteration, double mu);
 
   Options options;
   int optimize(const char *checkpoint);

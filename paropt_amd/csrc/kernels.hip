@@ -193,6 +193,19 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// y_i = +1 where x_i >= 0, else -1 (the step direction of checkGradients, src/ParOptProblem.cpp:262-270)
+__global__ void __launch_bounds__(kBlock)
+    sign_kernel(double *__restrict__ y, const double *__restrict__ x, int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    const double2 v = ld2(x, q, n);
+    st2(y, q, n, make_double2(v.x >= 0.0 ? 1.0 : -1.0, v.y >= 0.0 ? 1.0 : -1.0));
+  }
+}
+int k_sign(Ctx *c, double *y, const double *x, int64_t n) {
+  if (n <= 0) return PO_OK;
+  PO_LAUNCH(sign_kernel, grid_for(c, n), y, x, n);
+  return PO_OK;
+}
 int k_fill(Ctx *c, double *y, int64_t n, double a) {
   if (n <= 0) return PO_OK;
   PO_LAUNCH(fill_kernel, grid_for(c, n), y, n, a);
@@ -1114,6 +1127,45 @@ __global__ void __launch_bounds__(kBlock)
                                    b.use_upper)));
   }
 }
+// checkKKTStep (src/ParOptInteriorPoint.cpp:6212-6360): maxima of the three n-sized blocks of the residual of the
+// linearised KKT system at the computed step: r'x = rx - diag px + sum coef_j P_j + [L]pzl - [U]pzu,
+// r'zl = -((x-lb) zl - beta mu) - ((x-lb) pzl + px zl), r'zu likewise
+__global__ void __launch_bounds__(kBlock)
+    step_check_kernel(Bounds b, const double *__restrict__ rx, const double *__restrict__ px,
+                      const double *__restrict__ pzl, const double *__restrict__ pzu, CoefTable coef, PtrTable P,
+                      int nv, double diag, double beta_mu, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4 * 3];
+  double mx[3] = {0.0, 0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 acc = panel_sum(P, coef, nv, q);
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 r = ld2(rx, q, n), p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    const BE es[2] = {e0, e1};
+    const double rr[2] = {r.x, r.y}, pp[2] = {p.x, p.y}, ll[2] = {l.x, l.y}, uu[2] = {u.x, u.y},
+                 aa[2] = {acc.x, acc.y};
+    for (int k = 0; k < (_has2 ? 2 : 1); k++) {
+      double v = rr[k] - diag * pp[k] + aa[k];
+      if (b.use_lower) v += ll[k];
+      if (b.use_upper) v -= uu[k];
+      mx[0] = fmax(mx[0], fabs(v));
+      if (es[k].L) mx[1] = fmax(mx[1], fabs(-(es[k].xl * es[k].zl - beta_mu) - (es[k].xl * ll[k] + pp[k] * es[k].zl)));
+      if (es[k].U) mx[2] = fmax(mx[2], fabs(-(es[k].xu * es[k].zu - beta_mu) - (es[k].xu * uu[k] - pp[k] * es[k].zu)));
+    }
+  }
+  block_reduce_store<3, OP_MAX>(mx, partials, 0, sm);
+}
+int k_step_check(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl, const double *pzu,
+                 const double *coef, const double *const *P, int nv, double diag, double beta_mu, int64_t n,
+                 double out[3]) {
+  const int grid = grid_for(c, n, 3);
+  PO_TRY(ensure_partials(c, (size_t)grid * 3));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(coef, P, nv, &ct, &pt);
+  PO_LAUNCH(step_check_kernel, grid, b, rx, px, pzl, pzu, ct, pt, nv, diag, beta_mu, n, c->d_partials);
+  return reduce_finish(c, grid, 0, 0, 3, out);
+}
+
 int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
                const double *pzu, const double *dinv, const double *coef, const double *const *P,
                int nv, double diag, double beta_mu, int64_t n, double *tprime) {

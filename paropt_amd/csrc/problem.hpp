@@ -26,6 +26,11 @@ class Problem {
   int linear_constraints = 0;
   virtual int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) { return 0; }
   virtual int writeOutput(int iter, Vec *x) { return 0; }
+  // ParOptProblem::checkGradients (src/ParOptProblem.cpp:225-622) on device vectors: direction sign(g), forward
+  // differences with step dh of the objective and of every dense constraint against g.p and Ac_i.p (and, with
+  // check_hvec, of the Lagrangian's gradient against the Hessian-vector product).  work1/work2 are n-sized
+  // scratch; the report (one block of text) is appended to *report.  Collective.
+  int checkGradients(double dh, Vec *x, bool check_hvec, Vec *work1, Vec *work2, std::string *report);
   virtual int useLowerBounds() { return use_lower; }
   virtual int useUpperBounds() { return use_upper; }
   int use_lower = 1, use_upper = 1;  // setVarBoundOptions of the reference's Cython problems

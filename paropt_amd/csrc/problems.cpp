@@ -161,6 +161,79 @@ int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
   return PO_OK;
 }
 
+int Problem::checkGradients(double dh, Vec *x, bool check_hvec, Vec *xt, Vec *px, std::string *report) {
+  const int64_t n = nlocal;
+  Vec *g = vec_new(ctx, n), *gt = vec_new(ctx, n);
+  std::vector<Vec *> A, At;
+  bool ok = g && gt;
+  for (int j = 0; ok && j < ncon; j++) {
+    A.push_back(vec_new(ctx, n));
+    At.push_back(vec_new(ctx, n));
+    ok = A.back() && At.back();
+  }
+  int rc = ok ? PO_OK : PO_ERR_HIP;
+  auto run = [&]() -> int {
+    double f0 = 0.0, f1 = 0.0;
+    std::vector<double> c0(ncon > 0 ? ncon : 1, 0.0), c1(c0), Ap(c0);
+    if (evalObjCon(x, &f0, c0.data()) != 0 || evalObjConGradient(x, g, A.data()) != 0) return PO_ERR_USER;
+    PO_TRY(k_sign(ctx, px->d, g->d, n));  // p_i = +1 where g_i >= 0, else -1
+    double gp = 0.0;
+    PO_TRY(k_reduce1(ctx, RED_DOT, g->d, px->d, n, &gp));
+    std::vector<const double *> ap;
+    for (Vec *v : A) ap.push_back(v->d);
+    if (ncon > 0) PO_TRY(k_mdot(ctx, px->d, ap.data(), ncon, n, Ap.data()));
+    const double one[1] = {dh};
+    const double *pv[1] = {px->d};
+    PO_TRY(k_panel_axpy(ctx, xt->d, 1.0, x->d, 0.0, one, pv, 1, n));
+    if (evalObjCon(xt, &f1, c1.data()) != 0) return PO_ERR_USER;
+    char line[256];
+    auto row = [&](const char *what, int idx, double actual, double fd) {
+      const double err = fabs(actual - fd), rel = err / (fabs(actual) > 1e-300 ? fabs(actual) : 1.0);
+      if (idx < 0) {
+        snprintf(line, sizeof(line), "%s\n%15s %15s %15s %15s\n%15.6e %15.6e %15.4e %15.4e\n", what, "Actual", "FD",
+                 "Err", "Rel err", actual, fd, err, rel);
+      } else {
+        snprintf(line, sizeof(line), "%s[%d]\n%15.6e %15.6e %15.4e %15.4e\n", what, idx, actual, fd, err, rel);
+      }
+      *report += line;
+    };
+    *report += "\nGradient check (forward differences along sign(g))\n";
+    row("Objective gradient test", -1, gp, (f1 - f0) / dh);
+    for (int j = 0; j < ncon; j++) row("Constraint gradient test", j, Ap[j], (c1[j] - c0[j]) / dh);
+    if (check_hvec) {
+      std::vector<double> z(ncon > 0 ? ncon : 1, 0.0), mz(z);
+      for (int j = 0; j < ncon; j++) {
+        z[j] = 2.3 - 0.15 * (j % 5);
+        mz[j] = -z[j];
+      }
+      if (evalObjConGradient(xt, gt, At.data()) != 0) return PO_ERR_USER;
+      std::vector<const double *> atp;
+      for (Vec *v : At) atp.push_back(v->d);
+      // Lagrangian gradients g - sum z_j A_j (the sparse constraints of the built-in problems are linear or
+      // enter through zw = 0 here)
+      PO_TRY(k_panel_axpy(ctx, g->d, 0.0, nullptr, 1.0, mz.data(), ap.data(), ncon, n));
+      PO_TRY(k_panel_axpy(ctx, gt->d, 0.0, nullptr, 1.0, mz.data(), atp.data(), ncon, n));
+      if (evalHvecProduct(x, z.data(), nullptr, px, xt) == 0) {
+        PO_TRY(k_axpy(ctx, gt->d, -1.0, g->d, n));
+        PO_TRY(k_scale(ctx, gt->d, n, 1.0 / dh));
+        double hp = 0.0, fp = 0.0;
+        PO_TRY(k_reduce1(ctx, RED_DOT, xt->d, px->d, n, &hp));
+        PO_TRY(k_reduce1(ctx, RED_DOT, gt->d, px->d, n, &fp));
+        row("Hessian-vector product test (p^T H p)", -1, hp, fp);
+      } else {
+        *report += "Hessian-vector products are not implemented by this problem\n";
+      }
+    }
+    return PO_OK;
+  };
+  if (rc == PO_OK) rc = run();
+  vec_decref(g);
+  vec_decref(gt);
+  for (Vec *v : A) vec_decref(v);
+  for (Vec *v : At) vec_decref(v);
+  return rc;
+}
+
 int Problem::sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
                            Vec *) {
   if (csr) return csr->applyK0(d->d, bx, bw, yx->d, yw->d);

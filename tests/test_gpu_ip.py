@@ -628,6 +628,47 @@ def test_linear_constraints_python_callback_gets_no_jacobian(ctx):
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("problem,extra", [("quadratic", {}), ("convex", {"qn_type": "sr1"}),
+                                           ("rosenbrock", {"use_hvec_product": True, "gmres_subspace_size": 10})])
+def test_step_and_gradient_verification_options(ctx, problem, extra):
+    """step_verification_frequency / gradient_verification_frequency (src/ParOptInteriorPoint.cpp:4522-4525,
+    4635-4639, 5056-5073): the diagnostics land in the iteration history, the computed step zeroes every block of the
+    linearised KKT system, the user's gradients pass the finite-difference check, and the iterates are exactly those
+    of the run without the diagnostics."""
+    import re
+
+    import paropt_amd as pa
+
+    base = dict({"qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+                 "max_major_iters": 16, "write_output_frequency": 0}, **extra)
+    runs = []
+    for diag in (False, True):
+        opts = dict(base)
+        if diag:
+            opts.update(step_verification_frequency=5, gradient_verification_frequency=7)
+        ip = pa.InteriorPoint(pa.SeparableProblem(ctx, problem, 3001, 4), opts)
+        ip.optimize()
+        runs.append((ip.getHistory(), ip.getOptimizedPoint()[0].to_numpy(), ip.getIterationCounters()))
+    plain, diag = runs
+    assert plain[2] == diag[2]
+    np.testing.assert_array_equal(plain[1], diag[1])
+    hist = diag[0]
+    assert "Residual step check" not in plain[0] and "Gradient check" not in plain[0]
+    for k in (0, 5, 10, 15):
+        assert "Residual step check for iteration %d:" % k in hist
+    # every block of the linearised system is solved to round-off relative to the size of the step / state
+    vals = [float(v) for v in re.findall(r"max \|[^|]*\|:\s+([0-9.eE+-]+)", hist)]
+    assert len(vals) == 4 * 8
+    assert max(vals) < 1e-6, vals
+    assert hist.count("Gradient check") == 3  # iterations 0, 7, 14
+    rel = [float(ln.split()[3]) for ln in hist.splitlines()
+           if len(ln.split()) == 4 and ln.split()[0][0] in "-0123456789" and "e" in ln.split()[3]]
+    ncon = 2 if problem == "rosenbrock" else 4
+    assert len(rel) >= 3 * (1 + ncon) and max(rel) < 1e-4, rel
+    if problem == "rosenbrock":
+        assert "Hessian-vector product test" in hist
+
+
 def test_solution_file_format(ctx, tmp_path):
     """The binary checkpoint of writeSolutionFile (src/ParOptInteriorPoint.cpp:883-972): same
     layout as the file the reference left behind (header ints bit-exact, payload to 1e-6), and a
