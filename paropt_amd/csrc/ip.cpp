@@ -57,6 +57,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
   use_acz = !getenv("PAROPT_AMD_NO_ACZ");
+  use_ztpx_hint = !getenv("PAROPT_AMD_NO_ZTS_HINT");
   use_lower = prob->useLowerBounds();
   use_upper = prob->useUpperBounds();
   vars.resize(c);
@@ -501,14 +502,16 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   const double sigma = options.real("qn_sigma");
   const bool use_hdiag = options.integer("use_diag_hessian") && hdiag;  // h_i replaces b0 (:1840-1842)
   const double b0 = (!use_hdiag && qn && (use_qn || diag_only)) ? qn->diag() : 0.0;
-  PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   // The right-hand side of the solve that follows is known already (rx, the bounds and mu): t = Dinv o d1 is
-  // built now and rides through the Gram pass as one more, pre-weighted, column, so that P^T t -- the mdot pass
-  // at the head of solveKKT -- comes out of the pass over P that the Schur complements need anyway.
+  // built now (in the same pass over the bound data as Dinv) and rides through the Gram pass as one more,
+  // pre-weighted, column, so that P^T t -- the mdot pass at the head of solveKKT -- comes out of the pass over P
+  // that the Schur complements need anyway.
   const bool fuse_t = rhs_mu && fused_tdots && !has_w && c + (qn && use_qn && !diag_only ? qn->size() : 0) > 0;
   if (fuse_t) {
-    PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, options.real("rel_bound_barrier") * (*rhs_mu), n, tvec->d, nullptr,
-                nullptr));
+    PO_TRY(k_dinv_d1(ctx, bounds(), b0 + sigma, use_hdiag ? hdiag->d : nullptr, rx->d,
+                     options.real("rel_bound_barrier") * (*rhs_mu), n, Dinv->d, tvec->d));
+  } else {
+    PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   }
   int k = 0;
   // L-SR1 leaves its columns Z_j = Y_j - b0 S_j unformed after an update; when this Gram pass is their
@@ -1270,7 +1273,16 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     }
     int rcc = prob->computeQuasiNewtonUpdateCorrection(x, vars.z.data(), s_qn, y_qn);
     if (rcc != 0) return PO_ERR_USER;
-    PO_TRY(qn->update(s_qn, y_qn, update_type));
+    // Z^T s = alpha sx Z^T px is known from the solves (ptpx) when the step came from this very panel
+    const int kz = qn->size();
+    if (analytic_panel_dots && ptpx_valid && use_ztpx_hint && kz == wk && kz > 0 && (int)ptpx.size() == c + kz &&
+        !inexact_newton_step && !prob->quasiNewtonCorrectionMayChangeStep()) {
+      std::vector<double> zts(kz);
+      for (int j = 0; j < kz; j++) zts[j] = alpha * sx * ptpx[c + j];
+      PO_TRY(qn->updateWithZTs(s_qn, y_qn, zts.data(), update_type));
+    } else {
+      PO_TRY(qn->update(s_qn, y_qn, update_type));
+    }
   } else if (qn && perform_qn_update) {  // :4261-4263
     if (qn->updateMult(x, vars.z.data(), has_w ? wvar[0] : nullptr) != 0) return PO_ERR_USER;
     *update_type = 0;

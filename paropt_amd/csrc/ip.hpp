@@ -238,7 +238,7 @@ class InteriorPoint {
   // A^T z of a problem with linear dense constraints, kept by recurrence (computeResidual / computeStepAndUpdate)
   static const int kAczRefresh = 16;
   Vec *acz = nullptr;
-  bool acz_valid = false, use_acz = true;
+  bool acz_valid = false, use_acz = true, use_ztpx_hint = true;
   int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fused_tdots = true, t0_valid = false;

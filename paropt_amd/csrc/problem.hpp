@@ -25,6 +25,8 @@ class Problem {
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
   int linear_constraints = 0;
   virtual int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) { return 0; }
+  // false: the call above leaves s untouched (lets the solver reuse products it already has with the step)
+  virtual bool quasiNewtonCorrectionMayChangeStep() { return false; }
   virtual int writeOutput(int iter, Vec *x) { return 0; }
   // ParOptProblem::checkGradients (src/ParOptProblem.cpp:225-622) on device vectors: direction sign(g), forward
   // differences with step dh of the objective and of every dense constraint against g.p and Ac_i.p (and, with
@@ -106,6 +108,7 @@ class CallbackProblem : public Problem {
   int evalObjCon(Vec *x, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) override;
   int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) override;
+  bool quasiNewtonCorrectionMayChangeStep() override { return cb.qn_update_correction != nullptr; }
   int writeOutput(int iter, Vec *x) override;
   int evalSparseCon(Vec *x, Vec *out) override;
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;

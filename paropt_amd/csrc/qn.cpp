@@ -220,16 +220,22 @@ void LBFGS::computeMatUpdate() {  // :339-377
   factorM();
 }
 
-int LBFGS::update(Vec *s, Vec *y, int *rc) {
+int LBFGS::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {
   *rc = 0;
   const int k = (int)Z.size();  // = 2*msub of the current panel
   const int mold = k / 2;
-  // one pass: [Z^T s, s.s, s.y]; one more reduction for y.y
-  std::vector<const double *> vp = zPointers();
-  vp.push_back(s->d);
-  vp.push_back(y->d);
+  // one pass: [Z^T s, s.s, s.y] (Z^T s from the caller when it has it); one more reduction for y.y
   std::vector<double> dots(k + 2, 0.0);
-  PO_TRY(k_mdot(ctx, s->d, vp.data(), k + 2, n, dots.data()));
+  if (zTs) {
+    const double *two[2] = {s->d, y->d};
+    PO_TRY(k_mdot(ctx, s->d, two, 2, n, dots.data() + k));
+    for (int i = 0; i < k; i++) dots[i] = zTs[i];
+  } else {
+    std::vector<const double *> vp = zPointers();
+    vp.push_back(s->d);
+    vp.push_back(y->d);
+    PO_TRY(k_mdot(ctx, s->d, vp.data(), k + 2, n, dots.data()));
+  }
   double yTy = 0.0;
   PO_TRY(k_reduce1(ctx, RED_SUMSQ, y->d, nullptr, n, &yTy));
   double sTs = dots[k], yTs = dots[k + 1];
@@ -282,16 +288,32 @@ int LBFGS::update(Vec *s, Vec *y, int *rc) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int LSR1::update(Vec *s, Vec *y, int *rc) {  // :636-747
+int LSR1::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {  // :636-747
   *rc = 0;
   const int mold = msub;
-  std::vector<const double *> vp;
-  for (int i = 0; i < mold; i++) vp.push_back(S[i]->d);
-  for (int i = 0; i < mold; i++) vp.push_back(Y[i]->d);
-  vp.push_back(s->d);
-  vp.push_back(y->d);
   std::vector<double> dots(2 * mold + 2, 0.0);
-  PO_TRY(k_mdot(ctx, s->d, vp.data(), 2 * mold + 2, n, dots.data()));
+  if (zTs && (int)Z.size() == mold) {
+    // Z_j = Y_j - b0 S_j with the b0 still in place: Y_j.s = Z_j.s + b0 S_j.s, so only the S columns are streamed
+    std::vector<const double *> vp;
+    for (int i = 0; i < mold; i++) vp.push_back(S[i]->d);
+    vp.push_back(s->d);
+    vp.push_back(y->d);
+    std::vector<double> d2(mold + 2, 0.0);
+    PO_TRY(k_mdot(ctx, s->d, vp.data(), mold + 2, n, d2.data()));
+    for (int i = 0; i < mold; i++) {
+      dots[i] = d2[i];
+      dots[mold + i] = zTs[i] + b0 * d2[i];
+    }
+    dots[2 * mold] = d2[mold];
+    dots[2 * mold + 1] = d2[mold + 1];
+  } else {
+    std::vector<const double *> vp;
+    for (int i = 0; i < mold; i++) vp.push_back(S[i]->d);
+    for (int i = 0; i < mold; i++) vp.push_back(Y[i]->d);
+    vp.push_back(s->d);
+    vp.push_back(y->d);
+    PO_TRY(k_mdot(ctx, s->d, vp.data(), 2 * mold + 2, n, dots.data()));
+  }
   double yTy = 0.0;
   PO_TRY(k_reduce1(ctx, RED_SUMSQ, y->d, nullptr, n, &yTy));
   const double sTs = dots[2 * mold], sTy = dots[2 * mold + 1];

@@ -26,6 +26,11 @@ class CompactQuasiNewton {
   virtual void reset();
   // returns PO_* status; *rc = 0 normal, 1 damped, 2 skipped (src/ParOptQuasiNewton.cpp:162-334)
   virtual int update(Vec *s, Vec *y, int *rc) = 0;
+  // The same with Z^T s already known to the caller (the interior point has P^T px of the step it is about to
+  // store: s = alpha px): the pass over the whole panel inside update() shrinks to the columns that are not
+  // implied -- none for L-BFGS (Z = [S | Y]), the S columns for L-SR1 (Y_j.s = Z_j.s + b0 S_j.s).  zTs has
+  // size() entries in the order of the current panel.  Default: ignores the hint.
+  virtual int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) { return update(s, y, rc); }
   // update(x, z, zw): multiplier-only update, a no-op for the limited-memory classes
   // (src/ParOptQuasiNewton.h:60-63); ParOptEigenQuasiNewton records z[index] here
   virtual int updateMult(Vec *x, const double *z, Vec *zw) { return 0; }
@@ -83,7 +88,8 @@ class LBFGS : public CompactQuasiNewton {
     update_type = PO_BFGS_SKIP_NEGATIVE_CURVATURE;
   }
   void setBFGSUpdateType(int t) { update_type = t; }
-  int update(Vec *s, Vec *y, int *rc) override;
+  int update(Vec *s, Vec *y, int *rc) override { return updateWithZTs(s, y, nullptr, rc); }
+  int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) override;
   int getMaxLimitedMemorySize() override { return 2 * msub_max; }
 
  private:
@@ -98,7 +104,8 @@ class LSR1 : public CompactQuasiNewton {
     z_pending = false;
     CompactQuasiNewton::reset();
   }
-  int update(Vec *s, Vec *y, int *rc) override;
+  int update(Vec *s, Vec *y, int *rc) override { return updateWithZTs(s, y, nullptr, rc); }
+  int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) override;
   int getMaxLimitedMemorySize() override { return msub_max; }
   bool pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp, std::vector<double *> *Zout,
                 double *b0_) const override;

@@ -664,7 +664,7 @@ def test_step_and_gradient_verification_options(ctx, problem, extra):
     rel = [float(ln.split()[3]) for ln in hist.splitlines()
            if len(ln.split()) == 4 and ln.split()[0][0] in "-0123456789" and "e" in ln.split()[3]]
     ncon = 2 if problem == "rosenbrock" else 4
-    assert len(rel) >= 3 * (1 + ncon) and max(rel) < 1e-4, rel
+    assert len(rel) >= 3 * (1 + ncon) and max(rel) < 1e-3, rel  # forward differences, dh = 1e-6
     if problem == "rosenbrock":
         assert "Hessian-vector product test" in hist
 
