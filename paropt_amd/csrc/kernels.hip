@@ -990,13 +990,15 @@ __global__ void __launch_bounds__(kBlock, OCC)
       aA += cA * v;
       *reinterpret_cast<f64x2 *>(myslice + it * kS2Tile) = v;
     }
-    double *sa = sacc + (wave * 64 + lane) * 6;
-    sa[0] = a1.x;
-    sa[1] = a1.y;
-    sa[2] = a2.x;
-    sa[3] = a2.y;
-    sa[4] = aA.x;
-    sa[5] = aA.y;
+    // [value][wave][lane]: consecutive lanes hit consecutive 8-byte slots (the [lane][value] layout of round 2's
+    // first version cost 21 % LDS bank-conflict cycles, profiles/r02_pmc_counters.json)
+    double *sa = sacc + wave * 64 + lane;
+    sa[0 * 256] = a1.x;
+    sa[1 * 256] = a1.y;
+    sa[2 * 256] = a2.x;
+    sa[3 * 256] = a2.y;
+    sa[4 * 256] = aA.x;
+    sa[5 * 256] = aA.y;
     __syncthreads();
     const bool more = tile + gridDim.x < ntiles;
     // wave 0 issues its share of the next tile after the epilogue (keeps the prefetch registers out of the
@@ -1006,13 +1008,13 @@ __global__ void __launch_bounds__(kBlock, OCC)
       double2 acc = make_double2(0.0, 0.0), acc2 = acc, accA = acc;
 #pragma unroll
       for (int w = 0; w < 4; w++) {
-        const double *sp = sacc + (w * 64 + lane) * 6;
-        acc.x += sp[0];
-        acc.y += sp[1];
-        acc2.x += sp[2];
-        acc2.y += sp[3];
-        accA.x += sp[4];
-        accA.y += sp[5];
+        const double *sp = sacc + w * 64 + lane;
+        acc.x += sp[0 * 256];
+        acc.y += sp[1 * 256];
+        acc2.x += sp[2 * 256];
+        acc2.y += sp[3 * 256];
+        accA.x += sp[4 * 256];
+        accA.y += sp[5 * 256];
       }
       double2 tp = make_double2(0.0, 0.0);
       if (inc) {
