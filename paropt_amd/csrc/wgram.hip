@@ -244,6 +244,173 @@ __global__ void __launch_bounds__(kBlock, OCC)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Producer / consumer form (default for NG <= 16): 8 wavefronts per workgroup, ONE workgroup per CU.
+//   waves 4-7 (producers) keep three tiles of their column slice in flight in registers, stage the oldest into
+//     one of two LDS tile buffers (forming the L-SR1 columns on the way) and immediately re-issue the loads of the
+//     tile three ahead: the HBM stream never waits for matrix work;
+//   waves 0-3 (consumers, one per SIMD) run the matrix instructions of the tile staged one step earlier.
+// One workgroup barrier per tile: after it, buffer it%2 is full (read by the consumers during step `it`) and
+// buffer (it+1)%2 is free (filled by the producers during step `it`).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kGramDepth = 3;  // tiles a producer keeps in flight
+
+template <int NG, int ZP>
+struct GramProducer {
+  f64x2 buf[kGramDepth][NG];
+  f64x2 sbuf[kGramDepth][ZP > 0 ? ZP : 1];
+  f64x2 dbuf[kGramDepth];
+  int64_t row[kGramDepth];
+  bool in[kGramDepth];
+};
+
+template <int NG, int ZP, int R>
+__device__ __forceinline__ void gram_pc_load(GramProducer<NG, ZP> &P, const double *const (&colp)[NG],
+                                             const double *const (&scol)[ZP > 0 ? ZP : 1], const double *d,
+                                             int64_t tile, int64_t ntiles, int64_t n, int64_t ilast, int lane) {
+  if (tile >= ntiles) {
+    P.in[R] = false;
+    return;
+  }
+  int64_t i = tile * kGramTile + 2 * lane;
+  const bool in = (i < n);
+  if (!in) i = ilast;
+  P.in[R] = in;
+  P.row[R] = i;
+#pragma unroll
+  for (int it = 0; it < NG; it++) P.buf[R][it] = ld_nt(colp[it] + i);
+  if (ZP > 0) {
+#pragma unroll
+    for (int it = 0; it < ZP; it++) P.sbuf[R][it] = ld_nt(scol[it] + i);
+  }
+  P.dbuf[R] = *reinterpret_cast<const f64x2 *>(d + i);
+}
+
+template <int NG, int ZP, int R>
+__device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *__restrict__ pt,
+                                              double *__restrict__ dw, double *const (&zcol)[ZP > 0 ? ZP : 1], int pw,
+                                              int nv, int kpend, double b0, int lane) {
+  const bool in = P.in[R];
+#pragma unroll
+  for (int it = 0; it < NG; it++) {
+    const int j = pw + 4 * it;
+    f64x2 v = P.buf[R][it];
+    if (ZP > 0 && it < ZP && j < kpend) {
+      v.x -= b0 * P.sbuf[R][it].x;
+      v.y -= b0 * P.sbuf[R][it].y;
+      if (in) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + P.row[R]));
+    }
+    if (!in) v = (f64x2){0.0, 0.0};
+    if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;
+  }
+  if (pw == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = in ? P.dbuf[R] : (f64x2){0.0, 0.0};
+}
+
+template <int NG, int ZP>
+__global__ void __launch_bounds__(512, 1)
+    wgram_pc_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
+                    double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol,
+                    int ablate) {
+  constexpr int M = 4 * NG;
+  constexpr int NQ = GramPlanHolder<NG>::NQ;
+  constexpr int kBufDoubles = M * kGramLd + kGramTile;  // panel tile, then the row weights
+  extern __shared__ double lds[];                       // two tile buffers
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // zero the padded columns of both buffers once (never written by the staging)
+  for (int b2 = 0; b2 < 2; b2++)
+    for (int idx = tid; idx < (M - nv) * kGramLd; idx += 512) lds[b2 * kBufDoubles + nv * kGramLd + idx] = 0.0;
+  // tiles of this workgroup: blockIdx.x + it * gridDim.x, it = 0 .. nt-1
+  const int64_t first = blockIdx.x, stride = gridDim.x;
+  const int64_t nt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  __syncthreads();
+  if (wave >= 4) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    const int pw = wave - 4;
+    const double *colp[NG];
+#pragma unroll
+    for (int it = 0; it < NG; it++) {
+      const int j = pw + 4 * it;
+      colp[it] = V.p[j < nv ? j : nv - 1];
+    }
+    const double *scol[ZP > 0 ? ZP : 1];
+    double *zcol[ZP > 0 ? ZP : 1];
+#pragma unroll
+    for (int it = 0; it < (ZP > 0 ? ZP : 1); it++) {
+      const int j = pw + 4 * it;
+      scol[it] = (ZP > 0 && kpend > 0) ? S.p[j < kpend ? j : kpend - 1] : nullptr;
+      zcol[it] = (ZP > 0 && j < kpend) ? Zout.p[j] : nullptr;
+    }
+    const int64_t ilast = ((n - 1) >> 1) << 1;
+    GramProducer<NG, ZP> P;
+    gram_pc_load<NG, ZP, 0>(P, colp, scol, d, first, ntiles, n, ilast, lane);
+    gram_pc_load<NG, ZP, 1>(P, colp, scol, d, first + stride, ntiles, n, ilast, lane);
+    gram_pc_load<NG, ZP, 2>(P, colp, scol, d, first + 2 * stride, ntiles, n, ilast, lane);
+    // step `it` (ring slot it % 3, LDS buffer it % 2): stage tile `it`, reload the slot with tile it + 3, barrier
+#define PO_PC_STEP(R)                                                                                         \
+  if (it + (R) < nt) {                                                                                        \
+    double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
+    if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
+    else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
+    if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane); \
+    __syncthreads();                                                                                          \
+  }
+    for (int64_t it = 0; it < nt; it += kGramDepth) {
+      PO_PC_STEP(0)
+      PO_PC_STEP(1)
+      PO_PC_STEP(2)
+    }
+#undef PO_PC_STEP
+    __syncthreads();  // matches the consumers' trailing barrier
+  } else {
+    // ------------------------------------------------ consumers ------------------------------------------------
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+    for (int64_t it = 0; it < nt; it++) {
+      __syncthreads();  // tile `it` is staged in buffer it % 2
+      const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
+      if (ablate == 1) continue;  // tuning: no matrix work
+      switch (wave) {
+        case 0: gram_tile<NG, 0>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+        case 1: gram_tile<NG, 1>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+        case 2: gram_tile<NG, 2>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+        default: gram_tile<NG, 3>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+      }
+    }
+    __syncthreads();
+    switch (wave) {
+      case 0: gram_store<NG, 0>(acc, lane, partials); break;
+      case 1: gram_store<NG, 1>(acc, lane, partials); break;
+      case 2: gram_store<NG, 2>(acc, lane, partials); break;
+      default: gram_store<NG, 3>(acc, lane, partials); break;
+    }
+  }
+}
+
+template <int NG, int ZP>
+static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int64_t ntiles,
+                             const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out) {
+  const size_t lds = (size_t)2 * (4 * NG * kGramLd + kGramTile) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc_kernel<NG, ZP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  static const int ablate = getenv("PAROPT_AMD_WGRAM_ABLATE") ? atoi(getenv("PAROPT_AMD_WGRAM_ABLATE")) : 0;
+  int64_t g = (int64_t)c->num_cu;  // one workgroup per CU
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
+  hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
+                     c->d_partials, st, zt, kpend, b0, tcol, ablate);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  *grid_out = (int)g;
+  return PO_OK;
+}
+
 template <int NG, int ZP, int OCC>
 static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int64_t ntiles,
                           const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out) {
@@ -296,6 +463,8 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   int grid = 0;
   // resident wavefronts per SIMD the kernel is compiled for (register budget 512 / OCC per lane)
   static const int occ_env = getenv("PAROPT_AMD_WGRAM_OCC") ? atoi(getenv("PAROPT_AMD_WGRAM_OCC")) : 0;
+  // PAROPT_AMD_WGRAM_PC=0: the single-role form (every wavefront loads, stages and multiplies) for all widths
+  static const bool use_pc = !(getenv("PAROPT_AMD_WGRAM_PC") && atoi(getenv("PAROPT_AMD_WGRAM_PC")) == 0);
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \
@@ -304,7 +473,10 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     constexpr int OCC0A = OCC0 > 1 ? OCC0 - 1 : 1;                                                     \
     constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
     constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
-    if (kpend > 0) {                                                                                   \
+    if (NGv <= 16 && use_pc && n >= 4 * kGramTile) {                                                   \
+      if (kpend > 0) PO_TRY((wgram_pc_launch_t<(NGv <= 16 ? NGv : 16), 3>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+      else PO_TRY((wgram_pc_launch_t<(NGv <= 16 ? NGv : 16), 0>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));              \
+    } else if (kpend > 0) {                                                                            \
       if (occ_env == OCCZA) PO_TRY((wgram_launch_t<NGv, 3, OCCZA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
       else PO_TRY((wgram_launch_t<NGv, 3, OCCZ>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));     \
     } else {                                                                                           \

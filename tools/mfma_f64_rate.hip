@@ -12,6 +12,15 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 template <int KIND, int NACC>
 __global__ void __launch_bounds__(256) k(double *out, unsigned long long *clk, int iters, double a, double b) {
   double av = a + threadIdx.x * 1e-9, bv = b - threadIdx.x * 1e-9;
+  if (a < 0.0) {  // random mantissas per lane (the power drawn, and with it the clock the chip holds, depends on data)
+    unsigned long long z = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + 12345;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    av = 0.5 + (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    z = (z ^ (z >> 29)) * 0xBF58476D1CE4E5B9ull;
+    bv = -(0.5 + (double)(z >> 11) * (1.0 / 9007199254740992.0)) * 1e-3;
+  }
   double s = 0;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   if (KIND == 0) {
@@ -24,6 +33,21 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *clk, i
     }
 #pragma unroll
     for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else if (KIND == 3) {
+    // the Gram kernel's pattern: a different A operand per instruction, a B operand shared by runs of 8
+    double acc[NACC], aa[8], bb[2];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) aa[i] = av * (1.0 + 0.01 * i);
+    bb[0] = bv;
+    bb[1] = bv * 1.5;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(aa[i & 7], bb[(i >> 3) & 1], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += acc[i];
   } else if (KIND == 1) {
     double acc[NACC];
 #pragma unroll
@@ -54,20 +78,20 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *clk, i
 }
 
 template <int KIND, int NACC>
-void run(int wpc) {
+void run(int wpc, double a0 = 1.0) {
   double *out;
   unsigned long long *clk, h[2];
   hipMalloc(&out, 256 * 256 * wpc * 8);
   hipMalloc(&clk, 16);
-  const int iters = KIND == 0 ? 6000 : 20000;
-  const double flop = KIND == 0 ? 2048.0 : (KIND == 1 ? 512.0 : 128.0);
+  const int iters = (KIND == 0 ? 6000 : 20000) * (a0 < 0.0 ? 20 : 1);  // long enough for the clock to settle
+  const double flop = KIND == 0 ? 2048.0 : ((KIND == 1 || KIND == 3) ? 512.0 : 128.0);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, 100, 1.0, 2.0);
+  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, 100, a0, 2.0);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, iters, 1.0, 2.0);
+  hipLaunchKernelGGL((k<KIND, NACC>), dim3(256 * wpc), dim3(256), 0, 0, out, clk, iters, a0, 2.0);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -77,9 +101,9 @@ void run(int wpc) {
   const double n_per_simd = (double)iters * NACC * wpc;  // one wave per SIMD per workgroup
   const double tflops = (double)iters * NACC * flop * 4 * 256 * wpc / (ms * 1e-3) * 1e-12;
   const double ns = ms * 1e6 / n_per_simd;
-  printf("kind=%s NACC=%d waves/SIMD=%d: %.3f ms, %.1f TFLOP/s, %.2f ns per instr per SIMD (%.1f cycles @2.4GHz; "
+  printf("%skind=%s NACC=%d waves/SIMD=%d: %.3f ms, %.1f TFLOP/s, %.2f ns per instr per SIMD (%.1f cycles @2.4GHz; "
          "memtime/realtime -> %.0f MHz -> %.1f cycles)\n",
-         KIND == 0 ? "mfma16x16x4" : (KIND == 1 ? "mfma4x4x4" : "v_fma_f64"), NACC, wpc, ms, tflops, ns, ns * 2.4, mhz,
+         a0 < 0.0 ? "[random operands] " : "", KIND == 0 ? "mfma16x16x4" : (KIND == 1 ? "mfma4x4x4" : (KIND == 3 ? "mfma4x4x4/varied-operands" : "v_fma_f64")), NACC, wpc, ms, tflops, ns, ns * 2.4, mhz,
          ns * mhz * 1e-3);
   hipFree(out);
   hipFree(clk);
@@ -89,5 +113,8 @@ int main() {
   run<0, 1>(1); run<0, 6>(1); run<0, 6>(2); run<0, 6>(3); run<0, 4>(4); run<0, 4>(8);
   run<1, 1>(1); run<1, 8>(1); run<1, 16>(1); run<1, 16>(2); run<1, 16>(3); run<1, 16>(4); run<1, 8>(8);
   run<2, 8>(1); run<2, 8>(2); run<2, 8>(4); run<2, 8>(8);
+  // the same with random mantissas, 20x longer: what a real Gram pass can expect
+  run<1, 16>(1, -1.0); run<1, 16>(3, -1.0); run<0, 6>(3, -1.0); run<2, 8>(8, -1.0);
+  run<3, 16>(1, -1.0); run<3, 16>(3, -1.0); run<3, 16>(1); run<3, 16>(3);
   return 0;
 }
