@@ -3,8 +3,8 @@ GPU parity of the trust-region layer (through the C ABI): ParOptTrustRegion's SL
 the quadratic and the compact-eigenvalue subproblems against trajectories of the compiled
 reference (tests/golden/tr_*.npz) -- the iteration table to its print precision, accept / reject and
 quasi-Newton flags exactly, the interior-point iteration counts of the two subproblem solves per
-iteration (exact in >= 80 % of the rows: the degenerate steering LP terminates on round-off level
-tests), radius, penalty parameters, model values and the iterate.
+iteration exactly, except in the rows listed (with their reason) in TR_INEXACT_ROWS -- 6 of the 486 compared
+rows over twelve goldens --, radius, penalty parameters, model values and the iterate.
 """
 import numpy as np
 import pytest
@@ -73,6 +73,22 @@ def run_gpu_tr(ctx, case, python_eig_callback=False):
 
 TR_CASES = golden_names("tr_")
 
+# Rows of the iteration tables whose interior-point iteration counts differ from the reference's (everything
+# else in every row of every golden is identical: 480 of 486 compared rows).  In each of them the steering LP
+# (sequential linear method, predictor-corrector barrier) or the QP ends on a round-off level test: the iterate
+# crawls with |infeas| ~ 1e-15 against rho ~ 1e15 or sits on `LNoImprv` until the complementarity crosses
+# 0.1 abs_res_tol, and the iteration at which that happens moves by a few with the summation order of the
+# reductions (the reference itself is not reproducible across rank counts there).  counts: mine vs reference.
+TR_INEXACT_ROWS = {
+    "tr_convex_n300_c4_bfgs": {16, 17},          # 23/32 vs 23/31, 23/57 vs 23/54 (second solve)
+    "tr_csr_convex_n120_c2_chain3s2": {17},      # 23/31 vs 23/27
+    "tr_eig_convex_n300_c3_N6": {13, 16},        # 33/12 vs 34/12, 33/15 vs 32/15 (steering LP)
+    "tr_rosenbrock_n60_bfgs": {3},               # 20/24 vs 20/32
+    # filter method: the restoration LP of iteration 3 takes 37 vs 36 iterations; from iteration 26 on the two runs
+    # hold filters of different size (f2 / f3 ...: an entry on the envelope is or is not dominated at 1e-16)
+    "tr_filter_quadratic_n200_c3": {3},
+}
+
 
 @pytest.mark.parametrize("name", TR_CASES)
 def test_tr_trajectory_golden(ctx, name):
@@ -85,8 +101,9 @@ def test_tr_trajectory_golden(ctx, name):
     window = 40 if ("sr1" in name or loose) else 60
     unstable = name == "tr_filter_quadratic_n200_c3"  # see tests/test_oracle_tr.py
     if unstable:
-        window = 10
-    n = compare_tr(g, rows, snaps, final, window, check_snaps=not unstable)
+        window = 10  # the printed objective differs in the 6th digit from iteration 12 on
+    n = compare_tr(g, rows, snaps, final, window, check_snaps=not unstable,
+                   inexact_rows=TR_INEXACT_ROWS.get(name, set()))
     if unstable:
         return
     assert n >= 20

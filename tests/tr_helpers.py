@@ -89,8 +89,11 @@ def run_oracle_tr(case, nmax=None):
     return rows, snaps, final
 
 
-def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True):
-    """rows/snaps/final of a run (oracle or device) against a golden of the compiled reference."""
+def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True, inexact_rows=None):
+    """rows/snaps/final of a run (oracle or device) against a golden of the compiled reference.
+    inexact_rows (a set of iteration numbers): the info strings of all OTHER rows -- accept / reject and
+    quasi-Newton flags, interior-point iteration counts of both subproblem solves -- must be identical; in the
+    listed rows only the counts may differ (by at most 10 iterations)."""
     ref = parse_tr_table(g["paropt_tr"])
     ncmp = min(window, len(ref), len(rows))
     assert ncmp >= min(window, len(ref)), (ncmp, len(ref), len(rows))
@@ -111,6 +114,11 @@ def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True):
         rflags = [t for t in rtoks if "/" not in t and not t.isdigit()]
         assert flags == rflags, "flags @%d: %s vs %s" % (k, toks, rtoks)
         exact += int(toks == rtoks)
+        if inexact_rows is not None and toks != rtoks:
+            assert k in inexact_rows, "info @%d: %s vs %s" % (k, toks, rtoks)
+            mine_n = [int(v) for t in toks if "/" in t or t.isdigit() for v in t.split("/")]
+            ref_n = [int(v) for t in rtoks if "/" in t or t.isdigit() for v in t.split("/")]
+            assert len(mine_n) == len(ref_n) and max(abs(a - b) for a, b in zip(mine_n, ref_n)) <= 10, (k, toks, rtoks)
     # interior-point iteration counts of the two subproblem solves: bit-exact except where the
     # degenerate steering LP terminates on a round-off level test (see DESIGN.md "Parity")
     assert exact >= frac_exact * ncmp, "only %d of %d info strings identical" % (exact, ncmp)
