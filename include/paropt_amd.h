@@ -91,6 +91,16 @@ int po_ctx_time_wgram_result(po_ctx ctx, int which, double *ms_total, int64_t *l
 /* Communicator in use (0 self, 1 RCCL, 2 host callback) and the collectives issued so far: pure-sum
  * reductions go through ncclAllReduce, mixed SUM/MIN/MAX payloads through one rank-ordered ncclAllGather. */
 int po_ctx_comm_info(po_ctx ctx, int *kind, int64_t *allreduces, int64_t *allgathers);
+/* Reduction batching (default on; PAROPT_AMD_NO_BATCH=1 in the environment switches the default off): reductions
+ * whose results are not needed one before the other -- the barrier sums at the line search's trial point with the
+ * built-in problems' f and c (the MPI_Allreduce calls of src/ParOptInteriorPoint.cpp:3541-3565 and of the problem's
+ * evalObjCon), the next residual's norms (:1588-1723) with the quasi-Newton products of update()
+ * (src/ParOptQuasiNewton.cpp:162-186, 660-690) -- share ONE collective, one device-to-host copy and one host
+ * synchronisation.  The values are the same bits either way; po_ctx_counters() counts host synchronisations,
+ * po_ctx_batched_reductions() the reductions that rode along with another one.  Reductions issued by user code
+ * through this ABI are never deferred. */
+int po_ctx_set_reduction_batching(po_ctx ctx, int on);
+int po_ctx_batched_reductions(po_ctx ctx, int64_t *batched);
 /* Copy between a host buffer and a raw device array this library handed out (the Jacobian entries of
  * po_problem_set_sparse_jacobian_data), ordered with the context's stream; returns when the copy is done.
  * to_device != 0: host -> device. */

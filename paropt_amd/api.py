@@ -74,6 +74,17 @@ class Context:
         check(lib.po_ctx_comm_info(self._h, C.byref(k), C.byref(a), C.byref(b)))
         return k.value, a.value, b.value
 
+    def set_reduction_batching(self, on):
+        """Let independent reductions share one collective + host sync (default on)."""
+        check(lib.po_ctx_set_reduction_batching(self._h, int(bool(on))))
+        return self
+
+    def batched_reductions(self):
+        """Reductions that shared another reduction's collective + host sync so far."""
+        a = C.c_int64()
+        check(lib.po_ctx_batched_reductions(self._h, C.byref(a)))
+        return a.value
+
     def counters(self):
         """(host-synchronising reductions, kernel launches) issued on this context so far."""
         a, b = C.c_int64(), C.c_int64()

@@ -64,6 +64,17 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   if (launches) *launches = ctx->n_launches;
   return PO_OK;
 }
+int po_ctx_set_reduction_batching(po_ctx ctx, int on) {
+  PO_CHECK_PTR(ctx);
+  PO_TRY(po::batch_flush(ctx));
+  ctx->batch_enabled = on ? 1 : 0;
+  return PO_OK;
+}
+int po_ctx_batched_reductions(po_ctx ctx, int64_t *batched) {
+  PO_CHECK_PTR(ctx);
+  if (batched) *batched = ctx->n_batched;
+  return PO_OK;
+}
 int po_live_objects(int64_t *vectors, int64_t *bytes) {
   long v = 0;
   long long b = 0;
@@ -997,7 +1008,7 @@ int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg
   float ms = 0.f;
   PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   *avg_ms = (double)ms / (reps > 0 ? reps : 1);
-  if (out) PO_TRY(reduce_finish(c, grid, nvecs, 0, 0, out));
+  if (out) PO_TRY(reduce_finish(c, grid, nvecs, 0, 0, out, true));
   return PO_OK;
 }
 int po_bench_stream(po_vec x, po_vec y, int kind, int reps, double *avg_ms) {

@@ -22,7 +22,7 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
-int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin);
+int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
 
 // ---- RCCL through dlopen: the library is only needed for world sizes > 1 ----------------------
 struct Id128 {  // ncclUniqueId: 128 opaque bytes passed BY VALUE to ncclCommInitRank
@@ -158,6 +158,7 @@ int ctx_create(int device, Ctx **out) {
   PO_HIP(hipEventCreate(&c->ev0));
   PO_HIP(hipEventCreate(&c->ev1));
   c->partials_cap = 0;
+  if (getenv("PAROPT_AMD_NO_BATCH")) c->batch_enabled = 0;
   *out = c;
   return ensure_partials(c, (size_t)c->max_blocks * 64);
 }
@@ -189,22 +190,19 @@ int ensure_partials(Ctx *c, size_t doubles) {
   return PO_OK;
 }
 
-int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out) {
-  const int nslots = nsum + nmin + nmax;
-  if (nslots > kMaxRed) {
-    set_error("reduction of %d slots exceeds kMaxRed=%d", nslots, kMaxRed);
-    return PO_ERR_ARG;
-  }
-  PO_TRY(launch_reduce_final(c, nblocks, nslots, nsum, nmin));
-  c->n_reductions++;
-  const size_t bytes = sizeof(double) * (size_t)nslots;
+// One collective + device-to-host copy + host sync for `total` rank-local values in d_red[0..total); on return
+// *parts points at nparts consecutive copies (one per contributing rank, rank order; 1 when the collective has
+// already summed them) in h_red.
+static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **parts_out, int *nparts_out) {
+  const size_t bytes = sizeof(double) * (size_t)total;
   int nparts = 1;
   const double *parts = c->h_red;
-  if (c->comm_kind == COMM_RCCL && c->rccl_allreduce && nmin == 0 && nmax == 0) {
+  c->n_reductions++;
+  if (c->comm_kind == COMM_RCCL && c->rccl_allreduce && pure_sum) {
     // the MPI_Allreduce(SUM) sites of the reference (dot/mdot/Gram entries, src/ParOptVec.cpp:124-170,
     // src/ParOptInteriorPoint.cpp:1957) -> ONE ncclAllReduce over xGMI on the solver's stream, in place in d_red;
     // every rank receives the same bits (the reduced value is produced once per chunk and broadcast)
-    int rc = g_rccl.AllReduce(c->d_red, c->d_red, (size_t)nslots, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm,
+    int rc = g_rccl.AllReduce(c->d_red, c->d_red, (size_t)total, /*ncclDouble*/ 8, /*ncclSum*/ 0, c->rccl_comm,
                               c->stream);
     if (rc != 0) {
       set_error("ncclAllReduce failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
@@ -215,8 +213,7 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
     PO_HIP(hipStreamSynchronize(c->stream));
   } else if (c->comm_kind == COMM_RCCL) {
     c->n_allgather++;
-    int rc = g_rccl.AllGather(c->d_red, c->d_gather, (size_t)nslots, /*ncclDouble*/ 8, c->rccl_comm,
-                              c->stream);
+    int rc = g_rccl.AllGather(c->d_red, c->d_gather, (size_t)total, /*ncclDouble*/ 8, c->rccl_comm, c->stream);
     if (rc != 0) {
       set_error("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
       return PO_ERR_COMM;
@@ -229,7 +226,7 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
     PO_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_kind == COMM_CALLBACK) {
       double *all = c->h_red + kMaxRed;
-      int rc = c->cb_allgather(c->h_red, all, nslots, c->cb_user);
+      int rc = c->cb_allgather(c->h_red, all, total, c->cb_user);
       if (rc != 0) {
         set_error("allgather callback failed with code %d", rc);
         return PO_ERR_COMM;
@@ -238,11 +235,19 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
       nparts = c->size;
     }
   }
-  // combine the rank contributions in rank order: bit-identical on every rank
+  *parts_out = parts;
+  *nparts_out = nparts;
+  return PO_OK;
+}
+
+// combine the rank contributions of one segment in rank order: bit-identical on every rank
+static void combine_segment(const double *parts, int nparts, int stride, int off, int nsum, int nmin, int nmax,
+                            double *host_out) {
+  const int nslots = nsum + nmin + nmax;
   for (int s = 0; s < nslots; s++) {
-    double acc = parts[s];
+    double acc = parts[off + s];
     for (int r = 1; r < nparts; r++) {
-      const double v = parts[(size_t)r * nslots + s];
+      const double v = parts[(size_t)r * stride + off + s];
       if (s < nsum) {
         acc += v;
       } else if (s < nsum + nmin) {
@@ -253,6 +258,53 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
     }
     host_out[s] = acc;
   }
+}
+
+int batch_flush(Ctx *c) {
+  if (c->batch_pend.empty()) {
+    // nothing queued: deferred host work (if any slipped in) still runs
+    std::vector<std::function<void()>> after;
+    after.swap(c->batch_after);
+    for (auto &f : after) f();
+    return PO_OK;
+  }
+  std::vector<Ctx::PendingRed> pend;
+  pend.swap(c->batch_pend);
+  std::vector<std::function<void()>> after;
+  after.swap(c->batch_after);
+  const int total = c->batch_cursor;
+  c->batch_cursor = 0;
+  bool pure_sum = true;
+  for (const Ctx::PendingRed &p : pend) pure_sum = pure_sum && p.nmin == 0 && p.nmax == 0;
+  const double *parts = nullptr;
+  int nparts = 1;
+  PO_TRY(exchange_reduced(c, total, pure_sum, &parts, &nparts));
+  c->n_batched += (long)pend.size() - 1;
+  for (const Ctx::PendingRed &p : pend) combine_segment(parts, nparts, total, p.off, p.nsum, p.nmin, p.nmax, p.host_out);
+  for (auto &f : after) f();
+  return PO_OK;
+}
+
+int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out, bool now) {
+  const int nslots = nsum + nmin + nmax;
+  if (nslots > kMaxRed) {
+    set_error("reduction of %d slots exceeds kMaxRed=%d", nslots, kMaxRed);
+    return PO_ERR_ARG;
+  }
+  const bool queued = c->batch_depth > 0 || !c->batch_pend.empty();
+  if (queued && c->batch_cursor + nslots > kMaxRed) PO_TRY(batch_flush(c));
+  if (c->batch_depth > 0 || !c->batch_pend.empty()) {
+    PO_TRY(launch_reduce_final(c, nblocks, nslots, nsum, nmin, c->batch_cursor));
+    c->batch_pend.push_back(Ctx::PendingRed{c->batch_cursor, nsum, nmin, nmax, host_out});
+    c->batch_cursor += nslots;
+    if (now || c->batch_depth == 0) return batch_flush(c);
+    return PO_OK;
+  }
+  PO_TRY(launch_reduce_final(c, nblocks, nslots, nsum, nmin, 0));
+  const double *parts = nullptr;
+  int nparts = 1;
+  PO_TRY(exchange_reduced(c, nslots, nmin == 0 && nmax == 0, &parts, &nparts));
+  combine_segment(parts, nparts, nslots, 0, nsum, nmin, nmax, host_out);
   return PO_OK;
 }
 

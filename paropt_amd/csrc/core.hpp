@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,19 @@ struct Ctx {
   double *h_red = nullptr;       // pinned [size * kMaxRed]
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   long n_reductions = 0;  // statistics: host-synchronising reductions issued
+  // Batched reductions (BatchScope): while batch_depth > 0, reduce_finish only launches the rank-local final stage
+  // into d_red[batch_cursor...] and queues the segment; ONE collective + copy + host sync serves every queued
+  // segment when the batch is flushed.  Host code that depends on a queued result runs through after_reduce().
+  struct PendingRed {
+    int off, nsum, nmin, nmax;
+    double *host_out;
+  };
+  int batch_enabled = 1;  // po_ctx_set_reduction_batching / PAROPT_AMD_NO_BATCH=1: every reduction syncs by itself
+  int batch_depth = 0;
+  int batch_cursor = 0;
+  std::vector<PendingRed> batch_pend;
+  std::vector<std::function<void()>> batch_after;
+  long n_batched = 0;  // statistics: reductions that shared another one's host sync
   long n_launches = 0;
   // live timing of the headline kernel: mdot launches of exactly this many vectors are bracketed by ev0/ev1
   int time_mdot_nv = 0;
@@ -94,7 +108,42 @@ struct CoefTable {
 
 // Reduction finish: combine first-stage partials ([slot][nblocks] in ctx->d_partials) into
 // host_out[nsum+nmin+nmax]; slots are ordered sums, then mins, then maxs.  Collective.
-int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out);
+// Inside a BatchScope the call returns before host_out is valid unless `now` is set (which flushes the batch).
+int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out, bool now = false);
+int batch_flush(Ctx *c);  // collective + host sync for everything queued; runs the after_reduce() work in order
+// Host work that reads the result of the preceding reduce_finish: immediately outside a batch, at the flush inside.
+template <class F>
+inline void after_reduce(Ctx *c, F &&f) {
+  if (c->batch_depth > 0 && !c->batch_pend.empty()) {
+    c->batch_after.emplace_back(std::forward<F>(f));
+  } else {
+    f();
+  }
+}
+// Opens a batch on construction (when `on`); end() flushes whatever is queued -- also segments queued by an
+// enclosing scope, which is always safe: a flush only makes results available earlier.  Leaving the scope
+// without end() (error paths) flushes too, discarding errors.
+struct BatchScope {
+  Ctx *c;
+  bool open;
+  explicit BatchScope(Ctx *c_, bool on = true) : c(c_), open(on && c_->batch_enabled) {
+    if (open) c->batch_depth++;
+  }
+  int end() {
+    if (!open) return PO_OK;
+    open = false;
+    c->batch_depth--;
+    return batch_flush(c);
+  }
+  ~BatchScope() {
+    if (open) {
+      c->batch_depth--;
+      (void)batch_flush(c);
+    }
+  }
+  BatchScope(const BatchScope &) = delete;
+  BatchScope &operator=(const BatchScope &) = delete;
+};
 int ensure_partials(Ctx *c, size_t doubles);
 int grid_for(Ctx *c, int64_t n);           // persistent grid, 4 workgroups per CU
 int grid_for(Ctx *c, int64_t n, int bpc);  // ... with an explicit workgroups-per-CU cap

@@ -363,7 +363,7 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
 
 int InteriorPoint::computeResidual(double mu, bool vectors) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
-  double out[11];
+  double *out = res_out;  // a member: inside a BatchScope the values arrive at the flush (after_reduce below)
   if (has_w) PO_TRY(computeResidualW(mu));
   if (vectors) {
     std::vector<const double *> A;
@@ -395,20 +395,25 @@ int InteriorPoint::computeResidual(double mu, bool vectors) {
       zc.push_back(1.0);
     }
     PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out));
-    l1_rx = out[2];
-    l2_rx = out[5];
-    max_rx = out[8];
   } else {
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
   }
-  comp_prod = out[0];
-  comp_count = out[1];
-  l1_rzl = out[3];
-  l1_rzu = out[4];
-  l2_rzl = out[6];
-  l2_rzu = out[7];
-  max_rzl = out[9];
-  max_rzu = out[10];
+  after_reduce(ctx, [this, vectors] {
+    const double *o = res_out;
+    if (vectors) {
+      l1_rx = o[2];
+      l2_rx = o[5];
+      max_rx = o[8];
+    }
+    comp_prod = o[0];
+    comp_count = o[1];
+    l1_rzl = o[3];
+    l1_rzu = o[4];
+    l2_rzl = o[6];
+    l2_rzu = o[7];
+    max_rzl = o[9];
+    max_rzu = o[10];
+  });
   return PO_OK;
 }
 
@@ -1113,17 +1118,22 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
   const double eps = options.real("design_precision");
   double alpha = *alpha_;
   int fail = LS_FAILURE;
+  const bool batchable = prob->reductionsBatchable();
   double merit = 0.0, best_merit = 0.0, best_alpha = -1.0;
   std::vector<double> rs(c), rt(c);
   int j = 0;
   for (; j < max_it; j++) {
     double sums[2];
+    // the barrier sums at the trial point share the collective + host sync of the problem's own reductions
+    // (f, c) when those go through the internal launchers (built-in problems)
+    BatchScope batch(ctx, batchable);
     PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
     clampStepDense(rs, vars.s, alpha, step.s, eps, true);
     clampStepDense(rt, vars.t, alpha, step.t, eps, true);
     userBegin();
     int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
     userEnd();
+    PO_TRY(batch.end());
     neval++;
     if (fail_obj) {
       fprintf(stderr, "ParOpt: Evaluation failed during line search, trying new point\n");
@@ -1179,8 +1189,10 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     if (alpha != best_alpha) {
       alpha = best_alpha;
       double sums[2];
+      BatchScope batch(ctx, batchable);
       PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
       int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
+      PO_TRY(batch.end());
       neval++;
       if (fail_obj) {
         fprintf(stderr, "ParOpt: Evaluation failed during line search\n");
@@ -1238,7 +1250,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   if (eval_obj_con) {
     // the line search was skipped: form the new point now
     double sums[2];
-    PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
+    PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));  // (not in a batch: sums is local)
   }
   // the accepted trial point IS the new design point (same clamp, same arithmetic)
   std::swap(x->d, xt->d);
@@ -1258,6 +1270,9 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   if (fail_g) fprintf(stderr, "ParOpt: Gradient evaluation failed at final line search\n");
   if (do_qn) {
     PO_TRY(k_panel_axpy(ctx, s_qn->d, alpha * sx, px->d, 0.0, nullptr, nullptr, 0, n));
+    // the next residual's norms and the quasi-Newton products of the update are reduced together: nothing on the
+    // host needs the norms before the update has its dots.  Only when no user code runs in between.
+    BatchScope batch(ctx, fast_yqn && prob->reductionsBatchable() && qn->reductionsBatchable());
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
       PO_TRY(computeResidual(barrier_param, true));
@@ -1283,6 +1298,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     } else {
       PO_TRY(qn->update(s_qn, y_qn, update_type));
     }
+    PO_TRY(batch.end());
   } else if (qn && perform_qn_update) {  // :4261-4263
     if (qn->updateMult(x, vars.z.data(), has_w ? wvar[0] : nullptr) != 0) return PO_ERR_USER;
     *update_type = 0;

@@ -183,6 +183,7 @@ class InteriorPoint {
   std::vector<Vec *> Uw;    // U_j = Aw (Dinv o P_j)
   bool panel_valid = false;  // Uw matches the current setUpKKTSystem (consumed by solveKKTW)
   double w_sums[7], w_maxs[5];  // reductions of the last w residual (k_w_res layout)
+  double res_out[11] = {0}, wres_out[12] = {0};  // landing area of the residual reductions (see after_reduce)
   WVars wv() const;
   WVars wr() const;
   WVars wp() const;

@@ -66,10 +66,11 @@ int InteriorPoint::applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw)
 // the w blocks of computeKKTRes (:1358-1398) and their norms
 int InteriorPoint::computeResidualW(double mu) {
   if (prob->evalSparseCon(x, wresv[0]) != 0) return PO_ERR_USER;
-  double out[12];
-  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, out));
-  for (int i = 0; i < 7; i++) w_sums[i] = out[i];
-  for (int i = 0; i < 5; i++) w_maxs[i] = out[7 + i];
+  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, wres_out));
+  after_reduce(ctx, [this] {
+    for (int i = 0; i < 7; i++) w_sums[i] = wres_out[i];
+    for (int i = 0; i < 5; i++) w_maxs[i] = wres_out[7 + i];
+  });
   return PO_OK;
 }
 

@@ -115,10 +115,10 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
-int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin) {
+int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off) {
   const int grid = (nslots + 3) / 4;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(grid), dim3(kBlock), 0, c->stream, c->d_partials,
-                     nblocks, nslots, nsum, nmin, c->d_red);
+                     nblocks, nslots, nsum, nmin, c->d_red + dst_off);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   return PO_OK;
@@ -521,7 +521,7 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
   if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_mdot_launch(c, x, V, nv, n, &grid));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
-  PO_TRY(reduce_finish(c, grid, nv, 0, 0, out));  // synchronises the stream: ev1 has completed
+  PO_TRY(reduce_finish(c, grid, nv, 0, 0, out, timed));  // timed: synchronises the stream, ev1 has completed
   if (timed) {
     float ms = 0.0f;
     PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -1509,7 +1509,7 @@ int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double
   PO_LAUNCH(check_bounds_kernel, grid, x, lb, ub, zl, zu, max_bound, rel_bound, both, n,
             c->d_partials);
   double out[3];
-  PO_TRY(reduce_finish(c, grid, 0, 0, 3, out));
+  PO_TRY(reduce_finish(c, grid, 0, 0, 3, out, true));
   *flag = (out[0] > 0.0 ? 1 : 0) | (out[1] > 0.0 ? 2 : 0) | (out[2] > 0.0 ? 4 : 0);
   return PO_OK;
 }

@@ -28,6 +28,11 @@ class Problem {
   // false: the call above leaves s untouched (lets the solver reuse products it already has with the step)
   virtual bool quasiNewtonCorrectionMayChangeStep() { return false; }
   virtual int writeOutput(int iter, Vec *x) { return 0; }
+  // true: every reduction the evaluation callbacks issue goes through the internal launchers and tolerates an
+  // enclosing BatchScope (core.hpp), so the solver may let them share ONE collective + host sync with its own
+  // reductions (trial-point barrier sums with f and c; next residual with the quasi-Newton products).  false
+  // (default) for anything that calls out to user code: C-ABI reductions must return their values immediately.
+  virtual bool reductionsBatchable() { return false; }
   // ParOptProblem::checkGradients (src/ParOptProblem.cpp:225-622) on device vectors: direction sign(g), forward
   // differences with step dh of the objective and of every dense constraint against g.p and Ac_i.p (and, with
   // check_hvec, of the Lagrangian's gradient against the Hessian-vector product).  work1/work2 are n-sized
@@ -136,6 +141,7 @@ class SeparableProblem : public Problem {
   int getVarsAndBounds(Vec *x, Vec *lb, Vec *ub) override;
   int evalObjCon(Vec *x, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) override;
+  bool reductionsBatchable() override { return true; }
   // weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i (nw + nwskip) + k] on GLOBAL indices;
   // groups must not straddle rank boundaries (checked)
   int setWeighting(int64_t nwcon_global, int nw, int64_t nwstart, int nwskip, int64_t nwineq_global);

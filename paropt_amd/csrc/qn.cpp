@@ -226,6 +226,7 @@ int LBFGS::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {
   const int mold = k / 2;
   // one pass: [Z^T s, s.s, s.y] (Z^T s from the caller when it has it); one more reduction for y.y
   std::vector<double> dots(k + 2, 0.0);
+  BatchScope batch(ctx);  // both reductions (and whatever the caller has queued) share one collective + sync
   if (zTs) {
     const double *two[2] = {s->d, y->d};
     PO_TRY(k_mdot(ctx, s->d, two, 2, n, dots.data() + k));
@@ -238,6 +239,7 @@ int LBFGS::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {
   }
   double yTy = 0.0;
   PO_TRY(k_reduce1(ctx, RED_SUMSQ, y->d, nullptr, n, &yTy));
+  PO_TRY(batch.end());
   double sTs = dots[k], yTs = dots[k + 1];
   if (1e-8 * yTy >= fabs(yTs)) {  // Nocedal skip :175-179
     *rc = 2;
@@ -276,7 +278,9 @@ int LBFGS::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {
     y_update = r;
     const double *two[2] = {r->d, s->d};
     double d2[2];
+    BatchScope damped(ctx);  // the values are needed now, also when the caller has a batch open
     PO_TRY(k_mdot(ctx, r->d, two, 2, n, d2));
+    PO_TRY(damped.end());
     yTy = d2[0];
     yTs = d2[1];
     b0 = (diag_type == PO_QN_YTS_OVER_STS) ? yTs / sTs : yTy / yTs;
@@ -291,21 +295,16 @@ int LBFGS::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {
 int LSR1::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {  // :636-747
   *rc = 0;
   const int mold = msub;
-  std::vector<double> dots(2 * mold + 2, 0.0);
-  if (zTs && (int)Z.size() == mold) {
+  std::vector<double> dots(2 * mold + 2, 0.0), d2(mold + 2, 0.0);
+  const bool hint = zTs && (int)Z.size() == mold;
+  BatchScope batch(ctx);  // both reductions (and whatever the caller has queued) share one collective + sync
+  if (hint) {
     // Z_j = Y_j - b0 S_j with the b0 still in place: Y_j.s = Z_j.s + b0 S_j.s, so only the S columns are streamed
     std::vector<const double *> vp;
     for (int i = 0; i < mold; i++) vp.push_back(S[i]->d);
     vp.push_back(s->d);
     vp.push_back(y->d);
-    std::vector<double> d2(mold + 2, 0.0);
     PO_TRY(k_mdot(ctx, s->d, vp.data(), mold + 2, n, d2.data()));
-    for (int i = 0; i < mold; i++) {
-      dots[i] = d2[i];
-      dots[mold + i] = zTs[i] + b0 * d2[i];
-    }
-    dots[2 * mold] = d2[mold];
-    dots[2 * mold + 1] = d2[mold + 1];
   } else {
     std::vector<const double *> vp;
     for (int i = 0; i < mold; i++) vp.push_back(S[i]->d);
@@ -316,6 +315,15 @@ int LSR1::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {  // :636-7
   }
   double yTy = 0.0;
   PO_TRY(k_reduce1(ctx, RED_SUMSQ, y->d, nullptr, n, &yTy));
+  PO_TRY(batch.end());
+  if (hint) {
+    for (int i = 0; i < mold; i++) {
+      dots[i] = d2[i];
+      dots[mold + i] = zTs[i] + b0 * d2[i];
+    }
+    dots[2 * mold] = d2[mold];
+    dots[2 * mold + 1] = d2[mold + 1];
+  }
   const double sTs = dots[2 * mold], sTy = dots[2 * mold + 1];
   const double epsilon_precision = 1e-12;
   b0 = (sTy > epsilon_precision * yTy) ? yTy / sTy : 1.0;

@@ -31,6 +31,9 @@ class CompactQuasiNewton {
   // implied -- none for L-BFGS (Z = [S | Y]), the S columns for L-SR1 (Y_j.s = Z_j.s + b0 S_j.s).  zTs has
   // size() entries in the order of the current panel.  Default: ignores the hint.
   virtual int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) { return update(s, y, rc); }
+  // true: update() issues its reductions through the internal launchers only and tolerates an enclosing BatchScope
+  // (core.hpp); false for approximations that call out to user code (ParOptEigenQuasiNewton's update callback)
+  virtual bool reductionsBatchable() const { return false; }
   // update(x, z, zw): multiplier-only update, a no-op for the limited-memory classes
   // (src/ParOptQuasiNewton.h:60-63); ParOptEigenQuasiNewton records z[index] here
   virtual int updateMult(Vec *x, const double *z, Vec *zw) { return 0; }
@@ -90,6 +93,7 @@ class LBFGS : public CompactQuasiNewton {
   void setBFGSUpdateType(int t) { update_type = t; }
   int update(Vec *s, Vec *y, int *rc) override { return updateWithZTs(s, y, nullptr, rc); }
   int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) override;
+  bool reductionsBatchable() const override { return true; }
   int getMaxLimitedMemorySize() override { return 2 * msub_max; }
 
  private:
@@ -106,6 +110,7 @@ class LSR1 : public CompactQuasiNewton {
   }
   int update(Vec *s, Vec *y, int *rc) override { return updateWithZTs(s, y, nullptr, rc); }
   int updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) override;
+  bool reductionsBatchable() const override { return true; }
   int getMaxLimitedMemorySize() override { return msub_max; }
   bool pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp, std::vector<double *> *Zout,
                 double *b0_) const override;

@@ -503,7 +503,7 @@ int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, 
   PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
   std::vector<double> blocks(nslots);
-  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data()));  // synchronises the stream
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data(), true));  // synchronises the stream
   if (timed) {
     float ms = 0.0f;
     PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));

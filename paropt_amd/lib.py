@@ -94,6 +94,8 @@ SIGNATURES = {
     "po_ctx_time_wgram": (C.c_int, [po_ctx, C.c_int]),
     "po_ctx_time_wgram_result": (C.c_int, [po_ctx, C.c_int, c_double_p, c_i64_p, c_int_p, c_double_p]),
     "po_ctx_comm_info": (C.c_int, [po_ctx, c_int_p, c_i64_p, c_i64_p]),
+    "po_ctx_set_reduction_batching": (C.c_int, [po_ctx, C.c_int]),
+    "po_ctx_batched_reductions": (C.c_int, [po_ctx, c_i64_p]),
     "po_rccl_unique_id": (C.c_int, [C.c_void_p]),
     "po_ctx_comm_init_rccl": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_void_p]),
     "po_ctx_comm_init_callback": (C.c_int, [po_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),

@@ -905,3 +905,39 @@ def test_check_kkt_step_residual_sparse(ctx, form):
     scale = max(1.0, np.abs(rx).max(), np.abs(rzw).max(), np.abs(rz).max(), np.abs(rtw).max())
     for name, e in errs.items():
         assert np.abs(e).max() <= 1e-9 * scale, (form, name, np.abs(e).max(), scale)
+
+
+@pytest.mark.parametrize("problem,qn,strategy", [("convex", "sr1", "monotone"), ("quadratic", "bfgs", "monotone"),
+                                                 ("convex", "bfgs", "mehrotra_predictor_corrector"),
+                                                 ("rosenbrock", "bfgs", "monotone")])
+def test_reduction_batching_changes_no_bit(problem, qn, strategy):
+    """Batched reductions (po_ctx_set_reduction_batching): trial-point barrier sums + f + c, and the next
+    residual's norms + the quasi-Newton products, share one collective + host sync each.  The partial sums and the
+    final stage are the same kernels, so every iterate is the same bits; only the number of host syncs drops."""
+    import paropt_amd as pa
+
+    opts = {"qn_type": qn, "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 30, "write_output_frequency": 0, "barrier_strategy": strategy,
+            "qn_update_type": "damped_update"}
+    runs = []
+    for on in (False, True):
+        c = pa.Context(0).set_reduction_batching(on)
+        prob = pa.SeparableProblem(c, problem, 20011, 2 if problem == "rosenbrock" else 7)
+        ip = pa.InteriorPoint(prob, opts)
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        r0 = c.counters()[0]
+        ip.optimize()
+        runs.append((sn, ip.getOptimizedPoint()[0].to_numpy(), c.counters()[0] - r0, c.batched_reductions()))
+    a, b = runs
+    assert len(a[0]) == len(b[0]) and len(a[0]) >= 10
+    for sa, sb in zip(a[0], b[0]):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
+        np.testing.assert_array_equal(sa["norms"], sb["norms"])
+        np.testing.assert_array_equal(sa["z"], sb["z"])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert a[3] == 0 and b[3] > 2 * len(b[0])
+    # at least two host syncs fewer per iteration (three per quasi-Newton update + one per extra trial point)
+    assert b[2] <= a[2] - 2 * (len(b[0]) - 1), (a[2], b[2])
+    assert a[2] - b[2] == b[3]
