@@ -191,8 +191,9 @@ struct Bounds {  // the per-element data every bound-aware kernel needs
 // l1 rzu, l2^2 rx, l2^2 rzl, l2^2 rzu, max|rx|, max|rzl|, max|rzu|} with
 // rzl = -((x-lb) zl - beta*mu), rzu = -((ub-x) zu - beta*mu).
 // (computeKKTRes :1337-1446 + computeComp :2742-2820 + computeResNorm :1588-1723)
+// yqn != nullptr: the same pass also completes the quasi-Newton gradient difference, yqn += [lo]zl - [up]zu - rx
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[11]);
+              int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn = nullptr);
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);

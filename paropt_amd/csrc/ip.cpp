@@ -361,7 +361,7 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
   }
 }
 
-int InteriorPoint::computeResidual(double mu, bool vectors) {
+int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   double *out = res_out;  // a member: inside a BatchScope the values arrive at the flush (after_reduce below)
   if (has_w) PO_TRY(computeResidualW(mu));
@@ -394,7 +394,8 @@ int InteriorPoint::computeResidual(double mu, bool vectors) {
       A.push_back(tvec->d);
       zc.push_back(1.0);
     }
-    PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out));
+    PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
+                     yqn_complete ? yqn_complete->d : nullptr));
   } else {
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
   }
@@ -1275,11 +1276,9 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     BatchScope batch(ctx, fast_yqn && prob->reductionsBatchable() && qn->reductionsBatchable());
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
-      PO_TRY(computeResidual(barrier_param, true));
+      // ... and y_qn += [lo]zl+ - [up]zu+ - rx+ in the same pass (the residual kernel has all three in registers)
+      PO_TRY(computeResidual(barrier_param, true, y_qn));
       residual_cached = true;
-      const double cf[3] = {use_lower ? 1.0 : 0.0, use_upper ? -1.0 : 0.0, -1.0};
-      const double *vv[3] = {zl->d, zu->d, rx->d};
-      PO_TRY(k_panel_axpy(ctx, y_qn->d, 0.0, nullptr, 1.0, cf, vv, 3, n));
     } else {
       std::vector<double> mz(c > 0 ? c : 1);
       for (int i = 0; i < c; i++) mz[i] = -vars.z[i];
@@ -1294,9 +1293,15 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
         !inexact_newton_step && !prob->quasiNewtonCorrectionMayChangeStep()) {
       std::vector<double> zts(kz);
       for (int j = 0; j < kz; j++) zts[j] = alpha * sx * ptpx[c + j];
-      PO_TRY(qn->updateWithZTs(s_qn, y_qn, zts.data(), update_type));
+      qn->take_buffers = true;  // s_qn / y_qn are rewritten from scratch before their next use
+      const int urc = qn->updateWithZTs(s_qn, y_qn, zts.data(), update_type);
+      qn->take_buffers = false;
+      PO_TRY(urc);
     } else {
-      PO_TRY(qn->update(s_qn, y_qn, update_type));
+      qn->take_buffers = true;
+      const int urc = qn->update(s_qn, y_qn, update_type);
+      qn->take_buffers = false;
+      PO_TRY(urc);
     }
     PO_TRY(batch.end());
   } else if (qn && perform_qn_update) {  // :4261-4263

@@ -204,7 +204,7 @@ class InteriorPoint {
   int initLeastSquaresMultipliers();
   int initAffineStepMultipliers();
   void denseResidual(double mu, Dense &r) const;
-  int computeResidual(double mu, bool vectors);
+  int computeResidual(double mu, bool vectors, Vec *yqn_complete = nullptr);
   void resNorms(const Dense &r, double *max_prime, double *max_dual, double *max_infeas,
                 double *res_norm) const;
   double compFromSums(double prod, double count, const Dense &v, double wprod = 0.0) const;

@@ -28,8 +28,16 @@ namespace po {
 // Every device vector is allocated with an even number of (zero-initialised) elements plus slack
 // (qn.cpp::vec_new), so the last pair of an odd-length vector can be loaded and stored as a full
 // 16-byte access without a branch; the pad element is kept at exactly 0.0 by st2.
+// Every n-sized operand is read once per kernel, gigabytes apart: non-temporal loads (element-wise kernels +4-13 %
+// in tools/ab_libs.sh; -DPO_LD2_PLAIN builds the plain form for an A/B).
+typedef double f64x2l __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 ld2(const double *__restrict__ p, int64_t q, int64_t n) {
+#ifndef PO_LD2_PLAIN
+  const f64x2l v = __builtin_nontemporal_load(reinterpret_cast<const f64x2l *>(p + 2 * q));
+  return make_double2(v.x, v.y);
+#else
   return *reinterpret_cast<const double2 *>(p + 2 * q);
+#endif
 }
 #ifndef PO_ST2_PLAIN
 #define PO_ST2_NT 1
@@ -592,13 +600,16 @@ __device__ __forceinline__ void res_bound_acc(const BE &e, double beta_mu, doubl
 }
 __global__ void __launch_bounds__(kBlock)
     kkt_res_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc,
-                   double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ partials) {
+                   double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ yqn,
+                   double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[3] = {0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
     const double2 gv = ld2(g, q, n);
+    double2 yv = make_double2(0.0, 0.0);
+    if (yqn) yv = ld2(yqn, q, n);
     double2 r;
     r.x = (b.use_lower ? _zl.x : 0.0);
     r.y = (b.use_lower ? _zl.y : 0.0);
@@ -613,6 +624,14 @@ __global__ void __launch_bounds__(kBlock)
     r.y += ps.y;
     if (!_has2) r.y = 0.0;
     st2(rx, q, n, r);
+    if (yqn) {
+      // second bracket of the quasi-Newton gradient difference, y += [lo]zl - [up]zu - rx at the new point, in the
+      // operation order of the panel_axpy pass it replaces (computeStepAndUpdate)
+      const double cl = b.use_lower ? 1.0 : 0.0, cu = b.use_upper ? -1.0 : 0.0;
+      yv.x += fma(-1.0, r.x, fma(cu, _zu.x, fma(cl, _zl.x, 0.0)));
+      yv.y += fma(-1.0, r.y, fma(cu, _zu.y, fma(cl, _zl.y, 0.0)));
+      st2(yqn, q, n, yv);
+    }
     maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
     sums[2] += fabs(r.x) + fabs(r.y);
     sums[5] += r.x * r.x + r.y * r.y;
@@ -624,13 +643,13 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[11]) {
+              int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn) {
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
-  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, c->d_partials);
+  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, c->d_partials);
   return reduce_finish(c, grid, 8, 0, 3, out);
 }
 

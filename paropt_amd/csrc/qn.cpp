@@ -157,14 +157,22 @@ int CompactQuasiNewton::storePair(Vec *s, Vec *y, const double *sS, const double
                                   double sTy) {
   // pointer rotation and matrix shifts: src/ParOptQuasiNewton.cpp:266-303
   int shift = 0;
+  // the pair enters its slot by buffer exchange when the caller allows it (take_buffers), by copy otherwise
+  auto put = [&](Vec *slot, Vec *src) -> int {
+    if (take_buffers && src->n == slot->n && !src->h_live && !slot->h_live) {
+      std::swap(slot->d, src->d);
+      return PO_OK;
+    }
+    return k_copy(ctx, slot->d, src->d, n);
+  };
   if (msub < msub_max) {
-    PO_TRY(k_copy(ctx, S[msub]->d, s->d, n));
-    PO_TRY(k_copy(ctx, Y[msub]->d, y->d, n));
+    PO_TRY(put(S[msub], s));
+    PO_TRY(put(Y[msub], y));
     msub++;
   } else if (msub == msub_max && msub_max > 0) {
     shift = 1;
-    PO_TRY(k_copy(ctx, S[0]->d, s->d, n));
-    PO_TRY(k_copy(ctx, Y[0]->d, y->d, n));
+    PO_TRY(put(S[0], s));
+    PO_TRY(put(Y[0], y));
     Vec *st = S[0], *yt = Y[0];
     for (int i = 0; i < msub - 1; i++) {
       S[i] = S[i + 1];

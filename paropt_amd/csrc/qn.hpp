@@ -34,6 +34,11 @@ class CompactQuasiNewton {
   // true: update() issues its reductions through the internal launchers only and tolerates an enclosing BatchScope
   // (core.hpp); false for approximations that call out to user code (ParOptEigenQuasiNewton's update callback)
   virtual bool reductionsBatchable() const { return false; }
+  // Set by a caller that owns s and y and rewrites them completely before their next use (the interior point's
+  // s_qn / y_qn): the update then takes their device buffers into the pair slots and hands the slots' old buffers
+  // back instead of copying 2 n-vectors (the copies of src/ParOptQuasiNewton.cpp:266-303).  s and y hold
+  // unspecified values afterwards.  Never set for vectors that belong to user code.
+  bool take_buffers = false;
   // update(x, z, zw): multiplier-only update, a no-op for the limited-memory classes
   // (src/ParOptQuasiNewton.h:60-63); ParOptEigenQuasiNewton records z[index] here
   virtual int updateMult(Vec *x, const double *z, Vec *zw) { return 0; }

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libparopt_amd.so")
+LIB_PATH = os.environ.get("PAROPT_AMD_LIB") or os.path.join(_HERE, "libparopt_amd.so")  # override: A/B kernel builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
