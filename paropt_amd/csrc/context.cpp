@@ -260,6 +260,12 @@ static void combine_segment(const double *parts, int nparts, int stride, int off
   }
 }
 
+void batch_abort(Ctx *c) {
+  c->batch_pend.clear();
+  c->batch_after.clear();
+  c->batch_cursor = 0;
+}
+
 int batch_flush(Ctx *c) {
   if (c->batch_pend.empty()) {
     // nothing queued: deferred host work (if any slipped in) still runs

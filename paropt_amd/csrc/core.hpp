@@ -111,6 +111,7 @@ struct CoefTable {
 // Inside a BatchScope the call returns before host_out is valid unless `now` is set (which flushes the batch).
 int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out, bool now = false);
 int batch_flush(Ctx *c);  // collective + host sync for everything queued; runs the after_reduce() work in order
+void batch_abort(Ctx *c);  // forget everything queued (error paths)
 // Host work that reads the result of the preceding reduce_finish: immediately outside a batch, at the flush inside.
 template <class F>
 inline void after_reduce(Ctx *c, F &&f) {
@@ -122,7 +123,8 @@ inline void after_reduce(Ctx *c, F &&f) {
 }
 // Opens a batch on construction (when `on`); end() flushes whatever is queued -- also segments queued by an
 // enclosing scope, which is always safe: a flush only makes results available earlier.  Leaving the scope
-// without end() (error paths) flushes too, discarding errors.
+// without end() (an error is propagating) drops what is queued, enclosing scopes' segments included: nothing is
+// written to result locations whose owners may already have returned.
 struct BatchScope {
   Ctx *c;
   bool open;
@@ -138,7 +140,7 @@ struct BatchScope {
   ~BatchScope() {
     if (open) {
       c->batch_depth--;
-      (void)batch_flush(c);
+      batch_abort(c);
     }
   }
   BatchScope(const BatchScope &) = delete;
