@@ -264,6 +264,7 @@ void batch_abort(Ctx *c) {
   c->batch_pend.clear();
   c->batch_after.clear();
   c->batch_cursor = 0;
+  c->mdot_timing_pending = false;
 }
 
 int batch_flush(Ctx *c) {

@@ -80,6 +80,7 @@ struct Ctx {
   int time_mdot_nv = 0;
   double mdot_ms = 0.0;
   long mdot_count = 0;
+  bool mdot_timing_pending = false;  // a timed launch is queued in the open batch (its events are read at the flush)
   // the same for the weighted-Gram launches (po_ctx_time_wgram): [0] plain, [1] with L-SR1 columns formed in the pass
   int time_wgram = 0;
   double wgram_ms[2] = {0.0, 0.0};
@@ -131,11 +132,34 @@ struct BatchScope {
   explicit BatchScope(Ctx *c_, bool on = true) : c(c_), open(on && c_->batch_enabled) {
     if (open) c->batch_depth++;
   }
+  void begin() {  // for a scope constructed with on = false: open it now
+    if (!open && c->batch_enabled) {
+      open = true;
+      c->batch_depth++;
+    }
+  }
   int end() {
     if (!open) return PO_OK;
     open = false;
     c->batch_depth--;
     return batch_flush(c);
+  }
+  // For a callee whose results are only post-processed (not branched on): inside an enclosing scope the flush is
+  // left to that scope and `post` (host work on the reduced values) runs there; otherwise flush and run it now.
+  // The result locations must stay valid until the enclosing scope ends.
+  template <class F>
+  int end_then(F &&post) {
+    if (open) {
+      open = false;
+      c->batch_depth--;
+      if (c->batch_depth > 0) {
+        after_reduce(c, std::forward<F>(post));
+        return PO_OK;
+      }
+      PO_TRY(batch_flush(c));
+    }
+    post();
+    return PO_OK;
   }
   ~BatchScope() {
     if (open) {

@@ -364,6 +364,9 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
 int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   double *out = res_out;  // a member: inside a BatchScope the values arrive at the flush (after_reduce below)
+  // sparse and design blocks of the residual share one collective + sync (the problem's sparse callbacks run in
+  // between: built-in problems only)
+  BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
   if (has_w) PO_TRY(computeResidualW(mu));
   if (vectors) {
     std::vector<const double *> A;
@@ -415,7 +418,7 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
     max_rzl = o[9];
     max_rzu = o[10];
   });
-  return PO_OK;
+  return wbatch.end();
 }
 
 void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual,
@@ -905,19 +908,20 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
       az = ax / max_bnd;
     }
   }
-  double out[9];
+  double out[9], wprod = 0.0;
   if (!has_w) {
     // one pass also yields the merit pieces and the step norm the line search is about to ask for
     PO_TRY(k_comp_merit(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, g->d, n, out));
     for (int i = 0; i < 7; i++) merit_cache[i] = out[2 + i];
     merit_cache_valid = true;
   } else {
+    BatchScope batch(ctx);  // design and sparse parts of the complementarity: one collective + sync
     PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, n, out));
+    PO_TRY(wCompStep(ax, az, &wprod));  // :2866-2889
+    PO_TRY(batch.end());
   }
   double prod = out[0] / options.real("rel_bound_barrier"), count = out[1];
-  if (has_w) {  // :2866-2889
-    double wprod = 0.0;
-    PO_TRY(wCompStep(ax, az, &wprod));
+  if (has_w) {
     prod += wprod;
     count += 2.0 * nw_global;
   }
@@ -991,34 +995,42 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
   const double frac = options.real("penalty_descent_fraction");
   const bool seq_lin = options.integer("sequential_linear_method");
   double out[6];
-  if (merit_cache_valid) {
-    out[0] = merit_cache[0];
-    out[1] = merit_cache[1];
-    out[2] = sx * merit_cache[2];
-    out[3] = sx * merit_cache[3];
-    out[4] = sx * merit_cache[4];
-    out[5] = sx * sx * merit_cache[5];
-  } else {
-    PO_TRY(k_merit0(ctx, bounds(), px->d, sx, g->d, n, out));
-  }
-  double pos = out[0] * beta, neg = out[1] * beta, ppos = out[2] * beta, pneg = out[3] * beta;
-  const double gpx = out[4], pxpx = out[5];
+  double wm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int kq = 0;
   std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
   const int mq = c + kq;
   std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
-  if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
-    for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
-  } else if (mq > 0) {
-    PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+  {
+    // design part, panel products (when not known analytically) and sparse part: one collective + sync (the
+    // problem's sparse callbacks run in between: built-in problems only)
+    BatchScope batch(ctx, has_w && prob->reductionsBatchable());
+    if (merit_cache_valid) {
+      out[0] = merit_cache[0];
+      out[1] = merit_cache[1];
+      out[2] = sx * merit_cache[2];
+      out[3] = sx * merit_cache[3];
+      out[4] = sx * merit_cache[4];
+      out[5] = sx * sx * merit_cache[5];
+    } else {
+      PO_TRY(k_merit0(ctx, bounds(), px->d, sx, g->d, n, out));
+    }
+    if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
+      for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
+    } else if (mq > 0) {
+      PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
+    }
+    if (has_w) {  // :3735-3765, 3489-3503
+      if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
+      PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
+      if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
+      PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, wtmp->d, wtmp2->d, nw, wm));
+    }
+    PO_TRY(batch.end());
   }
+  double pos = out[0] * beta, neg = out[1] * beta, ppos = out[2] * beta, pneg = out[3] * beta;
+  const double gpx = out[4], pxpx = out[5];
   for (int i = 0; i < mq; i++) dots[i] *= sx;
-  double wm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  if (has_w) {  // :3735-3765, 3489-3503
-    if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
-    PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
-    if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
-    PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, wtmp->d, wtmp2->d, nw, wm));
+  if (has_w) {
     pos += wm[0];
     neg += wm[1];
     ppos += wm[2];
@@ -1124,7 +1136,7 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
   std::vector<double> rs(c), rt(c);
   int j = 0;
   for (; j < max_it; j++) {
-    double sums[2];
+    double sums[2], wsums[5];
     // the barrier sums at the trial point share the collective + host sync of the problem's own reductions
     // (f, c) when those go through the internal launchers (built-in problems)
     BatchScope batch(ctx, batchable);
@@ -1134,6 +1146,10 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     userBegin();
     int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
     userEnd();
+    if (has_w && batchable && !fail_obj) {  // the sparse slack sums ride in the same collective
+      if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
+      PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
+    }
     PO_TRY(batch.end());
     neval++;
     if (fail_obj) {
@@ -1141,8 +1157,7 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       alpha *= 0.1;
       continue;
     }
-    double wsums[5];
-    if (has_w) {
+    if (has_w && !batchable) {
       if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
       PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
     }

@@ -159,6 +159,9 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   // the panel the Gram correction already holds: dzw += -S^-1 (U alpha), dx += Dinv (P alpha + Aw^T of that) -
   // no second quasi-definite apply, and P alpha rides in the same pass that forms the bound multipliers
   double mins_x[2], mins_w[2];
+  // the fraction-to-boundary minima of the design and of the sparse blocks: one collective + sync (opened right
+  // before the first of the two launches: no user code runs between them)
+  BatchScope minbatch(ctx, false);
   if (m > 0 && (int)Uw.size() >= m && panel_valid) {
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
@@ -170,16 +173,19 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     std::vector<double> a1(alpha.begin(), alpha.begin() + m);
     P1.push_back(d1v->d);
     a1.push_back(1.0);
+    minbatch.begin();
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, a1.data(), P1.data(), m + 1, beta_mu, refine_pass ? 1 : 0,
                     tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl, cu));
   } else {
     if (m > 0) PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, alpha.data(), P.data(), m, n));
     PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+    minbatch.begin();
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, nullptr, nullptr, 0, beta_mu, refine_pass ? 1 : 0,
                     tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
                     cu));
   }
   PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
+  PO_TRY(minbatch.end());
   step_mins[0] = std::min(mins_x[0], mins_w[0]);
   step_mins[1] = std::min(mins_x[1], mins_w[1]);
   for (int i = 0; i < c; i++) {

@@ -526,15 +526,25 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
   if (nv <= 0) return PO_OK;
   int grid = 0;
   const bool timed = c->time_mdot_nv == nv;  // po_ctx_time_mdot: HIP events on the launch stream
+  // the event pair is read once the stream has been synchronised: right away, or when the enclosing batch is flushed
+  // (one timed launch per batch: a second one would reuse the events, so the batch is flushed first)
+  if (timed && c->mdot_timing_pending) PO_TRY(batch_flush(c));
   if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_mdot_launch(c, x, V, nv, n, &grid));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
-  PO_TRY(reduce_finish(c, grid, nv, 0, 0, out, timed));  // timed: synchronises the stream, ev1 has completed
+  const bool defer = timed && c->batch_depth > 0;
+  PO_TRY(reduce_finish(c, grid, nv, 0, 0, out, timed && !defer));
   if (timed) {
-    float ms = 0.0f;
-    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    c->mdot_ms += ms;
-    c->mdot_count++;
+    auto harvest = [c] {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+        c->mdot_ms += ms;
+        c->mdot_count++;
+      }
+      c->mdot_timing_pending = false;
+    };
+    if (defer) c->mdot_timing_pending = true;
+    after_reduce(c, harvest);
   }
   return PO_OK;
 }

@@ -142,6 +142,7 @@ class SeparableProblem : public Problem {
   int evalObjCon(Vec *x, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) override;
   bool reductionsBatchable() override { return true; }
+  double rosen_out[3] = {0, 0, 0};  // landing area of the Rosenbrock reductions (BatchScope::end_then)
   // weighting constraints cw_i = 1 - sum_{k<nw} x[nwstart + i (nw + nwskip) + k] on GLOBAL indices;
   // groups must not straddle rank boundaries (checked)
   int setWeighting(int64_t nwcon_global, int nw, int64_t nwstart, int nwskip, int64_t nwineq_global);

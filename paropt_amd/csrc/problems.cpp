@@ -537,14 +537,13 @@ int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
   const int64_t n = nlocal;
   if (csr) PO_TRY(k_chain_con(ctx, x->d, nwcon, chain_span, chain_stride, csr->cw->d));
   if (kind == PO_PROBLEM_ROSENBROCK) {
-    double out[3];
     BatchScope batch(ctx);
-    PO_TRY(k_rosen_f(ctx, x->d, n, out));
-    PO_TRY(batch.end());
-    *fobj = out[0];
-    cons[0] = out[1] + 0.25;
-    cons[1] = out[2] + 10.0;
-    return PO_OK;
+    PO_TRY(k_rosen_f(ctx, x->d, n, rosen_out));
+    return batch.end_then([this, fobj, cons] {
+      *fobj = rosen_out[0];
+      cons[0] = rosen_out[1] + 0.25;
+      cons[1] = rosen_out[2] + 10.0;
+    });
   }
   // objective sum and constraint products share one collective + host sync (and the caller's, if it has
   // reductions queued: the line search's barrier sums at the trial point)
@@ -557,11 +556,11 @@ int SeparableProblem::evalObjCon(Vec *x, double *fobj, double *cons) {
   std::vector<const double *> ap;
   for (Vec *v : A) ap.push_back(v->d);
   if (ncon > 0) PO_TRY(k_mdot(ctx, x->d, ap.data(), ncon, n, cons));
-  PO_TRY(batch.end());
-  for (int j = 0; j < ncon; j++) {
-    cons[j] = (kind == PO_PROBLEM_QUADRATIC) ? cons[j] + beta[j] : -cons[j] + beta[j];
-  }
-  return PO_OK;
+  return batch.end_then([this, cons] {
+    for (int j = 0; j < ncon; j++) {
+      cons[j] = (kind == PO_PROBLEM_QUADRATIC) ? cons[j] + beta[j] : -cons[j] + beta[j];
+    }
+  });
 }
 
 int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {

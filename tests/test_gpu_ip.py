@@ -907,10 +907,12 @@ def test_check_kkt_step_residual_sparse(ctx, form):
         assert np.abs(e).max() <= 1e-9 * scale, (form, name, np.abs(e).max(), scale)
 
 
-@pytest.mark.parametrize("problem,qn,strategy", [("convex", "sr1", "monotone"), ("quadratic", "bfgs", "monotone"),
-                                                 ("convex", "bfgs", "mehrotra_predictor_corrector"),
-                                                 ("rosenbrock", "bfgs", "monotone")])
-def test_reduction_batching_changes_no_bit(problem, qn, strategy):
+@pytest.mark.parametrize("problem,qn,strategy,nw", [("convex", "sr1", "monotone", 0), ("quadratic", "bfgs", "monotone", 0),
+                                                    ("convex", "bfgs", "mehrotra_predictor_corrector", 0),
+                                                    ("rosenbrock", "bfgs", "monotone", 0),
+                                                    ("convex", "bfgs", "monotone", 20),
+                                                    ("quadratic", "sr1", "mehrotra", 5)])
+def test_reduction_batching_changes_no_bit(problem, qn, strategy, nw):
     """Batched reductions (po_ctx_set_reduction_batching): trial-point barrier sums + f + c, and the next
     residual's norms + the quasi-Newton products, share one collective + host sync each.  The partial sums and the
     final stage are the same kernels, so every iterate is the same bits; only the number of host syncs drops."""
@@ -922,7 +924,10 @@ def test_reduction_batching_changes_no_bit(problem, qn, strategy):
     runs = []
     for on in (False, True):
         c = pa.Context(0).set_reduction_batching(on)
-        prob = pa.SeparableProblem(c, problem, 20011, 2 if problem == "rosenbrock" else 7)
+        prob = pa.SeparableProblem(c, problem, 20000 if nw else 20011, 2 if problem == "rosenbrock" else 7)
+        if nw:  # sparse (weighting) constraints: the w-sized reductions join the batches
+            prob.setWeighting(20000 // nw // 2, nw, 0, nw)
+            opts = dict(opts, penalty_gamma=1000.0, starting_point_strategy="affine_step")
         ip = pa.InteriorPoint(prob, opts)
         sn = []
         ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
@@ -936,6 +941,8 @@ def test_reduction_batching_changes_no_bit(problem, qn, strategy):
         assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
         np.testing.assert_array_equal(sa["norms"], sb["norms"])
         np.testing.assert_array_equal(sa["z"], sb["z"])
+        if nw:
+            np.testing.assert_array_equal(sa["wnorms"], sb["wnorms"])
     np.testing.assert_array_equal(a[1], b[1])
     assert a[3] == 0 and b[3] > 2 * len(b[0])
     # at least two host syncs fewer per iteration (three per quasi-Newton update + one per extra trial point)
