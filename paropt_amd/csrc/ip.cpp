@@ -552,9 +552,24 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   std::vector<const double *> P = panel(use_qn && !diag_only, &k);
   const int m = c + k;
   wk = k;
+  // Sparse constraints: the right-hand side of the first solve goes through the quasi-definite block solve,
+  // t = [K0^-1 (d1, d2)]_x, which needs Cw -- so the factor comes first, then t (and the sparse multiplier part
+  // wyw), then the Gram pass with t as its pre-weighted last column, as on the dense path.
+  bool fuse_tw = false;
+  if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930)
+    PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
+    PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:1930)
+    fuse_tw = rhs_mu && fused_tdots && m > 0 && m + 1 <= kWgramMaxVecs && !corrector_active;
+    if (fuse_tw) {
+      PO_TRY(computeResidualW(*rhs_mu));
+      PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, options.real("rel_bound_barrier") * (*rhs_mu), n, d1v->d));
+      PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
+      PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+    }
+  }
   if (!fuse_z) {
     W.assign((size_t)m * m, 0.0);
-    if (m > 0 && fuse_t && m + 1 <= kWgramMaxVecs) {
+    if (m > 0 && (fuse_t || fuse_tw) && m + 1 <= kWgramMaxVecs) {
       std::vector<const double *> Pt(P);
       Pt.push_back(tvec->d);
       const int mt = m + 1;
@@ -569,15 +584,12 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       t0dots.clear();
     }
   }
-  if (fuse_t && m > 0 && (int)t0dots.size() == m) {
+  if ((fuse_t || fuse_tw) && m > 0 && (int)t0dots.size() == m) {
     t0_valid = true;
     t0_mu = *rhs_mu;
   }
-  if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930), then W -= U^T Cw U
-    PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
-    PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:1930)
-    PO_TRY(sparseGramCorrection(P, m));
-  }
+  // W -= U^T Cw U (d1v is free again: scratch of the panel image; tvec holds t)
+  if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec));
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)
   Gf.assign((size_t)c * c, 0.0);
   gpiv.assign(c, 0);

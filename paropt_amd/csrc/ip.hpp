@@ -190,7 +190,7 @@ class InteriorPoint {
   int allocateW();
   int applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw);
   int computeResidualW(double mu);
-  int sparseGramCorrection(const std::vector<const double *> &P, int m);
+  int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr);
   int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out);
   int computeKKTStepWithRefinementW(double mu, bool use_qn, double tau);
   int initLeastSquaresMultipliersW();

@@ -79,7 +79,7 @@ int InteriorPoint::wCompStep(double ax, double az, double *prod) {
 }
 
 // W -= U^T S^-1 U with U_j = Aw (Dinv o P_j), S = C + Aw Dinv Aw^T (diagonal for the block form: Cw = S^-1)
-int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m) {
+int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work) {
   if (m <= 0) return PO_OK;
   while ((int)Uw.size() < m) {
     Vec *u = vec_new(ctx, nw);
@@ -92,7 +92,7 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
     U[j] = Uw[j]->d;
     Uc[j] = Uw[j]->d;
   }
-  PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), tvec));
+  PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), work ? work : tvec));
   // block form: U^T Cw U.  CSR form: U <- L^-1 U with S = L L^T, then U^T U
   const double *weights = Cw->d;
   PO_TRY(prob->sparseHalfSolve(U.data(), m, Cw, &weights));
@@ -117,11 +117,18 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   const int m = c + k;
   const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
   const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
-  if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, beta_mu, n, d1v->d, cl, cu));
-  PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
-  PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+  // t = [K0^-1 (d1, d2)]_x, wyw and P^T t were produced by setUpKKTSystem when the right-hand side was known then
+  const bool have_t0 = !refine_pass && t0_valid && t0_mu == mu && !cl && (int)t0dots.size() == m && m > 0;
   std::vector<double> dots(m > 0 ? m : 1, 0.0);
-  if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  if (have_t0) {
+    for (int i = 0; i < m; i++) dots[i] = t0dots[i];
+  } else {
+    if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, beta_mu, n, d1v->d, cl, cu));
+    PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
+    PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
+    if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  }
+  if (!refine_pass) t0_valid = false;  // tvec is overwritten below
   std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
   for (int i = 0; i < c; i++) {
     yz[i] = (b.z[i] + (b.zs[i] + vars.s[i] * b.s[i]) / vars.zs[i] -
@@ -204,7 +211,7 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
   const int nref = options.integer("iterative_refinement_steps");
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   const bool seq_lin = options.integer("sequential_linear_method");
-  PO_TRY(computeResidualW(mu));
+  if (!(t0_valid && t0_mu == mu)) PO_TRY(computeResidualW(mu));  // (setUpKKTSystem did it for the fused first solve)
   denseResidual(mu, res);
   PO_TRY(solveKKTW(res, mu, use_qn, false, tau, step));
   for (int it = 0; it < nref; it++) {  // :4985-4991
@@ -283,7 +290,7 @@ int InteriorPoint::initLeastSquaresMultipliersW() {
   std::vector<int> piv(c > 0 ? c : 1);
   if (c > 0) {
     PO_TRY(k_wgram(ctx, Dinv->d, A.data(), c, n, W.data()));
-    PO_TRY(sparseGramCorrection(A, c));
+    PO_TRY(sparseGramCorrection(A, c, nullptr));
     for (int i = 0; i < c; i++) W[(size_t)i * (c + 1)] += small;
     lu_factor(c, W.data(), c, piv.data());
   }
