@@ -258,11 +258,13 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
              const double *rx = nullptr, double diag = 0.0, double *tout = nullptr,
              double *va = nullptr, int nca = 0, const double *cl = nullptr,
              const double *cu = nullptr);
-// first solve pass + refinement residual + its panel dots in ONE pass: out = {P^T t' [nv], max_x, max_z}
+// first solve pass + refinement residual + its panel dots in ONE pass: out = {P^T t' [nv], max_x, max_z}.
+// traw != nullptr: the RAW right-hand side d1' is stored there instead of t' = Dinv o d1' in tout (the sparse-constraint
+// path applies its block solve to d1'); the dots are those of t' either way.
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out);
+                  double *tout, double *va, int nca, double *out, double *traw = nullptr);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

@@ -181,6 +181,7 @@ class InteriorPoint {
   Vec *gsw, *gtw, *Cw, *wd2, *wyw, *wtmp, *wtmp2;
   Vec *d1v;                 // n-sized: raw d1, then v = d1 + P alpha
   std::vector<Vec *> Uw;    // U_j = Aw (Dinv o P_j)
+  bool panel_plain = false;  // Uw is the unscaled panel image (scalar block form)
   bool panel_valid = false;  // Uw matches the current setUpKKTSystem (consumed by solveKKTW)
   double w_sums[7], w_maxs[5];  // reductions of the last w residual (k_w_res layout)
   double res_out[11] = {0}, wres_out[12] = {0};  // landing area of the residual reductions (see after_reduce)
@@ -191,7 +192,8 @@ class InteriorPoint {
   int applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw);
   int computeResidualW(double mu);
   int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr);
-  int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out);
+  int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
+                bool fuse_residual = false);
   int computeKKTStepWithRefinementW(double mu, bool use_qn, double tau);
   int initLeastSquaresMultipliersW();
   int wCompStep(double ax, double az, double *prod);

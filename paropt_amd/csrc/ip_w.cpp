@@ -96,6 +96,7 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
   // block form: U^T Cw U.  CSR form: U <- L^-1 U with S = L L^T, then U^T U
   const double *weights = Cw->d;
   PO_TRY(prob->sparseHalfSolve(U.data(), m, Cw, &weights));
+  panel_plain = (weights == Cw->d);  // scalar block form: Uw still holds U = Aw (Dinv o P) itself
   std::vector<double> W2((size_t)m * m, 0.0);
   PO_TRY(k_wgram(ctx, weights, Uc.data(), m, nw, W2.data()));
   for (size_t i = 0; i < W2.size(); i++) W[i] -= W2[i];
@@ -106,7 +107,7 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
 // computeKKTStep (:2700-2737) with both solveKKTDiagSystem overloads folded together, sparse blocks
 // included.  first pass: rhs = (rx, wres, b); refine pass: d1v already holds the raw d1' and wres r'.
 int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau,
-                             Dense &out) {
+                             Dense &out, bool fuse_residual) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   int k = 0;
   std::vector<const double *> P = panel(use_qn, &k);
@@ -126,7 +127,17 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, beta_mu, n, d1v->d, cl, cu));
     PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
     PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
-    if (m > 0) PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+    if (refine_pass && tdots_valid && (int)tdots.size() == m && m > 0 && panel_valid && panel_plain &&
+        (int)Uw.size() >= m) {
+      // tvec = Dinv o (d1' + Aw^T yw): P^T tvec = P^T (Dinv o d1') + U^T yw with U = Aw (Dinv o P) -- the first
+      // term came out of the fused first pass, the second is a w-sized product with the panel image
+      std::vector<const double *> Uc(m);
+      for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
+      PO_TRY(k_mdot(ctx, wyw->d, Uc.data(), m, nw, dots.data()));
+      for (int i = 0; i < m; i++) dots[i] += tdots[i];
+    } else if (m > 0) {
+      PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+    }
   }
   if (!refine_pass) t0_valid = false;  // tvec is overwritten below
   std::vector<double> yz(c > 0 ? c : 1, 0.0), yz2(c > 0 ? c : 1, 0.0), zeta(k > 0 ? k : 1, 0.0);
@@ -160,8 +171,8 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
-  tdots_valid = false;
-  residual_fused = false;
+  tdots_valid = false;        // (consumed above by a refinement pass; set again below by a fused first pass)
+  if (!refine_pass) residual_fused = false;
   // (dx, dzw) = K0^-1 (d1 + P alpha, d2) = K0^-1 (d1, d2) + K0^-1 (P alpha, 0), and the second term comes from
   // the panel the Gram correction already holds: dzw += -S^-1 (U alpha), dx += Dinv (P alpha + Aw^T of that) -
   // no second quasi-definite apply, and P alpha rides in the same pass that forms the bound multipliers
@@ -169,7 +180,58 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   // the fraction-to-boundary minima of the design and of the sparse blocks: one collective + sync (opened right
   // before the first of the two launches: no user code runs between them)
   BatchScope minbatch(ctx, false);
-  if (m > 0 && (int)Uw.size() >= m && panel_valid) {
+  const bool seq_lin = options.integer("sequential_linear_method");
+  const int kq = (qn && !seq_lin) ? qn->size() : 0;
+  // Fused refinement residual (as on the dense path, ip.cpp solveKKT): the coefficients of addKKTResStep are known
+  // before the axpy pass starts, and so is the sparse multiplier step pzw (it depends on wyw only), so ONE pass
+  // over P writes the step, the RAW right-hand side d1' of the refinement solve (its design rows, :1451-1483, with
+  // the extra column Aw^T pzw) and the panel products of Dinv o d1'.
+  const bool fuse = fuse_residual && !refine_pass && fused_dots && analytic_panel_dots && kq == k && m > 0 &&
+                    (int)Uw.size() >= m && panel_valid && panel_plain && !cl &&
+                    !(options.integer("use_diag_hessian") && hdiag) && m + 2 <= kMaxPanel;
+  if (fuse) {
+    std::vector<const double *> Uc(m);
+    for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
+    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
+    PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
+    PO_TRY(k_fill(ctx, d1v->d, n, 0.0));
+    if (prob->addSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    // sparse blocks of the step first: pzw = wstepv[0] feeds the residual column Aw^T pzw (its minima wait for
+    // those of the design blocks unless user code runs in between)
+    if (prob->reductionsBatchable()) minbatch.begin();
+    PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, 0, tau, wp(), nw, mins_w));
+    PO_TRY(k_fill(ctx, xt->d, n, 0.0));
+    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
+    std::vector<const double *> P1(P);
+    std::vector<double> a1(alpha.begin(), alpha.begin() + m), c2(m + 2, 0.0);
+    P1.push_back(d1v->d);
+    a1.push_back(1.0);
+    P1.push_back(xt->d);
+    a1.push_back(0.0);
+    for (int i = 0; i < c; i++) c2[i] = alpha[i];  // = step.z
+    double diag = options.real("qn_sigma");
+    if (qn && !seq_lin) {
+      diag += qn->diag();
+      if (k > 0) {
+        std::vector<double> rz(ptpx.begin() + c, ptpx.begin() + c + k);
+        qn->applyCompactInverse(rz.data());
+        for (int j = 0; j < k; j++) c2[c + j] = rz[j];
+      }
+    }
+    c2[m + 1] = 1.0;
+    std::vector<double> so(m + 4, 0.0);
+    // the raw right-hand side lands in y_qn (free while no corrector is active: y_qn is rebuilt from scratch by
+    // computeStepAndUpdate) -- d1v is one of the columns being read -- and the two exchange buffers afterwards
+    PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, a1.data(), c2.data(), P1.data(), m + 2, beta_mu, tau,
+                         rx->d, diag, n, px->d, pzl->d, pzu->d, nullptr, nullptr, 0, so.data(), y_qn->d));
+    std::swap(d1v->d, y_qn->d);
+    PO_TRY(minbatch.end());
+    tdots.assign(so.begin(), so.begin() + m);
+    tdots_valid = true;
+    residual_fused = true;
+    mins_x[0] = so[m + 2];
+    mins_x[1] = so[m + 3];
+  } else if (m > 0 && (int)Uw.size() >= m && panel_valid) {
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
     PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
@@ -191,8 +253,10 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
                     tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
                     cu));
   }
-  PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
-  PO_TRY(minbatch.end());
+  if (!fuse) {
+    PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
+    PO_TRY(minbatch.end());
+  }
   step_mins[0] = std::min(mins_x[0], mins_w[0]);
   step_mins[1] = std::min(mins_x[1], mins_w[1]);
   for (int i = 0; i < c; i++) {
@@ -213,7 +277,7 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
   const bool seq_lin = options.integer("sequential_linear_method");
   if (!(t0_valid && t0_mu == mu)) PO_TRY(computeResidualW(mu));  // (setUpKKTSystem did it for the fused first solve)
   denseResidual(mu, res);
-  PO_TRY(solveKKTW(res, mu, use_qn, false, tau, step));
+  PO_TRY(solveKKTW(res, mu, use_qn, false, tau, step, nref > 0));
   for (int it = 0; it < nref; it++) {  // :4985-4991
     int kq = 0;
     std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
@@ -242,13 +306,16 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
         for (int j = 0; j < kq; j++) coef[c + j] = rz[j];
       }
     }
-    // addKKTResStep (:1451-1583): design rows with the extra column Aw^T pzw, raw d1' into d1v
-    PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
-    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
-    Pq.push_back(tvec->d);
-    coef[mres++] = 1.0;
-    PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
-                      mres, diag, beta_mu, n, d1v->d));
+    // addKKTResStep (:1451-1583): design rows with the extra column Aw^T pzw, raw d1' into d1v (already there
+    // when the first solve ran in its fused form)
+    if (!(it == 0 && residual_fused)) {
+      PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
+      if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
+      Pq.push_back(tvec->d);
+      coef[mres++] = 1.0;
+      PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
+                        mres, diag, beta_mu, n, d1v->d));
+    }
     // sparse rows (:1492-1527)
     PO_TRY(computeResidualW(mu));
     if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;

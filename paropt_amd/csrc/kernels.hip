@@ -960,7 +960,8 @@ __global__ void __launch_bounds__(kBlock, OCC)
                        CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
-                       double *tout, double *__restrict__ va, int nca, double *__restrict__ partials) {
+                       double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
+                       double *__restrict__ partials) {
   extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
   double *pt = s2lds;
   double *sacc = s2lds + 4 * NPASS * kS2Tile;
@@ -1061,12 +1062,20 @@ __global__ void __launch_bounds__(kBlock, OCC)
         st2(px, q, n, make_double2(s0.px, s1.px));
         st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
         st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
-        tp.x = res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, dv.x, beta_mu, b.use_lower,
-                             b.use_upper);
-        tp.y = _has2 ? res_step_elem(e1, r.y, acc2.y, diag, s1.px, s1.pzl, s1.pzu, dv.y, beta_mu,
-                                     b.use_lower, b.use_upper)
-                     : 0.0;
-        st2(tout, q, n, tp);
+        // raw d1' and t' = Dinv o d1' (the product res_step_elem would form itself)
+        double2 raw;
+        raw.x = res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, 1.0, beta_mu, b.use_lower,
+                              b.use_upper);
+        raw.y = _has2 ? res_step_elem(e1, r.y, acc2.y, diag, s1.px, s1.pzl, s1.pzu, 1.0, beta_mu,
+                                      b.use_lower, b.use_upper)
+                      : 0.0;
+        tp.x = dv.x * raw.x;
+        tp.y = dv.y * raw.y;
+        if (traw) {  // the caller applies its own block solve to the raw right-hand side (sparse constraints)
+          st2(traw, q, n, raw);
+        } else {
+          st2(tout, q, n, tp);
+        }
         max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
         if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
       }
@@ -1102,7 +1111,8 @@ template <int NP, int OCC>
 static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const double *t, const double *dinv,
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
                               double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
-                              double *pzl, double *pzu, double *tout, double *va, int nca, int *grid_out) {
+                              double *pzl, double *pzu, double *tout, double *va, int nca, double *traw,
+                              int *grid_out) {
   const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1118,7 +1128,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
   hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
-                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, c->d_partials);
+                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, c->d_partials);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -1130,17 +1140,17 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
     if (occ_env == OA)                                                                                     \
       PO_TRY((solve2_dots_launch<NP, OA>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, &grid)));                                \
+                                         pzl, pzu, tout, va, nca, traw, &grid)));                          \
     else                                                                                                   \
       PO_TRY((solve2_dots_launch<NP, OD>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, &grid)));                                \
+                                         pzl, pzu, tout, va, nca, traw, &grid)));                          \
   } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out) {
+                  double *tout, double *va, int nca, double *out, double *traw) {
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
