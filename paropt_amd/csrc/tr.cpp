@@ -165,6 +165,7 @@ int TrustRegionSubproblem::allocate() {
   return PO_OK;
 }
 int TrustRegionSubproblem::initModelAndBounds(double tr_size) {  // :141-151
+  zts_valid = false;
   if (prob->getVarsAndBounds(xk, lb, ub) != 0) return PO_ERR_USER;
   PO_TRY(setTrustRegionBounds(tr_size));
   if (prob->evalObjCon(xk, &fk, ck.data()) != 0) return PO_ERR_USER;
@@ -207,11 +208,13 @@ int TrustRegionSubproblem::evalLinearModel(Vec *step, double *f, double *cons) {
   std::vector<const double *> P;
   P.push_back(gk->d);
   for (Vec *a : Ak) P.push_back(a->d);
-  std::vector<double> dots(m + 1, 0.0);
-  PO_TRY(k_mdot(ctx, step->d, P.data(), m + 1, nlocal, dots.data()));
-  *f = fk + dots[0];
-  for (int i = 0; i < m; i++) cons[i] = ck[i] + dots[1 + i];
-  return PO_OK;
+  lin_dots.assign(m + 1, 0.0);
+  BatchScope batch(ctx);
+  PO_TRY(k_mdot(ctx, step->d, P.data(), m + 1, nlocal, lin_dots.data()));
+  return batch.end_then([this, f, cons] {
+    *f = fk + lin_dots[0];
+    for (int i = 0; i < m; i++) cons[i] = ck[i] + lin_dots[1 + i];
+  });
 }
 int TrustRegionSubproblem::evalTrialPoint(Vec *step, double *fobj, double *cons) {  // :178-188
   const double one[1] = {1.0};
@@ -245,6 +248,7 @@ int TrustRegionSubproblem::lagrangianGradientDifference(const double *z, Vec *zw
   return PO_OK;
 }
 void TrustRegionSubproblem::acceptModel() {
+  zts_valid = false;
   fk = ft;
   std::swap(gk->d, gt->d);
   for (int i = 0; i < m; i++) {
@@ -256,6 +260,7 @@ void TrustRegionSubproblem::acceptModel() {
 // ---- quadratic --------------------------------------------------------------------------------
 int QuadraticSubproblem::evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw,
                                                 double *fobj, double *cons) {  // :175-212
+  zts_valid = false;
   PO_TRY(evalTrialPoint(step, fobj, cons));
   if (qn && update_flag) {
     PO_TRY(lagrangianGradientDifference(z, zw));
@@ -285,19 +290,28 @@ int QuadraticSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {  //
     P.insert(P.end(), zp.begin(), zp.end());
     P.push_back(step->d);
   }
-  std::vector<double> dots(P.size(), 0.0);
-  if (k_mdot(ctx, step->d, P.data(), (int)P.size(), nlocal, dots.data()) != PO_OK) return 1;
-  double f = fk + dots[0];
-  if (qn) {
-    std::vector<double> rz(dots.begin() + 1 + m, dots.begin() + 1 + m + k), cf = rz;
-    if (k > 0) qn->applyCompactInverse(cf.data());
-    double sBs = qn->diag() * dots[1 + m + k];
-    for (int i = 0; i < k; i++) sBs -= rz[i] * cf[i];
-    f += 0.5 * sBs;
-  }
-  *fobj = f;
-  for (int i = 0; i < m; i++) cons[i] = ck[i] + dots[1 + i];
-  return 0;
+  eo_dots.assign(P.size(), 0.0);
+  zts_valid = false;
+  BatchScope batch(ctx);
+  if (k_mdot(ctx, step->d, P.data(), (int)P.size(), nlocal, eo_dots.data()) != PO_OK) return 1;
+  const double *sd = step->d;
+  const int rc = batch.end_then([this, fobj, cons, k, sd] {
+    const std::vector<double> &dots = eo_dots;
+    double f = fk + dots[0];
+    if (qn) {
+      std::vector<double> rz(dots.begin() + 1 + m, dots.begin() + 1 + m + k), cf = rz;
+      if (k > 0) qn->applyCompactInverse(cf.data());
+      double sBs = qn->diag() * dots[1 + m + k];
+      for (int i = 0; i < k; i++) sBs -= rz[i] * cf[i];
+      f += 0.5 * sBs;
+      zts_cache = rz;  // Z^T step for the gradient evaluation at this very step
+      zts_ptr = sd;
+      zts_valid = true;
+    }
+    *fobj = f;
+    for (int i = 0; i < m; i++) cons[i] = ck[i] + dots[1 + i];
+  });
+  return rc == PO_OK ? 0 : 1;
 }
 int QuadraticSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :328-343
   std::vector<double *> dst;
@@ -312,7 +326,11 @@ int QuadraticSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :
   const int k = (int)zp.size();
   std::vector<double> cf(k + 1, 0.0);
   if (k > 0) {
-    if (k_mdot(ctx, step->d, zp.data(), k, nlocal, cf.data() + 1) != PO_OK) return 1;
+    if (zts_valid && zts_ptr == step->d && (int)zts_cache.size() == k) {
+      for (int i = 0; i < k; i++) cf[1 + i] = zts_cache[i];  // the products evalObjCon(step) just took
+    } else if (k_mdot(ctx, step->d, zp.data(), k, nlocal, cf.data() + 1) != PO_OK) {
+      return 1;
+    }
     qn->applyCompactInverse(cf.data() + 1);
     for (int i = 0; i < k; i++) cf[1 + i] = -cf[1 + i];
   }
@@ -336,9 +354,11 @@ int EigenSubproblem::initModelAndBounds(double tr_size) {  // :412-439
 }
 int EigenSubproblem::evalTrialStepAndUpdate(int, Vec *step, const double *, Vec *, double *fobj,
                                             double *cons) {  // :460-476
+  zts_valid = false;
   return evalTrialPoint(step, fobj, cons);
 }
 int EigenSubproblem::acceptTrialStep(Vec *step, const double *z, Vec *zw) {  // :478-529
+  zts_valid = false;
   const double one[1] = {1.0};
   const double *vv[1] = {step->d};
   PO_TRY(k_panel_axpy(ctx, xtemp->d, 1.0, xk->d, 0.0, one, vv, 1, nlocal));
@@ -381,23 +401,31 @@ int EigenSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {  // :58
     cons[idx] = e->c0;
     return 0;
   }
-  std::vector<double> dots;
   int kq = 0;
-  if (modelDots(step, dots, &kq) != PO_OK) return 1;
-  const int k = kq + N;
-  const double *rz = dots.data() + 1 + m;
-  std::vector<double> cf(rz, rz + k);
-  approx->applyCompactInverse(cf.data());
-  double sBs = approx->diag() * dots[1 + m + k + 1];
-  for (int i = 0; i < k; i++) sBs -= rz[i] * cf[i];
-  *fobj = fk + dots[0] + 0.5 * sBs;
-  for (int i = 0; i < m; i++) cons[i] = ck[i] + dots[1 + i];
-  const double *h = rz + kq;  // H^T s
-  double c = e->c0 + dots[1 + m + k];
-  for (int i = 0; i < N; i++)
-    for (int j = 0; j < N; j++) c += 0.5 * e->M[(size_t)i * N + j] * h[i] * h[j];
-  cons[idx] = c;
-  return 0;
+  zts_valid = false;
+  BatchScope batch(ctx);
+  if (modelDots(step, eo_dots, &kq) != PO_OK) return 1;
+  const double *sd = step->d;
+  const int rc = batch.end_then([this, fobj, cons, kq, sd, e, idx, N] {
+    const std::vector<double> &dots = eo_dots;
+    const int k = kq + N;
+    const double *rz = dots.data() + 1 + m;
+    std::vector<double> cf(rz, rz + k);
+    approx->applyCompactInverse(cf.data());
+    double sBs = approx->diag() * dots[1 + m + k + 1];
+    for (int i = 0; i < k; i++) sBs -= rz[i] * cf[i];
+    *fobj = fk + dots[0] + 0.5 * sBs;
+    for (int i = 0; i < m; i++) cons[i] = ck[i] + dots[1 + i];
+    const double *h = rz + kq;  // H^T s
+    double c = e->c0 + dots[1 + m + k];
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) c += 0.5 * e->M[(size_t)i * N + j] * h[i] * h[j];
+    cons[idx] = c;
+    zts_cache.assign(rz, rz + k);  // [Z_qn | H]^T step for the gradient evaluation at this very step
+    zts_ptr = sd;
+    zts_valid = true;
+  });
+  return rc == PO_OK ? 0 : 1;
 }
 int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-643
   CompactEigenApprox *e = approx->eigh;
@@ -405,7 +433,11 @@ int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-
   std::vector<const double *> zp = approx->zPointers();
   const int k = (int)zp.size(), kq = k - N;
   std::vector<double> rz(k > 0 ? k : 1, 0.0);
-  if (k > 0 && k_mdot(ctx, step->d, zp.data(), k, nlocal, rz.data()) != PO_OK) return 1;
+  if (k > 0 && zts_valid && zts_ptr == step->d && (int)zts_cache.size() == k) {
+    for (int i = 0; i < k; i++) rz[i] = zts_cache[i];  // the products evalObjCon(step) just took
+  } else if (k > 0 && k_mdot(ctx, step->d, zp.data(), k, nlocal, rz.data()) != PO_OK) {
+    return 1;
+  }
   // constraint gradients: copies, except the modelled one: g0 + H (M H^T s)
   std::vector<double *> dst;
   std::vector<const double *> src;
@@ -450,18 +482,23 @@ int InfeasSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {  // :5
     for (int i = 0; i < m; i++) cons[i] = sub->ck[i];
     return 0;
   }
-  std::vector<double> cs(m > 0 ? m : 1, 0.0), cl(m > 0 ? m : 1, 0.0);
-  double fs = 0.0, fl = 0.0;
+  eo_cs.assign(m > 0 ? m : 1, 0.0);
+  eo_cl.assign(m > 0 ? m : 1, 0.0);
+  eo_fs = eo_fl = 0.0;
   const bool need_sub = objective == SUBPROBLEM_OBJECTIVE || constraint == SUBPROBLEM_CONSTRAINT;
   const bool need_lin = objective == LINEAR_OBJECTIVE || constraint == LINEAR_CONSTRAINT;
-  if (need_sub && sub->evalObjCon(step, &fs, cs.data()) != 0) return 1;
-  if (need_lin && sub->evalLinearModel(step, &fl, cl.data()) != PO_OK) return 1;
-  double f = fs;
-  if (objective == LINEAR_OBJECTIVE) f = fl;
-  if (objective == CONSTANT_OBJECTIVE) f = sub->fk;
-  for (int i = 0; i < m; i++) cons[i] = constraint == LINEAR_CONSTRAINT ? cl[i] : cs[i];
-  *fobj = f * obj_scale;
-  return 0;
+  // both model evaluations (and the caller's reductions, if it has a batch open) share one collective + sync
+  BatchScope batch(ctx, sub->reductionsBatchable());
+  if (need_sub && sub->evalObjCon(step, &eo_fs, eo_cs.data()) != 0) return 1;
+  if (need_lin && sub->evalLinearModel(step, &eo_fl, eo_cl.data()) != PO_OK) return 1;
+  const int rc = batch.end_then([this, fobj, cons, m] {
+    double f = eo_fs;
+    if (objective == LINEAR_OBJECTIVE) f = eo_fl;
+    if (objective == CONSTANT_OBJECTIVE) f = sub->fk;
+    for (int i = 0; i < m; i++) cons[i] = constraint == LINEAR_CONSTRAINT ? eo_cl[i] : eo_cs[i];
+    *fobj = f * obj_scale;
+  });
+  return rc == PO_OK ? 0 : 1;
 }
 int InfeasSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :585-612
   const int m = sub->m;

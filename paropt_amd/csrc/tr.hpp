@@ -99,6 +99,9 @@ class TrustRegionSubproblem : public Problem {
     return prob->sparseCorrection(U, nv, alpha, cw, out);
   }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
+  // the model evaluations issue their reductions through the internal launchers and finish with
+  // BatchScope::end_then: inside the interior point's line-search batch they share its collective + host sync
+  bool reductionsBatchable() override { return prob->reductionsBatchable(); }
 
   Problem *prob;
   int m;
@@ -112,6 +115,13 @@ class TrustRegionSubproblem : public Problem {
   int lagrangianGradientDifference(const double *z, Vec *zw);  // into t (:187-205)
   void acceptModel();
   int qn_update_type;
+  // landing areas of the model reductions (the values may arrive at the flush of an enclosing batch)
+  std::vector<double> eo_dots, lin_dots;
+  // Z^T step of the last evalObjCon(step): evalObjConGradient at the same step buffer (the accepted trial point)
+  // does not stream the panel again.  Dropped whenever the model or the quasi-Newton panel changes.
+  std::vector<double> zts_cache;
+  const double *zts_ptr = nullptr;
+  bool zts_valid = false;
 };
 
 class QuadraticSubproblem : public TrustRegionSubproblem {  // :27-466
@@ -147,6 +157,7 @@ class EigenSubproblem : public TrustRegionSubproblem {  // ParOptCompactEigenval
   int modelDots(Vec *step, std::vector<double> &dots, int *kq);
 };
 
+
 class InfeasSubproblem : public Problem {  // :468-650
  public:
   enum { CONSTANT_OBJECTIVE = 0, LINEAR_OBJECTIVE = 1, SUBPROBLEM_OBJECTIVE = 2 };
@@ -155,6 +166,9 @@ class InfeasSubproblem : public Problem {  // :468-650
   int getVarsAndBounds(Vec *x, Vec *l, Vec *u) override { return sub->getVarsAndBounds(x, l, u); }
   int evalObjCon(Vec *step, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  bool reductionsBatchable() override { return sub->reductionsBatchable(); }
+  std::vector<double> eo_cs, eo_cl;  // landing areas (see TrustRegionSubproblem::eo_dots)
+  double eo_fs = 0.0, eo_fl = 0.0;
   int evalSparseCon(Vec *step, Vec *out) override { return sub->evalSparseCon(step, out); }
   int addSparseJacobian(double a, Vec *x, Vec *px, Vec *out) override {
     return sub->addSparseJacobian(a, x, px, out);
