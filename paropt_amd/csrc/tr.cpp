@@ -314,13 +314,15 @@ int QuadraticSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {  //
   return rc == PO_OK ? 0 : 1;
 }
 int QuadraticSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :328-343
+  // Ac == nullptr: the constraint model is linear (linear_constraints is set), the solver kept the Jacobian of the
+  // first evaluation of this solve
   std::vector<double *> dst;
   std::vector<const double *> src;
-  for (int i = 0; i < m; i++) {
+  for (int i = 0; Ac && i < m; i++) {
     dst.push_back(Ac[i]->d);
     src.push_back(Ak[i]->d);
   }
-  if (m > 0 && k_panel_lincomb(ctx, dst.data(), 1.0, src.data(), 0.0, nullptr, m, nlocal) != PO_OK) return 1;
+  if (Ac && m > 0 && k_panel_lincomb(ctx, dst.data(), 1.0, src.data(), 0.0, nullptr, m, nlocal) != PO_OK) return 1;
   if (!qn) return k_copy(ctx, g->d, gk->d, nlocal) == PO_OK ? 0 : 1;
   std::vector<const double *> zp = qn->zPointers();
   const int k = (int)zp.size();
@@ -441,7 +443,7 @@ int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-
   // constraint gradients: copies, except the modelled one: g0 + H (M H^T s)
   std::vector<double *> dst;
   std::vector<const double *> src;
-  for (int i = 0; i < m; i++) {
+  for (int i = 0; Ac && i < m; i++) {  // (Ac == nullptr: objective gradient only, asked for by a linearised wrapper)
     if (i == idx) continue;
     dst.push_back(Ac[i]->d);
     src.push_back(Ak[i]->d);
@@ -449,11 +451,13 @@ int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-
   if (!dst.empty() &&
       k_panel_lincomb(ctx, dst.data(), 1.0, src.data(), 0.0, nullptr, (int)dst.size(), nlocal) != PO_OK)
     return 1;
-  std::vector<double> mh(N, 0.0);
-  for (int i = 0; i < N; i++)
-    for (int j = 0; j < N; j++) mh[i] += e->M[(size_t)i * N + j] * rz[kq + j];
-  std::vector<const double *> hp = e->hPointers();
-  if (k_panel_axpy(ctx, Ac[idx]->d, 1.0, e->g0->d, 0.0, mh.data(), hp.data(), N, nlocal) != PO_OK) return 1;
+  if (Ac) {
+    std::vector<double> mh(N, 0.0);
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) mh[i] += e->M[(size_t)i * N + j] * rz[kq + j];
+    std::vector<const double *> hp = e->hPointers();
+    if (k_panel_axpy(ctx, Ac[idx]->d, 1.0, e->g0->d, 0.0, mh.data(), hp.data(), N, nlocal) != PO_OK) return 1;
+  }
   // g = gk + B s
   std::vector<double> cf(k + 1, 0.0);
   for (int i = 0; i < k; i++) cf[1 + i] = rz[i];
@@ -474,6 +478,9 @@ InfeasSubproblem::InfeasSubproblem(TrustRegionSubproblem *sub_, int objective_, 
   nglobal = sub_->nglobal;
   nwcon = sub_->nwcon;
   nwinequality = sub_->nwinequality;
+  // a linear constraint model has a constant Jacobian within a solve: the interior point keeps it (Ac == nullptr
+  // in later gradient calls) and carries A^T z by recurrence (po_problem_set_linear_constraints)
+  linear_constraints = (constraint_ == LINEAR_CONSTRAINT || sub_->linear_constraints) ? 1 : 0;
 }
 int InfeasSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {  // :541-580
   const int m = sub->m;
@@ -513,7 +520,7 @@ int InfeasSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :585
   } else {
     if (k_scale(ctx, g->d, nlocal, obj_scale) != PO_OK) return 1;
   }
-  if (constraint == LINEAR_CONSTRAINT && m > 0) {
+  if (constraint == LINEAR_CONSTRAINT && m > 0 && Ac) {
     std::vector<double *> dst;
     std::vector<const double *> src;
     for (int i = 0; i < m; i++) {

@@ -126,7 +126,9 @@ class TrustRegionSubproblem : public Problem {
 
 class QuadraticSubproblem : public TrustRegionSubproblem {  // :27-466
  public:
-  QuadraticSubproblem(Problem *p, CompactQuasiNewton *qn_) : TrustRegionSubproblem(p), qn(qn_) {}
+  QuadraticSubproblem(Problem *p, CompactQuasiNewton *qn_) : TrustRegionSubproblem(p), qn(qn_) {
+    linear_constraints = 1;  // c(s) = ck + Ak s: the Jacobian is constant within a subproblem solve
+  }
   CompactQuasiNewton *getQuasiNewton() override { return qn; }
   int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
                              double *cons) override;

@@ -71,16 +71,21 @@ def main():
 
     tr.setIterationCallback(cb)
     ctx.synchronize()
+    red0, lau0 = ctx.counters()
     t0 = time.perf_counter()
     tr.optimize()
     ctx.synchronize()
     dt = time.perf_counter() - t0
+    red1, lau1 = ctx.counters()
     s = tr.getState()
     counts.append((s["subproblem_iters"], s["adaptive_subproblem_iters"]))
     ip_iters = sum(x + y for x, y in counts)
     res = {"metric": "trust-region iterations/s (compact eigenvalue subproblem, SL1QP + adaptive penalty)",
            "value": s["iter_count"] / dt, "unit": "TR iterations/s", "n_gpus": 1, "tr_iterations": s["iter_count"],
            "seconds": dt, "inner_ip_iterations": ip_iters, "inner_ip_iterations_per_s": ip_iters / dt,
+           "launches_per_inner_iteration": (lau1 - lau0) / float(max(ip_iters, 1)),
+           "host_syncs_per_inner_iteration": (red1 - red0) / float(max(ip_iters, 1)),
+           "reductions_batched": ctx.batched_reductions(),
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "config 5: ParOptEigenSubproblem under ParOptTrustRegion, separable random_%s "
                                   "n=%d, m=%d, N=%d curvature directions, L-BFGS(%d), trust-region defaults, "
