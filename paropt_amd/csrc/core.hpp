@@ -264,7 +264,12 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out, double *traw = nullptr);
+                  double *tout, double *va, int nca, double *out, double *traw = nullptr, int store_step = 1);
+// store_step == 0 above leaves (px, pzl, pzu, va) unwritten; this refinement pass recomputes that first step from
+// (t1, a1) and applies the refinement (t2, a2) on top in ONE sweep over P: out = {max_x, max_z} of the final step
+int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
+              const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
+              double *pzl, double *pzu, double *va, int nca, double out[2]);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

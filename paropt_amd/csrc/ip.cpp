@@ -56,6 +56,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   if (getenv("PAROPT_AMD_EXPLICIT_DOTS")) analytic_panel_dots = false;
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
+  recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
   use_acz = !getenv("PAROPT_AMD_NO_ACZ");
   use_ztpx_hint = !getenv("PAROPT_AMD_NO_ZTS_HINT");
   use_lower = prob->useLowerBounds();
@@ -707,16 +708,26 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     }
   }
   if (fuse && fused_dots && m > 0 && !cl) {
-    // one pass: px, pzl, pzu, t' = refinement rhs, and P^T t' for the refinement solve
+    // one pass: t' = refinement rhs and P^T t' for the refinement solve.  The step itself (px, pzl, pzu, A^T pz) is
+    // NOT stored: the refinement pass recomputes it from (t, alpha) in registers (k_solve2r) -- four output streams
+    // less, and an HBM write costs about four reads here.  t' goes to xt (free during the solves), t stays in tvec.
     std::vector<double> out(m + 2, 0.0);
+    const bool defer = recompute_first_step;
     PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
-                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tvec->d, vA->d, c,
-                         out.data()));
+                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, defer ? xt->d : tvec->d, vA->d, c,
+                         out.data(), nullptr, defer ? 0 : 1));
     tdots.assign(out.begin(), out.begin() + m);
     tdots_valid = true;
     step_mins[0] = out[m];
     step_mins[1] = out[m + 1];
+    step_deferred = defer;
+    if (defer) alpha_first = alpha;
+  } else if (refine_pass && step_deferred) {
+    step_deferred = false;
+    PO_TRY(k_solve2r(ctx, bounds(), tvec->d, xt->d, Dinv->d, alpha_first.data(), alpha.data(), P.data(), m, beta_mu,
+                     tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins));
   } else {
+    if (!refine_pass) step_deferred = false;
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
                     refine_pass ? 1 : 0, tau, n, px->d, pzl->d, pzu->d, step_mins,
                     fuse ? coef.data() : nullptr, rx->d, diag, tvec->d, vA->d, c, cl, cu));

@@ -244,6 +244,8 @@ class InteriorPoint {
   bool acz_valid = false, use_acz = true, use_ztpx_hint = true;
   int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
+  bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step
+  std::vector<double> alpha_first;                                 // coefficients of that first pass
   bool fused_tdots = true, t0_valid = false;
   double t0_mu = 0.0;
   std::vector<double> t0dots;  // Ac holds the Jacobian of a problem with linear_constraints

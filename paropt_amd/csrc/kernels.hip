@@ -912,6 +912,63 @@ __global__ void __launch_bounds__(kBlock)
   block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
 }
 
+// Refinement pass that RECOMPUTES the first step instead of reading it: the first pass (solve2_dots_kernel with
+// store_step = 0) wrote only the refinement right-hand side t2, so here
+//   px1 = t1 + Dinv*(P a1), (pzl1, pzu1) from px1          (the first solve, in registers)
+//   px  = px1 + t2 + Dinv*(P a2), pzl, pzu accordingly      (solve2_elem<1>, as solve2_kernel<1,0>)
+// in one sweep over P with both coefficient sets.  Four output streams and three input streams less per iteration
+// than storing and re-reading the first step.
+__global__ void __launch_bounds__(kBlock)
+    solve2r_kernel(Bounds b, const double *__restrict__ t1, const double *__restrict__ t2,
+                   const double *__restrict__ dinv, CoefTable a1, CoefTable a2, PtrTable P, int nv, double beta_mu,
+                   double tau, int64_t n, double *__restrict__ px, double *__restrict__ pzl,
+                   double *__restrict__ pzu, double *__restrict__ va, int nca, double *__restrict__ partials) {
+  __shared__ double sm[4 * 2];
+  double mins[2] = {1.0, 1.0};
+  PO_PAIR_LOOP(q, n) {
+    double2 a1A, a2A, acc1, acc2;
+    panel_sum2(P, a1, a2, nca, q, a1A, a2A);
+    panel_sum2(P, a1, a2, nv, q, acc1, acc2, nca);
+    acc1.x += a1A.x;
+    acc1.y += a1A.y;
+    acc2.x += a2A.x;
+    acc2.y += a2A.y;
+    if (va) st2(va, q, n, make_double2(a2A.x + a1A.x, a2A.y + a1A.y));  // A^T pz of both solves
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 tv = ld2(t1, q, n), tw = ld2(t2, q, n), dv = ld2(dinv, q, n);
+    const Step3 f0 = solve2_elem<0>(e0, tv.x + dv.x * acc1.x, beta_mu, 0.0, 0.0, 0.0);
+    Step3 f1 = solve2_elem<0>(e1, tv.y + dv.y * acc1.y, beta_mu, 0.0, 0.0, 0.0);
+    if (!_has2) f1.px = f1.pzl = f1.pzu = 0.0;
+    const Step3 s0 = solve2_elem<1>(e0, tw.x + dv.x * acc2.x, beta_mu, f0.px, f0.pzl, f0.pzu);
+    Step3 s1 = solve2_elem<1>(e1, tw.y + dv.y * acc2.y, beta_mu, f1.px, f1.pzl, f1.pzu);
+    if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+    st2(px, q, n, make_double2(s0.px, s1.px));
+    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+    if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+  }
+  block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
+}
+
+int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
+              const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
+              double *pzl, double *pzu, double *va, int nca, double out[2]) {
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  const int grid = grid_for(c, n, 3);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PtrTable pt;
+  CoefTable ct1, ct2;
+  fill_tables(a1, P, nv, &ct1, &pt);
+  fill_tables(a2, P, nv, &ct2, &pt);
+  PO_LAUNCH(solve2r_kernel, grid, b, t1, t2, dinv, ct1, ct2, pt, nv, beta_mu, tau, n, px, pzl, pzu, va, nca,
+            c->d_partials);
+  return reduce_finish(c, grid, 0, 2, 0, out);
+}
+
 int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
              const double *const *P, int nv, double beta_mu, int refine, double tau, int64_t n,
              double *px, double *pzl, double *pzu, double out[2], const double *coef2,
@@ -961,7 +1018,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                        double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
-                       double *__restrict__ partials) {
+                       int store_step, double *__restrict__ partials) {
   extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
   double *pt = s2lds;
   double *sacc = s2lds + 4 * NPASS * kS2Tile;
@@ -1055,13 +1112,17 @@ __global__ void __launch_bounds__(kBlock, OCC)
         PO_MAKE_BOUNDS(b, q, n);
         const double2 tv = make_double2(eb[5].x, eb[5].y), dv = make_double2(eb[6].x, eb[6].y),
                       r = make_double2(eb[7].x, eb[7].y);
-        if (va) st2(va, q, n, accA);
+        if (va && store_step) st2(va, q, n, accA);
         const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
         Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
         if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
-        st2(px, q, n, make_double2(s0.px, s1.px));
-        st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
-        st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+        // store_step == 0: the refinement pass recomputes this first step from t and alpha in registers
+        // (solve2r_kernel) -- an HBM write costs about four reads on this part (tools/layout_probe.hip)
+        if (store_step) {
+          st2(px, q, n, make_double2(s0.px, s1.px));
+          st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+          st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+        }
         // raw d1' and t' = Dinv o d1' (the product res_step_elem would form itself)
         double2 raw;
         raw.x = res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, 1.0, beta_mu, b.use_lower,
@@ -1112,7 +1173,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
                               double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
                               double *pzl, double *pzu, double *tout, double *va, int nca, double *traw,
-                              int *grid_out) {
+                              int store_step, int *grid_out) {
   const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1128,7 +1189,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
   hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
-                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, c->d_partials);
+                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, c->d_partials);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -1140,17 +1201,17 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
     if (occ_env == OA)                                                                                     \
       PO_TRY((solve2_dots_launch<NP, OA>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, traw, &grid)));                          \
+                                         pzl, pzu, tout, va, nca, traw, store_step, &grid)));              \
     else                                                                                                   \
       PO_TRY((solve2_dots_launch<NP, OD>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, traw, &grid)));                          \
+                                         pzl, pzu, tout, va, nca, traw, store_step, &grid)));              \
   } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out, double *traw) {
+                  double *tout, double *va, int nca, double *out, double *traw, int store_step) {
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
