@@ -220,6 +220,12 @@ struct Bounds {  // the per-element data every bound-aware kernel needs
 // yqn != nullptr: the same pass also completes the quasi-Newton gradient difference, yqn += [lo]zl - [up]zu - rx
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
               int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn = nullptr);
+// k_update_mult_yqn + k_kkt_res(..., yqn) in one pass (see kernels.hip): the bound multipliers take their step
+// zl <- max(zl + a pzl, eps) here, y_qn gets both brackets, rx / out are those of the new point
+int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
+                     double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
+                     const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
+                     double az, double *acz, double az_acz);
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);

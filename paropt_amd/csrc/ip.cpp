@@ -57,6 +57,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   if (getenv("PAROPT_AMD_NO_FUSED_DOTS")) fused_dots = false;
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
   recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
+  fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
   use_acz = !getenv("PAROPT_AMD_NO_ACZ");
   use_ztpx_hint = !getenv("PAROPT_AMD_NO_ZTS_HINT");
   use_lower = prob->useLowerBounds();
@@ -362,13 +363,14 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
   }
 }
 
-int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
+int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, const MultUpdate *upd) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   double *out = res_out;  // a member: inside a BatchScope the values arrive at the flush (after_reduce below)
   // sparse and design blocks of the residual share one collective + sync (the problem's sparse callbacks run in
   // between: built-in problems only)
   BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
   if (has_w) PO_TRY(computeResidualW(mu));
+  bool acz_mode = false, acz_rebuilt = false;
   if (vectors) {
     std::vector<const double *> A;
     std::vector<double> zc;
@@ -384,10 +386,12 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
         PO_TRY(k_panel_axpy(ctx, acz->d, 0.0, nullptr, 0.0, vars.z.data(), Ap.data(), c, n));
         acz_valid = true;
         acz_age = 0;
+        acz_rebuilt = true;
       }
       acz_age++;
       A.push_back(acz->d);
       zc.push_back(1.0);
+      acz_mode = true;
     } else {
       for (Vec *a : Ac) A.push_back(a->d);
       zc = vars.z;
@@ -398,8 +402,17 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete) {
       A.push_back(tvec->d);
       zc.push_back(1.0);
     }
-    PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
-                     yqn_complete ? yqn_complete->d : nullptr));
+    if (upd && yqn_complete && !has_w) {
+      // the bound multipliers take their step in the same pass (see kkt_res_update_kernel); A^T z follows the dense
+      // multiplier step by recurrence unless it has just been rebuilt from the new multipliers
+      const double az_acz = (acz_mode && upd->acz_follow && !acz_rebuilt) ? upd->az : 0.0;
+      PO_TRY(k_kkt_res_update(ctx, bounds(), g->d, A.data(), zc.data(), acz_mode ? 0 : (int)A.size(), beta_mu, n,
+                              rx->d, out, yqn_complete->d, zl->d, pzl->d, zu->d, pzu->d, upd->a, upd->eps, vA->d,
+                              upd->az, acz_mode ? acz->d : nullptr, az_acz));
+    } else {
+      PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
+                       yqn_complete ? yqn_complete->d : nullptr));
+    }
   } else {
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
   }
@@ -1261,7 +1274,16 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
   // acz = A^T z follows z += alpha*sz*pz through va = A^T pz when the solves kept va; otherwise it is rebuilt
   const bool acz_follow = acz && acz_valid && vA_valid;
-  if (fast_yqn) {
+  // The bound-multiplier step and the first bracket of y_qn ride in the residual pass of the new point when that
+  // pass follows anyway (kkt_res_update_kernel): nothing in between reads zl / zu.
+  const bool fuse_upd = fast_yqn && fuse_mult_update;
+  MultUpdate upd;
+  upd.a = upd.az = alpha * sz;
+  upd.eps = eps;
+  upd.acz_follow = acz_follow;
+  if (fuse_upd) {
+    // (deferred)
+  } else if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
                              rx->d, vA->d, alpha * sz, n, y_qn->d, acz_follow ? acz->d : nullptr));
   } else {
@@ -1315,7 +1337,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
       // ... and y_qn += [lo]zl+ - [up]zu+ - rx+ in the same pass (the residual kernel has all three in registers)
-      PO_TRY(computeResidual(barrier_param, true, y_qn));
+      PO_TRY(computeResidual(barrier_param, true, y_qn, fuse_upd ? &upd : nullptr));
       residual_cached = true;
     } else {
       std::vector<double> mz(c > 0 ? c : 1);

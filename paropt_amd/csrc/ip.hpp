@@ -206,7 +206,11 @@ class InteriorPoint {
   int initLeastSquaresMultipliers();
   int initAffineStepMultipliers();
   void denseResidual(double mu, Dense &r) const;
-  int computeResidual(double mu, bool vectors, Vec *yqn_complete = nullptr);
+  struct MultUpdate {  // a bound-multiplier step that rides in the residual pass (computeStepAndUpdate)
+    double a = 0.0, az = 0.0, eps = 0.0;
+    bool acz_follow = false;
+  };
+  int computeResidual(double mu, bool vectors, Vec *yqn_complete = nullptr, const MultUpdate *upd = nullptr);
   void resNorms(const Dense &r, double *max_prime, double *max_dual, double *max_infeas,
                 double *res_norm) const;
   double compFromSums(double prod, double count, const Dense &v, double wprod = 0.0) const;
@@ -244,6 +248,7 @@ class InteriorPoint {
   bool acz_valid = false, use_acz = true, use_ztpx_hint = true;
   int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
+  bool fuse_mult_update = true;
   bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step
   std::vector<double> alpha_first;                                 // coefficients of that first pass
   bool fused_tdots = true, t0_valid = false;

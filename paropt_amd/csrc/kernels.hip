@@ -638,8 +638,8 @@ __global__ void __launch_bounds__(kBlock)
       // second bracket of the quasi-Newton gradient difference, y += [lo]zl - [up]zu - rx at the new point, in the
       // operation order of the panel_axpy pass it replaces (computeStepAndUpdate)
       const double cl = b.use_lower ? 1.0 : 0.0, cu = b.use_upper ? -1.0 : 0.0;
-      yv.x += fma(-1.0, r.x, fma(cu, _zu.x, fma(cl, _zl.x, 0.0)));
-      yv.y += fma(-1.0, r.y, fma(cu, _zu.y, fma(cl, _zl.y, 0.0)));
+      yv.x = __dadd_rn(yv.x, __fma_rn(-1.0, r.x, __fma_rn(cu, _zu.x, __fma_rn(cl, _zl.x, 0.0))));
+      yv.y = __dadd_rn(yv.y, __fma_rn(-1.0, r.y, __fma_rn(cu, _zu.y, __fma_rn(cl, _zl.y, 0.0))));
       st2(yqn, q, n, yv);
     }
     maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
@@ -1510,26 +1510,27 @@ __global__ void __launch_bounds__(kBlock)
                            double *__restrict__ yqn, double *__restrict__ acz) {
   PO_PAIR_LOOP(q, n) {
     const double2 r = ld2(rx, q, n), w = ld2(va, q, n);
-    double2 y = make_double2(r.x + az * w.x, r.y + az * w.y);
+    // (explicitly rounded operations: kkt_res_update_kernel forms the same sums and must give the same bits)
+    double2 y = make_double2(__fma_rn(az, w.x, r.x), __fma_rn(az, w.y, r.y));
     if (acz) {  // A^T z of a problem with a constant Jacobian follows the multiplier step: += az * A^T pz
       const double2 c0 = ld2(acz, q, n);
-      st2(acz, q, n, make_double2(c0.x + az * w.x, c0.y + az * w.y));
+      st2(acz, q, n, make_double2(__fma_rn(az, w.x, c0.x), __fma_rn(az, w.y, c0.y)));
     }
     if (use_lower) {
       const double2 z = ld2(zl, q, n), p = ld2(pzl, q, n);
-      y.x -= z.x;
-      y.y -= z.y;
+      y.x = __dsub_rn(y.x, z.x);
+      y.y = __dsub_rn(y.y, z.y);
       st2(zl, q, n,
-          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
-                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+          make_double2(clamp_elem(__fma_rn(a, p.x, z.x), true, 0.0, false, 0.0, eps),
+                       clamp_elem(__fma_rn(a, p.y, z.y), true, 0.0, false, 0.0, eps)));
     }
     if (use_upper) {
       const double2 z = ld2(zu, q, n), p = ld2(pzu, q, n);
-      y.x += z.x;
-      y.y += z.y;
+      y.x = __dadd_rn(y.x, z.x);
+      y.y = __dadd_rn(y.y, z.y);
       st2(zu, q, n,
-          make_double2(clamp_elem(z.x + a * p.x, true, 0.0, false, 0.0, eps),
-                       clamp_elem(z.y + a * p.y, true, 0.0, false, 0.0, eps)));
+          make_double2(clamp_elem(__fma_rn(a, p.x, z.x), true, 0.0, false, 0.0, eps),
+                       clamp_elem(__fma_rn(a, p.y, z.y), true, 0.0, false, 0.0, eps)));
     }
     st2(yqn, q, n, y);
   }
@@ -1541,6 +1542,105 @@ int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const d
   PO_LAUNCH(update_mult_yqn_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, rx,
             va, az, n, yqn, acz);
   return PO_OK;
+}
+
+// update_mult_yqn_kernel and kkt_res_kernel (with its y_qn completion) in ONE pass, run after the gradient of the new
+// point is known: the bound multipliers take their step here (nothing between the two original launches reads them:
+// the problem callbacks see x and the dense multipliers only), the first bracket of y_qn is formed from the OLD
+// (rx, zl, zu) and the second from the NEW ones, and rx / the norms are those of the new point.  One pass over the
+// bound data instead of two, one output stream (y_qn) and four input streams less.  Same arithmetic, same order.
+//   acz != nullptr: A^T z is that vector (+ az_acz * va first: the recurrence of the linear-constraint mode);
+//   otherwise A^T z = sum_j z_j A_j over the nc panel columns.
+__global__ void __launch_bounds__(kBlock)
+    kkt_res_update_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc, double beta_mu,
+                          int64_t n, double *__restrict__ rx, double *__restrict__ yqn, double *__restrict__ zl,
+                          const double *__restrict__ pzl, double *__restrict__ zu, const double *__restrict__ pzu,
+                          double a, double eps, const double *__restrict__ va, double az, double *__restrict__ acz,
+                          double az_acz, double *__restrict__ partials) {
+  __shared__ double sm[4 * 8];
+  double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double maxs[3] = {0.0, 0.0, 0.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 _x = ld2(b.x, q, n), _lb = ld2(b.lb, q, n), _ub = ld2(b.ub, q, n);
+    const double2 r0 = ld2(rx, q, n), w = ld2(va, q, n), gv = ld2(g, q, n);
+    // first bracket, as update_mult_yqn_kernel
+    double2 y = make_double2(__fma_rn(az, w.x, r0.x), __fma_rn(az, w.y, r0.y));
+    double2 aczv = make_double2(0.0, 0.0);
+    if (acz) {
+      const double2 c0 = ld2(acz, q, n);
+      aczv = az_acz != 0.0 ? make_double2(__fma_rn(az_acz, w.x, c0.x), __fma_rn(az_acz, w.y, c0.y)) : c0;
+      if (az_acz != 0.0) st2(acz, q, n, aczv);
+    }
+    double2 _zl = make_double2(0.0, 0.0), _zu = _zl;
+    if (b.use_lower) {
+      const double2 zo = ld2(zl, q, n), p = ld2(pzl, q, n);
+      y.x = __dsub_rn(y.x, zo.x);
+      y.y = __dsub_rn(y.y, zo.y);
+      _zl = make_double2(clamp_elem(__fma_rn(a, p.x, zo.x), true, 0.0, false, 0.0, eps),
+                         clamp_elem(__fma_rn(a, p.y, zo.y), true, 0.0, false, 0.0, eps));
+      st2(zl, q, n, _zl);
+      if (2 * q + 1 >= n) _zl.y = 0.0;  // what a later load of the padded pair would see
+    } else {
+      _zl = ld2(zl, q, n);
+    }
+    if (b.use_upper) {
+      const double2 zo = ld2(zu, q, n), p = ld2(pzu, q, n);
+      y.x = __dadd_rn(y.x, zo.x);
+      y.y = __dadd_rn(y.y, zo.y);
+      _zu = make_double2(clamp_elem(__fma_rn(a, p.x, zo.x), true, 0.0, false, 0.0, eps),
+                         clamp_elem(__fma_rn(a, p.y, zo.y), true, 0.0, false, 0.0, eps));
+      st2(zu, q, n, _zu);
+      if (2 * q + 1 >= n) _zu.y = 0.0;
+    } else {
+      _zu = ld2(zu, q, n);
+    }
+    PO_MAKE_BOUNDS(b, q, n);
+    // residual of the new point, as kkt_res_kernel
+    double2 r;
+    r.x = (b.use_lower ? _zl.x : 0.0);
+    r.y = (b.use_lower ? _zl.y : 0.0);
+    if (b.use_upper) {
+      r.x += -1.0 * _zu.x;
+      r.y += -1.0 * _zu.y;
+    }
+    r.x += -1.0 * gv.x;
+    r.y += -1.0 * gv.y;
+    double2 ps;
+    if (acz) {
+      ps = make_double2(fma(1.0, aczv.x, 0.0), fma(1.0, aczv.y, 0.0));
+    } else {
+      ps = panel_sum(A, z, nc, q);
+    }
+    r.x += ps.x;
+    r.y += ps.y;
+    if (!_has2) r.y = 0.0;
+    st2(rx, q, n, r);
+    const double cl = b.use_lower ? 1.0 : 0.0, cu = b.use_upper ? -1.0 : 0.0;
+    y.x = __dadd_rn(y.x, __fma_rn(-1.0, r.x, __fma_rn(cu, _zu.x, __fma_rn(cl, _zl.x, 0.0))));
+    y.y = __dadd_rn(y.y, __fma_rn(-1.0, r.y, __fma_rn(cu, _zu.y, __fma_rn(cl, _zl.y, 0.0))));
+    st2(yqn, q, n, y);
+    maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
+    sums[2] += fabs(r.x) + fabs(r.y);
+    sums[5] += r.x * r.x + r.y * r.y;
+    res_bound_acc(e0, beta_mu, sums, maxs, 3, 6, 1);
+    res_bound_acc(e1, beta_mu, sums, maxs, 3, 6, 1);
+  }
+  block_reduce_store<8, OP_SUM>(sums, partials, 0, sm);
+  block_reduce_store<3, OP_MAX>(maxs, partials, 8, sm);
+}
+
+int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
+                     double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
+                     const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
+                     double az, double *acz, double az_acz) {
+  const int grid = grid_for(c, n, 3);
+  PO_TRY(ensure_partials(c, (size_t)grid * 11));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(z, A, nc, &ct, &pt);
+  PO_LAUNCH(kkt_res_update_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz,
+            az_acz, c->d_partials);
+  return reduce_finish(c, grid, 8, 0, 3, out);
 }
 
 __global__ void __launch_bounds__(kBlock)

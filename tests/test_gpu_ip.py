@@ -948,3 +948,52 @@ def test_reduction_batching_changes_no_bit(problem, qn, strategy, nw):
     # at least two host syncs fewer per iteration (three per quasi-Newton update + one per extra trial point)
     assert b[2] <= a[2] - 2 * (len(b[0]) - 1), (a[2], b[2])
     assert a[2] - b[2] == b[3]
+
+
+@pytest.mark.parametrize("problem,qn,linear", [("convex", "sr1", True), ("convex", "bfgs", False),
+                                               ("quadratic", "bfgs", True)])
+def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn, linear):
+    """Round-2 fusions that exist to save HBM writes, each against the form it replaces (environment switch read when
+    the solver is created):
+    * PAROPT_AMD_NO_FUSED_UPDATE: bound-multiplier step + first bracket of y_qn inside the residual pass of the new
+      point (kkt_res_update_kernel) vs update_mult_yqn + kkt_res -- the same arithmetic in the same order: every
+      iterate is the same bits;
+    * PAROPT_AMD_NO_RECOMPUTE: first solve pass stores no step, the refinement pass recomputes it (solve2r_kernel) vs
+      stored and re-read -- the recomputed first step differs by the summation order of P alpha: same counters, state
+      to 1e-9 over the compared window."""
+    import paropt_amd as pa
+
+    opts = {"qn_type": qn, "qn_subspace_size": 6, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 22, "write_output_frequency": 0}
+
+    def run(env):
+        for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE"):
+            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            monkeypatch.setenv(k, "1")
+        c = pa.Context(0)
+        prob = pa.SeparableProblem(c, problem, 20011, 7)
+        prob.setLinearConstraints(linear)
+        ip = pa.InteriorPoint(prob, opts)
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        ip.optimize()
+        return sn, ip.getOptimizedPoint()[0].to_numpy()
+
+    base, xb = run([])
+    plain_upd, xu = run(["PAROPT_AMD_NO_FUSED_UPDATE"])
+    assert len(base) == len(plain_upd) >= 10
+    for sa, sb in zip(base, plain_upd):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
+        np.testing.assert_array_equal(sa["norms"], sb["norms"])
+        np.testing.assert_array_equal(sa["z"], sb["z"])
+    np.testing.assert_array_equal(xb, xu)
+    stored, xs = run(["PAROPT_AMD_NO_RECOMPUTE"])
+    window = 12 if qn == "sr1" else len(base)
+    assert len(stored) == len(base)
+    for sa, sb in list(zip(base, stored))[:window]:
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-9 * max(1.0, abs(sb["fobj"]))
+        np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(sa["z"], sb["z"], rtol=1e-6, atol=1e-9)
