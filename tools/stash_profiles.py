@@ -35,8 +35,8 @@ def main():
         d = json.load(open(src))
         raw = {}
         for k, v in d.items():
-            if any(t in k for t in ("mdot_kernel<32>", "solve2_dots_kernel<11", "solve2_kernel<1, 0>", "wgram_pc_kernel<11, 3>",
-                                    "wgram_kernel<11, 3")):
+            if any(t in k for t in ("mdot_kernel<32>", "solve2_dots_kernel<11", "solve2_kernel<1, 0>", "solve2r_kernel",
+                                    "kkt_res_update_kernel", "wgram_pc_kernel<11, 3>", "wgram_kernel<11, 3")):
                 e = {n: v[n] for n in ("hbm_read_bytes_corrected", "hbm_write_bytes") if n in v}
                 if "FETCH_SIZE" in v:
                     e["FETCH_SIZE_KB_mean"] = v["FETCH_SIZE"]["mean_per_dispatch"]
