@@ -124,6 +124,14 @@ extern "C" int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, c
         return k_solve2r(cx, b, t->d, t2->d, dinv->d, coef.data(), coef2.data(), P.data(), m, 1e-3, 0.95, n, px->d,
                          pzl->d, pzu->d, va->d, c, out.data());
       }));
+      PO_TRY(T.run("solve2_dots(nothing stored)", 8.0 * (m + 8) * N, 0.0, [&] {
+        return k_solve2_dots(cx, b, t->d, dinv->d, coef.data(), coef2.data(), P.data(), m, 1e-3, 0.95, rx->d, 1.0, n,
+                             px->d, pzl->d, pzu->d, nullptr, va->d, c, out.data(), nullptr, 0);
+      }));
+      PO_TRY(T.run("solve2r(refine, step and rhs recomputed)", 8.0 * (m + 12) * N, 0.0, [&] {
+        return k_solve2r(cx, b, t->d, nullptr, dinv->d, coef.data(), coef2.data(), P.data(), m, 1e-3, 0.95, n, px->d,
+                         pzl->d, pzu->d, va->d, c, out.data(), coef2.data(), rx->d, 1.0);
+      }));
       PO_TRY(T.run("solve2(refine)", 8.0 * (m + 14) * N, 0.0, [&] {
         return k_solve2(cx, b, t->d, dinv->d, coef.data(), P.data(), m, 1e-3, 1, 0.95, n, px->d, pzl->d, pzu->d,
                         out.data(), nullptr, rx->d, 1.0, t2->d, va->d, c);

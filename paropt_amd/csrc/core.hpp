@@ -275,7 +275,8 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
 // (t1, a1) and applies the refinement (t2, a2) on top in ONE sweep over P: out = {max_x, max_z} of the final step
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
-              double *pzl, double *pzu, double *va, int nca, double out[2]);
+              double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar = nullptr,
+              const double *rx = nullptr, double diag = 0.0);  // t2 == nullptr: t2 recomputed from (ar, rx, diag)
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

@@ -58,6 +58,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
   recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
   fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
+  recompute_rhs = recompute_first_step && !getenv("PAROPT_AMD_NO_RECOMPUTE_RHS");
   use_acz = !getenv("PAROPT_AMD_NO_ACZ");
   use_ztpx_hint = !getenv("PAROPT_AMD_NO_ZTS_HINT");
   use_lower = prob->useLowerBounds();
@@ -726,19 +727,27 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     // less, and an HBM write costs about four reads here.  t' goes to xt (free during the solves), t stays in tvec.
     std::vector<double> out(m + 2, 0.0);
     const bool defer = recompute_first_step;
+    // ... and with recompute_rhs not even t': the pass only takes the products P^T t', the refinement pass forms t'
+    // again from the residual coefficients (an output stream costs about four input streams)
+    double *tp_out = !defer ? tvec->d : (recompute_rhs ? nullptr : xt->d);
     PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
-                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, defer ? xt->d : tvec->d, vA->d, c,
+                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c,
                          out.data(), nullptr, defer ? 0 : 1));
     tdots.assign(out.begin(), out.begin() + m);
     tdots_valid = true;
     step_mins[0] = out[m];
     step_mins[1] = out[m + 1];
     step_deferred = defer;
-    if (defer) alpha_first = alpha;
+    if (defer) {
+      alpha_first = alpha;
+      coef_first = coef;
+      diag_first = diag;
+    }
   } else if (refine_pass && step_deferred) {
     step_deferred = false;
-    PO_TRY(k_solve2r(ctx, bounds(), tvec->d, xt->d, Dinv->d, alpha_first.data(), alpha.data(), P.data(), m, beta_mu,
-                     tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins));
+    PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
+                     alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins,
+                     coef_first.data(), rx->d, diag_first));
   } else {
     if (!refine_pass) step_deferred = false;
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,

@@ -250,7 +250,9 @@ class InteriorPoint {
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fuse_mult_update = true;
   bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step
-  std::vector<double> alpha_first;                                 // coefficients of that first pass
+  std::vector<double> alpha_first, coef_first;  // coefficients of that first pass (solve, refinement residual)
+  double diag_first = 0.0;
+  bool recompute_rhs = true;  // ... and the refinement right-hand side is recomputed as well
   bool fused_tdots = true, t0_valid = false;
   double t0_mu = 0.0;
   std::vector<double> t0dots;  // Ac holds the Jacobian of a problem with linear_constraints

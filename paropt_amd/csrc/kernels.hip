@@ -309,6 +309,45 @@ __device__ __forceinline__ void panel_sum2(const PtrTable &P, const CoefTable &a
   s2 = make_double2(acc2.x, acc2.y);
 }
 
+// three coefficient sets over the same panel in one pass (first solve, its refinement residual, refinement solve)
+template <int B>
+__device__ __forceinline__ void panel_batch3(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
+                                             const CoefTable &c3, int j, int64_t q, f64x2 &acc, f64x2 &acc2,
+                                             f64x2 &acc3) {
+  f64x2 v[B];
+#pragma unroll
+  for (int u = 0; u < B; u++) v[u] = ld_stream(P.p[j + u] + 2 * q);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < B; u++) {
+    acc.x += a.a[j + u] * v[u].x;
+    acc.y += a.a[j + u] * v[u].y;
+    acc2.x += b2.a[j + u] * v[u].x;
+    acc2.y += b2.a[j + u] * v[u].y;
+    acc3.x += c3.a[j + u] * v[u].x;
+    acc3.y += c3.a[j + u] * v[u].y;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void panel_sum3(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
+                                           const CoefTable &c3, int nv, int64_t q, double2 &s1, double2 &s2,
+                                           double2 &s3, int j = 0) {
+  f64x2 acc = (f64x2){0.0, 0.0}, acc2 = acc, acc3 = acc;
+  for (; j + 8 <= nv; j += 8) panel_batch3<8>(P, a, b2, c3, j, q, acc, acc2, acc3);
+  if (j + 4 <= nv) {
+    panel_batch3<4>(P, a, b2, c3, j, q, acc, acc2, acc3);
+    j += 4;
+  }
+  if (j + 2 <= nv) {
+    panel_batch3<2>(P, a, b2, c3, j, q, acc, acc2, acc3);
+    j += 2;
+  }
+  if (j < nv) panel_batch3<1>(P, a, b2, c3, j, q, acc, acc2, acc3);
+  s1 = make_double2(acc.x, acc.y);
+  s2 = make_double2(acc2.x, acc2.y);
+  s3 = make_double2(acc3.x, acc3.y);
+}
+
 // y <- a*x + b*y + sum_j alpha_j V_j : runtime panel width, no per-column registers needed.
 __global__ void __launch_bounds__(kBlock)
     panel_axpy_kernel(double *__restrict__ y, double a, const double *__restrict__ x, double b,
@@ -918,27 +957,48 @@ __global__ void __launch_bounds__(kBlock)
 //   px  = px1 + t2 + Dinv*(P a2), pzl, pzu accordingly      (solve2_elem<1>, as solve2_kernel<1,0>)
 // in one sweep over P with both coefficient sets.  Four output streams and three input streams less per iteration
 // than storing and re-reading the first step.
+// RECT != 0: the refinement right-hand side t2 is recomputed as well (from the residual coefficients ar, rx and diag,
+// as solve2_dots_kernel formed it when it took its panel products), so the first pass stores nothing at all.
+template <int RECT>
 __global__ void __launch_bounds__(kBlock)
     solve2r_kernel(Bounds b, const double *__restrict__ t1, const double *__restrict__ t2,
-                   const double *__restrict__ dinv, CoefTable a1, CoefTable a2, PtrTable P, int nv, double beta_mu,
-                   double tau, int64_t n, double *__restrict__ px, double *__restrict__ pzl,
-                   double *__restrict__ pzu, double *__restrict__ va, int nca, double *__restrict__ partials) {
+                   const double *__restrict__ dinv, CoefTable a1, CoefTable a2, CoefTable ar, PtrTable P, int nv,
+                   double beta_mu, double tau, const double *__restrict__ rx, double diag, int64_t n,
+                   double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
+                   double *__restrict__ va, int nca, double *__restrict__ partials) {
   __shared__ double sm[4 * 2];
   double mins[2] = {1.0, 1.0};
   PO_PAIR_LOOP(q, n) {
-    double2 a1A, a2A, acc1, acc2;
-    panel_sum2(P, a1, a2, nca, q, a1A, a2A);
-    panel_sum2(P, a1, a2, nv, q, acc1, acc2, nca);
+    double2 a1A, a2A, acc1, acc2, arA = make_double2(0.0, 0.0), accr = arA;
+    if (RECT) {
+      panel_sum3(P, a1, a2, ar, nca, q, a1A, a2A, arA);
+      panel_sum3(P, a1, a2, ar, nv, q, acc1, acc2, accr, nca);
+      accr.x += arA.x;
+      accr.y += arA.y;
+    } else {
+      panel_sum2(P, a1, a2, nca, q, a1A, a2A);
+      panel_sum2(P, a1, a2, nv, q, acc1, acc2, nca);
+    }
     acc1.x += a1A.x;
     acc1.y += a1A.y;
     acc2.x += a2A.x;
     acc2.y += a2A.y;
     if (va) st2(va, q, n, make_double2(a2A.x + a1A.x, a2A.y + a1A.y));  // A^T pz of both solves
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 tv = ld2(t1, q, n), tw = ld2(t2, q, n), dv = ld2(dinv, q, n);
+    const double2 tv = ld2(t1, q, n), dv = ld2(dinv, q, n);
     const Step3 f0 = solve2_elem<0>(e0, tv.x + dv.x * acc1.x, beta_mu, 0.0, 0.0, 0.0);
     Step3 f1 = solve2_elem<0>(e1, tv.y + dv.y * acc1.y, beta_mu, 0.0, 0.0, 0.0);
     if (!_has2) f1.px = f1.pzl = f1.pzu = 0.0;
+    double2 tw;
+    if (RECT) {
+      const double2 r = ld2(rx, q, n);
+      tw.x = dv.x * res_step_elem(e0, r.x, accr.x, diag, f0.px, f0.pzl, f0.pzu, 1.0, beta_mu, b.use_lower, b.use_upper);
+      tw.y = _has2 ? dv.y * res_step_elem(e1, r.y, accr.y, diag, f1.px, f1.pzl, f1.pzu, 1.0, beta_mu, b.use_lower,
+                                          b.use_upper)
+                   : 0.0;
+    } else {
+      tw = ld2(t2, q, n);
+    }
     const Step3 s0 = solve2_elem<1>(e0, tw.x + dv.x * acc2.x, beta_mu, f0.px, f0.pzl, f0.pzu);
     Step3 s1 = solve2_elem<1>(e1, tw.y + dv.y * acc2.y, beta_mu, f1.px, f1.pzl, f1.pzu);
     if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
@@ -953,7 +1013,8 @@ __global__ void __launch_bounds__(kBlock)
 
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
-              double *pzl, double *pzu, double *va, int nca, double out[2]) {
+              double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
+              double diag) {
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -961,11 +1022,21 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PtrTable pt;
-  CoefTable ct1, ct2;
+  CoefTable ct1, ct2, ctr;
   fill_tables(a1, P, nv, &ct1, &pt);
   fill_tables(a2, P, nv, &ct2, &pt);
-  PO_LAUNCH(solve2r_kernel, grid, b, t1, t2, dinv, ct1, ct2, pt, nv, beta_mu, tau, n, px, pzl, pzu, va, nca,
-            c->d_partials);
+  fill_tables(ar, P, nv, &ctr, &pt);
+  if (t2 == nullptr) {
+    if (!ar || !rx) {
+      set_error("k_solve2r: neither the refinement right-hand side nor the data to recompute it");
+      return PO_ERR_ARG;
+    }
+    PO_LAUNCH((solve2r_kernel<1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
+              pzu, va, nca, c->d_partials);
+  } else {
+    PO_LAUNCH((solve2r_kernel<0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
+              pzu, va, nca, c->d_partials);
+  }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
 
@@ -1134,7 +1205,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
         tp.y = dv.y * raw.y;
         if (traw) {  // the caller applies its own block solve to the raw right-hand side (sparse constraints)
           st2(traw, q, n, raw);
-        } else {
+        } else if (tout) {  // (nullptr: the refinement pass recomputes t' too -- this pass only takes its products)
           st2(tout, q, n, tp);
         }
         max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
