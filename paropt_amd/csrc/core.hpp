@@ -106,6 +106,14 @@ struct PtrTable {
 struct CoefTable {
   double a[kMaxPanel];
 };
+// Unformed L-SR1 columns at the head of a panel: column j < count has the value P.p[j] - b0 * s[j] (P.p[j] = Y_j,
+// s[j] = S_j), formed in registers by the consumer -- never written to HBM (a write costs about four reads).
+constexpr int kMaxVirt = 12;
+struct VirtCols {
+  const double *s[kMaxVirt];
+  int count;
+  double b0;
+};
 
 // Reduction finish: combine first-stage partials ([slot][nblocks] in ctx->d_partials) into
 // host_out[nsum+nmin+nmax]; slots are ordered sums, then mins, then maxs.  Collective.
@@ -270,13 +278,17 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out, double *traw = nullptr, int store_step = 1);
+                  double *tout, double *va, int nca, double *out, double *traw = nullptr, int store_step = 1,
+                  int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
+                  const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0);  // P[j] - b0v vs[j], j < nvirt
 // store_step == 0 above leaves (px, pzl, pzu, va) unwritten; this refinement pass recomputes that first step from
 // (t1, a1) and applies the refinement (t2, a2) on top in ONE sweep over P: out = {max_x, max_z} of the final step
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar = nullptr,
-              const double *rx = nullptr, double diag = 0.0);  // t2 == nullptr: t2 recomputed from (ar, rx, diag)
+              const double *rx = nullptr, double diag = 0.0,  // t2 == nullptr: t2 recomputed from (ar, rx, diag)
+              int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
+              const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0);  // P[j] - b0v vs[j], j < nvirt
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

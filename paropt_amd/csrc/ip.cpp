@@ -59,6 +59,9 @@ InteriorPoint::InteriorPoint(Problem *p)
   recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
   fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
   recompute_rhs = recompute_first_step && !getenv("PAROPT_AMD_NO_RECOMPUTE_RHS");
+  // Off by default: leaving the L-SR1 columns unformed saves the Gram pass 0.6 ms (its ten output streams) but costs
+  // the two solve passes ten more input streams each, +1.2 ms at n = 50 M; kept as a switch.
+  virtual_z = recompute_rhs && getenv("PAROPT_AMD_VIRTUAL_Z") != nullptr;
   use_acz = !getenv("PAROPT_AMD_NO_ACZ");
   use_ztpx_hint = !getenv("PAROPT_AMD_NO_ZTS_HINT");
   use_lower = prob->useLowerBounds();
@@ -553,8 +556,14 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
     for (Vec *a : Ac) P2.push_back(a->d);
     if (fuse_t) P2.push_back(tvec->d);
     std::vector<double> W2((size_t)mt * mt, 0.0);
-    PO_TRY(k_wgram(ctx, Dinv->d, P2.data(), mt, n, W2.data(), Sp.data(), Zo.data(), k, b0z, fuse_t ? 1 : 0));
-    qn->pendingZDone();
+    // Leave the columns unformed when the solves that follow take them unformed too (solveKKT): the ten output
+    // streams of the formation cost as much as forty input streams.  Any other consumer forms them on demand
+    // (CompactQuasiNewton::zPointers).
+    const bool leave_unformed = virtual_z && allow_virtual_z && fuse_t && k <= kMaxVirt;
+    std::vector<double *> Znull(Zo.size(), nullptr);
+    PO_TRY(k_wgram(ctx, Dinv->d, P2.data(), mt, n, W2.data(), Sp.data(), leave_unformed ? Znull.data() : Zo.data(), k,
+                   b0z, fuse_t ? 1 : 0));
+    if (!leave_unformed) qn->pendingZDone();
     W.assign((size_t)m2 * m2, 0.0);
     auto perm = [&](int i) { return i < c ? k + i : i - c; };  // index in [Ac | Z] -> index in [Z | Ac]
     for (int j = 0; j < m2; j++)
@@ -564,7 +573,13 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       for (int i = 0; i < m2; i++) t0dots[i] = W2[perm(i) + (size_t)mt * m2];
     }
   }
-  std::vector<const double *> P = panel(use_qn && !diag_only, &k);
+  std::vector<const double *> P;
+  if (!fuse_z) {
+    P = panel(use_qn && !diag_only, &k);  // (forms unformed columns: the plain Gram launch below reads them)
+  } else if (has_w) {
+    int k2 = 0;
+    P = panel(use_qn && !diag_only, &k2);
+  }
   const int m = c + k;
   wk = k;
   // Sparse constraints: the right-hand side of the first solve goes through the quasi-definite block solve,
@@ -644,13 +659,23 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
 int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau,
                             Dense &out, bool fuse_residual) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
-  int k = 0;
-  std::vector<const double *> P = panel(use_qn, &k);
+  const int k = (qn && use_qn) ? qn->size() : 0;
   if (k != wk) {
     set_error("internal: panel width changed between setUpKKTSystem and solve (%d vs %d)", k, wk);
     return PO_ERR_ARG;
   }
   const int m = c + k;
+  // The panel [Ac | Z] is only asked for when a pass needs it: zPointers() FORMS unformed L-SR1 columns (one pass
+  // over 3k vectors, k of them written), and the fused passes below take them unformed (Y_j - b0 S_j in registers).
+  std::vector<const double *> P;
+  bool have_panel = false;
+  auto need_panel = [&]() {
+    if (!have_panel) {
+      int k2 = 0;
+      P = panel(use_qn, &k2);
+      have_panel = true;
+    }
+  };
   const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
   const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
   // t = Dinv o d1 and P^T t were produced by setUpKKTSystem's Gram pass when the right-hand side was known then
@@ -662,6 +687,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   } else if (refine_pass && tdots_valid && (int)tdots.size() == m) {
     dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
   } else if (m > 0) {
+    need_panel();
     PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
   }
   if (!refine_pass) t0_valid = false;  // tvec is overwritten by the passes below
@@ -721,7 +747,29 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
       }
     }
   }
-  if (fuse && fused_dots && m > 0 && !cl) {
+  // Unformed L-SR1 columns (setUpKKTSystem left them unformed on purpose): the two fused passes take the panel as
+  // [Y_0..Y_{k-1} | Ac] with the S partners beside it; coefficients and products are permuted on the host.
+  std::vector<const double *> Yp, Sp;
+  std::vector<double *> Zo;
+  double b0z = 0.0;
+  const bool first_fused = fuse && fused_dots && m > 0 && !cl;
+  const bool virt = virtual_z && recompute_first_step && recompute_rhs && !have_panel && k > 0 && k <= kMaxVirt &&
+                    (first_fused || (refine_pass && step_deferred && virt_first)) && qn &&
+                    qn->pendingZ(&Yp, &Sp, &Zo, &b0z) && (int)Yp.size() == k;
+  std::vector<const double *> Pv;
+  auto to_virt = [&](const std::vector<double> &a) {  // [Ac | Z] order -> [Z | Ac] order
+    std::vector<double> r(m > 0 ? m : 1, 0.0);
+    for (int j = 0; j < k; j++) r[j] = a[c + j];
+    for (int i = 0; i < c; i++) r[k + i] = a[i];
+    return r;
+  };
+  if (virt) {
+    Pv = Yp;
+    for (Vec *a : Ac) Pv.push_back(a->d);
+  } else {
+    need_panel();
+  }
+  if (first_fused) {
     // one pass: t' = refinement rhs and P^T t' for the refinement solve.  The step itself (px, pzl, pzu, A^T pz) is
     // NOT stored: the refinement pass recomputes it from (t, alpha) in registers (k_solve2r) -- four output streams
     // less, and an HBM write costs about four reads here.  t' goes to xt (free during the solves), t stays in tvec.
@@ -730,10 +778,21 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     // ... and with recompute_rhs not even t': the pass only takes the products P^T t', the refinement pass forms t'
     // again from the residual coefficients (an output stream costs about four input streams)
     double *tp_out = !defer ? tvec->d : (recompute_rhs ? nullptr : xt->d);
-    PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
-                         beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c,
-                         out.data(), nullptr, defer ? 0 : 1));
-    tdots.assign(out.begin(), out.begin() + m);
+    if (virt) {
+      const std::vector<double> av = to_virt(alpha), cv = to_virt(coef);
+      PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, av.data(), cv.data(), Pv.data(), m, beta_mu, tau, rx->d,
+                           diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c, out.data(), nullptr, 0, k, Sp.data(), k,
+                           b0z));
+      tdots.assign(m, 0.0);
+      for (int j = 0; j < k; j++) tdots[c + j] = out[j];
+      for (int i = 0; i < c; i++) tdots[i] = out[k + i];
+    } else {
+      PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
+                           beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c,
+                           out.data(), nullptr, defer ? 0 : 1));
+      tdots.assign(out.begin(), out.begin() + m);
+    }
+    virt_first = virt;
     tdots_valid = true;
     step_mins[0] = out[m];
     step_mins[1] = out[m + 1];
@@ -745,9 +804,16 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     }
   } else if (refine_pass && step_deferred) {
     step_deferred = false;
-    PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
-                     alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins,
-                     coef_first.data(), rx->d, diag_first));
+    if (virt) {
+      const std::vector<double> a1v = to_virt(alpha_first), a2v = to_virt(alpha), crv = to_virt(coef_first);
+      PO_TRY(k_solve2r(ctx, bounds(), tvec->d, nullptr, Dinv->d, a1v.data(), a2v.data(), Pv.data(), m, beta_mu, tau, n,
+                       px->d, pzl->d, pzu->d, vA->d, c, step_mins, crv.data(), rx->d, diag_first, k, Sp.data(), k,
+                       b0z));
+    } else {
+      PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
+                       alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins,
+                       coef_first.data(), rx->d, diag_first));
+    }
   } else {
     if (!refine_pass) step_deferred = false;
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
@@ -776,13 +842,24 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
   PO_TRY(solveKKT(res, mu, use_qn, false, tau, step, nref > 0));
   for (int it = 0; it < nref; it++) {  // :4985-4991
     // dots of the current step with [Ac | Z_qn]: A px for r'.z, Z^T px for B px
-    int kq = 0;
-    std::vector<const double *> Pq = panel(qn && !options.integer("sequential_linear_method"), &kq);
+    const bool with_qn = qn && !options.integer("sequential_linear_method");
+    int kq = with_qn ? qn->size() : 0;
+    // (the panel is only asked for when a pass below streams it: zPointers() forms unformed L-SR1 columns)
+    std::vector<const double *> Pq;
+    bool have_pq = false;
+    auto need_pq = [&]() {
+      if (!have_pq) {
+        int k2 = 0;
+        Pq = panel(with_qn, &k2);
+        have_pq = true;
+      }
+    };
     const int mq = c + kq;
     std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
     if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
       for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
     } else if (mq > 0) {
+      need_pq();
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
     double diag = options.real("qn_sigma");
@@ -798,6 +875,7 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
       } else {
         PO_TRY(k_mul(ctx, xt->d, 1.0, hdiag->d, px->d, n));
       }
+      need_pq();
       Pq.push_back(xt->d);
       coef[mq] = -1.0;
       mres = mq + 1;
@@ -810,6 +888,7 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
       }
     }
     if (!(it == 0 && residual_fused)) {
+      need_pq();
       PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, Dinv->d, coef.data(), Pq.data(),
                         mres, diag, beta_mu, n, tvec->d));
     }
@@ -1041,8 +1120,8 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
   const bool seq_lin = options.integer("sequential_linear_method");
   double out[6];
   double wm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  int kq = 0;
-  std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
+  const int kq = (qn && !seq_lin) ? qn->size() : 0;
+  std::vector<const double *> Pq;  // (asked for only if streamed: zPointers() forms unformed L-SR1 columns)
   const int mq = c + kq;
   std::vector<double> dots(mq > 0 ? mq : 1, 0.0);
   {
@@ -1062,6 +1141,8 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
     if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
       for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
     } else if (mq > 0) {
+      int k2 = 0;
+      Pq = panel(qn && !seq_lin, &k2);
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
     if (has_w) {  // :3735-3765, 3489-3503
@@ -1669,7 +1750,14 @@ int InteriorPoint::optimize(const char *checkpoint) {
       // nothing to do: computeKKTGMRESStep left the step in (px, pzl, pzu, step)
     } else {
     const double rhs_mu = mehrotra ? 0.0 : barrier_param;  // of the solve that follows
-    PO_TRY(setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0, &rhs_mu));
+    // unformed L-SR1 columns may stay unformed when every pass of this iteration that reads the panel is one of the
+    // fused ones: a single quasi-Newton solve with one refinement step, no corrector solve
+    allow_virtual_z = !mehrotra && use_qn && !diagonal_quasi_newton_step && analytic_panel_dots && fused_dots &&
+                      options.integer("iterative_refinement_steps") == 1 && !options.integer("use_diag_hessian") &&
+                      !options.integer("sequential_linear_method");
+    const int setup_rc = setUpKKTSystem(use_qn, diagonal_quasi_newton_step != 0, &rhs_mu);
+    allow_virtual_z = false;
+    PO_TRY(setup_rc);
     phaseEnd("setup_kkt");
     if (!mehrotra) {
       PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));

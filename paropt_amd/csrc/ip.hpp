@@ -253,6 +253,8 @@ class InteriorPoint {
   std::vector<double> alpha_first, coef_first;  // coefficients of that first pass (solve, refinement residual)
   double diag_first = 0.0;
   bool recompute_rhs = true;  // ... and the refinement right-hand side is recomputed as well
+  // unformed L-SR1 columns are consumed unformed by the Gram pass and both solve passes (never written)
+  bool virtual_z = true, virt_first = false, allow_virtual_z = false;
   bool fused_tdots = true, t0_valid = false;
   double t0_mu = 0.0;
   std::vector<double> t0dots;  // Ac holds the Jacobian of a problem with linear_constraints

@@ -313,10 +313,22 @@ __device__ __forceinline__ void panel_sum2(const PtrTable &P, const CoefTable &a
 template <int B>
 __device__ __forceinline__ void panel_batch3(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
                                              const CoefTable &c3, int j, int64_t q, f64x2 &acc, f64x2 &acc2,
-                                             f64x2 &acc3) {
+                                             f64x2 &acc3, const VirtCols &vc) {
   f64x2 v[B];
 #pragma unroll
   for (int u = 0; u < B; u++) v[u] = ld_stream(P.p[j + u] + 2 * q);
+  if (j < vc.count) {  // unformed L-SR1 columns: Z = Y - b0 S in registers
+    f64x2 w[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) w[u] = ld_stream(vc.s[(j + u) < vc.count ? (j + u) : 0] + 2 * q);
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      if (j + u < vc.count) {
+        v[u].x -= vc.b0 * w[u].x;
+        v[u].y -= vc.b0 * w[u].y;
+      }
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int u = 0; u < B; u++) {
@@ -329,20 +341,21 @@ __device__ __forceinline__ void panel_batch3(const PtrTable &P, const CoefTable 
   }
   __builtin_amdgcn_sched_barrier(0);
 }
+// columns [j, nv) added onto (s1, s2, s3)
 __device__ __forceinline__ void panel_sum3(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
                                            const CoefTable &c3, int nv, int64_t q, double2 &s1, double2 &s2,
-                                           double2 &s3, int j = 0) {
-  f64x2 acc = (f64x2){0.0, 0.0}, acc2 = acc, acc3 = acc;
-  for (; j + 8 <= nv; j += 8) panel_batch3<8>(P, a, b2, c3, j, q, acc, acc2, acc3);
+                                           double2 &s3, int j, const VirtCols &vc) {
+  f64x2 acc = (f64x2){s1.x, s1.y}, acc2 = (f64x2){s2.x, s2.y}, acc3 = (f64x2){s3.x, s3.y};
+  for (; j + 8 <= nv; j += 8) panel_batch3<8>(P, a, b2, c3, j, q, acc, acc2, acc3, vc);
   if (j + 4 <= nv) {
-    panel_batch3<4>(P, a, b2, c3, j, q, acc, acc2, acc3);
+    panel_batch3<4>(P, a, b2, c3, j, q, acc, acc2, acc3, vc);
     j += 4;
   }
   if (j + 2 <= nv) {
-    panel_batch3<2>(P, a, b2, c3, j, q, acc, acc2, acc3);
+    panel_batch3<2>(P, a, b2, c3, j, q, acc, acc2, acc3, vc);
     j += 2;
   }
-  if (j < nv) panel_batch3<1>(P, a, b2, c3, j, q, acc, acc2, acc3);
+  if (j < nv) panel_batch3<1>(P, a, b2, c3, j, q, acc, acc2, acc3, vc);
   s1 = make_double2(acc.x, acc.y);
   s2 = make_double2(acc2.x, acc2.y);
   s3 = make_double2(acc3.x, acc3.y);
@@ -965,14 +978,18 @@ __global__ void __launch_bounds__(kBlock)
                    const double *__restrict__ dinv, CoefTable a1, CoefTable a2, CoefTable ar, PtrTable P, int nv,
                    double beta_mu, double tau, const double *__restrict__ rx, double diag, int64_t n,
                    double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
-                   double *__restrict__ va, int nca, double *__restrict__ partials) {
+                   double *__restrict__ va, int nca, int ca0, VirtCols vc, double *__restrict__ partials) {
   __shared__ double sm[4 * 2];
   double mins[2] = {1.0, 1.0};
   PO_PAIR_LOOP(q, n) {
-    double2 a1A, a2A, acc1, acc2, arA = make_double2(0.0, 0.0), accr = arA;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    double2 a1A = zero2, a2A = zero2, acc1 = zero2, acc2 = zero2, arA = zero2, accr = zero2;
     if (RECT) {
-      panel_sum3(P, a1, a2, ar, nca, q, a1A, a2A, arA);
-      panel_sum3(P, a1, a2, ar, nv, q, acc1, acc2, accr, nca);
+      // the constraint columns [ca0, ca0 + nca) are summed apart (A^T pz is kept), the rest in panel order:
+      // [0, ca0) (the quasi-Newton columns when they lead the panel, unformed ones included), then the tail
+      panel_sum3(P, a1, a2, ar, ca0 + nca, q, a1A, a2A, arA, ca0, vc);
+      if (ca0 > 0) panel_sum3(P, a1, a2, ar, ca0, q, acc1, acc2, accr, 0, vc);
+      panel_sum3(P, a1, a2, ar, nv, q, acc1, acc2, accr, ca0 + nca, vc);
       accr.x += arA.x;
       accr.y += arA.y;
     } else {
@@ -1014,7 +1031,7 @@ __global__ void __launch_bounds__(kBlock)
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
-              double diag) {
+              double diag, int ca0, const double *const *vs, int nvirt, double b0v) {
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -1026,16 +1043,33 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
   fill_tables(a1, P, nv, &ct1, &pt);
   fill_tables(a2, P, nv, &ct2, &pt);
   fill_tables(ar, P, nv, &ctr, &pt);
+  VirtCols vc;
+  vc.count = 0;
+  vc.b0 = b0v;
+  for (int j = 0; j < kMaxVirt; j++) vc.s[j] = nullptr;
+  if (nvirt > 0) {
+    if (nvirt > kMaxVirt || t2 != nullptr || ca0 < nvirt) {
+      set_error("k_solve2r: %d unformed columns (at most %d, leading the panel, recomputed right-hand side only)", nvirt,
+                kMaxVirt);
+      return PO_ERR_ARG;
+    }
+    vc.count = nvirt;
+    for (int j = 0; j < nvirt; j++) vc.s[j] = vs[j];
+  }
+  if (t2 != nullptr && ca0 != 0) {
+    set_error("k_solve2r: the stored right-hand side form expects the constraint columns first");
+    return PO_ERR_ARG;
+  }
   if (t2 == nullptr) {
     if (!ar || !rx) {
       set_error("k_solve2r: neither the refinement right-hand side nor the data to recompute it");
       return PO_ERR_ARG;
     }
     PO_LAUNCH((solve2r_kernel<1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, c->d_partials);
+              pzu, va, nca, ca0, vc, c->d_partials);
   } else {
     PO_LAUNCH((solve2r_kernel<0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, c->d_partials);
+              pzu, va, nca, ca0, vc, c->d_partials);
   }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
@@ -1082,14 +1116,14 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
 // Each wave reads back only the LDS columns it wrote itself, so two barriers per tile suffice.
 // -------------------------------------------------------------------------------------------------
 constexpr int kS2Tile = 128;
-template <int NPASS, int OCC>
+template <int NPASS, int OCC, int VIRT>
 __global__ void __launch_bounds__(kBlock, OCC)
     solve2_dots_kernel(Bounds b, const double *t, const double *__restrict__ dinv, CoefTable alpha,
                        CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                        double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
-                       int store_step, double *__restrict__ partials) {
+                       int store_step, int ca0, VirtCols vc, double *__restrict__ partials) {
   extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
   double *pt = s2lds;
   double *sacc = s2lds + 4 * NPASS * kS2Tile;
@@ -1105,6 +1139,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
   double mins[2] = {1.0, 1.0};
   const int64_t qlast = (n - 1) >> 1;
   f64x2 buf[NPASS];
+  f64x2 sbuf[VIRT ? 3 : 1];  // S partners of this wave's unformed L-SR1 columns (they lead the panel: j < 12)
   f64x2 eb[8];  // wave 0: x, lb, ub, zl, zu, t, dinv, rx of the tile
   int64_t q = 0;
   bool in = false;
@@ -1116,6 +1151,12 @@ __global__ void __launch_bounds__(kBlock, OCC)
     _Pragma("unroll") for (int it = 0; it < NPASS; it++) {                                   \
       const int j = wave + 4 * it;                                                           \
       buf[it] = ld_stream(P.p[j < nv ? j : 0] + 2 * q);                                      \
+    }                                                                                        \
+    if (VIRT) {                                                                              \
+      _Pragma("unroll") for (int it = 0; it < (VIRT ? 3 : 0); it++) {                        \
+        const int j = wave + 4 * it;                                                         \
+        sbuf[it] = ld_stream(vc.s[j < vc.count ? j : 0] + 2 * q);                            \
+      }                                                                                      \
     }                                                                                        \
   }
 #define PO_S2_PREFETCH_E(Q)                                                                  \
@@ -1141,8 +1182,12 @@ __global__ void __launch_bounds__(kBlock, OCC)
     for (int it = 0; it < NPASS; it++) {
       const int j = wave + 4 * it;  // coefficient tables are zero beyond nv
       f64x2 v = buf[it];
+      if (VIRT && it < 3 && j < vc.count) {  // Z_j = Y_j - b0 S_j in registers
+        v.x -= vc.b0 * sbuf[VIRT ? it : 0].x;
+        v.y -= vc.b0 * sbuf[VIRT ? it : 0].y;
+      }
       if (!inc) v = (f64x2){0.0, 0.0};
-      const double ca = alpha.a[j], cb = coef2.a[j], cA = j < nca ? ca : 0.0;
+      const double ca = alpha.a[j], cb = coef2.a[j], cA = (j >= ca0 && j < ca0 + nca) ? ca : 0.0;
       a1 += ca * v;
       a2 += cb * v;
       aA += cA * v;
@@ -1239,16 +1284,16 @@ __global__ void __launch_bounds__(kBlock, OCC)
   block_reduce_store<2, OP_MIN>(mins, partials, nv, sm);
 }
 
-template <int NP, int OCC>
+template <int NP, int OCC, int VIRT>
 static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const double *t, const double *dinv,
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
                               double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
                               double *pzl, double *pzu, double *tout, double *va, int nca, double *traw,
-                              int store_step, int *grid_out) {
+                              int store_step, int ca0, const VirtCols &vc, int *grid_out) {
   const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
   static bool attr_set = false;
   if (!attr_set) {
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(solve2_dots_kernel<NP, OCC>),
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(solve2_dots_kernel<NP, OCC, VIRT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1259,8 +1304,9 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   if (g > ntiles) g = ntiles;
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
-  hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
-                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, c->d_partials);
+  hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC, VIRT>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
+                     beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc,
+                     c->d_partials);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -1270,22 +1316,39 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
 #define PO_S2D_CASE(NP)                                                                                    \
   case NP: {                                                                                               \
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
-    if (occ_env == OA)                                                                                     \
-      PO_TRY((solve2_dots_launch<NP, OA>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, traw, store_step, &grid)));              \
+    constexpr int OV = NP <= 16 ? 2 : 1; /* with unformed columns: three more prefetch registers */        \
+    if (vc.count > 0)                                                                                      \
+      PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
+    else if (occ_env == OA)                                                                                \
+      PO_TRY((solve2_dots_launch<NP, OA, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
     else                                                                                                   \
-      PO_TRY((solve2_dots_launch<NP, OD>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, \
-                                         pzl, pzu, tout, va, nca, traw, store_step, &grid)));              \
+      PO_TRY((solve2_dots_launch<NP, OD, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
   } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out, double *traw, int store_step) {
+                  double *tout, double *va, int nca, double *out, double *traw, int store_step, int ca0,
+                  const double *const *vs, int nvirt, double b0v) {
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
+  }
+  VirtCols vc;
+  vc.count = 0;
+  vc.b0 = b0v;
+  for (int j = 0; j < kMaxVirt; j++) vc.s[j] = nullptr;
+  if (nvirt > 0) {
+    if (nvirt > kMaxVirt || ca0 < nvirt) {
+      set_error("k_solve2_dots: %d unformed columns (at most %d, leading the panel)", nvirt, kMaxVirt);
+      return PO_ERR_ARG;
+    }
+    vc.count = nvirt;
+    for (int j = 0; j < nvirt; j++) vc.s[j] = vs[j];
   }
   const int64_t ntiles = (((n + 1) >> 1) + 63) / 64;
   int grid = 0;

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
       if (ZP > 0 && it < ZP && j < kpend) {
         v.x -= b0 * sbuf[it].x;
         v.y -= b0 * sbuf[it].y;
-        if (pre_in) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
+        if (pre_in && zcol[it]) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + pre_i));
       }
       if (!pre_in) v = (f64x2){0.0, 0.0};
       if (ablate == 2) {  // tuning: no LDS staging
@@ -298,7 +298,7 @@ __device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *_
     if (ZP > 0 && it < ZP && j < kpend) {
       v.x -= b0 * P.sbuf[R][it].x;
       v.y -= b0 * P.sbuf[R][it].y;
-      if (in) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + P.row[R]));
+      if (in && zcol[it]) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + P.row[R]));
     }
     if (!in) v = (f64x2){0.0, 0.0};
     if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;

@@ -967,7 +967,8 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
             "max_major_iters": 22, "write_output_frequency": 0}
 
     def run(env):
-        for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE"):
+        for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS",
+                  "PAROPT_AMD_VIRTUAL_Z"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -989,11 +990,15 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
         np.testing.assert_array_equal(sa["norms"], sb["norms"])
         np.testing.assert_array_equal(sa["z"], sb["z"])
     np.testing.assert_array_equal(xb, xu)
-    stored, xs = run(["PAROPT_AMD_NO_RECOMPUTE"])
     window = 12 if qn == "sr1" else len(base)
-    assert len(stored) == len(base)
-    for sa, sb in list(zip(base, stored))[:window]:
-        np.testing.assert_array_equal(sa["counters"], sb["counters"])
-        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-9 * max(1.0, abs(sb["fobj"]))
-        np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-7, atol=1e-9)
-        np.testing.assert_allclose(sa["z"], sb["z"], rtol=1e-6, atol=1e-9)
+    # ... PAROPT_AMD_NO_RECOMPUTE_RHS: only the step is recomputed, the refinement right-hand side is stored;
+    # PAROPT_AMD_VIRTUAL_Z (off by default: slower): the L-SR1 columns Z_j = Y_j - b0 S_j are never formed in HBM,
+    # the Gram pass and both solve passes form them in registers
+    for switch in ("PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS", "PAROPT_AMD_VIRTUAL_Z"):
+        other, xs = run([switch])
+        assert len(other) == len(base), switch
+        for sa, sb in list(zip(base, other))[:window]:
+            np.testing.assert_array_equal(sa["counters"], sb["counters"], err_msg=switch)
+            assert abs(sa["fobj"] - sb["fobj"]) <= 1e-9 * max(1.0, abs(sb["fobj"])), switch
+            np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-7, atol=1e-9, err_msg=switch)
+            np.testing.assert_allclose(sa["z"], sb["z"], rtol=1e-6, atol=1e-9, err_msg=switch)
