@@ -357,9 +357,15 @@ def main():
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline and world == 1:
-            cpu_n = a.cpu_n or a.n
+            # bounded sample (about half a minute of host time): a quarter of the rows of a large workload, the rate
+            # scaled back linearly in n -- every pass of the reference is O(n) and memory-bound at these sizes
+            cpu_n = a.cpu_n or (a.n // 4 if a.n >= 20_000_000 and a.nwcon == 0 else a.n)
             cpu = cpu_baseline(cpu_n, a.ncon, a.cpu_iters, log, a.nwcon * cpu_n // a.n, a.nw, a.qn, a.qn_size,
                                a.problem)
+            if cpu and cpu_n != a.n and cpu.get("kind") == "reference":
+                cpu["value"] *= cpu_n / float(a.n)
+                cpu["sample"] += "; measured at n=%d, rate scaled by %d/%d to the workload's n (O(n) passes)" % (
+                    cpu_n, cpu_n, a.n)
         niter = det["niter"]
         kind, nred, ngat = ctx.comm_info()
         res = {
