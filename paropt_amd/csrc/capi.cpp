@@ -64,6 +64,10 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   if (launches) *launches = ctx->n_launches;
   return PO_OK;
 }
+/* tuning aid (not part of the interface): cycle stamps of the producer/consumer Gram kernel's workgroup 0, see
+ * PAROPT_AMD_WGRAM_ABLATE=16 in wgram.hip */
+int po_debug_wgram_stamps(double *out8) { return po::wgram_debug_stamps(out8); }
+
 int po_ctx_set_reduction_batching(po_ctx ctx, int on) {
   PO_CHECK_PTR(ctx);
   PO_TRY(po::batch_flush(ctx));

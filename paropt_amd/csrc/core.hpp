@@ -210,6 +210,7 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
             const double *const *S = nullptr, double *const *Zout = nullptr, int kpend = 0,
             double b0 = 0.0, int preweighted_last = 0);
+int wgram_debug_stamps(double out[8]);  // tuning aid: PAROPT_AMD_WGRAM_ABLATE=16
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
                    int *nblocks, int *nslots, const double *const *S = nullptr,
                    double *const *Zout = nullptr, int kpend = 0, double b0 = 0.0,

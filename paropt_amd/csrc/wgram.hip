@@ -255,6 +255,11 @@ __global__ void __launch_bounds__(kBlock, OCC)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kGramDepth = 3;  // tiles a producer keeps in flight
 
+// PAROPT_AMD_WGRAM_ABLATE=16: cycle stamps of workgroup 0 (s_memtime), read by po_debug_wgram_stamps:
+// [0] consumer barrier wait, [1] consumer matrix work, [2] producer staging (incl. the wait for its loads),
+// [3] producer load issue, [4] producer barrier wait, [5] tiles
+__device__ unsigned long long g_wgram_stamp[8];
+
 template <int NG, int ZP>
 struct GramProducer {
   f64x2 buf[kGramDepth][NG];
@@ -347,13 +352,25 @@ __global__ void __launch_bounds__(512, 1)
     gram_pc_load<NG, ZP, 1>(P, colp, scol, d, first + stride, ntiles, n, ilast, lane);
     gram_pc_load<NG, ZP, 2>(P, colp, scol, d, first + 2 * stride, ntiles, n, ilast, lane);
     // step `it` (ring slot it % 3, LDS buffer it % 2): stage tile `it`, reload the slot with tile it + 3, barrier
+    unsigned long long st_stage = 0, st_load = 0, st_wait = 0;
+    const bool stamp = (ablate == 16) && blockIdx.x == 0 && wave == 4;
 #define PO_PC_STEP(R)                                                                                         \
   if (it + (R) < nt) {                                                                                        \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
+    const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
     else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
+    if (stamp) __builtin_amdgcn_s_waitcnt(0);                                                                 \
+    const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane); \
+    const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     __syncthreads();                                                                                          \
+    if (stamp) {                                                                                              \
+      const unsigned long long _t3 = __builtin_amdgcn_s_memtime();                                            \
+      st_stage += _t1 - _t0;                                                                                  \
+      st_load += _t2 - _t1;                                                                                   \
+      st_wait += _t3 - _t2;                                                                                   \
+    }                                                                                                         \
   }
     for (int64_t it = 0; it < nt; it += kGramDepth) {
       PO_PC_STEP(0)
@@ -361,14 +378,24 @@ __global__ void __launch_bounds__(512, 1)
       PO_PC_STEP(2)
     }
 #undef PO_PC_STEP
+    if (stamp && lane == 0) {
+      g_wgram_stamp[2] = st_stage;
+      g_wgram_stamp[3] = st_load;
+      g_wgram_stamp[4] = st_wait;
+      g_wgram_stamp[5] = (unsigned long long)nt;
+    }
     __syncthreads();  // matches the consumers' trailing barrier
   } else {
     // ------------------------------------------------ consumers ------------------------------------------------
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+    unsigned long long sc_wait = 0, sc_work = 0;
+    const bool cstamp = (ablate == 16) && blockIdx.x == 0 && wave == 0;
     for (int64_t it = 0; it < nt; it++) {
+      const unsigned long long _t0 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       __syncthreads();  // tile `it` is staged in buffer it % 2
+      const unsigned long long _t1 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
       if (ablate == 1) continue;  // tuning: no matrix work
       switch (wave) {
@@ -377,6 +404,17 @@ __global__ void __launch_bounds__(512, 1)
         case 2: gram_tile<NG, 2>(bt, bt + M * kGramLd, lane, tcol, acc); break;
         default: gram_tile<NG, 3>(bt, bt + M * kGramLd, lane, tcol, acc); break;
       }
+      if (cstamp) {
+        // (the accumulators are consumed only at the end: read one so that the stamp follows the matrix work)
+        if (acc[0] == 1.2345e301) sc_work++;
+        const unsigned long long _t2 = __builtin_amdgcn_s_memtime();
+        sc_wait += _t1 - _t0;
+        sc_work += _t2 - _t1;
+      }
+    }
+    if (cstamp && lane == 0) {
+      g_wgram_stamp[0] = sc_wait;
+      g_wgram_stamp[1] = sc_work;
     }
     __syncthreads();
     switch (wave) {
@@ -491,6 +529,13 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
 #undef PO_WG
   *nblocks = grid;
   *nslots = (NG * (NG + 1) / 2) * 16;
+  return PO_OK;
+}
+
+int wgram_debug_stamps(double out[8]) {
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  PO_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wgram_stamp), sizeof(h)));
+  for (int i = 0; i < 8; i++) out[i] = (double)h[i];
   return PO_OK;
 }
 
