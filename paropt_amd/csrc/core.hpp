@@ -318,8 +318,9 @@ int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double 
              double out[6]);
 // trial point of the line search (:3997-4001) xt = clamp(x + a*px, lb+eps, ub-eps) and the
 // log-barrier partial sums of evalMeritFunc :3541-3565 at xt: out = {pos, neg}
+// sout != nullptr: also sout = a * px, the quasi-Newton step of this trial
 int k_trial(Ctx *c, const Bounds &b, const double *px, double a, double eps, int64_t n, double *xt,
-            double out[2]);
+            double out[2], double *sout = nullptr);
 // zl <- max(zl + a*pzl, eps) ; zu likewise  (computeStepAndUpdate :4186-4191)
 int k_update_mult(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                   double eps, int use_lower, int use_upper, int64_t n);

@@ -1258,6 +1258,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
   double alpha = *alpha_;
   int fail = LS_FAILURE;
   const bool batchable = prob->reductionsBatchable();
+  // the quasi-Newton step s = alpha sx px of the trial point is written by the trial pass itself (the accepted
+  // trial is the last one): no separate pass in computeStepAndUpdate
+  double *sq = (qn && options.integer("use_quasi_newton_update") && !has_w) ? s_qn->d : nullptr;
   double merit = 0.0, best_merit = 0.0, best_alpha = -1.0;
   std::vector<double> rs(c), rt(c);
   int j = 0;
@@ -1266,7 +1269,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     // the barrier sums at the trial point share the collective + host sync of the problem's own reductions
     // (f, c) when those go through the internal launchers (built-in problems)
     BatchScope batch(ctx, batchable);
-    PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
+    PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums, sq));
+    s_qn_a = alpha * sx;
+    s_qn_from_trial = sq != nullptr;
     clampStepDense(rs, vars.s, alpha, step.s, eps, true);
     clampStepDense(rt, vars.t, alpha, step.t, eps, true);
     userBegin();
@@ -1332,7 +1337,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       alpha = best_alpha;
       double sums[2];
       BatchScope batch(ctx, batchable);
-      PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));
+      PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums, sq));
+      s_qn_a = alpha * sx;
+      s_qn_from_trial = sq != nullptr;
       int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
       PO_TRY(batch.end());
       neval++;
@@ -1402,6 +1409,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     // the line search was skipped: form the new point now
     double sums[2];
     PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));  // (not in a batch: sums is local)
+    s_qn_from_trial = false;
   }
   // the accepted trial point IS the new design point (same clamp, same arithmetic)
   std::swap(x->d, xt->d);
@@ -1420,7 +1428,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   ngeval++;
   if (fail_g) fprintf(stderr, "ParOpt: Gradient evaluation failed at final line search\n");
   if (do_qn) {
-    PO_TRY(k_panel_axpy(ctx, s_qn->d, alpha * sx, px->d, 0.0, nullptr, nullptr, 0, n));
+    if (!(s_qn_from_trial && s_qn_a == alpha * sx)) {
+      PO_TRY(k_panel_axpy(ctx, s_qn->d, alpha * sx, px->d, 0.0, nullptr, nullptr, 0, n));
+    }
+    s_qn_from_trial = false;
     // the next residual's norms and the quasi-Newton products of the update are reduced together: nothing on the
     // host needs the norms before the update has its dots.  Only when no user code runs in between.
     BatchScope batch(ctx, fast_yqn && prob->reductionsBatchable() && qn->reductionsBatchable());

@@ -249,6 +249,8 @@ class InteriorPoint {
   int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fuse_mult_update = true;
+  bool s_qn_from_trial = false;  // s_qn holds s_qn_a * px, written by the last trial pass of the line search
+  double s_qn_a = 0.0;
   bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step
   std::vector<double> alpha_first, coef_first;  // coefficients of that first pass (solve, refinement residual)
   double diag_first = 0.0;

@@ -1578,7 +1578,7 @@ __device__ __forceinline__ double clamp_elem(double v, bool has_l, double lb, bo
 }
 __global__ void __launch_bounds__(kBlock)
     trial_kernel(Bounds b, const double *__restrict__ px, double a, double eps, int64_t n,
-                 double *__restrict__ xt, double *__restrict__ partials) {
+                 double *__restrict__ xt, double *__restrict__ sout, double *__restrict__ partials) {
   __shared__ double sm[4 * 2];
   double s[2] = {0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
@@ -1589,6 +1589,8 @@ __global__ void __launch_bounds__(kBlock)
     v.x = clamp_elem(x.x + a * p.x, true, lb.x, true, ub.x, eps);
     v.y = clamp_elem(x.y + a * p.y, true, lb.y, true, ub.y, eps);
     st2(xt, q, n, v);
+    // the quasi-Newton step s = a px of this trial (the unclamped increment, as computeStepAndUpdate forms it)
+    if (sout) st2(sout, q, n, make_double2(__dadd_rn(__dmul_rn(a, p.x), 0.0), __dadd_rn(__dmul_rn(a, p.y), 0.0)));
     BE e0 = bound_elem(v.x, lb.x, ub.x, 0.0, 0.0, b.max_bound, b.use_lower, b.use_upper);
     barrier_elem(e0, s[0], s[1]);
     if (has2) {
@@ -1599,10 +1601,10 @@ __global__ void __launch_bounds__(kBlock)
   block_reduce_store<2, OP_SUM>(s, partials, 0, sm);
 }
 int k_trial(Ctx *c, const Bounds &b, const double *px, double a, double eps, int64_t n, double *xt,
-            double out[2]) {
+            double out[2], double *sout) {
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
-  PO_LAUNCH(trial_kernel, grid, b, px, a, eps, n, xt, c->d_partials);
+  PO_LAUNCH(trial_kernel, grid, b, px, a, eps, n, xt, sout, c->d_partials);
   return reduce_finish(c, grid, 2, 0, 0, out);
 }
 
