@@ -74,6 +74,18 @@ def test_mdot_vs_oracle(ctx, n, nv):
     np.testing.assert_allclose(x.mdot(V), ref, rtol=0, atol=1e-13 * max(n, 16))
 
 
+@pytest.mark.parametrize("nv", [96, 97, 200])
+def test_mdot_wider_than_one_panel(ctx, nv):
+    """The reference's mdot has no limit on the number of vectors (src/ParOptVec.cpp:152-170); one kernel launch
+    takes 96 columns, wider calls are processed in slabs behind the same entry point."""
+    n = 1237
+    x = hvec(ctx, n, 10)
+    V = [hvec(ctx, n, 20 + j) for j in range(nv)]
+    xn = hnp(n, 10)
+    ref = np.array([np.dot(xn, hnp(n, 20 + j)) for j in range(nv)])
+    np.testing.assert_allclose(x.mdot(V), ref, rtol=0, atol=1e-13 * n)
+
+
 def test_elementwise_bit_exact(ctx):
     import paropt_amd as pa
 
