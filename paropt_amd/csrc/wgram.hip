@@ -257,7 +257,7 @@ constexpr int kGramDepth = 3;  // tiles a producer keeps in flight
 
 // PAROPT_AMD_WGRAM_ABLATE=16: cycle stamps of workgroup 0 (s_memtime), read by po_debug_wgram_stamps:
 // [0] consumer barrier wait, [1] consumer matrix work, [2] producer staging (incl. the wait for its loads),
-// [3] producer load issue, [4] producer barrier wait, [5] tiles
+// [3] producer load issue, [4] producer barrier wait, [5] tiles, [6] / [7] s_memtime / s_memrealtime ticks of the loop
 __device__ unsigned long long g_wgram_stamp[8];
 
 template <int NG, int ZP>
@@ -354,6 +354,8 @@ __global__ void __launch_bounds__(512, 1)
     // step `it` (ring slot it % 3, LDS buffer it % 2): stage tile `it`, reload the slot with tile it + 3, barrier
     unsigned long long st_stage = 0, st_load = 0, st_wait = 0;
     const bool stamp = (ablate == 16) && blockIdx.x == 0 && wave == 4;
+    const unsigned long long st_c0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long st_r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PO_PC_STEP(R)                                                                                         \
   if (it + (R) < nt) {                                                                                        \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
@@ -383,6 +385,8 @@ __global__ void __launch_bounds__(512, 1)
       g_wgram_stamp[3] = st_load;
       g_wgram_stamp[4] = st_wait;
       g_wgram_stamp[5] = (unsigned long long)nt;
+      g_wgram_stamp[6] = __builtin_amdgcn_s_memtime() - st_c0;      // shader-clock ticks of the whole loop
+      g_wgram_stamp[7] = __builtin_amdgcn_s_memrealtime() - st_r0;  // 100 MHz ticks of the whole loop
     }
     __syncthreads();  // matches the consumers' trailing barrier
   } else {
