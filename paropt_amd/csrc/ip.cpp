@@ -401,8 +401,7 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       zc = vars.z;
     }
     if (has_w) {  // + Aw^T zw as one more panel column (:1358-1361)
-      PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
-      if (prob->addSparseJacobianTranspose(1.0, x, wvar[0], tvec) != 0) return PO_ERR_USER;
+      if (prob->setSparseJacobianTranspose(1.0, x, wvar[0], tvec) != 0) return PO_ERR_USER;
       A.push_back(tvec->d);
       zc.push_back(1.0);
     }
@@ -934,8 +933,7 @@ int InteriorPoint::checkKKTStep(int iteration, double mu) {
     }
   }
   if (has_w) {  // the sparse multiplier step enters r'x through Aw^T pzw: one more column
-    PO_TRY(k_fill(ctx, xt->d, n, 0.0));
-    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
+    if (prob->setSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
     Pq.push_back(xt->d);
     coef.push_back(1.0);
   }

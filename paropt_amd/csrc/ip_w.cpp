@@ -194,14 +194,12 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
     PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
     PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
-    PO_TRY(k_fill(ctx, d1v->d, n, 0.0));
-    if (prob->addSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     // sparse blocks of the step first: pzw = wstepv[0] feeds the residual column Aw^T pzw (its minima wait for
     // those of the design blocks unless user code runs in between)
     if (prob->reductionsBatchable()) minbatch.begin();
     PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, 0, tau, wp(), nw, mins_w));
-    PO_TRY(k_fill(ctx, xt->d, n, 0.0));
-    if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
+    if (prob->setSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
     std::vector<const double *> P1(P);
     std::vector<double> a1(alpha.begin(), alpha.begin() + m), c2(m + 2, 0.0);
     P1.push_back(d1v->d);
@@ -236,8 +234,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
     PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
     PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
-    PO_TRY(k_fill(ctx, d1v->d, n, 0.0));
-    if (prob->addSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     std::vector<const double *> P1(P);
     std::vector<double> a1(alpha.begin(), alpha.begin() + m);
     P1.push_back(d1v->d);
@@ -309,8 +306,7 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
     // addKKTResStep (:1451-1583): design rows with the extra column Aw^T pzw, raw d1' into d1v (already there
     // when the first solve ran in its fused form)
     if (!(it == 0 && residual_fused)) {
-      PO_TRY(k_fill(ctx, tvec->d, n, 0.0));
-      if (prob->addSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
+      if (prob->setSparseJacobianTranspose(1.0, x, wstepv[0], tvec) != 0) return PO_ERR_USER;
       Pq.push_back(tvec->d);
       coef[mres++] = 1.0;
       PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),

@@ -50,6 +50,9 @@ class Problem {
   virtual int evalSparseCon(Vec *x, Vec *out);
   virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out);
   virtual int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
+  // out <- alpha Aw(x)^T pzw (overwrites): by default a zero fill followed by the call above; a problem that can
+  // write every entry in one pass overrides it
+  virtual int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
   virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A);
   // U_j = Aw (d o P_j) for a whole panel; the default goes column by column through
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
@@ -156,6 +159,7 @@ class SeparableProblem : public Problem {
   int evalSparseCon(Vec *x, Vec *out) override;
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
+  int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;

@@ -79,6 +79,10 @@ int Problem::addSparseJacobian(double alpha, Vec *, Vec *px, Vec *out) {  // .cp
   if (!csr) return 0;
   return csr->spmv(alpha, px->d, out->d) != PO_OK;
 }
+int Problem::setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  PO_TRY(k_fill(ctx, out->d, out->n, 0.0));
+  return addSparseJacobianTranspose(alpha, x, pzw, out) != 0 ? PO_ERR_USER : PO_OK;
+}
 int Problem::addSparseJacobianTranspose(double alpha, Vec *, Vec *pzw, Vec *out) {  // .cpp:790-816
   if (!csr) return 0;
   return csr->spmvT(alpha, pzw->d, out->d) != PO_OK;
@@ -464,6 +468,10 @@ int SeparableProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out)
 int SeparableProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
   if (csr) return Problem::addSparseJacobianTranspose(alpha, x, pzw, out);
   return k_group_scatter(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
+}
+int SeparableProblem::setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  if (csr) return Problem::setSparseJacobianTranspose(alpha, x, pzw, out);
+  return k_group_scatter_set(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
 }
 int SeparableProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
   if (csr) return Problem::addSparseInnerProduct(alpha, x, cvec, A);

@@ -82,6 +82,9 @@ class TrustRegionSubproblem : public Problem {
   int evalSparseCon(Vec *step, Vec *out) override;
   int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
+  int setSparseJacobianTranspose(double alpha, Vec *, Vec *pzw, Vec *out) override {
+    return prob->setSparseJacobianTranspose(alpha, xk, pzw, out);
+  }
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                           Vec *work) override;
@@ -177,6 +180,9 @@ class InfeasSubproblem : public Problem {  // :468-650
   }
   int addSparseJacobianTranspose(double a, Vec *x, Vec *pzw, Vec *out) override {
     return sub->addSparseJacobianTranspose(a, x, pzw, out);
+  }
+  int setSparseJacobianTranspose(double a, Vec *x, Vec *pzw, Vec *out) override {
+    return sub->setSparseJacobianTranspose(a, x, pzw, out);
   }
   int addSparseInnerProduct(double a, Vec *x, Vec *cvec, Vec *A) override {
     return sub->addSparseInnerProduct(a, x, cvec, A);

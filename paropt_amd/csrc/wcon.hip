@@ -179,6 +179,28 @@ int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const 
   PO_WLAUNCH(group_scatter_kernel, wgrid(c, n), m, out, alpha, w, n);
   return PO_OK;
 }
+// out[g] = alpha * w[i(g)] for the variables of a group, 0 elsewhere: "fill with zero, then scatter" in one pass
+// that never reads `out` (0 + alpha w = alpha w exactly)
+__global__ void __launch_bounds__(kBlock)
+    group_scatter_set_kernel(GroupMap m, double *__restrict__ out, double alpha, const double *__restrict__ w,
+                             int64_t n) {
+  const int64_t period = m.nw + m.skip;
+  PO_W_LOOP(g, n) {
+    const int64_t r = g - m.start;
+    double v = 0.0;
+    if (r >= 0) {
+      const int64_t i = r / period;
+      if (i < m.nwcon && (r - i * period) < m.nw) v = __dadd_rn(0.0, __dmul_rn(alpha, w[i]));
+    }
+    out[g] = v;
+  }
+}
+int k_group_scatter_set(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n) {
+  if (n <= 0) return PO_OK;
+  if (m.nwcon <= 0) return k_fill(c, out, n, 0.0);
+  PO_WLAUNCH(group_scatter_set_kernel, wgrid(c, n), m, out, alpha, w, n);
+  return PO_OK;
+}
 // U_j[i] = alpha * sum_k d[g] * P_j[g] over the group of constraint i, for all panel columns at once
 // (fallback for groups wider than a tile: one thread per constraint)
 __global__ void __launch_bounds__(kBlock)

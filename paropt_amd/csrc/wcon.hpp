@@ -22,6 +22,8 @@ struct GroupMap {
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
                 const double *v);
 int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n);
+// the same with `out` overwritten (zero outside the groups): no separate fill pass
+int k_group_scatter_set(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n);
 int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, const double *d,
                   double alpha, double *const *U);
 
