@@ -2,11 +2,18 @@
 """
 bench.py -- IP iterations/sec of the MI355X-native interior point on BASELINE.json's metric
 configuration (config 3: separable random_convex, n = 50 M design variables, m = 32 dense
-constraints + bounds, L-SR1(10) Hessian), plus the HBM roofline of the headline kernel
-(ParOptVec::mdot over the 32-column dense-constraint panel), a second roofline entry for the
-weighted-Gram kernel, same-run stream ceilings and a CPU baseline.
+constraints + bounds, L-SR1(10) Hessian), the HBM roofline of the headline kernel
+(ParOptVec::mdot over the 32-column dense-constraint panel) and of the whole iteration, a second
+roofline entry for the weighted-Gram kernel, same-run stream ceilings and a CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--boundary builtin|facade|both]
+
+`value` is measured under the REFERENCE's problem contract (src/ParOptProblem.h:146-189): the gradient callback
+rewrites the whole constraint Jacobian at every call.  The variant with the library's opt-in declaration that the
+dense constraints are linear (po_problem_set_linear_constraints, an EXTENSION of the reference API) is reported
+beside it under `variants`, never as `value`.  --boundary facade makes `value` the same workload implemented as a
+USER's ParOptProblem subclass outside the library (examples/random_convex_amd.cpp on include/ParOptAMD.hpp); the
+default run reports that measurement under `boundary`.
 
 N = 1 runs in this process.  N > 1 without WORLD_SIZE in the environment: this script starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py` as a CHILD process
@@ -21,6 +28,7 @@ iterations are bracketed by barrier + stream sync on both sides, max over ranks;
 median over R repeats (min / max beside it).
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -37,43 +45,133 @@ NCON = 32
 QN_SIZE = 10
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (spec); the measured sustained rate is in profiles/
+USER_LIB = os.path.join(ROOT, "examples", "librandom_convex_user.so")
 
 
-def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, problem="convex"):
-    """Reference (oracle/_ref/ref_driver, the unmodified C++ reference + MKL under MPICH) timed on
-    this box's host cores on a bounded sample; falls back to the numpy restatement."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------
+def host_cpu_budget():
+    """Cores this process may really use: scheduler affinity, capped by the cgroup CPU quota (v2 cpu.max or v1
+    cfs quota) -- os.cpu_count() ignores both, and oversubscribed busy-polling MPI ranks are 5x slower."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["affinity"] = info["os_cpu_count"]
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            a, b = f.read().split()
+            if a != "max":
+                quota = float(a) / float(b)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = float(f.read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    info["cgroup_quota_cpus"] = quota
+    usable = info["affinity"]
+    if quota is not None:
+        usable = max(1, min(usable, int(quota)))
+    info["usable"] = usable
+    try:
+        info["loadavg_1min"] = os.getloadavg()[0]
+    except Exception:
+        info["loadavg_1min"] = None
+    return info
+
+
+def reference_traffic_bytes(n, c, k):
+    """Bytes one iteration of the REFERENCE's operation sequence moves at quasi-Newton width k (SURVEY.md 3.4/8d,
+    validated there against the compiled reference): 8 n (332 + 48 c + c^2 + 45 k + 5 c k + 2 k^2)."""
+    return 8.0 * n * (332 + 48 * c + c * c + 45 * k + 5 * c * k + 2 * k * k)
+
+
+def run_reference(drv, mpiexec, ranks, n, ncon, iters, qn, qn_size, problem, nwcon, nw, timeout):
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1",
+               PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
+    cmd = [mpiexec, "-n", str(ranks), drv, "bench", "problem=%s" % problem, "n=%d" % n, "c=%d" % ncon,
+           "opt.qn_type=%s" % qn, "opt.qn_subspace_size=%d" % qn_size, "opt.abs_res_tol=1e-30",
+           "opt.start_affine_multiplier_min=0.01", "opt.max_major_iters=%d" % iters,
+           "opt.write_output_frequency=0"]
+    if nwcon > 0:
+        cmd += ["nwcon=%d" % (nwcon // ranks), "nw=%d" % nw, "nwstart=0", "nwskip=0"]
+    t0 = time.time()
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd="/tmp")
+    wall = time.time() - t0
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            r = json.loads(ln)
+            return r["niter"], r["seconds"], wall, None
+    return 0, 0.0, wall, out.stderr[-400:]
+
+
+def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, problem="convex", budget_s=60.0):
+    """The unmodified reference (oracle/_ref/ref_driver: the reference's C++ + MKL under MPICH) timed on this box's
+    host cores on a BOUNDED sample of the workload: a small probe first (n/25), then the largest n <= workload n / 4
+    whose predicted time fits the budget; every pass of the reference is O(n) and memory-bound at these sizes, so
+    the rate is scaled linearly to the workload's n (said in `sample`).  Falls back to the numpy restatement."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     mpiexec = "/opt/conda/bin/mpiexec"
-    ncpu = os.cpu_count() or 1
+    cpus = host_cpu_budget()
     if os.path.exists(drv) and os.path.exists(mpiexec):
-        ranks = max(1, min(64, ncpu // 2 if ncpu >= 4 else ncpu))
-        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1",
-                   PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
-        cmd = [mpiexec, "-n", str(ranks), drv, "bench", "problem=%s" % problem, "n=%d" % n, "c=%d" % ncon,
-               "opt.qn_type=%s" % qn, "opt.qn_subspace_size=%d" % qn_size, "opt.abs_res_tol=1e-30",
-               "opt.start_affine_multiplier_min=0.01", "opt.max_major_iters=%d" % iters,
-               "opt.write_output_frequency=0"]
+        ranks = max(1, min(64, cpus["usable"]))
         if nwcon > 0:
             # the driver's weighting groups are rank-local (as in examples/rosenbrock): pick a rank count
             # whose shards hold whole groups so that the sharded problem IS the global one
             while ranks > 1 and (n % ranks or (n // ranks) % nw or nwcon % ranks):
                 ranks -= 1
-            cmd[2] = str(ranks)
-            cmd += ["nwcon=%d" % (nwcon // ranks), "nw=%d" % nw, "nwstart=0", "nwskip=0"]
         try:
-            t0 = time.time()
-            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd="/tmp")
-            for ln in out.stdout.splitlines():
-                if ln.startswith("{"):
-                    r = json.loads(ln)
-                    return {"value": r["niter"] / r["seconds"], "unit": "IP iterations/s", "cores": ranks,
-                            "kind": "reference", "steady_state": False,
-                            "sample": "unmodified reference (MPICH ranks x MKL seq), same problem at n=%d, "
-                                      "first %d iterations (quasi-Newton memory ramping 0->%d: cheaper than "
-                                      "steady-state iterations, so the GPU/CPU ratio is conservative), optimize() "
-                                      "only; wall incl. launch %.1fs" % (n, r["niter"], min(r["niter"], qn_size),
-                                                                         time.time() - t0)}
-            log("cpu_baseline: reference produced no result: %s" % (out.stderr[-400:],))
+            t_start = time.time()
+            samples = []
+            n_probe = max(200_000, n // 25) if nwcon == 0 else n
+            niter, secs, wall, err = run_reference(drv, mpiexec, ranks, n_probe, ncon, iters, qn, qn_size, problem,
+                                                   nwcon * n_probe // n if nwcon else 0, nw, 600)
+            if niter <= 0:
+                log("cpu_baseline: reference produced no result: %s" % (err,))
+                raise RuntimeError("no result")
+            samples.append((n_probe, niter, secs, wall))
+            # scale up while the prediction fits what is left of the budget (launch overhead excluded)
+            n_big = n // 4 if (n >= 20_000_000 and nwcon == 0) else n
+            if n_big > n_probe:
+                per_elem = secs / n_probe
+                left = budget_s - (time.time() - t_start)
+                n_fit = int(min(n_big, 0.8 * left / per_elem)) if per_elem > 0 else n_big
+                if n_fit >= 2 * n_probe:
+                    niter2, secs2, wall2, err2 = run_reference(drv, mpiexec, ranks, n_fit, ncon, iters, qn, qn_size,
+                                                               problem, 0, nw, 900)
+                    if niter2 > 0:
+                        samples.append((n_fit, niter2, secs2, wall2))
+            n_s, it_s, sec_s, wall_s = samples[-1]
+            rate_at_sample = it_s / sec_s
+            kw = [min(i, qn_size) * (2 if qn == "bfgs" else 1) for i in range(it_s)]
+            traffic = sum(reference_traffic_bytes(n_s, ncon, k) for k in kw)
+            res = {"value": rate_at_sample * n_s / float(n), "unit": "IP iterations/s", "cores": ranks,
+                   "kind": "reference", "steady_state": False,
+                   "sample_n": n_s, "sample_iterations": it_s, "sample_seconds": sec_s,
+                   "seconds_per_iteration_at_sample_n": sec_s / it_s,
+                   "implied_host_GBps": traffic / sec_s * 1e-9,
+                   "host": cpus, "wall_s_incl_launch": time.time() - t_start,
+                   "probes": [{"n": a, "iterations": b, "seconds": c, "wall_s": d} for a, b, c, d in samples],
+                   "sample": "unmodified reference (%d MPICH ranks x sequential MKL; ranks = cores this process may use: "
+                             "affinity %d, cgroup quota %s, os.cpu_count %d), same problem at n=%d, first %d iterations "
+                             "(quasi-Newton memory ramping 0->%d: cheaper than steady-state iterations, so the GPU/CPU "
+                             "ratio is conservative), optimize() only; every reference pass is O(n) and memory-bound, "
+                             "the rate is scaled by %d/%d to the workload's n; implied_host_GBps = the reference "
+                             "sequence's traffic model (SURVEY 3.4) / seconds: far below the host's stream bandwidth "
+                             "means oversubscribed or throttled cores" % (
+                                 ranks, cpus["affinity"], cpus["cgroup_quota_cpus"], cpus["os_cpu_count"], n_s, it_s,
+                                 min(it_s, qn_size), n_s, n)}
+            if len(samples) > 1:
+                a, b = samples[0], samples[1]
+                res["probe_consistency"] = (b[2] / b[1] / b[0]) / (a[2] / a[1] / a[0])  # s/iter/elt ratio, ~1
+            return res
         except Exception as e:  # pragma: no cover
             log("cpu_baseline: reference failed: %r" % (e,))
     # numpy restatement ("port"), single core, smaller sample
@@ -88,7 +186,7 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
     ip.optimize()
     dt = time.time() - t0
     return {"value": ip.niter / dt * (ns / float(n)), "unit": "IP iterations/s", "cores": 1, "kind": "port",
-            "steady_state": False,
+            "steady_state": False, "host": cpus,
             "sample": "numpy oracle, n=%d, %d iterations, rate scaled linearly to n=%d" % (ns, ip.niter, n)}
 
 
@@ -107,14 +205,16 @@ def parse_args(argv=None):
     ap.add_argument("--nwcon", type=int, default=0,
                     help="config 4: number of sparse weighting constraints (one per group of --nw variables)")
     ap.add_argument("--nw", type=int, default=20)
+    ap.add_argument("--boundary", type=str, default="both", choices=["builtin", "facade", "both"],
+                    help="builtin: the library's own SeparableProblem; facade: the same workload as a user's "
+                         "ParOptProblem subclass outside the library (examples/random_convex_amd.cpp), which then "
+                         "is `value`; both (default): `value` from the built-in, the facade measurement under "
+                         "`boundary`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=0, help="n of the CPU sample (default: --nglobal)")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take")
     ap.add_argument("--cpu-iters", type=int, default=6)
-    ap.add_argument("--no-constant-jacobian", action="store_true",
-                    help="only measure the variant whose gradient callback rewrites the (constant) constraint "
-                         "Jacobian at every call, as the reference's example problems do")
-    ap.add_argument("--skip-copy-variant", action="store_true",
-                    help="do not also measure the Jacobian-rewriting variant beside the headline")
+    ap.add_argument("--skip-extension-variant", action="store_true",
+                    help="do not also measure the linear-constraint declaration (API extension) beside the headline")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N>1: continue on a torch.distributed callback if the native RCCL communicator fails "
                          "(default: exit non-zero)")
@@ -215,7 +315,9 @@ def main():
         comm_kind = "gloo callback (shared-GPU test mode)"
     elif world > 1:
         try:
-            ctx.init_rccl_from_torch()  # native ncclAllReduce / ncclAllGather on the solver's own stream
+            # native ncclAllReduce / ncclAllGather on the solver's own stream; po_ctx_comm_init_rccl runs
+            # known-answer collectives (sum of rank+1, rank order, SUM/MIN/MAX) before it returns
+            ctx.init_rccl_from_torch()
             comm_kind = "rccl"
         except Exception as e:
             if not a.allow_fallback:
@@ -240,68 +342,127 @@ def main():
     # the driver passes --warmup 5: the timed window must not start while the quasi-Newton memory is still
     # filling (iterations get more expensive until it is full), so the warmup is at least qn_size + 2
     W = max(a.warmup, a.qn_size + 2)
-    prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
-    if a.nwcon > 0:
-        prob.setWeighting(a.nwcon, a.nw, 0, 0)
     opts = {"qn_type": a.qn, "qn_subspace_size": a.qn_size, "abs_res_tol": 1e-30,
             "start_affine_multiplier_min": 0.01, "max_major_iters": W + K, "write_output_frequency": 0}
-    ip = pa.InteriorPoint(prob, opts)
-    stamp = {}
 
-    def cb(k):
-        if k == W:
+    def measure(prob, own_bytes=None):
+        """R optimize() runs on `prob`; returns (median seconds of the K timed iterations, sorted times, details of
+        the median run, all runs)."""
+        ip = pa.InteriorPoint(prob, opts)
+        stamp = {}
+
+        def cb(k):
+            if k == W:
+                barrier_sync()
+                stamp["counters0"] = ctx.counters()
+                stamp["bytes0"] = ctx.algorithmic_bytes()
+                stamp["own0"] = own_bytes() if own_bytes else 0.0
+                ctx.time_mdot(a.ncon)  # HIP events around every mdot<ncon> launch of the timed region
+                ctx.time_wgram(True)
+                stamp["t0"] = time.perf_counter()
+
+        ip.setIterationCallback(cb)
+
+        def one_run():
+            ip.resetQuasiNewtonHessian()
             barrier_sync()
-            stamp["counters0"] = ctx.counters()
-            ctx.time_mdot(a.ncon)  # HIP events around every mdot<ncon> launch of the timed region
-            ctx.time_wgram(True)
-            stamp["t0"] = time.perf_counter()
+            ip.optimize()
+            barrier_sync()
+            t1 = time.perf_counter()
+            elapsed = t1 - stamp["t0"]
+            red1, lau1 = ctx.counters()
+            by1 = ctx.algorithmic_bytes()
+            own1 = own_bytes() if own_bytes else 0.0
+            mdot_ms, mdot_n = ctx.time_mdot_result()
+            wg = [ctx.time_wgram_result(w) for w in (0, 1)]
+            ctx.time_mdot(0)
+            ctx.time_wgram(False)
+            if dist is not None:
+                t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            niter, neval, ngeval = ip.getIterationCounters()
+            assert niter == W + K, (niter, W, K)
+            own = own1 - stamp["own0"]
+            return elapsed, dict(red=(red1 - stamp["counters0"][0]) / float(K),
+                                 launches=(lau1 - stamp["counters0"][1]) / float(K), mdot_ms=mdot_ms, mdot_n=mdot_n,
+                                 wgram=wg, niter=niter, neval=neval, phases=ip.getPhaseTimes(),
+                                 bytes_total=(by1[0] - stamp["bytes0"][0] + own) / float(K),
+                                 bytes_user=(by1[1] - stamp["bytes0"][1] + own) / float(K))
 
-    ip.setIterationCallback(cb)
-
-    def one_run():
-        """One optimize() of W + K iterations; returns (seconds of the K timed iterations, details)."""
-        ip.resetQuasiNewtonHessian()
-        barrier_sync()
-        ip.optimize()
-        barrier_sync()
-        t1 = time.perf_counter()
-        elapsed = t1 - stamp["t0"]
-        red1, lau1 = ctx.counters()
-        mdot_ms, mdot_n = ctx.time_mdot_result()
-        wg = [ctx.time_wgram_result(w) for w in (0, 1)]
-        ctx.time_mdot(0)
-        ctx.time_wgram(False)
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        niter, neval, ngeval = ip.getIterationCounters()
-        assert niter == W + K, (niter, W, K)
-        return elapsed, dict(red=(red1 - stamp["counters0"][0]) / float(K),
-                             launches=(lau1 - stamp["counters0"][1]) / float(K), mdot_ms=mdot_ms, mdot_n=mdot_n,
-                             wgram=wg, niter=niter, neval=neval, phases=ip.getPhaseTimes())
-
-    def measure(constant_jacobian):
-        prob.setLinearConstraints(constant_jacobian)
         runs = [one_run() for _ in range(max(1, a.repeats))]
         times = sorted(r[0] for r in runs)
         med = statistics.median(times)
         det = min(runs, key=lambda r: abs(r[0] - med))[1]
+        ip.setIterationCallback(lambda k: None)  # break the cycle ip -> callback -> ip: the solver's vectors
+        del ip                                   # (tens of GB at the full size) are freed before the next variant
+        gc.collect()
         return med, times, det, runs
 
+    def summary(v):
+        """Per-variant numbers of the line: rate, host syncs, launches and the iteration-level roofline."""
+        med, times, det, runs = v
+        ms = 1e3 * med / K
+        user_ms = 1e3 * det["phases"].get("user_eval", 0.0) / det["niter"]
+        lib_bytes = det["bytes_total"] - det["bytes_user"]
+        lib_ms = ms - user_ms
+        return {"value": K / med, "ms_per_step": ms, "ms_per_step_min": 1e3 * times[0] / K,
+                "ms_per_step_max": 1e3 * times[-1] / K, "user_eval_ms_per_iter": user_ms,
+                "host_syncs_per_iter": det["red"], "launches_per_iter": det["launches"],
+                "iteration_bytes": det["bytes_total"], "iteration_bytes_user_callbacks": det["bytes_user"],
+                "iteration_frac": det["bytes_total"] / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS,
+                "iteration_frac_excl_user_callbacks":
+                    (lib_bytes / (lib_ms * 1e-3) * 1e-9 / HBM_PEAK_GBPS) if lib_ms > 0 else None}
+
+    # ---- the built-in problem: reference contract first (headline), the API extension beside it ----
     variants = {}
-    if not a.no_constant_jacobian:
-        variants["constant_jacobian"] = measure(True)
-    if a.no_constant_jacobian or not a.skip_copy_variant:
-        variants["jacobian_rewritten_every_gradient_call"] = measure(False)
-    head = "constant_jacobian" if "constant_jacobian" in variants else "jacobian_rewritten_every_gradient_call"
+    prob = pa.SeparableProblem(ctx, a.problem, a.n, a.ncon, 0)
+    nl, offset = prob.nvars, prob.offset
+    if a.nwcon > 0:
+        prob.setWeighting(a.nwcon, a.nw, 0, 0)
+    if a.boundary != "facade":
+        prob.setLinearConstraints(False)
+        variants["jacobian_rewritten_every_gradient_call"] = measure(prob)
+        if not a.skip_extension_variant:
+            prob.setLinearConstraints(True)
+            variants["linear_constraints_declared__API_EXTENSION"] = measure(prob)
+            prob.setLinearConstraints(False)
+    del prob
+    gc.collect()
+
+    # ---- the same workload through the user-side boundary (facade) ----
+    boundary = None
+    facade_ok = a.problem == "convex" and a.nwcon == 0 and os.path.exists(USER_LIB)
+    if a.boundary in ("facade", "both"):
+        if not facade_ok:
+            msg = "the facade workload is config 3 (convex, no sparse constraints) and needs %s" % USER_LIB
+            if a.boundary == "facade":
+                log("error: " + msg)
+                sys.exit(5)
+            log("skipping the facade measurement: " + msg)
+        else:
+            up = pa.UserLibraryProblem(ctx, USER_LIB, a.n, a.ncon)
+            fac = {"reference_semantics": measure(up, lambda: up.ownKernelBytes(True))}
+            up.setDeferredReductions(True)
+            fac["deferred_reductions__API_EXTENSION"] = measure(up, lambda: up.ownKernelBytes(True))
+            up.close()
+            boundary = {"what": "the workload as a USER ParOptProblem subclass on include/ParOptAMD.hpp, compiled outside "
+                                "libparopt_amd.so with its own HIP kernels (examples/random_convex_amd.cpp); "
+                                "evalObjConGradient rewrites the Jacobian at every call; reference_semantics: every "
+                                "reduction of the callbacks returns its value immediately; deferred_reductions: the "
+                                "opt-in of po_problem_set_deferred_reductions",
+                        **{k: summary(v) for k, v in fac.items()}}
+            if a.boundary == "facade":
+                variants = {"facade_reference_semantics": fac["reference_semantics"],
+                            "facade_deferred_reductions__API_EXTENSION": fac["deferred_reductions__API_EXTENSION"]}
+    head = next(iter(variants))
     elapsed, times, det, runs = variants[head]
+    all_runs = [r for v in variants.values() for r in v[3]]
 
     # ---- roofline of the headline kernel, measured live with HIP events on the context stream ----
-    nl = prob.nvars
-    x = pa.PVec(ctx, nl).fill_hash(1, 10, prob.offset, 2.0, -1.0)
+    x = pa.PVec(ctx, nl).fill_hash(1, 10, offset, 2.0, -1.0)
     # the dense-constraint panel the solver itself streams: fresh hash vectors of the same shape
-    V = [pa.PVec(ctx, nl).fill_hash(1, 20 + j, prob.offset, 2.0, -1.0) for j in range(a.ncon)]
+    V = [pa.PVec(ctx, nl).fill_hash(1, 20 + j, offset, 2.0, -1.0) for j in range(a.ncon)]
     ms_isolated, _ = pa.bench_mdot(x, V, 20)
     # same-run stream ceilings: what a read-only stream and a copy reach on this box right now
     ms_ro = pa.bench_stream(x, V[0], 0, 20)
@@ -309,15 +470,15 @@ def main():
     stream = {"read_only_GBps": 16.0 * nl / (ms_ro * 1e-3) * 1e-9, "copy_GBps": 16.0 * nl / (ms_cp * 1e-3) * 1e-9,
               "what": "x.y over two %d-element vectors (read-only) and y <- x (copy), 20 launches each, "
                       "HIP events on the solver's stream, same process as the timed run" % nl}
-    # the figure of record: the mdot<ncon> launches the solver itself issued in the timed regions (the constraint
-    # evaluations of the line search), HIP events on the launch stream; the isolated loop is kept beside it
-    mdot_ms_run = sum(r[1]["mdot_ms"] for r in runs)
-    mdot_launches_run = sum(r[1]["mdot_n"] for r in runs)
+    # the figure of record: the mdot<ncon> launches issued in the timed regions (the constraint evaluations of the
+    # line search: the problem's own ParOptVec::mdot calls), HIP events on the launch stream
+    mdot_ms_run = sum(r[1]["mdot_ms"] for r in all_runs)
+    mdot_launches_run = sum(r[1]["mdot_n"] for r in all_runs)
     ms = mdot_ms_run / mdot_launches_run if mdot_launches_run > 0 else ms_isolated
     alg_bytes = 8.0 * (a.ncon + 1) * nl
     achieved = alg_bytes / (ms * 1e-3) * 1e-9
     traffic, traffic_src = None, None
-    for fn in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    for fn in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         try:  # PMC bytes per launch from committed rocprofv3 passes (NOT measured in this run), this exact shape
             pm = json.load(open(os.path.join(ROOT, "profiles", fn)))
             if pm["n"] == nl and a.ncon == 32:
@@ -336,11 +497,11 @@ def main():
     # second entry: the weighted Gram (the only MFMA kernel), HBM and MFMA fractions of the in-run launches
     second = None
     for w in (1, 0):
-        wms = sum(r[1]["wgram"][w][0] for r in runs)
-        wn = sum(r[1]["wgram"][w][1] for r in runs)
+        wms = sum(r[1]["wgram"][w][0] for r in all_runs)
+        wn = sum(r[1]["wgram"][w][1] for r in all_runs)
         if wn > 0:
-            cols = runs[0][1]["wgram"][w][2]
-            wbytes = sum(r[1]["wgram"][w][3] for r in runs) / wn
+            cols = all_runs[0][1]["wgram"][w][2]
+            wbytes = sum(r[1]["wgram"][w][3] for r in all_runs) / wn
             avg = wms / wn
             flops = float(cols) * (cols + 1) * nl  # useful flops of the symmetric product
             second = {"kernel": "wgram_kernel (W = P^T diag(Dinv) P, %d columns%s)" % (
@@ -354,20 +515,23 @@ def main():
             break
     roofline["second"] = second
 
+    # ---- N > 1: what one reduction exchange costs on this communicator (the iteration pays host_syncs_per_iter
+    # of them), in the two forms the solver uses ----
+    collective = None
+    if world > 1:
+        collective = {"allreduce_2628_doubles": ctx.bench_collective(2628, True, 50),
+                      "allgather_16_doubles": ctx.bench_collective(16, False, 50),
+                      "what": "final-stage payload -> collective -> device-to-host copy -> host sync, median of 50 "
+                              "(po_ctx_bench_collective); 2628 doubles = the Gram payload at c + k = 72"}
+
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline and world == 1:
-            # bounded sample (about half a minute of host time): a quarter of the rows of a large workload, the rate
-            # scaled back linearly in n -- every pass of the reference is O(n) and memory-bound at these sizes
-            cpu_n = a.cpu_n or (a.n // 4 if a.n >= 20_000_000 and a.nwcon == 0 else a.n)
-            cpu = cpu_baseline(cpu_n, a.ncon, a.cpu_iters, log, a.nwcon * cpu_n // a.n, a.nw, a.qn, a.qn_size,
-                               a.problem)
-            if cpu and cpu_n != a.n and cpu.get("kind") == "reference":
-                cpu["value"] *= cpu_n / float(a.n)
-                cpu["sample"] += "; measured at n=%d, rate scaled by %d/%d to the workload's n (O(n) passes)" % (
-                    cpu_n, cpu_n, a.n)
+            cpu = cpu_baseline(a.n, a.ncon, a.cpu_iters, log, a.nwcon, a.nw, a.qn, a.qn_size, a.problem, a.cpu_budget)
         niter = det["niter"]
         kind, nred, ngat = ctx.comm_info()
+        head_sum = summary(variants[head])
+        k_full = a.qn_size * (2 if a.qn == "bfgs" else 1)
         res = {
             "metric": "IP iterations/sec (KKT solve+line search), n=%s vars m=%d, 1/2/4/8 GPUs" % (
                 ("%dM" % (a.n // 1000000)) if a.n % 1000000 == 0 else str(a.n), a.ncon),
@@ -391,19 +555,34 @@ def main():
                                        ("config 4 (+%d weighting constraints on groups of %d)" % (a.nwcon, a.nw))
                                        if a.nwcon > 0 else ("config 3" if a.problem == "convex" else "config 2"),
                                        a.problem, a.n, a.ncon, a.qn.upper(), a.qn_size, world),
-                       "n_global": a.n, "ncon": a.ncon, "nwcon": a.nwcon, "qn": a.qn,
+                       "n_global": a.n, "n_local": nl, "ncon": a.ncon, "nwcon": a.nwcon, "qn": a.qn,
                        "evals_per_iter": (det["neval"] - 1) / float(niter),
                        "collective": comm_kind, "reductions_per_iter": det["red"],
                        "launches_per_iter": det["launches"],
                        "rccl_allreduce_calls": nred, "rccl_allgather_calls": ngat,
-                       "constraint_jacobian": head},
-            "variants": {k: {"value": K / v[0], "ms_per_step": 1e3 * v[0] / K,
-                             "user_eval_ms_per_iter": 1e3 * v[2]["phases"].get("user_eval", 0.0) / v[2]["niter"]}
-                         for k, v in variants.items()},
+                       "launcher": "torchrun rank" if in_job else "direct",
+                       "headline_variant": head,
+                       "problem_contract": "reference (src/ParOptProblem.h:146-189): evalObjConGradient rewrites the "
+                                           "whole constraint Jacobian at every call; `value` uses no API extension"},
+            # iteration-level roofline: algorithmic bytes of every n-sized launch of the timed
+            # iterations (each operand stream of a launch counted once: po_ctx_algorithmic_bytes; for the facade the
+            # user's own kernels by their formula) / step time / HBM peak
+            "iteration_bytes": head_sum["iteration_bytes"],
+            "iteration_bytes_user_callbacks": head_sum["iteration_bytes_user_callbacks"],
+            "iteration_frac": head_sum["iteration_frac"],
+            "iteration_frac_excl_user_callbacks": head_sum["iteration_frac_excl_user_callbacks"],
+            "iteration_bytes_models": {
+                "survey_8d_fused_model_8n(165+15c+11k)": 8.0 * nl * (165 + 15 * a.ncon + 11 * k_full),
+                "reference_sequence_8n(332+48c+c^2+45k+5ck+2k^2)": reference_traffic_bytes(nl, a.ncon, k_full),
+                "note": "the build needs fewer bytes than SURVEY 8d's fused model assumed (3 passes over the panel "
+                        "per iteration); `iteration_bytes` is what its launches actually stream"},
+            "variants": {k: summary(v) for k, v in variants.items()},
+            "boundary": boundary,
             "roofline": roofline,
+            "collective_us": collective,
             "cpu_baseline": cpu,
             "phase_ms_per_iter": {k: 1e3 * v / niter for k, v in det["phases"].items()},
-            "user_eval_ms_per_iter": 1e3 * det["phases"].get("user_eval", 0.0) / niter,
+            "user_eval_ms_per_iter": head_sum["user_eval_ms_per_iter"],
         }
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -483,6 +483,13 @@ class ParOptProblem : public ParOptBase {
     linear_constraints = flag;
     if (hprob) po_problem_set_linear_constraints(hprob, flag);
   }
+  // facade extension (po_problem_set_deferred_reductions): the callbacks take reduced values only through ParOptVec
+  // reductions / po_ctx_reduce_device and post-process them in po_ctx_after_reduce hooks; the solver may then batch
+  // them with its own reductions (one collective + host sync per step instead of one per reduction)
+  void setDeferredReductions(int flag) {
+    deferred_reductions = flag;
+    if (hprob) po_problem_set_deferred_reductions(hprob, flag);
+  }
   virtual ~ParOptProblem() {
     if (hprob) po_problem_destroy(hprob);
   }
@@ -565,6 +572,7 @@ class ParOptProblem : public ParOptBase {
         if (!(useLowerBounds() && useUpperBounds()))
           po_problem_set_var_bound_options(hprob, useLowerBounds(), useUpperBounds());
         if (linear_constraints) po_problem_set_linear_constraints(hprob, 1);
+        if (deferred_reductions) po_problem_set_deferred_reductions(hprob, 1);
       }
     }
     return hprob;
@@ -575,6 +583,7 @@ class ParOptProblem : public ParOptBase {
   po_ctx ctx;
   int nvars, ncon, ninequality, nwcon, nwinequality;
   int nwblock, linear_constraints;
+  int deferred_reductions = 0;
   po_problem hprob;
   // registers the sparse-constraint callbacks with the library; ParOptSparseProblem registers its CSR form
   virtual void attachSparse() {

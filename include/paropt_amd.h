@@ -58,6 +58,12 @@ void *po_ctx_stream(po_ctx ctx);
 /* Diagnostics: host-synchronising reductions (= collectives when there is more than one rank) and kernel launches
  * issued on this context so far. */
 int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
+/* Diagnostics: algorithmic HBM bytes of every n-sized launch issued on this context so far -- each operand stream of
+ * a launch counted once (8 n bytes), e.g. 8 (nvecs + 1) n for ParOptVec::mdot (src/ParOptVec.cpp:152-170), SURVEY.md
+ * 8d's per-kernel figures.  `user` is the part issued from inside the problem's evaluation callbacks (the built-in
+ * problems' kernels and any po_vec_* call a callback makes; a callback's own kernels are not seen).  bench.py's
+ * iteration-level roofline is (bytes of the timed iterations) / time / HBM peak. */
+int po_ctx_algorithmic_bytes(po_ctx ctx, double *total, double *user);
 /* Leak check: device vectors currently alive in this process (every ParOptVec, the panels of the quasi-Newton
  * objects, the work vectors of the solvers) and the HBM bytes behind them.  The reference's intrusive
  * reference counts (src/ParOptVec.h:28-47) are kept, so after the last decref / destroy both return to their
@@ -110,7 +116,20 @@ int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_
  * po_ctx_comm_init_rccl.  Replaces the MPI_Allreduce/Reduce/Bcast sites of SURVEY.md 2.3. */
 #define PO_RCCL_ID_BYTES 128
 int po_rccl_unique_id(void *id128);
+/* Also runs known-answer collectives over the solver's own exchange path before it returns (all-reduce of rank + 1
+ * = N (N + 1) / 2; rank order of the all-gather; SUM / MIN / MAX combine) and checks the library's version against
+ * the ABI its hand-declared prototypes assume; any mismatch is PO_ERR_COMM with the reason in po_last_error(). */
 int po_ctx_comm_init_rccl(po_ctx ctx, int rank, int size, const void *id128);
+/* version code of the loaded librccl (ncclGetVersion; 0 before the library was needed) */
+int po_rccl_version(int *version_code);
+/* MPI_Allreduce for user code on `count` host values, in place (op 0 SUM, 1 MIN, 2 MAX): what a problem's evalObjCon
+ * does with its rank-local objective parts (examples/rosenbrock/rosenbrock.cpp:103-106).  Goes through the context's
+ * communicator (RCCL or the host callback); a no-op on one rank.  Collective. */
+int po_ctx_allreduce(po_ctx ctx, double *values, int count, int op);
+/* Latency of one reduction exchange as the solver issues it (final-stage payload of `count` doubles -> collective
+ * -> device-to-host copy -> host sync), `reps` times: out_us3 = {median, min, max} host microseconds.  pure_sum != 0:
+ * the ncclAllReduce form, else the rank-ordered ncclAllGather form.  Collective. */
+int po_ctx_bench_collective(po_ctx ctx, int count, int pure_sum, int reps, double *out_us3);
 /* Host-side communicator hook: `allgather` must gather `count` doubles from every rank into
  * `out` (rank-major).  Lets a maintainer keep MPI (or gloo) underneath. */
 typedef int (*po_allgather_fn)(const double *in, double *out, int count, void *user);
@@ -296,6 +315,27 @@ int po_problem_set_chain(po_problem p, int span, int stride, int reverse_cols);
  * a problem that declares a side unused never has that side's bound multipliers formed.  Before
  * po_ip_create. */
 int po_problem_set_var_bound_options(po_problem p, int use_lower, int use_upper);
+/* Opt-in extension (not in the reference): DEFERRED REDUCTIONS for a callback problem.  By default every reduction
+ * a callback issues through this ABI returns its value immediately (one collective + host synchronisation each, the
+ * reference's MPI_Allreduce semantics).  With flag != 0 the problem promises that its evaluation callbacks
+ *   - obtain reduced values ONLY through po_vec_dot / po_vec_mdot / po_vec_norm / ... and po_ctx_reduce_device,
+ *     with result pointers that stay valid until the solver consumes them (the `fobj` / `cons` arguments of
+ *     eval_obj_con are such pointers),
+ *   - do not READ those results before returning, and put any host post-processing of them (e.g.
+ *     cons[j] = beta[j] - cons[j]) into a hook registered with po_ctx_after_reduce,
+ * so that the solver may queue them with its own reductions of the same step (the barrier sums at a line-search
+ * trial point; the next residual's norms) and pay ONE collective + host synchronisation for all of them.  The
+ * values are the same bits either way.  Outside the solver's batches the calls stay immediate. */
+int po_problem_set_deferred_reductions(po_problem p, int flag);
+/* Host work that depends on the results of reductions queued so far on this context: runs right away when nothing
+ * is queued, else when the queue is flushed (in registration order). */
+typedef void (*po_after_reduce_fn)(void *user);
+int po_ctx_after_reduce(po_ctx ctx, po_after_reduce_fn fn, void *user);
+/* Reduce `count` rank-local values that live in DEVICE memory (e.g. the last stage of a problem's own reduction
+ * kernel) across the ranks of the context: op 0 SUM, 1 MIN, 2 MAX; host_out[count] receives the result --
+ * immediately, or at the flush when the problem has deferred reductions and the solver has a batch open.  The
+ * device-side counterpart of MPI_Allreduce; ordered with the context's stream.  Collective. */
+int po_ctx_reduce_device(po_ctx ctx, const double *device_values, int count, int op, double *host_out);
 /* Declares that the DENSE constraints are linear in x (their Jacobian is constant).  The reference's contract
  * (src/ParOptProblem.h:146-158) has evalObjConGradient rewrite all ncon gradient vectors at every call; with this
  * flag the solver keeps the Jacobian of the first evaluation of each optimize() call and afterwards invokes the

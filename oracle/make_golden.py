@@ -192,6 +192,35 @@ case(
     dump_vecs_every=0,
     **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}),
 )
+# panels wider than one launch of the product's kernels (c + k > 80: blocked Gram; > 96: collapsed panel sums) --
+# the reference has no limit on the number of dense constraints or on the quasi-Newton width
+case(
+    "ip_convex_n2000_c100_bfgs10",
+    "ip",
+    problem="convex",
+    n=2000,
+    c=100,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 40}),
+)
+case(
+    "ip_quadratic_n1500_c70_bfgs10",
+    "ip",
+    problem="quadratic",
+    n=1500,
+    c=70,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 40}),
+)
+case(
+    "ip_convex_n2000_c90_sr1",
+    "ip",
+    problem="convex",
+    n=2000,
+    c=90,
+    dump_vecs_every=0,
+    **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 20}),
+)
 # config 1: examples/rosenbrock/rosenbrock.cpp with algorithm=ip, w=0
 case(
     "ip_rosenbrock_n100",

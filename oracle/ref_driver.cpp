@@ -795,7 +795,7 @@ static int mode_vecops(std::map<std::string, std::string> &A, MPI_Comm comm, int
   int64_t offset;
   shard(n, rank, size, &nlocal, &offset);
   RecFile R;
-  if (rank == 0) R.open(gets(A, "out", "vecops.rec").c_str());
+  if (rank == 0) R.open(gets(A, "out", "/tmp/vecops.rec").c_str());
   ParOptBasicVec *x = new ParOptBasicVec(comm, nlocal);
   x->incref();
   ParOptBasicVec *y = new ParOptBasicVec(comm, nlocal);
@@ -853,7 +853,7 @@ static int mode_qn(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   qn->incref();
   qn->setInitDiagonalType(diag == "yts_over_sts" ? PAROPT_YTS_OVER_STS : PAROPT_YTY_OVER_YTS);
   RecFile R;
-  if (rank == 0) R.open(gets(A, "out", "qn.rec").c_str());
+  if (rank == 0) R.open(gets(A, "out", "/tmp/qn.rec").c_str());
   R.i32s("n", (int)n);
   R.i32s("msub_max", msub);
   R.i32s("steps", steps);
@@ -977,7 +977,7 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   hook.kat_iter = (int)geti(A, "kat_iter", -1);
   hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
   if (!bench) {
-    if (rank == 0) R.open(gets(A, "out", "ip.rec").c_str());
+    if (rank == 0) R.open(gets(A, "out", "/tmp/ip.rec").c_str());
     R.stride = (int)geti(A, "vec_stride", 1);
     prob->hook = &hook;
     R.i32s("n", (int)n);
@@ -1135,7 +1135,7 @@ static int mode_tr(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   hook.rec = &R;
   hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
   if (!bench) {
-    if (rank == 0) R.open(gets(A, "out", "tr.rec").c_str());
+    if (rank == 0) R.open(gets(A, "out", "/tmp/tr.rec").c_str());
     prob->tr_hook = &hook;
     R.i32s("n", (int)n);
     R.i32s("c", c);
@@ -1222,7 +1222,7 @@ static int mode_mma(std::map<std::string, std::string> &A, MPI_Comm comm, int ra
   double t1 = MPI_Wtime();
   RecFile R;
   if (!bench) {
-    if (rank == 0) R.open(gets(A, "out", "mma.rec").c_str());
+    if (rank == 0) R.open(gets(A, "out", "/tmp/mma.rec").c_str());
     R.i32s("n", (int)n);
     R.i32s("c", c);
     int it[2] = {mma->mma_iter, mma->subproblem_iter};

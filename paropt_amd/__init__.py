@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     TrustRegion,
     EigenApprox,
     CsrSymbolic,
+    UserLibraryProblem,
     live_host_mirrors,
     live_objects,
     quasidef_factor,

@@ -91,6 +91,28 @@ class Context:
         check(lib.po_ctx_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def bench_collective(self, count, pure_sum=True, reps=50):
+        """{median, min, max} host microseconds of one reduction exchange of `count` doubles (collective)."""
+        out = (C.c_double * 3)()
+        check(lib.po_ctx_bench_collective(self._h, int(count), 1 if pure_sum else 0, int(reps), out))
+        return {"median_us": out[0], "min_us": out[1], "max_us": out[2], "count": int(count),
+                "form": "allreduce" if pure_sum else "allgather+host combine"}
+
+    def allreduce(self, values, op="sum"):
+        """MPI_Allreduce counterpart on host values (numpy float64 array, in place)."""
+        import numpy as np
+
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        check(lib.po_ctx_allreduce(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.size,
+                                   {"sum": 0, "min": 1, "max": 2}[op]))
+        return a
+
+    def algorithmic_bytes(self):
+        """(total, issued from inside problem callbacks): algorithmic HBM bytes of the n-sized launches so far."""
+        a, b = C.c_double(), C.c_double()
+        check(lib.po_ctx_algorithmic_bytes(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def init_rccl_from_torch(self):
         """One process per GPU: ship the RCCL unique id over torch.distributed, then init."""
         import torch.distributed as dist
@@ -608,6 +630,70 @@ class SeparableProblem:
         try:
             if self._h and self.ctx._h:
                 lib.po_problem_destroy(self._h)
+        except Exception:
+            pass
+
+
+class UserLibraryProblem:
+    """A ParOptProblem subclass that lives in a USER'S shared library built on include/ParOptAMD.hpp (e.g.
+    examples/librandom_convex_user.so): the library hands over the `po_problem` of its facade object, the solver
+    classes of this module drive it like any other problem.  Entry points expected from the library (extern "C"):
+    <prefix>_problem_create(ctx, nglobal, ncon, seed) -> void*, <prefix>_problem_handle(void*) -> po_problem,
+    <prefix>_problem_sizes(void*, int64*, int64*), <prefix>_problem_destroy(void*), and optionally
+    <prefix>_problem_set_linear_constraints / _set_deferred_reductions(void*, int), _own_kernel_bytes(void*, int)."""
+
+    def __init__(self, ctx, path, nglobal, ncon, seed=0, prefix="rc"):
+        self.ctx = ctx
+        self._lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        f = lambda name: getattr(self._lib, "%s_problem_%s" % (prefix, name))
+        f("create").restype = C.c_void_p
+        f("create").argtypes = [L.po_ctx, C.c_int64, C.c_int, C.c_uint64]
+        f("handle").restype = L.po_problem
+        f("handle").argtypes = [C.c_void_p]
+        f("sizes").argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        f("destroy").argtypes = [C.c_void_p]
+        self._f = f
+        self._obj = C.c_void_p(f("create")(ctx.handle, int(nglobal), int(ncon), int(seed)))
+        if not self._obj:
+            raise L.ParOptAMDError(-1, "user library failed to create its problem")
+        self._h = L.po_problem(f("handle")(self._obj))
+        nl, off = C.c_int64(), C.c_int64()
+        f("sizes")(self._obj, C.byref(nl), C.byref(off))
+        self.nvars, self.offset, self.ncon, self.nwcon = nl.value, off.value, int(ncon), 0
+
+    @property
+    def handle(self):
+        return self._h
+
+    def setLinearConstraints(self, flag=True):
+        fn = self._f("set_linear_constraints")
+        fn.argtypes = [C.c_void_p, C.c_int]
+        fn(self._obj, int(bool(flag)))
+        return self
+
+    def setDeferredReductions(self, flag=True):
+        fn = self._f("set_deferred_reductions")
+        fn.argtypes = [C.c_void_p, C.c_int]
+        fn(self._obj, int(bool(flag)))
+        return self
+
+    def ownKernelBytes(self, jacobian_rewritten=True):
+        """Algorithmic HBM bytes of the user's own kernels so far (the library cannot count them)."""
+        fn = self._f("own_kernel_bytes")
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_void_p, C.c_int]
+        return fn(self._obj, int(bool(jacobian_rewritten)))
+
+    def close(self):
+        if self._obj:
+            self._f("destroy")(self._obj)
+            self._obj = None
+            self._h = None
+
+    def __del__(self):
+        try:
+            if self.ctx._h:
+                self.close()
         except Exception:
             pass
 

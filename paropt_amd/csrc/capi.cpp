@@ -11,6 +11,9 @@ int ctx_create(int device, Ctx **out);
 int ctx_destroy(Ctx *c);
 int rccl_unique_id(void *id128);
 int comm_init_rccl(Ctx *c, int rank, int size, const void *id128);
+int comm_bench(Ctx *c, int count, int pure_sum, int reps, double out_us[3]);
+int comm_allreduce_host(Ctx *c, double *values, int count, int op);
+int rccl_version();
 int comm_init_callback(Ctx *c, int rank, int size, po_allgather_fn fn, void *user);
 }  // namespace po
 
@@ -62,6 +65,12 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   PO_CHECK_PTR(ctx);
   if (reductions) *reductions = ctx->n_reductions;
   if (launches) *launches = ctx->n_launches;
+  return PO_OK;
+}
+int po_ctx_algorithmic_bytes(po_ctx ctx, double *total, double *user) {
+  PO_CHECK_PTR(ctx);
+  if (total) *total = ctx->alg_bytes;
+  if (user) *user = ctx->alg_bytes_user;
   return PO_OK;
 }
 /* tuning aid (not part of the interface): cycle stamps of the producer/consumer Gram kernel's workgroup 0, see
@@ -157,6 +166,21 @@ int po_ctx_memcpy(po_ctx ctx, void *dst, const void *src, int64_t bytes, int to_
   PO_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
                         ctx->stream));
   PO_HIP(hipStreamSynchronize(ctx->stream));
+  return PO_OK;
+}
+int po_ctx_bench_collective(po_ctx ctx, int count, int pure_sum, int reps, double *out_us3) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(out_us3);
+  return comm_bench(ctx, count, pure_sum, reps, out_us3);
+}
+int po_ctx_allreduce(po_ctx ctx, double *values, int count, int op) {
+  PO_CHECK_PTR(ctx);
+  if (count > 0) PO_CHECK_PTR(values);
+  return comm_allreduce_host(ctx, values, count, op);
+}
+int po_rccl_version(int *version_code) {
+  PO_CHECK_PTR(version_code);
+  *version_code = rccl_version();
   return PO_OK;
 }
 int po_rccl_unique_id(void *id128) {
@@ -358,10 +382,6 @@ int po_vec_get_device_array(po_vec v, double **device) {
 }
 int po_vec_maxpy(po_vec y, double beta, const double *alpha, const po_vec *vecs, int nvecs) {
   PO_CHECK_PTR(y);
-  if (nvecs > kMaxPanel) {
-    po::set_error("maxpy of %d vectors exceeds %d", nvecs, kMaxPanel);
-    return PO_ERR_ARG;
-  }
   std::vector<const double *> p(nvecs > 0 ? nvecs : 1);
   for (int j = 0; j < nvecs; j++) {
     PO_CHECK_PTR(vecs[j]);
@@ -713,6 +733,37 @@ int po_problem_set_bounds_mode(po_problem p, int mode) {
   }
   sp->bounds_mode = mode;
   return PO_OK;
+}
+int po_problem_set_deferred_reductions(po_problem p, int flag) {
+  PO_CHECK_PTR(p);
+  po::CallbackProblem *cp = dynamic_cast<po::CallbackProblem *>(p->p);
+  if (!cp) {
+    po::set_error("po_problem_set_deferred_reductions: not a callback problem (the built-in problems always defer)");
+    return PO_ERR_ARG;
+  }
+  cp->deferred_reductions = flag ? 1 : 0;
+  return PO_OK;
+}
+int po_ctx_after_reduce(po_ctx ctx, po_after_reduce_fn fn, void *user) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(fn);
+  po::after_reduce(ctx, [fn, user] { fn(user); });
+  return PO_OK;
+}
+int po_ctx_reduce_device(po_ctx ctx, const double *device_values, int count, int op, double *host_out) {
+  PO_CHECK_PTR(ctx);
+  PO_CHECK_PTR(host_out);
+  if (count <= 0) return PO_OK;
+  PO_CHECK_PTR(device_values);
+  if (op < 0 || op > 2 || count > po::kMaxRed) {
+    po::set_error("po_ctx_reduce_device: count %d / op %d out of range", count, op);
+    return PO_ERR_ARG;
+  }
+  // one "block" of first-stage partials: the values themselves
+  PO_TRY(po::ensure_partials(ctx, (size_t)count));
+  PO_HIP(hipMemcpyAsync(ctx->d_partials, device_values, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice,
+                        ctx->stream));
+  return po::reduce_finish(ctx, 1, op == 0 ? count : 0, op == 1 ? count : 0, op == 2 ? count : 0, host_out);
 }
 int po_problem_set_linear_constraints(po_problem p, int flag) {
   PO_CHECK_PTR(p);

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <algorithm>
 
 #include "core.hpp"
 
@@ -23,6 +26,7 @@ void set_error(const char *fmt, ...) {
 const char *last_error() { return g_err; }
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
+static int comm_self_test(Ctx *c);
 
 // ---- RCCL through dlopen: the library is only needed for world sizes > 1 ----------------------
 struct Id128 {  // ncclUniqueId: 128 opaque bytes passed BY VALUE to ncclCommInitRank
@@ -36,6 +40,8 @@ struct RcclApi {
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int *) = nullptr;
+  int version = 0;
 };
 static RcclApi g_rccl;
 
@@ -59,15 +65,37 @@ static int load_rccl() {
       (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
   g_rccl.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+  g_rccl.GetVersion = (int (*)(int *))dlsym(h, "ncclGetVersion");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce ||
       !g_rccl.CommDestroy) {
     set_error("librccl.so lacks an expected symbol");
     dlclose(h);
     return PO_ERR_COMM;
   }
+  // The prototypes above are hand-declared (no rccl.h at build time).  What they assume -- ncclUniqueId is 128 opaque
+  // bytes passed BY VALUE to ncclCommInitRank, ncclDouble == 8, ncclSum == 0 -- holds for every NCCL/RCCL 2.x release from 2.10 on; anything else is refused here
+  // instead of being called with a wrong layout.
+  int version = 0;
+  if (!g_rccl.GetVersion || g_rccl.GetVersion(&version) != 0) {
+    set_error("librccl.so: ncclGetVersion unavailable; cannot verify the ABI the hand-declared prototypes assume");
+    dlclose(h);
+    return PO_ERR_COMM;
+  }
+  // version code: major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + ... before)
+  const int major = version >= 10000 ? version / 10000 : version / 1000;
+  const int minor = version >= 10000 ? (version / 100) % 100 : (version / 100) % 10;
+  if (major != 2 || minor < 10) {
+    set_error("librccl.so reports version code %d (need NCCL/RCCL 2.x, x >= 10: 128-byte by-value unique id, ncclDouble == 8)",
+              version);
+    dlclose(h);
+    return PO_ERR_COMM;
+  }
+  g_rccl.version = version;
   g_rccl.handle = h;
   return PO_OK;
 }
+
+int rccl_version() { return g_rccl.version; }
 
 int rccl_unique_id(void *id128) {
   PO_TRY(load_rccl());
@@ -115,6 +143,17 @@ int comm_init_rccl(Ctx *c, int rank, int size, const void *id128) {
   if (c->h_red) (void)hipHostFree(c->h_red);
   PO_HIP(hipMalloc((void **)&c->d_gather, sizeof(double) * (size_t)size * kMaxRed));
   PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * (size_t)size * kMaxRed, hipHostMallocDefault));
+  // The first collectives a fresh communicator runs are known-answer ones: a wrong enum value, a wrong rank order or
+  // a communicator that does not span the ranks it claims fails HERE with a message, not as a diverging solve.
+  const int rc_test = comm_self_test(c);
+  if (rc_test != PO_OK) {
+    g_rccl.CommDestroy(c->rccl_comm);
+    c->rccl_comm = nullptr;
+    c->comm_kind = COMM_SELF;
+    c->size = 1;
+    c->rank = 0;
+    return rc_test;
+  }
   return PO_OK;
 }
 
@@ -157,6 +196,8 @@ int ctx_create(int device, Ctx **out) {
   PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * kMaxRed, hipHostMallocDefault));
   PO_HIP(hipEventCreate(&c->ev0));
   PO_HIP(hipEventCreate(&c->ev1));
+  PO_HIP(hipEventCreate(&c->ev_mdot0));
+  PO_HIP(hipEventCreate(&c->ev_mdot1));
   c->partials_cap = 0;
   if (getenv("PAROPT_AMD_NO_BATCH")) c->batch_enabled = 0;
   *out = c;
@@ -172,8 +213,12 @@ int ctx_destroy(Ctx *c) {
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->h_red) (void)hipHostFree(c->h_red);
+  for (int i = 0; i < 2; i++)
+    if (c->wide_scratch[i]) (void)hipFree(c->wide_scratch[i]);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_mdot0) (void)hipEventDestroy(c->ev_mdot0);
+  if (c->ev_mdot1) (void)hipEventDestroy(c->ev_mdot1);
   (void)hipStreamDestroy(c->stream);
   delete static_cast<po_ctx_s *>(c);
   return PO_OK;
@@ -237,6 +282,127 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
   }
   *parts_out = parts;
   *nparts_out = nparts;
+  return PO_OK;
+}
+
+static void combine_segment(const double *parts, int nparts, int stride, int off, int nsum, int nmin, int nmax,
+                            double *host_out);
+
+// Known-answer collectives over the solver's own exchange path (the code every reduction of the interior point goes
+// through), run once when an RCCL communicator is created -- also for the forced single-rank communicator of
+// PAROPT_AMD_FORCE_RCCL=1.  Rank r contributes (r + 1) everywhere.
+//   pure-sum payload  -> ncclAllReduce:                      N (N + 1) / 2                  [MPI_Allreduce(SUM) sites]
+//   mixed payload     -> rank-ordered ncclAllGather + host:  sum N (N + 1) / 2, min 1, max N, and slot r of the
+//                        gathered buffer must hold r + 1 (rank order = the order the host combine assumes)
+static int comm_self_test(Ctx *c) {
+  const int N = c->size;
+  const double mine = (double)(c->rank + 1), want_sum = 0.5 * N * (N + 1.0);
+  const double *parts = nullptr;
+  int nparts = 1;
+  const long red0 = c->n_reductions, ar0 = c->n_allreduce, ag0 = c->n_allgather;
+  auto put = [&](int count) -> int {
+    for (int i = 0; i < count; i++) c->h_red[i] = mine;
+    PO_HIP(hipMemcpyAsync(c->d_red, c->h_red, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+    PO_HIP(hipStreamSynchronize(c->stream));
+    return PO_OK;
+  };
+  int rc = PO_OK;
+  // 1. the all-reduce form (two slots: a payload, not a scalar)
+  if (c->rccl_allreduce) {
+    PO_TRY(put(2));
+    PO_TRY(exchange_reduced(c, 2, true, &parts, &nparts));
+    double got[2] = {0.0, 0.0};
+    combine_segment(parts, nparts, 2, 0, 2, 0, 0, got);
+    if (got[0] != want_sum || got[1] != want_sum) {
+      set_error("RCCL self-test: all-reduce(SUM) of rank+1 over %d ranks gave %.17g / %.17g on rank %d, expected %.17g "
+                "(librccl version code %d; wrong datatype/op enum or a communicator that does not span %d ranks)",
+                N, got[0], got[1], c->rank, want_sum, g_rccl.version, N);
+      rc = PO_ERR_COMM;
+    }
+  }
+  // 2. the rank-ordered all-gather form with a SUM, a MIN and a MAX segment
+  if (rc == PO_OK) {
+    PO_TRY(put(3));
+    PO_TRY(exchange_reduced(c, 3, false, &parts, &nparts));
+    if (nparts != N) {
+      set_error("RCCL self-test: the all-gather returned %d contributions for %d ranks", nparts, N);
+      rc = PO_ERR_COMM;
+    }
+    for (int r = 0; rc == PO_OK && r < N; r++) {
+      for (int s2 = 0; s2 < 3; s2++) {
+        if (parts[(size_t)r * 3 + s2] != (double)(r + 1)) {
+          set_error("RCCL self-test: slot %d of the gathered buffer holds %.17g on rank %d, expected %d (rank order)",
+                    r, parts[(size_t)r * 3 + s2], c->rank, r + 1);
+          rc = PO_ERR_COMM;
+          break;
+        }
+      }
+    }
+    if (rc == PO_OK) {
+      double got[3] = {0.0, 0.0, 0.0};
+      combine_segment(parts, nparts, 3, 0, 1, 1, 1, got);
+      if (got[0] != want_sum || got[1] != 1.0 || got[2] != (double)N) {
+        set_error("RCCL self-test: SUM/MIN/MAX over %d ranks gave %.17g / %.17g / %.17g, expected %.17g / 1 / %d", N,
+                  got[0], got[1], got[2], want_sum, N);
+        rc = PO_ERR_COMM;
+      }
+    }
+  }
+  // the self-test does not show up in the statistics the bench reports
+  c->n_reductions = red0;
+  c->n_allreduce = ar0;
+  c->n_allgather = ag0;
+  return rc;
+}
+
+// Latency of the solver's collective path as the interior point uses it (bench.py's `collective_us`): `reps`
+// exchanges of `count` doubles, each = final-stage payload in d_red -> collective -> device-to-host copy -> host
+// sync; out = {median, min, max} host wall microseconds per exchange.
+int comm_bench(Ctx *c, int count, int pure_sum, int reps, double out_us[3]) {
+  if (count < 1 || count > kMaxRed || reps < 1) {
+    set_error("comm_bench: bad arguments");
+    return PO_ERR_ARG;
+  }
+  std::vector<double> t((size_t)reps, 0.0);
+  PO_HIP(hipMemsetAsync(c->d_red, 0, sizeof(double) * count, c->stream));
+  PO_HIP(hipStreamSynchronize(c->stream));
+  const long red0 = c->n_reductions, ar0 = c->n_allreduce, ag0 = c->n_allgather;
+  for (int i = 0; i < reps + 2; i++) {  // two untimed warm-up exchanges
+    const double *parts = nullptr;
+    int nparts = 1;
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    PO_TRY(exchange_reduced(c, count, pure_sum != 0, &parts, &nparts));
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    if (i >= 2) t[i - 2] = 1e6 * (double)(b.tv_sec - a.tv_sec) + 1e-3 * (double)(b.tv_nsec - a.tv_nsec);
+  }
+  c->n_reductions = red0;
+  c->n_allreduce = ar0;
+  c->n_allgather = ag0;
+  std::sort(t.begin(), t.end());
+  out_us[0] = t[t.size() / 2];
+  out_us[1] = t.front();
+  out_us[2] = t.back();
+  return PO_OK;
+}
+
+// MPI_Allreduce on host values for user code (a problem's evalObjCon summing its rank-local objective parts, as
+// examples/rosenbrock/rosenbrock.cpp:103-106 does with MPI_Allreduce): op 0 SUM, 1 MIN, 2 MAX; in place; collective.
+int comm_allreduce_host(Ctx *c, double *values, int count, int op) {
+  if (count < 0 || count > kMaxRed || op < 0 || op > 2) {
+    set_error("po_ctx_allreduce: count %d (max %d) / op %d out of range", count, kMaxRed, op);
+    return PO_ERR_ARG;
+  }
+  if (count == 0 || c->comm_kind == COMM_SELF) return PO_OK;
+  PO_TRY(batch_flush(c));  // d_red is shared with queued reductions
+  memcpy(c->h_red, values, sizeof(double) * count);
+  PO_HIP(hipMemcpyAsync(c->d_red, c->h_red, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  const double *parts = nullptr;
+  int nparts = 1;
+  PO_TRY(exchange_reduced(c, count, op == 0, &parts, &nparts));
+  std::vector<double> out((size_t)count);
+  combine_segment(parts, nparts, count, 0, op == 0 ? count : 0, op == 1 ? count : 0, op == 2 ? count : 0, out.data());
+  memcpy(values, out.data(), sizeof(double) * count);
   return PO_OK;
 }
 

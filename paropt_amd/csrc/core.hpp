@@ -60,7 +60,12 @@ struct Ctx {
   double *d_red = nullptr;       // [kMaxRed] rank-local reduced values
   double *d_gather = nullptr;    // [size * kMaxRed]
   double *h_red = nullptr;       // pinned [size * kMaxRed]
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
+  // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
+  // allocated on first use
+  double *wide_scratch[2] = {nullptr, nullptr};
+  int64_t wide_n = 0;
+  hipEvent_t ev_mdot0 = nullptr, ev_mdot1 = nullptr;  // k_mdot's timing only: may stay pending inside an open batch
   long n_reductions = 0;  // statistics: host-synchronising reductions issued
   // Batched reductions (BatchScope): while batch_depth > 0, reduce_finish only launches the rank-local final stage
   // into d_red[batch_cursor...] and queues the segment; ONE collective + copy + host sync serves every queued
@@ -76,6 +81,11 @@ struct Ctx {
   std::vector<std::function<void()>> batch_after;
   long n_batched = 0;  // statistics: reductions that shared another one's host sync
   long n_launches = 0;
+  // algorithmic HBM bytes of the n-sized launches so far (every operand stream counted once per launch, what
+  // bench.py's iteration-level roofline divides by the step time); `alg_bytes_user` is the part issued between
+  // InteriorPoint::userBegin/userEnd, i.e. by the problem's own callbacks (built-in problems and C-ABI vector calls)
+  double alg_bytes = 0.0, alg_bytes_user = 0.0;
+  int in_user = 0;
   // live timing of the headline kernel: mdot launches of exactly this many vectors are bracketed by ev0/ev1
   int time_mdot_nv = 0;
   double mdot_ms = 0.0;
@@ -179,6 +189,12 @@ struct BatchScope {
   BatchScope &operator=(const BatchScope &) = delete;
 };
 int ensure_partials(Ctx *c, size_t doubles);
+// `streams` n-sized fp64 operand streams read or written by the launch being issued
+inline void count_bytes(Ctx *c, double streams, int64_t n) {
+  const double b = 8.0 * streams * (double)n;
+  c->alg_bytes += b;
+  if (c->in_user) c->alg_bytes_user += b;
+}
 int grid_for(Ctx *c, int64_t n);           // persistent grid, 4 workgroups per CU
 int grid_for(Ctx *c, int64_t n, int bpc);  // ... with an explicit workgroups-per-CU cap
 

@@ -731,6 +731,11 @@ int CsrSparse::factor(const double *dinv, const double *cdiag) {
 }
 
 int CsrSparse::solveInPlace(double *const *Y, int nv, bool forward, bool backward) {
+  if (nv > kMaxPanel) {  // independent right-hand sides: slabs of one kernel's pointer table
+    for (int j0 = 0; j0 < nv; j0 += kMaxPanel)
+      PO_TRY(solveInPlace(Y + j0, nv - j0 > kMaxPanel ? kMaxPanel : nv - j0, forward, backward));
+    return PO_OK;
+  }
   if (w <= 0 || nv <= 0) return PO_OK;
   if (forward) {
     for (int l = 0; l < nlevels_f; l++) {

@@ -193,9 +193,10 @@ __global__ void __launch_bounds__(kBlock)
 int k_csr_panel(Ctx *c, const int *rowp, const int *cols, const double *vals, int64_t w, const double *d,
                 const double *const *P, int nv, double *const *U, const int *outperm) {
   if (w <= 0 || nv <= 0) return PO_OK;
-  if (nv > kMaxPanel) {
-    set_error("sparse panel product: %d columns exceed the panel limit %d", nv, kMaxPanel);
-    return PO_ERR_ARG;
+  if (nv > kMaxPanel) {  // independent columns: slabs of one kernel's pointer table
+    for (int j0 = 0; j0 < nv; j0 += kMaxPanel)
+      PO_TRY(k_csr_panel(c, rowp, cols, vals, w, d, P + j0, nv - j0 > kMaxPanel ? kMaxPanel : nv - j0, U + j0, outperm));
+    return PO_OK;
   }
   PtrTable pt;
   PtrTableW ut;

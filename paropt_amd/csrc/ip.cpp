@@ -222,6 +222,7 @@ void InteriorPoint::phaseEnd(const char *name) {
 }
 
 void InteriorPoint::userBegin() {
+  ctx->in_user = 1;
   if (!user_events_ready) {
     for (int i = 0; i < 2 * kUserRing; i++)
       if (hipEventCreate(&user_ev[i]) != hipSuccess) return;
@@ -231,6 +232,7 @@ void InteriorPoint::userBegin() {
   (void)hipEventRecord(user_ev[2 * user_pending], ctx->stream);
 }
 void InteriorPoint::userEnd() {
+  ctx->in_user = 0;
   if (!user_events_ready) return;
   (void)hipEventRecord(user_ev[2 * user_pending + 1], ctx->stream);
   user_pending++;
@@ -730,8 +732,9 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   // so the same pass over P also emits the right-hand side t' of the refinement solve.
   const bool seq_lin = options.integer("sequential_linear_method");
   const int kq = (qn && !seq_lin) ? qn->size() : 0;
+  // (a panel wider than one kernel's argument tables takes the plain sequence: the launchers collapse it, kernels.hip)
   const bool fuse = fuse_residual && !refine_pass && analytic_panel_dots && kq == k &&
-                    !options.integer("use_diag_hessian") && !inexact_newton_step;
+                    !options.integer("use_diag_hessian") && !inexact_newton_step && m <= kMaxPanel;
   vA_valid = true;
   std::vector<double> coef(m > 0 ? m : 1, 0.0);
   double diag = options.real("qn_sigma");
@@ -1338,7 +1341,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums, sq));
       s_qn_a = alpha * sx;
       s_qn_from_trial = sq != nullptr;
+      userBegin();
       int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
+      userEnd();
       PO_TRY(batch.end());
       neval++;
       if (fail_obj) {
@@ -1412,7 +1417,9 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // the accepted trial point IS the new design point (same clamp, same arithmetic)
   std::swap(x->d, xt->d);
   if (eval_obj_con) {
+    userBegin();
     int fail = prob->evalObjCon(x, &fobj, cvals.data());
+    userEnd();
     neval++;
     if (fail) {
       fprintf(stderr, "ParOpt: Function and constraint evaluation failed\n");
@@ -1432,7 +1439,9 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     s_qn_from_trial = false;
     // the next residual's norms and the quasi-Newton products of the update are reduced together: nothing on the
     // host needs the norms before the update has its dots.  Only when no user code runs in between.
-    BatchScope batch(ctx, fast_yqn && prob->reductionsBatchable() && qn->reductionsBatchable());
+    // (user code between the two: only computeQuasiNewtonUpdateCorrection, and only when the problem has one)
+    BatchScope batch(ctx, fast_yqn && qn->reductionsBatchable() &&
+                              (prob->reductionsBatchable() || !prob->quasiNewtonCorrectionMayChangeStep()));
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
       // ... and y_qn += [lo]zl+ - [up]zu+ - rx+ in the same pass (the residual kernel has all three in registers)

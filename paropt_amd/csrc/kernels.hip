@@ -210,33 +210,39 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_sign(Ctx *c, double *y, const double *x, int64_t n) {
+  count_bytes(c, 2, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(sign_kernel, grid_for(c, n), y, x, n);
   return PO_OK;
 }
 int k_fill(Ctx *c, double *y, int64_t n, double a) {
+  count_bytes(c, 1, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(fill_kernel, grid_for(c, n), y, n, a);
   return PO_OK;
 }
 int k_fill_hash(Ctx *c, double *y, int64_t n, uint64_t seed, uint64_t aid, int64_t offset,
                 double scale, double shift) {
+  count_bytes(c, 1, n);
   if (n <= 0) return PO_OK;
   const uint64_t base = seed * 0x9E3779B97F4A7C15ULL + aid * 0xD1B54A32D192ED03ULL;
   PO_LAUNCH(fill_hash_kernel, grid_for(c, n), y, n, base, offset, scale, shift);
   return PO_OK;
 }
 int k_copy(Ctx *c, double *y, const double *x, int64_t n) {
+  count_bytes(c, 2, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(copy_kernel, grid_for(c, n), y, x, n);
   return PO_OK;
 }
 int k_scale(Ctx *c, double *y, int64_t n, double a) {
+  count_bytes(c, 2, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(scale_kernel, grid_for(c, n), y, n, a);
   return PO_OK;
 }
 int k_axpy(Ctx *c, double *y, double a, const double *x, int64_t n) {
+  count_bytes(c, 3, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(axpy_kernel, grid_for(c, n), y, a, x, n);
   return PO_OK;
@@ -395,14 +401,18 @@ static void fill_tables(const double *alpha, const double *const *V, int nv, Coe
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
                  const double *const *V, int nv, int64_t n) {
   if (n <= 0) return PO_OK;
-  if (nv > kMaxPanel) {
-    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
-    return PO_ERR_ARG;
-  }
-  CoefTable ct;
-  PtrTable pt;
-  fill_tables(alpha, V, nv, &ct, &pt);
-  PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, 3), y, a, x, b, ct, pt, nv, n);
+  // panels wider than one kernel's argument tables go in slabs: the first carries a*x + b*y, the others accumulate
+  int j0 = 0;
+  do {
+    const int w = nv - j0 > kMaxPanel ? kMaxPanel : nv - j0;
+    const double aa = j0 == 0 ? a : 0.0, bb = j0 == 0 ? b : 1.0;
+    count_bytes(c, w + 1 + (aa != 0.0 ? 1 : 0) + (bb != 0.0 ? 1 : 0), n);
+    CoefTable ct;
+    PtrTable pt;
+    fill_tables(alpha ? alpha + j0 : nullptr, V ? V + j0 : nullptr, w, &ct, &pt);
+    PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, 3), y, aa, x, bb, ct, pt, w, n);
+    j0 += w;
+  } while (j0 < nv);
   return PO_OK;
 }
 
@@ -431,17 +441,62 @@ __global__ void __launch_bounds__(kBlock)
 int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X, double b,
                     const double *const *Y, int nv, int64_t n) {
   if (n <= 0 || nv <= 0) return PO_OK;
-  if (nv > kMaxPanel) {
-    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
-    return PO_ERR_ARG;
+  count_bytes(c, (double)nv * (Y ? 3 : 2), n);
+  for (int j0 = 0; j0 < nv; j0 += kMaxPanel) {  // independent columns: slabs of one kernel's table width
+    const int w = nv - j0 > kMaxPanel ? kMaxPanel : nv - j0;
+    PtrTableW d;
+    PtrTable x, y;
+    CoefTable ct;
+    for (int j = 0; j < kMaxPanel; j++) d.p[j] = j < w ? dst[j0 + j] : nullptr;
+    fill_tables(nullptr, X + j0, w, &ct, &x);
+    fill_tables(nullptr, Y ? Y + j0 : nullptr, Y ? w : 0, &ct, &y);
+    PO_LAUNCH(panel_lincomb_kernel, grid_for(c, n), d, a, x, b, y, w, Y ? 1 : 0, n);
   }
-  PtrTableW d;
-  PtrTable x, y;
-  CoefTable ct;
-  for (int j = 0; j < kMaxPanel; j++) d.p[j] = j < nv ? dst[j] : nullptr;
-  fill_tables(nullptr, X, nv, &ct, &x);
-  fill_tables(nullptr, Y, Y ? nv : 0, &ct, &y);
-  PO_LAUNCH(panel_lincomb_kernel, grid_for(c, n), d, a, x, b, y, nv, Y ? 1 : 0, n);
+  return PO_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Panels wider than one kernel's argument tables (kMaxPanel columns).  The reference has no limit on the number of
+// dense constraints or on the quasi-Newton width (src/ParOptInteriorPoint.cpp:1935-1950, 2648-2654), so the panel
+// kernels below accept any width: sum_j coef_j P_j over a column range is formed by slabbed panel_axpy passes into
+// one of the context's two scratch vectors and enters the kernel as ONE column with coefficient 1.  Costs a pass
+// over the range plus one n-sized write per range: the wide path is correct, not fast.
+// ---------------------------------------------------------------------------------------------
+static int collapse_range(Ctx *c, int which, const double *coef, const double *const *P, int j0, int j1,
+                          int64_t n, const double **out) {
+  if (c->wide_n < n || !c->wide_scratch[which]) {
+    PO_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; i++) {
+      if (c->wide_n < n && c->wide_scratch[i]) {
+        PO_HIP(hipFree(c->wide_scratch[i]));
+        c->wide_scratch[i] = nullptr;
+      }
+    }
+    if (c->wide_n < n) c->wide_n = n;
+    const size_t bytes = sizeof(double) * (size_t)(((c->wide_n + 1) / 2) * 2 + 2);
+    PO_HIP(hipMalloc((void **)&c->wide_scratch[which], bytes));
+    PO_HIP(hipMemsetAsync(c->wide_scratch[which], 0, bytes, c->stream));
+  }
+  PO_TRY(k_panel_axpy(c, c->wide_scratch[which], 0.0, nullptr, 0.0, coef + j0, P + j0, j1 - j0, n));
+  *out = c->wide_scratch[which];
+  return PO_OK;
+}
+// [A-part | rest] -> at most two columns: P2/coef2 receive the collapsed panel, *nv2 / *nca2 its widths
+static int collapse_panel(Ctx *c, const double *coef, const double *const *P, int nv, int nca, int64_t n,
+                          const double *P2[2], double coef2[2], int *nv2, int *nca2) {
+  int m = 0;
+  *nca2 = 0;
+  if (nca > 0) {
+    PO_TRY(collapse_range(c, 0, coef, P, 0, nca, n, &P2[m]));
+    coef2[m++] = 1.0;
+    *nca2 = 1;
+  }
+  if (nv > nca) {
+    PO_TRY(collapse_range(c, 1, coef, P, nca, nv, n, &P2[m]));
+    coef2[m++] = 1.0;
+  }
+  *nv2 = m;
   return PO_OK;
 }
 
@@ -490,6 +545,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out) {
+  count_bytes(c, kind == RED_DOT ? 2 : 1, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid));
   switch (kind) {
@@ -547,6 +603,7 @@ __global__ void __launch_bounds__(kBlock)
     break;
 
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks) {
+  count_bytes(c, nv + 1, n);
   if (nv > kMaxPanel) {
     set_error("mdot of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -576,20 +633,25 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
 
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out) {
   if (nv <= 0) return PO_OK;
+  if (nv > kMaxPanel) {  // wider than one launch's pointer table: slabs (x is re-read once per slab)
+    for (int j0 = 0; j0 < nv; j0 += kMaxPanel)
+      PO_TRY(k_mdot(c, x, V + j0, nv - j0 > kMaxPanel ? kMaxPanel : nv - j0, n, out + j0));
+    return PO_OK;
+  }
   int grid = 0;
   const bool timed = c->time_mdot_nv == nv;  // po_ctx_time_mdot: HIP events on the launch stream
   // the event pair is read once the stream has been synchronised: right away, or when the enclosing batch is flushed
   // (one timed launch per batch: a second one would reuse the events, so the batch is flushed first)
   if (timed && c->mdot_timing_pending) PO_TRY(batch_flush(c));
-  if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
+  if (timed) PO_HIP(hipEventRecord(c->ev_mdot0, c->stream));
   PO_TRY(k_mdot_launch(c, x, V, nv, n, &grid));
-  if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
+  if (timed) PO_HIP(hipEventRecord(c->ev_mdot1, c->stream));
   const bool defer = timed && c->batch_depth > 0;
   PO_TRY(reduce_finish(c, grid, nv, 0, 0, out, timed && !defer));
   if (timed) {
     auto harvest = [c] {
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+      if (hipEventElapsedTime(&ms, c->ev_mdot0, c->ev_mdot1) == hipSuccess) {
         c->mdot_ms += ms;
         c->mdot_count++;
       }
@@ -706,6 +768,12 @@ __global__ void __launch_bounds__(kBlock)
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
               int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn) {
+  if (nc > kMaxPanel) {  // wide A^T z: one collapsed column
+    const double *w = nullptr, one = 1.0;
+    PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
+    return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn);
+  }
+  count_bytes(c, 7 + nc + (yqn ? 2 : 0), n);
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
@@ -732,6 +800,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]) {
+  count_bytes(c, 5, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PO_LAUNCH(res_norms_kernel, grid, b, beta_mu, n, c->d_partials);
@@ -756,6 +825,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_dinv(Ctx *c, const Bounds &b, double diag, int64_t n, double *dinv, const double *hdiag) {
+  count_bytes(c, 6 + (hdiag ? 1 : 0), n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(dinv_kernel, grid_for(c, n), b, diag, hdiag, n, dinv);
   return PO_OK;
@@ -790,6 +860,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double beta_mu, int64_t n,
          double *t, const double *cl, const double *cu) {
+  count_bytes(c, 7 + (dinv ? 1 : 0) + (cl ? 2 : 0), n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(d1_kernel, grid_for(c, n), b, rx, dinv, beta_mu, cl, cu, n, t);
   return PO_OK;
@@ -813,6 +884,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_dinv_d1(Ctx *c, const Bounds &b, double diag, const double *hdiag, const double *rx, double beta_mu,
               int64_t n, double *dinv, double *t) {
+  count_bytes(c, 8 + (hdiag ? 1 : 0), n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(dinv_d1_kernel, grid_for(c, n), b, diag, hdiag, rx, beta_mu, n, dinv, t);
   return PO_OK;
@@ -832,6 +904,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 int64_t n, double *cl, double *cu) {
+  count_bytes(c, 10, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(corrector_kernel, grid_for(c, n), b, px, pzl, pzu, n, cl, cu);
   return PO_OK;
@@ -1032,6 +1105,7 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
               double diag, int ca0, const double *const *vs, int nvirt, double b0v) {
+  count_bytes(c, nv + nvirt + 11 + (va ? 1 : 0), n);
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -1079,9 +1153,19 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
              double *px, double *pzl, double *pzu, double out[2], const double *coef2,
              const double *rx, double diag, double *tout, double *va, int nca, const double *cl,
              const double *cu) {
+  count_bytes(c, nv + 10 + (refine ? 3 : 0) + (va ? (refine ? 2 : 1) : 0) + (coef2 ? 2 : 0) + (cl ? 2 : 0), n);
   if (nv > kMaxPanel) {
-    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
-    return PO_ERR_ARG;
+    if (coef2) {
+      set_error("k_solve2: the fused refinement residual is not available for a panel of %d (> %d) columns", nv,
+                kMaxPanel);
+      return PO_ERR_ARG;
+    }
+    const double *P2[2] = {nullptr, nullptr};
+    double a2[2] = {0.0, 0.0};
+    int nv2 = 0, nca2 = 0;
+    PO_TRY(collapse_panel(c, alpha, P, nv, va ? nca : 0, n, P2, a2, &nv2, &nca2));
+    return k_solve2(c, b, t, dinv, a2, P2, nv2, beta_mu, refine, tau, n, px, pzl, pzu, out, nullptr, rx, diag, tout, va,
+                    nca2, cl, cu);
   }
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
@@ -1334,6 +1418,7 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
                   double *tout, double *va, int nca, double *out, double *traw, int store_step, int ca0,
                   const double *const *vs, int nvirt, double b0v) {
+  count_bytes(c, nv + nvirt + 8 + (store_step ? 3 + (va ? 1 : 0) : 0) + ((traw || tout) ? 1 : 0), n);
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -1416,6 +1501,12 @@ __global__ void __launch_bounds__(kBlock)
 int k_step_check(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl, const double *pzu,
                  const double *coef, const double *const *P, int nv, double diag, double beta_mu, int64_t n,
                  double out[3]) {
+  if (nv > kMaxPanel) {
+    const double *w = nullptr, one = 1.0;
+    PO_TRY(collapse_range(c, 0, coef, P, 0, nv, n, &w));
+    return k_step_check(c, b, rx, px, pzl, pzu, &one, &w, 1, diag, beta_mu, n, out);
+  }
+  count_bytes(c, nv + 9, n);
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 3));
   PtrTable pt;
@@ -1428,6 +1519,12 @@ int k_step_check(Ctx *c, const Bounds &b, const double *rx, const double *px, co
 int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, const double *pzl,
                const double *pzu, const double *dinv, const double *coef, const double *const *P,
                int nv, double diag, double beta_mu, int64_t n, double *tprime) {
+  if (nv > kMaxPanel) {
+    const double *w = nullptr, one = 1.0;
+    PO_TRY(collapse_range(c, 0, coef, P, 0, nv, n, &w));
+    return k_res_step(c, b, rx, px, pzl, pzu, dinv, &one, &w, 1, diag, beta_mu, n, tprime);
+  }
+  count_bytes(c, nv + 10 + (dinv ? 1 : 0), n);
   if (n <= 0) return PO_OK;
   PtrTable pt;
   CoefTable ct;
@@ -1469,6 +1566,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_comp_step(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 double ax, double az, int64_t n, double out[2]) {
+  count_bytes(c, 8, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PO_LAUNCH(comp_step_kernel, grid, b, px, pzl, pzu, ax, az, n, c->d_partials);
@@ -1511,6 +1609,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_merit0(Ctx *c, const Bounds &b, const double *px, double sx, const double *g, int64_t n,
              double out[6]) {
+  count_bytes(c, 7, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 6));
   PO_LAUNCH(merit0_kernel, grid, b, px, sx, g, n, c->d_partials);
@@ -1564,6 +1663,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_comp_merit(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu, double ax,
                  double az, const double *g, int64_t n, double out[9]) {
+  count_bytes(c, 9, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 9));
   PO_LAUNCH(comp_merit_kernel, grid, b, px, pzl, pzu, ax, az, g, n, c->d_partials);
@@ -1602,6 +1702,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_trial(Ctx *c, const Bounds &b, const double *px, double a, double eps, int64_t n, double *xt,
             double out[2], double *sout) {
+  count_bytes(c, 5 + (sout ? 1 : 0), n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PO_LAUNCH(trial_kernel, grid, b, px, a, eps, n, xt, sout, c->d_partials);
@@ -1629,6 +1730,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_update_mult(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                   double eps, int use_lower, int use_upper, int64_t n) {
+  count_bytes(c, 3 * (use_lower + use_upper), n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(update_mult_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, n);
   return PO_OK;
@@ -1674,6 +1776,7 @@ __global__ void __launch_bounds__(kBlock)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,
                       double az, int64_t n, double *yqn, double *acz) {
+  count_bytes(c, 3 + 3 * (use_lower + use_upper) + (acz ? 2 : 0), n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(update_mult_yqn_kernel, grid_for(c, n), zl, pzl, zu, pzu, a, eps, use_lower, use_upper, rx,
             va, az, n, yqn, acz);
@@ -1769,6 +1872,12 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz) {
+  if (nc > kMaxPanel) {
+    const double *w = nullptr, one = 1.0;
+    PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
+    return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz);
+  }
+  count_bytes(c, 14 + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
   const int grid = grid_for(c, n, 3);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
@@ -1797,6 +1906,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_affine_mult(Ctx *c, const Bounds &b, double *zl, const double *pzl, double *zu,
                   const double *pzu, double amin, int64_t n) {
+  count_bytes(c, 9, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(affine_mult_kernel, grid_for(c, n), b, zl, pzl, zu, pzu, amin, n);
   return PO_OK;
@@ -1840,6 +1950,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_check_bounds(Ctx *c, double *x, double *lb, double *ub, double *zl, double *zu,
                    double max_bound, double rel_bound, int both, int64_t n, int *flag) {
+  count_bytes(c, 5, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 3));
   PO_LAUNCH(check_bounds_kernel, grid, x, lb, ub, zl, zu, max_bound, rel_bound, both, n,
@@ -1889,6 +2000,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_clamp_count(Ctx *c, const double *x, const double *lb, const double *ub, const double *zl, const double *zu,
                   double eps, int64_t n, double out[4]) {
+  count_bytes(c, 5, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 4));
   PO_LAUNCH(clamp_count_kernel, grid, x, lb, ub, zl, zu, eps, n, c->d_partials);
@@ -1906,6 +2018,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_zero_inactive(Ctx *c, const double *lb, const double *ub, double *zl, double *zu,
                     double max_bound, int64_t n) {
+  count_bytes(c, 4, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(zero_inactive_kernel, grid_for(c, n), lb, ub, zl, zu, max_bound, n);
   return PO_OK;
@@ -1954,23 +2067,27 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_quadratic_f(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *f) {
+  count_bytes(c, 3, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid));
   PO_LAUNCH(sep_f_kernel<0>, grid, q, b, x, n, c->d_partials);
   return reduce_finish(c, grid, 1, 0, 0, f);
 }
 int k_convex_f(Ctx *c, const double *b, const double *x, int64_t n, double *f) {
+  count_bytes(c, 2, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid));
   PO_LAUNCH(sep_f_kernel<1>, grid, (const double *)nullptr, b, x, n, c->d_partials);
   return reduce_finish(c, grid, 1, 0, 0, f);
 }
 int k_quadratic_g(Ctx *c, const double *q, const double *b, const double *x, int64_t n, double *g) {
+  count_bytes(c, 4, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(sep_g_kernel<0>, grid_for(c, n), q, b, x, n, g);
   return PO_OK;
 }
 int k_convex_g(Ctx *c, const double *b, const double *x, int64_t n, double *g) {
+  count_bytes(c, 3, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(sep_g_kernel<1>, grid_for(c, n), (const double *)nullptr, b, x, n, g);
   return PO_OK;
@@ -2002,6 +2119,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_sep_hess(Ctx *c, int kind, const double *q, const double *b, const double *x, const double *px,
                int64_t n, double *h) {
+  count_bytes(c, 4, n);
   if (n <= 0) return PO_OK;
   if (kind == 0) {
     PO_LAUNCH(sep_h_kernel<0>, grid_for(c, n), q, b, x, px, n, h);
@@ -2037,6 +2155,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_rosen_hess(Ctx *c, const double *x, double z0, const double *px, int64_t n, double *h) {
+  count_bytes(c, 3, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(rosen_h_kernel, grid_for(c, n), x, z0, px, n, h);
   return PO_OK;
@@ -2060,6 +2179,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_d1s(Ctx *c, const Bounds &b, const double *bx, const double *dinv, double alpha, double beta_mu,
           int64_t n, double *t) {
+  count_bytes(c, 8, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(d1s_kernel, grid_for(c, n), b, bx, dinv, alpha, beta_mu, n, t);
   return PO_OK;
@@ -2102,6 +2222,12 @@ __global__ void __launch_bounds__(kBlock)
 int k_solve2s(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *coef,
               const double *const *P, int nv, double alpha, double beta_mu, int full, double tau, int64_t n,
               double *px, double *pzl, double *pzu, double out[2]) {
+  if (nv > kMaxPanel) {
+    const double *w = nullptr, one = 1.0;
+    PO_TRY(collapse_range(c, 0, coef, P, 0, nv, n, &w));
+    return k_solve2s(c, b, t, dinv, &one, &w, 1, alpha, beta_mu, full, tau, n, px, pzl, pzu, out);
+  }
+  count_bytes(c, nv + 10, n);
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -2154,12 +2280,14 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_rosen_f(Ctx *c, const double *x, int64_t n, double out[3]) {
+  count_bytes(c, 1, n);
   const int grid = grid_for(c, n);
   PO_TRY(ensure_partials(c, (size_t)grid * 3));
   PO_LAUNCH(rosen_f_kernel, grid, x, n, c->d_partials);
   return reduce_finish(c, grid, 3, 0, 0, out);
 }
 int k_rosen_g(Ctx *c, const double *x, int64_t n, double *g, double *a0, double *a1) {
+  count_bytes(c, 4, n);
   if (n <= 0) return PO_OK;
   PO_LAUNCH(rosen_g_kernel, grid_for(c, n), x, n, g, a0, a1);
   return PO_OK;

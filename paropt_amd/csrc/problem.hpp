@@ -124,6 +124,11 @@ class CallbackProblem : public Problem {
   int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
+  // po_problem_set_deferred_reductions: the problem's callbacks obtain reduced values only through this library's
+  // reductions (po_vec_dot/mdot/..., po_ctx_reduce_device) and post-process them in po_ctx_after_reduce hooks, so
+  // the solver may let them share a collective + host sync with its own (reductionsBatchable, above)
+  int deferred_reductions = 0;
+  bool reductionsBatchable() override { return deferred_reductions != 0; }
   po_problem_callbacks cb;
   SparseCallbacks sparse;
   // CSR form (CyParOptSparseProblem, src/CyParOptProblem.h:177-262): the two evaluation callbacks also fill

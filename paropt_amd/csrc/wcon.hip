@@ -218,6 +218,11 @@ __global__ void __launch_bounds__(kBlock)
 int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, const double *d,
                   double alpha, double *const *U) {
   if (m.nwcon <= 0 || nv <= 0) return PO_OK;
+  if (nv > kMaxPanel) {  // independent columns: slabs of one kernel's pointer table
+    for (int j0 = 0; j0 < nv; j0 += kMaxPanel)
+      PO_TRY(k_group_panel(c, m, P + j0, nv - j0 > kMaxPanel ? kMaxPanel : nv - j0, d, alpha, U + j0));
+    return PO_OK;
+  }
   PtrTable pt;
   PtrTableW ut;
   for (int j = 0; j < kMaxPanel; j++) {
@@ -356,9 +361,14 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_blk_solve(Ctx *c, const double *blk, int64_t nblocks, int B, double *const *Y, int nv, int mode) {
   if (nblocks <= 0 || nv <= 0) return PO_OK;
-  if (B > kMaxBlock || nv > kMaxPanel) {
-    set_error("block solve: nwblock %d (max %d) or %d right-hand sides (max %d)", B, kMaxBlock, nv, kMaxPanel);
+  if (B > kMaxBlock) {
+    set_error("block solve: nwblock %d exceeds %d", B, kMaxBlock);
     return PO_ERR_ARG;
+  }
+  if (nv > kMaxPanel) {  // independent right-hand sides: slabs
+    for (int j0 = 0; j0 < nv; j0 += kMaxPanel)
+      PO_TRY(k_blk_solve(c, blk, nblocks, B, Y + j0, nv - j0 > kMaxPanel ? kMaxPanel : nv - j0, mode));
+    return PO_OK;
   }
   PtrTableW t;
   for (int j = 0; j < kMaxPanel; j++) t.p[j] = j < nv ? Y[j] : Y[0];

@@ -30,6 +30,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <vector>
+
 namespace po {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -492,6 +494,7 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     set_error("wgram: %d pending columns cannot be materialised in the Gram pass", kpend);
     return PO_ERR_ARG;
   }
+  count_bytes(c, nv + 1 + 2 * kpend, n);  // panel + weights (+ S read, Z written)
   const int tcol = preweighted_last ? nv - 1 : -1;
   const int NG = wgram_groups(nv);
   const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
@@ -543,8 +546,50 @@ int wgram_debug_stamps(double out[8]) {
   return PO_OK;
 }
 
+static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
+                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last);
+
+// Panels wider than one launch (kWgramMaxVecs columns: registers and LDS of the kernel) are processed by column
+// BLOCKS: the columns are cut into nb blocks of <= kWgramMaxVecs / 2 columns (multiples of 4) and every pair of
+// blocks (I < J) is one launch over [V_I | V_J], which yields W_II, W_IJ and W_JJ.  nb (nb - 1) / 2 launches, each
+// block streamed nb - 1 times: slower per column than the single launch, but there is no limit on the width (the
+// reference has none either: src/ParOptInteriorPoint.cpp:1935-1950, 2648-2654).
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
             const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last) {
+  if (nv <= 0) return PO_OK;
+  if (nv <= kWgramMaxVecs) return wgram_one_launch(c, d, V, nv, n, W, S, Zout, kpend, b0, preweighted_last);
+  if (kpend > 0 || preweighted_last) {
+    set_error("wgram: a panel of %d columns is processed in blocks, which cannot form L-SR1 columns or carry a "
+              "pre-weighted column", nv);
+    return PO_ERR_ARG;
+  }
+  const int half = kWgramMaxVecs / 2;
+  const int nb = (nv + half - 1) / half;
+  int bw = (nv + nb - 1) / nb;
+  bw = ((bw + 3) / 4) * 4;  // whole column groups
+  std::vector<const double *> V2;
+  std::vector<double> W2;
+  for (int I = 0; I < nb; I++) {
+    const int i0 = I * bw, ni = (nv - i0 < bw) ? nv - i0 : bw;
+    if (ni <= 0) continue;
+    for (int J = I + 1; J < nb; J++) {
+      const int j0 = J * bw, nj = (nv - j0 < bw) ? nv - j0 : bw;
+      if (nj <= 0) continue;
+      const int m2 = ni + nj;
+      V2.assign(V + i0, V + i0 + ni);
+      V2.insert(V2.end(), V + j0, V + j0 + nj);
+      W2.assign((size_t)m2 * m2, 0.0);
+      PO_TRY(wgram_one_launch(c, d, V2.data(), m2, n, W2.data(), nullptr, nullptr, 0, 0.0, 0));
+      auto col = [&](int q) { return q < ni ? i0 + q : j0 + (q - ni); };
+      for (int q = 0; q < m2; q++)
+        for (int r = 0; r < m2; r++) W[col(r) + (size_t)nv * col(q)] = W2[r + (size_t)m2 * q];
+    }
+  }
+  return PO_OK;
+}
+
+static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
+                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
   const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream

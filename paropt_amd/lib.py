@@ -83,6 +83,7 @@ SIGNATURES = {
     "po_ctx_stream": (C.c_void_p, [po_ctx]),
     "po_ctx_memcpy": (C.c_int, [po_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "po_ctx_counters": (C.c_int, [po_ctx, c_i64_p, c_i64_p]),
+    "po_ctx_algorithmic_bytes": (C.c_int, [po_ctx, c_double_p, c_double_p]),
     "po_live_objects": (C.c_int, [c_i64_p, c_i64_p]),
     "po_live_host_mirrors": (C.c_int, [c_i64_p]),
     "po_device_count": (C.c_int, [c_int_p]),
@@ -97,6 +98,12 @@ SIGNATURES = {
     "po_ctx_set_reduction_batching": (C.c_int, [po_ctx, C.c_int]),
     "po_ctx_batched_reductions": (C.c_int, [po_ctx, c_i64_p]),
     "po_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "po_rccl_version": (C.c_int, [c_int_p]),
+    "po_ctx_allreduce": (C.c_int, [po_ctx, c_double_p, C.c_int, C.c_int]),
+    "po_ctx_after_reduce": (C.c_int, [po_ctx, C.c_void_p, C.c_void_p]),
+    "po_ctx_reduce_device": (C.c_int, [po_ctx, C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "po_problem_set_deferred_reductions": (C.c_int, [po_problem, C.c_int]),
+    "po_ctx_bench_collective": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_int, c_double_p]),
     "po_ctx_comm_init_rccl": (C.c_int, [po_ctx, C.c_int, C.c_int, C.c_void_p]),
     "po_ctx_comm_init_callback": (C.c_int, [po_ctx, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]),
     "po_vec_create": (C.c_int, [po_ctx, C.c_int64, C.POINTER(po_vec)]),

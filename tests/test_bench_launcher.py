@@ -50,7 +50,8 @@ def test_bench_gpus2_shared_gpu():
     """`python bench.py --gpus 2` (the shape of the driver's command) on a 1-GPU box: both ranks share GPU 0 and
     reduce through the host-callback communicator; the line must say n_gpus == 2 and carry the contract fields."""
     out, lines = _run(["--gpus", "2", "--nglobal", "2000000", "--steps", "3", "--warmup", "3", "--repeats", "2",
-                       "--no-cpu-baseline", "--qn-size", "3"], {"PAROPT_BENCH_SHARE_GPU": "1"}, 900)
+                       "--no-cpu-baseline", "--qn-size", "3", "--boundary", "builtin"], {"PAROPT_BENCH_SHARE_GPU": "1"},
+                      900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1, out.stdout
     r = json.loads(lines[0])
@@ -58,7 +59,10 @@ def test_bench_gpus2_shared_gpu():
     assert r["steps"] == 3 and r["warmup"] == 5  # clamped to qn_size + 2
     assert r["repeats"] == 2 and r["ms_per_step_min"] <= r["ms_per_step"] <= r["ms_per_step_max"]
     assert r["config"]["collective"].startswith("gloo callback")
-    assert set(r["variants"]) == {"constant_jacobian", "jacobian_rewritten_every_gradient_call"}
+    assert list(r["variants"]) == ["jacobian_rewritten_every_gradient_call",
+                                   "linear_constraints_declared__API_EXTENSION"]
+    assert r["config"]["headline_variant"] == "jacobian_rewritten_every_gradient_call"
+    assert r["config"]["n_local"] == 1000000
     assert r["roofline"]["stream_ceiling"]["read_only_GBps"] > 0
     assert r["roofline"]["second"] is not None and r["roofline"]["second"]["hbm"]["frac"] > 0
     assert r["user_eval_ms_per_iter"] > 0
@@ -73,4 +77,46 @@ def test_bench_single_gpu_line():
     assert r["n_gpus"] == 1 and r["metric"].startswith("IP iterations/sec") and "n=1M vars m=32" in r["metric"]
     assert r["roofline"]["traffic"] is None  # the committed PMC profile is for n = 50 M only
     v = r["variants"]
-    assert v["constant_jacobian"]["user_eval_ms_per_iter"] < v["jacobian_rewritten_every_gradient_call"]["user_eval_ms_per_iter"]
+    # `value` is the reference-contract variant (Jacobian rewritten at every gradient call), never the extension
+    head = v["jacobian_rewritten_every_gradient_call"]
+    assert r["config"]["headline_variant"] == "jacobian_rewritten_every_gradient_call"
+    assert abs(r["value"] - head["value"]) < 1e-9 * r["value"] and r["ms_per_step"] == head["ms_per_step"]
+    ext = v["linear_constraints_declared__API_EXTENSION"]
+    assert ext["user_eval_ms_per_iter"] < head["user_eval_ms_per_iter"]
+    # iteration-level roofline: algorithmic bytes per iteration, the user callbacks' share, and the fractions
+    assert r["iteration_bytes"] > r["iteration_bytes_user_callbacks"] > 0
+    assert 0 < r["iteration_frac"] < 1 and 0 < r["iteration_frac_excl_user_callbacks"] < 1
+    # one iteration streams the 42-column panel three times plus the problem's own passes: between 150 and 500
+    # doubles per design variable at c = 32 (the reference's sequence: ~5200)
+    assert 150 < r["iteration_bytes"] / (8 * 1_000_000) < 500
+    assert ext["iteration_bytes"] < head["iteration_bytes"]
+    # the same workload through the user-side boundary (examples/random_convex_amd.cpp), both reduction modes
+    b = r["boundary"]
+    assert b is not None
+    fr, fd = b["reference_semantics"], b["deferred_reductions__API_EXTENSION"]
+    assert fd["host_syncs_per_iter"] < fr["host_syncs_per_iter"]
+    assert fd["host_syncs_per_iter"] <= head["host_syncs_per_iter"] + 0.5
+    assert abs(fr["iteration_bytes"] - head["iteration_bytes"]) < 0.05 * head["iteration_bytes"]
+
+
+@pytest.mark.gpu
+def test_bench_boundary_facade_is_value():
+    out, lines = _run(["--nglobal", "1000000", "--steps", "3", "--warmup", "3", "--repeats", "1",
+                       "--no-cpu-baseline", "--qn-size", "3", "--boundary", "facade"], {}, 900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r["config"]["headline_variant"] == "facade_reference_semantics"
+    assert abs(r["value"] - r["boundary"]["reference_semantics"]["value"]) < 1e-9 * r["value"]
+
+
+def test_host_cpu_budget_respects_affinity_cpu():
+    """The CPU baseline sizes its MPI job from the cores the process may really use (affinity, cgroup quota)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    info = bench.host_cpu_budget()
+    assert 1 <= info["usable"] <= info["affinity"] <= max(info["os_cpu_count"], info["affinity"])
+    if info["cgroup_quota_cpus"] is not None:
+        assert info["usable"] <= max(1, int(info["cgroup_quota_cpus"]))
+    # traffic model of the reference's own sequence (SURVEY 3.4): 5200 doubles per variable at c = 32, k = 10
+    assert abs(bench.reference_traffic_bytes(1, 32, 10) / 8 - (332 + 48 * 32 + 32 * 32 + 450 + 1600 + 200)) < 1e-9

@@ -158,6 +158,40 @@ def test_wgram_vs_numpy(ctx, n, nv):
 
 
 @pytest.mark.parametrize("n", [1, 129, 1000, 70001])
+@pytest.mark.parametrize("nv", [81, 96, 97, 128, 200])
+def test_wgram_wider_than_one_launch(ctx, n, nv):
+    """Panels beyond one launch's 80 columns go by column-block pairs (wgram.hip: k_wgram): the reference has no
+    limit on ncon or on the quasi-Newton width (src/ParOptInteriorPoint.cpp:1935-1950, 2648-2654)."""
+    import paropt_amd as pa
+
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.01 * j) for j in range(nv)]
+    dn = hnp(n, 9, scale=1.0, shift=0.5)
+    P = np.stack([hnp(n, 20 + j, scale=2.0, shift=-1.0 + 0.01 * j) for j in range(nv)], axis=1)
+    ref = P.T @ (dn[:, None] * P)
+    W = pa.wgram(d, V)
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
+    np.testing.assert_array_equal(W, W.T)
+
+
+@pytest.mark.parametrize("nv", [97, 150, 200])
+def test_panel_launchers_wider_than_their_tables(ctx, nv):
+    """mdot / maxpy beyond the 96-entry kernel argument tables are slabbed inside the launchers."""
+    import paropt_amd as pa
+
+    n = 5003
+    x = hvec(ctx, n, 3)
+    V = [hvec(ctx, n, 40 + j, scale=2.0, shift=-1.0) for j in range(nv)]
+    xn = hnp(n, 3)
+    P = np.stack([hnp(n, 40 + j, scale=2.0, shift=-1.0) for j in range(nv)], axis=1)
+    np.testing.assert_allclose(x.mdot(V), P.T @ xn, rtol=0, atol=1e-13 * n * 10)
+    alpha = np.linspace(-1.0, 1.0, nv)
+    y = hvec(ctx, n, 4)
+    y.maxpy(0.5, alpha, V)
+    np.testing.assert_allclose(y.to_numpy(), 0.5 * hnp(n, 4) + P @ alpha, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 129, 1000, 70001])
 @pytest.mark.parametrize("nv", [2, 9, 16, 17, 33, 43, 48, 49, 80])
 def test_wgram_with_preweighted_rhs_column(ctx, n, nv):
     """The last column t is pre-weighted: its row/column hold the plain dots P^T t, the rest is the weighted Gram."""

@@ -9,7 +9,7 @@ shift || true
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 args=("$@")
-if [ ${#args[@]} -eq 0 ]; then args=(--steps 6 --warmup 12 --no-cpu-baseline --repeats 1 --skip-copy-variant); fi
+if [ ${#args[@]} -eq 0 ]; then args=(--steps 6 --warmup 12 --no-cpu-baseline --repeats 1 --skip-extension-variant --boundary builtin); fi
 pass() {  # name, counters...
   local name=$1
   shift

@@ -13,9 +13,9 @@ run() {  # name, command...
       > gpurun_out/bench_under_rocprof_$name.json 2> gpurun_out/prof_$name.err
   rm -f gpurun_out/prof_$name/*_kernel_trace.csv
 }
-run c3 python3 bench.py --steps 20 --warmup 12 --no-cpu-baseline --repeats 1 --skip-copy-variant
-run c2 python3 bench.py --nglobal 10000000 --ncon 8 --qn bfgs --qn-size 20 --problem quadratic --steps 20 --warmup 22 --no-cpu-baseline --repeats 1 --skip-copy-variant
-run c4 python3 bench.py --nglobal 20000000 --ncon 4 --nwcon 1000000 --nw 20 --qn bfgs --steps 20 --warmup 12 --no-cpu-baseline --repeats 1 --skip-copy-variant
+run c3 python3 bench.py --steps 20 --warmup 12 --no-cpu-baseline --repeats 1 --skip-extension-variant --boundary builtin
+run c2 python3 bench.py --nglobal 10000000 --ncon 8 --qn bfgs --qn-size 20 --problem quadratic --steps 20 --warmup 22 --no-cpu-baseline --repeats 1 --skip-extension-variant --boundary builtin
+run c4 python3 bench.py --nglobal 20000000 --ncon 4 --nwcon 1000000 --nw 20 --qn bfgs --steps 20 --warmup 12 --no-cpu-baseline --repeats 1 --skip-extension-variant --boundary builtin
 run c5 python3 tools/bench_tr.py --no-cpu-baseline
 run csr python3 tools/bench_csr.py
 ls -la gpurun_out/prof_c*/

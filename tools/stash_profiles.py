@@ -45,7 +45,7 @@ def main():
                     e["WRITE_SIZE_KB_mean"] = v["WRITE_SIZE"]["mean_per_dispatch"]
                 raw[k] = e
         out = {"command": "bash tools/collect_pmc.sh %s  (rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 6 "
-                          "--warmup 12 --no-cpu-baseline --repeats 1 --skip-copy-variant; one pass per group: FETCH_SIZE | "
+                          "--warmup 12 --no-cpu-baseline --repeats 1 --skip-extension-variant --boundary builtin; one pass per group: FETCH_SIZE | "
                           "WRITE_SIZE | SQ_* | GRBM/SQ_WAVES)" % tag,
                "n": 50000000, "mdot32_algorithmic_bytes": 13200000000, "raw": raw,
                "units": "mean per dispatch; FETCH_SIZE / WRITE_SIZE in KiB; hbm_read_bytes_corrected = 2 * 1024 * FETCH_SIZE "
