@@ -128,6 +128,9 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
             while ranks > 1 and (n % ranks or (n // ranks) % nw or nwcon % ranks):
                 ranks -= 1
         try:
+            # untimed tiny run first: pages in the driver, MKL and MPICH on a fresh box (the first launch was seen to
+            # take seconds longer than the second)
+            run_reference(drv, mpiexec, ranks, 20_000 * ranks, ncon, 2, qn, qn_size, problem, 0, nw, 300)
             t_start = time.time()
             samples = []
             n_probe = max(200_000, n // 25) if nwcon == 0 else n

@@ -477,6 +477,10 @@ int po_tr_get_state(po_tr tr, double *tr_size, int *iter_count, int *subproblem_
                     const double **ck);
 /* the last row of the iteration table (12 numeric columns without the wall time) and its info string */
 int po_tr_get_last_row(po_tr tr, const double **row12, const char **info);
+/* How the two interior-point solves of the latest trust-region iteration ENDED: the last line of each solve's
+ * iteration table (src/ParOptInteriorPoint.cpp:4777-4801; steering / restoration solve, then the QP; empty when the
+ * solve did not run).  Borrowed, valid until the next iteration. */
+int po_tr_get_last_solve_lines(po_tr tr, const char **steering, const char **qp);
 int po_tr_get_history(po_tr tr, const char **text);          /* the paropt.tr table :1406-1438 */
 int po_tr_get_quasi_newton(po_tr tr, po_qn *qn);             /* subproblem->getQuasiNewton() */
 int po_tr_get_model_vectors(po_tr tr, po_vec *xk, po_vec *gk);

@@ -473,6 +473,12 @@ case("tr_csr_convex_n120_c2_chain3s2", "tr", problem="convex", n=120, c=2, chain
      dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05, "tr.tr_max_iterations": 40}))
 case("tr_csr_rosenbrock_n60_chain2", "tr", problem="rosenbrock", n=60, chain_span=2, chain_stride=1,
      dump_vecs_every=10, **dict(tr_common, **{"opt.qn_subspace_size": 10, "tr.tr_max_iterations": 60}))
+# the metric's configuration (config 3 shape: convex objective, c = 32, L-SR1(10)) under the trust-region driver,
+# where L-SR1 makes progress, at n = 1e5 on four MPI ranks; subproblem solves capped at 200 interior-
+# point iterations as the reference's trust-region examples set it
+case("tr_convex_n100000_c32_sr1_r4", "tr", ranks=4, problem="convex", n=100000, c=32, dump_vecs_every=4, vec_stride=50,
+     **dict(tr_common, **{"opt.qn_type": "sr1", "opt.qn_subspace_size": 10, "tr.tr_max_size": 0.5,
+                          "tr.tr_init_size": 0.05, "tr.tr_max_iterations": 12, "opt.max_major_iters": 200}))
 # filter globalisation (filterOptimize :1690-2210)
 case("tr_filter_quadratic_n200_c3", "tr", problem="quadratic", n=200, c=3, dump_vecs_every=10,
      **dict(tr_common, **{"tr.tr_accept_step_strategy": "filter_method"}))

@@ -1066,6 +1066,13 @@ class TrustRegion:
         check(lib.po_tr_get_last_row(self._h, C.byref(row), C.byref(info)))
         return [row[i] for i in range(12)], info.value.decode().split()
 
+    def getLastSolveLines(self):
+        """Last iteration-table line of the steering (or restoration) solve and of the QP solve of the latest
+        trust-region iteration: how each interior-point solve ended."""
+        a, b = C.c_char_p(), C.c_char_p()
+        check(lib.po_tr_get_last_solve_lines(self._h, C.byref(a), C.byref(b)))
+        return (a.value or b"").decode(), (b.value or b"").decode()
+
     def getHistory(self):
         t = C.c_char_p()
         check(lib.po_tr_get_history(self._h, C.byref(t)))

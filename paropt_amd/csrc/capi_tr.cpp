@@ -168,6 +168,12 @@ int po_tr_get_last_row(po_tr tr, const double **row12, const char **info) {
   if (info) *info = tr->tr->row_info.c_str();
   return PO_OK;
 }
+int po_tr_get_last_solve_lines(po_tr tr, const char **steering, const char **qp) {
+  PO_CHECK_PTR(tr);
+  if (steering) *steering = tr->tr->last_solve_line[0].c_str();
+  if (qp) *qp = tr->tr->last_solve_line[1].c_str();
+  return PO_OK;
+}
 int po_tr_get_history(po_tr tr, const char **text) {
   PO_CHECK_PTR(tr);
   PO_CHECK_PTR(text);

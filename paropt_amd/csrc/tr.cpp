@@ -711,6 +711,7 @@ int TrustRegion::minimizeInfeas(std::vector<double> *best_out) {  // :1105-1228
   PO_TRY(ip->resetDesignAndBounds());
   int rc = ip->optimize(nullptr);
   if (rc != 0 && rc != 1) return rc;
+  captureSolveLine(0);
   Vec *step = nullptr;
   ip->getOptimizedPoint(&step, nullptr, nullptr, nullptr);
   if (std::string(o.str("tr_accept_step_strategy")) == "penalty_method" && o.integer("tr_adaptive_gamma_update")) {
@@ -796,6 +797,21 @@ int TrustRegion::sl1qpUpdate(Vec *step, const double *z, Vec *zw, double *infeas
   return PO_OK;
 }
 
+void TrustRegion::captureSolveLine(int which) {
+  const std::string &h = ip->history;
+  std::string last;
+  size_t pos = 0;
+  while (pos < h.size()) {
+    size_t e = h.find('\n', pos);
+    if (e == std::string::npos) e = h.size();
+    size_t q = pos;
+    while (q < e && h[q] == ' ') q++;
+    if (q < e && h[q] >= '0' && h[q] <= '9') last.assign(h, pos, e - pos);
+    pos = e + 1;
+  }
+  last_solve_line[which] = last;
+}
+
 int TrustRegion::optimize() {  // optimize :2365-2384
   PO_TRY(build());
   // tr_use_soc has no effect in the reference either: the only call of isAcceptedBySoc is commented
@@ -840,6 +856,7 @@ int TrustRegion::filterOptimize() {
     PO_TRY(ip->resetDesignAndBounds());
     int rc = ip->optimize(nullptr);
     if (rc != 0 && rc != 1) return rc;
+    captureSolveLine(1);
     // step / z / zw alias the solver's storage, so a restoration solve below replaces them (:1797-1799)
     Vec *step = nullptr;
     const double *z = nullptr;
@@ -978,6 +995,7 @@ int TrustRegion::sl1qpOptimize() {  // :1453-1687
     PO_TRY(ip->resetDesignAndBounds());
     int rc = ip->optimize(nullptr);
     if (rc != 0 && rc != 1) return rc;
+    captureSolveLine(1);
     Vec *step = nullptr, *zw = nullptr;
     const double *z = nullptr;
     ip->getOptimizedPoint(&step, &z, nullptr, nullptr);

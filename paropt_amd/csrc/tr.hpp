@@ -243,6 +243,10 @@ class TrustRegion {
   // zav, zmax, gav, gmax
   double row[12];
   std::string row_info;
+  // last line of the interior point's iteration table in the two subproblem solves of the latest iteration
+  // ([0] steering / restoration solve, [1] the QP): how each solve ended (po_tr_get_last_solve_lines)
+  std::string last_solve_line[2];
+  void captureSolveLine(int which);
 
  private:
   int eig_N, eig_index;

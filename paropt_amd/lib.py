@@ -231,6 +231,7 @@ SIGNATURES = {
         [po_tr, c_double_p, c_int_p, c_int_p, c_int_p, C.POINTER(c_double_p), c_double_p, C.POINTER(c_double_p)],
     ),
     "po_tr_get_last_row": (C.c_int, [po_tr, C.POINTER(c_double_p), C.POINTER(C.c_char_p)]),
+    "po_tr_get_last_solve_lines": (C.c_int, [po_tr, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
     "po_tr_get_history": (C.c_int, [po_tr, C.POINTER(C.c_char_p)]),
     "po_tr_get_quasi_newton": (C.c_int, [po_tr, C.POINTER(po_qn)]),
     "po_tr_get_model_vectors": (C.c_int, [po_tr, C.POINTER(po_vec), C.POINTER(po_vec)]),

@@ -50,13 +50,26 @@ def golden_dir():
     return GOLDEN_DIR
 
 
-# Trajectories whose later iterations are driven by round-off level quantities in the REFERENCE
-# itself (e.g. a penalty parameter rho = numer / (0.7 * infeas) with infeas ~ 1e-14 after an inexact
-# Newton step): compared over the stated number of leading iterations only.
+# How far each short-window golden is compared.  The reference's own later iterations are driven by round-off
+# level quantities in these runs (e.g. a penalty parameter rho = numer / (0.7 * infeas) with infeas ~ 1e-14 after an
+# inexact Newton step; L-SR1 inside the line-search interior point does not converge, SURVEY.md 8d: the steps
+# shrink to 1e-3..1e-6 and the state becomes a round-off artefact), so agreement cannot last for the whole record.
+# tools/agreement_windows.py measures, on the GPU, the first iteration at which a check of
+# tests/test_gpu_ip.py::test_ip_trajectory_golden fails when the window is the whole recorded run; the windows
+# below are that measurement minus a margin of two iterations ("agrees_through" in the comments, recorded length in
+# brackets; integers = counters, quasi-Newton size, pivots, clamp counts, info tokens).
 GOLDEN_WINDOWS = {
-    "ip_convex_hvec_n300_c3": 23,
-    "ip_convex_hvec_noprecon_n200_c2": 15,
-    "ipw_convex_n240_c3_w40_mpc": 15,
+    "ip_convex_hvec_n300_c3": 22,              # agrees through 24 [53]
+    "ip_convex_hvec_noprecon_n200_c2": 14,     # 16 [80]
+    "ipw_convex_n240_c3_w40_mpc": 16,          # state 18, integers 40 [60]
+    # L-SR1 (the quasi-Newton type of the metric's configuration)
+    "ip_convex_n300_c5_sr1": 14,               # 16 [25]
+    "ip_convex_sigma_sr1_n300_c3": 18,         # 20 [25]
+    "ip_convex_n2000_c32_sr1": 20,             # the whole record [20]
+    "ip_convex_n2000_c90_sr1": 20,             # the whole record [20] (panel of 100 columns: collapsed launchers)
+    "ip_convex_n100000_c32_sr1_r4": 15,        # state 17, integers the whole record [20]; n = 1e5 on 4 MPI ranks
+    "ipw_convex_n240_c3_w40_sr1": 22,          # 24 [60]
+    "ipcsr_convex_n200_c2_chain5s3_sr1": 34,   # state 36, integers 46 [60]
 }
 
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from tr_helpers import compare_tr, eig_model, tr_options_from_case
+from tr_helpers import TR_REFERENCE_IRREPRODUCIBLE, compare_tr, eig_model, tr_options_from_case
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def ctx():
     c.close()
 
 
-def run_gpu_tr(ctx, case, python_eig_callback=False):
+def run_gpu_tr(ctx, case, python_eig_callback=False, capture_lines=None):
     import paropt_amd as pa
 
     a = case["args"]
@@ -58,6 +58,8 @@ def run_gpu_tr(ctx, case, python_eig_callback=False):
     def cb(i):
         if i > 0:
             rows.append(tr.getLastRow())
+            if capture_lines is not None:  # how the two subproblem solves of row i - 1 ended
+                capture_lines[i - 1] = tr.getLastSolveLines()
         s = tr.snapshot()
         s["x"] = tr.getModelVectors()[0].to_numpy()
         snaps.append(s)
@@ -65,6 +67,8 @@ def run_gpu_tr(ctx, case, python_eig_callback=False):
     tr.setIterationCallback(cb)
     tr.optimize()
     rows.append(tr.getLastRow())
+    if capture_lines is not None:
+        capture_lines[len(rows) - 1] = tr.getLastSolveLines()
     st = tr.getState()
     x, z, zw = tr.getOptimizedPoint()
     final = dict(iter_count=st["iter_count"], fk=st["fk"], ck=st["ck"], x=x.to_numpy(), z=z)
@@ -93,7 +97,13 @@ TR_INEXACT_ROWS = {
 @pytest.mark.parametrize("name", TR_CASES)
 def test_tr_trajectory_golden(ctx, name):
     g, case = load_golden(name)
+    if name in TR_REFERENCE_IRREPRODUCIBLE:  # only the compared rows are run
+        case["args"]["tr.tr_max_iterations"] = TR_REFERENCE_IRREPRODUCIBLE[name]["rows"]
     tr, rows, snaps, final = run_gpu_tr(ctx, case)
+    if name in TR_REFERENCE_IRREPRODUCIBLE:  # the reference run itself depends on the rank count past these rows
+        nr = TR_REFERENCE_IRREPRODUCIBLE[name]["rows"]
+        assert compare_tr(g, rows, snaps, final, nr, check_snaps=False, check_counts=False) == nr
+        return
     # the eigen-model on the convex objective is the worst conditioned case (gradient ~ 1/(eps+x)^2 and a
     # nonlinear constraint model): tight agreement over 40 iterations, after which 1e-6 differences in
     # the constraint values start to show; its final point is compared through the objective only

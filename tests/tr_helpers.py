@@ -89,7 +89,18 @@ def run_oracle_tr(case, nmax=None):
     return rows, snaps, final
 
 
-def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True, inexact_rows=None):
+# Goldens whose REFERENCE run is not reproducible across MPI rank counts beyond the stated number of rows, so that
+# no implementation can agree with them further.  tr_convex_n100000_c32_sr1_r4 is the metric's configuration (config
+# 3 shape: convex objective, c = 32, L-SR1(10)) under the trust-region driver at n = 1e5: the steering LP of
+# iteration 3 crawls into its 200-iteration cap, and the unmodified reference run on 1 / 2 / 4 ranks prints
+# fobj = 8.70061e+05 / 8.70805e+05 / 8.69399e+05 at iteration 4 and interior-point counts 26/74, 26/73, 26/47 at
+# iteration 1 (oracle/make_golden.py; recorded here on 4 ranks).  Compared: the first `rows` rows of the table to
+# print precision and the accept / reject flags; not the interior-point counts, not the snapshots past the window.
+TR_REFERENCE_IRREPRODUCIBLE = {"tr_convex_n100000_c32_sr1_r4": dict(rows=4)}
+
+
+def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True, inexact_rows=None,
+               check_counts=True):
     """rows/snaps/final of a run (oracle or device) against a golden of the compiled reference.
     inexact_rows (a set of iteration numbers): the info strings of all OTHER rows -- accept / reject and
     quasi-Newton flags, interior-point iteration counts of both subproblem solves -- must be identical; in the
@@ -114,6 +125,8 @@ def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True, 
         rflags = [t for t in rtoks if "/" not in t and not t.isdigit()]
         assert flags == rflags, "flags @%d: %s vs %s" % (k, toks, rtoks)
         exact += int(toks == rtoks)
+        if not check_counts:
+            continue
         if inexact_rows is not None and toks != rtoks:
             assert k in inexact_rows, "info @%d: %s vs %s" % (k, toks, rtoks)
             mine_n = [int(v) for t in toks if "/" in t or t.isdigit() for v in t.split("/")]
@@ -121,7 +134,7 @@ def compare_tr(g, rows, snaps, final, window, frac_exact=0.8, check_snaps=True, 
             assert len(mine_n) == len(ref_n) and max(abs(a - b) for a, b in zip(mine_n, ref_n)) <= 10, (k, toks, rtoks)
     # interior-point iteration counts of the two subproblem solves: bit-exact except where the
     # degenerate steering LP terminates on a round-off level test (see DESIGN.md "Parity")
-    assert exact >= frac_exact * ncmp, "only %d of %d info strings identical" % (exact, ncmp)
+    assert exact >= frac_exact * ncmp or not check_counts, "only %d of %d info strings identical" % (exact, ncmp)
     for k in range(min(ncmp, len(snaps)) if check_snaps else 0):
         p = "tr%03d/" % k
         s = snaps[k]
