@@ -108,6 +108,17 @@ extern "C" int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, c
         }));
         for (int j = 0; j < k; j++) (void)k_fill_hash(cx, Zo[j], n, 7, 100 + c + j, 0, 2.0, -1.0);
       }
+      if (c > 0) {  // the problem's Jacobian rewrite: c columns copied (scaled) in one launch
+        std::vector<double *> dstp;
+        for (int j = 0; j < c; j++) dstp.push_back(const_cast<double *>(P[j]));
+        std::vector<const double *> srcp(P.begin(), P.begin() + c);
+        // (source and destination panels must differ: use the first c/2 columns as sources of the second half)
+        const int h = c / 2;
+        if (h > 0)
+          PO_TRY(T.run("panel_lincomb(c/2 columns)", 8.0 * 2 * h * N, 0.0, [&] {
+            return k_panel_lincomb(cx, dstp.data() + h, -1.0, srcp.data(), 0.0, nullptr, h, n);
+          }));
+      }
       PO_TRY(T.run("kkt_res", 8.0 * (c + 8) * N, 0.0,
                    [&] { return k_kkt_res(cx, b, g->d, P.data(), coef.data(), c, 1e-3, n, t2->d, out.data()); }));
       PO_TRY(T.run("dinv", 8.0 * 6 * N, 0.0, [&] { return k_dinv(cx, b, 1.0, n, t2->d); }));

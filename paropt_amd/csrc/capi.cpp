@@ -76,6 +76,11 @@ int po_ctx_algorithmic_bytes(po_ctx ctx, double *total, double *user) {
 /* tuning aid (not part of the interface): cycle stamps of the producer/consumer Gram kernel's workgroup 0, see
  * PAROPT_AMD_WGRAM_ABLATE=16 in wgram.hip */
 int po_debug_wgram_stamps(double *out8) { return po::wgram_debug_stamps(out8); }
+/* tuning aid (not part of the interface): kernel-variant switch for in-process A/B runs, see core.hpp DbgSwitch */
+int po_debug_set_switch(int id, int value) {
+  po::dbg_switch_set(id, value);
+  return PO_OK;
+}
 
 int po_ctx_set_reduction_batching(po_ctx ctx, int on) {
   PO_CHECK_PTR(ctx);

@@ -25,6 +25,16 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
+static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1};
+int dbg_switch(int id, const char *env, int dflt) {
+  if (id >= 0 && id < SW_COUNT && g_dbg_switch[id] >= 0) return g_dbg_switch[id];
+  const char *e = env ? getenv(env) : nullptr;
+  return e ? atoi(e) : dflt;
+}
+void dbg_switch_set(int id, int value) {
+  if (id >= 0 && id < SW_COUNT) g_dbg_switch[id] = value;
+}
+
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
 static int comm_self_test(Ctx *c);
 

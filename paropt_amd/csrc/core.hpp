@@ -188,6 +188,12 @@ struct BatchScope {
   BatchScope(const BatchScope &) = delete;
   BatchScope &operator=(const BatchScope &) = delete;
 };
+// Kernel-variant switches for A/B measurements inside ONE process (tools/ab_switch.py): the value set through
+// po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
+enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_WGRAM_DEPTH = 2, SW_S2R_VARIANT = 3, SW_SPARE4 = 4,
+                 SW_SPARE5 = 5, SW_SPARE6 = 6, SW_SPARE7 = 7, SW_COUNT = 8 };
+int dbg_switch(int id, const char *env, int dflt);
+void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);
 // `streams` n-sized fp64 operand streams read or written by the launch being issued
 inline void count_bytes(Ctx *c, double streams, int64_t n) {

@@ -438,6 +438,26 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
 }
+// the same with the columns spread over blockIdx.y: every workgroup streams ONE column (a contiguous read and a
+// contiguous write stream per workgroup, like the plain copy kernel) instead of touching all nv columns per row pair
+__global__ void __launch_bounds__(kBlock)
+    panel_lincomb2d_kernel(PtrTableW dst, double a, PtrTable X, double b, PtrTable Y, int has_y, int64_t n) {
+  const int j = blockIdx.y;
+  const double *__restrict__ xp = X.p[j];
+  const double *__restrict__ yp = Y.p[j];
+  double *__restrict__ dp = dst.p[j];
+  PO_PAIR_LOOP(q, n) {
+    const f64x2 xv = ld_stream(xp + 2 * q);
+    double2 r = make_double2(a * xv.x, a * xv.y);
+    if (has_y) {
+      const f64x2 yv = ld_stream(yp + 2 * q);
+      r.x += b * yv.x;
+      r.y += b * yv.y;
+    }
+    st2(dp, q, n, r);
+  }
+}
+
 int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X, double b,
                     const double *const *Y, int nv, int64_t n) {
   if (n <= 0 || nv <= 0) return PO_OK;
@@ -450,7 +470,18 @@ int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X
     for (int j = 0; j < kMaxPanel; j++) d.p[j] = j < w ? dst[j0 + j] : nullptr;
     fill_tables(nullptr, X + j0, w, &ct, &x);
     fill_tables(nullptr, Y ? Y + j0 : nullptr, Y ? w : 0, &ct, &y);
-    PO_LAUNCH(panel_lincomb_kernel, grid_for(c, n), d, a, x, b, y, w, Y ? 1 : 0, n);
+    const int form2d = dbg_switch(SW_LINCOMB_2D, "PAROPT_AMD_LINCOMB_2D", 1);
+    if (form2d && w >= 4) {
+      int gx = (c->num_cu * 8 + w - 1) / w;  // ~8 workgroups per CU in all
+      const int need = grid_for(c, n);
+      if (gx > need) gx = need;
+      if (gx < 1) gx = 1;
+      hipLaunchKernelGGL(panel_lincomb2d_kernel, dim3(gx, w), dim3(kBlock), 0, c->stream, d, a, x, b, y, Y ? 1 : 0, n);
+      c->n_launches++;
+      PO_HIP(hipGetLastError());
+    } else {
+      PO_LAUNCH(panel_lincomb_kernel, grid_for(c, n), d, a, x, b, y, w, Y ? 1 : 0, n);
+    }
   }
   return PO_OK;
 }

@@ -124,6 +124,63 @@ __device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const d
   }
 }
 
+// ---- ROW-SPLIT consumers (producer/consumer form, NG <= kGramRowSplitMaxNG) ------------------------------------
+// Each consumer wave takes two of the tile's eight 16-row steps and ALL NG (NG + 1) / 2 block pairs: every operand
+// is fetched from LDS once per workgroup (24 ds_read_b64 per wave and tile instead of 96 with the output split
+// above), the matrix-instruction count per wave is the same, and the four per-wave partial results are summed
+// through LDS once, at the end of the kernel, in wave order (deterministic).
+constexpr int kGramRowSplitMaxNG = 12;  // NG (NG + 1) / 2 accumulators of 2 VGPRs each must fit beside the operands
+
+template <int NG>
+__device__ __forceinline__ void gram_step_all(const double (&a)[NG], double w, bool tsel,
+                                              double (&acc)[NG * (NG + 1) / 2]) {
+  int q = 0;
+#pragma unroll
+  for (int J = 0; J < NG; J++) {
+    const double bw = a[J] * ((J == NG - 1 && tsel) ? 1.0 : w);
+#pragma unroll
+    for (int I = 0; I <= J; I++) {
+      acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[I], bw, acc[q], 0, 0, 0);
+      q++;
+    }
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void gram_tile_rows(const double *__restrict__ pt, const double *__restrict__ dw, int lane,
+                                               int wave, int tcol, double (&acc)[NG * (NG + 1) / 2]) {
+  const int ci = lane & 3;
+  const int rowoff = ((lane >> 2) & 3) + 4 * (lane >> 4);
+  const double *base = pt + ci * kGramLd + rowoff;
+  const double *dwl = dw + rowoff;
+  const bool tsel = (4 * (NG - 1) + ci == tcol);
+  double a0[NG], a1[NG], w0, w1;
+  gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);      // both steps requested before the first matrix instruction:
+  gram_fetch<NG>(base, dwl, 2 * wave + 1, a1, w1);  // the second fetch lands behind the first step's work
+  gram_step_all<NG>(a0, w0, tsel, acc);
+  gram_step_all<NG>(a1, w1, tsel, acc);
+}
+
+// column-major pair order of gram_step_all: q(I, J) = J (J + 1) / 2 + I
+template <int NG>
+__device__ __forceinline__ void gram_store_rows(const double (&acc)[NG * (NG + 1) / 2], int lane, int wave,
+                                                double *__restrict__ red /* [4][NP * 16] in LDS */) {
+  constexpr int NP = NG * (NG + 1) / 2;
+  int q = 0;
+#pragma unroll
+  for (int J = 0; J < NG; J++) {
+#pragma unroll
+    for (int I = 0; I <= J; I++) {
+      const int p = I * NG - (I * (I - 1)) / 2 + (J - I);  // row-major index of (I, J): the slot layout of gram_store
+      double v = acc[q];
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (((lane >> 2) & 3) == 0) red[(size_t)wave * NP * 16 + p * 16 + (lane >> 4) * 4 + (lane & 3)] = v;
+      q++;
+    }
+  }
+}
+
 template <int NG, int W>
 __device__ __forceinline__ void gram_store(const double (&acc)[GramPlanHolder<NG>::NQ], int lane,
                                            double *__restrict__ partials) {
@@ -313,7 +370,7 @@ __device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *_
   if (pw == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = in ? P.dbuf[R] : (f64x2){0.0, 0.0};
 }
 
-template <int NG, int ZP>
+template <int NG, int ZP, int RS>
 __global__ void __launch_bounds__(512, 1)
     wgram_pc_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
                     double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol,
@@ -391,11 +448,13 @@ __global__ void __launch_bounds__(512, 1)
       g_wgram_stamp[7] = __builtin_amdgcn_s_memrealtime() - st_r0;  // 100 MHz ticks of the whole loop
     }
     __syncthreads();  // matches the consumers' trailing barrier
+    if (RS) __syncthreads();  // ... and the one between their LDS partials and the cross-wave sum
   } else {
     // ------------------------------------------------ consumers ------------------------------------------------
-    double acc[NQ];
+    constexpr int NACC = RS ? NG * (NG + 1) / 2 : NQ;
+    double acc[NACC];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+    for (int q = 0; q < NACC; q++) acc[q] = 0.0;
     unsigned long long sc_wait = 0, sc_work = 0;
     const bool cstamp = (ablate == 16) && blockIdx.x == 0 && wave == 0;
     for (int64_t it = 0; it < nt; it++) {
@@ -404,11 +463,15 @@ __global__ void __launch_bounds__(512, 1)
       const unsigned long long _t1 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
       if (ablate == 1) continue;  // tuning: no matrix work
-      switch (wave) {
-        case 0: gram_tile<NG, 0>(bt, bt + M * kGramLd, lane, tcol, acc); break;
-        case 1: gram_tile<NG, 1>(bt, bt + M * kGramLd, lane, tcol, acc); break;
-        case 2: gram_tile<NG, 2>(bt, bt + M * kGramLd, lane, tcol, acc); break;
-        default: gram_tile<NG, 3>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+      if constexpr (RS) {
+        gram_tile_rows<NG>(bt, bt + M * kGramLd, lane, wave, tcol, acc);
+      } else {
+        switch (wave) {
+          case 0: gram_tile<NG, 0>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+          case 1: gram_tile<NG, 1>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+          case 2: gram_tile<NG, 2>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+          default: gram_tile<NG, 3>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+        }
       }
       if (cstamp) {
         // (the accumulators are consumed only at the end: read one so that the stamp follows the matrix work)
@@ -422,23 +485,32 @@ __global__ void __launch_bounds__(512, 1)
       g_wgram_stamp[0] = sc_wait;
       g_wgram_stamp[1] = sc_work;
     }
-    __syncthreads();
-    switch (wave) {
-      case 0: gram_store<NG, 0>(acc, lane, partials); break;
-      case 1: gram_store<NG, 1>(acc, lane, partials); break;
-      case 2: gram_store<NG, 2>(acc, lane, partials); break;
-      default: gram_store<NG, 3>(acc, lane, partials); break;
+    __syncthreads();  // the last tile has been consumed by every wave: the tile buffers are free
+    if constexpr (RS) {
+      constexpr int NP = NG * (NG + 1) / 2;
+      gram_store_rows<NG>(acc, lane, wave, lds);
+      __syncthreads();
+      for (int slot = tid; slot < NP * 16; slot += 256)
+        partials[(size_t)slot * gridDim.x + blockIdx.x] =
+            ((lds[slot] + lds[NP * 16 + slot]) + lds[2 * NP * 16 + slot]) + lds[3 * NP * 16 + slot];
+    } else {
+      switch (wave) {
+        case 0: gram_store<NG, 0>(acc, lane, partials); break;
+        case 1: gram_store<NG, 1>(acc, lane, partials); break;
+        case 2: gram_store<NG, 2>(acc, lane, partials); break;
+        default: gram_store<NG, 3>(acc, lane, partials); break;
+      }
     }
   }
 }
 
-template <int NG, int ZP>
+template <int NG, int ZP, int RS>
 static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int64_t ntiles,
                              const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out) {
   const size_t lds = (size_t)2 * (4 * NG * kGramLd + kGramTile) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc_kernel<NG, ZP>),
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc_kernel<NG, ZP, RS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -447,7 +519,7 @@ static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv
   if (g > ntiles) g = ntiles;
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
-  hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
+  hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP, RS>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
                      c->d_partials, st, zt, kpend, b0, tcol, ablate);
   c->n_launches++;
   PO_HIP(hipGetLastError());
@@ -510,6 +582,8 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   static const int occ_env = getenv("PAROPT_AMD_WGRAM_OCC") ? atoi(getenv("PAROPT_AMD_WGRAM_OCC")) : 0;
   // PAROPT_AMD_WGRAM_PC=0: the single-role form (every wavefront loads, stages and multiplies) for all widths
   static const bool use_pc = !(getenv("PAROPT_AMD_WGRAM_PC") && atoi(getenv("PAROPT_AMD_WGRAM_PC")) == 0);
+  // PAROPT_AMD_WGRAM_RS=0: consumers split the OUTPUT (block pairs) instead of the tile's rows (A/B switch)
+  const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", 1) != 0;
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \
@@ -519,8 +593,13 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
     constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
     if (NGv <= 16 && use_pc && n >= 4 * kGramTile) {                                                   \
-      if (kpend > 0) PO_TRY((wgram_pc_launch_t<(NGv <= 16 ? NGv : 16), 3>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
-      else PO_TRY((wgram_pc_launch_t<(NGv <= 16 ? NGv : 16), 0>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));              \
+      constexpr int NGc = NGv <= 16 ? NGv : 16;                                                        \
+      if (NGv <= kGramRowSplitMaxNG && row_split) {                                                    \
+        constexpr int NGr = NGv <= kGramRowSplitMaxNG ? NGv : kGramRowSplitMaxNG;                      \
+        if (kpend > 0) PO_TRY((wgram_pc_launch_t<NGr, 3, 1>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+        else PO_TRY((wgram_pc_launch_t<NGr, 0, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));              \
+      } else if (kpend > 0) PO_TRY((wgram_pc_launch_t<NGc, 3, 0>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+      else PO_TRY((wgram_pc_launch_t<NGc, 0, 0>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));                \
     } else if (kpend > 0) {                                                                            \
       if (occ_env == OCCZA) PO_TRY((wgram_launch_t<NGv, 3, OCCZA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
       else PO_TRY((wgram_launch_t<NGv, 3, OCCZ>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));     \

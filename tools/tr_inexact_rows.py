@@ -22,5 +22,5 @@ for name, rows in T.TR_INEXACT_ROWS.items():
     a = case["args"]
     tr, rws, snaps, final = T.run_gpu_tr(ctx, case, capture_lines=lines)
     for k in sorted(rows):
-        print(json.dumps({"golden": name, "row": k, "info": rws[k][1], "steering": lines.get(k, ("", ""))[0],
-                          "qp": lines.get(k, ("", ""))[1]}), flush=True)
+        print(json.dumps({"golden": name, "row": k, "info": rws[k][1], "steering": lines.get(k, ["", ""])[0],
+                          "qp": lines.get(k, ["", ""])[1]}), flush=True)
