@@ -374,9 +374,11 @@ template <int NG, int ZP, int RS>
 __global__ void __launch_bounds__(512, 1)
     wgram_pc_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
                     double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol,
-                    int ablate) {
+                    int ablate, int prio) {
   constexpr int M = 4 * NG;
   constexpr int NQ = GramPlanHolder<NG>::NQ;
+  const bool want_stamps = (ablate & 16) != 0;  // PAROPT_AMD_WGRAM_ABLATE: 16 = cycle stamps, low bits = what is cut
+  ablate &= 15;
   constexpr int kBufDoubles = M * kGramLd + kGramTile;  // panel tile, then the row weights
   extern __shared__ double lds[];                       // two tile buffers
   const int tid = threadIdx.x, lane = tid & 63;
@@ -390,6 +392,11 @@ __global__ void __launch_bounds__(512, 1)
   __syncthreads();
   if (wave >= 4) {
     // ------------------------------------------------ producers ------------------------------------------------
+    // The producers' few vector instructions (addresses, staging) must not queue behind the consumers' matrix
+    // instructions on the shared SIMD: static priority for the whole loop (MI355X_MICROARCH.md, two waves per SIMD)
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
     const int pw = wave - 4;
     const double *colp[NG];
 #pragma unroll
@@ -412,7 +419,7 @@ __global__ void __launch_bounds__(512, 1)
     gram_pc_load<NG, ZP, 2>(P, colp, scol, d, first + 2 * stride, ntiles, n, ilast, lane);
     // step `it` (ring slot it % 3, LDS buffer it % 2): stage tile `it`, reload the slot with tile it + 3, barrier
     unsigned long long st_stage = 0, st_load = 0, st_wait = 0;
-    const bool stamp = (ablate == 16) && blockIdx.x == 0 && wave == 4;
+    const bool stamp = want_stamps && blockIdx.x == 0 && wave == 4;
     const unsigned long long st_c0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long st_r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PO_PC_STEP(R)                                                                                         \
@@ -456,7 +463,7 @@ __global__ void __launch_bounds__(512, 1)
 #pragma unroll
     for (int q = 0; q < NACC; q++) acc[q] = 0.0;
     unsigned long long sc_wait = 0, sc_work = 0;
-    const bool cstamp = (ablate == 16) && blockIdx.x == 0 && wave == 0;
+    const bool cstamp = want_stamps && blockIdx.x == 0 && wave == 0;
     for (int64_t it = 0; it < nt; it++) {
       const unsigned long long _t0 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       __syncthreads();  // tile `it` is staged in buffer it % 2
@@ -514,13 +521,16 @@ static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const int ablate = getenv("PAROPT_AMD_WGRAM_ABLATE") ? atoi(getenv("PAROPT_AMD_WGRAM_ABLATE")) : 0;
+  const int ablate = dbg_switch(SW_SPARE5, "PAROPT_AMD_WGRAM_ABLATE", 0);
   int64_t g = (int64_t)c->num_cu;  // one workgroup per CU
   if (g > ntiles) g = ntiles;
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
+  // producers at raised priority: their address arithmetic no longer queues behind the consumers' matrix
+  // instructions on the shared SIMD (-4 % on the plain form, -1.7 % with the L-SR1 columns formed; 0 switches it off)
+  const int prio = dbg_switch(SW_SPARE4, "PAROPT_AMD_WGRAM_PRIO", 2);
   hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP, RS>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
-                     c->d_partials, st, zt, kpend, b0, tcol, ablate);
+                     c->d_partials, st, zt, kpend, b0, tcol, ablate, prio);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -583,7 +593,10 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // PAROPT_AMD_WGRAM_PC=0: the single-role form (every wavefront loads, stages and multiplies) for all widths
   static const bool use_pc = !(getenv("PAROPT_AMD_WGRAM_PC") && atoi(getenv("PAROPT_AMD_WGRAM_PC")) == 0);
   // PAROPT_AMD_WGRAM_RS=0: consumers split the OUTPUT (block pairs) instead of the tile's rows (A/B switch)
-  const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", 1) != 0;
+  // measured in one process (tools/ab_switch.py, profiles/r03_ab_wgram.txt, n = 50 M, 43 columns): with the L-SR1
+  // columns formed in the pass the row split is 1-2.5 % faster inside the iteration, without them the output split is
+  // 4-6 % faster
+  const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", kpend > 0 ? 1 : 0) != 0;
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \

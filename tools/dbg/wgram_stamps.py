@@ -9,7 +9,7 @@ import paropt_amd as pa
 from paropt_amd.lib import lib
 
 ctx = pa.Context(0)
-n, m = 50_000_000, 43
+n, m = 50_000_000, int(os.environ.get("STAMP_COLS", "43"))
 d = pa.PVec(ctx, n).fill_hash(0, 9, 0, 1.0, 0.5)
 V = [pa.PVec(ctx, n).fill_hash(0, 20 + j, 0, 2.0, -1.0) for j in range(m)]
 for rep in range(3):
