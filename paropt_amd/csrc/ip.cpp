@@ -1502,12 +1502,23 @@ void InteriorPoint::getIterationCounters(int *a, int *b, int *d) {
 }
 
 int InteriorPoint::optimize(const char *checkpoint) {
-  // host mirrors a caller obtained for the solver's vectors (getOptimizedPoint + getArray) stop being live here:
-  // the kernels below do not look at mirrors (po_vec_get_array)
+  // Host mirrors a caller obtained for the solver's vectors (getOptimizedPoint + getArray) are the vectors' data
+  // while they are live (the reference's pointers ARE the data, src/ParOptVec.cpp:212-217): what the caller wrote
+  // through them -- e.g. warm-start multipliers zl / zu for starting_point_strategy = no_start_strategy -- is
+  // uploaded before the first kernel reads it, as po_vec_release_array(v, 1) would.  The mirrors stop being live
+  // here (the kernels below do not look at mirrors): views handed out earlier go stale during the solve and are
+  // refreshed by the next getArray.
   {
     Vec *mine[] = {x, zl, zu, wvar[0], wvar[1], wvar[2], wvar[3], wvar[4]};
-    for (Vec *v : mine)
+    bool any = false;
+    for (Vec *v : mine) {
+      if (v && v->h_live && v->h && v->n > 0) {
+        PO_HIP(hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->n, hipMemcpyHostToDevice, ctx->stream));
+        any = true;
+      }
       if (v) v->h_live = 0;
+    }
+    if (any) PO_HIP(hipStreamSynchronize(ctx->stream));  // the pinned mirrors may be rewritten by the caller at once
   }
   PO_TRY(createQuasiNewton());
   const double abs_res_tol = options.real("abs_res_tol");

@@ -1004,3 +1004,38 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
             assert abs(sa["fobj"] - sb["fobj"]) <= 1e-9 * max(1.0, abs(sb["fobj"])), switch
             np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-7, atol=1e-9, err_msg=switch)
             np.testing.assert_allclose(sa["z"], sb["z"], rtol=1e-6, atol=1e-9, err_msg=switch)
+
+
+def test_host_writes_through_get_array_reach_the_solver(ctx):
+    """multipliers seeded through getOptimizedPoint() + getArray() (the reference's pointer contents are
+    used directly with starting_point_strategy = no_start_strategy, src/ParOptInteriorPoint.cpp:4577-4585) must not
+    be dropped when optimize() ends the live state of the solver's mirrors."""
+    import paropt_amd as pa
+
+    n, c = 3001, 2
+    opts = {"qn_subspace_size": 5, "abs_res_tol": 1e-8, "starting_point_strategy": "no_start_strategy",
+            "max_major_iters": 3, "write_output_frequency": 0}
+
+    def first_norms(seed_host):
+        prob = pa.SeparableProblem(ctx, "quadratic", n, c)
+        ip = pa.InteriorPoint(prob, opts)
+        x, z, zl, zu = ip.getOptimizedPoint()
+        if seed_host:
+            a = zl.getArray()  # live host view of the solver's own vector
+            a[:] = 0.25 + 0.5 * np.arange(n) / n
+            b = zu.getArray()
+            b[:] = 0.75
+        else:
+            zl.from_numpy(0.25 + 0.5 * np.arange(n) / n)
+            zu.from_numpy(np.full(n, 0.75))
+        seen = []
+        ip.setIterationCallback(lambda k: seen.append(ip.snapshot()["norms"].copy()) if k == 0 else None)
+        ip.optimize()
+        return seen[0], ip.getOptimizedPoint()[0].to_numpy()
+
+    n_host, x_host = first_norms(True)
+    n_dev, x_dev = first_norms(False)
+    expect_zl = np.linalg.norm(0.25 + 0.5 * np.arange(n) / n)
+    assert abs(n_host[1] - expect_zl) <= 1e-12 * expect_zl and abs(n_host[2] - 0.75 * np.sqrt(n)) <= 1e-12 * n
+    np.testing.assert_array_equal(n_host, n_dev)
+    np.testing.assert_array_equal(x_host, x_dev)
