@@ -143,6 +143,11 @@ extern "C" int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, c
         return k_solve2r(cx, b, t->d, nullptr, dinv->d, coef.data(), coef2.data(), P.data(), m, 1e-3, 0.95, n, px->d,
                          pzl->d, pzu->d, va->d, c, out.data(), coef2.data(), rx->d, 1.0);
       }));
+      PO_TRY(T.run("solve2r(refine, recomputed, + merit sums)", 8.0 * (m + 13) * N, 0.0, [&] {
+        return k_solve2r(cx, b, t->d, nullptr, dinv->d, coef.data(), coef2.data(), P.data(), m, 1e-3, 0.95, n, px->d,
+                         pzl->d, pzu->d, va->d, c, out.data(), coef2.data(), rx->d, 1.0, 0, nullptr, 0, 0.0, g->d,
+                         out.data());
+      }));
       PO_TRY(T.run("solve2(refine)", 8.0 * (m + 14) * N, 0.0, [&] {
         return k_solve2(cx, b, t->d, dinv->d, coef.data(), P.data(), m, 1e-3, 1, 0.95, n, px->d, pzl->d, pzu->d,
                         out.data(), nullptr, rx->d, 1.0, t2->d, va->d, c);

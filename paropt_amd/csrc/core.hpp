@@ -311,7 +311,10 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar = nullptr,
               const double *rx = nullptr, double diag = 0.0,  // t2 == nullptr: t2 recomputed from (ar, rx, diag)
               int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
-              const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0);  // P[j] - b0v vs[j], j < nvirt
+              const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0,  // P[j] - b0v vs[j], j < nvirt
+              // g != nullptr (recomputed right-hand side form only): merit_out[10] = {S10, S01, S11, ppos, pneg, g.px,
+              // px.px | max_x, max_z | max|px|} of the final step (see solve2r_kernel) instead of `out`
+              const double *g = nullptr, double *merit_out = nullptr);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

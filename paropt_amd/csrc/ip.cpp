@@ -43,6 +43,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   vA_valid = false;
   inexact_newton_step = false;
   merit_cache_valid = false;
+  fuse_merit = !getenv("PAROPT_AMD_NO_FUSED_MERIT");
   nhvec = 0;
   nw = p->nwcon;
   has_w = false;
@@ -727,6 +728,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  fused_merit_valid = false;
   // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
   // the axpy pass starts (A-part = p.z = alpha_A; Z-part = d0 M^-1 d0 Z^T px with Z^T px = ptpx),
   // so the same pass over P also emits the right-hand side t' of the refinement solve.
@@ -806,15 +808,27 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     }
   } else if (refine_pass && step_deferred) {
     step_deferred = false;
+    // the same sweep takes the sums the complementarity check of scaleKKTStep and the merit derivative need of the
+    // final step (see solve2r_kernel): no separate pass over the step afterwards
+    const bool take_merit = fuse_merit && recompute_rhs && !cl && dbg_switch(SW_SPARE6, nullptr, 1) != 0;
+    const double *gm = take_merit ? g->d : nullptr;
+    double *mo = take_merit ? fused_merit : nullptr;
     if (virt) {
       const std::vector<double> a1v = to_virt(alpha_first), a2v = to_virt(alpha), crv = to_virt(coef_first);
       PO_TRY(k_solve2r(ctx, bounds(), tvec->d, nullptr, Dinv->d, a1v.data(), a2v.data(), Pv.data(), m, beta_mu, tau, n,
                        px->d, pzl->d, pzu->d, vA->d, c, step_mins, crv.data(), rx->d, diag_first, k, Sp.data(), k,
-                       b0z));
+                       b0z, gm, mo));
     } else {
       PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
                        alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins,
-                       coef_first.data(), rx->d, diag_first));
+                       coef_first.data(), rx->d, diag_first, 0, nullptr, 0, 0.0, gm, mo));
+    }
+    if (take_merit) {
+      after_reduce(ctx, [this] {
+        step_mins[0] = fused_merit[7];
+        step_mins[1] = fused_merit[8];
+        fused_merit_valid = true;
+      });
     }
   } else {
     if (!refine_pass) step_deferred = false;
@@ -1034,7 +1048,20 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
     }
   }
   double out[9], wprod = 0.0;
-  if (!has_w) {
+  if (!has_w && fused_merit_valid && iterate_logs_valid) {
+    // everything was taken by the refinement pass: the complementarity at the scaled step is
+    // S00 + ax S10 + az S01 + ax az S11 with S00 / the bound count from the residual pass of this iterate
+    out[0] = comp_prod + ax * fused_merit[0] + az * fused_merit[1] + ax * az * fused_merit[2];
+    out[1] = comp_count;
+    merit_cache[0] = iterate_logs[0];
+    merit_cache[1] = iterate_logs[1];
+    merit_cache[2] = fused_merit[3];
+    merit_cache[3] = fused_merit[4];
+    merit_cache[4] = fused_merit[5];
+    merit_cache[5] = fused_merit[6];
+    merit_cache[6] = fused_merit[9];
+    merit_cache_valid = true;
+  } else if (!has_w) {
     // one pass also yields the merit pieces and the step norm the line search is about to ask for
     PO_TRY(k_comp_merit(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, g->d, n, out));
     for (int i = 0; i < 7; i++) merit_cache[i] = out[2 + i];
@@ -1283,6 +1310,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
     }
     PO_TRY(batch.end());
+    trial_logs[0] = sums[0];  // barrier sums at the point xt holds now
+    trial_logs[1] = sums[1];
+    trial_logs_valid = true;
     neval++;
     if (fail_obj) {
       fprintf(stderr, "ParOpt: Evaluation failed during line search, trying new point\n");
@@ -1345,6 +1375,9 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
       int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
       userEnd();
       PO_TRY(batch.end());
+      trial_logs[0] = sums[0];
+      trial_logs[1] = sums[1];
+      trial_logs_valid = true;
       neval++;
       if (fail_obj) {
         fprintf(stderr, "ParOpt: Evaluation failed during line search\n");
@@ -1413,9 +1446,17 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     double sums[2];
     PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums));  // (not in a batch: sums is local)
     s_qn_from_trial = false;
+    trial_logs[0] = sums[0];
+    trial_logs[1] = sums[1];
+    trial_logs_valid = true;
   }
   // the accepted trial point IS the new design point (same clamp, same arithmetic)
   std::swap(x->d, xt->d);
+  // ... and its barrier sums are those of the new iterate (trial_kernel and the merit pass take them alike)
+  iterate_logs[0] = trial_logs[0];
+  iterate_logs[1] = trial_logs[1];
+  iterate_logs_valid = trial_logs_valid;
+  trial_logs_valid = false;
   if (eval_obj_con) {
     userBegin();
     int fail = prob->evalObjCon(x, &fobj, cvals.data());
@@ -1560,6 +1601,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const std::string start = options.str("starting_point_strategy");
   niter = neval = ngeval = nhvec = 0;
   residual_cached = false;
+  iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
   history.clear();
   phase_names.clear();
   phase_seconds.clear();

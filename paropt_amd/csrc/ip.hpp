@@ -164,6 +164,13 @@ class InteriorPoint {
   // scaleKKTStep: {pos log, neg log, ppos, pneg, g.px, px.px, max|px|}
   double merit_cache[7];
   bool merit_cache_valid;
+  // the same pieces taken by the refinement pass itself (k_solve2r with g): {S10, S01, S11, ppos, pneg, g.px, px.px,
+  // max_x, max_z, max|px|}; the log-barrier sums of the iterate are those of the accepted trial point of the last
+  // line search (same kernel arithmetic, same element order as the separate pass took them)
+  double fused_merit[10] = {0};
+  bool fused_merit_valid = false, fuse_merit = true;
+  double trial_logs[2] = {0, 0}, iterate_logs[2] = {0, 0};
+  bool trial_logs_valid = false, iterate_logs_valid = false;
   int gatherCounts(int64_t mine, std::vector<int64_t> *all);
   int solutionFileOffsets(int64_t *nvars_total, int64_t *var_off, int64_t *nw_total, int64_t *w_off);
   int ensureHdiag();

@@ -69,6 +69,7 @@ int InteriorPoint::solveKKTAlpha(const double *bx, double alpha, const Dense &b,
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  fused_merit_valid = false;
   tdots_valid = false;
   residual_fused = false;
   vA_valid = false;
@@ -140,6 +141,7 @@ int InteriorPoint::solveKKTAlphaW(const double *bx, double alpha, const Dense &b
   }
   ptpx_valid = true;
   merit_cache_valid = false;
+  fused_merit_valid = false;
   tdots_valid = false;
   residual_fused = false;
   vA_valid = false;

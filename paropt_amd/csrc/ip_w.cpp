@@ -171,6 +171,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  fused_merit_valid = false;
   tdots_valid = false;        // (consumed above by a refinement pass; set again below by a fused first pass)
   if (!refine_pass) residual_fused = false;
   // (dx, dzw) = K0^-1 (d1 + P alpha, d2) = K0^-1 (d1, d2) + K0^-1 (P alpha, 0), and the second term comes from

@@ -1076,15 +1076,27 @@ __global__ void __launch_bounds__(kBlock)
 // than storing and re-reading the first step.
 // RECT != 0: the refinement right-hand side t2 is recomputed as well (from the residual coefficients ar, rx and diag,
 // as solve2_dots_kernel formed it when it took its panel products), so the first pass stores nothing at all.
-template <int RECT>
+// MERIT != 0: the pass also takes, for the FINAL step it has in registers, every sum scaleKKTStep's complementarity
+// check (computeCompStep :2825-2923) and evalMeritInitDeriv (:3652-3714) need of it -- the separate pass over
+// (x, lb, ub, zl, zu, px, pzl, pzu, g) disappears for one more input stream (g).  The complementarity at the scaled
+// step is a polynomial in the two step lengths,
+//   sum_L (zl + az pzl)(x - lb + ax px) + sum_U (zu + az pzu)(ub - x - ax px) = S00 + ax S10 + az S01 + ax az S11,
+// so the pass needs no step length: S00 is the complementarity product of the iterate (known from the residual
+// pass), S10 = sum_L zl px - sum_U zu px, S01 = sum_L pzl (x - lb) + sum_U pzu (ub - x), S11 = sum_L pzl px -
+// sum_U pzu px.  sums {S10, S01, S11, ppos, pneg, g.px, px.px}, max {|px|}; the log-barrier sums of the iterate
+// come from the accepted trial point of the previous line search (trial_kernel: same elements, same order).
+template <int RECT, int MERIT>
 __global__ void __launch_bounds__(kBlock)
     solve2r_kernel(Bounds b, const double *__restrict__ t1, const double *__restrict__ t2,
                    const double *__restrict__ dinv, CoefTable a1, CoefTable a2, CoefTable ar, PtrTable P, int nv,
                    double beta_mu, double tau, const double *__restrict__ rx, double diag, int64_t n,
                    double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
-                   double *__restrict__ va, int nca, int ca0, VirtCols vc, double *__restrict__ partials) {
-  __shared__ double sm[4 * 2];
+                   double *__restrict__ va, int nca, int ca0, VirtCols vc, const double *__restrict__ g,
+                   double *__restrict__ partials) {
+  __shared__ double sm[4 * 8];
   double mins[2] = {1.0, 1.0};
+  double ms[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double mx[1] = {0.0};
   PO_PAIR_LOOP(q, n) {
     const double2 zero2 = make_double2(0.0, 0.0);
     double2 a1A = zero2, a2A = zero2, acc1 = zero2, acc2 = zero2, arA = zero2, accr = zero2;
@@ -1128,21 +1140,58 @@ __global__ void __launch_bounds__(kBlock)
     st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
     max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
     if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+    if (MERIT) {
+      const double2 gv = ld2(g, q, n);
+      if (e0.L) {
+        ms[0] += _zl.x * s0.px;
+        ms[1] += s0.pzl * e0.xl;
+        ms[2] += s0.pzl * s0.px;
+        if (s0.px > 0.0) ms[3] += s0.px / e0.xl; else ms[4] += s0.px / e0.xl;
+      }
+      if (e1.L) {
+        ms[0] += _zl.y * s1.px;
+        ms[1] += s1.pzl * e1.xl;
+        ms[2] += s1.pzl * s1.px;
+        if (s1.px > 0.0) ms[3] += s1.px / e1.xl; else ms[4] += s1.px / e1.xl;
+      }
+      if (e0.U) {
+        ms[0] -= _zu.x * s0.px;
+        ms[1] += s0.pzu * e0.xu;
+        ms[2] -= s0.pzu * s0.px;
+        if (s0.px > 0.0) ms[4] -= s0.px / e0.xu; else ms[3] -= s0.px / e0.xu;
+      }
+      if (e1.U) {
+        ms[0] -= _zu.y * s1.px;
+        ms[1] += s1.pzu * e1.xu;
+        ms[2] -= s1.pzu * s1.px;
+        if (s1.px > 0.0) ms[4] -= s1.px / e1.xu; else ms[3] -= s1.px / e1.xu;
+      }
+      ms[5] += gv.x * s0.px + gv.y * s1.px;
+      ms[6] += s0.px * s0.px + s1.px * s1.px;
+      mx[0] = fmax(mx[0], fmax(fabs(s0.px), fabs(s1.px)));
+    }
   }
-  block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
+  if (MERIT) {  // slots: 7 sums, 2 minima, 1 maximum
+    block_reduce_store<7, OP_SUM>(ms, partials, 0, sm);
+    block_reduce_store<2, OP_MIN>(mins, partials, 7, sm);
+    block_reduce_store<1, OP_MAX>(mx, partials, 9, sm);
+  } else {
+    block_reduce_store<2, OP_MIN>(mins, partials, 0, sm);
+  }
 }
 
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
-              double diag, int ca0, const double *const *vs, int nvirt, double b0v) {
-  count_bytes(c, nv + nvirt + 11 + (va ? 1 : 0), n);
+              double diag, int ca0, const double *const *vs, int nvirt, double b0v, const double *g,
+              double *merit_out) {
+  count_bytes(c, nv + nvirt + 11 + (va ? 1 : 0) + (g ? 1 : 0), n);
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
   }
   const int grid = grid_for(c, n, 3);
-  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PO_TRY(ensure_partials(c, (size_t)grid * 10));
   PtrTable pt;
   CoefTable ct1, ct2, ctr;
   fill_tables(a1, P, nv, &ct1, &pt);
@@ -1170,11 +1219,18 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
       set_error("k_solve2r: neither the refinement right-hand side nor the data to recompute it");
       return PO_ERR_ARG;
     }
-    PO_LAUNCH((solve2r_kernel<1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, c->d_partials);
+    if (g && merit_out) {
+      PO_LAUNCH((solve2r_kernel<1, 1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px,
+                pzl, pzu, va, nca, ca0, vc, g, c->d_partials);
+      // {7 sums, 2 minima, 1 maximum} land in merit_out[0..10); the minima are copied to `out` by the caller's hook
+      (void)out;
+      return reduce_finish(c, grid, 7, 2, 1, merit_out);
+    }
+    PO_LAUNCH((solve2r_kernel<1, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
+              pzu, va, nca, ca0, vc, g, c->d_partials);
   } else {
-    PO_LAUNCH((solve2r_kernel<0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, c->d_partials);
+    PO_LAUNCH((solve2r_kernel<0, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
+              pzu, va, nca, ca0, vc, g, c->d_partials);
   }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }

@@ -970,7 +970,7 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
 
     def run(env):
         for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS",
-                  "PAROPT_AMD_VIRTUAL_Z"):
+                  "PAROPT_AMD_VIRTUAL_Z", "PAROPT_AMD_NO_FUSED_MERIT"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -996,7 +996,11 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
     # ... PAROPT_AMD_NO_RECOMPUTE_RHS: only the step is recomputed, the refinement right-hand side is stored;
     # PAROPT_AMD_VIRTUAL_Z (off by default: slower): the L-SR1 columns Z_j = Y_j - b0 S_j are never formed in HBM,
     # the Gram pass and both solve passes form them in registers
-    for switch in ("PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS", "PAROPT_AMD_VIRTUAL_Z"):
+    # PAROPT_AMD_NO_FUSED_MERIT (round 3): the complementarity / merit sums of the final step in their own pass
+    # (comp_merit_kernel) instead of inside the refinement pass (solve2r_kernel<.,1>, polynomial form of the
+    # complementarity at the scaled step): sums in another order, same counters, state to 1e-9
+    for switch in ("PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS", "PAROPT_AMD_VIRTUAL_Z",
+                   "PAROPT_AMD_NO_FUSED_MERIT"):
         other, xs = run([switch])
         assert len(other) == len(base), switch
         for sa, sb in list(zip(base, other))[:window]:
