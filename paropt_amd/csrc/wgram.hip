@@ -155,8 +155,14 @@ __device__ __forceinline__ void gram_tile_rows(const double *__restrict__ pt, co
   const double *dwl = dw + rowoff;
   const bool tsel = (4 * (NG - 1) + ci == tcol);
   double a0[NG], a1[NG], w0, w1;
-  gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);      // both steps requested before the first matrix instruction:
-  gram_fetch<NG>(base, dwl, 2 * wave + 1, a1, w1);  // the second fetch lands behind the first step's work
+  // The two steps' operands are 16 doubles apart: left alone, hipcc merges each pair of fetches into one
+  // ds_read2_b64, whose banking ((addr / 4) mod 32, MI355X_MICROARCH.md LDS table) makes the [column][row] stride of
+  // 136 doubles a two-way conflict (SQ_LDS_BANK_CONFLICT = a third of the LDS-active cycles, r03 PMC pass).  The
+  // second step's offset is laundered through an empty asm so that the fetches stay separate ds_read_b64.
+  int off1 = 16 * (2 * wave + 1);  // (an opaque OFFSET: laundering the pointer itself would lose its LDS address
+  asm volatile("" : "+v"(off1));   //  space and turn the fetches into flat loads)
+  gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);        // both steps requested before the first matrix instruction:
+  gram_fetch<NG>(base + off1, dwl + off1, 0, a1, w1);  // the second fetch lands behind the first step's work
   gram_step_all<NG>(a0, w0, tsel, acc);
   gram_step_all<NG>(a1, w1, tsel, acc);
 }
@@ -593,10 +599,10 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // PAROPT_AMD_WGRAM_PC=0: the single-role form (every wavefront loads, stages and multiplies) for all widths
   static const bool use_pc = !(getenv("PAROPT_AMD_WGRAM_PC") && atoi(getenv("PAROPT_AMD_WGRAM_PC")) == 0);
   // PAROPT_AMD_WGRAM_RS=0: consumers split the OUTPUT (block pairs) instead of the tile's rows (A/B switch)
-  // measured in one process (tools/ab_switch.py, profiles/r03_ab_wgram.txt, n = 50 M, 43 columns): with the L-SR1
-  // columns formed in the pass the row split is 1-2.5 % faster inside the iteration, without them the output split is
-  // 4-6 % faster
-  const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", kpend > 0 ? 1 : 0) != 0;
+  // measured in one process (tools/ab_switch.py, profiles/r03_ab_wgram.txt, n = 50 M, 43 columns): the row split is
+  // 8 % faster than the output split on the plain form (2.93 vs 3.18 ms = 0.75 of the HBM peak) and 2 % with the L-SR1
+  // columns formed in the pass -- once its operand fetches stay ds_read_b64 (see gram_tile_rows)
+  const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", 1) != 0;
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \

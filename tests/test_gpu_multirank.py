@@ -316,6 +316,14 @@ def test_rccl_plumbing_single_rank(monkeypatch):
     kind, nred, ngat = ctx.comm_info()
     assert kind == 1 and nred > 10 and ngat > 10
     assert ref.comm_info() == (0, 0, 0)
+    # po_ctx_comm_init_rccl ran its known-answer collectives (they are not counted above) and checked the library's
+    # version against the ABI the hand-declared prototypes assume
+    ver = C.c_int()
+    check(lib.po_rccl_version(C.byref(ver)))
+    assert ver.value >= 21000, ver.value
+    lat = ctx.bench_collective(64, True, 10)
+    assert lat["median_us"] > 0 and ctx.comm_info()[1] == nred  # the latency probe is not counted either
+    np.testing.assert_array_equal(ctx.allreduce(np.array([3.0, 4.0]), "sum"), [3.0, 4.0])
 
 
 def _worker_ckpt(rank, world, port, q, args, opts, path):
@@ -398,3 +406,70 @@ def test_two_rank_solution_file_is_the_references_single_file(name, tmp_path):
         ip = pa.InteriorPoint(pa.SeparableProblem(ctx, a["problem"], a["n"], a["c"]), opts)
         ip.readSolutionFile(path)
         np.testing.assert_array_equal(ip.getOptimizedPoint()[0].to_numpy(), pm[1 + 5 * c: 1 + 5 * c + nv])
+
+
+def _worker_user(rank, world, port, q, deferred):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    # po_ctx_allreduce: the MPI_Allreduce of user code, through the context's communicator
+    a = ctx.allreduce(np.array([rank + 1.0, 10.0 * (rank + 1)]), "sum")
+    b = ctx.allreduce(np.array([rank + 1.0]), "min")
+    c = ctx.allreduce(np.array([rank + 1.0]), "max")
+    assert list(a) == [world * (world + 1) / 2, 10.0 * world * (world + 1) / 2] and b[0] == 1.0 and c[0] == world
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                       "librandom_convex_user.so")
+    user = pa.UserLibraryProblem(ctx, lib, 30011, 5)
+    if deferred:
+        user.setDeferredReductions(True)
+    ip = pa.InteriorPoint(user, {"qn_type": "bfgs", "qn_subspace_size": 6, "abs_res_tol": 1e-8,
+                                 "start_affine_multiplier_min": 0.01, "max_major_iters": 15,
+                                 "write_output_frequency": 0})
+    ip.optimize()
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    xs = [None] * world
+    dist.all_gather_object(xs, (user.offset, x))
+    if rank == 0:
+        q.put((ip.getIterationCounters(), ip.getObjective()[0],
+               np.concatenate([v for _, v in sorted(xs, key=lambda t: t[0])])))
+    dist.barrier()
+    user.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("deferred", [False, True])
+def test_user_library_problem_on_two_ranks(deferred):
+    """The user-side problem of examples/random_convex_amd.cpp sharded over two ranks (its rank-local objective parts
+    summed by po_ctx_allreduce, or -- deferred -- by po_ctx_reduce_device inside the solver's batch) against the
+    same problem on one rank."""
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                       "librandom_convex_user.so")
+    user = pa.UserLibraryProblem(ctx, lib, 30011, 5)
+    ip = pa.InteriorPoint(user, {"qn_type": "bfgs", "qn_subspace_size": 6, "abs_res_tol": 1e-8,
+                                 "start_affine_multiplier_min": 0.01, "max_major_iters": 15,
+                                 "write_output_frequency": 0})
+    ip.optimize()
+    ref = (ip.getIterationCounters(), ip.getObjective()[0], ip.getOptimizedPoint()[0].to_numpy())
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_user, args=(r, 2, port, q, deferred)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0] == ref[0]
+    assert abs(got[1] - ref[1]) <= 1e-9 * max(1.0, abs(ref[1]))
+    np.testing.assert_allclose(got[2], ref[2], rtol=0, atol=1e-7)
+    user.close()
