@@ -470,9 +470,26 @@ int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X
     for (int j = 0; j < kMaxPanel; j++) d.p[j] = j < w ? dst[j0 + j] : nullptr;
     fill_tables(nullptr, X + j0, w, &ct, &x);
     fill_tables(nullptr, Y ? Y + j0 : nullptr, Y ? w : 0, &ct, &y);
-    const int form2d = dbg_switch(SW_LINCOMB_2D, "PAROPT_AMD_LINCOMB_2D", 1);
-    if (form2d && w >= 4) {
-      int gx = (c->num_cu * 8 + w - 1) / w;  // ~8 workgroups per CU in all
+    // A/B (profiles/r03_ab_lincomb.txt): all columns per row pair (0, default), one column per blockIdx.y (1) and one
+    // launch per column (2) all copy at 5.1-6.2 TB/s with the same run-to-run spread; the best samples of each sit on
+    // the copy ceiling measured in the same process (6.15 TB/s)
+    const int form2d = dbg_switch(SW_LINCOMB_2D, "PAROPT_AMD_LINCOMB_2D", 0);
+    if (form2d == 2) {  // one launch per column (A/B: the plain 1-D copy shape)
+      for (int j = 0; j < w; j++) {
+        PtrTableW d1;
+        PtrTable x1, y1;
+        for (int q = 0; q < kMaxPanel; q++) {
+          d1.p[q] = d.p[j];
+          x1.p[q] = x.p[j];
+          y1.p[q] = y.p[j];
+        }
+        hipLaunchKernelGGL(panel_lincomb2d_kernel, dim3(grid_for(c, n), 1), dim3(kBlock), 0, c->stream, d1, a, x1, b, y1,
+                           Y ? 1 : 0, n);
+        c->n_launches++;
+      }
+      PO_HIP(hipGetLastError());
+    } else if (form2d && w >= 4) {
+      int gx = (c->num_cu * dbg_switch(SW_SPARE7, "PAROPT_AMD_LINCOMB_BPC", 8) + w - 1) / w;  // ~8 workgroups per CU in all
       const int need = grid_for(c, n);
       if (gx > need) gx = need;
       if (gx < 1) gx = 1;
