@@ -256,7 +256,10 @@ int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, 
 int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
                      double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
-                     double az, double *acz, double az_acz);
+                     double az, double *acz, double az_acz,
+                     // lean step (pxs != nullptr): pzl / pzu are not read but formed from the design step pxs, the
+                     // old point xold and the old multipliers with the barrier term of the step's solve
+                     const double *pxs = nullptr, const double *xold = nullptr, double beta_mu_step = 0.0);
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);
@@ -315,6 +318,8 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               // g != nullptr (recomputed right-hand side form only): merit_out[10] = {S10, S01, S11, ppos, pneg, g.px,
               // px.px | max_x, max_z | max|px|} of the final step (see solve2r_kernel) instead of `out`
               const double *g = nullptr, double *merit_out = nullptr);
+// (pzl, pzu) of a lean step as vectors: [L] (rzl - zl px) / (x - lb), [U] (rzu + zu px) / (ub - x)
+int k_form_pz(Ctx *c, const Bounds &b, const double *px, double beta_mu, int64_t n, double *pzl, double *pzu);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)
 int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const double *pzu, double a,
                       double eps, int use_lower, int use_upper, const double *rx, const double *va,

@@ -44,6 +44,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   inexact_newton_step = false;
   merit_cache_valid = false;
   fuse_merit = !getenv("PAROPT_AMD_NO_FUSED_MERIT");
+  lean_step = !getenv("PAROPT_AMD_NO_LEAN_STEP");
   nhvec = 0;
   nw = p->nwcon;
   has_w = false;
@@ -412,9 +413,11 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       // the bound multipliers take their step in the same pass (see kkt_res_update_kernel); A^T z follows the dense
       // multiplier step by recurrence unless it has just been rebuilt from the new multipliers
       const double az_acz = (acz_mode && upd->acz_follow && !acz_rebuilt) ? upd->az : 0.0;
+      // (lean step: px and the old point -- xt after the swap of computeStepAndUpdate -- instead of pzl / pzu)
       PO_TRY(k_kkt_res_update(ctx, bounds(), g->d, A.data(), zc.data(), acz_mode ? 0 : (int)A.size(), beta_mu, n,
                               rx->d, out, yqn_complete->d, zl->d, pzl->d, zu->d, pzu->d, upd->a, upd->eps, vA->d,
-                              upd->az, acz_mode ? acz->d : nullptr, az_acz));
+                              upd->az, acz_mode ? acz->d : nullptr, az_acz, pz_stored ? nullptr : px->d,
+                              pz_stored ? nullptr : xt->d, step_beta_mu));
     } else {
       PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
                        yqn_complete ? yqn_complete->d : nullptr));
@@ -729,6 +732,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
   fused_merit_valid = false;
+  pz_stored = true;
   // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
   // the axpy pass starts (A-part = p.z = alpha_A; Z-part = d0 M^-1 d0 Z^T px with Z^T px = ptpx),
   // so the same pass over P also emits the right-hand side t' of the refinement solve.
@@ -813,14 +817,22 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     const bool take_merit = fuse_merit && recompute_rhs && !cl && dbg_switch(SW_SPARE6, nullptr, 1) != 0;
     const double *gm = take_merit ? g->d : nullptr;
     double *mo = take_merit ? fused_merit : nullptr;
+    // lean step: (pzl, pzu) stay in registers; their only consumer left, the multiplier update, re-forms them
+    const bool lean = lean_step && lean_step_allowed && take_merit && iterate_logs_valid &&
+                      dbg_switch(SW_S2R_VARIANT, nullptr, 1) != 0;
+    double *pzl_out = lean ? nullptr : pzl->d, *pzu_out = lean ? nullptr : pzu->d;
+    if (lean) {
+      pz_stored = false;
+      step_beta_mu = beta_mu;
+    }
     if (virt) {
       const std::vector<double> a1v = to_virt(alpha_first), a2v = to_virt(alpha), crv = to_virt(coef_first);
       PO_TRY(k_solve2r(ctx, bounds(), tvec->d, nullptr, Dinv->d, a1v.data(), a2v.data(), Pv.data(), m, beta_mu, tau, n,
-                       px->d, pzl->d, pzu->d, vA->d, c, step_mins, crv.data(), rx->d, diag_first, k, Sp.data(), k,
+                       px->d, pzl_out, pzu_out, vA->d, c, step_mins, crv.data(), rx->d, diag_first, k, Sp.data(), k,
                        b0z, gm, mo));
     } else {
       PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
-                       alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d, pzu->d, vA->d, c, step_mins,
+                       alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl_out, pzu_out, vA->d, c, step_mins,
                        coef_first.data(), rx->d, diag_first, 0, nullptr, 0, 0.0, gm, mo));
     }
     if (take_merit) {
@@ -933,6 +945,10 @@ int InteriorPoint::computeKKTStepWithRefinement(double mu, bool use_qn, double t
 
 int InteriorPoint::checkKKTStep(int iteration, double mu) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
+  if (!pz_stored) {  // lean step: materialise the bound-multiplier steps exactly as the update will form them
+    PO_TRY(k_form_pz(ctx, bounds(), px->d, step_beta_mu, n, pzl->d, pzu->d));
+    pz_stored = true;
+  }
   const bool seq_lin = options.integer("sequential_linear_method");
   int kq = 0;
   std::vector<const double *> Pq = panel(qn && !seq_lin, &kq);
@@ -1410,6 +1426,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // The bound-multiplier step and the first bracket of y_qn ride in the residual pass of the new point when that
   // pass follows anyway (kkt_res_update_kernel): nothing in between reads zl / zu.
   const bool fuse_upd = fast_yqn && fuse_mult_update;
+  if (!pz_stored && !fuse_upd) {
+    set_error("internal: lean step without the fused multiplier update");
+    return PO_ERR_ARG;
+  }
   MultUpdate upd;
   upd.a = upd.az = alpha * sz;
   upd.eps = eps;
@@ -1831,7 +1851,12 @@ int InteriorPoint::optimize(const char *checkpoint) {
     PO_TRY(setup_rc);
     phaseEnd("setup_kkt");
     if (!mehrotra) {
-      PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
+      // every consumer of (pzl, pzu) after this solve is the fused multiplier update of computeStepAndUpdate
+      lean_step_allowed = qn && use_qnu && use_qn && !diagonal_quasi_newton_step && analytic_panel_dots &&
+                          fuse_mult_update && !use_hvec_product && !use_diag_hessian && !seq_lin;
+      const int step_rc = computeKKTStepWithRefinement(barrier_param, use_qn, tau);
+      lean_step_allowed = false;
+      PO_TRY(step_rc);
     } else {
       // affine (mu = 0) predictor step, probed all the way to the boundary (:4956-5009)
       PO_TRY(computeKKTStepWithRefinement(0.0, use_qn, 1.0));

@@ -169,6 +169,12 @@ class InteriorPoint {
   // line search (same kernel arithmetic, same element order as the separate pass took them)
   double fused_merit[10] = {0};
   bool fused_merit_valid = false, fuse_merit = true;
+  // "lean step" (round 3): in the plain quasi-Newton iteration the refinement pass stores px only; the bound-
+  // multiplier steps are re-formed from it inside the multiplier update (kkt_res_update_kernel) -- two output streams
+  // of the refinement pass less.  lean_step_allowed is set by optimize() around the step computation of an iteration
+  // whose every later consumer of (pzl, pzu) is that update; pz_stored says whether the vectors hold the current step.
+  bool lean_step = true, lean_step_allowed = false, pz_stored = true;
+  double step_beta_mu = 0.0;
   double trial_logs[2] = {0, 0}, iterate_logs[2] = {0, 0};
   bool trial_logs_valid = false, iterate_logs_valid = false;
   int gatherCounts(int64_t mine, std::vector<int64_t> *all);

@@ -1153,8 +1153,10 @@ __global__ void __launch_bounds__(kBlock)
     Step3 s1 = solve2_elem<1>(e1, tw.y + dv.y * acc2.y, beta_mu, f1.px, f1.pzl, f1.pzu);
     if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
     st2(px, q, n, make_double2(s0.px, s1.px));
-    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
-    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    if (pzl) {  // (nullptr: lean step, the multiplier update recomputes them: kkt_res_update_kernel)
+      st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+      st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    }
     max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
     if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
     if (MERIT) {
@@ -1202,7 +1204,7 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
               double diag, int ca0, const double *const *vs, int nvirt, double b0v, const double *g,
               double *merit_out) {
-  count_bytes(c, nv + nvirt + 11 + (va ? 1 : 0) + (g ? 1 : 0), n);
+  count_bytes(c, nv + nvirt + 9 + (pzl ? 2 : 0) + (va ? 1 : 0) + (g ? 1 : 0), n);
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -1887,6 +1889,27 @@ int k_update_mult_yqn(Ctx *c, double *zl, const double *pzl, double *zu, const d
   return PO_OK;
 }
 
+// lean step: (pzl, pzu) from the design step by the first-solve formula, as kkt_res_update_kernel forms them in
+// registers -- for the consumers that want them as vectors (checkKKTStep)
+__global__ void __launch_bounds__(kBlock)
+    form_pz_kernel(Bounds b, const double *__restrict__ px, double beta_mu, int64_t n, double *__restrict__ pzl,
+                   double *__restrict__ pzu) {
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 pv = ld2(px, q, n);
+    const Step3 t0 = solve2_elem<0>(e0, pv.x, beta_mu, 0.0, 0.0, 0.0);
+    const Step3 t1 = solve2_elem<0>(e1, pv.y, beta_mu, 0.0, 0.0, 0.0);
+    st2(pzl, q, n, make_double2(t0.pzl, t1.pzl));
+    st2(pzu, q, n, make_double2(t0.pzu, t1.pzu));
+  }
+}
+int k_form_pz(Ctx *c, const Bounds &b, const double *px, double beta_mu, int64_t n, double *pzl, double *pzu) {
+  if (n <= 0) return PO_OK;
+  count_bytes(c, 8, n);
+  PO_LAUNCH(form_pz_kernel, grid_for(c, n), b, px, beta_mu, n, pzl, pzu);
+  return PO_OK;
+}
+
 // update_mult_yqn_kernel and kkt_res_kernel (with its y_qn completion) in ONE pass, run after the gradient of the new
 // point is known: the bound multipliers take their step here (nothing between the two original launches reads them:
 // the problem callbacks see x and the dense multipliers only), the first bracket of y_qn is formed from the OLD
@@ -1899,12 +1922,34 @@ __global__ void __launch_bounds__(kBlock)
                           int64_t n, double *__restrict__ rx, double *__restrict__ yqn, double *__restrict__ zl,
                           const double *__restrict__ pzl, double *__restrict__ zu, const double *__restrict__ pzu,
                           double a, double eps, const double *__restrict__ va, double az, double *__restrict__ acz,
-                          double az_acz, double *__restrict__ partials) {
+                          double az_acz, const double *__restrict__ pxs, const double *__restrict__ xold,
+                          double beta_mu_step, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[3] = {0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     const double2 _x = ld2(b.x, q, n), _lb = ld2(b.lb, q, n), _ub = ld2(b.ub, q, n);
+    // pxs != nullptr ("lean step"): the refinement pass did not store the bound-multiplier steps; they are formed
+    // here from the design step px, the OLD point (xold) and the old multipliers by the first-solve formula
+    // pzl = [L] (rzl - zl px) / (x - lb), pzu = [U] (rzu + zu px) / (ub - x) -- which the refined values equal up to the
+    // round-off the refinement itself corrects (two output streams of the refinement pass saved)
+    double2 lean_pl = make_double2(0.0, 0.0), lean_pu = lean_pl;
+    if (pxs) {
+      const double2 pv = ld2(pxs, q, n), xo = ld2(xold, q, n);
+      const double2 zlo = ld2(zl, q, n), zuo = ld2(zu, q, n);
+      const BE o0 = bound_elem(xo.x, _lb.x, _ub.x, zlo.x, zuo.x, b.max_bound, b.use_lower, b.use_upper);
+      BE o1 = bound_elem(xo.y, _lb.y, _ub.y, zlo.y, zuo.y, b.max_bound, b.use_lower, b.use_upper);
+      if (2 * q + 1 >= n) {
+        o1.L = false;
+        o1.U = false;
+        o1.xl = 1.0;
+        o1.xu = 1.0;
+      }
+      const Step3 t0 = solve2_elem<0>(o0, pv.x, beta_mu_step, 0.0, 0.0, 0.0);
+      const Step3 t1 = solve2_elem<0>(o1, pv.y, beta_mu_step, 0.0, 0.0, 0.0);
+      lean_pl = make_double2(t0.pzl, t1.pzl);
+      lean_pu = make_double2(t0.pzu, t1.pzu);
+    }
     const double2 r0 = ld2(rx, q, n), w = ld2(va, q, n), gv = ld2(g, q, n);
     // first bracket, as update_mult_yqn_kernel
     double2 y = make_double2(__fma_rn(az, w.x, r0.x), __fma_rn(az, w.y, r0.y));
@@ -1916,7 +1961,7 @@ __global__ void __launch_bounds__(kBlock)
     }
     double2 _zl = make_double2(0.0, 0.0), _zu = _zl;
     if (b.use_lower) {
-      const double2 zo = ld2(zl, q, n), p = ld2(pzl, q, n);
+      const double2 zo = ld2(zl, q, n), p = pxs ? lean_pl : ld2(pzl, q, n);
       y.x = __dsub_rn(y.x, zo.x);
       y.y = __dsub_rn(y.y, zo.y);
       _zl = make_double2(clamp_elem(__fma_rn(a, p.x, zo.x), true, 0.0, false, 0.0, eps),
@@ -1927,7 +1972,7 @@ __global__ void __launch_bounds__(kBlock)
       _zl = ld2(zl, q, n);
     }
     if (b.use_upper) {
-      const double2 zo = ld2(zu, q, n), p = ld2(pzu, q, n);
+      const double2 zo = ld2(zu, q, n), p = pxs ? lean_pu : ld2(pzu, q, n);
       y.x = __dadd_rn(y.x, zo.x);
       y.y = __dadd_rn(y.y, zo.y);
       _zu = make_double2(clamp_elem(__fma_rn(a, p.x, zo.x), true, 0.0, false, 0.0, eps),
@@ -1975,11 +2020,13 @@ __global__ void __launch_bounds__(kBlock)
 int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
                      double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
-                     double az, double *acz, double az_acz) {
+                     double az, double *acz, double az_acz, const double *pxs, const double *xold,
+                     double beta_mu_step) {
   if (nc > kMaxPanel) {
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
-    return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz);
+    return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz,
+                            pxs, xold, beta_mu_step);
   }
   count_bytes(c, 14 + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
   const int grid = grid_for(c, n, 3);
@@ -1988,7 +2035,7 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
   PO_LAUNCH(kkt_res_update_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz,
-            az_acz, c->d_partials);
+            az_acz, pxs, xold, beta_mu_step, c->d_partials);
   return reduce_finish(c, grid, 8, 0, 3, out);
 }
 

@@ -130,6 +130,8 @@ __device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const d
 // above), the matrix-instruction count per wave is the same, and the four per-wave partial results are summed
 // through LDS once, at the end of the kernel, in wave order (deterministic).
 constexpr int kGramRowSplitMaxNG = 12;  // NG (NG + 1) / 2 accumulators of 2 VGPRs each must fit beside the operands
+constexpr int kGramRowSplitMinNG = 5;   // narrow panels (<= 16 columns) are nowhere near the LDS / matrix limits: they
+                                        // keep the output split (and with it round 2's summation order)
 
 template <int NG>
 __device__ __forceinline__ void gram_step_all(const double (&a)[NG], double w, bool tsel,
@@ -613,7 +615,7 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
     if (NGv <= 16 && use_pc && n >= 4 * kGramTile) {                                                   \
       constexpr int NGc = NGv <= 16 ? NGv : 16;                                                        \
-      if (NGv <= kGramRowSplitMaxNG && row_split) {                                                    \
+      if (NGv >= kGramRowSplitMinNG && NGv <= kGramRowSplitMaxNG && row_split) {                       \
         constexpr int NGr = NGv <= kGramRowSplitMaxNG ? NGv : kGramRowSplitMaxNG;                      \
         if (kpend > 0) PO_TRY((wgram_pc_launch_t<NGr, 3, 1>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
         else PO_TRY((wgram_pc_launch_t<NGr, 0, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));              \

@@ -970,7 +970,7 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
 
     def run(env):
         for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS",
-                  "PAROPT_AMD_VIRTUAL_Z", "PAROPT_AMD_NO_FUSED_MERIT"):
+                  "PAROPT_AMD_VIRTUAL_Z", "PAROPT_AMD_NO_FUSED_MERIT", "PAROPT_AMD_NO_LEAN_STEP"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -984,9 +984,13 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
         return sn, ip.getOptimizedPoint()[0].to_numpy()
 
     base, xb = run([])
-    plain_upd, xu = run(["PAROPT_AMD_NO_FUSED_UPDATE"])
-    assert len(base) == len(plain_upd) >= 10
-    for sa, sb in zip(base, plain_upd):
+    # (the bit-for-bit statement is about the fused multiplier update alone: both runs store the bound-multiplier
+    # steps -- the lean step of round 3, which needs the fused update, re-forms them with other round-off)
+    stored, xs0 = run(["PAROPT_AMD_NO_LEAN_STEP"])
+    plain_upd, xu = run(["PAROPT_AMD_NO_LEAN_STEP", "PAROPT_AMD_NO_FUSED_UPDATE"])
+    assert len(base) == len(stored) == len(plain_upd) >= 10
+    xb_lean, xb = xb, xs0
+    for sa, sb in zip(stored, plain_upd):
         np.testing.assert_array_equal(sa["counters"], sb["counters"])
         assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
         np.testing.assert_array_equal(sa["norms"], sb["norms"])
@@ -999,8 +1003,11 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
     # PAROPT_AMD_NO_FUSED_MERIT (round 3): the complementarity / merit sums of the final step in their own pass
     # (comp_merit_kernel) instead of inside the refinement pass (solve2r_kernel<.,1>, polynomial form of the
     # complementarity at the scaled step): sums in another order, same counters, state to 1e-9
+    # PAROPT_AMD_NO_LEAN_STEP (round 3): the refinement pass stores the bound-multiplier steps (pzl, pzu) instead of
+    # leaving them to be re-formed from px inside the multiplier update (they differ by the round-off the refinement
+    # corrects)
     for switch in ("PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS", "PAROPT_AMD_VIRTUAL_Z",
-                   "PAROPT_AMD_NO_FUSED_MERIT"):
+                   "PAROPT_AMD_NO_FUSED_MERIT", "PAROPT_AMD_NO_LEAN_STEP"):
         other, xs = run([switch])
         assert len(other) == len(base), switch
         for sa, sb in list(zip(base, other))[:window]:
