@@ -129,7 +129,7 @@ __device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const d
 // is fetched from LDS once per workgroup (24 ds_read_b64 per wave and tile instead of 96 with the output split
 // above), the matrix-instruction count per wave is the same, and the four per-wave partial results are summed
 // through LDS once, at the end of the kernel, in wave order (deterministic).
-constexpr int kGramRowSplitMaxNG = 12;  // NG (NG + 1) / 2 accumulators of 2 VGPRs each must fit beside the operands
+constexpr int kGramRowSplitMaxNG = 14;  // NG (NG + 1) / 2 accumulators of 2 VGPRs each must fit beside the operands
 constexpr int kGramRowSplitMinNG = 5;   // narrow panels (<= 16 columns) are nowhere near the LDS / matrix limits: they
                                         // keep the output split (and with it round 2's summation order)
 
@@ -163,10 +163,17 @@ __device__ __forceinline__ void gram_tile_rows(const double *__restrict__ pt, co
   // second step's offset is laundered through an empty asm so that the fetches stay separate ds_read_b64.
   int off1 = 16 * (2 * wave + 1);  // (an opaque OFFSET: laundering the pointer itself would lose its LDS address
   asm volatile("" : "+v"(off1));   //  space and turn the fetches into flat loads)
-  gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);        // both steps requested before the first matrix instruction:
-  gram_fetch<NG>(base + off1, dwl + off1, 0, a1, w1);  // the second fetch lands behind the first step's work
-  gram_step_all<NG>(a0, w0, tsel, acc);
-  gram_step_all<NG>(a1, w1, tsel, acc);
+  if constexpr (NG <= 12) {
+    gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);        // both steps requested before the first matrix instruction:
+    gram_fetch<NG>(base + off1, dwl + off1, 0, a1, w1);  // the second fetch lands behind the first step's work
+    gram_step_all<NG>(a0, w0, tsel, acc);
+    gram_step_all<NG>(a1, w1, tsel, acc);
+  } else {  // wider panels: the accumulators leave no room for both steps' operands
+    gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);
+    gram_step_all<NG>(a0, w0, tsel, acc);
+    gram_fetch<NG>(base + off1, dwl + off1, 0, a0, w0);
+    gram_step_all<NG>(a0, w0, tsel, acc);
+  }
 }
 
 // column-major pair order of gram_step_all: q(I, J) = J (J + 1) / 2 + I
