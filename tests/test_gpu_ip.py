@@ -227,6 +227,15 @@ SWEEP = [
     ("convex", 300, 2, "bfgs", 5, {"use_diag_hessian": True}, (60, 5, 0, 0, 60)),
     ("convex", 640, 3, "bfgs", 6, {"use_hvec_product": True, "gmres_subspace_size": 8, "nk_switch_tol": 1e3,
                                    "max_gmres_rtol": 1.0}, None),
+    # panels wider than one launch of the kernels (c + k > 80: blocked Gram; > 96: collapsed panel sums) on the
+    # branches that take other kernels than the plain quasi-Newton iteration (which has reference-run goldens)
+    ("convex", 900, 97, "bfgs", 4, {"barrier_strategy": "mehrotra_predictor_corrector"}, None),
+    ("quadratic", 700, 101, "bfgs", 3, {"use_line_search": False, "norm_type": "l2"}, None),
+    ("convex", 1000, 90, "bfgs", 5, {}, (100, 8, 0, 2, 100)),       # sparse constraints + 100 panel columns
+    ("convex", 800, 99, "bfgs", 4, {"use_diag_hessian": True}, None),
+    ("convex", 640, 98, "bfgs", 3, {"use_hvec_product": True, "gmres_subspace_size": 6, "nk_switch_tol": 1e3,
+                                    "max_gmres_rtol": 1.0}, None),
+    ("quadratic", 600, 60, "bfgs", 15, {}, None),                   # 60 + 30 = 90 columns: blocked Gram, fused passes
 ]
 
 

@@ -189,3 +189,31 @@ def test_trust_region_over_csr_sparse_constraints(ctx):
     st = tr.getState()
     assert st["iter_count"] == otr.iter_count
     np.testing.assert_allclose(tr.getOptimizedPoint()[0].to_numpy(), sub.xk, rtol=0, atol=1e-6)
+
+
+def test_trust_region_with_a_panel_wider_than_one_launch(ctx):
+    """c + k = 70 + 2 * 15 = 100 panel columns under the trust-region driver (subproblem evaluations, steering LP and
+    QP solves all take the slabbed / blocked / collapsed forms of the panel kernels) against the oracle's driver."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+    from oracle import tr_oracle as tro
+
+    n, c, m = 400, 70, 15
+    opts = {"tr_init_size": 0.1, "tr_max_iterations": 8, "qn_subspace_size": m, "output_file": "", "tr_output_file": ""}
+    tr = pa.TrustRegion(pa.SeparableProblem(ctx, "quadratic", n, c), opts)
+    rows = []
+    tr.setIterationCallback(lambda i: rows.append(tr.getLastRow()) if i > 0 else None)
+    tr.optimize()
+    rows.append(tr.getLastRow())
+    ops = po.VecOps(po.SelfComm())
+    sub = tro.QuadraticSubproblem(po.SepProblem("quadratic", n, c), po.LBFGS(n, m, ops, "skip_negative_curvature"))
+    otr = tro.TrustRegion(sub, po.InteriorPoint(sub, {}), {"tr_init_size": 0.1, "tr_max_iterations": 8})
+    otr.optimize()
+    st = tr.getState()
+    assert st["iter_count"] == otr.iter_count
+    assert abs(st["fk"] - sub.fk) <= 1e-8 * max(1.0, abs(sub.fk))
+    np.testing.assert_allclose(tr.getOptimizedPoint()[0].to_numpy(), sub.xk, rtol=0, atol=1e-6)
+    # interior-point iteration counts of both subproblem solves of every iteration
+    mine = [t for _, t in rows]
+    ref = [list(t["info"]) for t in otr.trace]
+    assert mine == ref, (mine, ref)

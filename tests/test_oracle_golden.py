@@ -10,7 +10,8 @@ bookkeeping (counters, quasi-Newton size, update return codes, info tokens) bit-
 import numpy as np
 import pytest
 
-from conftest import (GOLDEN_WINDOWS, golden_names, golden_vec_view, golden_window, ip_options_from_case,
+from conftest import (GOLDEN_WINDOWS_ORACLE as GOLDEN_WINDOWS, golden_names, golden_vec_view,
+                      oracle_window as golden_window, ip_options_from_case,
                       load_golden)
 from oracle import paropt_oracle as po
 
