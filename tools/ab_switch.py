@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--qn", default="sr1")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--problem", default="convex")
+    ap.add_argument("--nwcon", type=int, default=0, help="iter: sparse weighting constraints (config 4)")
+    ap.add_argument("--nw", type=int, default=20)
     a = ap.parse_args()
     import paropt_amd as pa
     from paropt_amd.lib import lib
@@ -53,7 +56,9 @@ def main():
                         res[vi].setdefault(row["kernel"], []).append(row["avg_ms"])
     else:
         W, K = 12, 20
-        prob = pa.SeparableProblem(ctx, "convex", a.n, a.c, 0)
+        prob = pa.SeparableProblem(ctx, a.problem, a.n, a.c, 0)
+        if a.nwcon > 0:
+            prob.setWeighting(a.nwcon, a.nw, 0, 0)
         prob.setLinearConstraints(False)
         opts = {"qn_type": a.qn, "qn_subspace_size": a.k, "abs_res_tol": 1e-30, "start_affine_multiplier_min": 0.01,
                 "max_major_iters": W + K, "write_output_frequency": 0}
