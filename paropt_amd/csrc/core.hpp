@@ -317,7 +317,9 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0,  // P[j] - b0v vs[j], j < nvirt
               // g != nullptr (recomputed right-hand side form only): merit_out[10] = {S10, S01, S11, ppos, pneg, g.px,
               // px.px | max_x, max_z | max|px|} of the final step (see solve2r_kernel) instead of `out`
-              const double *g = nullptr, double *merit_out = nullptr);
+              const double *g = nullptr, double *merit_out = nullptr,
+              // t1 == nullptr: Dinv (diagonal dinv_diag) and t1 re-formed from the bound data and rx in registers
+              double dinv_diag = 0.0);
 // (pzl, pzu) of a lean step as vectors: [L] (rzl - zl px) / (x - lb), [U] (rzu + zu px) / (ub - x)
 int k_form_pz(Ctx *c, const Bounds &b, const double *px, double beta_mu, int64_t n, double *pzl, double *pzu);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)

@@ -45,6 +45,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   merit_cache_valid = false;
   fuse_merit = !getenv("PAROPT_AMD_NO_FUSED_MERIT");
   lean_step = !getenv("PAROPT_AMD_NO_LEAN_STEP");
+  recompute_dt = !getenv("PAROPT_AMD_NO_RECOMPUTE_DT");
   nhvec = 0;
   nw = p->nwcon;
   has_w = false;
@@ -539,9 +540,12 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   // pre-weighted, column, so that P^T t -- the mdot pass at the head of solveKKT -- comes out of the pass over P
   // that the Schur complements need anyway.
   const bool fuse_t = rhs_mu && fused_tdots && !has_w && c + (qn && use_qn && !diag_only ? qn->size() : 0) > 0;
+  t_is_plain_dinv_d1 = false;
   if (fuse_t) {
     PO_TRY(k_dinv_d1(ctx, bounds(), b0 + sigma, use_hdiag ? hdiag->d : nullptr, rx->d,
                      options.real("rel_bound_barrier") * (*rhs_mu), n, Dinv->d, tvec->d));
+    t_is_plain_dinv_d1 = !use_hdiag;
+    t0_diag = b0 + sigma;
   } else {
     PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   }
@@ -695,6 +699,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     need_panel();
     PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
   }
+  if (!refine_pass) first_t_recomputable = have_t0 && t_is_plain_dinv_d1;  // tvec / Dinv are dinv_d1's for this mu
   if (!refine_pass) t0_valid = false;  // tvec is overwritten by the passes below
   tdots_valid = false;
   // yz = G^-1 (d3 - A yx0)   (:2150-2159)
@@ -821,19 +826,23 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     const bool lean = lean_step && lean_step_allowed && take_merit && iterate_logs_valid &&
                       dbg_switch(SW_S2R_VARIANT, nullptr, 1) != 0;
     double *pzl_out = lean ? nullptr : pzl->d, *pzu_out = lean ? nullptr : pzu->d;
+    // Dinv and the first right-hand side t re-formed in registers from data the pass loads anyway (same bits)
+    const bool redo_dt = recompute_dt && recompute_rhs && first_t_recomputable &&
+                         dbg_switch(SW_WGRAM_DEPTH, nullptr, 1) != 0;
+    const double *t1p = redo_dt ? nullptr : tvec->d;
     if (lean) {
       pz_stored = false;
       step_beta_mu = beta_mu;
     }
     if (virt) {
       const std::vector<double> a1v = to_virt(alpha_first), a2v = to_virt(alpha), crv = to_virt(coef_first);
-      PO_TRY(k_solve2r(ctx, bounds(), tvec->d, nullptr, Dinv->d, a1v.data(), a2v.data(), Pv.data(), m, beta_mu, tau, n,
+      PO_TRY(k_solve2r(ctx, bounds(), t1p, nullptr, Dinv->d, a1v.data(), a2v.data(), Pv.data(), m, beta_mu, tau, n,
                        px->d, pzl_out, pzu_out, vA->d, c, step_mins, crv.data(), rx->d, diag_first, k, Sp.data(), k,
-                       b0z, gm, mo));
+                       b0z, gm, mo, t0_diag));
     } else {
-      PO_TRY(k_solve2r(ctx, bounds(), tvec->d, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
+      PO_TRY(k_solve2r(ctx, bounds(), t1p, recompute_rhs ? nullptr : xt->d, Dinv->d, alpha_first.data(),
                        alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl_out, pzu_out, vA->d, c, step_mins,
-                       coef_first.data(), rx->d, diag_first, 0, nullptr, 0, 0.0, gm, mo));
+                       coef_first.data(), rx->d, diag_first, 0, nullptr, 0, 0.0, gm, mo, t0_diag));
     }
     if (take_merit) {
       after_reduce(ctx, [this] {

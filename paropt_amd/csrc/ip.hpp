@@ -173,6 +173,10 @@ class InteriorPoint {
   // multiplier steps are re-formed from it inside the multiplier update (kkt_res_update_kernel) -- two output streams
   // of the refinement pass less.  lean_step_allowed is set by optimize() around the step computation of an iteration
   // whose every later consumer of (pzl, pzu) is that update; pz_stored says whether the vectors hold the current step.
+  // tvec / Dinv hold exactly what dinv_d1_kernel formed for (t0_diag, t0_mu) from the bound data and rx: a pass that
+  // loads those anyway may re-form them in registers instead of reading them (k_solve2r with t1 == nullptr)
+  bool t_is_plain_dinv_d1 = false, first_t_recomputable = false, recompute_dt = true;
+  double t0_diag = 0.0;
   bool lean_step = true, lean_step_allowed = false, pz_stored = true;
   double step_beta_mu = 0.0;
   double trial_logs[2] = {0, 0}, iterate_logs[2] = {0, 0};

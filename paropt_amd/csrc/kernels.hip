@@ -1109,7 +1109,7 @@ __global__ void __launch_bounds__(kBlock)
                    double beta_mu, double tau, const double *__restrict__ rx, double diag, int64_t n,
                    double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                    double *__restrict__ va, int nca, int ca0, VirtCols vc, const double *__restrict__ g,
-                   double *__restrict__ partials) {
+                   double dinv_diag, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double mins[2] = {1.0, 1.0};
   double ms[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1135,7 +1135,18 @@ __global__ void __launch_bounds__(kBlock)
     acc2.y += a2A.y;
     if (va) st2(va, q, n, make_double2(a2A.x + a1A.x, a2A.y + a1A.y));  // A^T pz of both solves
     PO_LOAD_BOUNDS(b, q, n);
-    const double2 tv = ld2(t1, q, n), dv = ld2(dinv, q, n);
+    double2 tv, dv;
+    if (t1) {
+      tv = ld2(t1, q, n);
+      dv = ld2(dinv, q, n);
+    } else {
+      // t1 == nullptr (RECT form): Dinv and t = Dinv o d1 of the first solve are re-formed from the bound data and rx
+      // this pass loads anyway, exactly as dinv_d1_kernel formed them (same expressions: same bits) -- two input
+      // streams less
+      const double2 r0 = ld2(rx, q, n);
+      dv = make_double2(dinv_elem(e0, dinv_diag), dinv_elem(e1, dinv_diag));
+      tv = make_double2(dv.x * d1_elem(e0, r0.x, beta_mu), dv.y * d1_elem(e1, r0.y, beta_mu));
+    }
     const Step3 f0 = solve2_elem<0>(e0, tv.x + dv.x * acc1.x, beta_mu, 0.0, 0.0, 0.0);
     Step3 f1 = solve2_elem<0>(e1, tv.y + dv.y * acc1.y, beta_mu, 0.0, 0.0, 0.0);
     if (!_has2) f1.px = f1.pzl = f1.pzu = 0.0;
@@ -1203,8 +1214,12 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
               double diag, int ca0, const double *const *vs, int nvirt, double b0v, const double *g,
-              double *merit_out) {
-  count_bytes(c, nv + nvirt + 9 + (pzl ? 2 : 0) + (va ? 1 : 0) + (g ? 1 : 0), n);
+              double *merit_out, double dinv_diag) {
+  count_bytes(c, nv + nvirt + 7 + (t1 ? 2 : 0) + (pzl ? 2 : 0) + (va ? 1 : 0) + (g ? 1 : 0), n);
+  if (!t1 && (t2 != nullptr || !rx)) {
+    set_error("k_solve2r: Dinv / t can only be re-formed in the recomputed right-hand side form");
+    return PO_ERR_ARG;
+  }
   if (nv > kMaxPanel) {
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -1240,16 +1255,16 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
     }
     if (g && merit_out) {
       PO_LAUNCH((solve2r_kernel<1, 1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px,
-                pzl, pzu, va, nca, ca0, vc, g, c->d_partials);
+                pzl, pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
       // {7 sums, 2 minima, 1 maximum} land in merit_out[0..10); the minima are copied to `out` by the caller's hook
       (void)out;
       return reduce_finish(c, grid, 7, 2, 1, merit_out);
     }
     PO_LAUNCH((solve2r_kernel<1, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, g, c->d_partials);
+              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
   } else {
     PO_LAUNCH((solve2r_kernel<0, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, g, c->d_partials);
+              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
   }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }

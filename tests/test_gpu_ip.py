@@ -979,7 +979,8 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
 
     def run(env):
         for k in ("PAROPT_AMD_NO_FUSED_UPDATE", "PAROPT_AMD_NO_RECOMPUTE", "PAROPT_AMD_NO_RECOMPUTE_RHS",
-                  "PAROPT_AMD_VIRTUAL_Z", "PAROPT_AMD_NO_FUSED_MERIT", "PAROPT_AMD_NO_LEAN_STEP"):
+                  "PAROPT_AMD_VIRTUAL_Z", "PAROPT_AMD_NO_FUSED_MERIT", "PAROPT_AMD_NO_LEAN_STEP",
+                  "PAROPT_AMD_NO_RECOMPUTE_DT"):
             monkeypatch.delenv(k, raising=False)
         for k in env:
             monkeypatch.setenv(k, "1")
@@ -1005,6 +1006,16 @@ def test_write_saving_fusions_against_their_plain_forms(monkeypatch, problem, qn
         np.testing.assert_array_equal(sa["norms"], sb["norms"])
         np.testing.assert_array_equal(sa["z"], sb["z"])
     np.testing.assert_array_equal(xb, xu)
+    # PAROPT_AMD_NO_RECOMPUTE_DT (round 3): the refinement pass READS Dinv and the first right-hand side t instead of
+    # re-forming them from the bound data and rx it loads anyway -- the same expressions as dinv_d1_kernel: same bits
+    read_dt, xr = run(["PAROPT_AMD_NO_RECOMPUTE_DT"])
+    assert len(read_dt) == len(base)
+    for sa, sb in zip(base, read_dt):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
+        np.testing.assert_array_equal(sa["norms"], sb["norms"])
+        np.testing.assert_array_equal(sa["z"], sb["z"])
+    np.testing.assert_array_equal(xb_lean, xr)
     window = 12 if qn == "sr1" else len(base)
     # ... PAROPT_AMD_NO_RECOMPUTE_RHS: only the step is recomputed, the refinement right-hand side is stored;
     # PAROPT_AMD_VIRTUAL_Z (off by default: slower): the L-SR1 columns Z_j = Y_j - b0 S_j are never formed in HBM,
