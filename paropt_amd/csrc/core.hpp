@@ -306,7 +306,8 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
                   double *tout, double *va, int nca, double *out, double *traw = nullptr, int store_step = 1,
                   int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
-                  const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0);  // P[j] - b0v vs[j], j < nvirt
+                  const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0,  // P[j] - b0v vs[j], j < nvirt
+                  double dinv_diag = 0.0);  // t == nullptr: Dinv (this diagonal) and t re-formed from the bound data and rx
 // store_step == 0 above leaves (px, pzl, pzu, va) unwritten; this refinement pass recomputes that first step from
 // (t1, a1) and applies the refinement (t2, a2) on top in ONE sweep over P: out = {max_x, max_z} of the final step
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,

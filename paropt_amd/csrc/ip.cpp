@@ -791,18 +791,22 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     // ... and with recompute_rhs not even t': the pass only takes the products P^T t', the refinement pass forms t'
     // again from the residual coefficients (an output stream costs about four input streams)
     double *tp_out = !defer ? tvec->d : (recompute_rhs ? nullptr : xt->d);
+    // Dinv and t re-formed in the element epilogue from the bound data and rx it loads anyway (same bits)
+    const bool redo_dt1 = recompute_dt && defer && recompute_rhs && first_t_recomputable &&
+                          dbg_switch(SW_SPARE7, nullptr, 1) != 0;
+    const double *t_in = redo_dt1 ? nullptr : tvec->d;
     if (virt) {
       const std::vector<double> av = to_virt(alpha), cv = to_virt(coef);
-      PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, av.data(), cv.data(), Pv.data(), m, beta_mu, tau, rx->d,
+      PO_TRY(k_solve2_dots(ctx, bounds(), t_in, Dinv->d, av.data(), cv.data(), Pv.data(), m, beta_mu, tau, rx->d,
                            diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c, out.data(), nullptr, 0, k, Sp.data(), k,
-                           b0z));
+                           b0z, t0_diag));
       tdots.assign(m, 0.0);
       for (int j = 0; j < k; j++) tdots[c + j] = out[j];
       for (int i = 0; i < c; i++) tdots[i] = out[k + i];
     } else {
-      PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), coef.data(), P.data(), m,
+      PO_TRY(k_solve2_dots(ctx, bounds(), t_in, Dinv->d, alpha.data(), coef.data(), P.data(), m,
                            beta_mu, tau, rx->d, diag, n, px->d, pzl->d, pzu->d, tp_out, vA->d, c,
-                           out.data(), nullptr, defer ? 0 : 1));
+                           out.data(), nullptr, defer ? 0 : 1, 0, nullptr, 0, 0.0, t0_diag));
       tdots.assign(out.begin(), out.begin() + m);
     }
     virt_first = virt;

@@ -1328,7 +1328,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                        double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
-                       int store_step, int ca0, VirtCols vc, double *__restrict__ partials) {
+                       int store_step, int ca0, VirtCols vc, double dinv_diag, double *__restrict__ partials) {
   extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
   double *pt = s2lds;
   double *sacc = s2lds + 4 * NPASS * kS2Tile;
@@ -1371,8 +1371,10 @@ __global__ void __launch_bounds__(kBlock, OCC)
     eb[2] = *reinterpret_cast<const f64x2 *>(b.ub + 2 * (Q));                                \
     eb[3] = *reinterpret_cast<const f64x2 *>(b.zl + 2 * (Q));                                \
     eb[4] = *reinterpret_cast<const f64x2 *>(b.zu + 2 * (Q));                                \
-    eb[5] = *reinterpret_cast<const f64x2 *>(t + 2 * (Q));                                   \
-    eb[6] = *reinterpret_cast<const f64x2 *>(dinv + 2 * (Q));                                \
+    if (t) { /* (nullptr: t and Dinv re-formed from the bound data and rx, as dinv_d1_kernel formed them) */ \
+      eb[5] = *reinterpret_cast<const f64x2 *>(t + 2 * (Q));                                 \
+      eb[6] = *reinterpret_cast<const f64x2 *>(dinv + 2 * (Q));                              \
+    }                                                                                        \
     eb[7] = *reinterpret_cast<const f64x2 *>(rx + 2 * (Q));                                  \
   }
   if ((int64_t)blockIdx.x < ntiles) {
@@ -1431,8 +1433,15 @@ __global__ void __launch_bounds__(kBlock, OCC)
                       _zu = make_double2(eb[4].x, eb[4].y);
         const int64_t q = qc;
         PO_MAKE_BOUNDS(b, q, n);
-        const double2 tv = make_double2(eb[5].x, eb[5].y), dv = make_double2(eb[6].x, eb[6].y),
-                      r = make_double2(eb[7].x, eb[7].y);
+        const double2 r = make_double2(eb[7].x, eb[7].y);
+        double2 tv, dv;
+        if (t) {
+          tv = make_double2(eb[5].x, eb[5].y);
+          dv = make_double2(eb[6].x, eb[6].y);
+        } else {
+          dv = make_double2(dinv_elem(e0, dinv_diag), dinv_elem(e1, dinv_diag));
+          tv = make_double2(dv.x * d1_elem(e0, r.x, beta_mu), dv.y * d1_elem(e1, r.y, beta_mu));
+        }
         if (va && store_step) st2(va, q, n, accA);
         const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
         Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
@@ -1494,7 +1503,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
                               double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
                               double *pzl, double *pzu, double *tout, double *va, int nca, double *traw,
-                              int store_step, int ca0, const VirtCols &vc, int *grid_out) {
+                              int store_step, int ca0, const VirtCols &vc, double dinv_diag, int *grid_out) {
   const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1511,7 +1520,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
   hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC, VIRT>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
                      beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc,
-                     c->d_partials);
+                     dinv_diag, c->d_partials);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -1524,13 +1533,13 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     constexpr int OV = NP <= 16 ? 2 : 1; /* with unformed columns: three more prefetch registers */        \
     if (vc.count > 0)                                                                                      \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
     else if (occ_env == OA)                                                                                \
       PO_TRY((solve2_dots_launch<NP, OA, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
     else                                                                                                   \
       PO_TRY((solve2_dots_launch<NP, OD, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
   } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
@@ -1538,8 +1547,8 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
                   double *tout, double *va, int nca, double *out, double *traw, int store_step, int ca0,
-                  const double *const *vs, int nvirt, double b0v) {
-  count_bytes(c, nv + nvirt + 8 + (store_step ? 3 + (va ? 1 : 0) : 0) + ((traw || tout) ? 1 : 0), n);
+                  const double *const *vs, int nvirt, double b0v, double dinv_diag) {
+  count_bytes(c, nv + nvirt + 6 + (t ? 2 : 0) + (store_step ? 3 + (va ? 1 : 0) : 0) + ((traw || tout) ? 1 : 0), n);
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
