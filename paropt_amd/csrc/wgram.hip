@@ -626,7 +626,9 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
         constexpr int NGr = NGv <= kGramRowSplitMaxNG ? NGv : kGramRowSplitMaxNG;                      \
         if (kpend > 0) PO_TRY((wgram_pc_launch_t<NGr, 3, 1>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
         else PO_TRY((wgram_pc_launch_t<NGr, 0, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));              \
-      } else if (kpend > 0) PO_TRY((wgram_pc_launch_t<NGc, 3, 0>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
+      } else if (kpend > 0 && NGv == 16) /* (the producer/consumer form with column formation spills at 16 groups) */ \
+        PO_TRY((wgram_launch_t<NGv, 3, 1>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid)));                   \
+      else if (kpend > 0) PO_TRY((wgram_pc_launch_t<(NGc < 16 ? NGc : 15), 3, 0>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
       else PO_TRY((wgram_pc_launch_t<NGc, 0, 0>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid)));                \
     } else if (kpend > 0) {                                                                            \
       if (occ_env == OCCZA) PO_TRY((wgram_launch_t<NGv, 3, OCCZA>(c, d, pt, nv, n, ntiles, st, zt, kpend, b0, tcol, &grid))); \
