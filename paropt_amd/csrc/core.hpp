@@ -191,7 +191,8 @@ struct BatchScope {
 // Kernel-variant switches for A/B measurements inside ONE process (tools/ab_switch.py): the value set through
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
 enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_WGRAM_DEPTH = 2, SW_S2R_VARIANT = 3, SW_SPARE4 = 4,
-                 SW_SPARE5 = 5, SW_SPARE6 = 6, SW_SPARE7 = 7, SW_COUNT = 8 };
+                 SW_SPARE5 = 5, SW_SPARE6 = 6, SW_SPARE7 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_SPARE10 = 10, SW_SPARE11 = 11,
+                 SW_COUNT = 12 };
 int dbg_switch(int id, const char *env, int dflt);
 void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);
@@ -201,7 +202,9 @@ inline void count_bytes(Ctx *c, double streams, int64_t n) {
   c->alg_bytes += b;
   if (c->in_user) c->alg_bytes_user += b;
 }
-int grid_for(Ctx *c, int64_t n);           // persistent grid, 4 workgroups per CU
+constexpr int kBpcPanel = 2;   // workgroups per CU, panel-streaming kernels (solve passes, residual, panel axpy)
+constexpr int kBpcStream = 4;  // workgroups per CU, few-stream kernels
+int grid_for(Ctx *c, int64_t n);           // persistent grid, kBpcStream workgroups per CU
 int grid_for(Ctx *c, int64_t n, int bpc);  // ... with an explicit workgroups-per-CU cap
 
 // ---- vector kernels (kernels.hip) -----------------------------------------------------------

@@ -134,12 +134,12 @@ int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int
 
 // Persistent grid for an n-element streaming kernel: `bpc` workgroups per CU (tools/tune_mdot.hip:
 // 3-6 resident workgroups per CU stream at 6.2-6.5 TB/s; 8 per CU with ~6 resident leaves a
-// 1.33-wave tail and drops to 5.5 TB/s), fewer when n is small.
+// 1.33-wave tail and drops to 5.5 TB/s), fewer when n is small.  The two classes of the iteration were
+// swept in-process at config 3 (profiles/r03_ab_bpc.txt): the panel-streaming kernels (c+k+~10 concurrent
+// streams per thread) are fastest at 2 per CU, the few-stream kernels at 4.
 int grid_for(Ctx *c, int64_t n, int bpc) {
-  static const int bpc3 = getenv("PAROPT_AMD_BPC3") ? atoi(getenv("PAROPT_AMD_BPC3")) : 0;  // tuning aid
-  static const int bpc4 = getenv("PAROPT_AMD_BPC4") ? atoi(getenv("PAROPT_AMD_BPC4")) : 0;
-  if (bpc == 3 && bpc3 > 0) bpc = bpc3;
-  if (bpc == 4 && bpc4 > 0) bpc = bpc4;
+  if (bpc == kBpcPanel) bpc = dbg_switch(SW_BPC3, "PAROPT_AMD_BPC_PANEL", bpc);
+  else if (bpc == kBpcStream) bpc = dbg_switch(SW_BPC4, "PAROPT_AMD_BPC_STREAM", bpc);
   const int64_t npairs = (n + 1) >> 1;
   int64_t blocks = (npairs + kBlock - 1) / kBlock;
   const int64_t cap = (int64_t)c->num_cu * bpc;
@@ -147,7 +147,7 @@ int grid_for(Ctx *c, int64_t n, int bpc) {
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
-int grid_for(Ctx *c, int64_t n) { return grid_for(c, n, 4); }
+int grid_for(Ctx *c, int64_t n) { return grid_for(c, n, kBpcStream); }
 
 #define PO_LAUNCH(kernel, grid, ...)                                                      \
   do {                                                                                    \
@@ -410,7 +410,7 @@ int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const d
     CoefTable ct;
     PtrTable pt;
     fill_tables(alpha ? alpha + j0 : nullptr, V ? V + j0 : nullptr, w, &ct, &pt);
-    PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, 3), y, aa, x, bb, ct, pt, w, n);
+    PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, kBpcPanel), y, aa, x, bb, ct, pt, w, n);
     j0 += w;
   } while (j0 < nv);
   return PO_OK;
@@ -822,7 +822,7 @@ int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, 
     return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn);
   }
   count_bytes(c, 7 + nc + (yqn ? 2 : 0), n);
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
   CoefTable ct;
@@ -1224,7 +1224,7 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
   }
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 10));
   PtrTable pt;
   CoefTable ct1, ct2, ctr;
@@ -1288,7 +1288,7 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
     return k_solve2(c, b, t, dinv, a2, P2, nv2, beta_mu, refine, tau, n, px, pzl, pzu, out, nullptr, rx, diag, tout, va,
                     nca2, cl, cu);
   }
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PtrTable pt;
   CoefTable ct, ct2;
@@ -1637,7 +1637,7 @@ int k_step_check(Ctx *c, const Bounds &b, const double *rx, const double *px, co
     return k_step_check(c, b, rx, px, pzl, pzu, &one, &w, 1, diag, beta_mu, n, out);
   }
   count_bytes(c, nv + 9, n);
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 3));
   PtrTable pt;
   CoefTable ct;
@@ -1659,7 +1659,7 @@ int k_res_step(Ctx *c, const Bounds &b, const double *rx, const double *px, cons
   PtrTable pt;
   CoefTable ct;
   fill_tables(coef, P, nv, &ct, &pt);
-  PO_LAUNCH(res_step_kernel, grid_for(c, n, 3), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
+  PO_LAUNCH(res_step_kernel, grid_for(c, n, kBpcPanel), b, rx, px, pzl, pzu, dinv, ct, pt, nv, diag, beta_mu, n,
             tprime);
   return PO_OK;
 }
@@ -2053,7 +2053,7 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                             pxs, xold, beta_mu_step);
   }
   count_bytes(c, 14 + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 11));
   PtrTable pt;
   CoefTable ct;
@@ -2407,7 +2407,7 @@ int k_solve2s(Ctx *c, const Bounds &b, const double *t, const double *dinv, cons
     set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
     return PO_ERR_ARG;
   }
-  const int grid = grid_for(c, n, 3);
+  const int grid = grid_for(c, n, kBpcPanel);
   PtrTable pt;
   CoefTable ct;
   fill_tables(coef, P, nv, &ct, &pt);
