@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(kBlock)
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
                 const double *v) {
   if (m.nwcon <= 0) return PO_OK;
+  count_bytes(c, 1.0, m.nwcon * (int64_t)m.nw);  // the grouped part of v (the w-sized output is noise beside it)
+  count_bytes(c, init ? 2.0 : 1.0, m.nwcon);
   int G = 0;
   int64_t ntiles = 0;
   if (group_tiling(m, &G, &ntiles)) {
@@ -176,6 +178,8 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n) {
   if (m.nwcon <= 0 || n <= 0) return PO_OK;
+  count_bytes(c, 2.0, n);
+  count_bytes(c, 1.0, m.nwcon);
   PO_WLAUNCH(group_scatter_kernel, wgrid(c, n), m, out, alpha, w, n);
   return PO_OK;
 }
@@ -198,6 +202,8 @@ __global__ void __launch_bounds__(kBlock)
 int k_group_scatter_set(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n) {
   if (n <= 0) return PO_OK;
   if (m.nwcon <= 0) return k_fill(c, out, n, 0.0);
+  count_bytes(c, 1.0, n);
+  count_bytes(c, 1.0, m.nwcon);
   PO_WLAUNCH(group_scatter_set_kernel, wgrid(c, n), m, out, alpha, w, n);
   return PO_OK;
 }
@@ -229,6 +235,8 @@ int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, con
     pt.p[j] = j < nv ? P[j] : nullptr;
     ut.p[j] = j < nv ? U[j] : nullptr;
   }
+  count_bytes(c, (double)nv + 1.0, m.nwcon * (int64_t)m.nw);
+  count_bytes(c, (double)nv, m.nwcon);
   int G = 0;
   int64_t ntiles = 0;
   if (group_tiling(m, &G, &ntiles)) {
@@ -263,6 +271,8 @@ __global__ void __launch_bounds__(kBlock)
 int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, double alpha, const double *yw,
                   int64_t n, double *yx) {
   if (n <= 0) return PO_OK;
+  count_bytes(c, 3.0, n);
+  count_bytes(c, 1.0, m.nwcon);
   PO_WLAUNCH(group_apply_kernel, wgrid(c, n), m, d, bx, alpha, yw, n, yx);
   return PO_OK;
 }
@@ -274,6 +284,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_w_apply_mid(Ctx *c, const double *cw, const double *bw, const double *u, int64_t w, double *yw) {
   if (w <= 0) return PO_OK;
+  count_bytes(c, bw ? 4.0 : 3.0, w);
   PO_WLAUNCH(w_apply_mid_kernel, wgrid(c, w), cw, bw, u, w, yw);
   return PO_OK;
 }
@@ -384,6 +395,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n) {
   if (n <= 0) return PO_OK;
+  count_bytes(c, 3.0, n);
   PO_WLAUNCH(mul_kernel, wgrid(c, n), y, a, x1, x2, n);
   return PO_OK;
 }
@@ -393,6 +405,7 @@ __global__ void __launch_bounds__(kBlock) recip_kernel(double *__restrict__ y, i
 }
 int k_recip(Ctx *c, double *y, int64_t n) {
   if (n <= 0) return PO_OK;
+  count_bytes(c, 2.0, n);
   PO_WLAUNCH(recip_kernel, wgrid(c, n), y, n);
   return PO_OK;
 }
@@ -437,6 +450,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
             int64_t w, double out[12]) {
+  count_bytes(c, 12.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 12));
   PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, mu, w, c->d_partials);
@@ -454,6 +468,7 @@ __global__ void __launch_bounds__(kBlock) w_scale5_kernel(WVars dst, WVars src, 
   }
 }
 int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t w) {
+  count_bytes(c, 10.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_scale5_kernel, wgrid(c, w), dst, src, alpha, w);
   return PO_OK;
@@ -472,6 +487,7 @@ __global__ void __launch_bounds__(kBlock) w_sumsq5_kernel(WVars r, int64_t w, do
   w_block_reduce<5, 0>(s, partials, 0, sm);
 }
 int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]) {
+  count_bytes(c, 5.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 5));
   PO_WLAUNCH(w_sumsq5_kernel, grid, r, w, c->d_partials);
@@ -483,6 +499,7 @@ __global__ void __launch_bounds__(kBlock) w_cdiag_kernel(WVars v, int64_t w, dou
   PO_W_LOOP(i, w) cd[i] = v.sw[i] / v.zsw[i] + v.tw[i] / v.ztw[i];
 }
 int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd) {
+  count_bytes(c, 5.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_cdiag_kernel, wgrid(c, w), v, w, cd);
   return PO_OK;
@@ -496,6 +513,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2) {
+  count_bytes(c, 10.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_d2_kernel, wgrid(c, w), v, b, w, d2);
   return PO_OK;
@@ -536,6 +554,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
              const WVars &p, int64_t w, double out[2]) {
+  count_bytes(c, refine ? 20.0 : 15.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 2));
   PO_WLAUNCH(w_step_kernel, grid, v, b, dzw, refine, tau, p, w, c->d_partials);
@@ -553,6 +572,7 @@ __global__ void __launch_bounds__(kBlock) w_res_step_kernel(WVars v, WVars p, WV
   }
 }
 int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w) {
+  count_bytes(c, 15.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_res_step_kernel, wgrid(c, w), v, p, r, w);
   return PO_OK;
@@ -565,6 +585,7 @@ __global__ void __launch_bounds__(kBlock) w_corrector_kernel(WVars p, WVars r, i
   }
 }
 int k_w_corrector(Ctx *c, const WVars &p, const WVars &r, int64_t w) {
+  count_bytes(c, 10.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_corrector_kernel, wgrid(c, w), p, r, w);
   return PO_OK;
@@ -582,6 +603,7 @@ __global__ void __launch_bounds__(kBlock)
   w_block_reduce<1, 0>(s, partials, 0, sm);
 }
 int k_w_comp_step(Ctx *c, const WVars &v, const WVars &p, double ax, double az, int64_t w, double *out) {
+  count_bytes(c, 10.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid));
   PO_WLAUNCH(w_comp_step_kernel, grid, v, p, ax, az, w, c->d_partials);
@@ -616,6 +638,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_w_merit(Ctx *c, const WVars &v, const WVars &p, double sx, const double *gsw, const double *gtw,
               const double *cw, const double *awpx, int64_t w, double out[10]) {
+  count_bytes(c, 12.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 10));
   PO_WLAUNCH(w_merit_kernel, grid, v, p, sx, gsw, gtw, cw, awpx, w, c->d_partials);
@@ -647,6 +670,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_w_trial(Ctx *c, const WVars &v, const WVars &p, double a, double eps, const double *gsw,
               const double *gtw, const double *cwt, int64_t w, double out[5]) {
+  count_bytes(c, 14.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 5));
   PO_WLAUNCH(w_trial_kernel, grid, v, p, a, eps, gsw, gtw, cwt, w, c->d_partials);
@@ -669,6 +693,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_w_update(Ctx *c, const WVars &v, const WVars &p, double ax, double az, double eps, int64_t w) {
+  count_bytes(c, 15.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_update_kernel, wgrid(c, w), v, p, ax, az, eps, w);
   return PO_OK;
@@ -685,6 +710,7 @@ __global__ void __launch_bounds__(kBlock) w_affine_kernel(WVars v, WVars p, doub
   }
 }
 int k_w_affine(Ctx *c, const WVars &v, const WVars &p, double amin, int64_t w) {
+  count_bytes(c, 10.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_affine_kernel, wgrid(c, w), v, p, amin, w);
   return PO_OK;
@@ -701,6 +727,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_w_clip(Ctx *c, double *zw, const double *src, const double *gsw, const double *gtw, int64_t w) {
+  count_bytes(c, 4.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_clip_kernel, wgrid(c, w), zw, src, gsw, gtw, w);
   return PO_OK;
@@ -716,6 +743,7 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 int k_w_gamma(Ctx *c, double *gsw, double *gtw, double gamma, int64_t nwineq, int64_t w) {
+  count_bytes(c, 2.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
   PO_WLAUNCH(w_gamma_kernel, wgrid(c, w), gsw, gtw, gamma, nwineq, w);
   return PO_OK;
