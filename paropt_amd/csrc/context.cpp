@@ -2,6 +2,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
+#include <execinfo.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -253,6 +254,13 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
   int nparts = 1;
   const double *parts = c->h_red;
   c->n_reductions++;
+  static const bool trace = getenv("PAROPT_AMD_SYNC_TRACE") != nullptr;  // development aid: who synchronises?
+  if (trace) {
+    void *frames[12];
+    const int nf = backtrace(frames, 12);
+    fprintf(stderr, "== host sync %ld (%d values)\n", c->n_reductions, total);
+    backtrace_symbols_fd(frames + 1, nf > 1 ? nf - 1 : 0, 2);
+  }
   if (c->comm_kind == COMM_RCCL && c->rccl_allreduce && pure_sum) {
     // the MPI_Allreduce(SUM) sites of the reference (dot/mdot/Gram entries, src/ParOptVec.cpp:124-170,
     // src/ParOptInteriorPoint.cpp:1957) -> ONE ncclAllReduce over xGMI on the solver's stream, in place in d_red;

@@ -232,9 +232,11 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
 // preweighted_last != 0: the last column V[nv-1] = t already carries its weight (t = Dinv o d1), so that
 // W[i][nv-1] = V_i . t for i < nv-1 -- the panel dots P^T t of the following bordered solve ride in the same
 // pass over P (the entry W[nv-1][nv-1] is sum t^2, unused).
+// may_defer: inside an open BatchScope the entries arrive in W at the flush (W must live until then; follow-up host
+// work goes through after_reduce); otherwise, and always for panels processed in blocks, W is complete on return.
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
             const double *const *S = nullptr, double *const *Zout = nullptr, int kpend = 0,
-            double b0 = 0.0, int preweighted_last = 0);
+            double b0 = 0.0, int preweighted_last = 0, bool may_defer = false);
 int wgram_debug_stamps(double out[8]);  // tuning aid: PAROPT_AMD_WGRAM_ABLATE=16
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
                    int *nblocks, int *nslots, const double *const *S = nullptr,

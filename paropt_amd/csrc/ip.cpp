@@ -595,6 +595,10 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   // t = [K0^-1 (d1, d2)]_x, which needs Cw -- so the factor comes first, then t (and the sparse multiplier part
   // wyw), then the Gram pass with t as its pre-weighted last column, as on the dense path.
   bool fuse_tw = false;
+  // sparse constraints: the sparse residual norms of the new barrier parameter, the Gram pass and its sparse correction
+  // share ONE collective + host sync (three before); the host algebra on W waits for the flush below
+  BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
+  bool t0_ready = fuse_z && fuse_t;
   if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930)
     PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
     PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:1930)
@@ -612,23 +616,27 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       std::vector<const double *> Pt(P);
       Pt.push_back(tvec->d);
       const int mt = m + 1;
-      std::vector<double> Wt((size_t)mt * mt, 0.0);
-      PO_TRY(k_wgram(ctx, Dinv->d, Pt.data(), mt, n, Wt.data(), nullptr, nullptr, 0, 0.0, 1));
-      for (int j = 0; j < m; j++)
-        for (int i = 0; i < m; i++) W[i + (size_t)m * j] = Wt[i + (size_t)mt * j];
+      Wt_buf.assign((size_t)mt * mt, 0.0);
+      PO_TRY(k_wgram(ctx, Dinv->d, Pt.data(), mt, n, Wt_buf.data(), nullptr, nullptr, 0, 0.0, 1, wbatch.open));
       t0dots.assign(m, 0.0);
-      for (int i = 0; i < m; i++) t0dots[i] = Wt[i + (size_t)mt * m];
+      after_reduce(ctx, [this, m, mt] {
+        for (int j = 0; j < m; j++)
+          for (int i = 0; i < m; i++) W[i + (size_t)m * j] = Wt_buf[i + (size_t)mt * j];
+        for (int i = 0; i < m; i++) t0dots[i] = Wt_buf[i + (size_t)mt * m];
+      });
+      t0_ready = true;
     } else {
-      if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data()));
+      if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data(), nullptr, nullptr, 0, 0.0, 0, wbatch.open));
       t0dots.clear();
     }
   }
-  if ((fuse_t || fuse_tw) && m > 0 && (int)t0dots.size() == m) {
+  if ((fuse_t || fuse_tw) && m > 0 && t0_ready && (int)t0dots.size() == m) {
     t0_valid = true;
     t0_mu = *rhs_mu;
   }
   // W -= U^T Cw U (d1v is free again: scratch of the panel image; tvec holds t)
-  if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec));
+  if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec, wbatch.open));
+  PO_TRY(wbatch.end());
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)
   Gf.assign((size_t)c * c, 0.0);
   gpiv.assign(c, 0);
@@ -736,6 +744,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  px_amax_valid = false;
   fused_merit_valid = false;
   pz_stored = true;
   // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
@@ -1194,6 +1203,10 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
       out[5] = sx * sx * merit_cache[5];
     } else {
       PO_TRY(k_merit0(ctx, bounds(), px->d, sx, g->d, n, out));
+      if (batch.open) {  // max|px| for the line search's minimum step rides in this batch (its own sync otherwise)
+        PO_TRY(k_reduce1(ctx, RED_AMAX, px->d, nullptr, n, &px_amax_w));
+        px_amax_valid = true;
+      }
     }
     if (analytic_panel_dots && ptpx_valid && mq == c + wk) {
       for (int i = 0; i < mq; i++) dots[i] = ptpx[i];
@@ -1978,6 +1991,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
           double px_norm = 0.0;
           if (merit_cache_valid) {
             px_norm = merit_cache[6];
+          } else if (px_amax_valid) {
+            px_norm = px_amax_w;
           } else {
             PO_TRY(k_reduce1(ctx, RED_AMAX, px->d, nullptr, n, &px_norm));
           }

@@ -163,6 +163,9 @@ class InteriorPoint {
   // merit pieces of the current (unscaled) step, produced together with the complementarity check of
   // scaleKKTStep: {pos log, neg log, ppos, pneg, g.px, px.px, max|px|}
   double merit_cache[7];
+  double px_amax_w = 0.0;       // max|px| taken inside evalMeritInitDeriv's batch (sparse-constraint path)
+  bool px_amax_valid = false;
+  std::vector<double> Wt_buf, W2_buf;  // landing areas of Gram launches deferred to a batch flush (setUpKKTSystem)
   bool merit_cache_valid;
   // the same pieces taken by the refinement pass itself (k_solve2r with g): {S10, S01, S11, ppos, pneg, g.px, px.px,
   // max_x, max_z, max|px|}; the log-barrier sums of the iterate are those of the accepted trial point of the last
@@ -207,8 +210,8 @@ class InteriorPoint {
   WVars wp() const;
   int allocateW();
   int applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw);
-  int computeResidualW(double mu);
-  int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr);
+  int computeResidualW(double mu, bool norms = true);
+  int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr, bool may_defer = false);
   int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                 bool fuse_residual = false);
   int computeKKTStepWithRefinementW(double mu, bool use_qn, double tau);

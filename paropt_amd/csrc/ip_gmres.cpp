@@ -69,6 +69,7 @@ int InteriorPoint::solveKKTAlpha(const double *bx, double alpha, const Dense &b,
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  px_amax_valid = false;
   fused_merit_valid = false;
   tdots_valid = false;
   residual_fused = false;
@@ -141,6 +142,7 @@ int InteriorPoint::solveKKTAlphaW(const double *bx, double alpha, const Dense &b
   }
   ptpx_valid = true;
   merit_cache_valid = false;
+  px_amax_valid = false;
   fused_merit_valid = false;
   tdots_valid = false;
   residual_fused = false;

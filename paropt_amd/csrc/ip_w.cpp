@@ -64,9 +64,11 @@ int InteriorPoint::applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw)
 }
 
 // the w blocks of computeKKTRes (:1358-1398) and their norms
-int InteriorPoint::computeResidualW(double mu) {
+// (norms = false: the blocks only -- the caller knows that the sums of this mu and iterate are already in place)
+int InteriorPoint::computeResidualW(double mu, bool norms) {
   if (prob->evalSparseCon(x, wresv[0]) != 0) return PO_ERR_USER;
-  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, wres_out));
+  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, norms ? wres_out : nullptr));
+  if (!norms) return PO_OK;
   after_reduce(ctx, [this] {
     for (int i = 0; i < 7; i++) w_sums[i] = wres_out[i];
     for (int i = 0; i < 5; i++) w_maxs[i] = wres_out[7 + i];
@@ -79,7 +81,7 @@ int InteriorPoint::wCompStep(double ax, double az, double *prod) {
 }
 
 // W -= U^T S^-1 U with U_j = Aw (Dinv o P_j), S = C + Aw Dinv Aw^T (diagonal for the block form: Cw = S^-1)
-int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work) {
+int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work, bool may_defer) {
   if (m <= 0) return PO_OK;
   while ((int)Uw.size() < m) {
     Vec *u = vec_new(ctx, nw);
@@ -97,9 +99,13 @@ int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, in
   const double *weights = Cw->d;
   PO_TRY(prob->sparseHalfSolve(U.data(), m, Cw, &weights));
   panel_plain = (weights == Cw->d);  // scalar block form: Uw still holds U = Aw (Dinv o P) itself
-  std::vector<double> W2((size_t)m * m, 0.0);
-  PO_TRY(k_wgram(ctx, weights, Uc.data(), m, nw, W2.data()));
-  for (size_t i = 0; i < W2.size(); i++) W[i] -= W2[i];
+  // (may_defer: inside setUpKKTSystem's batch the product arrives at the flush: a member holds it, the subtraction
+  // follows it there)
+  W2_buf.assign((size_t)m * m, 0.0);
+  PO_TRY(k_wgram(ctx, weights, Uc.data(), m, nw, W2_buf.data(), nullptr, nullptr, 0, 0.0, 0, may_defer));
+  after_reduce(ctx, [this] {
+    for (size_t i = 0; i < W2_buf.size() && i < W.size(); i++) W[i] -= W2_buf[i];
+  });
   panel_valid = true;  // Uw holds the (half-solved) panel of the CURRENT Dinv, factor and panel columns
   return PO_OK;
 }
@@ -171,6 +177,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   }
   ptpx_valid = true;
   merit_cache_valid = false;  // the step is about to change
+  px_amax_valid = false;
   fused_merit_valid = false;
   tdots_valid = false;        // (consumed above by a refinement pass; set again below by a fused first pass)
   if (!refine_pass) residual_fused = false;
@@ -313,8 +320,8 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
       PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
                         mres, diag, beta_mu, n, d1v->d));
     }
-    // sparse rows (:1492-1527)
-    PO_TRY(computeResidualW(mu));
+    // sparse rows (:1492-1527); the blocks are rebuilt, their norms (same mu, same iterate) are in place already
+    PO_TRY(computeResidualW(mu, false));
     if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;
     PO_TRY(k_w_res_step(ctx, wv(), wp(), wr(), nw));
     Dense r2;

@@ -454,6 +454,7 @@ int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const dou
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 12));
   PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, mu, w, c->d_partials);
+  if (!out) return PO_OK;  // the residual blocks only
   return reduce_finish(c, grid, 7, 0, 5, out);
 }
 

@@ -30,6 +30,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <memory>
 #include <vector>
 
 namespace po {
@@ -656,7 +657,8 @@ int wgram_debug_stamps(double out[8]) {
 }
 
 static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
-                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last);
+                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last,
+                            bool may_defer);
 
 // Panels wider than one launch (kWgramMaxVecs columns: registers and LDS of the kernel) are processed by column
 // BLOCKS: the columns are cut into nb blocks of <= kWgramMaxVecs / 2 columns (multiples of 4) and every pair of
@@ -664,9 +666,10 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
 // block streamed nb - 1 times: slower per column than the single launch, but there is no limit on the width (the
 // reference has none either: src/ParOptInteriorPoint.cpp:1935-1950, 2648-2654).
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
-            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last) {
+            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last, bool may_defer) {
   if (nv <= 0) return PO_OK;
-  if (nv <= kWgramMaxVecs) return wgram_one_launch(c, d, V, nv, n, W, S, Zout, kpend, b0, preweighted_last);
+  if (nv <= kWgramMaxVecs)
+    return wgram_one_launch(c, d, V, nv, n, W, S, Zout, kpend, b0, preweighted_last, may_defer);
   if (kpend > 0 || preweighted_last) {
     set_error("wgram: a panel of %d columns is processed in blocks, which cannot form L-SR1 columns or carry a "
               "pre-weighted column", nv);
@@ -688,7 +691,7 @@ int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, 
       V2.assign(V + i0, V + i0 + ni);
       V2.insert(V2.end(), V + j0, V + j0 + nj);
       W2.assign((size_t)m2 * m2, 0.0);
-      PO_TRY(wgram_one_launch(c, d, V2.data(), m2, n, W2.data(), nullptr, nullptr, 0, 0.0, 0));
+      PO_TRY(wgram_one_launch(c, d, V2.data(), m2, n, W2.data(), nullptr, nullptr, 0, 0.0, 0, false));
       auto col = [&](int q) { return q < ni ? i0 + q : j0 + (q - ni); };
       for (int q = 0; q < m2; q++)
         for (int r = 0; r < m2; r++) W[col(r) + (size_t)nv * col(q)] = W2[r + (size_t)m2 * q];
@@ -698,15 +701,18 @@ int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, 
 }
 
 static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
-                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last) {
+                            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last,
+                            bool may_defer) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
   const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream
   if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
-  std::vector<double> blocks(nslots);
-  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks.data(), true));  // synchronises the stream
+  // (the block sums live on the heap: a deferred launch unpacks them at the flush of the enclosing batch)
+  auto blocks = std::make_shared<std::vector<double>>(nslots);
+  const bool defer = may_defer && !timed && c->batch_depth > 0;
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks->data(), !defer));  // !defer: synchronises the stream
   if (timed) {
     float ms = 0.0f;
     PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -716,24 +722,27 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
     c->wgram_cols[w] = nv;
     c->wgram_bytes[w] += 8.0 * (double)n * (nv + 1 + 2 * kpend);  // panel + weights (+ S read, Z written)
   }
-  const int NG = wgram_groups(nv);
-  int p = 0;
-  for (int I = 0; I < NG; I++) {
-    for (int J = I; J < NG; J++, p++) {
-      for (int i = 0; i < 4; i++) {
-        for (int j = 0; j < 4; j++) {
-          const int r = 4 * I + i, s = 4 * J + j;
-          // upper entries only: a diagonal block pair computes both triangles, and with a pre-weighted last
-          // column only W[r][last] = P_r . t is meaningful
-          if (r < nv && s < nv && r <= s) {
-            const double v = blocks[(size_t)p * 16 + i * 4 + j];
-            W[r + (size_t)nv * s] = v;
-            W[s + (size_t)nv * r] = v;
+  auto unpack = [blocks, nv, W] {
+    const int NG = wgram_groups(nv);
+    int p = 0;
+    for (int I = 0; I < NG; I++) {
+      for (int J = I; J < NG; J++, p++) {
+        for (int i = 0; i < 4; i++) {
+          for (int j = 0; j < 4; j++) {
+            const int r = 4 * I + i, s = 4 * J + j;
+            // upper entries only: a diagonal block pair computes both triangles, and with a pre-weighted last
+            // column only W[r][last] = P_r . t is meaningful
+            if (r < nv && s < nv && r <= s) {
+              const double v = (*blocks)[(size_t)p * 16 + i * 4 + j];
+              W[r + (size_t)nv * s] = v;
+              W[s + (size_t)nv * r] = v;
+            }
           }
         }
       }
     }
-  }
+  };
+  after_reduce(c, unpack);  // (runs at once unless the reduction was queued)
   return PO_OK;
 }
 
