@@ -281,6 +281,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the host driver of the pool supports dmabuf IPC only (RCCL's buffer exchange between the ranks' processes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if os.environ.get("PAROPT_BENCH_STUB", "0") == "1":
         sys.exit(stub_rank(a, rank, world))
 
