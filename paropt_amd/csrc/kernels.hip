@@ -1527,6 +1527,9 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   return PO_OK;
 }
 
+// (OD / OA: workgroups per CU, default and alternative (PAROPT_AMD_S2D_OCC).  The stored-step form of narrow panels --
+// the sparse-constraint path -- takes the alternative 2 by default: its epilogue keeps the step and the raw right-hand
+// side live beside the prefetched operands, 2.9 vs 3.1 ms per iteration in the solves of config 4.)
 #define PO_S2D_CASE(NP)                                                                                    \
   case NP: {                                                                                               \
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
@@ -1534,7 +1537,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     if (vc.count > 0)                                                                                      \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
                                             px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
-    else if (occ_env == OA)                                                                                \
+    else if (occ_env == OA || (occ_env == 0 && store_step && NP <= 8))                                     \
       PO_TRY((solve2_dots_launch<NP, OA, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
                                             px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
     else                                                                                                   \
