@@ -40,11 +40,12 @@ __device__ __forceinline__ void st(double *p, f64x2 v) {
 }
 
 template <int NIN, int NOUT, int POLICY>
-__global__ void __launch_bounds__(256) pass_kernel(Streams s, long npairs) {
+__global__ void __launch_bounds__(256) pass_kernel(Streams s, long npairs, double *sink) {
+  double red = 0.0;
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < npairs; q += (long)gridDim.x * 256) {
     if (NOUT >= 8) {
       // copy-/form-shaped: output o is a combination of the inputs o, o + NOUT, ... (eight outputs at a time)
-      constexpr int R = NIN / NOUT;
+      constexpr int R = NOUT > 0 ? NIN / NOUT : 1;
 #pragma unroll
       for (int o0 = 0; o0 < NOUT; o0 += 8) {
         f64x2 v[R][8];
@@ -76,9 +77,16 @@ __global__ void __launch_bounds__(256) pass_kernel(Streams s, long npairs) {
       }
 #pragma unroll
       for (int i = 0; i < NOUT; i++) st<POLICY>(s.out[i] + 2 * q, acc * (double)(i + 1));
+      if (NOUT == 0) red += acc.x + acc.y;
     }
   }
+  if (NOUT == 0) {  // read-only mix: reduced in registers, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) red += __shfl_xor(red, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sink + (blockIdx.x & 255), red);
+  }
 }
+
+static double *g_sink = nullptr;
 
 template <int NIN, int NOUT, int POLICY>
 void run(const char *shape, Streams s, long npairs, int bpc) {
@@ -90,7 +98,7 @@ void run(const char *shape, Streams s, long npairs, int bpc) {
   const int reps = 6;
   for (int r = 0; r < reps; r++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((pass_kernel<NIN, NOUT, POLICY>), dim3(256 * bpc), dim3(256), 0, 0, s, npairs);
+    hipLaunchKernelGGL((pass_kernel<NIN, NOUT, POLICY>), dim3(256 * bpc), dim3(256), 0, 0, s, npairs, g_sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -133,6 +141,8 @@ int main(int argc, char **argv) {
     hipMemset(p, 0, n * 8);
     s.out[j] = p;
   }
+  hipMalloc(&g_sink, 256 * sizeof(double));
+  hipMemset(g_sink, 0, 256 * sizeof(double));
   hipDeviceSynchronize();
   if (argc > 2) {  // the stream mixes of the product's storing passes, `nt` stores only (what the product uses)
     for (int round = 0; round < 3; round++) {
@@ -142,6 +152,9 @@ int main(int argc, char **argv) {
       run<6, 2, 1>("dinv_d1 mix", s, npairs, 4);
       run<4, 2, 1>("trial mix", s, npairs, 4);
       run<48, 1, 1>("(48 in, 1 out)", s, npairs, 2);
+      run<33, 0, 1>("mdot<32> mix", s, npairs, 5);
+      run<48, 0, 1>("solve2_dots mix", s, npairs, 2);
+      run<44, 0, 1>("plain gram mix", s, npairs, 4);
     }
     return 0;
   }
