@@ -129,18 +129,23 @@ int main(int argc, char **argv) {
   const long n = argc > 1 ? atol(argv[1]) : 50000000L;
   const long npairs = n / 2;
   Streams s;
+  // PROBE_SKEW=<bytes>: stream j starts (j mod 61) * skew bytes into its allocation (do equal offsets of all streams
+  // within their 2 MB-aligned allocations cost DRAM bank conflicts?)
+  const long skew = getenv("PROBE_SKEW") ? atol(getenv("PROBE_SKEW")) : 0;
+  const long pad = 61 * skew + 256;
   for (int j = 0; j < MAXS; j++) {
-    double *p;
-    if (hipMalloc(&p, n * 8) != hipSuccess) return 1;
-    hipMemset(p, 0, n * 8);
-    s.in[j] = p;
+    char *p;
+    if (hipMalloc(&p, n * 8 + pad) != hipSuccess) return 1;
+    hipMemset(p, 0, n * 8 + pad);
+    s.in[j] = reinterpret_cast<double *>(p + (j % 61) * skew);
   }
   for (int j = 0; j < 32; j++) {
-    double *p;
-    if (hipMalloc(&p, n * 8) != hipSuccess) return 1;
-    hipMemset(p, 0, n * 8);
-    s.out[j] = p;
+    char *p;
+    if (hipMalloc(&p, n * 8 + pad) != hipSuccess) return 1;
+    hipMemset(p, 0, n * 8 + pad);
+    s.out[j] = reinterpret_cast<double *>(p + ((j + 37) % 61) * skew);
   }
+  printf("# skew %ld bytes per stream index\n", skew);
   hipMalloc(&g_sink, 256 * sizeof(double));
   hipMemset(g_sink, 0, 256 * sizeof(double));
   hipDeviceSynchronize();
