@@ -133,16 +133,34 @@ int main(int argc, char **argv) {
   // within their 2 MB-aligned allocations cost DRAM bank conflicts?)
   const long skew = getenv("PROBE_SKEW") ? atol(getenv("PROBE_SKEW")) : 0;
   const long pad = 61 * skew + 256;
+  // PROBE_ARENA=k: the streams are carved out of slabs of k streams each (stride rounded up to 2 MB); unset / 0: one
+  // hipMalloc per stream (what a vector-per-allocation library does)
+  const int slab = getenv("PROBE_ARENA") ? atoi(getenv("PROBE_ARENA")) : 0;
+  const long stride = ((n * 8 + pad + (2L << 20) - 1) >> 21) << 21;
+  char *base = nullptr;
+  int used = 0;
+  auto take = [&]() -> char * {
+    char *p = nullptr;
+    if (slab <= 0) {
+      if (hipMalloc(&p, n * 8 + pad) != hipSuccess) return nullptr;
+      hipMemset(p, 0, n * 8 + pad);
+      return p;
+    }
+    if (!base || used == slab) {
+      if (hipMalloc(&base, stride * slab) != hipSuccess) return nullptr;
+      hipMemset(base, 0, stride * slab);
+      used = 0;
+    }
+    return base + stride * (used++);
+  };
   for (int j = 0; j < MAXS; j++) {
-    char *p;
-    if (hipMalloc(&p, n * 8 + pad) != hipSuccess) return 1;
-    hipMemset(p, 0, n * 8 + pad);
+    char *p = take();
+    if (!p) return 1;
     s.in[j] = reinterpret_cast<double *>(p + (j % 61) * skew);
   }
   for (int j = 0; j < 32; j++) {
-    char *p;
-    if (hipMalloc(&p, n * 8 + pad) != hipSuccess) return 1;
-    hipMemset(p, 0, n * 8 + pad);
+    char *p = take();
+    if (!p) return 1;
     s.out[j] = reinterpret_cast<double *>(p + ((j + 37) % 61) * skew);
   }
   printf("# skew %ld bytes per stream index\n", skew);
