@@ -705,13 +705,15 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
                             bool may_defer) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
-  const bool timed = c->time_wgram != 0;  // po_ctx_time_wgram: HIP events on the launch stream
+  // (the block sums live on the heap: a deferred launch unpacks them at the flush of the enclosing batch)
+  const bool defer = may_defer && c->batch_depth > 0;
+  // po_ctx_time_wgram: HIP events on the launch stream (not for deferred launches: the one event pair is read back
+  // right after the launch)
+  const bool timed = c->time_wgram != 0 && !defer;
   if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
   PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
-  // (the block sums live on the heap: a deferred launch unpacks them at the flush of the enclosing batch)
   auto blocks = std::make_shared<std::vector<double>>(nslots);
-  const bool defer = may_defer && !timed && c->batch_depth > 0;
   PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks->data(), !defer));  // !defer: synchronises the stream
   if (timed) {
     float ms = 0.0f;
