@@ -162,6 +162,14 @@ struct BatchScope {
     c->batch_depth--;
     return batch_flush(c);
   }
+  // Like end(), but inside an enclosing scope the flush is left to that scope (for a callee whose results are all
+  // delivered through after_reduce()).
+  int end_nested() {
+    if (!open) return PO_OK;
+    open = false;
+    c->batch_depth--;
+    return c->batch_depth > 0 ? PO_OK : batch_flush(c);
+  }
   // For a callee whose results are only post-processed (not branched on): inside an enclosing scope the flush is
   // left to that scope and `post` (host work on the reduced values) runs there; otherwise flush and run it now.
   // The result locations must stay valid until the enclosing scope ends.

@@ -442,7 +442,9 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
     max_rzl = o[9];
     max_rzu = o[10];
   });
-  return wbatch.end();
+  // (inside computeStepAndUpdate's batch the norms arrive with the quasi-Newton products: everything above that reads
+  // them runs through after_reduce)
+  return wbatch.end_nested();
 }
 
 void InteriorPoint::resNorms(const Dense &r, double *max_prime, double *max_dual,
@@ -1527,7 +1529,11 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     // the next residual's norms and the quasi-Newton products of the update are reduced together: nothing on the
     // host needs the norms before the update has its dots.  Only when no user code runs in between.
     // (user code between the two: only computeQuasiNewtonUpdateCorrection, and only when the problem has one)
-    BatchScope batch(ctx, fast_yqn && qn->reductionsBatchable() &&
+    // (sparse constraints: y_qn is assembled by its own passes, the residual of the next iteration is still taken
+    // here, early, so that its norms ride with the products of the update -- built-in problems only: their sparse
+    // callbacks queue nothing that is read before the flush)
+    const bool early_w = has_w && !fast_yqn && prob->reductionsBatchable();
+    BatchScope batch(ctx, (fast_yqn || early_w) && qn->reductionsBatchable() &&
                               (prob->reductionsBatchable() || !prob->quasiNewtonCorrectionMayChangeStep()));
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
@@ -1539,6 +1545,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
       for (int i = 0; i < c; i++) mz[i] = -vars.z[i];
       PO_TRY(k_panel_axpy(ctx, y_qn->d, 1.0, g->d, 1.0, mz.data(), A.data(), c, n));
       if (has_w && prob->addSparseJacobianTranspose(-1.0, x, wvar[0], y_qn) != 0) return PO_ERR_USER;
+      if (early_w) {
+        PO_TRY(computeResidual(barrier_param, true));
+        residual_cached = true;
+      }
     }
     int rcc = prob->computeQuasiNewtonUpdateCorrection(x, vars.z.data(), s_qn, y_qn);
     if (rcc != 0) return PO_ERR_USER;
