@@ -37,6 +37,22 @@ void dbg_switch_set(int id, int value) {
 }
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
+// (Re)allocates the pinned result buffer and the alias the device writes through (see Ctx::h_red_dev).
+static int alloc_h_red(Ctx *c, size_t doubles) {
+  if (c->h_red) (void)hipHostFree(c->h_red);
+  c->h_red = nullptr;
+  c->h_red_dev = nullptr;
+  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * doubles, hipHostMallocDefault));
+  // (coherent pinned memory: what a kernel wrote there is visible to the host once the stream has been synchronised)
+  if (getenv("PAROPT_AMD_NO_DIRECT_RED") ||
+      hipHostGetDevicePointer((void **)&c->h_red_dev, c->h_red, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    c->h_red_dev = nullptr;
+  }
+  return PO_OK;
+}
+
+
 static int comm_self_test(Ctx *c);
 
 // ---- RCCL through dlopen: the library is only needed for world sizes > 1 ----------------------
@@ -151,9 +167,8 @@ int comm_init_rccl(Ctx *c, int rank, int size, const void *id128) {
   c->rccl_allreduce = getenv("PAROPT_AMD_RCCL_ALLGATHER") ? 0 : 1;
   // gather buffers sized for the communicator
   if (c->d_gather) (void)hipFree(c->d_gather);
-  if (c->h_red) (void)hipHostFree(c->h_red);
   PO_HIP(hipMalloc((void **)&c->d_gather, sizeof(double) * (size_t)size * kMaxRed));
-  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * (size_t)size * kMaxRed, hipHostMallocDefault));
+  PO_TRY(alloc_h_red(c, (size_t)size * kMaxRed));
   // The first collectives a fresh communicator runs are known-answer ones: a wrong enum value, a wrong rank order or
   // a communicator that does not span the ranks it claims fails HERE with a message, not as a diverging solve.
   const int rc_test = comm_self_test(c);
@@ -178,8 +193,7 @@ int comm_init_callback(Ctx *c, int rank, int size, po_allgather_fn fn, void *use
   c->cb_allgather = fn;
   c->cb_user = user;
   c->comm_kind = size > 1 ? COMM_CALLBACK : COMM_SELF;
-  if (c->h_red) (void)hipHostFree(c->h_red);
-  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * (size_t)(size + 1) * kMaxRed, hipHostMallocDefault));
+  PO_TRY(alloc_h_red(c, (size_t)(size + 1) * kMaxRed));
   return PO_OK;
 }
 
@@ -204,7 +218,7 @@ int ctx_create(int device, Ctx **out) {
   c->max_blocks = c->num_cu * 8;  // upper bound used only to size the partials buffer
   PO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   PO_HIP(hipMalloc((void **)&c->d_red, sizeof(double) * kMaxRed));
-  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * kMaxRed, hipHostMallocDefault));
+  PO_TRY(alloc_h_red(c, kMaxRed));
   PO_HIP(hipEventCreate(&c->ev0));
   PO_HIP(hipEventCreate(&c->ev1));
   PO_HIP(hipEventCreate(&c->ev_mdot0));
@@ -285,7 +299,8 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
     PO_HIP(hipStreamSynchronize(c->stream));
     nparts = c->size;
   } else {
-    PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
+    // (with h_red_dev the final stages have written their results into h_red themselves)
+    if (!c->h_red_dev) PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
     PO_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_kind == COMM_CALLBACK) {
       double *all = c->h_red + kMaxRed;

@@ -60,6 +60,8 @@ struct Ctx {
   double *d_red = nullptr;       // [kMaxRed] rank-local reduced values
   double *d_gather = nullptr;    // [size * kMaxRed]
   double *h_red = nullptr;       // pinned [size * kMaxRed]
+  double *h_red_dev = nullptr;   // the same memory as the device sees it: without a device-side collective the final
+                                 // reduction stage writes its results there (no device-to-host copy command)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
   // allocated on first use

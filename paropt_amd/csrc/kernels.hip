@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(kBlock)
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off) {
   const int grid = (nslots + 3) / 4;
+  // no device-side collective (one rank, or the host-callback communicator): straight into the pinned host buffer
+  double *dst = (c->comm_kind != COMM_RCCL && c->h_red_dev) ? c->h_red_dev : c->d_red;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(grid), dim3(kBlock), 0, c->stream, c->d_partials,
-                     nblocks, nslots, nsum, nmin, c->d_red + dst_off);
+                     nblocks, nslots, nsum, nmin, dst + dst_off);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   return PO_OK;
