@@ -164,8 +164,9 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
                    "probes": [{"n": a, "iterations": b, "seconds": c, "wall_s": d} for a, b, c, d in samples],
                    "sample": "unmodified reference (%d MPICH ranks x sequential MKL; ranks = cores this process may use: "
                              "affinity %d, cgroup quota %s, os.cpu_count %d), same problem at n=%d, first %d iterations "
-                             "(quasi-Newton memory ramping 0->%d: cheaper than steady-state iterations, so the GPU/CPU "
-                             "ratio is conservative), optimize() only; every reference pass is O(n) and memory-bound, "
+                             "(initialisation included, quasi-Newton memory ramping 0->%d: not the full-memory iterations the "
+                             "GPU line times; differences of longer runs were too noisy on the shared hosts to rescale it), "
+                             "optimize() only; every reference pass is O(n) and memory-bound, "
                              "the rate is scaled by %d/%d to the workload's n; implied_host_GBps = the reference "
                              "sequence's traffic model (SURVEY 3.4) / seconds: far below the host's stream bandwidth "
                              "means oversubscribed or throttled cores" % (
@@ -174,6 +175,11 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
             if len(samples) > 1:
                 a, b = samples[0], samples[1]
                 res["probe_consistency"] = (b[2] / b[1] / b[0]) / (a[2] / a[1] / a[0])  # s/iter/elt ratio, ~1
+            if (cpus.get("loadavg_1min") or 0.0) > 0.75 * ranks:
+                # seen on the pool: the same code and ranks gave 0.12-0.29 it/s with implied_host_GBps 160-390
+                res["note"] = ("the host's 1-minute load average (%.1f) was already at the level of the %d granted cores "
+                               "before the ranks started: other jobs share the cores' memory system, compare "
+                               "implied_host_GBps between runs" % (cpus["loadavg_1min"], ranks))
             return res
         except Exception as e:  # pragma: no cover
             log("cpu_baseline: reference failed: %r" % (e,))
