@@ -1145,9 +1145,11 @@ __global__ void __launch_bounds__(kBlock)
       // t1 == nullptr (RECT form): Dinv and t = Dinv o d1 of the first solve are re-formed from the bound data and rx
       // this pass loads anyway, exactly as dinv_d1_kernel formed them (same expressions: same bits) -- two input
       // streams less
+      // (the pad element of an odd n has no bounds: with a zero diagonal -- sequential linear method -- 1 / 0 would
+      // enter the sums as inf * 0; the stored Dinv and t hold exactly 0 there)
       const double2 r0 = ld2(rx, q, n);
-      dv = make_double2(dinv_elem(e0, dinv_diag), dinv_elem(e1, dinv_diag));
-      tv = make_double2(dv.x * d1_elem(e0, r0.x, beta_mu), dv.y * d1_elem(e1, r0.y, beta_mu));
+      dv = make_double2(dinv_elem(e0, dinv_diag), _has2 ? dinv_elem(e1, dinv_diag) : 0.0);
+      tv = make_double2(dv.x * d1_elem(e0, r0.x, beta_mu), _has2 ? dv.y * d1_elem(e1, r0.y, beta_mu) : 0.0);
     }
     const Step3 f0 = solve2_elem<0>(e0, tv.x + dv.x * acc1.x, beta_mu, 0.0, 0.0, 0.0);
     Step3 f1 = solve2_elem<0>(e1, tv.y + dv.y * acc1.y, beta_mu, 0.0, 0.0, 0.0);
@@ -1441,8 +1443,9 @@ __global__ void __launch_bounds__(kBlock, OCC)
           tv = make_double2(eb[5].x, eb[5].y);
           dv = make_double2(eb[6].x, eb[6].y);
         } else {
-          dv = make_double2(dinv_elem(e0, dinv_diag), dinv_elem(e1, dinv_diag));
-          tv = make_double2(dv.x * d1_elem(e0, r.x, beta_mu), dv.y * d1_elem(e1, r.y, beta_mu));
+          // (pad element of an odd n: exactly 0, as the stored Dinv / t have it -- see solve2r_kernel)
+          dv = make_double2(dinv_elem(e0, dinv_diag), _has2 ? dinv_elem(e1, dinv_diag) : 0.0);
+          tv = make_double2(dv.x * d1_elem(e0, r.x, beta_mu), _has2 ? dv.y * d1_elem(e1, r.y, beta_mu) : 0.0);
         }
         if (va && store_step) st2(va, q, n, accA);
         const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);

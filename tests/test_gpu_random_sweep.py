@@ -1,0 +1,131 @@
+"""
+Seeded random differential test: the device path (through the C ABI) against the numpy oracle on problem /
+size / option combinations drawn at random -- counters, quasi-Newton sizes and info tokens exactly, mu / objective /
+norms to 1e-6 over the first iterations.  The fixed sweep of test_gpu_ip.py covers the corners chosen by hand; this
+one covers combinations nobody chose.  PAROPT_SWEEP_CASES=<N> widens the campaign (default 24 cases, seed fixed).
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from test_gpu_ip import info_tokens
+
+pytestmark = pytest.mark.gpu
+
+NCASES = int(os.environ.get("PAROPT_SWEEP_CASES", "24"))
+SEED = int(os.environ.get("PAROPT_SWEEP_SEED", "20261003"))
+
+
+def draw(rng):
+    problem = rng.choice(["convex", "quadratic", "quadratic", "rosenbrock"])
+    n = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 513, 700, 1023, 1025, 1500, 2049, 3000])
+    if problem == "rosenbrock":
+        n = max(n, 8)
+        c = 2
+    else:
+        c = rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 40])
+    qn = rng.choice(["bfgs", "bfgs", "sr1"])
+    m = rng.choice([1, 2, 3, 5, 8, 10, 13])
+    opts = {"qn_subspace_size": m, "qn_type": qn, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
+            "max_major_iters": 8 if qn == "sr1" else 12}
+    if qn == "bfgs":
+        opts["barrier_strategy"] = rng.choice(["monotone", "monotone", "mehrotra", "mehrotra_predictor_corrector",
+                                               "complementarity_fraction"])
+    opts["norm_type"] = rng.choice(["infinity", "infinity", "l1", "l2"])
+    if rng.random() < 0.25:
+        opts["starting_point_strategy"] = rng.choice(["least_squares_multipliers", "affine_step", "no_start_strategy"])
+    if rng.random() < 0.2:
+        opts["use_line_search"] = False
+    if rng.random() < 0.2:
+        opts["use_backtracking_alpha"] = True
+    if rng.random() < 0.2 and qn == "bfgs":
+        opts["qn_update_type"] = "damped_update"
+    if rng.random() < 0.15:
+        opts["qn_diag_type"] = rng.choice(["yty_over_yts", "yts_over_sts", "inner_yty_over_yts", "inner_yts_over_sts"])
+    if rng.random() < 0.15:
+        opts["sequential_linear_method"] = True
+    if rng.random() < 0.15 and problem != "rosenbrock":
+        opts["use_diag_hessian"] = True
+    if rng.random() < 0.15:
+        opts["qn_sigma"] = rng.choice([0.1, 1.0])
+    wt = None
+    if problem != "rosenbrock" and n >= 64 and rng.random() < 0.3:
+        nw = rng.choice([2, 3, 5, 8])
+        skip = rng.choice([0, 0, 1, 3])
+        start = rng.choice([0, 0, 1, 5])
+        nwcon = max(1, (n - start) // (nw + skip) // rng.choice([1, 2]))
+        nwineq = rng.choice([nwcon, nwcon, nwcon // 2, 0])
+        wt = (nwcon, nw, start, skip, nwineq)
+        opts.setdefault("starting_point_strategy", "affine_step")
+        opts["penalty_gamma"] = 1000.0
+    return problem, n, c, opts, wt
+
+
+def cases():
+    rng = random.Random(SEED)
+    return [draw(rng) for _ in range(NCASES)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paropt_amd as pa
+
+    c = pa.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("idx", range(NCASES))
+def test_random_case_against_oracle(ctx, idx):
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    problem, n, c, opts, wt = cases()[idx]
+    wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
+    oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
+    osn = []
+    oip.hook = lambda s, k: osn.append(s.snapshot())
+    oip.optimize()
+    prob = pa.SeparableProblem(ctx, problem, n, c)
+    if wt:
+        prob.setWeighting(*wt)
+    ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
+    gsn = []
+    ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
+    ip.optimize()
+    what = (idx, problem, n, c, opts, wt)
+    ncmp = min(len(osn), len(gsn))
+    assert ncmp >= min(len(osn), 4), what
+    # a difference of 1e-16 decides branches once the iterate is at round-off level (converged tiny problems, the
+    # non-convergent L-SR1 iteration): the comparison stops where the oracle's residual is below 1e-7
+    for k in range(ncmp):
+        if k > 2 and float(np.max(osn[k]["norms"])) < 1e-7:
+            ncmp = k
+            break
+    for k in range(ncmp):
+        np.testing.assert_array_equal(gsn[k]["counters"], osn[k]["counters"], err_msg="counters @%d %r" % (k, what))
+        assert gsn[k]["qn_size"] == osn[k]["qn_size"], (k, what)
+        assert abs(gsn[k]["mu"] - osn[k]["mu"]) <= 1e-6 * abs(osn[k]["mu"]), (k, what)
+        assert abs(gsn[k]["fobj"] - osn[k]["fobj"]) <= 1e-6 * max(1.0, abs(osn[k]["fobj"])), (k, what)
+        np.testing.assert_allclose(gsn[k]["norms"], osn[k]["norms"], rtol=1e-6, atol=1e-11, err_msg="%d %r" % (k, what))
+        if wt:
+            np.testing.assert_allclose(gsn[k]["wnorms"], osn[k]["wnorms"], rtol=1e-6, atol=1e-11)
+    assert [t["info"].split() for t in oip.trace[1:ncmp]] == [
+        info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)], what
+
+
+if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaign with one line per failing case
+    import paropt_amd as pa
+
+    c = pa.Context(0)
+    nbad = 0
+    for i in range(NCASES):
+        try:
+            test_random_case_against_oracle(c, i)
+        except AssertionError as e:
+            nbad += 1
+            msg = str(e).strip().splitlines()
+            print("CASE %d %r\n     -> %s" % (i, cases()[i], " | ".join(m.strip() for m in msg[:6])[:700]), flush=True)
+    print("%d of %d cases differ" % (nbad, NCASES))
