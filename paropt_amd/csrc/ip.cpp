@@ -1865,7 +1865,9 @@ int InteriorPoint::optimize(const char *checkpoint) {
         seq_linear_step = 0;
         diagonal_quasi_newton_step = 1;
       }
-    } else if (use_diag_hessian) {  // :4940-4948
+    } else if (use_diag_hessian && !seq_lin) {  // :4940-4948
+      // (an else-if chain in the reference, :4920-4949: under the sequential linear method the diagonal is never
+      // evaluated -- hdiag keeps its initial zeros, which setUpKKTDiagSystem and addKKTResStep then use)
       use_qn = false;
       if (prob->evalHessianDiag(x, vars.z.data(), has_w ? wvar[0] : nullptr, hdiag) != 0) {
         fprintf(stderr, "ParOpt: Hessian diagonal evaluation failed\n");
