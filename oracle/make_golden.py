@@ -473,6 +473,26 @@ case("tr_csr_convex_n120_c2_chain3s2", "tr", problem="convex", n=120, c=2, chain
      dump_vecs_every=10, **dict(tr_common, **{"tr.tr_max_size": 0.5, "tr.tr_init_size": 0.05, "tr.tr_max_iterations": 40}))
 case("tr_csr_rosenbrock_n60_chain2", "tr", problem="rosenbrock", n=60, chain_span=2, chain_stride=1,
      dump_vecs_every=10, **dict(tr_common, **{"opt.qn_subspace_size": 10, "tr.tr_max_iterations": 60}))
+# option combinations of the trust-region driver drawn at random (round 3: the random sweep of the interior point
+# compares with the oracle; the oracle's trust-region driver is not a reliable comparator on drawn cases -- its
+# subproblem solves end on other round-off level tests than the reference's -- so these come from the reference)
+tr_rand = {"tr.tr_max_iterations": 12}
+case("tr_rand_convex_n257_c2_eta01", "tr", problem="convex", n=257, c=2, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 3, "opt.qn_update_type": "damped_update", "tr.tr_init_size": 0.5,
+                        "tr.tr_eta": 0.1, "tr.tr_max_size": 0.5}))
+case("tr_rand_quadratic_n129_c4_fixedgamma100", "tr", problem="quadratic", n=129, c=4, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 5, "tr.tr_adaptive_gamma_update": 0, "opt.penalty_gamma": 100.0}))
+case("tr_rand_rosenbrock_n127_eta05", "tr", problem="rosenbrock", n=127, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 8, "tr.tr_eta": 0.5, "tr.tr_max_size": 2.0}))
+case("tr_rand_quadratic_n300_c8_subcon", "tr", problem="quadratic", n=300, c=8, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 8, "opt.qn_update_type": "damped_update",
+                        "tr.tr_adaptive_constraint": "subproblem_constraint"}))
+case("tr_rand_convex_n200_c3_constobj", "tr", problem="convex", n=200, c=3, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 2, "tr.tr_adaptive_objective": "constant_objective",
+                        "tr.tr_init_size": 0.05}))
+case("tr_rand_quadratic_n65_c1_subobj", "tr", problem="quadratic", n=65, c=1, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_subspace_size": 2, "tr.tr_adaptive_objective": "subproblem_objective",
+                        "tr.tr_init_size": 0.05, "opt.penalty_gamma": 10.0}))
 # the metric's configuration (config 3 shape: convex objective, c = 32, L-SR1(10)) under the trust-region driver,
 # where L-SR1 makes progress, at n = 1e5 on four MPI ranks; subproblem solves capped at 200 interior-
 # point iterations as the reference's trust-region examples set it

