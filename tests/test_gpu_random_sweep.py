@@ -54,6 +54,34 @@ def draw(rng):
         opts["use_diag_hessian"] = True
     if rng.random() < 0.15:
         opts["qn_sigma"] = rng.choice([0.1, 1.0])
+    if rng.random() < 0.12:
+        opts["hessian_reset_freq"] = rng.choice([2, 3, 5])
+    if rng.random() < 0.12:
+        opts["use_quasi_newton_update"] = False
+    if rng.random() < 0.12:
+        opts["min_fraction_to_boundary"] = rng.choice([0.9, 0.99])
+    if rng.random() < 0.12:
+        opts["armijo_constant"] = rng.choice([1e-3, 0.1])
+    if rng.random() < 0.12:
+        opts["max_line_iters"] = rng.choice([2, 4])
+    if rng.random() < 0.12:
+        opts["init_barrier_param"] = rng.choice([1.0, 10.0])
+    if rng.random() < 0.12 and opts.get("barrier_strategy", "monotone") == "monotone":
+        opts["monotone_barrier_fraction"] = rng.choice([0.1, 0.5])
+    if rng.random() < 0.1:
+        opts["rel_bound_barrier"] = 0.5
+    if rng.random() < 0.1:
+        opts["penalty_gamma"] = rng.choice([10.0, 100.0])
+    if rng.random() < 0.1 and problem != "rosenbrock" and not opts.get("use_diag_hessian") and \
+            not opts.get("sequential_linear_method"):
+        opts.update(use_hvec_product=True, gmres_subspace_size=rng.choice([4, 8]), nk_switch_tol=1e3, max_gmres_rtol=1.0)
+    extra = {}
+    if rng.random() < 0.3:
+        extra["seed"] = rng.choice([1, 2, 7])
+    if problem == "quadratic" and rng.random() < 0.3:
+        extra["eig_max"] = rng.choice([10.0, 1e3, 1e5])
+    if rng.random() < 0.15:
+        extra["bounds_mode"] = rng.choice([2, 5, 7])
     wt = None
     if problem != "rosenbrock" and n >= 64 and rng.random() < 0.3:
         nw = rng.choice([2, 3, 5, 8])
@@ -64,7 +92,7 @@ def draw(rng):
         wt = (nwcon, nw, start, skip, nwineq)
         opts.setdefault("starting_point_strategy", "affine_step")
         opts["penalty_gamma"] = 1000.0
-    return problem, n, c, opts, wt
+    return problem, n, c, opts, wt, extra
 
 
 def cases():
@@ -86,20 +114,23 @@ def test_random_case_against_oracle(ctx, idx):
     import paropt_amd as pa
     from oracle import paropt_oracle as po
 
-    problem, n, c, opts, wt = cases()[idx]
+    problem, n, c, opts, wt, extra = cases()[idx]
     wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
+    wargs.update(extra)
     oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
     osn = []
     oip.hook = lambda s, k: osn.append(s.snapshot())
     oip.optimize()
-    prob = pa.SeparableProblem(ctx, problem, n, c)
+    prob = pa.SeparableProblem(ctx, problem, n, c, extra.get("seed", 0), 1.0, extra.get("eig_max", 100.0))
     if wt:
         prob.setWeighting(*wt)
+    if extra.get("bounds_mode", 0):
+        prob.setBoundsMode(extra["bounds_mode"])
     ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
     gsn = []
     ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
     ip.optimize()
-    what = (idx, problem, n, c, opts, wt)
+    what = (idx, problem, n, c, opts, wt, extra)
     # eight iterations: beyond that, combinations that do not converge (the sequential linear method or the
     # predictor-corrector on the convex objective) take Armijo decisions on a knife's edge -- in three of 400 drawn
     # cases the reference, the oracle and the device path each count a different number of line-search evaluations at
