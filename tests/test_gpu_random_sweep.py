@@ -157,6 +157,80 @@ def test_random_case_against_oracle(ctx, idx):
         info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)], what
 
 
+
+# ---- compact quasi-Newton classes -----------------------------------------------------------------------------------
+NQN = int(os.environ.get("PAROPT_SWEEP_QN_CASES", "16"))
+
+
+def qn_cases():
+    rng = random.Random(SEED + 2)
+    out = []
+    for _ in range(NQN):
+        kind = rng.choice(["bfgs", "bfgs", "sr1"])
+        n = rng.choice([1, 2, 3, 7, 63, 64, 65, 127, 129, 255, 300, 511, 513, 1025, 2050])
+        if kind == "sr1" and n < 3:
+            kind = "bfgs"  # (one variable under L-SR1: the compact matrix is zero up to one rounding, see draw())
+        m = rng.choice([1, 2, 3, 5, 8, 12, 20])
+        update = rng.choice(["skip_negative_curvature", "damped_update"])
+        diag = rng.choice(["yty_over_yts", "yts_over_sts", "inner_yty_over_yts", "inner_yts_over_sts"])
+        steps = rng.choice([3, m + 2, 2 * m + 3])
+        # kinds of pairs: 0 well-behaved, 1 negative curvature, 2 tiny step, 3 huge y, 4 y = 0
+        seq = [rng.choice([0, 0, 0, 0, 1, 2, 3, 4]) for _ in range(steps)]
+        out.append((kind, n, m, update, diag, seq, rng.randrange(1 << 30)))
+    return out
+
+
+@pytest.mark.parametrize("idx", range(NQN))
+def test_random_quasi_newton_sequence_against_oracle(ctx, idx):
+    """Drawn update sequences (well-behaved, negative-curvature, tiny, huge and zero pairs; widths from 1 to 20;
+    vector lengths around the tile sizes) through the device L-BFGS / L-SR1 and through the oracle: return codes and
+    compact-matrix sizes exactly, b0 / d0 / M and the products to the tolerances of the golden test."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    kind, n, m, update, diag, seq, seed = qn_cases()[idx]
+    what = qn_cases()[idx]
+    ops = po.VecOps(po.SelfComm())
+    if kind == "bfgs":
+        qn, oq = pa.LBFGS(ctx, n, m, update), po.LBFGS(n, m, ops, update)
+    else:
+        qn, oq = pa.LSR1(ctx, n, m), po.LSR1(n, m, ops)
+    qn.setInitDiagonalType(diag)
+    oq.diag_type = diag
+    rng = np.random.default_rng(seed)
+    h = 0.5 + 4.0 * rng.random(n)
+    xp_np = rng.standard_normal(n)
+    xp, s, y, out = (pa.PVec(ctx, n) for _ in range(4))
+    xp.from_numpy(xp_np)
+    for k, pk in enumerate(seq):
+        sn = rng.standard_normal(n)
+        yn = h * sn + 0.1 * rng.standard_normal(n)
+        if pk == 1:
+            yn = -0.5 * h * sn
+        elif pk == 2:
+            sn, yn = 1e-9 * sn, 1e-9 * yn
+        elif pk == 3:
+            yn = 1e8 * yn
+        elif pk == 4:
+            yn = np.zeros(n)
+        s.from_numpy(sn)
+        y.from_numpy(yn)
+        rc, orc = qn.update(s, y), oq.update(sn.copy(), yn.copy())
+        assert rc == orc, (k, what)
+        b0, d0, M, Z = qn.getCompactMat()
+        ob0, od0, oM, oZ = oq.get_compact()
+        assert len(Z) == len(oZ), (k, what)
+        assert abs(b0 - ob0) <= 1e-10 * abs(ob0), (k, b0, ob0, what)
+        if len(Z) and np.all(np.isfinite(oM)) and np.all(np.isfinite(od0)):
+            np.testing.assert_allclose(d0, od0, rtol=1e-9, err_msg=repr((k, what)))
+            np.testing.assert_allclose(M, oM, rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(oM).max()), err_msg=repr((k, what)))
+            want = oq.mult(xp_np)
+            if np.all(np.isfinite(want)) and np.linalg.cond(oM) < 1e10:
+                qn.mult(xp, out)
+                np.testing.assert_allclose(out.to_numpy(), want, rtol=0, atol=1e-6 * max(1e-300, np.abs(want).max()),
+                                           err_msg=repr((k, what)))
+
+
 if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaign with one line per failing case
     import paropt_amd as pa
 
@@ -170,3 +244,11 @@ if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaig
             msg = str(e).strip().splitlines()
             print("CASE %d %r\n     -> %s" % (i, cases()[i], " | ".join(m.strip() for m in msg[:6])[:700]), flush=True)
     print("%d of %d cases differ" % (nbad, NCASES))
+    nbad = 0
+    for i in range(NQN):
+        try:
+            test_random_quasi_newton_sequence_against_oracle(c, i)
+        except AssertionError as e:
+            nbad += 1
+            print("QN CASE %d %r\n     -> %s" % (i, qn_cases()[i], " | ".join(str(e).strip().splitlines()[:6])[:600]), flush=True)
+    print("%d of %d quasi-Newton cases differ" % (nbad, NQN))
