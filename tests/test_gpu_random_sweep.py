@@ -92,6 +92,12 @@ def draw(rng):
         wt = (nwcon, nw, start, skip, nwineq)
         opts.setdefault("starting_point_strategy", "affine_step")
         opts["penalty_gamma"] = 1000.0
+    if wt is None and n >= 63 and rng.random() < 0.15:
+        # the CSR form (ParOptSparseProblem): overlapping chain constraints, device sparse Cholesky
+        extra["chain"] = (rng.choice([2, 3]), rng.choice([1, 2]))
+        opts.setdefault("starting_point_strategy", "affine_step")
+        opts["penalty_gamma"] = opts.get("penalty_gamma", 1000.0)
+        opts.pop("use_hvec_product", None)
     return problem, n, c, opts, wt, extra
 
 
@@ -126,6 +132,8 @@ def test_random_case_against_oracle(ctx, idx):
         prob.setWeighting(*wt)
     if extra.get("bounds_mode", 0):
         prob.setBoundsMode(extra["bounds_mode"])
+    if extra.get("chain"):
+        prob.setChain(*extra["chain"])
     ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
     gsn = []
     ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
