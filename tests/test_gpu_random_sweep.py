@@ -126,7 +126,12 @@ def test_random_case_against_oracle(ctx, idx):
     oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
     osn = []
     oip.hook = lambda s, k: osn.append(s.snapshot())
-    oip.optimize()
+    try:
+        oip.optimize()
+    except np.linalg.LinAlgError:
+        # the oracle factors the sparse-constraint block with a dense Cholesky and gives up where the iterate has
+        # made it numerically indefinite (drawn CSR chains with non-convergent option sets): nothing to compare with
+        pytest.skip("the oracle's dense Cholesky of the sparse-constraint block failed")
     prob = pa.SeparableProblem(ctx, problem, n, c, extra.get("seed", 0), 1.0, extra.get("eig_max", 100.0))
     if wt:
         prob.setWeighting(*wt)
@@ -164,6 +169,92 @@ def test_random_case_against_oracle(ctx, idx):
     assert [t["info"].split() for t in oip.trace[1:ncmp]] == [
         info_tokens(ip.getHistory()).get(k, []) for k in range(1, ncmp)], what
 
+
+
+
+# ---- the same drawn cases through the host-callback boundary ---------------------------------------------------------
+def _host_twin(pa, ctx, oprob, n, c, wt):
+    """A user problem written on host arrays (getArray views), as the reference's Python examples are: every callback
+    delegates to the oracle's problem definition."""
+
+    class Twin(pa.Problem):
+        def getVarsAndBounds(self, x, lb, ub):
+            x0, l0, u0 = oprob.vars_and_bounds()
+            x[:], lb[:], ub[:] = x0, l0, u0
+
+        def evalObjCon(self, x):
+            return oprob.eval_obj_con(x)
+
+        def evalObjConGradient(self, x, g, A):
+            _, gg, aa = oprob.eval_obj_con_gradient(x)
+            g[:] = gg
+            for j in range(c):
+                A[j][:] = aa[j]
+            return 0
+
+        def evalHvecProduct(self, x, z, zw, px, hvec):
+            hvec[:] = oprob.hvec_product(x, z, px, zw)
+            return 0
+
+        def evalHessianDiag(self, x, z, zw, hdiag):
+            hdiag[:] = oprob.hessian_diag(x, z, zw)
+            return 0
+
+        def evalSparseCon(self, x, out):
+            out[:] = oprob.eval_sparse_con(x)
+            return 0
+
+        def addSparseJacobian(self, alpha, x, px, out):
+            oprob.add_sparse_jacobian(alpha, px, out)
+            return 0
+
+        def addSparseJacobianTranspose(self, alpha, x, pzw, out):
+            oprob.add_sparse_jacobian_transpose(alpha, pzw, out)
+            return 0
+
+        def addSparseInnerProduct(self, alpha, x, cvec, A):
+            oprob.add_sparse_inner_product(alpha, cvec, A)
+            return 0
+
+    if wt:
+        return Twin(ctx, n, c, nwcon=wt[0], nwinequality=wt[4])
+    return Twin(ctx, n, c)
+
+
+@pytest.mark.parametrize("idx", [i for i in range(NCASES) if i % 3 == 0])
+def test_random_case_through_host_callbacks(ctx, idx):
+    """Every third drawn case again with the problem implemented in Python on host arrays (the mirror / upload
+    machinery of po_vec_get_array under all those option combinations), against the oracle like the device problem."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    problem, n, c, opts, wt, extra = cases()[idx]
+    if extra.get("chain") or extra.get("bounds_mode"):
+        pytest.skip("CSR form / broken bounds are set-up calls of the built-in problem")
+    wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
+    wargs.update(extra)
+    oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
+    osn = []
+    oip.hook = lambda s, k: osn.append(s.snapshot())
+    oip.optimize()
+    twin = _host_twin(pa, ctx, po.SepProblem(problem, n, c, **wargs), n, c, wt)
+    ip = pa.InteriorPoint(twin, dict(opts, write_output_frequency=0))
+    gsn = []
+    ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
+    ip.optimize()
+    what = ("host", idx, problem, n, c, opts, wt, extra)
+    ncmp = min(len(osn), len(gsn), 6 if opts["qn_type"] == "sr1" else 8)
+    assert ncmp >= min(len(osn), 4), what
+    for k in range(ncmp):
+        if k > 2 and float(np.max(osn[k]["norms"])) < 1e-7:
+            ncmp = k
+            break
+    for k in range(ncmp):
+        np.testing.assert_array_equal(gsn[k]["counters"], osn[k]["counters"], err_msg="counters @%d %r" % (k, what))
+        assert gsn[k]["qn_size"] == osn[k]["qn_size"], (k, what)
+        assert abs(gsn[k]["mu"] - osn[k]["mu"]) <= 1e-6 * abs(osn[k]["mu"]), (k, what)
+        assert abs(gsn[k]["fobj"] - osn[k]["fobj"]) <= 1e-6 * max(1.0, abs(osn[k]["fobj"])), (k, what)
+        np.testing.assert_allclose(gsn[k]["norms"], osn[k]["norms"], rtol=1e-6, atol=1e-11, err_msg="%d %r" % (k, what))
 
 
 # ---- compact quasi-Newton classes -----------------------------------------------------------------------------------
@@ -251,7 +342,23 @@ if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaig
             nbad += 1
             msg = str(e).strip().splitlines()
             print("CASE %d %r\n     -> %s" % (i, cases()[i], " | ".join(m.strip() for m in msg[:6])[:700]), flush=True)
+        except BaseException as e:  # pytest.skip
+            if type(e).__name__ != "Skipped":
+                raise
     print("%d of %d cases differ" % (nbad, NCASES))
+    nbad = nrun = 0
+    for i in range(0, NCASES, 3):
+        try:
+            test_random_case_through_host_callbacks(c, i)
+            nrun += 1
+        except AssertionError as e:
+            nbad += 1
+            nrun += 1
+            print("HOST CASE %d %r\n     -> %s" % (i, cases()[i], " | ".join(str(e).strip().splitlines()[:6])[:700]), flush=True)
+        except BaseException as e:  # pytest.skip
+            if type(e).__name__ != "Skipped":
+                raise
+    print("%d of %d host-callback cases differ" % (nbad, nrun))
     nbad = 0
     for i in range(NQN):
         try:
