@@ -257,6 +257,51 @@ def test_random_case_through_host_callbacks(ctx, idx):
         np.testing.assert_allclose(gsn[k]["norms"], osn[k]["norms"], rtol=1e-6, atol=1e-11, err_msg="%d %r" % (k, what))
 
 
+
+# ---- the user-side C++ problem (examples/random_convex_amd.cpp) under drawn options ------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+USER_LIB = os.path.join(ROOT, "examples", "librandom_convex_user.so")
+
+
+def facade_cases():
+    out = []
+    for i, (problem, n, c, opts, wt, extra) in enumerate(cases()):
+        if problem == "convex" and wt is None and not extra and not opts.get("use_hvec_product") \
+                and not opts.get("use_diag_hessian") and n >= 2:
+            out.append(i)
+    return out
+
+
+@pytest.mark.parametrize("idx", facade_cases())
+def test_random_case_user_library_problem_matches_builtin(ctx, idx):
+    """The drawn convex cases once more with the problem living OUTSIDE the library (a ParOptProblem subclass on the C++
+    facade with its own kernels): counters, info tokens and pivots as the built-in twin, state to round-off."""
+    import paropt_amd as pa
+
+    assert os.path.exists(USER_LIB), "examples/librandom_convex_user.so is not built (__graft_entry__.build())"
+    problem, n, c, opts, wt, extra = cases()[idx]
+    runs = []
+    for make in (lambda: pa.SeparableProblem(ctx, "convex", n, c), lambda: pa.UserLibraryProblem(ctx, USER_LIB, n, c)):
+        prob = make()
+        ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
+        sn = []
+        ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+        ip.optimize()
+        runs.append((sn, info_tokens(ip.getHistory()), ip.getIterationCounters()))
+        del ip
+        if hasattr(prob, "close"):
+            prob.close()
+    (sa, ta, ca), (sb, tb, cb) = runs
+    what = ("facade", idx, n, c, opts)
+    ncmp = min(len(sa), len(sb), 6 if opts["qn_type"] == "sr1" else 8)
+    for k in range(ncmp):
+        np.testing.assert_array_equal(sa[k]["counters"], sb[k]["counters"], err_msg=repr((k, what)))
+        assert sa[k].get("qn_size", 0) == sb[k].get("qn_size", 0), (k, what)
+        assert abs(sa[k]["mu"] - sb[k]["mu"]) <= 1e-8 * abs(sa[k]["mu"]), (k, what)
+        assert abs(sa[k]["fobj"] - sb[k]["fobj"]) <= 1e-8 * max(1.0, abs(sa[k]["fobj"])), (k, what)
+        assert ta.get(k, []) == tb.get(k, []), (k, what)
+
+
 # ---- compact quasi-Newton classes -----------------------------------------------------------------------------------
 NQN = int(os.environ.get("PAROPT_SWEEP_QN_CASES", "16"))
 
@@ -359,6 +404,15 @@ if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaig
             if type(e).__name__ != "Skipped":
                 raise
     print("%d of %d host-callback cases differ" % (nbad, nrun))
+    nbad = 0
+    fc = facade_cases()
+    for i in fc:
+        try:
+            test_random_case_user_library_problem_matches_builtin(c, i)
+        except AssertionError as e:
+            nbad += 1
+            print("FACADE CASE %d %r\n     -> %s" % (i, cases()[i], " | ".join(str(e).strip().splitlines()[:6])[:700]), flush=True)
+    print("%d of %d user-library cases differ" % (nbad, len(fc)))
     nbad = 0
     for i in range(NQN):
         try:
