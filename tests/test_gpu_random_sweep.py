@@ -25,7 +25,7 @@ def draw(rng):
         n = max(n, 8)
         c = 2
     else:
-        c = rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 40])
+        c = rng.choice([1, 1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 40, 40, 70, 97])  # (70 / 97: blocked Gram, collapsed sums)
     qn = rng.choice(["bfgs", "bfgs", "sr1"])
     if qn == "sr1" and n < 3:
         # one variable: the L-SR1 compact matrix s.y - (y.y / s.y) s.s is zero up to one rounding and the reference
