@@ -473,3 +473,80 @@ def test_user_library_problem_on_two_ranks(deferred):
     assert abs(got[1] - ref[1]) <= 1e-9 * max(1.0, abs(ref[1]))
     np.testing.assert_allclose(got[2], ref[2], rtol=0, atol=1e-7)
     user.close()
+
+
+# ---- drawn cases (tests/test_gpu_random_sweep.py) sharded over three ranks ---------------------------------------------
+def _drawn_dense_cases(limit):
+    import test_gpu_random_sweep as T
+
+    out = []
+    for problem, n, c, opts, wt, extra in T.cases():
+        if wt is None and not extra.get("chain") and n >= 3 and problem != "rosenbrock":
+            out.append((problem, n, c, opts, extra))
+        if len(out) == limit:
+            break
+    return out
+
+
+def _run_drawn(pa, ctx, case):
+    problem, n, c, opts, extra = case
+    prob = pa.SeparableProblem(ctx, problem, n, c, extra.get("seed", 0), 1.0, extra.get("eig_max", 100.0))
+    if extra.get("bounds_mode", 0):
+        prob.setBoundsMode(extra["bounds_mode"])
+    ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0, max_major_iters=6))
+    snaps = []
+    ip.setIterationCallback(lambda k: snaps.append(ip.snapshot()))
+    ip.optimize()
+    return prob, [(tuple(int(v) for v in s["counters"]), int(s["qn_size"]), float(s["fobj"]), float(s["mu"]),
+                   tuple(float(v) for v in s["norms"])) for s in snaps], ip.getOptimizedPoint()[0].to_numpy()
+
+
+def _worker_drawn(rank, world, port, q, ncases):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import paropt_amd as pa
+
+    ctx = pa.Context(0)
+    ctx.init_callback_from_torch()
+    res = []
+    for case in _drawn_dense_cases(ncases):
+        prob, snaps, x = _run_drawn(pa, ctx, case)
+        xs = [None] * world
+        dist.all_gather_object(xs, (prob.offset, x))
+        res.append((snaps, np.concatenate([a for _, a in sorted(xs, key=lambda t: t[0])])))
+    if rank == 0:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_drawn_cases_on_three_ranks_match_single_rank():
+    """Ten drawn dense cases (sizes around the tile sizes, all barrier strategies, norms, line-search and quasi-Newton
+    switches) with the design vector sharded over THREE ranks -- uneven shards, odd shard lengths -- against the
+    single-rank run: counters exactly, objective / barrier parameter / norms / the point to 1e-7."""
+    import paropt_amd as pa
+
+    ncases = 10
+    ctx = pa.Context(0)
+    single = [_run_drawn(pa, ctx, case)[1:] for case in _drawn_dense_cases(ncases)]
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_worker_drawn, args=(r, 3, port, q, ncases)) for r in range(3)]
+    for p in procs:
+        p.start()
+    multi = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for case, (s1, x1), (s3, x3) in zip(_drawn_dense_cases(ncases), single, multi):
+        assert len(s1) == len(s3), case
+        for a, b in zip(s3, s1):
+            assert a[0] == b[0] and a[1] == b[1], (case, a, b)
+            assert abs(a[2] - b[2]) <= 1e-7 * max(1.0, abs(b[2])), (case, a, b)
+            assert abs(a[3] - b[3]) <= 1e-7 * abs(b[3]), (case, a, b)
+            np.testing.assert_allclose(a[4], b[4], rtol=1e-6, atol=1e-10, err_msg=repr(case))
+        np.testing.assert_allclose(x3, x1, rtol=0, atol=1e-7, err_msg=repr(case))
