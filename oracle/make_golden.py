@@ -493,6 +493,14 @@ case("tr_rand_convex_n200_c3_constobj", "tr", problem="convex", n=200, c=3, dump
 case("tr_rand_quadratic_n65_c1_subobj", "tr", problem="quadratic", n=65, c=1, dump_vecs_every=4,
      **dict(tr_rand, **{"opt.qn_subspace_size": 2, "tr.tr_adaptive_objective": "subproblem_objective",
                         "tr.tr_init_size": 0.05, "opt.penalty_gamma": 10.0}))
+case("tr_rand_eig_quadratic_n257_c3_N5_subcon", "tr", problem="quadratic", n=257, c=3, eig_N=5, eig_index=2, eig_curv=1.0,
+     dump_vecs_every=4, **dict(tr_rand, **{"opt.qn_subspace_size": 3, "tr.tr_adaptive_constraint": "subproblem_constraint",
+                                            "tr.tr_eta": 0.1}))
+case("tr_rand_convex_n255_c2_w51_fixedgamma", "tr", problem="convex", n=255, c=2, nwcon=51, nw=4, nwstart=0, nwskip=1,
+     dump_vecs_every=4, **dict(tr_rand, **{"opt.qn_subspace_size": 4, "tr.tr_adaptive_gamma_update": 0,
+                                            "opt.penalty_gamma": 100.0, "tr.tr_init_size": 0.05}))
+case("tr_rand_rosenbrock_n129_sr1_eta01", "tr", problem="rosenbrock", n=129, dump_vecs_every=4,
+     **dict(tr_rand, **{"opt.qn_type": "sr1", "opt.qn_subspace_size": 5, "tr.tr_eta": 0.1, "tr.tr_max_size": 2.0}))
 # the metric's configuration (config 3 shape: convex objective, c = 32, L-SR1(10)) under the trust-region driver,
 # where L-SR1 makes progress, at n = 1e5 on four MPI ranks; subproblem solves capped at 200 interior-
 # point iterations as the reference's trust-region examples set it

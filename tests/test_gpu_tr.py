@@ -83,7 +83,7 @@ def run_gpu_tr(ctx, case, python_eig_callback=False, capture_lines=None):
 TR_CASES = golden_names("tr_")
 
 # Rows of the iteration tables whose interior-point iteration counts differ from the reference's (everything
-# else in every row of every golden is identical: 548 of 558 compared rows).  In each of them the steering LP
+# else in every row of every golden is identical: 584 of 594 compared rows).  In each of them the steering LP
 # (sequential linear method, predictor-corrector barrier) or the QP ends on a round-off level test: the iterate
 # crawls with |infeas| ~ 1e-15 against rho ~ 1e15 or sits on `LNoImprv` until the complementarity crosses
 # 0.1 abs_res_tol, and the iteration at which that happens moves by a few with the summation order of the
