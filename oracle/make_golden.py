@@ -441,6 +441,23 @@ case("ip_convex_diaghess_n300_c3", "ip", problem="convex", n=300, c=3, dump_vecs
 case("ip_rosenbrock_diaghess_n100", "ip", problem="rosenbrock", n=100, dump_vecs_every=10,
      **{"opt.use_diag_hessian": 1, "opt.qn_subspace_size": 10, "opt.abs_res_tol": 1e-6,
         "opt.write_output_frequency": 1, "opt.max_major_iters": 150})
+# the two defects the random sweep of round 3 found, pinned against the reference itself: an odd n under the sequential
+# linear method (zero diagonal: the pad element of the re-formed Dinv), and the sequential linear method together with
+# use_diag_hessian (the diagonal is never evaluated, :4920-4949) on a problem with sparse constraints
+case("ip_convex_n2049_c3_seqlin", "ip", problem="convex", n=2049, c=3, dump_vecs_every=6,
+     **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-8, "opt.start_affine_multiplier_min": 0.01,
+        "opt.max_major_iters": 12, "opt.barrier_strategy": "monotone", "opt.sequential_linear_method": 1,
+        "opt.write_output_frequency": 1})
+case("ip_quadratic_n129_c17_w20_seqlin_diaghess", "ip", problem="quadratic", n=129, c=17, nwcon=20, nw=2, nwstart=5,
+     nwskip=1, nwineq=20, dump_vecs_every=4,
+     **{"opt.qn_subspace_size": 2, "opt.qn_type": "sr1", "opt.abs_res_tol": 1e-8, "opt.start_affine_multiplier_min": 0.01,
+        "opt.max_major_iters": 8, "opt.norm_type": "l2", "opt.sequential_linear_method": 1, "opt.use_diag_hessian": 1,
+        "opt.qn_sigma": 1.0, "opt.starting_point_strategy": "affine_step", "opt.penalty_gamma": 1000.0,
+        "opt.write_output_frequency": 1})
+case("ip_quadratic_n511_c2_seqlin_mpc", "ip", problem="quadratic", n=511, c=2, dump_vecs_every=6,
+     **{"opt.qn_subspace_size": 5, "opt.qn_type": "bfgs", "opt.abs_res_tol": 1e-8, "opt.start_affine_multiplier_min": 0.01,
+        "opt.max_major_iters": 10, "opt.barrier_strategy": "mehrotra_predictor_corrector",
+        "opt.sequential_linear_method": 1, "opt.write_output_frequency": 1})
 # --- method of moving asymptotes (ParOptOptimizer algorithm = "mma", src/ParOptMMA.cpp) ---
 case("mma_convex_n300_c3", "mma", problem="convex", n=300, c=3, **{"mma.mma_max_iterations": 30})
 case("mma_quadratic_n200_c2", "mma", problem="quadratic", n=200, c=2, **{"mma.mma_max_iterations": 25})
