@@ -485,6 +485,9 @@ def _drawn_dense_cases(limit):
             out.append((problem, n, c, opts, extra))
         if len(out) == limit:
             break
+    # ... and one with fewer variables than ranks: the third rank owns an EMPTY shard
+    out.append(("quadratic", 2, 1, {"qn_subspace_size": 2, "qn_type": "bfgs", "abs_res_tol": 1e-8,
+                                    "start_affine_multiplier_min": 0.01, "max_major_iters": 6}, {}))
     return out
 
 
