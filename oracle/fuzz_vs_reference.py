@@ -36,7 +36,11 @@ def main():
     for i, (problem, n, c, opts, wt, extra) in enumerate(T.cases()):
         wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
         wargs.update(extra)
-        oip = po.InteriorPoint(po.SepProblem(problem, n, c, **wargs), opts)
+        bopt = wargs.pop("bound_options", None)
+        oprob = po.SepProblem(problem, n, c, **wargs)
+        if bopt:
+            oprob.use_lower, oprob.use_upper = bool(bopt[0]), bool(bopt[1])
+        oip = po.InteriorPoint(oprob, opts)
         osn = []
         oip.hook = lambda s, k: osn.append(s.snapshot())
         try:
@@ -54,6 +58,8 @@ def main():
             args.append("eig_max=%r" % extra["eig_max"])
         if "bounds_mode" in extra:
             args.append("bounds_mode=%d" % extra["bounds_mode"])
+        if "bound_options" in extra:
+            args += ["use_lower=%d" % extra["bound_options"][0], "use_upper=%d" % extra["bound_options"][1]]
         if "chain" in extra:
             args += ["chain_span=%d" % extra["chain"][0], "chain_stride=%d" % extra["chain"][1]]
         for k, v in opts.items():
@@ -85,7 +91,7 @@ def main():
             if abs(g[p + "mu"][0] - osn[k]["mu"]) > 1e-6 * abs(g[p + "mu"][0]):
                 msg = "mu @%d: reference %r oracle %r" % (k, g[p + "mu"][0], osn[k]["mu"])
                 break
-            if not np.allclose(g[p + "norms"], osn[k]["norms"], rtol=1e-6, atol=1e-11):
+            if not np.allclose(g[p + "norms"], osn[k]["norms"], rtol=1e-6, atol=1e-11, equal_nan=True):
                 msg = "norms @%d: reference %s oracle %s" % (k, g[p + "norms"], osn[k]["norms"])
                 break
         if msg:
