@@ -114,11 +114,29 @@ def cases():
     return [draw(rng) for _ in range(NCASES)]
 
 
-@pytest.fixture(scope="module")
-def ctx():
+def _make_ctx():
+    """PAROPT_SWEEP_RCCL=1: every reduction of the campaign goes through the RCCL communicator (one rank: ncclAllReduce /
+    ncclAllGather on the solver's stream, device-to-host copy) instead of the single-rank shortcut."""
     import paropt_amd as pa
 
+    if os.environ.get("PAROPT_SWEEP_RCCL", "0") != "1":
+        return pa.Context(0)
+    import ctypes as C
+
+    from paropt_amd.lib import check, lib
+
+    os.environ["PAROPT_AMD_FORCE_RCCL"] = "1"
     c = pa.Context(0)
+    buf = (C.c_char * 128)()
+    check(lib.po_rccl_unique_id(buf))
+    check(lib.po_ctx_comm_init_rccl(c.handle, 0, 1, buf))
+    assert c.comm_info()[0] == 1
+    return c
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _make_ctx()
     yield c
     c.close()
 
@@ -401,9 +419,7 @@ def test_random_quasi_newton_sequence_against_oracle(ctx, idx):
 
 
 if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaign with one line per failing case
-    import paropt_amd as pa
-
-    c = pa.Context(0)
+    c = _make_ctx()
     nbad = 0
     for i in range(NCASES):
         try:
