@@ -547,8 +547,9 @@ class ParOptProblem : public ParOptBase {
   // relative error seen (the reference returns nothing).
   double checkGradients(double dh, ParOptVec *xvec = NULL, int check_hvec_product = 0);
 
-  // the C-callback problem handed to the library (created on first use)
-  po_problem handle() {
+  // the C-callback problem handed to the library (created on first use); the library-backed trust-region
+  // subproblems return the library's own object instead
+  virtual po_problem handle() {
     if (!hprob) {
       ParOptQuasiDefMat *qd = createQuasiDefMat();
       if (qd) {
@@ -754,7 +755,7 @@ enum ParOptQuasiNewtonDiagonalType {
 
 class ParOptCompactQuasiNewton : public ParOptBase {
  public:
-  ~ParOptCompactQuasiNewton() {
+  virtual ~ParOptCompactQuasiNewton() {
     for (ParOptVec *v : zwrap) v->decref();
     if (h) po_qn_destroy(h);
   }
@@ -762,11 +763,13 @@ class ParOptCompactQuasiNewton : public ParOptBase {
     po_qn_set_diag_type(h, t == PAROPT_YTS_OVER_STS ? PO_QN_YTS_OVER_STS : PO_QN_YTY_OVER_YTS);
   }
   void reset() { po_qn_reset(h); }
-  int update(ParOptVec *, const ParOptScalar *, ParOptVec *, ParOptVec *s, ParOptVec *y) {
+  virtual int update(ParOptVec *, const ParOptScalar *, ParOptVec *, ParOptVec *s, ParOptVec *y) {
     int rc = 0;
     po_qn_update(h, s->handle(), y->handle(), &rc);
     return rc;
   }
+  // multiplier-only update (src/ParOptQuasiNewton.h:60-63): a no-op for the limited-memory classes
+  virtual int update(ParOptVec *, const ParOptScalar *, ParOptVec *) { return 0; }
   void mult(ParOptVec *x, ParOptVec *y) { po_qn_mult(h, x->handle(), y->handle()); }
   void multAdd(ParOptScalar alpha, ParOptVec *x, ParOptVec *y) { po_qn_mult_add(h, alpha, x->handle(), y->handle()); }
   int getCompactMat(ParOptScalar *b0, const ParOptScalar **d, const ParOptScalar **M, ParOptVec ***Z) {
@@ -908,6 +911,37 @@ class ParOptInteriorPoint : public ParOptBase {
   }
   void resetQuasiNewtonHessian() { po_ip_reset_quasi_newton(ip); }
   void resetDesignAndBounds() { po_ip_reset_design_and_bounds(ip); }
+  // checkGradients(dh) (src/ParOptInteriorPoint.h:166, .cpp:6196-6199): the problem's finite-difference check at the
+  // solver's current point (with the Hessian-vector product when use_hvec_product is set); prints the report
+  void checkGradients(double dh) {
+    applyOptions();
+    const char *report = NULL;
+    if (po_ip_check_gradients(ip, dh, &report) != 0) {
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    } else if (report) {
+      int rank = 0;
+      po_ctx_rank(prob->getContext(), &rank, NULL);
+      if (rank == 0) fputs(report, stdout);
+    }
+  }
+  // setBFGSUpdateType (.h:172, .cpp:1179-1186): applies to the solver's own L-BFGS object
+  void setBFGSUpdateType(ParOptBFGSUpdateType update) {
+    po_qn q = NULL;
+    if (po_ip_get_quasi_newton(ip, &q) == 0 && q)
+      po_qn_set_update_type(q, update == PAROPT_DAMPED_UPDATE ? PO_BFGS_DAMPED_UPDATE : PO_BFGS_SKIP_NEGATIVE_CURVATURE);
+  }
+  // setUseDiagHessian (.h:181; declared but never defined in the reference): the use_diag_hessian option
+  void setUseDiagHessian(int truth) {
+    if (options) options->setOption("use_diag_hessian", truth ? 1 : 0);
+    po_ip_set_option_int(ip, "use_diag_hessian", truth ? 1 : 0);
+  }
+  // checkMeritFuncGradient(xpt, dh) (.h:199, .cpp:3280-3432): prints "Merit function test" and the two derivatives
+  void checkMeritFuncGradient(ParOptVec *xpt = NULL, double dh = 1e-6) {
+    applyOptions();
+    if (po_ip_check_merit_func_gradient(ip, xpt ? xpt->handle() : NULL, dh, NULL, NULL) != 0)
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  po_ip handle() { return ip; }
   int writeSolutionFile(const char *filename) { return po_ip_write_solution_file(ip, filename); }
   int readSolutionFile(const char *filename) { return po_ip_read_solution_file(ip, filename); }
   const char *getHistory() { const char *t = ""; po_ip_get_history(ip, &t); return t; }
@@ -927,6 +961,353 @@ class ParOptInteriorPoint : public ParOptBase {
   ParOptVec *x, *zl, *zu, *zw, *sw, *tw;
 };
 
+// ---- the trust-region layer, class by class (src/ParOptTrustRegion.h:15-480, ----------------------------------
+// src/ParOptCompactEigenvalueApprox.h:7-206).  The objects are handles to the library's device-side
+// implementations; they are assembled exactly as the reference's user code assembles them
+// (examples/eigenvalue/eigenvalue_opt.py:298-308, src/ParOptOptimizer.cpp:108-183):
+//     qn = new ParOptLBFGS(problem, m);                      approx = new ParOptCompactEigenApprox(problem, N);
+//     eig_qn = new ParOptEigenQuasiNewton(qn, approx, 0);    sub = new ParOptEigenSubproblem(problem, eig_qn);
+//     sub->setEigenModelUpdate(data, update);                ip = new ParOptInteriorPoint(sub, options);
+//     tr = new ParOptTrustRegion(sub, options);              tr->optimize(ip);
+// c(s) = c0 + g0^T s + 1/2 s^T H M H^T s with N curvature directions H = [h_0 .. h_{N-1}]
+class ParOptCompactEigenApprox : public ParOptBase {
+ public:
+  ParOptCompactEigenApprox(ParOptProblem *problem, int _N) : h(NULL), g0w(NULL) {
+    if (po_eig_create(problem->handle(), _N, &h) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  ~ParOptCompactEigenApprox() {
+    dropWrappers();
+    if (h) po_eig_destroy(h);
+  }
+  void multAdd(ParOptScalar alpha, ParOptVec *x, ParOptVec *y) { po_eig_mult_add(h, alpha, x->handle(), y->handle()); }
+  // borrowed pointers into the approximation: the caller writes c0, M, Minv directly and the vectors through
+  // getArray (what it wrote is uploaded when the model-update callback returns, or by releaseArray(1))
+  void getApproximation(ParOptScalar **_c0, ParOptVec **_g0, int *_N, ParOptScalar **_M, ParOptScalar **_Minv,
+                        ParOptVec ***_hvecs) {
+    po_vec g0 = NULL;
+    const po_vec *hv = NULL;
+    int N = 0;
+    po_eig_get_approximation(h, _c0, &g0, &N, _M, _Minv, &hv);
+    if (!g0w) {
+      g0w = new ParOptBasicVec(g0);
+      g0w->incref();
+      for (int i = 0; i < N; i++) {
+        hw.push_back(new ParOptBasicVec(hv[i]));
+        hw.back()->incref();
+      }
+    }
+    if (_g0) *_g0 = g0w;
+    if (_N) *_N = N;
+    if (_hvecs) *_hvecs = hw.data();
+  }
+  ParOptScalar evalApproximation(ParOptVec *s, ParOptVec *t) {
+    double v = 0.0;
+    po_eig_eval_approximation(h, s ? s->handle() : NULL, t ? t->handle() : NULL, &v);
+    return v;
+  }
+  void evalApproximationGradient(ParOptVec *s, ParOptVec *grad) {
+    po_eig_eval_approximation_gradient(h, s->handle(), grad->handle());
+  }
+  po_eig handle() { return h; }
+
+ private:
+  void dropWrappers() {
+    if (g0w) g0w->decref();
+    g0w = NULL;
+    for (ParOptVec *v : hw) v->decref();
+    hw.clear();
+  }
+  po_eig h;
+  ParOptVec *g0w;
+  std::vector<ParOptVec *> hw;
+};
+
+// B = B_qn - z0 * H M H^T as one compact matrix over [Z_qn | H]; z0 follows the multiplier of constraint `index`
+class ParOptEigenQuasiNewton : public ParOptCompactQuasiNewton {
+ public:
+  ParOptEigenQuasiNewton(ParOptCompactQuasiNewton *_qn, ParOptCompactEigenApprox *_eigh, int _index = 0)
+      : qn(_qn), eigh(_eigh), index(_index) {
+    if (qn) qn->incref();
+    eigh->incref();
+    if (po_eigqn_create(qn ? qn->handle() : NULL, eigh->handle(), index, &h) != 0)
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  ~ParOptEigenQuasiNewton() {
+    if (h) po_qn_destroy(h);  // before the objects it borrows
+    h = NULL;
+    eigh->decref();
+    if (qn) qn->decref();
+  }
+  void setUseQuasiNewtonObjective(int truth) { po_eigqn_set_use_quasi_newton_objective(h, truth); }
+  // the curvature pair goes to the quasi-Newton object itself (acceptTrialStep); here only z0 is recorded
+  int update(ParOptVec *, const ParOptScalar *z, ParOptVec *, ParOptVec *, ParOptVec *) {
+    po_eigqn_update_multipliers(h, z);
+    return 0;
+  }
+  int update(ParOptVec *, const ParOptScalar *z, ParOptVec *) {
+    po_eigqn_update_multipliers(h, z);
+    return 0;
+  }
+  ParOptCompactQuasiNewton *getCompactQuasiNewton() { return qn; }
+  ParOptCompactEigenApprox *getCompactEigenApprox() { return eigh; }
+  int getMultiplierIndex() { return index; }
+
+ private:
+  ParOptCompactQuasiNewton *qn;
+  ParOptCompactEigenApprox *eigh;
+  int index;
+};
+
+// The subproblem interface (src/ParOptTrustRegion.h:15-151).  The two library forms below implement it on the
+// device; ParOptTrustRegion drives those (a user-written subclass has no device-side counterpart: INTEGRATION.md 5).
+class ParOptTrustRegionSubproblem : public ParOptProblem {
+ public:
+  explicit ParOptTrustRegionSubproblem(ParOptComm _comm) : ParOptProblem(_comm) {}
+  virtual ParOptCompactQuasiNewton *getQuasiNewton() = 0;
+  virtual void initModelAndBounds(double tr_size) = 0;
+  virtual void setTrustRegionBounds(double tr_size) = 0;
+  virtual int evalTrialStepAndUpdate(int update_flag, ParOptVec *step, ParOptScalar *z, ParOptVec *zw,
+                                     ParOptScalar *fobj, ParOptScalar *cons) = 0;
+  virtual int acceptTrialStep(ParOptVec *xt, ParOptScalar *z, ParOptVec *zw) = 0;
+  virtual void rejectTrialStep() = 0;
+  virtual int getQuasiNewtonUpdateType() { return 0; }
+  virtual int getLinearModel(ParOptVec **_xk = NULL, ParOptScalar *fk = NULL, ParOptVec **gk = NULL,
+                             const ParOptScalar **ck = NULL, ParOptVec ***Ak = NULL, ParOptVec **lb = NULL,
+                             ParOptVec **ub = NULL) = 0;
+  // the library object behind a library-backed subproblem (NULL for a user-written one)
+  virtual po_trsub subHandle() { return NULL; }
+};
+
+// common part of the two library-backed subproblems: everything forwards to the po_trsub object
+class ParOptLibrarySubproblem : public ParOptTrustRegionSubproblem {
+ public:
+  ~ParOptLibrarySubproblem() {
+    dropWrappers();
+    if (sub) po_trsub_destroy(sub);
+    if (base) base->decref();
+  }
+  po_trsub subHandle() { return sub; }
+  po_problem handle() {
+    po_problem p = NULL;
+    if (sub) po_trsub_problem(sub, &p);
+    return p;
+  }
+  void initModelAndBounds(double tr_size) { check(po_trsub_init_model_and_bounds(sub, tr_size)); }
+  void setTrustRegionBounds(double tr_size) { check(po_trsub_set_trust_region_bounds(sub, tr_size)); }
+  int evalTrialStepAndUpdate(int update_flag, ParOptVec *step, ParOptScalar *z, ParOptVec *zw, ParOptScalar *fobj,
+                             ParOptScalar *cons) {
+    return po_trsub_eval_trial_step_and_update(sub, update_flag, step->handle(), z, zw ? zw->handle() : NULL, fobj,
+                                               cons) != 0;
+  }
+  int acceptTrialStep(ParOptVec *step, ParOptScalar *z, ParOptVec *zw) {
+    return po_trsub_accept_trial_step(sub, step->handle(), z, zw ? zw->handle() : NULL) != 0;
+  }
+  void rejectTrialStep() { po_trsub_reject_trial_step(sub); }
+  int getQuasiNewtonUpdateType() {
+    int t = 0;
+    po_trsub_get_quasi_newton_update_type(sub, &t);
+    return t;
+  }
+  int getLinearModel(ParOptVec **_xk = NULL, ParOptScalar *_fk = NULL, ParOptVec **_gk = NULL,
+                     const ParOptScalar **_ck = NULL, ParOptVec ***_Ak = NULL, ParOptVec **_lb = NULL,
+                     ParOptVec **_ub = NULL) {
+    po_vec xk, gk, lb, ub;
+    const po_vec *Ak = NULL;
+    int m = 0;
+    po_trsub_get_linear_model(sub, &xk, _fk, &gk, _ck, &Ak, &lb, &ub, &m);
+    dropWrappers();
+    po_vec hs[4] = {xk, gk, lb, ub};
+    for (int i = 0; i < 4; i++) {
+      lin[i] = new ParOptBasicVec(hs[i]);
+      lin[i]->incref();
+    }
+    for (int i = 0; i < m; i++) {
+      akw.push_back(new ParOptBasicVec(Ak[i]));
+      akw.back()->incref();
+    }
+    if (_xk) *_xk = lin[0];
+    if (_gk) *_gk = lin[1];
+    if (_lb) *_lb = lin[2];
+    if (_ub) *_ub = lin[3];
+    if (_Ak) *_Ak = akw.data();
+    return m;
+  }
+  // the ParOptProblem side (what the interior-point solver sees) answers through the library object as well
+  void getVarsAndBounds(ParOptVec *x, ParOptVec *lb, ParOptVec *ub) {
+    check(po_problem_get_vars_and_bounds(handle(), x->handle(), lb->handle(), ub->handle()));
+  }
+  int evalObjCon(ParOptVec *x, ParOptScalar *fobj, ParOptScalar *cons) {
+    return po_problem_eval_obj_con(handle(), x->handle(), fobj, cons) != 0;
+  }
+  int evalObjConGradient(ParOptVec *x, ParOptVec *g, ParOptVec **Ac) {
+    std::vector<po_vec> hs(ncon > 0 ? ncon : 1, (po_vec)NULL);
+    for (int i = 0; Ac && i < ncon; i++) hs[i] = Ac[i]->handle();
+    return po_problem_eval_obj_con_gradient(handle(), x->handle(), g->handle(), Ac ? hs.data() : NULL) != 0;
+  }
+  void writeOutput(int iter, ParOptVec *x) { base->writeOutput(iter, x); }
+
+ protected:
+  ParOptLibrarySubproblem(ParOptProblem *_base) : ParOptTrustRegionSubproblem(_base->getMPIComm()), base(_base), sub(NULL) {
+    base->incref();
+    int nv = 0, nc = 0, nwc = 0, nineq = 0, nwineq = 0;
+    base->getProblemSizes(&nv, &nc, &nwc);
+    base->getNumInequalities(&nineq, &nwineq);
+    setProblemSizes(nv, nc, nwc);
+    setNumInequalities(nineq, nwineq);
+    for (int i = 0; i < 4; i++) lin[i] = NULL;
+  }
+  void check(int rc) {
+    if (rc != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  void dropWrappers() {
+    for (int i = 0; i < 4; i++) {
+      if (lin[i]) lin[i]->decref();
+      lin[i] = NULL;
+    }
+    for (ParOptVec *v : akw) v->decref();
+    akw.clear();
+  }
+  ParOptProblem *base;
+  po_trsub sub;
+  ParOptVec *lin[4];
+  std::vector<ParOptVec *> akw;
+};
+
+// quadratic model with the compact quasi-Newton Hessian (src/ParOptTrustRegion.h:153-300); _qn may be NULL
+class ParOptQuadraticSubproblem : public ParOptLibrarySubproblem {
+ public:
+  ParOptQuadraticSubproblem(ParOptProblem *_problem, ParOptCompactQuasiNewton *_qn)
+      : ParOptLibrarySubproblem(_problem), qn(_qn) {
+    if (qn) qn->incref();
+    check(po_trsub_create_quadratic(_problem->handle(), qn ? qn->handle() : NULL, &sub));
+  }
+  ~ParOptQuadraticSubproblem() {
+    if (sub) po_trsub_destroy(sub);  // before the quasi-Newton object it borrows
+    sub = NULL;
+    if (qn) qn->decref();
+  }
+  ParOptCompactQuasiNewton *getQuasiNewton() { return qn; }
+
+ private:
+  ParOptCompactQuasiNewton *qn;
+};
+
+// the compact eigenvalue model of one constraint under the same driver (...EigenvalueApprox.h:86-206)
+class ParOptEigenSubproblem : public ParOptLibrarySubproblem {
+ public:
+  ParOptEigenSubproblem(ParOptProblem *_problem, ParOptEigenQuasiNewton *_qn)
+      : ParOptLibrarySubproblem(_problem), approx(_qn), data(NULL), updateEigenModel(NULL) {
+    approx->incref();
+    check(po_trsub_create_eigen(_problem->handle(), approx->handle(), &sub));
+  }
+  ~ParOptEigenSubproblem() {
+    if (sub) po_trsub_destroy(sub);
+    sub = NULL;
+    approx->decref();
+  }
+  // update(data, x, approx) is called at the starting point and at every accepted point with c0 and g0 preset to
+  // the constraint's value and gradient; it fills hvecs, M and Minv (and may change c0 / g0)
+  void setEigenModelUpdate(void *_data, void (*update)(void *, ParOptVec *, ParOptCompactEigenApprox *)) {
+    data = _data;
+    updateEigenModel = update;
+    check(po_trsub_set_eigen_model_update(sub, update ? &ParOptEigenSubproblem::tramp_update : NULL, this));
+  }
+  ParOptCompactQuasiNewton *getQuasiNewton() { return approx; }
+
+ private:
+  static int tramp_update(void *self, po_vec x, po_eig) {
+    ParOptEigenSubproblem *me = static_cast<ParOptEigenSubproblem *>(self);
+    Arg vx(x, 0);
+    // the library's approximation IS the one behind the caller's object: hand that object over, as the reference does
+    me->updateEigenModel(me->data, vx.p(), me->approx->getCompactEigenApprox());
+    return 0;
+  }
+  ParOptEigenQuasiNewton *approx;
+  void *data;
+  void (*updateEigenModel)(void *, ParOptVec *, ParOptCompactEigenApprox *);
+};
+
+// ParOptTrustRegion (src/ParOptTrustRegion.h:376-480): SL1QP with the adaptive penalty update, or the filter method
+class ParOptTrustRegion : public ParOptBase {
+ public:
+  static void addDefaultOptions(ParOptOptions *options) { options->addLibraryDefaults(1); }
+  ParOptTrustRegion(ParOptTrustRegionSubproblem *_subproblem, ParOptOptions *_options = NULL)
+      : subproblem(_subproblem), options(_options), tr(NULL), x(NULL) {
+    subproblem->incref();
+    if (!options) {
+      options = new ParOptOptions();
+      addDefaultOptions(options);
+    }
+    options->incref();
+    if (!subproblem->subHandle()) {
+      fprintf(stderr, "ParOptAMD: ParOptTrustRegion needs a library-backed subproblem (ParOptQuadraticSubproblem or "
+                      "ParOptEigenSubproblem)\n");
+    } else if (po_tr_create_subproblem(subproblem->subHandle(), &tr) != 0) {
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+    }
+    applyOptions();
+  }
+  ~ParOptTrustRegion() {
+    if (x) x->decref();
+    if (tr) po_tr_destroy(tr);
+    options->decref();
+    subproblem->decref();
+  }
+  ParOptOptions *getOptions() { return options; }
+  void initialize() {
+    applyOptions();
+    if (tr && po_tr_initialize(tr) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  void setPenaltyGamma(double gamma) {
+    applyOptions();
+    if (tr) po_tr_set_penalty_gamma(tr, gamma);
+  }
+  void setPenaltyGamma(const double *gamma) {
+    applyOptions();
+    if (tr) po_tr_set_penalty_gamma_array(tr, gamma);
+  }
+  int getPenaltyGamma(const double **gamma) {
+    int m = 0;
+    subproblem->getProblemSizes(NULL, &m, NULL);
+    if (tr) po_tr_get_state(tr, NULL, NULL, NULL, NULL, gamma, NULL, NULL);
+    return m;
+  }
+  // declared by the reference (src/ParOptTrustRegion.h:394-395) without a definition: the two options
+  void setPenaltyGammaMax(double gamma_max) { options->setOption("tr_penalty_gamma_max", gamma_max); }
+  void setPenaltyGammaMin(double gamma_min) { options->setOption("tr_penalty_gamma_min", gamma_min); }
+  // optimize(ip): `optimizer` must have been built on this subproblem (ParOptInteriorPoint(subproblem, options))
+  void optimize(ParOptInteriorPoint *optimizer) {
+    if (!tr || !optimizer) return;
+    optimizer->applyOptions();
+    applyOptions();
+    if (po_tr_optimize_with(tr, optimizer->handle()) != 0) fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  void getOptimizedPoint(ParOptVec **_x) {
+    if (_x && subproblem) subproblem->getLinearModel(_x);
+  }
+  const char *getHistory() {
+    const char *t = "";
+    if (tr) po_tr_get_history(tr, &t);
+    return t;
+  }
+  po_tr handle() { return tr; }
+
+ private:
+  void applyOptions() {
+    if (!tr) return;
+    po_tr h = tr;
+    if (options->forward(
+            1, [h](const char *n, const char *v) { return po_tr_set_option_str(h, n, v); },
+            [h](const char *n, int v) { return po_tr_set_option_int(h, n, v); },
+            [h](const char *n, double v) { return po_tr_set_option_float(h, n, v); }) != 0)
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  ParOptTrustRegionSubproblem *subproblem;
+  ParOptOptions *options;
+  po_tr tr;
+  ParOptVec *x;
+};
+
 // ---- ParOptOptimizer: algorithm = "ip" | "tr" | "mma" (src/ParOptOptimizer.cpp:65-206) --------------
 // The reference's generic entry point.  "tr" builds the quasi-Newton object, the quadratic
 // subproblem, the interior-point sub-solver and the trust-region driver exactly as :108-183 does.
@@ -944,13 +1325,28 @@ class ParOptOptimizer : public ParOptBase {
   ParOptOptions *getOptions() { return options; }
   ParOptProblem *getProblem() { return prob; }
   ParOptOptimizer(ParOptProblem *_prob, ParOptOptions *_options)
-      : prob(_prob), options(_options), ip(NULL), tr(NULL), mma(NULL), x(NULL) {
+      : prob(_prob), options(_options), ip(NULL), tr(NULL), mma(NULL), x(NULL), subproblem(NULL), trobj(NULL) {
     prob->incref();
     options->incref();
   }
+  // setTrustRegionSubproblem (src/ParOptOptimizer.h:42, .cpp:226-237): algorithm = "tr" then drives the caller's
+  // subproblem (e.g. a ParOptEigenSubproblem) instead of building a ParOptQuadraticSubproblem from the options
+  void setTrustRegionSubproblem(ParOptTrustRegionSubproblem *_subproblem) {
+    if (_subproblem) _subproblem->incref();
+    if (trobj) trobj->decref();
+    trobj = NULL;
+    if (subproblem) {
+      if (ip) ip->decref();
+      ip = NULL;
+      subproblem->decref();
+    }
+    subproblem = _subproblem;
+  }
   ~ParOptOptimizer() {
     if (x) x->decref();
+    if (trobj) trobj->decref();
     if (ip) ip->decref();
+    if (subproblem) subproblem->decref();
     if (tr) po_tr_destroy(tr);
     if (mma) po_mma_destroy(mma);
     options->decref();
@@ -965,6 +1361,16 @@ class ParOptOptimizer : public ParOptBase {
         ip->incref();
       }
       ip->optimize(options->getStringOption("ip_checkpoint_file"));
+    } else if (algorithm == "tr" && subproblem) {  // :158-183 with the caller's subproblem
+      if (!ip) {
+        ip = new ParOptInteriorPoint(subproblem, options);
+        ip->incref();
+      }
+      if (!trobj) {
+        trobj = new ParOptTrustRegion(subproblem, options);
+        trobj->incref();
+      }
+      trobj->optimize(ip);
     } else if (algorithm == "tr") {
       if (!tr && po_tr_create(prob->handle(), &tr) != 0) {
         fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
@@ -999,7 +1405,10 @@ class ParOptOptimizer : public ParOptBase {
   }
   void getOptimizedPoint(ParOptVec **_x, ParOptScalar **_z, ParOptVec **_zw, ParOptVec **_zl,
                          ParOptVec **_zu) {
-    if (tr || mma) {
+    if (trobj && ip) {  // :209-213
+      trobj->getOptimizedPoint(_x);
+      ip->getOptimizedPoint(NULL, _z, _zw, _zl, _zu);
+    } else if (tr || mma) {
       po_vec hx = NULL;
       const double *z = NULL;
       if (tr) {
@@ -1021,6 +1430,7 @@ class ParOptOptimizer : public ParOptBase {
   }
   const char *getTrustRegionHistory() {
     const char *t = "";
+    if (trobj) return trobj->getHistory();
     if (tr) po_tr_get_history(tr, &t);
     return t;
   }
@@ -1032,6 +1442,8 @@ class ParOptOptimizer : public ParOptBase {
   po_tr tr;
   po_mma mma;
   ParOptVec *x;
+  ParOptTrustRegionSubproblem *subproblem;
+  ParOptTrustRegion *trobj;
 };
 
 // ---- ParOptProblem::checkGradients -------------------------------------------------------------------

@@ -385,6 +385,12 @@ int po_ip_reset_problem_instance(po_ip ip, po_problem prob);
 /* number of Hessian-vector products of the last optimize (getIterationCounters' 4th output) */
 int po_ip_get_hvec_count(po_ip ip, int *nhvec);
 int po_ip_reset_design_and_bounds(po_ip ip);                /* .cpp:1249-1251 */
+/* checkGradients(dh) (.h:166, .cpp:6196-6199): the problem's finite-difference check at the solver's current point;
+ * *report (borrowed, valid until the next call) holds the text the reference prints */
+int po_ip_check_gradients(po_ip ip, double dh, const char **report);
+/* checkMeritFuncGradient(xpt, dh) (.h:199, .cpp:3280-3432): prints the reference's two lines on rank 0;
+ * xpt may be NULL (the current point and step are used); fd / actual may be NULL */
+int po_ip_check_merit_func_gradient(po_ip ip, po_vec xpt, double dh, double *fd, double *actual);
 int po_ip_reset_quasi_newton(po_ip ip);                     /* resetQuasiNewtonHessian .cpp:1241-1245 */
 int po_ip_get_quasi_newton(po_ip ip, po_qn *qn);            /* borrowed */
 /* collective: ONE file in the reference's MPI-IO layout whatever the rank count (rank 0 writes the header and
@@ -486,6 +492,60 @@ int po_tr_get_quasi_newton(po_tr tr, po_qn *qn);             /* subproblem->getQ
 int po_tr_get_model_vectors(po_tr tr, po_vec *xk, po_vec *gk);
 typedef int (*po_tr_iteration_fn)(void *user, int iter);     /* where the reference calls writeOutput */
 int po_tr_set_iteration_callback(po_tr tr, po_tr_iteration_fn fn, void *user);
+
+/* ---- the same layer piece by piece, as the reference's user code assembles it -------------------------------
+ * (examples/eigenvalue/eigenvalue_opt.py:298-308, src/ParOptOptimizer.cpp:108-183, 226-237):
+ *   qn = ParOptLBFGS(problem, m)                         po_qn_create
+ *   approx = ParOptCompactEigenApprox(problem, N)        po_eig_create
+ *   eig_qn = ParOptEigenQuasiNewton(qn, approx, index)   po_eigqn_create      (a po_qn like any other)
+ *   sub = ParOptEigenSubproblem(problem, eig_qn)         po_trsub_create_eigen (or _quadratic(problem, qn))
+ *   sub->setEigenModelUpdate(data, fn)                   po_trsub_set_eigen_model_update
+ *   ip = ParOptInteriorPoint(sub, options)               po_trsub_problem + po_ip_create
+ *   tr = ParOptTrustRegion(sub, options)                 po_tr_create_subproblem
+ *   tr->optimize(ip)                                     po_tr_optimize_with
+ * Every argument is borrowed: the caller keeps the objects alive for as long as the objects built on them live,
+ * and destroys them in reverse order (the reference's incref/decref chain, src/ParOptTrustRegion.cpp:660-737). */
+/* ParOptCompactEigenApprox (src/ParOptCompactEigenvalueApprox.h:7-32, .cpp:23-120) */
+int po_eig_create(po_problem prob, int N, po_eig *out);
+int po_eig_destroy(po_eig approx);
+int po_eig_mult_add(po_eig approx, double alpha, po_vec x, po_vec y);            /* y += alpha H M H^T x  .cpp:52-64 */
+int po_eig_eval_approximation(po_eig approx, po_vec s, po_vec t, double *value); /* .cpp:92-106 (s or t NULL: c0) */
+int po_eig_eval_approximation_gradient(po_eig approx, po_vec s, po_vec grad);    /* .cpp:108-120 */
+/* ParOptEigenQuasiNewton(qn, eigh, index) (.h:34-84, .cpp:122-291): B = B_qn - z0 H M H^T as ONE compact matrix over
+ * [Z_qn | H]; `qn` may be NULL.  The result is a po_qn: po_qn_mult / mult_add / get_compact / max_size / reset /
+ * destroy apply; po_qn_update is the no-op of .cpp:176-179. */
+int po_eigqn_create(po_qn qn, po_eig approx, int index, po_qn *out);
+int po_eigqn_set_use_quasi_newton_objective(po_qn eig_qn, int truth);            /* .cpp:164-166 */
+int po_eigqn_update_multipliers(po_qn eig_qn, const double *z);                  /* update(x, z, zw) .cpp:181-187 */
+int po_eigqn_get_multiplier_index(po_qn eig_qn, int *index);
+/* ParOptTrustRegionSubproblem (src/ParOptTrustRegion.h:15-151) in its two library forms */
+typedef struct po_trsub_s *po_trsub;
+int po_trsub_create_quadratic(po_problem prob, po_qn qn, po_trsub *out);         /* .h:153-300; qn may be NULL */
+int po_trsub_create_eigen(po_problem prob, po_qn eig_qn, po_trsub *out);         /* ...EigenvalueApprox.h:86-206 */
+int po_trsub_destroy(po_trsub sub);
+int po_trsub_set_eigen_model_update(po_trsub sub, po_eig_update_fn update, void *user); /* setEigenModelUpdate */
+/* the subproblem as the ParOptProblem the interior-point solver is built on (borrowed; lives as long as `sub`) */
+int po_trsub_problem(po_trsub sub, po_problem *out);
+int po_trsub_get_quasi_newton(po_trsub sub, po_qn *qn);                          /* getQuasiNewton (borrowed) */
+int po_trsub_init_model_and_bounds(po_trsub sub, double tr_size);
+int po_trsub_set_trust_region_bounds(po_trsub sub, double tr_size);
+int po_trsub_eval_trial_step_and_update(po_trsub sub, int update_flag, po_vec step, const double *z, po_vec zw,
+                                        double *fobj, double *cons);
+int po_trsub_accept_trial_step(po_trsub sub, po_vec step, const double *z, po_vec zw);
+int po_trsub_reject_trial_step(po_trsub sub);
+int po_trsub_get_quasi_newton_update_type(po_trsub sub, int *type);
+/* getLinearModel (.h:91-95): returns the number of dense constraints in *m; borrowed pointers */
+int po_trsub_get_linear_model(po_trsub sub, po_vec *xk, double *fk, po_vec *gk, const double **ck,
+                              const po_vec **Ak, po_vec *lb, po_vec *ub, int *m);
+/* ParOptTrustRegion(subproblem, options) and optimize(ip) (src/ParOptTrustRegion.cpp:660-718, 2365-2384).  `ip` must
+ * have been created on po_trsub_problem(sub).  Options set on `tr` that the interior-point registry lacks (tr_*,
+ * filter_*) are carried into the solver's registry at the call: one registry serves both, as the reference's shared
+ * ParOptOptions object does. */
+int po_tr_create_subproblem(po_trsub sub, po_tr *out);
+int po_tr_optimize_with(po_tr tr, po_ip ip);
+int po_tr_initialize(po_tr tr);                                                  /* initialize .cpp:1086-1099 */
+int po_tr_set_penalty_gamma(po_tr tr, double gamma);                             /* .cpp:1049-1055 */
+int po_tr_set_penalty_gamma_array(po_tr tr, const double *gamma);                /* .cpp:1062-1068 */
 
 /* ---- ParOptMMA: method of moving asymptotes (src/ParOptMMA.h:22-192), assembled as ParOptOptimizer
  * does for algorithm = "mma" (src/ParOptOptimizer.cpp:184-204): the MMA object is the separable

@@ -293,6 +293,40 @@ class InteriorPoint(_api.InteriorPoint):
                 PVec(zu) if zu is not None else None)
 
 
+class TrustRegionSubproblem:
+    """paropt.ParOpt.TrustRegionSubproblem (ParOpt.pyx:1395-1413): base of the subproblem wrappers; ``subproblem`` is
+    the library object."""
+
+    subproblem = None
+
+    def checkGradients(self, dh=1e-6, x=None, check_hvec_product=False):
+        return self.problem.checkGradients(dh, x, check_hvec_product)
+
+
+class QuadraticSubproblem(TrustRegionSubproblem):
+    """paropt.ParOpt.QuadraticSubproblem(problem, qn=None) (ParOpt.pyx:1415-1422)."""
+
+    def __init__(self, problem, qn=None):
+        self.problem = problem
+        self.subproblem = _api.QuadraticSubproblem(problem, qn)
+
+
+class TrustRegion:
+    """paropt.ParOpt.TrustRegion(subproblem, options) with optimize(InteriorPoint) (ParOpt.pyx:1424-1459)."""
+
+    def __init__(self, prob, options=None):
+        algorithm, opts = _split_options(options)
+        opts = {k: v for k, v in opts.items() if k != "ip_checkpoint_file" and not k.startswith(_MMA_ONLY)}
+        self.prob = prob
+        self.tr = _api.TrustRegion(prob.subproblem, opts)
+
+    def optimize(self, optimizer):
+        self.tr.optimize(optimizer)
+
+    def getOptimizedPoint(self):
+        return PVec(self.prob.subproblem.getLinearModel()[0])
+
+
 class Optimizer:
     """paropt.ParOpt.Optimizer (ParOpt.pyx:1461-1521, src/ParOptOptimizer.cpp:65-206)."""
 
@@ -300,10 +334,24 @@ class Optimizer:
         self.problem = problem
         self.algorithm, self.options = _split_options(options)
         self.ip = self.tr = self.mma = None
+        self.subproblem = None
         if self.algorithm not in ("ip", "tr", "mma"):
             raise ValueError("ParOptOptimizer Error: Unrecognized algorithm option %s" % self.algorithm)
 
+    def setTrustRegionSubproblem(self, prob):
+        """ParOptOptimizer::setTrustRegionSubproblem (src/ParOptOptimizer.cpp:226-237): algorithm 'tr' then drives the
+        caller's subproblem (e.g. ParOptEig.EigenSubproblem) instead of a QuadraticSubproblem built from the options."""
+        self.subproblem = prob
+        self.ip = self.tr = None
+
     def optimize(self):
+        if self.algorithm == "tr" and self.subproblem is not None:  # :158-183 with the caller's subproblem
+            if self.ip is None:
+                self.ip = InteriorPoint(self.subproblem.subproblem, self.options)
+            if self.tr is None:
+                self.tr = TrustRegion(self.subproblem, dict(self.options, algorithm="tr"))
+            self.tr.optimize(self.ip)
+            return
         if self.algorithm == "ip":
             if self.ip is None:
                 self.ip = InteriorPoint(self.problem, self.options)
@@ -325,6 +373,9 @@ class Optimizer:
             self.mma.optimize()
 
     def getOptimizedPoint(self):
+        if self.subproblem is not None and self.tr is not None:  # :209-213
+            _, z, zw, zl, zu = self.ip.getOptimizedPoint()
+            return self.tr.getOptimizedPoint(), z, zw, zl, zu
         if self.mma is not None:
             x, z, zw, zl, zu = self.mma.getOptimizedPoint()
             return PVec(x), z, (PVec(zw) if zw is not None else None), PVec(zl), PVec(zu)
@@ -334,8 +385,32 @@ class Optimizer:
         return self.ip.getOptimizedPoint()
 
 
-LBFGS = _api.LBFGS
-LSR1 = _api.LSR1
+SKIP_NEGATIVE_CURVATURE, DAMPED_UPDATE = 0, 1
+
+
+class LBFGS(_api.LBFGS):
+    """paropt.ParOpt.LBFGS(prob, subspace=10, update_type=SKIP_NEGATIVE_CURVATURE) (ParOpt.pyx:1210-1219); the
+    library's own (ctx, n, subspace) form is accepted too."""
+
+    def __init__(self, prob, *args, subspace=10, update_type=SKIP_NEGATIVE_CURVATURE, **kw):
+        if isinstance(prob, _api.Context):
+            super().__init__(prob, *args, **kw)
+        else:
+            if args:
+                subspace = args[0]
+            super().__init__(prob.ctx, prob.nvars, subspace, update_type)
+
+
+class LSR1(_api.LSR1):
+    """paropt.ParOpt.LSR1(prob, subspace=10) (ParOpt.pyx:1221-1227)."""
+
+    def __init__(self, prob, *args, subspace=10, **kw):
+        if isinstance(prob, _api.Context):
+            super().__init__(prob, *args, **kw)
+        else:
+            if args:
+                subspace = args[0]
+            super().__init__(prob.ctx, prob.nvars, subspace)
 
 
 def unpack_checkpoint(filename, full=False):

@@ -12,6 +12,11 @@ from .api import (  # noqa: F401
     PVec,
     SeparableProblem,
     TrustRegion,
+    TrustRegionSubproblem,
+    QuadraticSubproblem,
+    EigenSubproblem,
+    EigenQuasiNewton,
+    CompactEigenApprox,
     EigenApprox,
     CsrSymbolic,
     UserLibraryProblem,

@@ -857,6 +857,32 @@ class InteriorPoint:
     def resetDesignAndBounds(self):
         check(lib.po_ip_reset_design_and_bounds(self._h))
 
+    def checkGradients(self, dh=1e-6):
+        """ParOptInteriorPoint::checkGradients(dh) (reference .cpp:6196-6199): the problem's finite-difference check
+        at the solver's current point; returns (and prints) the report."""
+        t = C.c_char_p()
+        check(lib.po_ip_check_gradients(self._h, float(dh), C.byref(t)))
+        text = (t.value or b"").decode()
+        print(text, end="")
+        return text
+
+    def checkMeritFuncGradient(self, xpt=None, dh=1e-6):
+        """ParOptInteriorPoint::checkMeritFuncGradient(xpt, dh) (.cpp:3280-3432): returns (finite difference, actual)."""
+        fd, act = C.c_double(), C.c_double()
+        check(lib.po_ip_check_merit_func_gradient(self._h, xpt.handle if xpt is not None else None, float(dh),
+                                                  C.byref(fd), C.byref(act)))
+        return fd.value, act.value
+
+    def setBFGSUpdateType(self, update_type):
+        """setBFGSUpdateType (.cpp:1179-1186): applies to the solver's own L-BFGS object."""
+        h = L.po_qn()
+        check(lib.po_ip_get_quasi_newton(self._h, C.byref(h)))
+        if h:
+            check(lib.po_qn_set_update_type(h, 1 if update_type in (1, "damped_update", "damped") else 0))
+
+    def setUseDiagHessian(self, truth):
+        self.setOption("use_diag_hessian", bool(truth))
+
     def getHvecCount(self):
         v = C.c_int()
         check(lib.po_ip_get_hvec_count(self._h, C.byref(v)))
@@ -976,9 +1002,169 @@ class EigenApprox:
         self._c0[0] = float(v)
 
 
+class CompactEigenApprox(EigenApprox):
+    """ParOptCompactEigenApprox(problem, N) (reference src/ParOptCompactEigenvalueApprox.h:7-32): the object the user's
+    code creates and hands to EigenQuasiNewton; c0 / g0 / M / Minv / hvecs as in EigenApprox."""
+
+    def __init__(self, problem, N):
+        self.ctx = problem.ctx
+        self.problem = problem
+        self._eh = L.po_eig()
+        check(lib.po_eig_create(problem.handle, int(N), C.byref(self._eh)))
+        super().__init__(problem.ctx, self._eh)
+
+    def __del__(self):
+        try:
+            if self._eh and self.ctx._h:
+                lib.po_eig_destroy(self._eh)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._eh
+
+    def multAdd(self, alpha, x, y):
+        check(lib.po_eig_mult_add(self._eh, float(alpha), x.handle, y.handle))
+
+    def evalApproximation(self, s=None, t=None):
+        v = C.c_double()
+        check(lib.po_eig_eval_approximation(self._eh, s.handle if s is not None else None,
+                                            t.handle if t is not None else None, C.byref(v)))
+        return v.value
+
+    def evalApproximationGradient(self, s, grad):
+        check(lib.po_eig_eval_approximation_gradient(self._eh, s.handle, grad.handle))
+
+
+class EigenQuasiNewton(_QuasiNewton):
+    """ParOptEigenQuasiNewton(qn, eigh, index) (.h:34-84): B = B_qn - z0 H M H^T as one compact matrix; qn may be
+    None.  A quasi-Newton object like any other (mult / multAdd / getCompactMat)."""
+
+    def __init__(self, qn, eigh, index=0):
+        self.qn, self.eigh = qn, eigh  # kept alive: the library object borrows both
+        h = L.po_qn()
+        check(lib.po_eigqn_create(qn._h if qn is not None else None, eigh.handle, int(index), C.byref(h)))
+        super().__init__(eigh.ctx, 0, 0, 0, handle=h)
+        self._owned = True
+        self.index = int(index)
+
+    def setUseQuasiNewtonObjective(self, truth):
+        check(lib.po_eigqn_set_use_quasi_newton_objective(self._h, int(bool(truth))))
+
+    def updateMultipliers(self, z):
+        za = (C.c_double * len(z))(*[float(v) for v in z])
+        check(lib.po_eigqn_update_multipliers(self._h, za))
+
+
+class TrustRegionSubproblem:
+    """ParOptTrustRegionSubproblem (reference src/ParOptTrustRegion.h:15-151) in its library forms.  Also the
+    ParOptProblem the interior-point solver is built on: ``InteriorPoint(subproblem, options)``."""
+
+    def __init__(self, problem):
+        self.problem = problem
+        self.ctx = problem.ctx
+        self.nvars, self.ncon = problem.nvars, problem.ncon
+        self.nwcon = getattr(problem, "nwcon", 0)
+        self._h = L.po_trsub()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib.po_trsub_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        """the subproblem as a po_problem (borrowed)"""
+        p = L.po_problem()
+        check(lib.po_trsub_problem(self._h, C.byref(p)))
+        return p
+
+    def _raise_pending(self):
+        if hasattr(self.problem, "_raise_pending"):
+            self.problem._raise_pending()
+
+    def initModelAndBounds(self, tr_size):
+        check(lib.po_trsub_init_model_and_bounds(self._h, float(tr_size)))
+
+    def setTrustRegionBounds(self, tr_size):
+        check(lib.po_trsub_set_trust_region_bounds(self._h, float(tr_size)))
+
+    def evalTrialStepAndUpdate(self, update_flag, step, z, zw=None):
+        za = (C.c_double * max(1, self.ncon))(*[float(v) for v in z])
+        f, cons = C.c_double(), (C.c_double * max(1, self.ncon))()
+        check(lib.po_trsub_eval_trial_step_and_update(self._h, int(update_flag), step.handle, za,
+                                                      zw.handle if zw is not None else None, C.byref(f), cons))
+        return f.value, np.array(cons[:self.ncon])
+
+    def acceptTrialStep(self, step, z, zw=None):
+        za = (C.c_double * max(1, self.ncon))(*[float(v) for v in z]) if z is not None else None
+        check(lib.po_trsub_accept_trial_step(self._h, step.handle, za, zw.handle if zw is not None else None))
+
+    def rejectTrialStep(self):
+        check(lib.po_trsub_reject_trial_step(self._h))
+
+    def getQuasiNewtonUpdateType(self):
+        t = C.c_int()
+        check(lib.po_trsub_get_quasi_newton_update_type(self._h, C.byref(t)))
+        return t.value
+
+    def getLinearModel(self):
+        """(xk, fk, gk, ck, Ak, lb, ub) of the current model (borrowed vectors)."""
+        xk, gk, lb, ub, Ak = L.po_vec(), L.po_vec(), L.po_vec(), L.po_vec(), L.vec_p()
+        fk, ck, m = C.c_double(), L.c_double_p(), C.c_int()
+        check(lib.po_trsub_get_linear_model(self._h, C.byref(xk), C.byref(fk), C.byref(gk), C.byref(ck), C.byref(Ak),
+                                            C.byref(lb), C.byref(ub), C.byref(m)))
+        wrap = lambda h: PVec(self.ctx, handle=L.po_vec(h), owned=False)  # noqa: E731
+        return (wrap(xk), fk.value, wrap(gk), np.array([ck[i] for i in range(m.value)]),
+                [wrap(Ak[i]) for i in range(m.value)], wrap(lb), wrap(ub))
+
+
+class QuadraticSubproblem(TrustRegionSubproblem):
+    """ParOptQuadraticSubproblem(problem, qn) (.h:153-300); qn may be None."""
+
+    def __init__(self, problem, qn=None):
+        super().__init__(problem)
+        self.qn = qn
+        check(lib.po_trsub_create_quadratic(problem.handle, qn._h if qn is not None else None, C.byref(self._h)))
+
+    def getQuasiNewton(self):
+        return self.qn
+
+
+class EigenSubproblem(TrustRegionSubproblem):
+    """ParOptEigenSubproblem(problem, eig_qn) (src/ParOptCompactEigenvalueApprox.h:86-206)."""
+
+    def __init__(self, problem, eig_qn):
+        super().__init__(problem)
+        self.eig_qn = eig_qn
+        check(lib.po_trsub_create_eigen(problem.handle, eig_qn._h, C.byref(self._h)))
+
+    def getQuasiNewton(self):
+        return self.eig_qn
+
+    def setEigenModelUpdate(self, update):
+        """update(x: PVec, approx: CompactEigenApprox) is called at the starting point and at every accepted point with
+        c0 / g0 preset; it fills hvecs, M and Minv (setEigenModelUpdate, .h:166-170)."""
+        approx = self.eig_qn.eigh
+
+        def _cb(user, x, eig):
+            update(PVec(self.ctx, handle=L.po_vec(x), owned=False), approx)
+            return 0
+
+        fn = L.EIG_UPDATE_FN(_cb)
+        self._keep.append(fn)
+        check(lib.po_trsub_set_eigen_model_update(self._h, fn, None))
+
+
 class TrustRegion:
-    """ParOptTrustRegion over ParOptQuadraticSubproblem (or ParOptEigenSubproblem), assembled the
-    way ParOptOptimizer does for algorithm='tr' (reference src/ParOptOptimizer.cpp:108-183).
+    """ParOptTrustRegion.  ``TrustRegion(problem, options)`` assembles quasi-Newton object, quadratic (or eigenvalue)
+    subproblem and interior-point solver the way ParOptOptimizer does for algorithm='tr' (reference
+    src/ParOptOptimizer.cpp:108-183); ``TrustRegion(subproblem, options)`` with a TrustRegionSubproblem is the
+    reference's own constructor (src/ParOptTrustRegion.cpp:660-718) and takes the solver at ``optimize(ip)``.
     `options` may mix interior-point and trust-region option names (one shared registry)."""
 
     COLS = ("fobj", "infeas", "l1", "linfty", "smax", "tr", "rho", "model_reduc", "zav", "zmax", "gav", "gmax")
@@ -987,7 +1173,11 @@ class TrustRegion:
         self.problem = problem
         self.ctx = problem.ctx
         self._h = L.po_tr()
-        check(lib.po_tr_create(problem.handle, C.byref(self._h)))
+        self.subproblem = problem if isinstance(problem, TrustRegionSubproblem) else None
+        if self.subproblem is not None:
+            check(lib.po_tr_create_subproblem(problem._h, C.byref(self._h)))
+        else:
+            check(lib.po_tr_create(problem.handle, C.byref(self._h)))
         self._cbs = []
         opts = dict(options or {})
         opts.setdefault("tr_output_file", "")
@@ -1036,13 +1226,29 @@ class TrustRegion:
         self._cbs.append(cb)
         check(lib.po_tr_set_iteration_callback(self._h, cb, None))
 
-    def optimize(self):
-        rc = lib.po_tr_optimize(self._h)
+    def optimize(self, ip=None):
+        """optimize() for the self-assembled form; optimize(ip) with an InteriorPoint built on the subproblem for the
+        reference's form (ParOptTrustRegion::optimize(ParOptInteriorPoint*), .cpp:2365-2384)."""
+        if ip is not None:
+            self._ip = ip
+            rc = lib.po_tr_optimize_with(self._h, ip._h)
+        else:
+            rc = lib.po_tr_optimize(self._h)
         if hasattr(self.problem, "_raise_pending"):
             self.problem._raise_pending()
         if rc != 0:
             raise L.ParOptAMDError(rc, lib.po_last_error().decode(errors="replace"))
         return rc
+
+    def initialize(self):
+        check(lib.po_tr_initialize(self._h))
+
+    def setPenaltyGamma(self, gamma):
+        if np.isscalar(gamma):
+            check(lib.po_tr_set_penalty_gamma(self._h, float(gamma)))
+        else:
+            ga = (C.c_double * len(gamma))(*[float(v) for v in gamma])
+            check(lib.po_tr_set_penalty_gamma_array(self._h, ga))
 
     def getOptimizedPoint(self):
         x, z, zw = L.po_vec(), L.c_double_p(), L.po_vec()

@@ -841,6 +841,23 @@ int po_ip_destroy(po_ip ip) {
   delete ip;
   return PO_OK;
 }
+int po_ip_check_gradients(po_ip ip, double dh, const char **report) {
+  PO_CHECK_PTR(ip);
+  static thread_local std::string text;
+  text.clear();
+  PO_TRY(ip->ip->checkGradients(dh, &text));
+  if (report) *report = text.c_str();
+  return PO_OK;
+}
+int po_ip_check_merit_func_gradient(po_ip ip, po_vec xpt, double dh, double *fd, double *actual) {
+  PO_CHECK_PTR(ip);
+  if (xpt) PO_TRY(mirror_up(xpt));
+  double out[2] = {0.0, 0.0};
+  PO_TRY(ip->ip->checkMeritFuncGradient(xpt, dh, out));
+  if (fd) *fd = out[0];
+  if (actual) *actual = out[1];
+  return PO_OK;
+}
 int po_ip_set_option_str(po_ip ip, const char *name, const char *value) {
   PO_CHECK_PTR(ip);
   PO_CHECK_PTR(name);

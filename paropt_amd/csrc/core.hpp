@@ -293,7 +293,7 @@ int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double b
          double *t, const double *cl = nullptr, const double *cu = nullptr);
 // k_dinv followed by k_d1 (no corrector terms) in one pass over the bound data
 int k_dinv_d1(Ctx *c, const Bounds &b, double diag, const double *hdiag, const double *rx, double beta_mu,
-              int64_t n, double *dinv, double *t);
+              int64_t n, double *dinv, double *t, int raw = 0);  // raw: t = d1 (not weighted by Dinv)
 // Mehrotra corrector products of the affine step (addMehrotraCorrectorResidual :1765-1788)
 int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 int64_t n, double *cl, double *cu);

@@ -61,6 +61,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   fused_tdots = !getenv("PAROPT_AMD_NO_FUSED_TDOTS");
   recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
   fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
+  fast_yqn_w = !getenv("PAROPT_AMD_NO_FAST_YQN_W");
   recompute_rhs = recompute_first_step && !getenv("PAROPT_AMD_NO_RECOMPUTE_RHS");
   // Off by default: leaving the L-SR1 columns unformed saves the Gram pass 0.6 ms (its ten output streams) but costs
   // the two solve passes ten more input streams each, +1.2 ms at n = 50 M; kept as a switch.
@@ -103,7 +104,7 @@ InteriorPoint::~InteriorPoint() {
   Vec *all[] = {x, zl, zu, lb, ub, g, px, pzl, pzu, Dinv, rx, tvec, xt, y_qn, s_qn, vA, acz};
   for (Vec *v : all) vec_decref(v);
   for (Vec *v : Ac) vec_decref(v);
-  Vec *wall[] = {gsw, gtw, Cw, wd2, wyw, wtmp, wtmp2, d1v};
+  Vec *wall[] = {gsw, gtw, Cw, wd2, wyw, wtmp, wtmp2, d1v, cwx};
   for (Vec *v : wall) vec_decref(v);
   for (int i = 0; i < 5; i++) {
     vec_decref(wvar[i]);
@@ -145,6 +146,7 @@ int InteriorPoint::resetProblemInstance(Problem *p) {  // :745-764
   prob = p;
   ac_valid = false;
   acz_valid = false;
+  cwx_valid = false;
   return PO_OK;
 }
 
@@ -286,9 +288,24 @@ int InteriorPoint::clampCounts(double out[8]) {
   return PO_OK;
 }
 
+// A host mirror the caller still holds for one of the solver's vectors (getOptimizedPoint + getArray) is the vector's
+// data while it is live: after an internal writer has changed the device copy the mirror is refreshed, so that the
+// caller's pointer shows the new values (the reference has one buffer) and optimize()'s upload of live mirrors cannot
+// put the old ones back.
+static int refreshLiveMirror(Vec *v) {
+  if (!v || !v->h_live || !v->h || v->n <= 0) return PO_OK;
+  PO_HIP(hipMemcpyAsync(v->h, v->d, sizeof(double) * (size_t)v->n, hipMemcpyDeviceToHost, v->ctx->stream));
+  PO_HIP(hipStreamSynchronize(v->ctx->stream));
+  return PO_OK;
+}
+
 int InteriorPoint::resetDesignAndBounds() {  // :1249-1251
+  cwx_valid = false;
   int rc = prob->getVarsAndBounds(x, lb, ub);
-  return rc == 0 ? PO_OK : PO_ERR_USER;
+  if (rc != 0) return PO_ERR_USER;
+  PO_TRY(refreshLiveMirror(x));
+  PO_TRY(refreshLiveMirror(lb));
+  return refreshLiveMirror(ub);
 }
 
 void InteriorPoint::resetQuasiNewtonHessian() {
@@ -410,7 +427,7 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       A.push_back(tvec->d);
       zc.push_back(1.0);
     }
-    if (upd && yqn_complete && !has_w) {
+    if (upd && yqn_complete) {
       // the bound multipliers take their step in the same pass (see kkt_res_update_kernel); A^T z follows the dense
       // multiplier step by recurrence unless it has just been rebuilt from the new multipliers
       const double az_acz = (acz_mode && upd->acz_follow && !acz_rebuilt) ? upd->az : 0.0;
@@ -543,11 +560,17 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   // that the Schur complements need anyway.
   const bool fuse_t = rhs_mu && fused_tdots && !has_w && c + (qn && use_qn && !diag_only ? qn->size() : 0) > 0;
   t_is_plain_dinv_d1 = false;
+  // sparse constraints: the RAW right-hand side d1 of the first solve (the block solve applies to it) comes out of
+  // the same pass over the bound data as Dinv (round 4; it is used below when the fused first solve is taken)
+  const bool raw_d1_w = has_w && rhs_mu && fused_tdots && !corrector_active;
   if (fuse_t) {
     PO_TRY(k_dinv_d1(ctx, bounds(), b0 + sigma, use_hdiag ? hdiag->d : nullptr, rx->d,
                      options.real("rel_bound_barrier") * (*rhs_mu), n, Dinv->d, tvec->d));
     t_is_plain_dinv_d1 = !use_hdiag;
     t0_diag = b0 + sigma;
+  } else if (raw_d1_w) {
+    PO_TRY(k_dinv_d1(ctx, bounds(), b0 + sigma, use_hdiag ? hdiag->d : nullptr, rx->d,
+                     options.real("rel_bound_barrier") * (*rhs_mu), n, Dinv->d, d1v->d, 1));
   } else {
     PO_TRY(k_dinv(ctx, bounds(), b0 + sigma, n, Dinv->d, use_hdiag ? hdiag->d : nullptr));
   }
@@ -607,7 +630,8 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
     fuse_tw = rhs_mu && fused_tdots && m > 0 && m + 1 <= kWgramMaxVecs && !corrector_active;
     if (fuse_tw) {
       PO_TRY(computeResidualW(*rhs_mu));
-      PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, options.real("rel_bound_barrier") * (*rhs_mu), n, d1v->d));
+      if (!raw_d1_w)
+        PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, options.real("rel_bound_barrier") * (*rhs_mu), n, d1v->d));
       PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
       PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
     }
@@ -1027,6 +1051,92 @@ int InteriorPoint::checkKKTStep(int iteration, double mu) {
   return PO_OK;
 }
 
+int InteriorPoint::checkGradients(double dh, std::string *report) {  // :6196-6199
+  return prob->checkGradients(dh, x, options.integer("use_hvec_product"), xt, tvec, report);
+}
+
+int InteriorPoint::checkMeritFuncGradient(Vec *xpt, double dh, double out[2]) {  // :3280-3432
+  if (xpt) PO_TRY(k_copy(ctx, x->d, xpt->d, n));
+  cwx_valid = false;
+  if (prob->evalObjCon(x, &fobj, cvals.data()) != 0) {
+    fprintf(stderr, "ParOpt: Function and constraint evaluation failed\n");
+    return PO_ERR_USER;
+  }
+  neval++;
+  if (prob->evalObjConGradient(x, g, Ac.data()) != 0) {
+    fprintf(stderr, "ParOpt: Gradient evaluation failed\n");
+    return PO_ERR_USER;
+  }
+  ngeval++;
+  ac_valid = true;
+  acz_valid = false;
+  if (!pz_stored) {  // a lean step keeps px only; nothing below reads pzl / pzu
+    pz_stored = true;
+  }
+  if (xpt) {  // a direction of our own: px = -g / |g|, fixed slack steps, zero elsewhere (:3327-3352)
+    double g2 = 0.0;
+    PO_TRY(k_reduce1(ctx, RED_SUMSQ, g->d, nullptr, n, &g2));
+    PO_TRY(k_panel_axpy(ctx, px->d, g2 > 0.0 ? -1.0 / sqrt(g2) : 0.0, g->d, 0.0, nullptr, nullptr, 0, n));
+    for (int i = 0; i < c; i++) {
+      step.s[i] = -0.259 * (1 + (i % 3));
+      step.t[i] = -0.349 * (4 - (i % 2));
+    }
+    if (has_w && nw > 0) {
+      std::vector<double> hs((size_t)nw), ht((size_t)nw);
+      for (int64_t i = 0; i < nw; i++) {
+        hs[i] = -0.419 * (1 + (i % 5));
+        ht[i] = -0.7513 * (1 + (i % 19));
+      }
+      PO_HIP(hipMemcpyAsync(wstepv[1]->d, hs.data(), sizeof(double) * (size_t)nw, hipMemcpyHostToDevice, ctx->stream));
+      PO_HIP(hipMemcpyAsync(wstepv[2]->d, ht.data(), sizeof(double) * (size_t)nw, hipMemcpyHostToDevice, ctx->stream));
+      PO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  sx = sz = 1.0;
+  ptpx_valid = false;
+  merit_cache_valid = false;
+  fused_merit_valid = false;
+  px_amax_valid = false;
+  double m0 = 0.0, dm0 = 0.0;
+  PO_TRY(evalMeritInitDeriv(1.0, &m0, &dm0));
+  // the merit function at (x + dh px, s + dh ps, t + dh pt, sw + dh psw, tw + dh ptw) (:3386-3409)
+  const double eps = 0.0;  // no clamping: the reference evaluates the perturbed point as it is
+  double sums[2], wsums[5];
+  std::vector<double> rs(c), rt(c), cs(cvals);
+  for (int i = 0; i < c; i++) {
+    rs[i] = vars.s[i] + dh * step.s[i];
+    rt[i] = vars.t[i] + dh * step.t[i];
+  }
+  {
+    // k_trial clamps into [lb + eps, ub - eps]; with eps = 0 an interior point is left alone
+    PO_TRY(k_trial(ctx, bounds(), px->d, dh, eps, n, xt->d, sums));
+    trial_logs_valid = false;
+    s_qn_from_trial = false;
+  }
+  double ftemp = 0.0;
+  if (prob->evalObjCon(xt, &ftemp, cs.data()) != 0) {
+    fprintf(stderr, "ParOpt: Function and constraint evaluation failed\n");
+    return PO_ERR_USER;
+  }
+  neval++;
+  if (has_w) {
+    if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
+    PO_TRY(k_w_trial(ctx, wv(), wp(), dh, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
+  }
+  const double m1 = evalMeritFromSums(ftemp, cs.data(), rs.data(), rt.data(), sums[0], sums[1], has_w ? wsums : nullptr);
+  const double fd = (m1 - m0) / dh;
+  if (ctx->rank == 0) {
+    fprintf(stdout, "Merit function test\n");
+    fprintf(stdout, "dm FD: %15.8e  Actual: %15.8e  Err: %8.2e  Rel err: %8.2e\n", fd, dm0, fabs(fd - dm0),
+            fabs((fd - dm0) / fd));
+  }
+  if (out) {
+    out[0] = fd;
+    out[1] = dm0;
+  }
+  return PO_OK;
+}
+
 int InteriorPoint::debugKKTStep(double mu) {
   PO_TRY(createQuasiNewton());
   PO_TRY(computeResidual(mu, true));
@@ -1108,9 +1218,13 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
     merit_cache_valid = true;
   } else {
     BatchScope batch(ctx);  // design and sparse parts of the complementarity: one collective + sync
-    PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, n, out));
+    // (the design pass also yields the merit pieces and max|px| the line search is about to ask for, as on the
+    // dense path: the separate merit pass and its max|px| reduction disappear)
+    PO_TRY(k_comp_merit(ctx, bounds(), px->d, pzl->d, pzu->d, ax, az, g->d, n, out));
     PO_TRY(wCompStep(ax, az, &wprod));  // :2866-2889
     PO_TRY(batch.end());
+    for (int i = 0; i < 7; i++) merit_cache[i] = out[2 + i];
+    merit_cache_valid = true;
   }
   double prod = out[0] / options.real("rel_bound_barrier"), count = out[1];
   if (has_w) {
@@ -1218,10 +1332,11 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
     if (has_w) {  // :3735-3765, 3489-3503
-      if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
+      const double *cw = nullptr;
+      PO_TRY(sparseConAtIterate(&cw));
       PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
       if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
-      PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, wtmp->d, wtmp2->d, nw, wm));
+      PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, cw, wtmp2->d, nw, wm));
     }
     PO_TRY(batch.end());
   }
@@ -1332,7 +1447,7 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
   const bool batchable = prob->reductionsBatchable();
   // the quasi-Newton step s = alpha sx px of the trial point is written by the trial pass itself (the accepted
   // trial is the last one): no separate pass in computeStepAndUpdate
-  double *sq = (qn && options.integer("use_quasi_newton_update") && !has_w) ? s_qn->d : nullptr;
+  double *sq = (qn && options.integer("use_quasi_newton_update")) ? s_qn->d : nullptr;
   double merit = 0.0, best_merit = 0.0, best_alpha = -1.0;
   std::vector<double> rs(c), rt(c);
   int j = 0;
@@ -1349,8 +1464,10 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     userBegin();
     int fail_obj = prob->evalObjCon(xt, &fobj, cvals.data());
     userEnd();
+    trial_cw_valid = false;
     if (has_w && batchable && !fail_obj) {  // the sparse slack sums ride in the same collective
       if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
+      trial_cw_valid = true;  // wtmp = cw(xt): handed to the iterate when this trial is accepted
       PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
     }
     PO_TRY(batch.end());
@@ -1365,6 +1482,7 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     }
     if (has_w && !batchable) {
       if (prob->evalSparseCon(xt, wtmp) != 0) return PO_ERR_USER;
+      trial_cw_valid = true;
       PO_TRY(k_w_trial(ctx, wv(), wp(), alpha * sx, eps, gsw->d, gtw->d, wtmp->d, nw, wsums));
     }
     merit = evalMeritFromSums(fobj, cvals.data(), rs.data(), rt.data(), sums[0], sums[1],
@@ -1410,6 +1528,7 @@ int InteriorPoint::lineSearch(double alpha_min, double *alpha_, double m0, doubl
     }
     if (alpha != best_alpha) {
       alpha = best_alpha;
+      trial_cw_valid = false;  // xt is rebuilt below without its sparse constraint values
       double sums[2];
       BatchScope batch(ctx, batchable);
       PO_TRY(k_trial(ctx, bounds(), px->d, alpha * sx, eps, n, xt->d, sums, sq));
@@ -1447,7 +1566,21 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // iteration's KKT residual rx = [lo]zl - [up]zu - g + A^T z and va = A^T pz (kept by the solves),
   // the second from the NEXT iteration's residual, which is evaluated right after the gradient and
   // reused at the top of the loop.
-  const bool fast_yqn = do_qn && analytic_panel_dots && !has_w && vA_valid;
+  // Sparse constraints (round 4): the same identity holds with A^T pz + Aw(x)^T pzw in place of A^T pz -- the first
+  // bracket adds Aw(x_old)^T (zw+ - zw) = alpha sz Aw(x_old)^T pzw (:4207-4210 evaluate it at the OLD point), the second
+  // is completed by the residual of the new point, whose panel carries Aw(x+)^T zw+ as one more column.  The sum is
+  // formed here, from the final step, in one pass over the c constraint gradients: two panel passes, two sparse
+  // transposes and the separate multiplier update disappear.  (Not with the linear-constraint recurrence, whose
+  // `acz` follows the dense part of this vector alone.)
+  const bool fast_w = has_w && do_qn && analytic_panel_dots && fast_yqn_w && !prob->linear_constraints && pz_stored;
+  const bool fast_yqn = do_qn && analytic_panel_dots && ((!has_w && vA_valid) || fast_w);
+  if (fast_w) {
+    // vA <- sz Aw^T pzw + sum_j step.z[j] A_j   (step.z already carries sz: scaleKKTStep)
+    if (prob->setSparseJacobianTranspose(sz, x, wstepv[0], vA) != 0) return PO_ERR_USER;
+    std::vector<const double *> Aold;
+    for (Vec *a : Ac) Aold.push_back(a->d);
+    if (c > 0) PO_TRY(k_panel_axpy(ctx, vA->d, 0.0, nullptr, 1.0, step.z.data(), Aold.data(), c, n));
+  }
   if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
   // acz = A^T z follows z += alpha*sz*pz through va = A^T pz when the solves kept va; otherwise it is rebuilt
   const bool acz_follow = acz && acz_valid && vA_valid;
@@ -1460,13 +1593,14 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   }
   MultUpdate upd;
   upd.a = upd.az = alpha * sz;
+  if (fast_w) upd.az = alpha;  // vA was built from the scaled step
   upd.eps = eps;
   upd.acz_follow = acz_follow;
   if (fuse_upd) {
     // (deferred)
   } else if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
-                             rx->d, vA->d, alpha * sz, n, y_qn->d, acz_follow ? acz->d : nullptr));
+                             rx->d, vA->d, upd.az, n, y_qn->d, acz_follow ? acz->d : nullptr));
   } else {
     PO_TRY(k_update_mult(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper, n));
     if (acz_follow) PO_TRY(k_axpy(ctx, acz->d, alpha * sz, vA->d, n));
@@ -1500,6 +1634,13 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   }
   // the accepted trial point IS the new design point (same clamp, same arithmetic)
   std::swap(x->d, xt->d);
+  // ... and so are its sparse constraint values when the line search's last trial left them in wtmp
+  cwx_valid = false;
+  if (has_w && trial_cw_valid && !eval_obj_con) {
+    std::swap(cwx->d, wtmp->d);
+    cwx_valid = true;
+  }
+  trial_cw_valid = false;
   // ... and its barrier sums are those of the new iterate (trial_kernel and the merit pass take them alike)
   iterate_logs[0] = trial_logs[0];
   iterate_logs[1] = trial_logs[1];
@@ -1656,6 +1797,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   const int gradient_verification_frequency = options.integer("gradient_verification_frequency");
   const std::string start = options.str("starting_point_strategy");
   niter = neval = ngeval = nhvec = 0;
+  cwx_valid = trial_cw_valid = false;
   residual_cached = false;
   iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
   history.clear();
@@ -2032,8 +2174,9 @@ int InteriorPoint::optimize(const char *checkpoint) {
       PO_TRY(k_trial(ctx, bounds(), px->d, 0.0, design_precision, n, xt->d, bs));
       double wsums[5];
       if (has_w) {
-        if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
-        PO_TRY(k_w_trial(ctx, wv(), wp(), 0.0, design_precision, gsw->d, gtw->d, wtmp->d, nw, wsums));
+        const double *cw = nullptr;
+        PO_TRY(sparseConAtIterate(&cw));
+        PO_TRY(k_w_trial(ctx, wv(), wp(), 0.0, design_precision, gsw->d, gtw->d, cw, nw, wsums));
       }
       const double m1 = evalMeritFromSums(fobj, cvals.data(), vars.s.data(), vars.t.data(), bs[0], bs[1],
                                           has_w ? wsums : nullptr);
@@ -2217,6 +2360,7 @@ int InteriorPoint::writeSolutionFile(const char *filename) {
 // readSolutionFile (:983-1104): restart state written by writeSolutionFile (same layout, any rank count)
 int InteriorPoint::readSolutionFile(const char *filename) {
   acz_valid = false;
+  cwx_valid = false;
   int64_t N = 0, off = 0, Wt = 0, woff = 0;
   PO_TRY(solutionFileOffsets(&N, &off, &Wt, &woff));  // collective
   FILE *fp = fopen(filename, "rb");
@@ -2262,6 +2406,8 @@ int InteriorPoint::readSolutionFile(const char *filename) {
       return PO_ERR_ARG;
     }
   }
+  Vec *written[5] = {x, zl, zu, has_w ? wvar[0] : nullptr, has_w ? wvar[1] : nullptr};
+  for (Vec *v : written) PO_TRY(refreshLiveMirror(v));
   return PO_OK;
 }
 

@@ -38,6 +38,9 @@ class Options {
   bool has(const char *name) const { return e.count(name) > 0; }
   // calls fn for every entry that `skip` (may be null) does not hold: po_options_visit_defaults
   int visit(const Options *skip, po_option_visitor fn, void *user) const;
+  // takes over every entry of `src` that `base` does not hold (the trust-region / MMA options of a driver whose
+  // interior-point solver was created separately: one registry serves both, as in the reference)
+  void adoptExtras(const Options &src, const Options &base);
 
  private:
   std::map<std::string, Entry> e;
@@ -88,6 +91,12 @@ class InteriorPoint {
   int readSolutionFile(const char *filename);
   int debugKKTStep(double mu);
   void flushHistory();
+  // checkGradients(dh) (:6196-6199): the problem's finite-difference check at the current point; the report text
+  // (what the reference prints) is returned
+  int checkGradients(double dh, std::string *report);
+  // checkMeritFuncGradient(xpt, dh) (:3280-3432): forward difference of the merit function along the current step
+  // (xpt == nullptr) or, from xpt, along -g/|g| with the reference's fixed slack steps; out = {fd, actual}
+  int checkMeritFuncGradient(Vec *xpt, double dh, double out[2]);
 
   Problem *prob;
   Ctx *ctx;
@@ -199,6 +208,13 @@ class InteriorPoint {
 
   // ---- sparse-constraint path (ip_w.cpp) ----
   Vec *gsw, *gtw, *Cw, *wd2, *wyw, *wtmp, *wtmp2;
+  // cw(x) of the CURRENT iterate (round 4): the residual (twice per iteration: new barrier parameter), the
+  // refinement's residual and the merit derivative all need the sparse constraint values at the same point; the
+  // reference calls evalSparseCon each time (:1358, 3740), here the callback runs once per point and the accepted
+  // trial point of the line search hands its values over.  Dropped whenever x or the problem instance changes.
+  Vec *cwx = nullptr;
+  bool cwx_valid = false, trial_cw_valid = false;
+  int sparseConAtIterate(const double **cw);
   Vec *d1v;                 // n-sized: raw d1, then v = d1 + P alpha
   std::vector<Vec *> Uw;    // U_j = Aw (Dinv o P_j)
   bool panel_plain = false;  // Uw is the unscaled panel image (scalar block form)
@@ -269,6 +285,7 @@ class InteriorPoint {
   int acz_age = 0;
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fuse_mult_update = true;
+  bool fast_yqn_w = true;  // sparse constraints: y_qn from the residuals (PAROPT_AMD_NO_FAST_YQN_W=1 restores the passes)
   bool s_qn_from_trial = false;  // s_qn holds s_qn_a * px, written by the last trial pass of the line search
   double s_qn_a = 0.0;
   bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step

@@ -189,10 +189,11 @@ int InteriorPoint::evalObjBarrierDeriv(const Dense &p, double *pmerit_) {
   if (has_w) {
     // the sparse slacks (:5711-5730, :5767) and, in the same pass, sum (cw - sw + tw)(Aw px - psw + ptw)
     // for the constraint-descent test of the Krylov loop
-    if (prob->evalSparseCon(x, wtmp) != 0) return PO_ERR_USER;
+    const double *cw = nullptr;
+    PO_TRY(sparseConAtIterate(&cw));
     PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
     if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
-    PO_TRY(k_w_merit(ctx, wv(), wp(), 1.0, gsw->d, gtw->d, wtmp->d, wtmp2->d, nw, w_merit_last));
+    PO_TRY(k_w_merit(ctx, wv(), wp(), 1.0, gsw->d, gtw->d, cw, wtmp2->d, nw, w_merit_last));
     ppos += w_merit_last[2];
     pneg += w_merit_last[3];
   }

@@ -39,7 +39,7 @@ int InteriorPoint::allocateW() {
   nw_global = total;
   has_w = total > 0.0;
   if (!has_w) return PO_OK;
-  Vec **all[] = {&gsw, &gtw, &Cw, &wd2, &wyw, &wtmp, &wtmp2};
+  Vec **all[] = {&gsw, &gtw, &Cw, &wd2, &wyw, &wtmp, &wtmp2, &cwx};
   for (Vec **v : all) {
     *v = vec_new(ctx, nw);
     if (!*v) return PO_ERR_HIP;
@@ -65,9 +65,19 @@ int InteriorPoint::applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw)
 
 // the w blocks of computeKKTRes (:1358-1398) and their norms
 // (norms = false: the blocks only -- the caller knows that the sums of this mu and iterate are already in place)
+int InteriorPoint::sparseConAtIterate(const double **cw) {
+  if (!cwx_valid) {
+    if (prob->evalSparseCon(x, cwx) != 0) return PO_ERR_USER;
+    cwx_valid = true;
+  }
+  *cw = cwx->d;
+  return PO_OK;
+}
+
 int InteriorPoint::computeResidualW(double mu, bool norms) {
-  if (prob->evalSparseCon(x, wresv[0]) != 0) return PO_ERR_USER;
-  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, norms ? wres_out : nullptr));
+  const double *cw = nullptr;
+  PO_TRY(sparseConAtIterate(&cw));
+  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, norms ? wres_out : nullptr, cw));
   if (!norms) return PO_OK;
   after_reduce(ctx, [this] {
     for (int i = 0; i < 7; i++) w_sums[i] = wres_out[i];
@@ -200,8 +210,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   if (fuse) {
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
-    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
-    PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
+    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2, wyw));  // ... and wyw += wtmp2
     if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     // sparse blocks of the step first: pzw = wstepv[0] feeds the residual column Aw^T pzw (its minima wait for
     // those of the design blocks unless user code runs in between)
@@ -240,8 +249,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   } else if (m > 0 && (int)Uw.size() >= m && panel_valid) {
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
-    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2));
-    PO_TRY(k_axpy(ctx, wyw->d, 1.0, wtmp2->d, nw));
+    PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2, wyw));  // ... and wyw += wtmp2
     if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     std::vector<const double *> P1(P);
     std::vector<double> a1(alpha.begin(), alpha.begin() + m);

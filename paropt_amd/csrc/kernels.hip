@@ -919,9 +919,11 @@ int k_d1(Ctx *c, const Bounds &b, const double *rx, const double *dinv, double b
 // Dinv and t = Dinv * d1 in one pass over the bound data (setUpKKTDiagSystem :1864-1910 + the d1 build of the
 // solve that follows :2091-2108, when its right-hand side is known at set-up time): bit-identical to
 // dinv_kernel followed by d1_kernel
+// raw != 0: t receives d1 itself (the sparse-constraint path applies its block solve to the raw right-hand side),
+// as d1_kernel with dinv == nullptr
 __global__ void __launch_bounds__(kBlock)
     dinv_d1_kernel(Bounds b, double diag, const double *__restrict__ hdiag, const double *__restrict__ rx,
-                   double beta_mu, int64_t n, double *__restrict__ dinv, double *__restrict__ t) {
+                   double beta_mu, int64_t n, double *__restrict__ dinv, double *__restrict__ t, int raw) {
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
     double2 h = make_double2(0.0, 0.0);
@@ -929,14 +931,15 @@ __global__ void __launch_bounds__(kBlock)
     const double2 r = ld2(rx, q, n);
     const double2 dv = make_double2(dinv_elem(e0, diag + h.x), dinv_elem(e1, diag + h.y));
     st2(dinv, q, n, dv);
-    st2(t, q, n, make_double2(dv.x * d1_elem(e0, r.x, beta_mu), dv.y * d1_elem(e1, r.y, beta_mu)));
+    const double w0 = raw ? 1.0 : dv.x, w1 = raw ? 1.0 : dv.y;
+    st2(t, q, n, make_double2(w0 * d1_elem(e0, r.x, beta_mu), w1 * d1_elem(e1, r.y, beta_mu)));
   }
 }
 int k_dinv_d1(Ctx *c, const Bounds &b, double diag, const double *hdiag, const double *rx, double beta_mu,
-              int64_t n, double *dinv, double *t) {
+              int64_t n, double *dinv, double *t, int raw) {
   count_bytes(c, 8 + (hdiag ? 1 : 0), n);
   if (n <= 0) return PO_OK;
-  PO_LAUNCH(dinv_d1_kernel, grid_for(c, n), b, diag, hdiag, rx, beta_mu, n, dinv, t);
+  PO_LAUNCH(dinv_d1_kernel, grid_for(c, n), b, diag, hdiag, rx, beta_mu, n, dinv, t, raw);
   return PO_OK;
 }
 

@@ -63,8 +63,8 @@ class MMA : public Problem {
   }
   const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
   long sparseFactorBreakdowns() override { return prob->sparseFactorBreakdowns(); }
-  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) override {
-    return prob->sparseCorrection(U, nv, alpha, cw, out);
+  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out, Vec *acc) override {
+    return prob->sparseCorrection(U, nv, alpha, cw, out, acc);
   }
 
   Problem *prob;

@@ -288,6 +288,10 @@ int Options::visit(const Options *skip, po_option_visitor fn, void *user) const 
   }
   return PO_OK;
 }
+void Options::adoptExtras(const Options &src, const Options &base) {
+  for (const auto &kv : src.e)
+    if (!base.has(kv.first.c_str())) e[kv.first] = kv.second;
+}
 const char *Options::str(const char *name) const { return e.at(name).s.c_str(); }
 int Options::integer(const char *name) const { return e.at(name).i; }
 double Options::real(const char *name) const { return e.at(name).f; }

@@ -75,7 +75,10 @@ class Problem {
   // out = -S^-1 (U alpha) for the panel as sparseHalfSolve left it (nv columns, w-sized, `out` w-sized):
   // K0^-1 (P alpha, 0) = (Dinv (P alpha + Aw^T out), out), which turns the second quasi-definite apply of a
   // bordered solve into a correction of the first.  Block form: -cw o (U alpha).  CSR form: -L^-T (Y alpha).
-  virtual int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out);
+  // acc != nullptr: acc += out as well (the caller's running sparse multiplier part), in the same launch where the
+  // form allows it
+  virtual int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out,
+                               Vec *acc = nullptr);
   // one line for the output file, null when there is nothing to say (getFactorInfo, :61)
   virtual const char *sparseFactorInfo();
   // number of factorizations so far that met a non-positive pivot (CSR form; 0 otherwise)
@@ -170,6 +173,7 @@ class SeparableProblem : public Problem {
                           Vec *work) override;
   int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
                     Vec *wwork) override;
+  int sparseFactor(Vec *x, Vec *d, Vec *cw) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   GroupMap gmap;

@@ -129,15 +129,26 @@ int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **w
   return PO_OK;
 }
 
-int Problem::sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) {
-  if (csr) return csr->correction(U, nv, alpha, out->d);
-  PO_TRY(k_panel_axpy(ctx, out->d, 0.0, nullptr, 0.0, alpha, U, nv, nwcon));
-  if (nwblock > 1) {  // -U^-1 (Y alpha)
-    double *Y[1] = {out->d};
-    PO_TRY(k_blk_solve(ctx, blk->d, nwcon / nwblock, nwblock, Y, 1, 2));
-    return k_scale(ctx, out->d, nwcon, -1.0);
+int Problem::sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out, Vec *acc) {
+  if (!csr && nwblock == 1 && nv <= kMaxPanel) {
+    // scalar block form: sum, scale by -cw and the caller's accumulation in ONE w-sized launch (round 4; the same
+    // operations in the same order as the three launches below)
+    return k_w_correction(ctx, U, nv, alpha, cw->d, nwcon, out->d, acc ? acc->d : nullptr);
   }
-  return k_mul(ctx, out->d, -1.0, cw->d, out->d, nwcon);
+  if (csr) {
+    PO_TRY(csr->correction(U, nv, alpha, out->d));
+  } else {
+    PO_TRY(k_panel_axpy(ctx, out->d, 0.0, nullptr, 0.0, alpha, U, nv, nwcon));
+    if (nwblock > 1) {  // -U^-1 (Y alpha)
+      double *Y[1] = {out->d};
+      PO_TRY(k_blk_solve(ctx, blk->d, nwcon / nwblock, nwblock, Y, 1, 2));
+      PO_TRY(k_scale(ctx, out->d, nwcon, -1.0));
+    } else {
+      PO_TRY(k_mul(ctx, out->d, -1.0, cw->d, out->d, nwcon));
+    }
+  }
+  if (acc) PO_TRY(k_axpy(ctx, acc->d, 1.0, out->d, nwcon));
+  return PO_OK;
 }
 
 int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
@@ -485,9 +496,17 @@ int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P
 
 // the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
 // Aw = -(group indicator): u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx - yw[group])
+// Cw = 1 / (Cdiag + sum of d over the group): the group sum and the reciprocal in one launch
+int SeparableProblem::sparseFactor(Vec *xv, Vec *d, Vec *cw) {
+  if (csr || nwblock > 1) return Problem::sparseFactor(xv, d, cw);
+  return k_group_sum(ctx, gmap, cw->d, 1, 0.0, 1.0, d->d, 1);
+}
 int SeparableProblem::sparseApplyK0(Vec *xv, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
                                     Vec *yw, Vec *wwork) {
   if (csr) return Problem::sparseApplyK0(xv, d, cw, bx, bw, yx, yw, wwork);
+  bool done = false;
+  PO_TRY(k_group_k0(ctx, gmap, d->d, bx, cw->d, bw, -1.0, nlocal, yx->d, yw->d, &done));  // one launch (round 4)
+  if (done) return PO_OK;
   const double *P[1] = {bx};
   double *U[1] = {wwork->d};
   PO_TRY(k_group_panel(ctx, gmap, P, 1, d->d, -1.0, U));

@@ -546,10 +546,20 @@ TrustRegion::TrustRegion(Problem *p)
   opts.set("output_file", "");
   for (double &v : row) v = 0.0;
 }
+TrustRegion::TrustRegion(TrustRegionSubproblem *s)
+    : prob(s->prob), ctx(s->ctx), qn(nullptr), eigh(nullptr), eqn(nullptr), sub(s), infeas(nullptr), ip(nullptr),
+      m(s->ncon), nineq(s->ninequality), tr_size(0.1), iter_count(0), subproblem_iters(0),
+      adaptive_subproblem_iters(0), iter_cb(nullptr), iter_cb_user(nullptr), own_sub(false), eig_N(0), eig_index(0),
+      eig_update(nullptr), eig_user(nullptr), tvec(nullptr) {
+  qn_handle.qn = nullptr;
+  opts.addTrustRegionDefaults();
+  opts.set("output_file", "");
+  for (double &v : row) v = 0.0;
+}
 TrustRegion::~TrustRegion() {
-  delete ip;
+  if (own_ip) delete ip;
   delete infeas;
-  delete sub;
+  if (own_sub) delete sub;
   delete eqn;
   delete eigh;
   delete qn;
@@ -572,11 +582,46 @@ int TrustRegion::setEigenModel(int N, int index, EigenModelUpdate update, void *
 }
 
 // the set-up of ParOptOptimizer::optimize for algorithm = "tr" (src/ParOptOptimizer.cpp:108-183)
+int TrustRegion::initState() {
+  if (state_ready) return PO_OK;
+  penalty_gamma.assign(m, options().real("penalty_gamma"));
+  tr_size = options().real("tr_init_size");
+  state_ready = true;
+  return PO_OK;
+}
+void TrustRegion::setPenaltyGamma(double gamma) {
+  initState();
+  if (gamma >= 0.0) penalty_gamma.assign(m, gamma);
+}
+void TrustRegion::setPenaltyGammaArray(const double *g) {
+  initState();
+  for (int i = 0; i < m; i++)
+    if (g[i] >= 0.0) penalty_gamma[i] = g[i];
+}
+int TrustRegion::initialize() {
+  PO_TRY(build());
+  PO_TRY(sub->initModelAndBounds(tr_size));
+  iter_count = 0;
+  return PO_OK;
+}
+
 int TrustRegion::build() {
-  if (ip) return PO_OK;
+  if (ip) return initState();
+  const int64_t n = prob->nlocal;
+  if (!own_sub) {
+    // the caller's subproblem (allocated by its creator); an interior-point solver of our own only if optimize() is
+    // called without one
+    if (!tvec) tvec = vec_new(ctx, n);
+    if (!tvec) return PO_ERR_HIP;
+    ip = new InteriorPoint(sub);
+    ip->options = opts;
+    PO_TRY(ip->allocate());
+    own_ip = true;
+    qn_handle.qn = sub->getQuasiNewton();
+    return initState();
+  }
   const std::string qt = opts.str("qn_type");
   const int msub = opts.integer("qn_subspace_size");
-  const int64_t n = prob->nlocal;
   if (qt == "bfgs") {
     LBFGS *b = new LBFGS(ctx, n, msub);
     b->setBFGSUpdateType(std::string(opts.str("qn_update_type")) == "damped_update"
@@ -607,10 +652,8 @@ int TrustRegion::build() {
   ip = new InteriorPoint(sub);
   ip->options = opts;
   PO_TRY(ip->allocate());
-  penalty_gamma.assign(m, ip->options.real("penalty_gamma"));
-  tr_size = ip->options.real("tr_init_size");
   qn_handle.qn = sub->getQuasiNewton();
-  return PO_OK;
+  return initState();
 }
 
 double TrustRegion::infeasOf(const double *c, const double *weights) const {
@@ -698,9 +741,11 @@ int TrustRegion::minimizeInfeas(std::vector<double> *best_out) {  // :1105-1228
   if (tr_barrier != "default") PO_TRY(o.set("barrier_strategy", tr_barrier.c_str()));
   if (tr_start != "default") PO_TRY(o.set("starting_point_strategy", tr_start.c_str()));
   const int is_seq = o.integer("sequential_linear_method");
+  // (:1150-1156: whatever compact approximation the subproblem carries, the caller's included)
+  EigenQuasiNewton *eq = eqn ? eqn : dynamic_cast<EigenQuasiNewton *>(sub->getQuasiNewton());
   if (infeas->objective == InfeasSubproblem::LINEAR_OBJECTIVE ||
       infeas->objective == InfeasSubproblem::CONSTANT_OBJECTIVE) {
-    if (eqn) eqn->use_qn_objective = 0;
+    if (eq) eq->use_qn_objective = 0;
     if (infeas->constraint == InfeasSubproblem::LINEAR_CONSTRAINT) PO_TRY(o.set("sequential_linear_method", 1));
   }
   double gamma = 1e6;
@@ -726,7 +771,7 @@ int TrustRegion::minimizeInfeas(std::vector<double> *best_out) {  // :1105-1228
   }
   ip->setPenaltyGammaArray(penalty_gamma.data());
   PO_TRY(ip->resetProblemInstance(sub));
-  if (eqn) eqn->use_qn_objective = 1;
+  if (eq) eq->use_qn_objective = 1;
   PO_TRY(o.set("starting_point_strategy", start_option.c_str()));
   PO_TRY(o.set("barrier_strategy", barrier_option.c_str()));
   PO_TRY(o.set("sequential_linear_method", is_seq));
@@ -812,7 +857,27 @@ void TrustRegion::captureSolveLine(int which) {
   last_solve_line[which] = last;
 }
 
-int TrustRegion::optimize() {  // optimize :2365-2384
+int TrustRegion::optimize(InteriorPoint *ext) {  // optimize :2365-2384
+  if (ext) {
+    if (own_sub || ext->prob != sub) {
+      set_error("ParOptTrustRegion::optimize: the interior-point solver was not built on this subproblem");
+      return PO_ERR_ARG;
+    }
+    // one registry, as in the reference (the same ParOptOptions object serves both): the trust-region entries set on
+    // this object move into the solver's registry; the interior-point entries are the solver's own
+    Options base;
+    if (ip != ext) {
+      const Options &mine = ip ? ip->options : opts;
+      ext->options.adoptExtras(mine, base);
+      if (ip && own_ip) delete ip;
+      ip = ext;
+      own_ip = false;
+    }
+    if (!tvec) tvec = vec_new(ctx, prob->nlocal);
+    if (!tvec) return PO_ERR_HIP;
+    qn_handle.qn = sub->getQuasiNewton();
+    PO_TRY(initState());
+  }
   PO_TRY(build());
   // tr_use_soc has no effect in the reference either: the only call of isAcceptedBySoc is commented
   // out (:2002-2052), the option merely allocates a scratch vector (:702-706)

@@ -98,8 +98,8 @@ class TrustRegionSubproblem : public Problem {
   }
   const char *sparseFactorInfo() override { return prob->sparseFactorInfo(); }
   long sparseFactorBreakdowns() override { return prob->sparseFactorBreakdowns(); }
-  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) override {
-    return prob->sparseCorrection(U, nv, alpha, cw, out);
+  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out, Vec *acc) override {
+    return prob->sparseCorrection(U, nv, alpha, cw, out, acc);
   }
   int writeOutput(int iter, Vec *x) override { return prob->writeOutput(iter, x); }
   // the model evaluations issue their reductions through the internal launchers and finish with
@@ -201,8 +201,8 @@ class InfeasSubproblem : public Problem {  // :468-650
   }
   const char *sparseFactorInfo() override { return sub->sparseFactorInfo(); }
   long sparseFactorBreakdowns() override { return sub->sparseFactorBreakdowns(); }
-  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out) override {
-    return sub->sparseCorrection(U, nv, alpha, cw, out);
+  int sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out, Vec *acc) override {
+    return sub->sparseCorrection(U, nv, alpha, cw, out, acc);
   }
   TrustRegionSubproblem *sub;
   int objective, constraint;
@@ -213,13 +213,22 @@ typedef int (*TrIterationFn)(void *user, int iter);
 
 class TrustRegion {
  public:
+  // everything assembled from the options, as ParOptOptimizer does for algorithm = "tr"
   explicit TrustRegion(Problem *prob);
+  // ParOptTrustRegion(subproblem, options) (src/ParOptTrustRegion.cpp:660-718): the caller owns the subproblem
+  // (and, through it, the quasi-Newton object); the interior-point solver arrives with optimize(ip)
+  explicit TrustRegion(TrustRegionSubproblem *subproblem);
   ~TrustRegion();
   Options &options() { return ip ? ip->options : opts; }
   // compact eigenvalue model for constraint `index` with N curvature directions (before optimize)
   int setEigenModel(int N, int index, EigenModelUpdate update, void *user);
-  int optimize();
+  // ext != nullptr: ParOptTrustRegion::optimize(ParOptInteriorPoint*) (.cpp:2365-2384) -- the caller's solver, built
+  // on the subproblem, is used (borrowed); the trust-region options set on this object are carried into its registry
+  int optimize(InteriorPoint *ext = nullptr);
   int build();  // quasi-Newton, subproblem, interior point from the current options (idempotent)
+  int initialize();  // ParOptTrustRegion::initialize (.cpp:1086-1099)
+  void setPenaltyGamma(double gamma);           // .cpp:1049-1055
+  void setPenaltyGammaArray(const double *g);   // .cpp:1062-1068
 
   Problem *prob;
   Ctx *ctx;
@@ -249,6 +258,8 @@ class TrustRegion {
   void captureSolveLine(int which);
 
  private:
+  bool own_sub = true, own_ip = true, state_ready = false;
+  int initState();  // penalty parameters and radius from the options (the reference's constructor)
   int eig_N, eig_index;
   EigenModelUpdate eig_update;
   void *eig_user;

@@ -60,18 +60,39 @@ __device__ __forceinline__ void w_block_reduce(double (&a)[N], double *partials,
 // then one thread per (group, column) adds its nw LDS values and the results leave coalesced over the
 // group index.  JB panel columns share one tile pass (one d load, JB independent loads in flight).
 constexpr int kGroupTile = 512;  // variables per tile = 2 per thread
+// sum of nw consecutive LDS values in index order (the loads of four entries are issued together, the adds keep
+// the order of the plain loop: same bits)
+__device__ __forceinline__ double row_sum(const double *row, int nw) {
+  double sacc = 0.0;
+  int k = 0;
+  for (; k + 4 <= nw; k += 4) {
+    const double a = row[k], b = row[k + 1], c = row[k + 2], e = row[k + 3];
+    sacc += a;
+    sacc += b;
+    sacc += c;
+    sacc += e;
+  }
+  for (; k < nw; k++) sacc += row[k];
+  return sacc;
+}
+// LDS rows of the tiled kernels: group gi of a tile starts at gi * (period + pad) with pad = 1 when the period is
+// even -- an odd row stride in doubles keeps the ds_read_b64 of 64 lanes that walk 64 different groups free of bank
+// conflicts (stride 20 doubles = 40 banks was an 8-way conflict: round 4).  Element e of the tile (group e / period)
+// therefore lives at e + pad * (e / period).
 template <int JB>
 __global__ void __launch_bounds__(kBlock)
     group_panel_tiled_kernel(GroupMap m, PtrTable P, int nv, const double *__restrict__ d, double alpha,
                              PtrTableW U, int G, int64_t ntiles) {
   __shared__ double sm[JB * kGroupTile];
-  const int64_t period = m.nw + m.skip;
+  const int period = m.nw + m.skip;
+  const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
   const int tid = threadIdx.x;
+  const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t g0 = tile * G;
     const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
-    const int64_t v0 = m.start + g0 * period;
-    const int nvv = (int)((ng - 1) * period + m.nw);
+    const int64_t v0 = m.start + g0 * (int64_t)period;
+    const int nvv = (ng - 1) * period + m.nw;
     const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
     const double d0 = in0 ? (d ? d[v0 + tid] : 1.0) : 0.0;
     const double d1 = in1 ? (d ? d[v0 + tid + kBlock] : 1.0) : 0.0;
@@ -85,51 +106,50 @@ __global__ void __launch_bounds__(kBlock)
       }
 #pragma unroll
       for (int u = 0; u < JB; u++) {
-        sm[u * kGroupTile + tid] = d0 * a0[u];
-        sm[u * kGroupTile + tid + kBlock] = d1 * a1[u];
+        if (in0) sm[u * kGroupTile + s0] = d0 * a0[u];
+        if (in1) sm[u * kGroupTile + s1] = d1 * a1[u];
       }
       __syncthreads();
       for (int pair = tid; pair < ng * JB; pair += kBlock) {
         const int u = pair / ng, gi = pair - u * ng;
-        if (jb + u < nv) {
-          const double *row = sm + u * kGroupTile + gi * period;
-          double sacc = 0.0;
-          for (int k = 0; k < m.nw; k++) sacc += row[k];
-          U.p[jb + u][g0 + gi] = alpha * sacc;
-        }
+        if (jb + u < nv) U.p[jb + u][g0 + gi] = alpha * row_sum(sm + u * kGroupTile + gi * rstride, m.nw);
       }
       __syncthreads();
     }
   }
 }
 // out_i = (init ? out_i : cst) + alpha * (group sum of v), same tiling with a single column
+// recip != 0: out_i = 1 / (...) (the factor Cw = 1 / (Cdiag + Aw D^-1 Aw^T) of the scalar block form in one launch)
 __global__ void __launch_bounds__(kBlock)
     group_sum_tiled_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
-                           const double *__restrict__ v, int G, int64_t ntiles) {
+                           const double *__restrict__ v, int G, int64_t ntiles, int recip) {
   __shared__ double sm[kGroupTile];
-  const int64_t period = m.nw + m.skip;
+  const int period = m.nw + m.skip;
+  const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
   const int tid = threadIdx.x;
+  const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t g0 = tile * G;
     const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
-    const int64_t v0 = m.start + g0 * period;
-    const int nvv = (int)((ng - 1) * period + m.nw);
-    sm[tid] = tid < nvv ? v[v0 + tid] : 0.0;
-    sm[tid + kBlock] = tid + kBlock < nvv ? v[v0 + tid + kBlock] : 0.0;
+    const int64_t v0 = m.start + g0 * (int64_t)period;
+    const int nvv = (ng - 1) * period + m.nw;
+    if (tid < nvv) sm[s0] = v[v0 + tid];
+    if (tid + kBlock < nvv) sm[s1] = v[v0 + tid + kBlock];
     __syncthreads();
     if (tid < ng) {
-      const double *row = sm + tid * period;
-      double sacc = 0.0;
-      for (int k = 0; k < m.nw; k++) sacc += row[k];
-      out[g0 + tid] = (init ? out[g0 + tid] : cst) + alpha * sacc;
+      const double sacc = row_sum(sm + tid * rstride, m.nw);
+      const double val = (init ? out[g0 + tid] : cst) + alpha * sacc;
+      out[g0 + tid] = recip ? 1.0 / val : val;
     }
     __syncthreads();
   }
 }
+// G whole groups per tile with the padded row layout inside kGroupTile doubles: (G-1)*(period+pad) + nw <= kGroupTile
 static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles) {
   const int64_t period = (int64_t)m.nw + m.skip;
-  if (m.nw > kGroupTile || period <= 0) return false;
-  int64_t g = (kGroupTile - m.nw) / period + 1;  // (g-1)*period + nw <= kGroupTile
+  if (m.nw > kGroupTile || period <= 0 || period > kGroupTile) return false;
+  const int64_t rstride = period + ((period & 1) ? 0 : 1);
+  int64_t g = (kGroupTile - m.nw) / rstride + 1;
   if (g > kBlock) g = kBlock;
   if (g < 1) return false;
   *G = (int)g;
@@ -140,16 +160,17 @@ static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles) {
 // out_i = (init ? out_i : cst) + alpha * sum_{k<nw} v[start + i*(nw+skip) + k]
 __global__ void __launch_bounds__(kBlock)
     group_sum_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
-                     const double *__restrict__ v) {
+                     const double *__restrict__ v, int recip) {
   PO_W_LOOP(i, m.nwcon) {
     const int64_t j0 = m.start + i * (int64_t)(m.nw + m.skip);
     double s = 0.0;
     for (int k = 0; k < m.nw; k++) s += v[j0 + k];
-    out[i] = (init ? out[i] : cst) + alpha * s;
+    const double val = (init ? out[i] : cst) + alpha * s;
+    out[i] = recip ? 1.0 / val : val;
   }
 }
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
-                const double *v) {
+                const double *v, int recip) {
   if (m.nwcon <= 0) return PO_OK;
   count_bytes(c, 1.0, m.nwcon * (int64_t)m.nw);  // the grouped part of v (the w-sized output is noise beside it)
   count_bytes(c, init ? 2.0 : 1.0, m.nwcon);
@@ -157,10 +178,10 @@ int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, do
   int64_t ntiles = 0;
   if (group_tiling(m, &G, &ntiles)) {
     int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
-    PO_WLAUNCH(group_sum_tiled_kernel, (int)grid, m, out, init, cst, alpha, v, G, ntiles);
+    PO_WLAUNCH(group_sum_tiled_kernel, (int)grid, m, out, init, cst, alpha, v, G, ntiles, recip);
     return PO_OK;
   }
-  PO_WLAUNCH(group_sum_kernel, wgrid(c, m.nwcon), m, out, init, cst, alpha, v);
+  PO_WLAUNCH(group_sum_kernel, wgrid(c, m.nwcon), m, out, init, cst, alpha, v, recip);
   return PO_OK;
 }
 // out[g] += alpha * w[i(g)] for every variable g that belongs to a group
@@ -176,10 +197,64 @@ __global__ void __launch_bounds__(kBlock)
     }
   }
 }
+// Group index of the variables of an element PAIR (2q, 2q + 1): one 32-bit division per pair (the 64-bit division per
+// element of the plain kernels costs more than the memory access it guards); valid for n < 2^31.
+struct PairGroups {
+  int64_t i0, i1;  // constraint of element 2q / 2q + 1, or -1
+};
+__device__ __forceinline__ PairGroups pair_groups(const GroupMap &m, uint32_t period, int64_t q) {
+  PairGroups p;
+  p.i0 = p.i1 = -1;
+  const int64_t r0 = 2 * q - m.start;
+  if (r0 >= 0) {
+    const uint32_t i = (uint32_t)r0 / period, k = (uint32_t)r0 - i * period;
+    if (k < (uint32_t)m.nw && (int64_t)i < m.nwcon) p.i0 = i;
+    uint32_t i1 = i, k1 = k + 1;
+    if (k1 == period) {
+      i1 = i + 1;
+      k1 = 0;
+    }
+    if (k1 < (uint32_t)m.nw && (int64_t)i1 < m.nwcon) p.i1 = i1;
+  } else if (r0 == -1) {
+    if (m.nw > 0 && m.nwcon > 0) p.i1 = 0;
+  }
+  return p;
+}
+__global__ void __launch_bounds__(kBlock)
+    group_scatter2_kernel(GroupMap m, double *__restrict__ out, double alpha, const double *__restrict__ w, int64_t n,
+                          int set) {
+  const uint32_t period = (uint32_t)(m.nw + m.skip);
+  const int64_t npairs = (n + 1) >> 1;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    const PairGroups p = pair_groups(m, period, q);
+    double2 *dst = reinterpret_cast<double2 *>(out + 2 * q);
+    double2 v = make_double2(0.0, 0.0);
+    if (set) {  // 0 + alpha w = alpha w exactly: "zero, then add" in one pass that never reads `out`
+      if (p.i0 >= 0) v.x = __dadd_rn(0.0, __dmul_rn(alpha, w[p.i0]));
+      if (p.i1 >= 0) v.y = __dadd_rn(0.0, __dmul_rn(alpha, w[p.i1]));
+    } else {
+      v = *dst;
+      if (p.i0 >= 0) v.x += alpha * w[p.i0];
+      if (p.i1 >= 0) v.y += alpha * w[p.i1];
+    }
+    if (2 * q + 1 >= n) v.y = 0.0;  // the pad element of an odd length stays zero
+    *dst = v;
+  }
+}
+static int pair_grid(Ctx *c, int64_t n) {
+  int64_t b = (((n + 1) >> 1) + kBlock - 1) / kBlock;
+  if (b > (int64_t)c->num_cu * 4) b = (int64_t)c->num_cu * 4;
+  if (b < 1) b = 1;
+  return (int)b;
+}
 int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n) {
   if (m.nwcon <= 0 || n <= 0) return PO_OK;
   count_bytes(c, 2.0, n);
   count_bytes(c, 1.0, m.nwcon);
+  if (n < 2000000000LL) {
+    PO_WLAUNCH(group_scatter2_kernel, pair_grid(c, n), m, out, alpha, w, n, 0);
+    return PO_OK;
+  }
   PO_WLAUNCH(group_scatter_kernel, wgrid(c, n), m, out, alpha, w, n);
   return PO_OK;
 }
@@ -204,6 +279,10 @@ int k_group_scatter_set(Ctx *c, const GroupMap &m, double *out, double alpha, co
   if (m.nwcon <= 0) return k_fill(c, out, n, 0.0);
   count_bytes(c, 1.0, n);
   count_bytes(c, 1.0, m.nwcon);
+  if (n < 2000000000LL) {
+    PO_WLAUNCH(group_scatter2_kernel, pair_grid(c, n), m, out, alpha, w, n, 1);
+    return PO_OK;
+  }
   PO_WLAUNCH(group_scatter_set_kernel, wgrid(c, n), m, out, alpha, w, n);
   return PO_OK;
 }
@@ -276,6 +355,106 @@ int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, 
   PO_WLAUNCH(group_apply_kernel, wgrid(c, n), m, d, bx, alpha, yw, n, yx);
   return PO_OK;
 }
+// The whole structured K0^-1 apply in ONE pass over (d, bx) (round 4): u_i = alpha * sum_{g in group i} d_g bx_g,
+// yw_i = cw_i ((bw ? bw_i : 0) - u_i), yx_g = d_g (bx_g + alpha yw_i(g)) inside a group and d_g bx_g outside --
+// group_panel_tiled_kernel on one column, w_apply_mid_kernel and group_apply_kernel with the same arithmetic in the
+// same order, the tile kept in registers between the two halves.  A tile is G whole PERIODS (G * period <=
+// kGroupTile), so consecutive tiles cover [start, start + nwcon * period) without gaps; what lies before `start`
+// and after the last period is element-wise.
+__global__ void __launch_bounds__(kBlock)
+    group_k0_tiled_kernel(GroupMap m, const double *__restrict__ d, const double *__restrict__ bx,
+                          const double *__restrict__ cw, const double *__restrict__ bw, double alpha, int64_t n,
+                          double *__restrict__ yx, double *__restrict__ yw, int G, int64_t ntiles) {
+  __shared__ double sm[kGroupTile + kBlock];
+  double *smw = sm + kGroupTile;
+  const int period = m.nw + m.skip;
+  const int tid = threadIdx.x;
+  const int gi0 = tid / period, k0 = tid - gi0 * period;
+  const int gi1 = (tid + kBlock) / period, k1 = tid + kBlock - gi1 * period;
+  const int64_t cover_end = (m.start + m.nwcon * (int64_t)period) < n ? (m.start + m.nwcon * (int64_t)period) : n;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int64_t v0 = m.start + g0 * (int64_t)period;
+    int64_t vend = v0 + (int64_t)ng * period;
+    if (vend > n) vend = n;
+    const int nvv = (int)(vend - v0);
+    const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
+    const double d0 = in0 ? d[v0 + tid] : 0.0, d1 = in1 ? d[v0 + tid + kBlock] : 0.0;
+    const double b0 = in0 ? bx[v0 + tid] : 0.0, b1 = in1 ? bx[v0 + tid + kBlock] : 0.0;
+    sm[tid] = d0 * b0;
+    sm[tid + kBlock] = d1 * b1;
+    __syncthreads();
+    if (tid < ng) {
+      const double u = alpha * row_sum(sm + tid * period, m.nw);
+      const double y = cw[g0 + tid] * ((bw ? bw[g0 + tid] : 0.0) - u);
+      yw[g0 + tid] = y;
+      smw[tid] = y;
+    }
+    __syncthreads();
+    if (in0) {
+      double v = b0;
+      if (k0 < m.nw) v += alpha * smw[gi0];
+      yx[v0 + tid] = d0 * v;
+    }
+    if (in1) {
+      double v = b1;
+      if (k1 < m.nw) v += alpha * smw[gi1];
+      yx[v0 + tid + kBlock] = d1 * v;
+    }
+  }
+  // variables outside every group's period: yx = d bx
+  const int64_t nout = m.start + (n - cover_end);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + tid; i < nout; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t g = i < m.start ? i : cover_end + (i - m.start);
+    yx[g] = d[g] * bx[g];
+  }
+}
+int k_group_k0(Ctx *c, const GroupMap &m, const double *d, const double *bx, const double *cw, const double *bw,
+               double alpha, int64_t n, double *yx, double *yw, bool *done) {
+  *done = false;
+  const int64_t period = (int64_t)m.nw + m.skip;
+  if (m.nwcon <= 0 || n <= 0 || period <= 0 || period > kGroupTile || m.start + (m.nwcon - 1) * period + m.nw > n)
+    return PO_OK;
+  int64_t G = kGroupTile / period;
+  if (G > kBlock) G = kBlock;
+  const int64_t ntiles = (m.nwcon + G - 1) / G;
+  count_bytes(c, 3.0, n);
+  count_bytes(c, bw ? 3.0 : 2.0, m.nwcon);
+  int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
+  PO_WLAUNCH(group_k0_tiled_kernel, (int)grid, m, d, bx, cw, bw, alpha, n, yx, yw, (int)G, ntiles);
+  *done = true;
+  return PO_OK;
+}
+
+// out = -cw o (sum_j alpha_j U_j) (the second K0^-1 apply of a bordered solve as a correction from the panel image,
+// Problem::sparseCorrection) and, with acc != nullptr, acc += out in the same pass: panel_axpy + mul + axpy
+__global__ void __launch_bounds__(kBlock)
+    w_correction_kernel(PtrTable U, CoefTable a, int nv, const double *__restrict__ cw, int64_t w,
+                        double *__restrict__ out, double *__restrict__ acc) {
+  PO_W_LOOP(i, w) {
+    double s = 0.0;
+    for (int j = 0; j < nv; j++) s = fma(a.a[j], U.p[j][i], s);
+    const double o = -1.0 * cw[i] * s;
+    out[i] = o;
+    if (acc) acc[i] = fma(1.0, o, acc[i]);
+  }
+}
+int k_w_correction(Ctx *c, const double *const *U, int nv, const double *alpha, const double *cw, int64_t w,
+                   double *out, double *acc) {
+  if (w <= 0) return PO_OK;
+  if (nv > kMaxPanel) return PO_ERR_ARG;  // (callers fall back to the separate launches)
+  count_bytes(c, (double)nv + 2.0 + (acc ? 2.0 : 0.0), w);
+  PtrTable pt;
+  CoefTable ct;
+  for (int j = 0; j < kMaxPanel; j++) {
+    pt.p[j] = j < nv ? U[j] : nullptr;
+    ct.a[j] = j < nv ? alpha[j] : 0.0;
+  }
+  PO_WLAUNCH(w_correction_kernel, wgrid(c, w), pt, ct, nv, cw, w, out, acc);
+  return PO_OK;
+}
+
 // yw = cw * (bw - u)   (bw may be null)
 __global__ void __launch_bounds__(kBlock)
     w_apply_mid_kernel(const double *__restrict__ cw, const double *__restrict__ bw, const double *__restrict__ u,
@@ -416,13 +595,13 @@ int k_recip(Ctx *c, double *y, int64_t n) {
 // sums {sw.zsw + tw.ztw, l1 rzw, l2^2 rzw, l1 rsw, l1 rtw, l1 rzsw, l1 rztw}; maxs {rzw, rsw, rtw, rzsw, rztw}
 __global__ void __launch_bounds__(kBlock)
     w_res_kernel(WVars v, WVars r, const double *__restrict__ gsw, const double *__restrict__ gtw,
-                 double mu, int64_t w, double *__restrict__ partials) {
+                 const double *cw, double mu, int64_t w, double *__restrict__ partials) {
   __shared__ double sm[4 * 7];
   double sums[7] = {0, 0, 0, 0, 0, 0, 0};
   double maxs[5] = {0, 0, 0, 0, 0};
   PO_W_LOOP(i, w) {
     const double sw = v.sw[i], tw = v.tw[i], zw = v.zw[i], zsw = v.zsw[i], ztw = v.ztw[i];
-    const double a = -(r.zw[i] - sw + tw);
+    const double a = -(cw[i] - sw + tw);  // cw may be r.zw itself (the constraint values left there by the caller)
     const double b = zsw - gsw[i] - zw;
     const double cc = ztw - gtw[i] + zw;
     const double d = mu - sw * zsw;
@@ -449,11 +628,11 @@ __global__ void __launch_bounds__(kBlock)
   w_block_reduce<5, 2>(maxs, partials, 7, sm);
 }
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
-            int64_t w, double out[12]) {
+            int64_t w, double out[12], const double *cw) {
   count_bytes(c, 12.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 12));
-  PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, mu, w, c->d_partials);
+  PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, cw ? cw : r.zw, mu, w, c->d_partials);
   if (!out) return PO_OK;  // the residual blocks only
   return reduce_finish(c, grid, 7, 0, 5, out);
 }

@@ -20,7 +20,14 @@ struct GroupMap {
 };
 
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
-                const double *v);
+                const double *v, int recip = 0);
+// the structured K0^-1 apply in one launch (see wcon.hip); *done = false when the map does not tile (the caller then
+// takes the three-launch form)
+int k_group_k0(Ctx *c, const GroupMap &m, const double *d, const double *bx, const double *cw, const double *bw,
+               double alpha, int64_t n, double *yx, double *yw, bool *done);
+// out = -cw o (sum_j alpha_j U_j); acc += out when acc != nullptr
+int k_w_correction(Ctx *c, const double *const *U, int nv, const double *alpha, const double *cw, int64_t w,
+                   double *out, double *acc);
 int k_group_scatter(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n);
 // the same with `out` overwritten (zero outside the groups): no separate fill pass
 int k_group_scatter_set(Ctx *c, const GroupMap &m, double *out, double alpha, const double *w, int64_t n);
@@ -37,8 +44,9 @@ int k_blk_solve(Ctx *c, const double *blk, int64_t nblocks, int B, double *const
 int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64_t n);
 int k_recip(Ctx *c, double *y, int64_t n);
 
+// cw: the sparse constraint values (null: they sit in r.zw, which is overwritten)
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
-            int64_t w, double out[12]);
+            int64_t w, double out[12], const double *cw = nullptr);
 int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t w);
 int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]);
 int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd);

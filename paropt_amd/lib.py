@@ -26,6 +26,7 @@ po_problem = C.c_void_p
 po_ip = C.c_void_p
 po_tr = C.c_void_p
 po_eig = C.c_void_p
+po_trsub = C.c_void_p
 po_mma = C.c_void_p
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -199,6 +200,8 @@ SIGNATURES = {
     "po_ip_reset_problem_instance": (C.c_int, [po_ip, po_problem]),
     "po_ip_get_hvec_count": (C.c_int, [po_ip, c_int_p]),
     "po_ip_reset_design_and_bounds": (C.c_int, [po_ip]),
+    "po_ip_check_gradients": (C.c_int, [po_ip, C.c_double, C.POINTER(C.c_char_p)]),
+    "po_ip_check_merit_func_gradient": (C.c_int, [po_ip, po_vec, C.c_double, c_double_p, c_double_p]),
     "po_ip_reset_quasi_newton": (C.c_int, [po_ip]),
     "po_ip_get_quasi_newton": (C.c_int, [po_ip, C.POINTER(po_qn)]),
     "po_ip_write_solution_file": (C.c_int, [po_ip, C.c_char_p]),
@@ -236,6 +239,37 @@ SIGNATURES = {
     "po_tr_get_quasi_newton": (C.c_int, [po_tr, C.POINTER(po_qn)]),
     "po_tr_get_model_vectors": (C.c_int, [po_tr, C.POINTER(po_vec), C.POINTER(po_vec)]),
     "po_tr_set_iteration_callback": (C.c_int, [po_tr, TR_ITER_FN, C.c_void_p]),
+    # the trust-region layer piece by piece (the reference's own assembly, eigenvalue_opt.py:298-308)
+    "po_eig_create": (C.c_int, [po_problem, C.c_int, C.POINTER(po_eig)]),
+    "po_eig_destroy": (C.c_int, [po_eig]),
+    "po_eig_mult_add": (C.c_int, [po_eig, C.c_double, po_vec, po_vec]),
+    "po_eig_eval_approximation": (C.c_int, [po_eig, po_vec, po_vec, c_double_p]),
+    "po_eig_eval_approximation_gradient": (C.c_int, [po_eig, po_vec, po_vec]),
+    "po_eigqn_create": (C.c_int, [po_qn, po_eig, C.c_int, C.POINTER(po_qn)]),
+    "po_eigqn_set_use_quasi_newton_objective": (C.c_int, [po_qn, C.c_int]),
+    "po_eigqn_update_multipliers": (C.c_int, [po_qn, c_double_p]),
+    "po_eigqn_get_multiplier_index": (C.c_int, [po_qn, c_int_p]),
+    "po_trsub_create_quadratic": (C.c_int, [po_problem, po_qn, C.POINTER(po_trsub)]),
+    "po_trsub_create_eigen": (C.c_int, [po_problem, po_qn, C.POINTER(po_trsub)]),
+    "po_trsub_destroy": (C.c_int, [po_trsub]),
+    "po_trsub_set_eigen_model_update": (C.c_int, [po_trsub, EIG_UPDATE_FN, C.c_void_p]),
+    "po_trsub_problem": (C.c_int, [po_trsub, C.POINTER(po_problem)]),
+    "po_trsub_get_quasi_newton": (C.c_int, [po_trsub, C.POINTER(po_qn)]),
+    "po_trsub_init_model_and_bounds": (C.c_int, [po_trsub, C.c_double]),
+    "po_trsub_set_trust_region_bounds": (C.c_int, [po_trsub, C.c_double]),
+    "po_trsub_eval_trial_step_and_update": (
+        C.c_int, [po_trsub, C.c_int, po_vec, c_double_p, po_vec, c_double_p, c_double_p]),
+    "po_trsub_accept_trial_step": (C.c_int, [po_trsub, po_vec, c_double_p, po_vec]),
+    "po_trsub_reject_trial_step": (C.c_int, [po_trsub]),
+    "po_trsub_get_quasi_newton_update_type": (C.c_int, [po_trsub, c_int_p]),
+    "po_trsub_get_linear_model": (
+        C.c_int, [po_trsub, C.POINTER(po_vec), c_double_p, C.POINTER(po_vec), C.POINTER(c_double_p),
+                  C.POINTER(vec_p), C.POINTER(po_vec), C.POINTER(po_vec), c_int_p]),
+    "po_tr_create_subproblem": (C.c_int, [po_trsub, C.POINTER(po_tr)]),
+    "po_tr_optimize_with": (C.c_int, [po_tr, po_ip]),
+    "po_tr_initialize": (C.c_int, [po_tr]),
+    "po_tr_set_penalty_gamma": (C.c_int, [po_tr, C.c_double]),
+    "po_tr_set_penalty_gamma_array": (C.c_int, [po_tr, c_double_p]),
     "po_mma_create": (C.c_int, [po_problem, C.POINTER(po_mma)]),
     "po_mma_destroy": (C.c_int, [po_mma]),
     "po_mma_set_option_str": (C.c_int, [po_mma, C.c_char_p, C.c_char_p]),

@@ -1070,3 +1070,39 @@ def test_host_writes_through_get_array_reach_the_solver(ctx):
     assert abs(n_host[1] - expect_zl) <= 1e-12 * expect_zl and abs(n_host[2] - 0.75 * np.sqrt(n)) <= 1e-12 * n
     np.testing.assert_array_equal(n_host, n_dev)
     np.testing.assert_array_equal(x_host, x_dev)
+@pytest.mark.gpu
+def test_reset_design_and_bounds_wins_over_a_live_mirror(ctx, tmp_path):
+    """a caller that still holds getArray views of the previous optimum calls resetDesignAndBounds() (or
+    readSolutionFile()) and optimizes again.  The reference has ONE buffer: the reset is what the solve starts from and
+    what the caller's pointer shows.  The live mirror must be refreshed by the internal writer, not uploaded over it."""
+    import paropt_amd as pa
+
+    n, c = 2001, 2
+    opts = {"qn_subspace_size": 5, "abs_res_tol": 1e-8, "max_major_iters": 6, "write_output_frequency": 0}
+    prob = pa.SeparableProblem(ctx, "quadratic", n, c)
+    ip = pa.InteriorPoint(prob, opts)
+    first = []
+    ip.setIterationCallback(lambda k: first.append(ip.getOptimizedPoint()[0].to_numpy().copy()) if k == 0 else None)
+    ip.optimize()
+    x0 = first[0]                      # the point the first solve started from (after the bound checks)
+    ckpt = str(tmp_path / "sol.bin")
+    ip.writeSolutionFile(ckpt)
+    x = ip.getOptimizedPoint()[0]
+    xopt = x.to_numpy().copy()
+    assert np.abs(xopt - x0).max() > 1e-3
+    view = x.getArray()                # live host view of the solver's own vector: holds the optimum
+    np.testing.assert_array_equal(view, xopt)
+    ip.resetDesignAndBounds()
+    np.testing.assert_array_equal(view, x.to_numpy())  # the caller's pointer shows the reset point ...
+    assert np.abs(view - xopt).max() > 1e-3
+    first.clear()
+    ip.resetQuasiNewtonHessian()
+    ip.optimize()
+    np.testing.assert_array_equal(first[0], x0)        # ... and the solve starts from it, not from the stale mirror
+    # the same through readSolutionFile: the restart point is the file's, also behind a live view
+    view = ip.getOptimizedPoint()[0].getArray()
+    view[:] = 0.123
+    ip.readSolutionFile(ckpt)
+    np.testing.assert_array_equal(view, xopt)
+
+
