@@ -37,6 +37,7 @@ void dbg_switch_set(int id, int value) {
 }
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
+int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count);
 // (Re)allocates the pinned result buffer and the alias the device writes through (see Ctx::h_red_dev).
 static int alloc_h_red(Ctx *c, size_t doubles) {
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -234,7 +235,7 @@ int ctx_destroy(Ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
-  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->partials_base) (void)hipFree(c->partials_base);
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->h_red) (void)hipHostFree(c->h_red);
@@ -249,14 +250,37 @@ int ctx_destroy(Ctx *c) {
   return PO_OK;
 }
 
-int ensure_partials(Ctx *c, size_t doubles) {
-  if (doubles <= c->partials_cap) return PO_OK;
-  // growth happens outside hot loops in practice (first use of a wider kernel)
+static int grow_partials(Ctx *c, size_t doubles) {
+  // growth happens outside hot loops in practice (first use of a wider kernel); nothing is queued when it happens
   PO_HIP(hipStreamSynchronize(c->stream));
-  if (c->d_partials) PO_HIP(hipFree(c->d_partials));
+  if (c->partials_base) PO_HIP(hipFree(c->partials_base));
+  c->partials_base = nullptr;
   size_t cap = doubles + doubles / 4;
-  PO_HIP(hipMalloc((void **)&c->d_partials, cap * sizeof(double)));
+  if (cap < ((size_t)1 << 22)) cap = (size_t)1 << 22;  // 32 MB: room for the regions of a whole batch
+  PO_HIP(hipMalloc((void **)&c->partials_base, cap * sizeof(double)));
   c->partials_cap = cap;
+  c->partials_cursor = 0;
+  return PO_OK;
+}
+// Region for the first-stage partials of the launch about to be issued (c->d_partials).  Outside a batch: the arena
+// itself.  Inside a batch: a region of its own, so that the final stage can wait for the flush; when the arena is
+// full the queued reductions are flushed first (always safe: a flush only makes results available earlier).
+int ensure_partials(Ctx *c, size_t doubles) {
+  const bool queued = c->batch_depth > 0 || !c->batch_pend.empty();
+  if (!queued) {
+    if (doubles > c->partials_cap) PO_TRY(grow_partials(c, doubles));
+    c->partials_cursor = 0;
+    c->d_partials = c->partials_base;
+    return PO_OK;
+  }
+  const size_t need = (doubles + 63) & ~(size_t)63;  // 512-byte granules
+  if (c->partials_cursor + need > c->partials_cap) {
+    PO_TRY(batch_flush(c));
+    if (need > c->partials_cap) PO_TRY(grow_partials(c, need));
+  }
+  c->d_partials = c->partials_base + c->partials_cursor;
+  c->partials_cursor += need;
+  c->partials_last = need;
   return PO_OK;
 }
 
@@ -463,6 +487,7 @@ void batch_abort(Ctx *c) {
   c->batch_pend.clear();
   c->batch_after.clear();
   c->batch_cursor = 0;
+  c->partials_cursor = 0;
   c->mdot_timing_pending = false;
 }
 
@@ -480,6 +505,9 @@ int batch_flush(Ctx *c) {
   after.swap(c->batch_after);
   const int total = c->batch_cursor;
   c->batch_cursor = 0;
+  c->partials_cursor = 0;
+  // the final stages of everything queued: ONE launch (same per-slot arithmetic as the single-reduction kernel)
+  PO_TRY(launch_reduce_final_multi(c, pend.data(), (int)pend.size()));
   bool pure_sum = true;
   for (const Ctx::PendingRed &p : pend) pure_sum = pure_sum && p.nmin == 0 && p.nmax == 0;
   const double *parts = nullptr;
@@ -498,10 +526,14 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
     return PO_ERR_ARG;
   }
   const bool queued = c->batch_depth > 0 || !c->batch_pend.empty();
-  if (queued && c->batch_cursor + nslots > kMaxRed) PO_TRY(batch_flush(c));
+  if (queued && c->batch_cursor + nslots > kMaxRed) {
+    PO_TRY(batch_flush(c));
+    // (the partials of THIS reduction are still waiting in their region: the next one must not land on them)
+    if (c->d_partials >= c->partials_base)
+      c->partials_cursor = (size_t)(c->d_partials - c->partials_base) + c->partials_last;
+  }
   if (c->batch_depth > 0 || !c->batch_pend.empty()) {
-    PO_TRY(launch_reduce_final(c, nblocks, nslots, nsum, nmin, c->batch_cursor));
-    c->batch_pend.push_back(Ctx::PendingRed{c->batch_cursor, nsum, nmin, nmax, host_out});
+    c->batch_pend.push_back(Ctx::PendingRed{c->batch_cursor, nsum, nmin, nmax, host_out, c->d_partials, nblocks});
     c->batch_cursor += nslots;
     if (now || c->batch_depth == 0) return batch_flush(c);
     return PO_OK;

@@ -55,8 +55,15 @@ struct Ctx {
   po_allgather_fn cb_allgather = nullptr;
   void *cb_user = nullptr;
   // reduction plumbing
-  double *d_partials = nullptr;  // [slot][block] first-stage partials
-  size_t partials_cap = 0;       // doubles
+  // First-stage partials, [slot][block].  `d_partials` is the region of the launch being issued: the arena itself
+  // outside a batch; inside one (round 4) every reduction gets its OWN region of the arena (ensure_partials advances
+  // `partials_cursor`), so that the final stages of all queued reductions run as ONE launch at the flush instead of
+  // one launch per reduction.
+  double *d_partials = nullptr;
+  double *partials_base = nullptr;  // the arena
+  size_t partials_cap = 0;          // doubles
+  size_t partials_cursor = 0;       // doubles handed out to queued reductions
+  size_t partials_last = 0;         // size of the region handed out last
   double *d_red = nullptr;       // [kMaxRed] rank-local reduced values
   double *d_gather = nullptr;    // [size * kMaxRed]
   double *h_red = nullptr;       // pinned [size * kMaxRed]
@@ -75,6 +82,8 @@ struct Ctx {
   struct PendingRed {
     int off, nsum, nmin, nmax;
     double *host_out;
+    const double *part;  // its first-stage partials
+    int nblocks;
   };
   int batch_enabled = 1;  // po_ctx_set_reduction_batching / PAROPT_AMD_NO_BATCH=1: every reduction syncs by itself
   int batch_depth = 0;

@@ -134,6 +134,69 @@ int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int
   return PO_OK;
 }
 
+// The final stages of several queued reductions in ONE launch (BatchScope, round 4): wave `g` of the grid owns global
+// slot g, finds the reduction it belongs to in the by-value table and sums that slot over the reduction's own blocks
+// exactly as reduce_final_kernel does (same lane stride, same butterfly: same bits).
+constexpr int kMaxSeg = 16;
+struct RedSegTable {
+  const double *part[kMaxSeg];
+  int nblocks[kMaxSeg], nslots[kMaxSeg], nsum[kMaxSeg], nmin[kMaxSeg], dst[kMaxSeg];
+  int count, total;
+};
+__global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable T, double *__restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int slot = blockIdx.x * 4 + wave;
+  if (slot >= T.total) return;
+  int k = 0;
+  while (k + 1 < T.count && slot >= T.nslots[k]) {
+    slot -= T.nslots[k];
+    k++;
+  }
+  const int nblocks = T.nblocks[k], nsum = T.nsum[k], nmin = T.nmin[k];
+  const double *p = T.part[k] + (size_t)slot * nblocks;
+  double *o = out + T.dst[k];
+  if (slot < nsum) {
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += p[b];
+    acc = wave_reduce<OP_SUM>(acc);
+    if (lane == 0) o[slot] = acc;
+  } else if (slot < nsum + nmin) {
+    double acc = INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmin(acc, p[b]);
+    acc = wave_reduce<OP_MIN>(acc);
+    if (lane == 0) o[slot] = acc;
+  } else {
+    double acc = -INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmax(acc, p[b]);
+    acc = wave_reduce<OP_MAX>(acc);
+    if (lane == 0) o[slot] = acc;
+  }
+}
+int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count) {
+  double *dst = (c->comm_kind != COMM_RCCL && c->h_red_dev) ? c->h_red_dev : c->d_red;
+  for (int i0 = 0; i0 < count; i0 += kMaxSeg) {
+    RedSegTable T;
+    T.count = count - i0 < kMaxSeg ? count - i0 : kMaxSeg;
+    T.total = 0;
+    for (int k = 0; k < kMaxSeg; k++) {
+      const bool live = k < T.count;
+      const Ctx::PendingRed &p = pend[i0 + (live ? k : 0)];
+      T.part[k] = live ? p.part : nullptr;
+      T.nblocks[k] = live ? p.nblocks : 0;
+      T.nslots[k] = live ? p.nsum + p.nmin + p.nmax : 0;
+      T.nsum[k] = live ? p.nsum : 0;
+      T.nmin[k] = live ? p.nmin : 0;
+      T.dst[k] = live ? p.off : 0;
+      T.total += T.nslots[k];
+    }
+    if (T.total <= 0) continue;
+    hipLaunchKernelGGL(reduce_final_multi_kernel, dim3((T.total + 3) / 4), dim3(kBlock), 0, c->stream, T, dst);
+    c->n_launches++;
+    PO_HIP(hipGetLastError());
+  }
+  return PO_OK;
+}
+
 // Persistent grid for an n-element streaming kernel: `bpc` workgroups per CU (tools/tune_mdot.hip:
 // 3-6 resident workgroups per CU stream at 6.2-6.5 TB/s; 8 per CU with ~6 resident leaves a
 // 1.33-wave tail and drops to 5.5 TB/s), fewer when n is small.  The two classes of the iteration were

@@ -94,20 +94,30 @@ __global__ void __launch_bounds__(kBlock)
     const int64_t v0 = m.start + g0 * (int64_t)period;
     const int nvv = (ng - 1) * period + m.nw;
     const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
-    const double d0 = in0 ? (d ? d[v0 + tid] : 1.0) : 0.0;
-    const double d1 = in1 ? (d ? d[v0 + tid + kBlock] : 1.0) : 0.0;
-    for (int jb = 0; jb < nv; jb += JB) {
-      double a0[JB], a1[JB];
+    // (loads are unconditional on clamped indices: every lane's requests of a batch are in flight together)
+    const int64_t i0 = v0 + (in0 ? tid : 0), i1 = v0 + (in1 ? tid + kBlock : 0);
+    const double d0 = d ? d[i0] : 1.0, d1 = d ? d[i1] : 1.0;
+    double a0[JB], a1[JB];
 #pragma unroll
-      for (int u = 0; u < JB; u++) {
-        const double *pj = P.p[(jb + u < nv) ? jb + u : jb];
-        a0[u] = in0 ? __builtin_nontemporal_load(pj + v0 + tid) : 0.0;
-        a1[u] = in1 ? __builtin_nontemporal_load(pj + v0 + tid + kBlock) : 0.0;
-      }
+    for (int u = 0; u < JB; u++) {
+      const double *pj = P.p[u < nv ? u : 0];
+      a0[u] = __builtin_nontemporal_load(pj + i0);
+      a1[u] = __builtin_nontemporal_load(pj + i1);
+    }
+    for (int jb = 0; jb < nv; jb += JB) {
 #pragma unroll
       for (int u = 0; u < JB; u++) {
         if (in0) sm[u * kGroupTile + s0] = d0 * a0[u];
         if (in1) sm[u * kGroupTile + s1] = d1 * a1[u];
+      }
+      // the next batch of columns of this tile is requested before the row sums of the current one
+      if (jb + JB < nv) {
+#pragma unroll
+        for (int u = 0; u < JB; u++) {
+          const double *pj = P.p[(jb + JB + u < nv) ? jb + JB + u : jb];
+          a0[u] = __builtin_nontemporal_load(pj + i0);
+          a1[u] = __builtin_nontemporal_load(pj + i1);
+        }
       }
       __syncthreads();
       for (int pair = tid; pair < ng * JB; pair += kBlock) {
@@ -128,13 +138,26 @@ __global__ void __launch_bounds__(kBlock)
   const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
   const int tid = threadIdx.x;
   const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // tile geometry + unconditional loads on clamped indices (both requests of a lane in flight together); the next
+  // tile of this workgroup is requested before the row sums of the current one (round 4: the kernel was bound by
+  // one load latency after the other per tile)
+  auto tile_load = [&](int64_t tile, double &a0, double &a1) {
     const int64_t g0 = tile * G;
     const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
     const int64_t v0 = m.start + g0 * (int64_t)period;
     const int nvv = (ng - 1) * period + m.nw;
-    if (tid < nvv) sm[s0] = v[v0 + tid];
-    if (tid + kBlock < nvv) sm[s1] = v[v0 + tid + kBlock];
+    a0 = v[v0 + (tid < nvv ? tid : 0)];
+    a1 = v[v0 + (tid + kBlock < nvv ? tid + kBlock : 0)];
+  };
+  double c0 = 0.0, c1 = 0.0;
+  if ((int64_t)blockIdx.x < ntiles) tile_load(blockIdx.x, c0, c1);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int nvv = (ng - 1) * period + m.nw;
+    if (tid < nvv) sm[s0] = c0;
+    if (tid + kBlock < nvv) sm[s1] = c1;
+    if (tile + gridDim.x < ntiles) tile_load(tile + gridDim.x, c0, c1);
     __syncthreads();
     if (tid < ng) {
       const double sacc = row_sum(sm + tid * rstride, m.nw);
@@ -380,10 +403,10 @@ __global__ void __launch_bounds__(kBlock)
     if (vend > n) vend = n;
     const int nvv = (int)(vend - v0);
     const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
-    const double d0 = in0 ? d[v0 + tid] : 0.0, d1 = in1 ? d[v0 + tid + kBlock] : 0.0;
-    const double b0 = in0 ? bx[v0 + tid] : 0.0, b1 = in1 ? bx[v0 + tid + kBlock] : 0.0;
-    sm[tid] = d0 * b0;
-    sm[tid + kBlock] = d1 * b1;
+    const int64_t i0 = v0 + (in0 ? tid : 0), i1 = v0 + (in1 ? tid + kBlock : 0);  // clamped: all four in flight
+    const double d0 = d[i0], d1 = d[i1], b0 = bx[i0], b1 = bx[i1];
+    sm[tid] = in0 ? d0 * b0 : 0.0;
+    sm[tid + kBlock] = in1 ? d1 * b1 : 0.0;
     __syncthreads();
     if (tid < ng) {
       const double u = alpha * row_sum(sm + tid * period, m.nw);
@@ -434,7 +457,15 @@ __global__ void __launch_bounds__(kBlock)
                         double *__restrict__ out, double *__restrict__ acc) {
   PO_W_LOOP(i, w) {
     double s = 0.0;
-    for (int j = 0; j < nv; j++) s = fma(a.a[j], U.p[j][i], s);
+    int j = 0;
+    for (; j + 4 <= nv; j += 4) {  // the loads of four columns together, the sum in column order
+      const double u0 = U.p[j][i], u1 = U.p[j + 1][i], u2 = U.p[j + 2][i], u3 = U.p[j + 3][i];
+      s = fma(a.a[j], u0, s);
+      s = fma(a.a[j + 1], u1, s);
+      s = fma(a.a[j + 2], u2, s);
+      s = fma(a.a[j + 3], u3, s);
+    }
+    for (; j < nv; j++) s = fma(a.a[j], U.p[j][i], s);
     const double o = -1.0 * cw[i] * s;
     out[i] = o;
     if (acc) acc[i] = fma(1.0, o, acc[i]);

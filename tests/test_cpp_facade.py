@@ -246,6 +246,66 @@ def test_cpp_optimizer_trust_region(tmp_path):
     np.testing.assert_allclose([out["z0"], out["z1"]], g["final/z"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["objects", "optimizer"])
+def test_cpp_eigenvalue_example_reproduces_reference_rows(tmp_path, driver):
+    """BASELINE config 5 from the user's side in C++: examples/eigenvalue_amd.cpp assembles ParOptLBFGS,
+    ParOptCompactEigenApprox, ParOptEigenQuasiNewton, ParOptEigenSubproblem (+ setEigenModelUpdate with a callback
+    that fills the directions through getArray) and runs ParOptTrustRegion::optimize(ip) -- or ParOptOptimizer with
+    setTrustRegionSubproblem -- the way the reference's examples/eigenvalue/eigenvalue_opt.py:298-308 does; the
+    table it prints is the compiled reference's (golden tr_eig_quadratic_n200_c2_N4), row for row."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tr_helpers import compare_tr
+    from tr_helpers import parse_tr_table as parse_rows
+
+    exe = build(tmp_path, "eigenvalue_amd")
+    g, case = load_golden("tr_eig_quadratic_n200_c2_N4")
+    a = case["args"]
+    cmd = [exe, "n=%d" % a["n"], "c=%d" % a["c"], "N=%d" % a["eig_N"], "index=%d" % a["eig_index"],
+           "curv=%g" % a["eig_curv"], "driver=" + driver, "opt.qn_subspace_size=%d" % a["opt.qn_subspace_size"],
+           "opt.tr_max_iterations=%d" % a["tr.tr_max_iterations"]]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    table = parse_rows(res.stdout)
+    rows = [table[k] for k in sorted(table)]
+    n = compare_tr(g, rows, [], None, 60, check_snaps=False)
+    assert n >= 20 and len(rows) == int(g["final/iter_count"][0])
+    last = [ln for ln in res.stdout.splitlines() if ln.startswith("final:")][0].split()
+    assert abs(float(last[2]) - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+    np.testing.assert_allclose(float(last[4]), g["final/xnorm"][0], rtol=1e-6)
+
+
+def test_eigenvalue_example_compiles_with_the_reference_header_names(tmp_path):
+    """The class set of src/ParOptTrustRegion.h / src/ParOptCompactEigenvalueApprox.h is there under the reference's
+    header names (include/paropt_compat, MPI_Comm communicators): a translation unit that includes only those headers
+    and touches every class of VERDICT r3 missing #1 compiles."""
+    src = tmp_path / "uses_tr_classes.cpp"
+    src.write_text(
+        '#include "ParOptCompactEigenvalueApprox.h"\n#include "ParOptTrustRegion.h"\n#include "ParOptOptimizer.h"\n'
+        "static void upd(void *, ParOptVec *, ParOptCompactEigenApprox *a) { ParOptScalar *c0; a->getApproximation(&c0, "
+        "NULL, NULL, NULL, NULL, NULL); }\n"
+        "void assemble(ParOptProblem *p, ParOptOptions *o) {\n"
+        "  ParOptLBFGS *qn = new ParOptLBFGS(p, 10);\n"
+        "  ParOptCompactEigenApprox *ap = new ParOptCompactEigenApprox(p, 4);\n"
+        "  ParOptEigenQuasiNewton *eq = new ParOptEigenQuasiNewton(qn, ap, 0);\n"
+        "  ParOptEigenSubproblem *es = new ParOptEigenSubproblem(p, eq);\n"
+        "  es->setEigenModelUpdate(NULL, upd);\n"
+        "  ParOptTrustRegionSubproblem *sub = es;\n"
+        "  ParOptQuadraticSubproblem *qs = new ParOptQuadraticSubproblem(p, qn);\n"
+        "  ParOptInteriorPoint *ip = new ParOptInteriorPoint(sub, o);\n"
+        "  ParOptTrustRegion *tr = new ParOptTrustRegion(sub, o);\n"
+        "  tr->setPenaltyGamma(10.0); tr->initialize(); tr->optimize(ip);\n"
+        "  ParOptVec *x; tr->getOptimizedPoint(&x);\n"
+        "  ParOptOptimizer *opt = new ParOptOptimizer(p, o); opt->setTrustRegionSubproblem(qs); opt->optimize();\n"
+        "  ip->checkGradients(1e-6); ip->setBFGSUpdateType(PAROPT_DAMPED_UPDATE); ip->setUseDiagHessian(0);\n"
+        "  ip->checkMeritFuncGradient(NULL, 1e-6);\n"
+        "}\n")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-c", "-I" + os.path.join(ROOT, "include", "paropt_compat"),
+                           "-I/opt/conda/include", str(src), "-o", str(tmp_path / "uses_tr_classes.o")])
+
+
 def test_sparse_facade_compiles(tmp_path):
     import torch
 
