@@ -94,32 +94,54 @@ def reference_traffic_bytes(n, c, k):
 
 
 def run_reference(drv, mpiexec, ranks, n, ncon, iters, qn, qn_size, problem, nwcon, nw, timeout):
+    """One optimize() of the unmodified reference; returns (niter, seconds of optimize(), seconds of every major
+    iteration, wall seconds incl. launch, error text)."""
     env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1",
                PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
     cmd = [mpiexec, "-n", str(ranks), drv, "bench", "problem=%s" % problem, "n=%d" % n, "c=%d" % ncon,
            "opt.qn_type=%s" % qn, "opt.qn_subspace_size=%d" % qn_size, "opt.abs_res_tol=1e-30",
-           "opt.start_affine_multiplier_min=0.01", "opt.max_major_iters=%d" % iters,
-           "opt.write_output_frequency=0"]
+           "opt.start_affine_multiplier_min=0.01", "opt.max_major_iters=%d" % iters]
     if nwcon > 0:
         cmd += ["nwcon=%d" % (nwcon // ranks), "nw=%d" % nw, "nwstart=0", "nwskip=0"]
     t0 = time.time()
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd="/tmp")
     wall = time.time() - t0
+    niter, secs, per_iter = 0, 0.0, []
     for ln in out.stdout.splitlines():
         if ln.startswith("{"):
             r = json.loads(ln)
-            return r["niter"], r["seconds"], wall, None
-    return 0, 0.0, wall, out.stderr[-400:]
+            if "niter" in r:
+                niter, secs = r["niter"], r["seconds"]
+            if "iteration_seconds" in r:
+                per_iter = r["iteration_seconds"]
+    return niter, secs, per_iter, wall, (None if niter > 0 else out.stderr[-400:])
+
+
+def run_reference_mdot(drv, mpiexec, ranks, n, nvecs, reps, timeout):
+    """ParOptBasicVec::mdot of the unmodified reference alone (src/ParOptVec.cpp:152-170): seconds per call."""
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1",
+               PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
+    cmd = [mpiexec, "-n", str(ranks), drv, "mdot", "n=%d" % n, "nvecs=%d" % nvecs, "reps=%d" % reps]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd="/tmp")
+    for ln in out.stdout.splitlines():
+        if ln.startswith("{"):
+            return json.loads(ln)["seconds"]
+    return None
 
 
 def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, problem="convex", budget_s=60.0):
     """The unmodified reference (oracle/_ref/ref_driver: the reference's C++ + MKL under MPICH) timed on this box's
-    host cores on a BOUNDED sample of the workload: a small probe first (n/25), then the largest n <= workload n / 4
-    whose predicted time fits the budget; every pass of the reference is O(n) and memory-bound at these sizes, so
-    the rate is scaled linearly to the workload's n (said in `sample`).  Falls back to the numpy restatement."""
+    host cores to the protocol of BASELINE.md section 4: K = qn_size + 8 major iterations from a cold quasi-Newton
+    memory (abs_res_tol = 1e-30), optimize() only; WHOLE-RUN rate and STEADY-STATE rate (the iterations that run with
+    full memory, from the driver's per-iteration stamps); best of up to three runs at one size (the hosts are
+    shared); plus ParOptVec::mdot alone at nvecs 8, 32, 40.  The sample is bounded: a probe at n/25 sizes the largest
+    n <= workload n / 4 whose runs fit the budget; every pass of the reference is O(n) and memory-bound at these
+    sizes, so rates are scaled linearly to the workload's n (said in `sample`).  Falls back to the numpy restatement."""
     drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     mpiexec = "/opt/conda/bin/mpiexec"
     cpus = host_cpu_budget()
+    K = max(iters, qn_size + 8)
+    kfull = qn_size + 1  # iterations k >= kfull run with full memory (k pairs are held at iteration k)
     if os.path.exists(drv) and os.path.exists(mpiexec):
         ranks = max(1, min(64, cpus["usable"]))
         if nwcon > 0:
@@ -128,55 +150,89 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
             while ranks > 1 and (n % ranks or (n // ranks) % nw or nwcon % ranks):
                 ranks -= 1
         try:
-            # untimed tiny run first: pages in the driver, MKL and MPICH on a fresh box (the first launch was seen to
-            # take seconds longer than the second)
+            # untimed tiny run first: pages in the driver, MKL and MPICH on a fresh box
             run_reference(drv, mpiexec, ranks, 20_000 * ranks, ncon, 2, qn, qn_size, problem, 0, nw, 300)
             t_start = time.time()
-            samples = []
-            n_probe = max(200_000, n // 25) if nwcon == 0 else n
-            niter, secs, wall, err = run_reference(drv, mpiexec, ranks, n_probe, ncon, iters, qn, qn_size, problem,
-                                                   nwcon * n_probe // n if nwcon else 0, nw, 600)
-            if niter <= 0:
-                log("cpu_baseline: reference produced no result: %s" % (err,))
-                raise RuntimeError("no result")
-            samples.append((n_probe, niter, secs, wall))
-            # scale up while the prediction fits what is left of the budget (launch overhead excluded)
-            n_big = n // 4 if (n >= 20_000_000 and nwcon == 0) else n
-            if n_big > n_probe:
-                per_elem = secs / n_probe
-                left = budget_s - (time.time() - t_start)
-                n_fit = int(min(n_big, 0.8 * left / per_elem)) if per_elem > 0 else n_big
-                if n_fit >= 2 * n_probe:
-                    niter2, secs2, wall2, err2 = run_reference(drv, mpiexec, ranks, n_fit, ncon, iters, qn, qn_size,
-                                                               problem, 0, nw, 900)
-                    if niter2 > 0:
-                        samples.append((n_fit, niter2, secs2, wall2))
-            n_s, it_s, sec_s, wall_s = samples[-1]
-            rate_at_sample = it_s / sec_s
-            kw = [min(i, qn_size) * (2 if qn == "bfgs" else 1) for i in range(it_s)]
-            traffic = sum(reference_traffic_bytes(n_s, ncon, k) for k in kw)
-            res = {"value": rate_at_sample * n_s / float(n), "unit": "IP iterations/s", "cores": ranks,
-                   "kind": "reference", "steady_state": False,
-                   "sample_n": n_s, "sample_iterations": it_s, "sample_seconds": sec_s,
-                   "seconds_per_iteration_at_sample_n": sec_s / it_s,
-                   "implied_host_GBps": traffic / sec_s * 1e-9,
-                   "host": cpus, "wall_s_incl_launch": time.time() - t_start,
-                   "probes": [{"n": a, "iterations": b, "seconds": c, "wall_s": d} for a, b, c, d in samples],
+
+            def steady(per_iter):
+                tail = per_iter[kfull:]
+                return (len(tail) / sum(tail)) if len(tail) >= 4 and sum(tail) > 0 else None
+
+            runs = []
+            n_probe = max(200_000, n // 25) if nwcon == 0 else max(nw * ranks * 1000, n // 10)
+            if nwcon > 0:
+                n_probe -= n_probe % (nw * ranks)
+            wfrac = (nwcon / float(n)) if nwcon else 0.0
+
+            def one(n_s):
+                niter, secs, per_iter, wall, err = run_reference(
+                    drv, mpiexec, ranks, n_s, ncon, K, qn, qn_size, problem,
+                    int(round(wfrac * n_s)) if nwcon else 0, nw, 900)
+                if niter <= 0:
+                    log("cpu_baseline: reference produced no result: %s" % (err,))
+                    raise RuntimeError("no result")
+                runs.append({"n": n_s, "iterations": niter, "seconds": secs, "wall_s": wall,
+                             "whole_run_it_per_s": niter / secs, "steady_state_it_per_s": steady(per_iter),
+                             "iteration_seconds": [round(v, 4) for v in per_iter]})
+                return secs
+
+            secs_probe = one(n_probe)
+            # the mdot leg gets a sixth of the budget; the rest goes to up to three runs at the largest size that fits
+            per_elem = secs_probe / n_probe
+            n_big = n // 4 if n >= 20_000_000 else n
+            left = 0.8 * budget_s - (time.time() - t_start)
+            n_fit, reps = n_probe, 0
+            for want in (3, 2, 1):
+                cand = int(min(n_big, left / (want * per_elem * 1.15))) if per_elem > 0 else n_big
+                if nwcon > 0:
+                    cand -= cand % (nw * ranks)
+                if cand >= 2 * n_probe:
+                    n_fit, reps = cand, want
+                    break
+            for _ in range(reps):
+                one(n_fit)
+            best_n = runs[-1]["n"]
+            same = [r for r in runs if r["n"] == best_n]
+            best = max(same, key=lambda r: r["whole_run_it_per_s"])
+            best_ss = max((r["steady_state_it_per_s"] for r in same if r["steady_state_it_per_s"]), default=None)
+            scale = best_n / float(n)
+            kw = [min(i, qn_size) * (2 if qn == "bfgs" else 1) for i in range(best["iterations"])]
+            traffic = sum(reference_traffic_bytes(best_n, ncon, k) for k in kw)
+            # ParOptVec::mdot alone (the headline kernel's CPU counterpart) at the workload's n when it fits
+            mdot = {}
+            n_md = n
+            t_md = time.time()
+            for nv in (8, 32, 40):
+                if time.time() - t_start > budget_s + 20.0:
+                    break
+                try:
+                    sec = run_reference_mdot(drv, mpiexec, ranks, n_md, nv, 3, 300)
+                except Exception:  # pragma: no cover
+                    sec = None
+                if sec:
+                    mdot["nvecs_%d" % nv] = {"ms": 1e3 * sec, "n": n_md,
+                                             "algorithmic_GBps": 8.0 * (nv + 1) * n_md / sec * 1e-9}
+            res = {"value": (best_ss if best_ss else best["whole_run_it_per_s"]) * scale,
+                   "unit": "IP iterations/s", "cores": ranks, "kind": "reference",
+                   "steady_state": best_ss is not None,
+                   "whole_run_it_per_s": best["whole_run_it_per_s"] * scale,
+                   "steady_state_it_per_s": (best_ss * scale) if best_ss else None,
+                   "iterations_per_run": best["iterations"], "full_memory_iterations": max(0, best["iterations"] - kfull),
+                   "runs_at_sample_n": len(same), "sample_n": best_n,
+                   "seconds_per_iteration_at_sample_n": best["seconds"] / best["iterations"],
+                   "implied_host_GBps": traffic / best["seconds"] * 1e-9,
+                   "mdot_ms": mdot, "mdot_seconds_spent": time.time() - t_md,
+                   "host": cpus, "wall_s_incl_launch": time.time() - t_start, "probes": runs,
                    "sample": "unmodified reference (%d MPICH ranks x sequential MKL; ranks = cores this process may use: "
-                             "affinity %d, cgroup quota %s, os.cpu_count %d), same problem at n=%d, first %d iterations "
-                             "(initialisation included, quasi-Newton memory ramping 0->%d: not the full-memory iterations the "
-                             "GPU line times; differences of longer runs were too noisy on the shared hosts to rescale it), "
-                             "optimize() only; every reference pass is O(n) and memory-bound, "
-                             "the rate is scaled by %d/%d to the workload's n; implied_host_GBps = the reference "
-                             "sequence's traffic model (SURVEY 3.4) / seconds: far below the host's stream bandwidth "
-                             "means oversubscribed or throttled cores" % (
-                                 ranks, cpus["affinity"], cpus["cgroup_quota_cpus"], cpus["os_cpu_count"], n_s, it_s,
-                                 min(it_s, qn_size), n_s, n)}
-            if len(samples) > 1:
-                a, b = samples[0], samples[1]
-                res["probe_consistency"] = (b[2] / b[1] / b[0]) / (a[2] / a[1] / a[0])  # s/iter/elt ratio, ~1
+                             "affinity %d, cgroup quota %s, os.cpu_count %d), same problem at n=%d, K = %d major iterations "
+                             "from a cold quasi-Newton memory (BASELINE.md section 4), optimize() only; `value` = the "
+                             "steady-state rate (iterations %d.. with full memory, per-iteration stamps of the driver), "
+                             "best of %d run(s) at this n; every reference pass is O(n) and memory-bound, rates are "
+                             "scaled by %d/%d to the workload's n; mdot_ms = ParOptBasicVec::mdot alone at n=%d; "
+                             "implied_host_GBps = the reference sequence's traffic model (SURVEY 3.4) / seconds" % (
+                                 ranks, cpus["affinity"], cpus["cgroup_quota_cpus"], cpus["os_cpu_count"], best_n, K,
+                                 kfull, len(same), best_n, n, n_md)}
             if (cpus.get("loadavg_1min") or 0.0) > 0.75 * ranks:
-                # seen on the pool: the same code and ranks gave 0.12-0.29 it/s with implied_host_GBps 160-390
                 res["note"] = ("the host's 1-minute load average (%.1f) was already at the level of the %d granted cores "
                                "before the ranks started: other jobs share the cores' memory system, compare "
                                "implied_host_GBps between runs" % (cpus["loadavg_1min"], ranks))
@@ -221,7 +277,9 @@ def parse_args(argv=None):
                          "`boundary`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take")
-    ap.add_argument("--cpu-iters", type=int, default=6)
+    ap.add_argument("--cpu-iters", type=int, default=0,
+                    help="major iterations of a CPU baseline run (default and minimum: qn_size + 8, so that at least "
+                         "six run with full quasi-Newton memory)")
     ap.add_argument("--skip-extension-variant", action="store_true",
                     help="do not also measure the linear-constraint declaration (API extension) beside the headline")
     ap.add_argument("--allow-fallback", action="store_true",

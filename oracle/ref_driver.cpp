@@ -392,6 +392,9 @@ class SepProblem : public ParOptProblem {
   std::vector<double> beta;
   DumpHook *hook;
   struct TrHook *tr_hook;
+  // bench mode: wall-clock stamp at the top of every major iteration (write_output_frequency = 1), so that the
+  // steady-state iterations (quasi-Newton memory full) can be told from the ramp-up ones
+  std::vector<double> *stamps = NULL;
 };
 
 // ---------------------------------------------------------------------------
@@ -562,6 +565,7 @@ struct DumpHook {
 };
 
 void SepProblem::writeOutput(int iter, ParOptVec *x) {
+  if (stamps) stamps->push_back(MPI_Wtime());
   if (tr_hook && tr_hook->rec) {
     RecFile &R = *tr_hook->rec;
     ParOptTrustRegion *tr = tr_hook->tr;
@@ -983,10 +987,16 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
     R.i32s("n", (int)n);
     R.i32s("c", c);
   }
+  std::vector<double> stamps;
+  if (bench) {
+    opt->setOption("write_output_frequency", 1);
+    prob->stamps = &stamps;
+  }
   double t0 = MPI_Wtime();
   std::string ckpt = gets(A, "checkpoint", "");
   int rc = ip->optimize(ckpt.size() ? ckpt.c_str() : NULL);
   double t1 = MPI_Wtime();
+  stamps.push_back(t1);
   int niter, neval, ngeval;
   ip->getIterationCounters(&niter, &neval, &ngeval);
   if (!bench) {
@@ -1011,6 +1021,11 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
         "\"neval\":%d,\"ngeval\":%d,\"seconds\":%.6f,\"it_per_s\":%.6f,\"fobj\":%.17g}\n",
         pname.c_str(), (long)n, c, size, niter, neval, ngeval, t1 - t0,
         niter / (t1 - t0 > 0 ? t1 - t0 : 1.0), ip->fobj);
+    if (bench) {  // seconds of every major iteration (stamp k = top of iteration k; the last one = optimize() returned)
+      printf("{\"iteration_seconds\":[");
+      for (size_t k = 0; k + 1 < stamps.size(); k++) printf("%s%.6f", k ? "," : "", stamps[k + 1] - stamps[k]);
+      printf("],\"init_seconds\":%.6f}\n", stamps.empty() ? 0.0 : stamps[0] - t0);
+    }
   }
   ip->decref();
   return rc;

@@ -1118,9 +1118,9 @@ class TrustRegionSubproblem:
         fk, ck, m = C.c_double(), L.c_double_p(), C.c_int()
         check(lib.po_trsub_get_linear_model(self._h, C.byref(xk), C.byref(fk), C.byref(gk), C.byref(ck), C.byref(Ak),
                                             C.byref(lb), C.byref(ub), C.byref(m)))
-        wrap = lambda h: PVec(self.ctx, handle=L.po_vec(h), owned=False)  # noqa: E731
+        wrap = lambda h: PVec(self.ctx, handle=h, owned=False)  # noqa: E731
         return (wrap(xk), fk.value, wrap(gk), np.array([ck[i] for i in range(m.value)]),
-                [wrap(Ak[i]) for i in range(m.value)], wrap(lb), wrap(ub))
+                [wrap(L.po_vec(Ak[i])) for i in range(m.value)], wrap(lb), wrap(ub))
 
 
 class QuadraticSubproblem(TrustRegionSubproblem):

@@ -328,7 +328,8 @@ int k_solve2(Ctx *c, const Bounds &b, const double *t, const double *dinv, const
 int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
-                  double *tout, double *va, int nca, double *out, double *traw = nullptr, int store_step = 1,
+                  double *tout, double *va, int nca, double *out, double *traw = nullptr,
+                  int store_step = 1,  // 0: nothing of the step, 1: px, pzl, pzu (and va), 2: px only
                   int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
                   const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0,  // P[j] - b0v vs[j], j < nvirt
                   double dinv_diag = 0.0);  // t == nullptr: Dinv (this diagonal) and t re-formed from the bound data and rx

@@ -62,6 +62,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   recompute_first_step = !getenv("PAROPT_AMD_NO_RECOMPUTE");
   fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
   fast_yqn_w = !getenv("PAROPT_AMD_NO_FAST_YQN_W");
+  w_lean = !getenv("PAROPT_AMD_NO_W_LEAN");
   recompute_rhs = recompute_first_step && !getenv("PAROPT_AMD_NO_RECOMPUTE_RHS");
   // Off by default: leaving the L-SR1 columns unformed saves the Gram pass 0.6 ms (its ten output streams) but costs
   // the two solve passes ten more input streams each, +1.2 ms at n = 50 M; kept as a switch.
@@ -772,6 +773,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   merit_cache_valid = false;  // the step is about to change
   px_amax_valid = false;
   fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = false;
   pz_stored = true;
   // Fused refinement residual: the coefficients of addKKTResStep (:1475-1483) are known before
   // the axpy pass starts (A-part = p.z = alpha_A; Z-part = d0 M^-1 d0 Z^T px with Z^T px = ptpx),
@@ -1096,6 +1098,7 @@ int InteriorPoint::checkMeritFuncGradient(Vec *xpt, double dh, double out[2]) { 
   ptpx_valid = false;
   merit_cache_valid = false;
   fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = false;
   px_amax_valid = false;
   double m0 = 0.0, dm0 = 0.0;
   PO_TRY(evalMeritInitDeriv(1.0, &m0, &dm0));
@@ -1129,6 +1132,7 @@ int InteriorPoint::checkMeritFuncGradient(Vec *xpt, double dh, double out[2]) { 
     fprintf(stdout, "Merit function test\n");
     fprintf(stdout, "dm FD: %15.8e  Actual: %15.8e  Err: %8.2e  Rel err: %8.2e\n", fd, dm0, fabs(fd - dm0),
             fabs((fd - dm0) / fd));
+    fflush(stdout);
   }
   if (out) {
     out[0] = fd;
@@ -1198,7 +1202,10 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
     }
   }
   double out[9], wprod = 0.0;
-  if (!has_w && fused_merit_valid && iterate_logs_valid) {
+  if (fused_merit_valid && iterate_logs_valid && (!has_w || w_comp_valid)) {
+    // (sparse constraints: the slacks' share of the polynomial came out of the step kernel, S00 = the complementarity
+    // sum of the iterate's sparse slacks from its residual pass)
+    if (has_w) wprod = w_sums[0] + ax * w_comp_poly[0] + az * w_comp_poly[1] + ax * az * w_comp_poly[2];
     // everything was taken by the refinement pass: the complementarity at the scaled step is
     // S00 + ax S10 + az S01 + ax az S11 with S00 / the bound count from the residual pass of this iterate
     out[0] = comp_prod + ax * fused_merit[0] + az * fused_merit[1] + ax * az * fused_merit[2];
@@ -1331,7 +1338,15 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
       Pq = panel(qn && !seq_lin, &k2);
       PO_TRY(k_mdot(ctx, px->d, Pq.data(), mq, n, dots.data()));
     }
-    if (has_w) {  // :3735-3765, 3489-3503
+    if (has_w && w_merit_cache_valid) {
+      // taken at sx = 1 in the refinement batch (solveKKTW); every sum that depends on the step is linear in sx > 0
+      for (int i = 0; i < 10; i++) wm[i] = w_merit_cache[i];
+      wm[2] *= sx;
+      wm[3] *= sx;
+      wm[6] *= sx;
+      wm[7] *= sx;
+      wm[9] *= sx;
+    } else if (has_w) {  // :3735-3765, 3489-3503
       const double *cw = nullptr;
       PO_TRY(sparseConAtIterate(&cw));
       PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
@@ -1572,7 +1587,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // formed here, from the final step, in one pass over the c constraint gradients: two panel passes, two sparse
   // transposes and the separate multiplier update disappear.  (Not with the linear-constraint recurrence, whose
   // `acz` follows the dense part of this vector alone.)
-  const bool fast_w = has_w && do_qn && analytic_panel_dots && fast_yqn_w && !prob->linear_constraints && pz_stored;
+  const bool fast_w = has_w && do_qn && analytic_panel_dots && fast_yqn_w && !prob->linear_constraints;
   const bool fast_yqn = do_qn && analytic_panel_dots && ((!has_w && vA_valid) || fast_w);
   if (fast_w) {
     // vA <- sz Aw^T pzw + sum_j step.z[j] A_j   (step.z already carries sz: scaleKKTStep)
@@ -1800,6 +1815,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
   cwx_valid = trial_cw_valid = false;
   residual_cached = false;
   iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = false;
+  px_first_only = false;
   history.clear();
   phase_names.clear();
   phase_seconds.clear();

@@ -286,6 +286,14 @@ class InteriorPoint {
   // P^T t of the first solve, produced by the Gram pass of setUpKKTSystem (see there)
   bool fuse_mult_update = true;
   bool fast_yqn_w = true;  // sparse constraints: y_qn from the residuals (PAROPT_AMD_NO_FAST_YQN_W=1 restores the passes)
+  // sparse constraints, round 4 ("lean" solve passes, PAROPT_AMD_NO_W_LEAN=1 restores the stored forms): the fused
+  // first pass stores px only (px_first_only), the refinement pass re-forms the first bound-multiplier steps from it,
+  // takes the complementarity / merit sums of the final step (fused_merit, as on the dense path) and, in the plain
+  // quasi-Newton iteration, stores px only again; the sparse blocks' share of the complementarity polynomial comes
+  // out of the step kernel (w_comp_poly) and the sparse merit sums ride in the same batch (w_merit_cache, sx = 1)
+  bool w_lean = true, px_first_only = false;
+  double w_step_out[5] = {0, 0, 0, 0, 0}, w_comp_poly[3] = {0, 0, 0}, w_merit_cache[10] = {0};
+  bool w_comp_valid = false, w_merit_cache_valid = false;
   bool s_qn_from_trial = false;  // s_qn holds s_qn_a * px, written by the last trial pass of the line search
   double s_qn_a = 0.0;
   bool recompute_first_step = true, step_deferred = false;  // see solveKKT: the first pass stores no step

@@ -71,6 +71,7 @@ int InteriorPoint::solveKKTAlpha(const double *bx, double alpha, const Dense &b,
   merit_cache_valid = false;  // the step is about to change
   px_amax_valid = false;
   fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = false;
   tdots_valid = false;
   residual_fused = false;
   vA_valid = false;
@@ -144,6 +145,7 @@ int InteriorPoint::solveKKTAlphaW(const double *bx, double alpha, const Dense &b
   merit_cache_valid = false;
   px_amax_valid = false;
   fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = false;
   tdots_valid = false;
   residual_fused = false;
   vA_valid = false;

@@ -189,12 +189,24 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
   merit_cache_valid = false;  // the step is about to change
   px_amax_valid = false;
   fused_merit_valid = false;
+  w_comp_valid = false;
+  w_merit_cache_valid = false;
+  pz_stored = true;
+  bool first_px_only = refine_pass && px_first_only;  // px holds the first step, pzl / pzu were not stored
+  px_first_only = false;
+  if (first_px_only && !(m > 0 && (int)Uw.size() >= m && panel_valid)) {
+    // (not reached with the flags as they are set: the fused first pass implies a valid panel) the stored-step forms
+    // below need the first bound-multiplier steps as vectors
+    PO_TRY(k_form_pz(ctx, bounds(), px->d, beta_mu, n, pzl->d, pzu->d));
+    first_px_only = false;
+  }
   tdots_valid = false;        // (consumed above by a refinement pass; set again below by a fused first pass)
   if (!refine_pass) residual_fused = false;
   // (dx, dzw) = K0^-1 (d1 + P alpha, d2) = K0^-1 (d1, d2) + K0^-1 (P alpha, 0), and the second term comes from
   // the panel the Gram correction already holds: dzw += -S^-1 (U alpha), dx += Dinv (P alpha + Aw^T of that) -
   // no second quasi-definite apply, and P alpha rides in the same pass that forms the bound multipliers
   double mins_x[2], mins_w[2];
+  bool w_done = false;  // the refinement branch below already took the sparse step with its other sums
   // the fraction-to-boundary minima of the design and of the sparse blocks: one collective + sync (opened right
   // before the first of the two launches: no user code runs between them)
   BatchScope minbatch(ctx, false);
@@ -236,9 +248,13 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     c2[m + 1] = 1.0;
     std::vector<double> so(m + 4, 0.0);
     // the raw right-hand side lands in y_qn (free while no corrector is active: y_qn is rebuilt from scratch by
-    // computeStepAndUpdate) -- d1v is one of the columns being read -- and the two exchange buffers afterwards
+    // computeStepAndUpdate) -- d1v is one of the columns being read -- and the two exchange buffers afterwards.
+    // Of the step only px is stored (w_lean): the refinement's sparse rows need Aw px as a vector, the bound-
+    // multiplier steps are re-formed from px by the refinement pass (two output streams less)
+    const int sstep = w_lean ? 2 : 1;
     PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, a1.data(), c2.data(), P1.data(), m + 2, beta_mu, tau,
-                         rx->d, diag, n, px->d, pzl->d, pzu->d, nullptr, nullptr, 0, so.data(), y_qn->d));
+                         rx->d, diag, n, px->d, pzl->d, pzu->d, nullptr, nullptr, 0, so.data(), y_qn->d, sstep));
+    px_first_only = sstep == 2;
     std::swap(d1v->d, y_qn->d);
     PO_TRY(minbatch.end());
     tdots.assign(so.begin(), so.begin() + m);
@@ -256,8 +272,49 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     P1.push_back(d1v->d);
     a1.push_back(1.0);
     minbatch.begin();
-    PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, a1.data(), P1.data(), m + 1, beta_mu, refine_pass ? 1 : 0,
-                    tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl, cu));
+    if (first_px_only) {
+      // Refinement on top of a first step of which only px was stored: solve2r_kernel in its stored right-hand side
+      // form with a ZERO first coefficient set and t1 = px -- it re-forms (pzl, pzu) of the first step from px
+      // (the very expressions the first pass evaluated: same bits), applies the refinement (t2 = tvec, a2) and takes
+      // the complementarity / merit sums of the FINAL step (fused_merit); the final px goes to xt (free during the
+      // solves) and the two buffers are exchanged.  Lean step: (pzl, pzu) are not stored either -- their only
+      // consumer left is the multiplier update of computeStepAndUpdate, which re-forms them (kkt_res_update_kernel)
+      const bool take_merit = fuse_merit && !cl;
+      const bool lean = take_merit && lean_step && lean_step_allowed && iterate_logs_valid && fast_yqn_w &&
+                        !prob->linear_constraints && options.integer("iterative_refinement_steps") == 1;
+      std::vector<double> azero(m + 1, 0.0);
+      PO_TRY(k_solve2r(ctx, bounds(), px->d, tvec->d, Dinv->d, azero.data(), a1.data(), P1.data(), m + 1, beta_mu, tau,
+                       n, xt->d, lean ? nullptr : pzl->d, lean ? nullptr : pzu->d, nullptr, 0, mins_x, nullptr, nullptr,
+                       0.0, 0, nullptr, 0, 0.0, take_merit ? g->d : nullptr, take_merit ? fused_merit : nullptr, 0.0));
+      std::swap(px->d, xt->d);
+      if (lean) {
+        pz_stored = false;
+        step_beta_mu = beta_mu;
+      }
+      if (take_merit) {
+        // the sparse blocks of the final step, their share of the complementarity polynomial and the sparse merit
+        // sums (at sx = 1) in the same batch: scaleKKTStep and evalMeritInitDeriv then launch nothing
+        PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, 1, tau, wp(), nw, w_step_out, 1));
+        const double *cw = nullptr;
+        PO_TRY(sparseConAtIterate(&cw));
+        PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
+        if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
+        PO_TRY(k_w_merit(ctx, wv(), wp(), 1.0, gsw->d, gtw->d, cw, wtmp2->d, nw, w_merit_cache));
+        PO_TRY(minbatch.end());
+        mins_x[0] = fused_merit[7];
+        mins_x[1] = fused_merit[8];
+        mins_w[0] = w_step_out[3];
+        mins_w[1] = w_step_out[4];
+        for (int i = 0; i < 3; i++) w_comp_poly[i] = w_step_out[i];
+        fused_merit_valid = true;
+        w_comp_valid = true;
+        w_merit_cache_valid = true;
+        w_done = true;
+      }
+    } else {
+      PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, a1.data(), P1.data(), m + 1, beta_mu, refine_pass ? 1 : 0,
+                      tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl, cu));
+    }
   } else {
     if (m > 0) PO_TRY(k_panel_axpy(ctx, d1v->d, 0.0, nullptr, 1.0, alpha.data(), P.data(), m, n));
     PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
@@ -266,7 +323,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
                     tau, n, px->d, pzl->d, pzu->d, mins_x, nullptr, rx->d, 0.0, nullptr, nullptr, 0, cl,
                     cu));
   }
-  if (!fuse) {
+  if (!fuse && !w_done) {
     PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, refine_pass ? 1 : 0, tau, wp(), nw, mins_w));
     PO_TRY(minbatch.end());
   }

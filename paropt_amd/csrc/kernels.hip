@@ -1332,6 +1332,11 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
     }
     PO_LAUNCH((solve2r_kernel<1, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
               pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+  } else if (g && merit_out) {
+    PO_LAUNCH((solve2r_kernel<0, 1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
+              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+    (void)out;
+    return reduce_finish(c, grid, 7, 2, 1, merit_out);
   } else {
     PO_LAUNCH((solve2r_kernel<0, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
               pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
@@ -1513,16 +1518,20 @@ __global__ void __launch_bounds__(kBlock, OCC)
           dv = make_double2(dinv_elem(e0, dinv_diag), _has2 ? dinv_elem(e1, dinv_diag) : 0.0);
           tv = make_double2(dv.x * d1_elem(e0, r.x, beta_mu), _has2 ? dv.y * d1_elem(e1, r.y, beta_mu) : 0.0);
         }
-        if (va && store_step) st2(va, q, n, accA);
+        if (va && store_step == 1) st2(va, q, n, accA);
         const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
         Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
         if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
         // store_step == 0: the refinement pass recomputes this first step from t and alpha in registers
         // (solve2r_kernel) -- an HBM write costs about four reads on this part (tools/layout_probe.hip)
+        // store_step == 2: px only -- the bound-multiplier steps are functions of it and of data every later pass
+        // loads anyway (sparse-constraint path, whose refinement residual needs Aw px as a vector)
         if (store_step) {
           st2(px, q, n, make_double2(s0.px, s1.px));
-          st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
-          st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+          if (store_step == 1) {
+            st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+            st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+          }
         }
         // raw d1' and t' = Dinv o d1' (the product res_step_elem would form itself)
         double2 raw;

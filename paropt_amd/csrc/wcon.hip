@@ -732,11 +732,16 @@ int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2) {
 
 // step blocks (:2180-2208), y.zw = dzw given; refine accumulates into p.
 // out mins {max_x over sw, tw ; max_z over zsw, ztw} with fraction tau (computeMaxStep :3017-3061)
+// comp != 0: also {S10, S01, S11} of the step written here -- the complementarity of the sparse slacks at step lengths
+// (ax, az) is sum (sw + ax psw)(zsw + az pzsw) + (tw + ax ptw)(ztw + az pztw) = S00 + ax S10 + az S01 + ax az S11 with
+// S00 = sum sw zsw + tw ztw of the iterate (w_res_kernel's first sum): computeCompStep's sparse part (:2866-2889)
+// without a pass of its own and without knowing the step lengths (as solve2r_kernel does for the bound terms)
 __global__ void __launch_bounds__(kBlock)
     w_step_kernel(WVars v, WVars b, const double *__restrict__ dzw, int refine, double tau, WVars p,
-                  int64_t w, double *__restrict__ partials) {
-  __shared__ double sm[4 * 2];
+                  int64_t w, int comp, double *__restrict__ partials) {
+  __shared__ double sm[4 * 3];
   double mins[2] = {1.0, 1.0};
+  double cs[3] = {0.0, 0.0, 0.0};
   PO_W_LOOP(i, w) {
     const double yzw = dzw[i];
     const double yzsw = yzw - b.sw[i];
@@ -760,16 +765,27 @@ __global__ void __launch_bounds__(kBlock)
     if (q2 < 0.0) mins[0] = fmin(mins[0], -tau * v.tw[i] / q2);
     if (q3 < 0.0) mins[1] = fmin(mins[1], -tau * v.zsw[i] / q3);
     if (q4 < 0.0) mins[1] = fmin(mins[1], -tau * v.ztw[i] / q4);
+    if (comp) {
+      cs[0] += q1 * v.zsw[i] + q2 * v.ztw[i];
+      cs[1] += v.sw[i] * q3 + v.tw[i] * q4;
+      cs[2] += q1 * q3 + q2 * q4;
+    }
   }
-  w_block_reduce<2, 1>(mins, partials, 0, sm);
+  if (comp) {
+    w_block_reduce<3, 0>(cs, partials, 0, sm);
+    w_block_reduce<2, 1>(mins, partials, 3, sm);
+  } else {
+    w_block_reduce<2, 1>(mins, partials, 0, sm);
+  }
 }
+// out = {min_x, min_z}, or with comp {S10, S01, S11, min_x, min_z}
 int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
-             const WVars &p, int64_t w, double out[2]) {
+             const WVars &p, int64_t w, double *out, int comp) {
   count_bytes(c, refine ? 20.0 : 15.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
-  PO_TRY(ensure_partials(c, (size_t)grid * 2));
-  PO_WLAUNCH(w_step_kernel, grid, v, b, dzw, refine, tau, p, w, c->d_partials);
-  return reduce_finish(c, grid, 0, 2, 0, out);
+  PO_TRY(ensure_partials(c, (size_t)grid * 5));
+  PO_WLAUNCH(w_step_kernel, grid, v, b, dzw, refine, tau, p, w, comp, c->d_partials);
+  return reduce_finish(c, grid, comp ? 3 : 0, 2, 0, out);
 }
 
 // addKKTResStep, w blocks (:1498-1527); r.zw already holds r.zw - Aw px.

@@ -51,8 +51,9 @@ int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t
 int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]);
 int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd);
 int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2);
+// out = {min_x, min_z}; comp != 0: {S10, S01, S11, min_x, min_z} (complementarity polynomial of the step, wcon.hip)
 int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
-             const WVars &p, int64_t w, double out[2]);
+             const WVars &p, int64_t w, double *out, int comp = 0);
 int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w);
 int k_w_corrector(Ctx *c, const WVars &p, const WVars &r, int64_t w);
 int k_w_comp_step(Ctx *c, const WVars &v, const WVars &p, double ax, double az, int64_t w, double *out);

@@ -59,18 +59,47 @@ def golden_dir():
 # below are that measurement minus a margin of two iterations ("agrees_through" in the comments, recorded length in
 # brackets; integers = counters, quasi-Newton size, pivots, clamp counts, info tokens).
 GOLDEN_WINDOWS = {
-    "ip_convex_hvec_n300_c3": 22,              # agrees through 24 [53]
-    "ip_convex_hvec_noprecon_n200_c2": 14,     # 16 [80]
-    "ipw_convex_n240_c3_w40_mpc": 16,          # state 18, integers 40 [60]
+    # device "agrees through" (tools/agreement_windows.py) | the REFERENCE agrees with ITSELF through
+    # (oracle/reference_self_agreement.py: 1-4 MPI ranks, four BLAS code paths) | [recorded iterations]
+    "ip_convex_hvec_n300_c3": 22,              # 24 | 24 [53]
+    "ip_convex_hvec_noprecon_n200_c2": 14,     # 16 | 16 [80]
+    "ipw_convex_n240_c3_w40_mpc": 16,          # state 18, integers 40 | 17 [60]
     # L-SR1 (the quasi-Newton type of the metric's configuration)
-    "ip_convex_n300_c5_sr1": 14,               # 16 [25]
-    "ip_convex_sigma_sr1_n300_c3": 18,         # 20 [25]
-    "ip_convex_n2000_c32_sr1": 20,             # the whole record [20]
-    "ip_convex_n2000_c90_sr1": 20,             # the whole record [20] (panel of 100 columns: collapsed launchers)
-    "ip_convex_n100000_c32_sr1_r4": 15,        # state 17, integers the whole record [20]; n = 1e5 on 4 MPI ranks
-    "ipw_convex_n240_c3_w40_sr1": 22,          # 24 [60]
-    "ipcsr_convex_n200_c2_chain5s3_sr1": 34,   # state 36, integers 46 [60]
+    "ip_convex_n300_c5_sr1": 14,               # 16 | 16 [25]
+    "ip_convex_sigma_sr1_n300_c3": 18,         # 20 | 20 [25]
+    "ip_convex_n2000_c32_sr1": 20,             # the whole record | the whole record [20]
+    "ip_convex_n2000_c90_sr1": 20,             # the whole record | the whole record [20] (100-column panel)
+    "ip_convex_n100000_c32_sr1_r4": 15,        # state 17, integers the whole record | 16 [20]; n = 1e5 on 4 MPI ranks
+    "ipw_convex_n240_c3_w40_sr1": 22,          # 24 | 24 [60]
+    "ipcsr_convex_n200_c2_chain5s3_sr1": 34,   # state 36, integers 46 | 33 [60]
 }
+
+
+def reference_self_agreement():
+    """{golden: first iteration at which the REFERENCE differs from ITSELF} -- the unmodified reference run on 1-4 MPI
+    ranks and with four BLAS code paths (oracle/reference_self_agreement.py, measured in the build container,
+    committed as profiles/r04_reference_self_agreement.jsonl).  Past that iteration the golden is one summation
+    order's artefact."""
+    import json
+
+    out = {}
+    path = os.path.join(ROOT, "profiles", "r04_reference_self_agreement.jsonl")
+    with open(path) as f:
+        for ln in f:
+            if ln.strip():
+                d = json.loads(ln)
+                out[d["golden"]] = d["reference_self_agrees_through"]
+    return out
+
+
+# A short window is only legitimate where the reference itself is unstable: every hand-set window must reach to
+# within two iterations of the point where the reference stops agreeing with itself, so that a product regression
+# cannot hide inside a window that was merely measured on the product (VERDICT r3, next #5).
+_SELF = reference_self_agreement()
+for _name, _w in GOLDEN_WINDOWS.items():
+    assert _name in _SELF and _SELF[_name] is not None, "no reference self-agreement record for %s" % _name
+    assert _w >= _SELF[_name] - 2, "window of %s (%d) ends before the reference's own instability (%d)" % (
+        _name, _w, _SELF[_name])
 
 
 # The numpy oracle (oracle/paropt_oracle.py) is compared at a tighter tolerance (1e-7) and, being another
