@@ -639,6 +639,8 @@ def main():
             "iteration_bytes": head_sum["iteration_bytes"],
             "iteration_bytes_user_callbacks": head_sum["iteration_bytes_user_callbacks"],
             "iteration_frac": head_sum["iteration_frac"],
+            "iteration_frac_basis": "rank-local algorithmic bytes (n_local = %d of n = %d) / max-over-ranks step time "
+                                    "/ 8 TB/s: a per-GPU fraction at every N" % (nl, a.n),
             "iteration_frac_excl_user_callbacks": head_sum["iteration_frac_excl_user_callbacks"],
             "iteration_bytes_models": {
                 "survey_8d_fused_model_8n(165+15c+11k)": 8.0 * nl * (165 + 15 * a.ncon + 11 * k_full),

@@ -237,6 +237,9 @@ int k_axpy(Ctx *c, double *y, double alpha, const double *x, int64_t n);
 // y <- a*x + b*y + sum_j alpha[j]*V[j]   (x may be null when a == 0; b == 0 never reads y)
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
                  const double *const *V, int nv, int64_t n);
+// y1 <- a1*x1 + sum_j c1[j]*V[j] and y2 <- a2*x2 + sum_j c2[j]*V[j] in ONE pass over V (nv <= kMaxPanel)
+int k_panel_axpy2(Ctx *c, double *y1, double a1, const double *x1, const double *c1, double *y2, double a2,
+                  const double *x2, const double *c2, const double *const *V, int nv, int64_t n);
 // dst_j <- a*X_j + b*Y_j, j < nv, one launch (Y may be null)
 int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X, double b,
                     const double *const *Y, int nv, int64_t n);
@@ -273,17 +276,20 @@ struct Bounds {  // the per-element data every bound-aware kernel needs
 // rzl = -((x-lb) zl - beta*mu), rzu = -((ub-x) zu - beta*mu).
 // (computeKKTRes :1337-1446 + computeComp :2742-2820 + computeResNorm :1588-1723)
 // yqn != nullptr: the same pass also completes the quasi-Newton gradient difference, yqn += [lo]zl - [up]zu - rx
+// beta_mu2 >= 0: out has 13 entries, the last two are max|rzl|, max|rzu| for that second barrier term
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn = nullptr);
+              int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn = nullptr,
+              double beta_mu2 = -1.0);
 // k_update_mult_yqn + k_kkt_res(..., yqn) in one pass (see kernels.hip): the bound multipliers take their step
 // zl <- max(zl + a pzl, eps) here, y_qn gets both brackets, rx / out are those of the new point
 int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
-                     double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
+                     double beta_mu, int64_t n, double *rx, double *out, double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz,
                      // lean step (pxs != nullptr): pzl / pzu are not read but formed from the design step pxs, the
                      // old point xold and the old multipliers with the barrier term of the step's solve
-                     const double *pxs = nullptr, const double *xold = nullptr, double beta_mu_step = 0.0);
+                     const double *pxs = nullptr, const double *xold = nullptr, double beta_mu_step = 0.0,
+                     double beta_mu2 = -1.0);  // as k_kkt_res
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);

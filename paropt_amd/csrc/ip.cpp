@@ -63,6 +63,7 @@ InteriorPoint::InteriorPoint(Problem *p)
   fuse_mult_update = !getenv("PAROPT_AMD_NO_FUSED_UPDATE");
   fast_yqn_w = !getenv("PAROPT_AMD_NO_FAST_YQN_W");
   w_lean = !getenv("PAROPT_AMD_NO_W_LEAN");
+  spec_mu_on = !getenv("PAROPT_AMD_NO_SPEC_MU");
   recompute_rhs = recompute_first_step && !getenv("PAROPT_AMD_NO_RECOMPUTE_RHS");
   // Off by default: leaving the L-SR1 columns unformed saves the Gram pass 0.6 ms (its ten output streams) but costs
   // the two solve passes ten more input streams each, +1.2 ms at n = 50 M; kept as a switch.
@@ -390,9 +391,25 @@ void InteriorPoint::denseResidual(double mu, Dense &r) const {  // :1403-1409
   }
 }
 
+// the barrier parameter the monotone strategy switches to from the current one (:4693-4707)
+double InteriorPoint::nextMonotoneMu() const {
+  const double abs_res_tol = options.real("abs_res_tol");
+  const double mu_frac = options.real("monotone_barrier_fraction") * barrier_param;
+  const double mu_pow = pow(barrier_param, options.real("monotone_barrier_power"));
+  double new_mu = mu_frac;
+  if (mu_pow < mu_frac) new_mu = mu_pow;
+  if (new_mu < 0.1 * abs_res_tol) new_mu = 0.09999 * abs_res_tol;
+  return new_mu;
+}
+
 int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, const MultUpdate *upd) {
   const double beta_mu = options.real("rel_bound_barrier") * mu;
   double *out = res_out;  // a member: inside a BatchScope the values arrive at the flush (after_reduce below)
+  // speculative maxima for the next barrier parameter (see ip.hpp): only beside the norms of the CURRENT one
+  const bool spec = vectors && spec_enabled && spec_mu_on && !has_w && mu == barrier_param;
+  const double mu2 = spec ? nextMonotoneMu() : 0.0;
+  const double beta_mu2 = spec ? options.real("rel_bound_barrier") * mu2 : -1.0;
+  spec_valid = false;
   // sparse and design blocks of the residual share one collective + sync (the problem's sparse callbacks run in
   // between: built-in problems only)
   BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
@@ -428,28 +445,35 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       A.push_back(tvec->d);
       zc.push_back(1.0);
     }
-    if (upd && yqn_complete) {
+    if (upd) {
       // the bound multipliers take their step in the same pass (see kkt_res_update_kernel); A^T z follows the dense
       // multiplier step by recurrence unless it has just been rebuilt from the new multipliers
       const double az_acz = (acz_mode && upd->acz_follow && !acz_rebuilt) ? upd->az : 0.0;
       // (lean step: px and the old point -- xt after the swap of computeStepAndUpdate -- instead of pzl / pzu)
       PO_TRY(k_kkt_res_update(ctx, bounds(), g->d, A.data(), zc.data(), acz_mode ? 0 : (int)A.size(), beta_mu, n,
-                              rx->d, out, yqn_complete->d, zl->d, pzl->d, zu->d, pzu->d, upd->a, upd->eps, vA->d,
+                              rx->d, out, yqn_complete ? yqn_complete->d : nullptr, zl->d, pzl->d, zu->d, pzu->d,
+                              upd->a, upd->eps, (yqn_complete || az_acz != 0.0) ? vA->d : nullptr,
                               upd->az, acz_mode ? acz->d : nullptr, az_acz, pz_stored ? nullptr : px->d,
-                              pz_stored ? nullptr : xt->d, step_beta_mu));
+                              pz_stored ? nullptr : xt->d, step_beta_mu, beta_mu2));
     } else {
       PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
-                       yqn_complete ? yqn_complete->d : nullptr));
+                       yqn_complete ? yqn_complete->d : nullptr, beta_mu2));
     }
   } else {
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
   }
-  after_reduce(ctx, [this, vectors] {
+  after_reduce(ctx, [this, vectors, spec, mu2] {
     const double *o = res_out;
     if (vectors) {
       l1_rx = o[2];
       l2_rx = o[5];
       max_rx = o[8];
+    }
+    if (spec) {
+      spec_mu = mu2;
+      spec_max[0] = o[11];
+      spec_max[1] = o[12];
+      spec_valid = true;
     }
     comp_prod = o[0];
     comp_count = o[1];
@@ -1602,6 +1626,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   // The bound-multiplier step and the first bracket of y_qn ride in the residual pass of the new point when that
   // pass follows anyway (kkt_res_update_kernel): nothing in between reads zl / zu.
   const bool fuse_upd = fast_yqn && fuse_mult_update;
+  // No quasi-Newton update (a fixed approximation: the trust-region subproblem solves): the multiplier step still
+  // rides in the residual pass of the new point, which is then taken here, right after the gradient, instead of at
+  // the top of the next iteration (round 4: one pass over the bound data and one launch less per inner iteration)
+  const bool fuse_upd_noqn = !do_qn && fuse_mult_update && !has_w && pz_stored;
   if (!pz_stored && !fuse_upd) {
     set_error("internal: lean step without the fused multiplier update");
     return PO_ERR_ARG;
@@ -1611,7 +1639,7 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   if (fast_w) upd.az = alpha;  // vA was built from the scaled step
   upd.eps = eps;
   upd.acz_follow = acz_follow;
-  if (fuse_upd) {
+  if (fuse_upd || fuse_upd_noqn) {
     // (deferred)
   } else if (fast_yqn) {
     PO_TRY(k_update_mult_yqn(ctx, zl->d, pzl->d, zu->d, pzu->d, alpha * sz, eps, use_lower, use_upper,
@@ -1673,7 +1701,12 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   }
   // a problem with linear dense constraints keeps the Jacobian of the first evaluation (Ac == nullptr)
   userBegin();
-  int fail_g = prob->evalObjConGradient(x, g, (prob->linear_constraints && ac_valid) ? nullptr : Ac.data());
+  // (constantJacobianMask: the library's own model problems may declare single columns constant; those are kept)
+  std::vector<Vec *> Acp(Ac);
+  const std::vector<char> *cmask = ac_valid ? prob->constantJacobianMask() : nullptr;
+  for (int i = 0; cmask && i < c && i < (int)cmask->size(); i++)
+    if ((*cmask)[i]) Acp[i] = nullptr;
+  int fail_g = prob->evalObjConGradient(x, g, (prob->linear_constraints && ac_valid) ? nullptr : Acp.data());
   userEnd();
   ngeval++;
   if (fail_g) fprintf(stderr, "ParOpt: Gradient evaluation failed at final line search\n");
@@ -1728,6 +1761,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   } else if (qn && perform_qn_update) {  // :4261-4263
     if (qn->updateMult(x, vars.z.data(), has_w ? wvar[0] : nullptr) != 0) return PO_ERR_USER;
     *update_type = 0;
+  }
+  if (fuse_upd_noqn) {
+    PO_TRY(computeResidual(barrier_param, true, nullptr, &upd));
+    residual_cached = true;
   }
   return PO_OK;
 }
@@ -1817,6 +1854,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
   w_comp_valid = w_merit_cache_valid = false;
   px_first_only = false;
+  spec_enabled = spec_valid = false;
   history.clear();
   phase_names.clear();
   phase_seconds.clear();
@@ -1900,6 +1938,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
     double max_prime = 0.0, max_dual = 0.0, max_infeas = 0.0, res_norm = 0.0;
     int monotone_barrier_converged = 0;
     double comp = 0.0;
+    // (the inexact Newton step reads the 2-norms of the bound residuals, computeKKTGMRESStep: no shortcut there)
+    spec_enabled = barrier_strategy == B_MONOTONE && norm_type == 0 && !has_w && !use_hvec_product;
     if (barrier_strategy == B_MONOTONE) {
       if (!residual_cached) PO_TRY(computeResidual(barrier_param, true));
       residual_cached = false;
@@ -1916,7 +1956,15 @@ int InteriorPoint::optimize(const char *checkpoint) {
         double new_mu = mu_frac;
         if (mu_pow < mu_frac) new_mu = mu_pow;
         if (new_mu < 0.1 * abs_res_tol) new_mu = 0.09999 * abs_res_tol;
-        PO_TRY(computeResidual(new_mu, false));  // rx does not depend on mu
+        if (spec_valid && spec_mu == new_mu && norm_type == 0) {
+          // the residual pass of this iterate took the two maxima for new_mu as well (the complementarity product
+          // and the bound count do not depend on mu): what computeResidual(new_mu, false) would produce
+          max_rzl = spec_max[0];
+          max_rzu = spec_max[1];
+          spec_valid = false;
+        } else {
+          PO_TRY(computeResidual(new_mu, false));  // rx does not depend on mu
+        }
         denseResidual(new_mu, res);
         resNorms(res, &max_prime, &max_dual, &max_infeas, &res_norm);
         rho_penalty_search = options.real("min_rho_penalty_search");

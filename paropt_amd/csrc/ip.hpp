@@ -220,7 +220,13 @@ class InteriorPoint {
   bool panel_plain = false;  // Uw is the unscaled panel image (scalar block form)
   bool panel_valid = false;  // Uw matches the current setUpKKTSystem (consumed by solveKKTW)
   double w_sums[7], w_maxs[5];  // reductions of the last w residual (k_w_res layout)
-  double res_out[11] = {0}, wres_out[12] = {0};  // landing area of the residual reductions (see after_reduce)
+  double res_out[13] = {0}, wres_out[12] = {0};  // landing area of the residual reductions (see after_reduce)
+  // Monotone barrier strategy with the infinity norm (round 4): the residual pass also takes max|rzl|, max|rzu| for the
+  // barrier parameter the strategy would switch to (a function of the current one alone), so that the switch needs
+  // neither the mu-only pass over the bound data nor its host synchronisation (PAROPT_AMD_NO_SPEC_MU=1 restores it)
+  bool spec_mu_on = true, spec_enabled = false, spec_valid = false;
+  double spec_mu = 0.0, spec_max[2] = {0.0, 0.0};
+  double nextMonotoneMu() const;
   WVars wv() const;
   WVars wr() const;
   WVars wp() const;

@@ -455,6 +455,28 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// two linear combinations over ONE pass of the same panel: y1 = a1 x1 + sum_j c1_j V_j, y2 = a2 x2 + sum_j c2_j V_j
+// (the objective gradient gk + B s and the modelled constraint's gradient g0 + H M H^T s of the compact eigenvalue
+// subproblem share the columns H: src/ParOptCompactEigenvalueApprox.cpp:626-643).  Same accumulation order per output
+// as panel_axpy_kernel; a zero coefficient contributes an exact zero.
+__global__ void __launch_bounds__(kBlock)
+    panel_axpy2_kernel(double *__restrict__ y1, double a1, const double *__restrict__ x1, double *__restrict__ y2,
+                       double a2, const double *__restrict__ x2, CoefTable c1, CoefTable c2, PtrTable V, int nv,
+                       int64_t n) {
+  PO_PAIR_LOOP(q, n) {
+    const double2 v1 = ld2(x1, q, n), v2 = ld2(x2, q, n);
+    double2 s1, s2;
+    panel_sum2(V, c1, c2, nv, q, s1, s2);
+    double2 r1 = make_double2(a1 * v1.x, a1 * v1.y), r2 = make_double2(a2 * v2.x, a2 * v2.y);
+    r1.x += s1.x;
+    r1.y += s1.y;
+    r2.x += s2.x;
+    r2.y += s2.y;
+    st2(y1, q, n, r1);
+    st2(y2, q, n, r2);
+  }
+}
+
 static void fill_tables(const double *alpha, const double *const *V, int nv, CoefTable *ct,
                         PtrTable *pt) {
   for (int j = 0; j < kMaxPanel; j++) {
@@ -478,6 +500,22 @@ int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const d
     PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, kBpcPanel), y, aa, x, bb, ct, pt, w, n);
     j0 += w;
   } while (j0 < nv);
+  return PO_OK;
+}
+
+int k_panel_axpy2(Ctx *c, double *y1, double a1, const double *x1, const double *c1, double *y2, double a2,
+                  const double *x2, const double *c2, const double *const *V, int nv, int64_t n) {
+  if (nv > kMaxPanel) {
+    set_error("panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  count_bytes(c, nv + 4, n);
+  if (n <= 0) return PO_OK;
+  PtrTable pt;
+  CoefTable ct1, ct2;
+  fill_tables(c1, V, nv, &ct1, &pt);
+  fill_tables(c2, V, nv, &ct2, &pt);
+  PO_LAUNCH(panel_axpy2_kernel, grid_for(c, n, kBpcPanel), y1, a1, x1, y2, a2, x2, ct1, ct2, pt, nv, n);
   return PO_OK;
 }
 
@@ -835,13 +873,21 @@ __device__ __forceinline__ void res_bound_acc(const BE &e, double beta_mu, doubl
     maxs[imax + 1] = fmax(maxs[imax + 1], r);
   }
 }
+// max |rzl|, |rzu| for a SECOND barrier parameter (the one the monotone strategy would switch to, known before the
+// pass: a function of the current one alone): when the switch happens the pass over the bound data that only
+// re-evaluates these two maxima (res_norms_kernel) and its host synchronisation are not needed.  Same expression as
+// res_bound_acc: the same bits as that pass would produce (a maximum does not depend on the summation order).
+__device__ __forceinline__ void res_bound_max2(const BE &e, double beta_mu2, double *m2) {
+  if (e.L) m2[0] = fmax(m2[0], fabs(-(e.xl * e.zl - beta_mu2)));
+  if (e.U) m2[1] = fmax(m2[1], fabs(-(e.xu * e.zu - beta_mu2)));
+}
 __global__ void __launch_bounds__(kBlock)
     kkt_res_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc,
                    double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ yqn,
-                   double *__restrict__ partials) {
+                   double beta_mu2, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  double maxs[3] = {0.0, 0.0, 0.0};
+  double maxs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     PO_LOAD_BOUNDS(b, q, n);
     const double2 gv = ld2(g, q, n);
@@ -874,26 +920,35 @@ __global__ void __launch_bounds__(kBlock)
     sums[5] += r.x * r.x + r.y * r.y;
     res_bound_acc(e0, beta_mu, sums, maxs, 3, 6, 1);
     res_bound_acc(e1, beta_mu, sums, maxs, 3, 6, 1);
+    if (beta_mu2 >= 0.0) {
+      res_bound_max2(e0, beta_mu2, maxs + 3);
+      res_bound_max2(e1, beta_mu2, maxs + 3);
+    }
   }
   block_reduce_store<8, OP_SUM>(sums, partials, 0, sm);
-  block_reduce_store<3, OP_MAX>(maxs, partials, 8, sm);
+  if (beta_mu2 >= 0.0) {
+    block_reduce_store<5, OP_MAX>(maxs, partials, 8, sm);
+  } else {
+    double m3[3] = {maxs[0], maxs[1], maxs[2]};
+    block_reduce_store<3, OP_MAX>(m3, partials, 8, sm);
+  }
 }
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double out[11], double *yqn) {
+              int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn, double beta_mu2) {
   if (nc > kMaxPanel) {  // wide A^T z: one collapsed column
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
-    return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn);
+    return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, beta_mu2);
   }
   count_bytes(c, 7 + nc + (yqn ? 2 : 0), n);
   const int grid = grid_for(c, n, kBpcPanel);
-  PO_TRY(ensure_partials(c, (size_t)grid * 11));
+  PO_TRY(ensure_partials(c, (size_t)grid * 13));
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
-  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, c->d_partials);
-  return reduce_finish(c, grid, 8, 0, 3, out);
+  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, beta_mu2, c->d_partials);
+  return reduce_finish(c, grid, 8, 0, beta_mu2 >= 0.0 ? 5 : 3, out);
 }
 
 // the mu-dependent part only: sums {comp product, count, -, l1 rzl, l1 rzu, -, l2 rzl, l2 rzu}
@@ -2030,10 +2085,10 @@ __global__ void __launch_bounds__(kBlock)
                           const double *__restrict__ pzl, double *__restrict__ zu, const double *__restrict__ pzu,
                           double a, double eps, const double *__restrict__ va, double az, double *__restrict__ acz,
                           double az_acz, const double *__restrict__ pxs, const double *__restrict__ xold,
-                          double beta_mu_step, double *__restrict__ partials) {
+                          double beta_mu_step, double beta_mu2, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  double maxs[3] = {0.0, 0.0, 0.0};
+  double maxs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
     const double2 _x = ld2(b.x, q, n), _lb = ld2(b.lb, q, n), _ub = ld2(b.ub, q, n);
     // pxs != nullptr ("lean step"): the refinement pass did not store the bound-multiplier steps; they are formed
@@ -2057,7 +2112,9 @@ __global__ void __launch_bounds__(kBlock)
       lean_pl = make_double2(t0.pzl, t1.pzl);
       lean_pu = make_double2(t0.pzu, t1.pzu);
     }
-    const double2 r0 = ld2(rx, q, n), w = ld2(va, q, n), gv = ld2(g, q, n);
+    // (yqn == nullptr: no quasi-Newton update follows -- the multiplier step and the residual of the new point only)
+    const double2 zero2 = make_double2(0.0, 0.0);
+    const double2 r0 = yqn ? ld2(rx, q, n) : zero2, w = va ? ld2(va, q, n) : zero2, gv = ld2(g, q, n);
     // first bracket, as update_mult_yqn_kernel
     double2 y = make_double2(__fma_rn(az, w.x, r0.x), __fma_rn(az, w.y, r0.y));
     double2 aczv = make_double2(0.0, 0.0);
@@ -2111,39 +2168,50 @@ __global__ void __launch_bounds__(kBlock)
     if (!_has2) r.y = 0.0;
     st2(rx, q, n, r);
     const double cl = b.use_lower ? 1.0 : 0.0, cu = b.use_upper ? -1.0 : 0.0;
-    y.x = __dadd_rn(y.x, __fma_rn(-1.0, r.x, __fma_rn(cu, _zu.x, __fma_rn(cl, _zl.x, 0.0))));
-    y.y = __dadd_rn(y.y, __fma_rn(-1.0, r.y, __fma_rn(cu, _zu.y, __fma_rn(cl, _zl.y, 0.0))));
-    st2(yqn, q, n, y);
+    if (yqn) {
+      y.x = __dadd_rn(y.x, __fma_rn(-1.0, r.x, __fma_rn(cu, _zu.x, __fma_rn(cl, _zl.x, 0.0))));
+      y.y = __dadd_rn(y.y, __fma_rn(-1.0, r.y, __fma_rn(cu, _zu.y, __fma_rn(cl, _zl.y, 0.0))));
+      st2(yqn, q, n, y);
+    }
     maxs[0] = fmax(maxs[0], fmax(fabs(r.x), fabs(r.y)));
     sums[2] += fabs(r.x) + fabs(r.y);
     sums[5] += r.x * r.x + r.y * r.y;
     res_bound_acc(e0, beta_mu, sums, maxs, 3, 6, 1);
     res_bound_acc(e1, beta_mu, sums, maxs, 3, 6, 1);
+    if (beta_mu2 >= 0.0) {
+      res_bound_max2(e0, beta_mu2, maxs + 3);
+      res_bound_max2(e1, beta_mu2, maxs + 3);
+    }
   }
   block_reduce_store<8, OP_SUM>(sums, partials, 0, sm);
-  block_reduce_store<3, OP_MAX>(maxs, partials, 8, sm);
+  if (beta_mu2 >= 0.0) {
+    block_reduce_store<5, OP_MAX>(maxs, partials, 8, sm);
+  } else {
+    double m3[3] = {maxs[0], maxs[1], maxs[2]};
+    block_reduce_store<3, OP_MAX>(m3, partials, 8, sm);
+  }
 }
 
 int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
-                     double beta_mu, int64_t n, double *rx, double out[11], double *yqn, double *zl,
+                     double beta_mu, int64_t n, double *rx, double *out, double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz, const double *pxs, const double *xold,
-                     double beta_mu_step) {
+                     double beta_mu_step, double beta_mu2) {
   if (nc > kMaxPanel) {
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
     return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz,
-                            pxs, xold, beta_mu_step);
+                            pxs, xold, beta_mu_step, beta_mu2);
   }
-  count_bytes(c, 14 + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
+  count_bytes(c, (yqn ? 14 : 11) + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
   const int grid = grid_for(c, n, kBpcPanel);
-  PO_TRY(ensure_partials(c, (size_t)grid * 11));
+  PO_TRY(ensure_partials(c, (size_t)grid * 13));
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
   PO_LAUNCH(kkt_res_update_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz,
-            az_acz, pxs, xold, beta_mu_step, c->d_partials);
-  return reduce_finish(c, grid, 8, 0, 3, out);
+            az_acz, pxs, xold, beta_mu_step, beta_mu2, c->d_partials);
+  return reduce_finish(c, grid, 8, 0, beta_mu2 >= 0.0 ? 5 : 3, out);
 }
 
 __global__ void __launch_bounds__(kBlock)

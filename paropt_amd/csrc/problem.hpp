@@ -24,6 +24,10 @@ class Problem {
   // contract (src/ParOptProblem.h:146-158) is unchanged for problems that do not set the flag.
   virtual int evalObjConGradient(Vec *x, Vec *g, Vec **Ac) = 0;
   int linear_constraints = 0;
+  // Per-constraint form of the same declaration for the library's own model problems (round 4): entry i != 0 says that
+  // the gradient of dense constraint i does not depend on x within one optimize(); the solver then passes Ac[i] ==
+  // nullptr after the first evaluation and keeps the column (null: no such knowledge).  Never set for C-ABI problems.
+  virtual const std::vector<char> *constantJacobianMask() { return nullptr; }
   virtual int computeQuasiNewtonUpdateCorrection(Vec *x, const double *z, Vec *s, Vec *y) { return 0; }
   // false: the call above leaves s untouched (lets the solver reuse products it already has with the step)
   virtual bool quasiNewtonCorrectionMayChangeStep() { return false; }

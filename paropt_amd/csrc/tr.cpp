@@ -444,20 +444,13 @@ int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-
   std::vector<double *> dst;
   std::vector<const double *> src;
   for (int i = 0; Ac && i < m; i++) {  // (Ac == nullptr: objective gradient only, asked for by a linearised wrapper)
-    if (i == idx) continue;
+    if (i == idx || !Ac[i]) continue;  // (Ac[i] == nullptr: the solver kept this constant column, constantJacobianMask)
     dst.push_back(Ac[i]->d);
     src.push_back(Ak[i]->d);
   }
   if (!dst.empty() &&
       k_panel_lincomb(ctx, dst.data(), 1.0, src.data(), 0.0, nullptr, (int)dst.size(), nlocal) != PO_OK)
     return 1;
-  if (Ac) {
-    std::vector<double> mh(N, 0.0);
-    for (int i = 0; i < N; i++)
-      for (int j = 0; j < N; j++) mh[i] += e->M[(size_t)i * N + j] * rz[kq + j];
-    std::vector<const double *> hp = e->hPointers();
-    if (k_panel_axpy(ctx, Ac[idx]->d, 1.0, e->g0->d, 0.0, mh.data(), hp.data(), N, nlocal) != PO_OK) return 1;
-  }
   // g = gk + B s
   std::vector<double> cf(k + 1, 0.0);
   for (int i = 0; i < k; i++) cf[1 + i] = rz[i];
@@ -467,6 +460,21 @@ int EigenSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {  // :626-
   std::vector<const double *> P;
   P.push_back(step->d);
   P.insert(P.end(), zp.begin(), zp.end());
+  if (Ac && Ac[idx] && k + 1 <= kMaxPanel) {
+    // ... and the modelled constraint's gradient g0 + H (M H^T s) in the same pass over [step | Z_qn | H]
+    std::vector<double> ch(k + 1, 0.0);
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) ch[1 + kq + i] += e->M[(size_t)i * N + j] * rz[kq + j];
+    return k_panel_axpy2(ctx, g->d, 1.0, gk->d, cf.data(), Ac[idx]->d, 1.0, e->g0->d, ch.data(), P.data(), k + 1,
+                         nlocal) == PO_OK ? 0 : 1;
+  }
+  if (Ac && Ac[idx]) {
+    std::vector<double> mh(N, 0.0);
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < N; j++) mh[i] += e->M[(size_t)i * N + j] * rz[kq + j];
+    std::vector<const double *> hp = e->hPointers();
+    if (k_panel_axpy(ctx, Ac[idx]->d, 1.0, e->g0->d, 0.0, mh.data(), hp.data(), N, nlocal) != PO_OK) return 1;
+  }
   return k_panel_axpy(ctx, g->d, 1.0, gk->d, 0.0, cf.data(), P.data(), k + 1, nlocal) == PO_OK ? 0 : 1;
 }
 

@@ -154,6 +154,13 @@ class EigenSubproblem : public TrustRegionSubproblem {  // ParOptCompactEigenval
   int acceptTrialStep(Vec *step, const double *z, Vec *zw) override;
   int evalObjCon(Vec *step, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  // every constraint model but the eigenvalue one is linear in the step
+  const std::vector<char> *constantJacobianMask() override {
+    const_mask.assign(m, 1);
+    if (approx->index >= 0 && approx->index < m) const_mask[approx->index] = 0;
+    return &const_mask;
+  }
+  std::vector<char> const_mask;
   EigenQuasiNewton *approx;
   EigenModelUpdate update_model;
   void *update_user;
@@ -172,6 +179,9 @@ class InfeasSubproblem : public Problem {  // :468-650
   int evalObjCon(Vec *step, double *fobj, double *cons) override;
   int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
   bool reductionsBatchable() override { return sub->reductionsBatchable(); }
+  const std::vector<char> *constantJacobianMask() override {
+    return constraint == SUBPROBLEM_CONSTRAINT ? sub->constantJacobianMask() : nullptr;
+  }
   std::vector<double> eo_cs, eo_cl;  // landing areas (see TrustRegionSubproblem::eo_dots)
   double eo_fs = 0.0, eo_fl = 0.0;
   int evalSparseCon(Vec *step, Vec *out) override { return sub->evalSparseCon(step, out); }

@@ -109,6 +109,41 @@ def test_bench_boundary_facade_is_value():
     assert abs(r["value"] - r["boundary"]["reference_semantics"]["value"]) < 1e-9 * r["value"]
 
 
+@pytest.mark.gpu
+def test_torchrun_child_at_n1_equals_the_in_process_path():
+    """one rank started the way the driver starts N ranks (python -m torch.distributed.run
+    --nproc-per-node 1 ... bench.py --gpus 1: WORLD_SIZE = 1, RCCL process group of one) measures what the in-process
+    N = 1 path measures -- same counters per iteration, `value` within 2 % -- and the line's `iteration_frac` is built
+    from the rank-local bytes and the max-over-ranks time."""
+    import socket
+
+    args = ["--gpus", "1", "--nglobal", "16000000", "--steps", "10", "--warmup", "12", "--repeats", "3",
+            "--no-cpu-baseline", "--skip-extension-variant", "--boundary", "builtin"]
+    out, lines = _run(args, {}, 900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    direct = json.loads(lines[0])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    child = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert child["n_gpus"] == 1 and child["config"]["launcher"] == "torchrun rank"
+    assert child["config"]["reductions_per_iter"] == direct["config"]["reductions_per_iter"]
+    assert child["config"]["launches_per_iter"] == direct["config"]["launches_per_iter"]
+    assert child["iteration_bytes"] == direct["iteration_bytes"]
+    assert abs(child["value"] / direct["value"] - 1.0) <= 0.02, (child["value"], direct["value"])
+    assert "n_local" in child["iteration_frac_basis"]
+    frac = child["iteration_bytes"] / (child["ms_per_step"] * 1e-3) * 1e-9 / 8000.0
+    assert abs(frac - child["iteration_frac"]) <= 1e-9
+
+
 def test_host_cpu_budget_respects_affinity_cpu():
     """The CPU baseline sizes its MPI job from the cores the process may really use (affinity, cgroup quota)."""
     sys.path.insert(0, ROOT)
