@@ -650,14 +650,12 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
   bool t0_ready = fuse_z && fuse_t;
   if (has_w) {  // Cw = 1/(sw/zsw + tw/ztw + Aw Dinv Aw^T) (:1912-1930)
-    PO_TRY(k_w_cdiag(ctx, wv(), nw, Cw->d));
-    PO_TRY(prob->sparseFactor(x, Dinv, Cw));  // mat->factor (:1930)
+    PO_TRY(prob->sparseFactorFromSlacks(x, Dinv, wv(), Cw));  // Cdiag (:1912-1927) + mat->factor (:1930)
     fuse_tw = rhs_mu && fused_tdots && m > 0 && m + 1 <= kWgramMaxVecs && !corrector_active;
     if (fuse_tw) {
-      PO_TRY(computeResidualW(*rhs_mu));
+      PO_TRY(computeResidualW(*rhs_mu, true, true));  // ... with d2 of the block solve below (wd2)
       if (!raw_d1_w)
         PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, options.real("rel_bound_barrier") * (*rhs_mu), n, d1v->d));
-      PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
       PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
     }
   }
@@ -1373,8 +1371,7 @@ int InteriorPoint::evalMeritInitDeriv(double max_x, double *merit_, double *pmer
     } else if (has_w) {  // :3735-3765, 3489-3503
       const double *cw = nullptr;
       PO_TRY(sparseConAtIterate(&cw));
-      PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
-      if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
+      PO_TRY(prob->setSparseJacobian(1.0, x, px, wtmp2));
       PO_TRY(k_w_merit(ctx, wv(), wp(), sx, gsw->d, gtw->d, cw, wtmp2->d, nw, wm));
     }
     PO_TRY(batch.end());

@@ -232,7 +232,9 @@ class InteriorPoint {
   WVars wp() const;
   int allocateW();
   int applyK0(const double *bx, const double *bw, Vec *yx, Vec *yw);
-  int computeResidualW(double mu, bool norms = true);
+  // d2out: also wd2 = d2 of the block solve that follows (one launch less); wd2_ready tells solveKKTW
+  int computeResidualW(double mu, bool norms = true, bool with_d2 = false);
+  bool wd2_ready = false;
   int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr, bool may_defer = false);
   int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                 bool fuse_residual = false);

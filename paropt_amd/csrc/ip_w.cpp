@@ -74,10 +74,11 @@ int InteriorPoint::sparseConAtIterate(const double **cw) {
   return PO_OK;
 }
 
-int InteriorPoint::computeResidualW(double mu, bool norms) {
+int InteriorPoint::computeResidualW(double mu, bool norms, bool with_d2) {
   const double *cw = nullptr;
   PO_TRY(sparseConAtIterate(&cw));
-  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, norms ? wres_out : nullptr, cw));
+  wd2_ready = false;
+  PO_TRY(k_w_res(ctx, wv(), wr(), gsw->d, gtw->d, mu, nw, norms ? wres_out : nullptr, cw, with_d2 ? wd2->d : nullptr));
   if (!norms) return PO_OK;
   after_reduce(ctx, [this] {
     for (int i = 0; i < 7; i++) w_sums[i] = wres_out[i];
@@ -141,7 +142,8 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     for (int i = 0; i < m; i++) dots[i] = t0dots[i];
   } else {
     if (!refine_pass) PO_TRY(k_d1(ctx, bounds(), rx->d, nullptr, beta_mu, n, d1v->d, cl, cu));
-    PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));
+    if (!wd2_ready) PO_TRY(k_w_d2(ctx, wv(), wr(), nw, wd2->d));  // (else: formed by the pass that wrote the blocks)
+    wd2_ready = false;
     PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
     if (refine_pass && tdots_valid && (int)tdots.size() == m && m > 0 && panel_valid && panel_plain &&
         (int)Uw.size() >= m) {
@@ -297,8 +299,7 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
         PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, 1, tau, wp(), nw, w_step_out, 1));
         const double *cw = nullptr;
         PO_TRY(sparseConAtIterate(&cw));
-        PO_TRY(k_fill(ctx, wtmp2->d, nw, 0.0));
-        if (prob->addSparseJacobian(1.0, x, px, wtmp2) != 0) return PO_ERR_USER;
+        PO_TRY(prob->setSparseJacobian(1.0, x, px, wtmp2));
         PO_TRY(k_w_merit(ctx, wv(), wp(), 1.0, gsw->d, gtw->d, cw, wtmp2->d, nw, w_merit_cache));
         PO_TRY(minbatch.end());
         mins_x[0] = fused_merit[7];
@@ -388,7 +389,8 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
     // sparse rows (:1492-1527); the blocks are rebuilt, their norms (same mu, same iterate) are in place already
     PO_TRY(computeResidualW(mu, false));
     if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;
-    PO_TRY(k_w_res_step(ctx, wv(), wp(), wr(), nw));
+    PO_TRY(k_w_res_step(ctx, wv(), wp(), wr(), nw, wd2->d));  // ... and d2 of the refinement's block solve
+    wd2_ready = true;
     Dense r2;
     r2.resize(c);
     denseResidual(mu, r2);

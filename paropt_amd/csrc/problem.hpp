@@ -54,6 +54,9 @@ class Problem {
   virtual int evalSparseCon(Vec *x, Vec *out);
   virtual int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out);
   virtual int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
+  // out <- alpha Aw(x) px (overwrites): by default a zero fill followed by addSparseJacobian; a problem that can write
+  // every entry in one pass overrides it
+  virtual int setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out);
   // out <- alpha Aw(x)^T pzw (overwrites): by default a zero fill followed by the call above; a problem that can
   // write every entry in one pass overrides it
   virtual int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
@@ -72,6 +75,9 @@ class Problem {
   // (nwblock = 1): cw <- 1/(Cdiag + diag(Aw d Aw^T)).  CSR form: S = Cdiag + Aw d Aw^T is factored on the
   // device and cw is left alone.
   virtual int sparseFactor(Vec *x, Vec *d, Vec *cw);
+  // The same with Cdiag = sw/zsw + tw/ztw (:1912-1927) formed from the sparse slack blocks on the way (one launch
+  // less where the form allows it); the default forms Cdiag into cw and calls sparseFactor
+  virtual int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw);
   // Second half of the Gram correction W -= U^T S^-1 U: turns the panel from sparseJacobianPanel into Y
   // with U^T S^-1 U = Y^T diag(weights) Y.  Block form: Y = U, weights = cw.  CSR form: Y = L^-1 U in
   // place, unit weights.
@@ -178,6 +184,8 @@ class SeparableProblem : public Problem {
   int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
                     Vec *wwork) override;
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override;
+  int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override;
+  int setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
   GroupMap gmap;

@@ -87,6 +87,14 @@ int Problem::addSparseJacobianTranspose(double alpha, Vec *, Vec *pzw, Vec *out)
   if (!csr) return 0;
   return csr->spmvT(alpha, pzw->d, out->d) != PO_OK;
 }
+int Problem::setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  PO_TRY(k_fill(ctx, out->d, nwcon, 0.0));
+  return addSparseJacobian(alpha, x, px, out) != 0 ? PO_ERR_USER : PO_OK;
+}
+int Problem::sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) {
+  PO_TRY(k_w_cdiag(ctx, v, nwcon, cw->d));
+  return sparseFactor(x, d, cw);
+}
 int Problem::addSparseInnerProduct(double alpha, Vec *, Vec *cvec, Vec *A) {
   if (!csr) return 0;
   return csr->innerProduct(alpha, cvec->d, A->d) != PO_OK;
@@ -500,6 +508,16 @@ int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P
 int SeparableProblem::sparseFactor(Vec *xv, Vec *d, Vec *cw) {
   if (csr || nwblock > 1) return Problem::sparseFactor(xv, d, cw);
   return k_group_sum(ctx, gmap, cw->d, 1, 0.0, 1.0, d->d, 1);
+}
+// ... and with Cdiag formed from the slack blocks in the same launch
+int SeparableProblem::sparseFactorFromSlacks(Vec *xv, Vec *d, const WVars &v, Vec *cw) {
+  if (csr || nwblock > 1) return Problem::sparseFactorFromSlacks(xv, d, v, cw);
+  return k_group_factor(ctx, gmap, v, d->d, cw->d);
+}
+// out = alpha Aw px = -alpha (group sums of px), every entry written
+int SeparableProblem::setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  if (csr) return Problem::setSparseJacobian(alpha, x, px, out);
+  return k_group_sum(ctx, gmap, out->d, 0, 0.0, -alpha, px->d);
 }
 int SeparableProblem::sparseApplyK0(Vec *xv, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
                                     Vec *yw, Vec *wwork) {

@@ -93,6 +93,12 @@ class TrustRegionSubproblem : public Problem {
     return prob->sparseApplyK0(xk, d, cw, bx, bw, yx, yw, wwork);
   }
   int sparseFactor(Vec *, Vec *d, Vec *cw) override { return prob->sparseFactor(xk, d, cw); }
+  int sparseFactorFromSlacks(Vec *, Vec *d, const WVars &v, Vec *cw) override {
+    return prob->sparseFactorFromSlacks(xk, d, v, cw);
+  }
+  int setSparseJacobian(double alpha, Vec *, Vec *px, Vec *out) override {
+    return prob->setSparseJacobian(alpha, xk, px, out);
+  }
   int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) override {
     return prob->sparseHalfSolve(U, nv, cw, weights);
   }
@@ -206,6 +212,10 @@ class InfeasSubproblem : public Problem {  // :468-650
     return sub->sparseApplyK0(x, d, cw, bx, bw, yx, yw, wwork);
   }
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override { return sub->sparseFactor(x, d, cw); }
+  int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override {
+    return sub->sparseFactorFromSlacks(x, d, v, cw);
+  }
+  int setSparseJacobian(double a, Vec *x, Vec *px, Vec *out) override { return sub->setSparseJacobian(a, x, px, out); }
   int sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) override {
     return sub->sparseHalfSolve(U, nv, cw, weights);
   }

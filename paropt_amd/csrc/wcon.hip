@@ -167,6 +167,50 @@ __global__ void __launch_bounds__(kBlock)
     __syncthreads();
   }
 }
+// Cw_i = 1 / (sw_i/zsw_i + tw_i/ztw_i + sum of d over group i): w_cdiag_kernel + group_sum_tiled_kernel(recip) in
+// one launch (same expressions, same order)
+__global__ void __launch_bounds__(kBlock)
+    group_factor_tiled_kernel(GroupMap m, WVars v, const double *__restrict__ d, double *__restrict__ cw, int G,
+                              int64_t ntiles) {
+  __shared__ double sm[kGroupTile];
+  const int period = m.nw + m.skip;
+  const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
+  const int tid = threadIdx.x;
+  const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int64_t v0 = m.start + g0 * (int64_t)period;
+    const int nvv = (ng - 1) * period + m.nw;
+    const double a0 = d[v0 + (tid < nvv ? tid : 0)], a1 = d[v0 + (tid + kBlock < nvv ? tid + kBlock : 0)];
+    if (tid < nvv) sm[s0] = a0;
+    if (tid + kBlock < nvv) sm[s1] = a1;
+    __syncthreads();
+    if (tid < ng) {
+      const int64_t i = g0 + tid;
+      const double cd = v.sw[i] / v.zsw[i] + v.tw[i] / v.ztw[i];
+      const double val = cd + 1.0 * row_sum(sm + tid * rstride, m.nw);
+      cw[i] = 1.0 / val;
+    }
+    __syncthreads();
+  }
+}
+static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles);
+int k_group_factor(Ctx *c, const GroupMap &m, const WVars &v, const double *d, double *cw) {
+  if (m.nwcon <= 0) return PO_OK;
+  int G = 0;
+  int64_t ntiles = 0;
+  if (!group_tiling(m, &G, &ntiles)) {
+    PO_TRY(k_w_cdiag(c, v, m.nwcon, cw));
+    return k_group_sum(c, m, cw, 1, 0.0, 1.0, d, 1);
+  }
+  count_bytes(c, 1.0, m.nwcon * (int64_t)m.nw);
+  count_bytes(c, 5.0, m.nwcon);
+  int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
+  PO_WLAUNCH(group_factor_tiled_kernel, (int)grid, m, v, d, cw, G, ntiles);
+  return PO_OK;
+}
+
 // G whole groups per tile with the padded row layout inside kGroupTile doubles: (G-1)*(period+pad) + nw <= kGroupTile
 static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles) {
   const int64_t period = (int64_t)m.nw + m.skip;
@@ -626,7 +670,7 @@ int k_recip(Ctx *c, double *y, int64_t n) {
 // sums {sw.zsw + tw.ztw, l1 rzw, l2^2 rzw, l1 rsw, l1 rtw, l1 rzsw, l1 rztw}; maxs {rzw, rsw, rtw, rzsw, rztw}
 __global__ void __launch_bounds__(kBlock)
     w_res_kernel(WVars v, WVars r, const double *__restrict__ gsw, const double *__restrict__ gtw,
-                 const double *cw, double mu, int64_t w, double *__restrict__ partials) {
+                 const double *cw, double mu, int64_t w, double *__restrict__ d2out, double *__restrict__ partials) {
   __shared__ double sm[4 * 7];
   double sums[7] = {0, 0, 0, 0, 0, 0, 0};
   double maxs[5] = {0, 0, 0, 0, 0};
@@ -642,6 +686,8 @@ __global__ void __launch_bounds__(kBlock)
     r.tw[i] = cc;
     r.zsw[i] = d;
     r.ztw[i] = e;
+    // d2 of the block solve that follows, from the blocks just formed (w_d2_kernel's expression: same bits)
+    if (d2out) d2out[i] = a + (d + sw * b) / zsw - (e + tw * cc) / ztw;
     sums[0] += sw * zsw + tw * ztw;
     sums[1] += fabs(a);
     sums[2] += a * a;
@@ -659,11 +705,11 @@ __global__ void __launch_bounds__(kBlock)
   w_block_reduce<5, 2>(maxs, partials, 7, sm);
 }
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
-            int64_t w, double out[12], const double *cw) {
-  count_bytes(c, 12.0, w);  // w-sized block vectors touched
+            int64_t w, double out[12], const double *cw, double *d2out) {
+  count_bytes(c, d2out ? 13.0 : 12.0, w);  // w-sized block vectors touched
   const int grid = wgrid(c, w);
   PO_TRY(ensure_partials(c, (size_t)grid * 12));
-  PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, cw ? cw : r.zw, mu, w, c->d_partials);
+  PO_WLAUNCH(w_res_kernel, grid, v, r, gsw, gtw, cw ? cw : r.zw, mu, w, d2out, c->d_partials);
   if (!out) return PO_OK;  // the residual blocks only
   return reduce_finish(c, grid, 7, 0, 5, out);
 }
@@ -789,19 +835,27 @@ int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refi
 }
 
 // addKKTResStep, w blocks (:1498-1527); r.zw already holds r.zw - Aw px.
-__global__ void __launch_bounds__(kBlock) w_res_step_kernel(WVars v, WVars p, WVars r, int64_t w) {
+__global__ void __launch_bounds__(kBlock)
+    w_res_step_kernel(WVars v, WVars p, WVars r, int64_t w, double *__restrict__ d2out) {
   PO_W_LOOP(i, w) {
-    r.zw[i] += p.sw[i] - p.tw[i];
-    r.sw[i] += p.zsw[i] - p.zw[i];
-    r.tw[i] += p.ztw[i] + p.zw[i];
-    r.zsw[i] -= p.sw[i] * v.zsw[i] + v.sw[i] * p.zsw[i];
-    r.ztw[i] -= p.tw[i] * v.ztw[i] + v.tw[i] * p.ztw[i];
+    const double a = r.zw[i] + (p.sw[i] - p.tw[i]);
+    const double b = r.sw[i] + (p.zsw[i] - p.zw[i]);
+    const double cc = r.tw[i] + (p.ztw[i] + p.zw[i]);
+    const double d = r.zsw[i] - (p.sw[i] * v.zsw[i] + v.sw[i] * p.zsw[i]);
+    const double e = r.ztw[i] - (p.tw[i] * v.ztw[i] + v.tw[i] * p.ztw[i]);
+    r.zw[i] = a;
+    r.sw[i] = b;
+    r.tw[i] = cc;
+    r.zsw[i] = d;
+    r.ztw[i] = e;
+    // d2 of the refinement's block solve from the updated blocks (w_d2_kernel's expression)
+    if (d2out) d2out[i] = a + (d + v.sw[i] * b) / v.zsw[i] - (e + v.tw[i] * cc) / v.ztw[i];
   }
 }
-int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w) {
-  count_bytes(c, 15.0, w);  // w-sized block vectors touched
+int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w, double *d2out) {
+  count_bytes(c, d2out ? 16.0 : 15.0, w);  // w-sized block vectors touched
   if (w <= 0) return PO_OK;
-  PO_WLAUNCH(w_res_step_kernel, wgrid(c, w), v, p, r, w);
+  PO_WLAUNCH(w_res_step_kernel, wgrid(c, w), v, p, r, w, d2out);
   return PO_OK;
 }
 // Mehrotra corrector (:1733-1750): r.zsw -= psw pzsw, r.ztw -= ptw pztw

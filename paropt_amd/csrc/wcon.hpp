@@ -21,6 +21,8 @@ struct GroupMap {
 
 int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, double alpha,
                 const double *v, int recip = 0);
+// Cw = 1 / (Cdiag(v) + group sums of d): the factor of the scalar block form in one launch
+int k_group_factor(Ctx *c, const GroupMap &m, const WVars &v, const double *d, double *cw);
 // the structured K0^-1 apply in one launch (see wcon.hip); *done = false when the map does not tile (the caller then
 // takes the three-launch form)
 int k_group_k0(Ctx *c, const GroupMap &m, const double *d, const double *bx, const double *cw, const double *bw,
@@ -45,8 +47,9 @@ int k_mul(Ctx *c, double *y, double a, const double *x1, const double *x2, int64
 int k_recip(Ctx *c, double *y, int64_t n);
 
 // cw: the sparse constraint values (null: they sit in r.zw, which is overwritten)
+// d2out != nullptr: also d2 of the block solve that follows (k_w_d2 of the blocks just written)
 int k_w_res(Ctx *c, const WVars &v, const WVars &r, const double *gsw, const double *gtw, double mu,
-            int64_t w, double out[12], const double *cw = nullptr);
+            int64_t w, double out[12], const double *cw = nullptr, double *d2out = nullptr);
 int k_w_scale5(Ctx *c, const WVars &dst, const WVars &src, double alpha, int64_t w);
 int k_w_sumsq5(Ctx *c, const WVars &r, int64_t w, double out[5]);
 int k_w_cdiag(Ctx *c, const WVars &v, int64_t w, double *cd);
@@ -54,7 +57,7 @@ int k_w_d2(Ctx *c, const WVars &v, const WVars &b, int64_t w, double *d2);
 // out = {min_x, min_z}; comp != 0: {S10, S01, S11, min_x, min_z} (complementarity polynomial of the step, wcon.hip)
 int k_w_step(Ctx *c, const WVars &v, const WVars &b, const double *dzw, int refine, double tau,
              const WVars &p, int64_t w, double *out, int comp = 0);
-int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w);
+int k_w_res_step(Ctx *c, const WVars &v, const WVars &p, const WVars &r, int64_t w, double *d2out = nullptr);
 int k_w_corrector(Ctx *c, const WVars &p, const WVars &r, int64_t w);
 int k_w_comp_step(Ctx *c, const WVars &v, const WVars &p, double ax, double az, int64_t w, double *out);
 int k_w_merit(Ctx *c, const WVars &v, const WVars &p, double sx, const double *gsw, const double *gtw,
