@@ -287,6 +287,10 @@ int ensure_partials(Ctx *c, size_t doubles) {
 // One collective + device-to-host copy + host sync for `total` rank-local values in d_red[0..total); on return
 // *parts points at nparts consecutive copies (one per contributing rank, rank order; 1 when the collective has
 // already summed them) in h_red.
+// One place decides where the final reduction stages write: without a device-side collective (one rank, or the
+// host-callback communicator) straight into the pinned host buffer -- no device-to-host copy command before the sync.
+bool red_direct(const Ctx *c) { return c->comm_kind != COMM_RCCL && c->h_red_dev != nullptr; }
+
 static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **parts_out, int *nparts_out) {
   const size_t bytes = sizeof(double) * (size_t)total;
   int nparts = 1;
@@ -323,8 +327,8 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
     PO_HIP(hipStreamSynchronize(c->stream));
     nparts = c->size;
   } else {
-    // (with h_red_dev the final stages have written their results into h_red themselves)
-    if (!c->h_red_dev) PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
+    // (red_direct: the final stages have written their results into h_red themselves)
+    if (!red_direct(c)) PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
     PO_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_kind == COMM_CALLBACK) {
       double *all = c->h_red + kMaxRed;
@@ -421,14 +425,20 @@ int comm_bench(Ctx *c, int count, int pure_sum, int reps, double out_us[3]) {
     return PO_ERR_ARG;
   }
   std::vector<double> t((size_t)reps, 0.0);
+  PO_TRY(batch_flush(c));
+  PO_TRY(ensure_partials(c, (size_t)count));
+  PO_HIP(hipMemsetAsync(c->d_partials, 0, sizeof(double) * count, c->stream));
   PO_HIP(hipMemsetAsync(c->d_red, 0, sizeof(double) * count, c->stream));
   PO_HIP(hipStreamSynchronize(c->stream));
-  const long red0 = c->n_reductions, ar0 = c->n_allreduce, ag0 = c->n_allgather;
+  const long red0 = c->n_reductions, ar0 = c->n_allreduce, ag0 = c->n_allgather, la0 = c->n_launches;
   for (int i = 0; i < reps + 2; i++) {  // two untimed warm-up exchanges
     const double *parts = nullptr;
     int nparts = 1;
     struct timespec a, b;
     clock_gettime(CLOCK_MONOTONIC, &a);
+    // a real final stage (one block of partials per slot) in front of the exchange, as every reduction has it: the
+    // number is "final-stage launch -> collective -> (copy) -> host sync", not a bare stream sync
+    PO_TRY(launch_reduce_final(c, 1, count, count, 0, 0));
     PO_TRY(exchange_reduced(c, count, pure_sum != 0, &parts, &nparts));
     clock_gettime(CLOCK_MONOTONIC, &b);
     if (i >= 2) t[i - 2] = 1e6 * (double)(b.tv_sec - a.tv_sec) + 1e-3 * (double)(b.tv_nsec - a.tv_nsec);
@@ -436,6 +446,7 @@ int comm_bench(Ctx *c, int count, int pure_sum, int reps, double out_us[3]) {
   c->n_reductions = red0;
   c->n_allreduce = ar0;
   c->n_allgather = ag0;
+  c->n_launches = la0;
   std::sort(t.begin(), t.end());
   out_us[0] = t[t.size() / 2];
   out_us[1] = t.front();

@@ -140,6 +140,7 @@ struct VirtCols {
 // host_out[nsum+nmin+nmax]; slots are ordered sums, then mins, then maxs.  Collective.
 // Inside a BatchScope the call returns before host_out is valid unless `now` is set (which flushes the batch).
 int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out, bool now = false);
+bool red_direct(const Ctx *c);  // the final stages write straight into the pinned host buffer (no RCCL collective)
 int batch_flush(Ctx *c);  // collective + host sync for everything queued; runs the after_reduce() work in order
 void batch_abort(Ctx *c);  // forget everything queued (error paths)
 // Host work that reads the result of the preceding reduce_finish: immediately outside a batch, at the flush inside.
@@ -209,9 +210,9 @@ struct BatchScope {
 };
 // Kernel-variant switches for A/B measurements inside ONE process (tools/ab_switch.py): the value set through
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
-enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_WGRAM_DEPTH = 2, SW_S2R_VARIANT = 3, SW_SPARE4 = 4,
-                 SW_SPARE5 = 5, SW_SPARE6 = 6, SW_SPARE7 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_SPARE10 = 10, SW_SPARE11 = 11,
-                 SW_COUNT = 12 };
+enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_REDO_DT = 2, SW_LEAN_STEP = 3, SW_WGRAM_PRIO = 4,
+                 SW_WGRAM_ABLATE = 5, SW_FUSED_MERIT = 6, SW_REDO_DT1 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_LINCOMB_BPC = 10,
+                 SW_SPARE11 = 11, SW_COUNT = 12 };  // one entry per use: an A/B run changes one thing
 int dbg_switch(int id, const char *env, int dflt);
 void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);

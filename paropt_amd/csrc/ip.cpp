@@ -852,7 +852,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     double *tp_out = !defer ? tvec->d : (recompute_rhs ? nullptr : xt->d);
     // Dinv and t re-formed in the element epilogue from the bound data and rx it loads anyway (same bits)
     const bool redo_dt1 = recompute_dt && defer && recompute_rhs && first_t_recomputable &&
-                          dbg_switch(SW_SPARE7, nullptr, 1) != 0;
+                          dbg_switch(SW_REDO_DT1, nullptr, 1) != 0;
     const double *t_in = redo_dt1 ? nullptr : tvec->d;
     if (virt) {
       const std::vector<double> av = to_virt(alpha), cv = to_virt(coef);
@@ -882,16 +882,16 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     step_deferred = false;
     // the same sweep takes the sums the complementarity check of scaleKKTStep and the merit derivative need of the
     // final step (see solve2r_kernel): no separate pass over the step afterwards
-    const bool take_merit = fuse_merit && recompute_rhs && !cl && dbg_switch(SW_SPARE6, nullptr, 1) != 0;
+    const bool take_merit = fuse_merit && recompute_rhs && !cl && dbg_switch(SW_FUSED_MERIT, nullptr, 1) != 0;
     const double *gm = take_merit ? g->d : nullptr;
     double *mo = take_merit ? fused_merit : nullptr;
     // lean step: (pzl, pzu) stay in registers; their only consumer left, the multiplier update, re-forms them
     const bool lean = lean_step && lean_step_allowed && take_merit && iterate_logs_valid &&
-                      dbg_switch(SW_S2R_VARIANT, nullptr, 1) != 0;
+                      dbg_switch(SW_LEAN_STEP, nullptr, 1) != 0;
     double *pzl_out = lean ? nullptr : pzl->d, *pzu_out = lean ? nullptr : pzu->d;
     // Dinv and the first right-hand side t re-formed in registers from data the pass loads anyway (same bits)
     const bool redo_dt = recompute_dt && recompute_rhs && first_t_recomputable &&
-                         dbg_switch(SW_WGRAM_DEPTH, nullptr, 1) != 0;
+                         dbg_switch(SW_REDO_DT, nullptr, 1) != 0;
     const double *t1p = redo_dt ? nullptr : tvec->d;
     if (lean) {
       pz_stored = false;

@@ -386,7 +386,9 @@ int InteriorPoint::computeKKTStepWithRefinementW(double mu, bool use_qn, double 
       PO_TRY(k_res_step(ctx, bounds(), rx->d, px->d, pzl->d, pzu->d, nullptr, coef.data(), Pq.data(),
                         mres, diag, beta_mu, n, d1v->d));
     }
-    // sparse rows (:1492-1527); the blocks are rebuilt, their norms (same mu, same iterate) are in place already
+    // sparse rows (:1492-1527); only the blocks are rebuilt here.  w_sums / w_maxs are deliberately LEFT at the norms
+    // of the iterate's own barrier parameter (the affine solve of the Mehrotra strategies runs this with mu = 0, and
+    // nothing reads the norms before the next computeResidual evaluates them again)
     PO_TRY(computeResidualW(mu, false));
     if (prob->addSparseJacobian(-1.0, x, px, wresv[0]) != 0) return PO_ERR_USER;
     PO_TRY(k_w_res_step(ctx, wv(), wp(), wr(), nw, wd2->d));  // ... and d2 of the refinement's block solve

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(kBlock)
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off) {
   const int grid = (nslots + 3) / 4;
   // no device-side collective (one rank, or the host-callback communicator): straight into the pinned host buffer
-  double *dst = (c->comm_kind != COMM_RCCL && c->h_red_dev) ? c->h_red_dev : c->d_red;
+  double *dst = red_direct(c) ? c->h_red_dev : c->d_red;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(grid), dim3(kBlock), 0, c->stream, c->d_partials,
                      nblocks, nslots, nsum, nmin, dst + dst_off);
   c->n_launches++;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable 
   }
 }
 int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count) {
-  double *dst = (c->comm_kind != COMM_RCCL && c->h_red_dev) ? c->h_red_dev : c->d_red;
+  double *dst = red_direct(c) ? c->h_red_dev : c->d_red;
   for (int i0 = 0; i0 < count; i0 += kMaxSeg) {
     RedSegTable T;
     T.count = count - i0 < kMaxSeg ? count - i0 : kMaxSeg;
@@ -592,7 +592,7 @@ int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X
       }
       PO_HIP(hipGetLastError());
     } else if (form2d && w >= 4) {
-      int gx = (c->num_cu * dbg_switch(SW_SPARE7, "PAROPT_AMD_LINCOMB_BPC", 8) + w - 1) / w;  // ~8 workgroups per CU in all
+      int gx = (c->num_cu * dbg_switch(SW_LINCOMB_BPC, "PAROPT_AMD_LINCOMB_BPC", 8) + w - 1) / w;  // ~8 workgroups per CU in all
       const int need = grid_for(c, n);
       if (gx > need) gx = need;
       if (gx < 1) gx = 1;

@@ -537,14 +537,14 @@ static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int ablate = dbg_switch(SW_SPARE5, "PAROPT_AMD_WGRAM_ABLATE", 0);
+  const int ablate = dbg_switch(SW_WGRAM_ABLATE, "PAROPT_AMD_WGRAM_ABLATE", 0);
   int64_t g = (int64_t)c->num_cu;  // one workgroup per CU
   if (g > ntiles) g = ntiles;
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
   // producers at raised priority: their address arithmetic no longer queues behind the consumers' matrix
   // instructions on the shared SIMD (-4 % on the plain form, -1.7 % with the L-SR1 columns formed; 0 switches it off)
-  const int prio = dbg_switch(SW_SPARE4, "PAROPT_AMD_WGRAM_PRIO", 2);
+  const int prio = dbg_switch(SW_WGRAM_PRIO, "PAROPT_AMD_WGRAM_PRIO", 2);
   hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP, RS>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
                      c->d_partials, st, zt, kpend, b0, tcol, ablate, prio);
   c->n_launches++;
