@@ -435,6 +435,16 @@ int po_wgram(po_vec d, const po_vec *vecs, int nvecs, double *W);
  * (the panel dots P^T t of the bordered solve that follows setUpKKTSystem ride in the Gram pass,
  * src/ParOptInteriorPoint.cpp:2139-2147); W[nvecs-1][nvecs-1] = t . t. */
 int po_wgram_with_rhs(po_vec d, const po_vec *vecs, int nvecs, double *W);
+/* Structured sparse Jacobian (one constraint per group of `nw` consecutive variables, period nw + skip, first group at
+ * variable 0 -- the pattern of examples/rosenbrock/rosenbrock.cpp:131-184): the panel image U_j = alpha * (group sums
+ * of d o vecs_j), j < ncols, which the reference forms column by column through ParOptProblem::addSparseJacobian
+ * (src/ParOptProblem.h:215-262).  po_group_panel is the pass of its own; po_wgram_with_groups lets it ride in the Gram
+ * pass over the same panel (W as po_wgram / po_wgram_with_rhs) and reports in *fused whether the fused kernel covered
+ * this shape (0: U is left untouched).  Same bits from both. */
+int po_group_panel(po_vec d, const po_vec *vecs, int ncols, int64_t nwcon, int nw, int skip, double alpha,
+                   const po_vec *U);
+int po_wgram_with_groups(po_vec d, const po_vec *vecs, int nvecs, int preweighted_last, int64_t nwcon, int nw,
+                         int skip, double alpha, const po_vec *U, int ncols, double *W, int *fused);
 /* Launch mdot `reps` times back to back on the context stream and return the average kernel
  * time in milliseconds measured with HIP events on that stream (bench.py's roofline leg). */
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out);

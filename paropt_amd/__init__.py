@@ -30,5 +30,7 @@ from .api import (  # noqa: F401
     bench_stream,
     bench_wgram,
     wgram,
+    wgram_with_groups,
+    group_panel,
 )
 from .lib import LIB_PATH, ParOptAMDError  # noqa: F401

@@ -1400,6 +1400,27 @@ def wgram(d, vecs, rhs_last=False):
     return W.T  # column-major symmetric
 
 
+def group_panel(d, vecs, nwcon, nw, skip, alpha, U):
+    """U_j = alpha * (sums of d o vecs_j over groups of nw consecutive variables, period nw + skip): the structured
+    sparse-Jacobian panel image in a pass of its own."""
+    nv = len(vecs)
+    arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+    uarr = (L.po_vec * max(nv, 1))(*[u.handle for u in U])
+    check(lib.po_group_panel(d.handle, arr, nv, nwcon, nw, skip, alpha, uarr))
+
+
+def wgram_with_groups(d, vecs, nwcon, nw, skip, alpha, U, rhs_last=False):
+    """wgram() with the panel image of the first len(U) columns riding in the same pass; returns (W, fused)."""
+    nv = len(vecs)
+    W = np.zeros((nv, nv))
+    arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])
+    uarr = (L.po_vec * max(len(U), 1))(*[u.handle for u in U])
+    fused = C.c_int(0)
+    check(lib.po_wgram_with_groups(d.handle, arr, nv, 1 if rhs_last else 0, nwcon, nw, skip, alpha, uarr, len(U),
+                                   W.ctypes.data_as(L.c_double_p), C.byref(fused)))
+    return W.T, bool(fused.value)
+
+
 def bench_mdot(x, vecs, reps=10):
     nv = len(vecs)
     arr = (L.po_vec * max(nv, 1))(*[v.handle for v in vecs])

@@ -1069,6 +1069,58 @@ int po_wgram_with_rhs(po_vec d, const po_vec *vecs, int nvecs, double *W) {
   PO_TRY(gather_ptrs(d, vecs, nvecs, p));
   return k_wgram(d->ctx, d->d, p.data(), nvecs, d->n, W, nullptr, nullptr, 0, 0.0, 1);
 }
+static int fail_arg(const char *msg) {
+  set_error("%s", msg);
+  return PO_ERR_ARG;
+}
+int po_group_panel(po_vec d, const po_vec *vecs, int ncols, int64_t nwcon, int nw, int skip, double alpha,
+                   const po_vec *U) {
+  PO_CHECK_PTR(d);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(d, vecs, ncols, p));
+  std::vector<double *> u;
+  for (int j = 0; j < ncols; j++) {
+    if (!U || !U[j] || U[j]->n < nwcon) return fail_arg("po_group_panel: U vectors must hold nwcon entries");
+    u.push_back(U[j]->d);
+  }
+  GroupMap m;
+  m.nwcon = nwcon;
+  m.start = 0;
+  m.nw = nw;
+  m.skip = skip;
+  if (nwcon < 0 || nw <= 0 || skip < 0 || (nwcon > 0 && (nwcon - 1) * (int64_t)(nw + skip) + nw > d->n))
+    return fail_arg("po_group_panel: the groups do not fit the vectors");
+  return k_group_panel(d->ctx, m, p.data(), ncols, d->d, alpha, u.data());
+}
+int po_wgram_with_groups(po_vec d, const po_vec *vecs, int nvecs, int preweighted_last, int64_t nwcon, int nw,
+                         int skip, double alpha, const po_vec *U, int ncols, double *W, int *fused) {
+  PO_CHECK_PTR(d);
+  PO_CHECK_PTR(W);
+  PO_CHECK_PTR(fused);
+  std::vector<const double *> p;
+  PO_TRY(gather_ptrs(d, vecs, nvecs, p));
+  std::vector<double *> u;
+  for (int j = 0; j < ncols; j++) {
+    if (!U || !U[j] || U[j]->n < nwcon) return fail_arg("po_wgram_with_groups: U vectors must hold nwcon entries");
+    u.push_back(U[j]->d);
+  }
+  if (nwcon < 0 || nw <= 0 || skip < 0 || ncols > nvecs ||
+      (nwcon > 0 && (nwcon - 1) * (int64_t)(nw + skip) + nw > d->n))
+    return fail_arg("po_wgram_with_groups: the groups do not fit the vectors");
+  GramGroups g;
+  g.nwcon = nwcon;
+  g.start = 0;
+  g.nw = nw;
+  g.skip = skip;
+  g.alpha = alpha;
+  g.ncols = ncols;
+  g.U = u.data();
+  bool done = false;
+  PO_TRY(k_wgram(d->ctx, d->d, p.data(), nvecs, d->n, W, nullptr, nullptr, 0, 0.0, preweighted_last ? 1 : 0, false, &g,
+                 &done));
+  *fused = done ? 1 : 0;
+  return PO_OK;
+}
 int po_bench_mdot(po_vec x, const po_vec *vecs, int nvecs, int reps, double *avg_ms, double *out) {
   PO_CHECK_PTR(x);
   PO_CHECK_PTR(avg_ms);

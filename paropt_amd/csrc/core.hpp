@@ -257,14 +257,27 @@ int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64
 // pass over P (the entry W[nv-1][nv-1] is sum t^2, unused).
 // may_defer: inside an open BatchScope the entries arrive in W at the flush (W must live until then; follow-up host
 // work goes through after_reduce); otherwise, and always for panels processed in blocks, W is complete on return.
+// groups != nullptr: the sparse constraints are the structured pattern (one constraint per group of nw consecutive
+// variables, first group at variable 0) and the pass ALSO writes the panel image U_j = alpha * (group sums of
+// d o V_j) for the first `ncols` columns -- what k_group_panel (wcon.hpp) computes in a pass of its own, same bits.
+// *groups_done tells whether it did (panels / maps the fused kernel does not cover leave it false: the caller then
+// runs k_group_panel).
+struct GramGroups {
+  int64_t nwcon = 0, start = 0;
+  int nw = 0, skip = 0;
+  double alpha = 1.0;
+  int ncols = 0;
+  double *const *U = nullptr;
+};
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
             const double *const *S = nullptr, double *const *Zout = nullptr, int kpend = 0,
-            double b0 = 0.0, int preweighted_last = 0, bool may_defer = false);
+            double b0 = 0.0, int preweighted_last = 0, bool may_defer = false,
+            const GramGroups *groups = nullptr, bool *groups_done = nullptr);
 int wgram_debug_stamps(double out[8]);  // tuning aid: PAROPT_AMD_WGRAM_ABLATE=16
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n,
                    int *nblocks, int *nslots, const double *const *S = nullptr,
                    double *const *Zout = nullptr, int kpend = 0, double b0 = 0.0,
-                   int preweighted_last = 0);
+                   int preweighted_last = 0, const GramGroups *groups = nullptr, bool *groups_done = nullptr);
 
 // ---- interior-point kernels -------------------------------------------------------------------
 struct Bounds {  // the per-element data every bound-aware kernel needs

@@ -659,6 +659,18 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       PO_TRY(applyK0(d1v->d, wd2->d, tvec, wyw));
     }
   }
+  // structured sparse constraints: the panel image U = Aw (Dinv o P) of the Gram correction rides in the Gram pass
+  // itself (one pass over the panel instead of two) where the problem and the kernel allow it
+  GramGroups gram_groups;
+  std::vector<double *> Ugs;
+  const GramGroups *ggp = nullptr;
+  bool panel_done = false;
+  if (has_w && !fuse_z && m > 0 && prob->sparseGramGroups(x, &gram_groups)) {
+    PO_TRY(panelImageVectors(m, Ugs));
+    gram_groups.ncols = m;
+    gram_groups.U = Ugs.data();
+    ggp = &gram_groups;
+  }
   if (!fuse_z) {
     W.assign((size_t)m * m, 0.0);
     if (m > 0 && (fuse_t || fuse_tw) && m + 1 <= kWgramMaxVecs) {
@@ -666,7 +678,8 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       Pt.push_back(tvec->d);
       const int mt = m + 1;
       Wt_buf.assign((size_t)mt * mt, 0.0);
-      PO_TRY(k_wgram(ctx, Dinv->d, Pt.data(), mt, n, Wt_buf.data(), nullptr, nullptr, 0, 0.0, 1, wbatch.open));
+      PO_TRY(k_wgram(ctx, Dinv->d, Pt.data(), mt, n, Wt_buf.data(), nullptr, nullptr, 0, 0.0, 1, wbatch.open, ggp,
+                     &panel_done));
       t0dots.assign(m, 0.0);
       after_reduce(ctx, [this, m, mt] {
         for (int j = 0; j < m; j++)
@@ -675,7 +688,9 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
       });
       t0_ready = true;
     } else {
-      if (m > 0) PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data(), nullptr, nullptr, 0, 0.0, 0, wbatch.open));
+      if (m > 0)
+        PO_TRY(k_wgram(ctx, Dinv->d, P.data(), m, n, W.data(), nullptr, nullptr, 0, 0.0, 0, wbatch.open, ggp,
+                       &panel_done));
       t0dots.clear();
     }
   }
@@ -684,7 +699,7 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
     t0_mu = *rhs_mu;
   }
   // W -= U^T Cw U (d1v is free again: scratch of the panel image; tvec holds t)
-  if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec, wbatch.open));
+  if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec, wbatch.open, panel_done));
   PO_TRY(wbatch.end());
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)
   Gf.assign((size_t)c * c, 0.0);

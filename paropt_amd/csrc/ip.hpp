@@ -235,7 +235,9 @@ class InteriorPoint {
   // d2out: also wd2 = d2 of the block solve that follows (one launch less); wd2_ready tells solveKKTW
   int computeResidualW(double mu, bool norms = true, bool with_d2 = false);
   bool wd2_ready = false;
-  int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr, bool may_defer = false);
+  int sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work = nullptr, bool may_defer = false,
+                           bool panel_done = false);
+  int panelImageVectors(int m, std::vector<double *> &U);  // Uw[0..m) as raw pointers (allocated on demand)
   int solveKKTW(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                 bool fuse_residual = false);
   int computeKKTStepWithRefinementW(double mu, bool use_qn, double tau);

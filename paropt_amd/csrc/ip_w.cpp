@@ -92,20 +92,24 @@ int InteriorPoint::wCompStep(double ax, double az, double *prod) {
 }
 
 // W -= U^T S^-1 U with U_j = Aw (Dinv o P_j), S = C + Aw Dinv Aw^T (diagonal for the block form: Cw = S^-1)
-int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work, bool may_defer) {
-  if (m <= 0) return PO_OK;
+int InteriorPoint::panelImageVectors(int m, std::vector<double *> &U) {
   while ((int)Uw.size() < m) {
     Vec *u = vec_new(ctx, nw);
     if (!u) return PO_ERR_HIP;
     Uw.push_back(u);
   }
-  std::vector<double *> U(m);
-  std::vector<const double *> Uc(m);
-  for (int j = 0; j < m; j++) {
-    U[j] = Uw[j]->d;
-    Uc[j] = Uw[j]->d;
-  }
-  PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), work ? work : tvec));
+  U.resize(m);
+  for (int j = 0; j < m; j++) U[j] = Uw[j]->d;
+  return PO_OK;
+}
+// panel_done: the Gram pass over P has already written U (Problem::sparseGramGroups)
+int InteriorPoint::sparseGramCorrection(const std::vector<const double *> &P, int m, Vec *work, bool may_defer,
+                                        bool panel_done) {
+  if (m <= 0) return PO_OK;
+  std::vector<double *> U;
+  PO_TRY(panelImageVectors(m, U));
+  std::vector<const double *> Uc(U.begin(), U.end());
+  if (!panel_done) PO_TRY(prob->sparseJacobianPanel(x, Dinv, P.data(), m, U.data(), work ? work : tvec));
   // block form: U^T Cw U.  CSR form: U <- L^-1 U with S = L L^T, then U^T U
   const double *weights = Cw->d;
   PO_TRY(prob->sparseHalfSolve(U.data(), m, Cw, &weights));

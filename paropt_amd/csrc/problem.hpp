@@ -65,6 +65,10 @@ class Problem {
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
   virtual int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                                   Vec *work);
+  // Structured problems (one constraint per group of consecutive variables) let that panel image ride in the Gram
+  // pass over the same panel (k_wgram's `groups`, one pass over P instead of two): the map and the Jacobian's
+  // entry value, or false (the default: the panel image is sparseJacobianPanel's pass of its own)
+  virtual bool sparseGramGroups(Vec *x, GramGroups *g) { return false; }
   // (yx, yw) = K0^-1 (bx, bw) of ParOptQuasiDefBlockMat::apply (src/ParOptSparseMat.cpp:122-190) with
   // the diagonal blocks d (n) and cw (w): yx = d o bx; yw = cw o (bw - Aw yx); yx = d o (bx + Aw^T yw).
   // The default is that sequence through the Jacobian callbacks (11 n-sized passes); structured problems
@@ -185,6 +189,7 @@ class SeparableProblem : public Problem {
                     Vec *wwork) override;
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override;
   int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override;
+  bool sparseGramGroups(Vec *x, GramGroups *g) override;
   int setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;

@@ -502,6 +502,16 @@ int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P
   return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
 }
 
+bool SeparableProblem::sparseGramGroups(Vec *x, GramGroups *g) {
+  if (csr || nwblock > 1 || nwcon <= 0) return false;
+  g->nwcon = gmap.nwcon;
+  g->start = gmap.start;
+  g->nw = gmap.nw;
+  g->skip = gmap.skip;
+  g->alpha = -1.0;  // Aw = -(group indicator), as in sparseJacobianPanel above
+  return true;
+}
+
 // the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
 // Aw = -(group indicator): u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx - yw[group])
 // Cw = 1 / (Cdiag + sum of d over the group): the group sum and the reciprocal in one launch

@@ -93,6 +93,7 @@ class TrustRegionSubproblem : public Problem {
     return prob->sparseApplyK0(xk, d, cw, bx, bw, yx, yw, wwork);
   }
   int sparseFactor(Vec *, Vec *d, Vec *cw) override { return prob->sparseFactor(xk, d, cw); }
+  bool sparseGramGroups(Vec *, GramGroups *g) override { return prob->sparseGramGroups(xk, g); }
   int sparseFactorFromSlacks(Vec *, Vec *d, const WVars &v, Vec *cw) override {
     return prob->sparseFactorFromSlacks(xk, d, v, cw);
   }
@@ -212,6 +213,7 @@ class InfeasSubproblem : public Problem {  // :468-650
     return sub->sparseApplyK0(x, d, cw, bx, bw, yx, yw, wwork);
   }
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override { return sub->sparseFactor(x, d, cw); }
+  bool sparseGramGroups(Vec *x, GramGroups *g) override { return sub->sparseGramGroups(x, g); }
   int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override {
     return sub->sparseFactorFromSlacks(x, d, v, cw);
   }

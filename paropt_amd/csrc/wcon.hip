@@ -84,10 +84,15 @@ __global__ void __launch_bounds__(kBlock)
     group_panel_tiled_kernel(GroupMap m, PtrTable P, int nv, const double *__restrict__ d, double alpha,
                              PtrTableW U, int G, int64_t ntiles) {
   __shared__ double sm[JB * kGroupTile];
+  // the output pointers in LDS: indexing the kernel-argument table with a per-lane column is a VECTOR load from the
+  // kernel-argument segment (host memory), one per batch of columns
+  __shared__ double *utab[kMaxPanel];
   const int period = m.nw + m.skip;
   const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
   const int tid = threadIdx.x;
   const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
+  if (tid < kMaxPanel) utab[tid] = U.p[tid];
+  __syncthreads();
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t g0 = tile * G;
     const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
@@ -122,7 +127,11 @@ __global__ void __launch_bounds__(kBlock)
       __syncthreads();
       for (int pair = tid; pair < ng * JB; pair += kBlock) {
         const int u = pair / ng, gi = pair - u * ng;
-        if (jb + u < nv) U.p[jb + u][g0 + gi] = alpha * row_sum(sm + u * kGroupTile + gi * rstride, m.nw);
+        if (jb + u < nv) {  // (a GLOBAL store: the pointer from LDS is generic, and a flat store costs every wait its count)
+          typedef __attribute__((address_space(1))) double gdouble;
+          gdouble *up = (gdouble *)utab[jb + u];
+          up[g0 + gi] = alpha * row_sum(sm + u * kGroupTile + gi * rstride, m.nw);
+        }
       }
       __syncthreads();
     }
@@ -439,6 +448,23 @@ __global__ void __launch_bounds__(kBlock)
   const int gi0 = tid / period, k0 = tid - gi0 * period;
   const int gi1 = (tid + kBlock) / period, k1 = tid + kBlock - gi1 * period;
   const int64_t cover_end = (m.start + m.nwcon * (int64_t)period) < n ? (m.start + m.nwcon * (int64_t)period) : n;
+  // the loads of a tile (clamped: all four in flight whatever the tile's fill); the NEXT tile's are issued before
+  // this tile's two barriers, so the tile loop is not one memory latency per tile
+  double d0 = 0.0, d1 = 0.0, b0 = 0.0, b1 = 0.0;
+  auto tile_load = [&](int64_t tile, double &e0, double &e1, double &c0, double &c1) {
+    const int64_t g0 = tile * G;
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+    const int64_t v0 = m.start + g0 * (int64_t)period;
+    int64_t vend = v0 + (int64_t)ng * period;
+    if (vend > n) vend = n;
+    const int nvv = (int)(vend - v0);
+    const int64_t i0 = v0 + (tid < nvv ? tid : 0), i1 = v0 + (tid + kBlock < nvv ? tid + kBlock : 0);
+    e0 = __builtin_nontemporal_load(d + i0);
+    e1 = __builtin_nontemporal_load(d + i1);
+    c0 = __builtin_nontemporal_load(bx + i0);
+    c1 = __builtin_nontemporal_load(bx + i1);
+  };
+  if ((int64_t)blockIdx.x < ntiles) tile_load(blockIdx.x, d0, d1, b0, b1);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t g0 = tile * G;
     const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
@@ -447,10 +473,10 @@ __global__ void __launch_bounds__(kBlock)
     if (vend > n) vend = n;
     const int nvv = (int)(vend - v0);
     const bool in0 = tid < nvv, in1 = tid + kBlock < nvv;
-    const int64_t i0 = v0 + (in0 ? tid : 0), i1 = v0 + (in1 ? tid + kBlock : 0);  // clamped: all four in flight
-    const double d0 = d[i0], d1 = d[i1], b0 = bx[i0], b1 = bx[i1];
-    sm[tid] = in0 ? d0 * b0 : 0.0;
-    sm[tid + kBlock] = in1 ? d1 * b1 : 0.0;
+    const double cd0 = d0, cd1 = d1, cb0 = b0, cb1 = b1;
+    if (tile + gridDim.x < ntiles) tile_load(tile + gridDim.x, d0, d1, b0, b1);
+    sm[tid] = in0 ? cd0 * cb0 : 0.0;
+    sm[tid + kBlock] = in1 ? cd1 * cb1 : 0.0;
     __syncthreads();
     if (tid < ng) {
       const double u = alpha * row_sum(sm + tid * period, m.nw);
@@ -460,14 +486,14 @@ __global__ void __launch_bounds__(kBlock)
     }
     __syncthreads();
     if (in0) {
-      double v = b0;
+      double v = cb0;
       if (k0 < m.nw) v += alpha * smw[gi0];
-      yx[v0 + tid] = d0 * v;
+      yx[v0 + tid] = cd0 * v;
     }
     if (in1) {
-      double v = b1;
+      double v = cb1;
       if (k1 < m.nw) v += alpha * smw[gi1];
-      yx[v0 + tid + kBlock] = d1 * v;
+      yx[v0 + tid + kBlock] = cd1 * v;
     }
   }
   // variables outside every group's period: yx = d bx

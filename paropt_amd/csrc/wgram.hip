@@ -149,9 +149,15 @@ __device__ __forceinline__ void gram_step_all(const double (&a)[NG], double w, b
   }
 }
 
-template <int NG>
+struct GramNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `between`: called after the tile's operand fetches have been issued and before its matrix instructions (the fused
+// group sums request THEIR operands there: LDS serves the matrix operands first, the rest arrives behind the matrix work)
+template <int NG, class Hook = GramNoHook>
 __device__ __forceinline__ void gram_tile_rows(const double *__restrict__ pt, const double *__restrict__ dw, int lane,
-                                               int wave, int tcol, double (&acc)[NG * (NG + 1) / 2]) {
+                                               int wave, int tcol, double (&acc)[NG * (NG + 1) / 2],
+                                               const Hook &between = Hook()) {
   const int ci = lane & 3;
   const int rowoff = ((lane >> 2) & 3) + 4 * (lane >> 4);
   const double *base = pt + ci * kGramLd + rowoff;
@@ -167,10 +173,12 @@ __device__ __forceinline__ void gram_tile_rows(const double *__restrict__ pt, co
   if constexpr (NG <= 12) {
     gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);        // both steps requested before the first matrix instruction:
     gram_fetch<NG>(base + off1, dwl + off1, 0, a1, w1);  // the second fetch lands behind the first step's work
+    between();
     gram_step_all<NG>(a0, w0, tsel, acc);
     gram_step_all<NG>(a1, w1, tsel, acc);
   } else {  // wider panels: the accumulators leave no room for both steps' operands
     gram_fetch<NG>(base, dwl, 2 * wave, a0, w0);
+    between();
     gram_step_all<NG>(a0, w0, tsel, acc);
     gram_fetch<NG>(base + off1, dwl + off1, 0, a0, w0);
     gram_step_all<NG>(a0, w0, tsel, acc);
@@ -335,6 +343,86 @@ constexpr int kGramDepth = 3;  // tiles a producer keeps in flight
 // [3] producer load issue, [4] producer barrier wait, [5] tiles, [6] / [7] s_memtime / s_memrealtime ticks of the loop
 __device__ unsigned long long g_wgram_stamp[8];
 
+// ---- structured sparse Jacobian riding in the pass (round 4) ---------------------------------------------------
+// One sparse constraint per group of `nw` consecutive variables (period nw + skip, first group at variable 0; the
+// GroupMap of wcon.hpp).  The panel image U_j = alpha Aw (d o V_j) -- group sums of the weighted columns -- is what
+// group_panel_tiled_kernel (wcon.hip) computes in a pass of its own over the same panel; with the tile pitch cut to
+// whole groups (G groups = trows <= 128 rows per tile, the rest of the tile staged as zeros) the consumers take the
+// sums from the LDS tile they have just multiplied: the panel is read once instead of twice.  Same arithmetic as
+// group_panel_tiled_kernel -- rounded products d * v added in index order, then * alpha -- so U has the same bits.
+// Variables past the last group are covered by ordinary 128-row tiles behind the group tiles.
+struct GramGeom {
+  int64_t ngt = 0;    // tiles of whole groups (0: plain 128-row tiling from row 0)
+  int64_t rg = 0;     // rows covered by the group tiles
+  int64_t nwcon = 0;  // groups
+  int trows = kGramTile, G = 0, period = 0, nw = 0, ncols = 0;
+  double alpha = 0.0;
+};
+// (branch-free: with branches here hipcc loses count of the producers' outstanding loads and waits for ALL of them
+// before staging a tile -- vmcnt(0) instead of vmcnt(newer tiles) -- which serialises the three-tile prefetch)
+__device__ __forceinline__ void gram_tile_geom(const GramGeom &gg, int64_t tile, int64_t &row0, int &nrows) {
+  const bool grp = tile < gg.ngt;
+  const int64_t rowg = tile * gg.trows, rowp = gg.rg + (tile - gg.ngt) * kGramTile;
+  const int64_t left = gg.rg - rowg;
+  const int nrg = left < gg.trows ? (int)left : gg.trows;
+  row0 = grp ? rowg : rowp;
+  nrows = grp ? nrg : kGramTile;
+}
+// The sums of one (column u, group gi) pair per consumer lane, in two phases around the tile's matrix work: the
+// operands (nw rows of the column and their weights, <= kGramGroupNw each) are REQUESTED from LDS before the matrix
+// instructions and consumed after them, so the LDS latency of the sums hides behind the tile's matrix work and what is
+// left on the consumers' critical path is the chain of nw ordered adds.  (Measured on the way: summing straight from LDS
+// after the matrix work -- 20 dependent load/add steps -- made the pass 1.6 us per tile slower whatever the panel
+// width; indexing the kernel-argument pointer table per lane is a vector load from HOST memory per tile; and ONE flat
+// store in the kernel makes hipcc wait for vmcnt(0) everywhere, the producers' prefetch included.)
+constexpr int kGramGroupNw = 24;  // widest group the fused form takes (registers: 2 x 24 doubles per lane)
+struct GramGroupOps {
+  double p[kGramGroupNw], w[kGramGroupNw];
+};
+__device__ __forceinline__ void gram_groups_request(const double *__restrict__ pt, const double *__restrict__ dw,
+                                                    const GramGeom &gg, int u, int gi, GramGroupOps &o) {
+  // (ds_read_b64 each: two rows per ds_read_b128 was tried and is 70 % slower on the whole pass)
+  const double *row = pt + u * kGramLd + gi * gg.period;
+  const double *wr = dw + gi * gg.period;
+#pragma unroll
+  for (int k = 0; k < kGramGroupNw; k++) {
+    if (k < gg.nw) {  // (wave-uniform)
+      o.p[k] = row[k];
+      o.w[k] = wr[k];
+    }
+  }
+}
+__device__ __forceinline__ double gram_groups_sum(const GramGeom &gg, const GramGroupOps &o) {
+#pragma clang fp contract(off)  // rounded products, then ordered adds: the bits of group_panel_tiled_kernel
+  double sacc = 0.0;
+#pragma unroll
+  for (int k = 0; k < kGramGroupNw; k++) {
+    if (k < gg.nw) {
+      const double prod = o.w[k] * o.p[k];
+      sacc = sacc + prod;
+    }
+  }
+  return gg.alpha * sacc;
+}
+// pairs beyond the first 256 of a tile (wide panels with many small groups): straight from LDS after the matrix work
+__device__ __forceinline__ void gram_groups_rest(const double *__restrict__ pt, const double *__restrict__ dw,
+                                                 const GramGeom &gg, double *const *Utab, int64_t g0, int ng, int ctid) {
+#pragma clang fp contract(off)
+  typedef __attribute__((address_space(1))) double gdouble;
+  for (int pair = ctid + 256; pair < ng * gg.ncols; pair += 256) {
+    const int u = pair / ng, gi = pair - u * ng;
+    const double *row = pt + u * kGramLd + gi * gg.period;
+    const double *wr = dw + gi * gg.period;
+    double sacc = 0.0;
+    for (int k = 0; k < gg.nw; k++) {
+      const double prod = wr[k] * row[k];
+      sacc = sacc + prod;
+    }
+    gdouble *up = (gdouble *)Utab[u];
+    up[g0 + gi] = gg.alpha * sacc;
+  }
+}
+
 template <int NG, int ZP>
 struct GramProducer {
   f64x2 buf[kGramDepth][NG];
@@ -347,14 +435,22 @@ struct GramProducer {
 template <int NG, int ZP, int R>
 __device__ __forceinline__ void gram_pc_load(GramProducer<NG, ZP> &P, const double *const (&colp)[NG],
                                              const double *const (&scol)[ZP > 0 ? ZP : 1], const double *d,
-                                             int64_t tile, int64_t ntiles, int64_t n, int64_t ilast, int lane) {
+                                             int64_t tile, int64_t ntiles, int64_t n, int64_t ilast, int lane,
+                                             const GramGeom &gg) {
   if (tile >= ntiles) {
     P.in[R] = false;
     return;
   }
-  int64_t i = tile * kGramTile + 2 * lane;
-  const bool in = (i < n);
-  if (!in) i = ilast;
+  int64_t row0;
+  int nrows;
+  gram_tile_geom(gg, tile, row0, nrows);
+  int64_t i = row0 + 2 * lane;
+  const bool in = (2 * lane < nrows) && (i < n);
+  // (lanes outside the tile: any in-range pair will do, its value is not used -- with group tiles one of THIS tile's,
+  // whose lines the instruction requests anyway)
+  int64_t alt = row0 + 2 * (lane & 3);
+  alt = alt > ilast ? ilast : alt;
+  if (!in) i = gg.ngt > 0 ? alt : ilast;
   P.in[R] = in;
   P.row[R] = i;
 #pragma unroll
@@ -386,15 +482,16 @@ __device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *_
   if (pw == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = in ? P.dbuf[R] : (f64x2){0.0, 0.0};
 }
 
-template <int NG, int ZP, int RS>
+template <int NG, int ZP, int RS, int GS>
 __global__ void __launch_bounds__(512, 1)
     wgram_pc_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
                     double *__restrict__ partials, PtrTable S, PtrTableW Zout, int kpend, double b0, int tcol,
-                    int ablate, int prio) {
+                    int ablate, int prio, GramGeom gg, PtrTableW Ugs) {
   constexpr int M = 4 * NG;
   constexpr int NQ = GramPlanHolder<NG>::NQ;
   const bool want_stamps = (ablate & 16) != 0;  // PAROPT_AMD_WGRAM_ABLATE: 16 = cycle stamps, low bits = what is cut
   ablate &= 15;
+  if constexpr (GS == 0) gg = GramGeom();  // plain tiling, folded at compile time
   constexpr int kBufDoubles = M * kGramLd + kGramTile;  // panel tile, then the row weights
   extern __shared__ double lds[];                       // two tile buffers
   const int tid = threadIdx.x, lane = tid & 63;
@@ -402,9 +499,23 @@ __global__ void __launch_bounds__(512, 1)
   // zero the padded columns of both buffers once (never written by the staging)
   for (int b2 = 0; b2 < 2; b2++)
     for (int idx = tid; idx < (M - nv) * kGramLd; idx += 512) lds[b2 * kBufDoubles + nv * kGramLd + idx] = 0.0;
+  double **utab = reinterpret_cast<double **>(lds + 2 * kBufDoubles);  // GS: the panel image's output pointers
+  if constexpr (GS != 0) {
+    if (tid < kMaxPanel) utab[tid] = Ugs.p[tid];
+  }
   // tiles of this workgroup: blockIdx.x + it * gridDim.x, it = 0 .. nt-1
-  const int64_t first = blockIdx.x, stride = gridDim.x;
-  const int64_t nt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  // GS = 0: tile blockIdx.x + it * gridDim.x.  GS: a workgroup takes CONSECUTIVE tiles -- the 120-row (15-line) tiles
+  // of e.g. groups of 20 do not end on cache-line boundaries, and with neighbouring tiles on different CUs every
+  // column of every tile fetched two partial lines twice (measured: +40 % on the pass)
+  int64_t first = blockIdx.x, stride = gridDim.x;
+  int64_t nt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  if constexpr (GS != 0) {
+    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    first = blockIdx.x * per;
+    stride = 1;
+    nt = ntiles - first;
+    nt = nt < 0 ? 0 : (nt < per ? nt : per);
+  }
   __syncthreads();
   if (wave >= 4) {
     // ------------------------------------------------ producers ------------------------------------------------
@@ -430,9 +541,9 @@ __global__ void __launch_bounds__(512, 1)
     }
     const int64_t ilast = ((n - 1) >> 1) << 1;
     GramProducer<NG, ZP> P;
-    gram_pc_load<NG, ZP, 0>(P, colp, scol, d, first, ntiles, n, ilast, lane);
-    gram_pc_load<NG, ZP, 1>(P, colp, scol, d, first + stride, ntiles, n, ilast, lane);
-    gram_pc_load<NG, ZP, 2>(P, colp, scol, d, first + 2 * stride, ntiles, n, ilast, lane);
+    gram_pc_load<NG, ZP, 0>(P, colp, scol, d, first, ntiles, n, ilast, lane, gg);
+    gram_pc_load<NG, ZP, 1>(P, colp, scol, d, first + stride, ntiles, n, ilast, lane, gg);
+    gram_pc_load<NG, ZP, 2>(P, colp, scol, d, first + 2 * stride, ntiles, n, ilast, lane, gg);
     // step `it` (ring slot it % 3, LDS buffer it % 2): stage tile `it`, reload the slot with tile it + 3, barrier
     unsigned long long st_stage = 0, st_load = 0, st_wait = 0;
     const bool stamp = want_stamps && blockIdx.x == 0 && wave == 4;
@@ -446,7 +557,7 @@ __global__ void __launch_bounds__(512, 1)
     else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
     if (stamp) __builtin_amdgcn_s_waitcnt(0);                                                                 \
     const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane); \
+    if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
     const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     __syncthreads();                                                                                          \
     if (stamp) {                                                                                              \
@@ -480,20 +591,66 @@ __global__ void __launch_bounds__(512, 1)
     for (int q = 0; q < NACC; q++) acc[q] = 0.0;
     unsigned long long sc_wait = 0, sc_work = 0;
     const bool cstamp = want_stamps && blockIdx.x == 0 && wave == 0;
+    // (GS) this lane's pair of a full tile of G groups; the last group tile may hold fewer groups (recomputed there)
+    int gs_u = 0, gs_gi = 0;
+    if constexpr (GS != 0) {
+      gs_u = tid / gg.G;
+      gs_gi = tid - gs_u * gg.G;
+    }
     for (int64_t it = 0; it < nt; it++) {
       const unsigned long long _t0 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       __syncthreads();  // tile `it` is staged in buffer it % 2
       const unsigned long long _t1 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
       const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
       if (ablate == 1) continue;  // tuning: no matrix work
+      // (GS) phase 1: request the operands of this lane's group sum before the matrix work
+      [[maybe_unused]] GramGroupOps gops;
+      [[maybe_unused]] bool gs_on = false, gs_mine = false;
+      [[maybe_unused]] int gs_ng = 0, pu = 0, pgi = 0;
+      [[maybe_unused]] int64_t gs_g0 = 0;
+      if constexpr (GS != 0) {
+        const int64_t tile = first + it * stride;
+        gs_on = tile < gg.ngt;
+        if (gs_on) {
+          gs_g0 = tile * gg.G;
+          gs_ng = (int)((gg.nwcon - gs_g0) < gg.G ? (gg.nwcon - gs_g0) : gg.G);
+          pu = gs_u;
+          pgi = gs_gi;
+          if (gs_ng != gg.G) {
+            pu = tid / gs_ng;
+            pgi = tid - pu * gs_ng;
+          }
+          gs_mine = tid < gs_ng * gg.ncols;
+          if (!RS && gs_mine && ablate != 5) gram_groups_request(bt, bt + M * kGramLd, gg, pu, pgi, gops);
+        }
+      }
       if constexpr (RS) {
-        gram_tile_rows<NG>(bt, bt + M * kGramLd, lane, wave, tcol, acc);
+        if constexpr (GS != 0) {
+          auto request = [&]() {
+            if (gs_on && gs_mine && ablate != 5) gram_groups_request(bt, bt + M * kGramLd, gg, pu, pgi, gops);
+          };
+          gram_tile_rows<NG>(bt, bt + M * kGramLd, lane, wave, tcol, acc, request);
+        } else {
+          gram_tile_rows<NG>(bt, bt + M * kGramLd, lane, wave, tcol, acc);
+        }
       } else {
         switch (wave) {
           case 0: gram_tile<NG, 0>(bt, bt + M * kGramLd, lane, tcol, acc); break;
           case 1: gram_tile<NG, 1>(bt, bt + M * kGramLd, lane, tcol, acc); break;
           case 2: gram_tile<NG, 2>(bt, bt + M * kGramLd, lane, tcol, acc); break;
           default: gram_tile<NG, 3>(bt, bt + M * kGramLd, lane, tcol, acc); break;
+        }
+      }
+      // (GS) phase 2: the ordered sum and its store (a GLOBAL store: the pointer from LDS is generic)
+      if constexpr (GS != 0) {
+        if (gs_on) {
+          if (gs_mine && ablate != 6) {  // (tuning: 4 = no store, 5 = no operand requests, 6 = neither sums nor store)
+            typedef __attribute__((address_space(1))) double gdouble;
+            gdouble *up = (gdouble *)utab[pu];
+            const double sum = gram_groups_sum(gg, gops);
+            if (ablate != 4 || sum == 1.2345e301) up[gs_g0 + pgi] = sum;
+          }
+          if (gs_ng * gg.ncols > 256) gram_groups_rest(bt, bt + M * kGramLd, gg, utab, gs_g0, gs_ng, tid);
         }
       }
       if (cstamp) {
@@ -527,13 +684,14 @@ __global__ void __launch_bounds__(512, 1)
   }
 }
 
-template <int NG, int ZP, int RS>
+template <int NG, int ZP, int RS, int GS = 0>
 static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int64_t ntiles,
-                             const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out) {
-  const size_t lds = (size_t)2 * (4 * NG * kGramLd + kGramTile) * sizeof(double);
+                             const PtrTable &st, const PtrTableW &zt, int kpend, double b0, int tcol, int *grid_out,
+                             const GramGeom *gg = nullptr, const PtrTableW *ut = nullptr) {
+  const size_t lds = (size_t)2 * (4 * NG * kGramLd + kGramTile) * sizeof(double) + (GS ? kMaxPanel * sizeof(double *) : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc_kernel<NG, ZP, RS>),
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc_kernel<NG, ZP, RS, GS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -545,8 +703,9 @@ static int wgram_pc_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv
   // producers at raised priority: their address arithmetic no longer queues behind the consumers' matrix
   // instructions on the shared SIMD (-4 % on the plain form, -1.7 % with the L-SR1 columns formed; 0 switches it off)
   const int prio = dbg_switch(SW_WGRAM_PRIO, "PAROPT_AMD_WGRAM_PRIO", 2);
-  hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP, RS>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
-                     c->d_partials, st, zt, kpend, b0, tcol, ablate, prio);
+  static const PtrTableW no_u = PtrTableW();
+  hipLaunchKernelGGL((wgram_pc_kernel<NG, ZP, RS, GS>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
+                     c->d_partials, st, zt, kpend, b0, tcol, ablate, prio, gg ? *gg : GramGeom(), ut ? *ut : no_u);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -581,9 +740,39 @@ static int wgram_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, i
 
 static int wgram_groups(int nv) { return (nv + 3) / 4; }
 
+// the tile geometry of a pass that also takes the group sums, or false when this panel / map does not qualify (the
+// caller then runs group_panel_tiled_kernel as before)
+static bool wgram_groups_geom(const GramGroups *g, int nv, int64_t n, int kpend, GramGeom *gg) {
+  if (!g || g->nwcon <= 0 || g->ncols <= 0 || g->ncols > nv || !g->U || kpend > 0) return false;
+  static const bool off = getenv("PAROPT_AMD_NO_GRAM_GROUPS") != nullptr;
+  if (off) return false;
+  const int64_t period = (int64_t)g->nw + g->skip;
+  if (g->start != 0 || g->nw <= 0 || g->nw > kGramGroupNw || period > kGramTile) return false;
+  if ((g->nwcon - 1) * period + g->nw > n) return false;
+  int G = (int)(kGramTile / period);
+  if (period & 1) G &= ~1;  // an even number of rows per tile: lanes hold row pairs
+  if (G < 1) return false;
+  int64_t rg = g->nwcon * period;
+  if (rg > n) rg = n;
+  if ((rg & 1) && rg != n) return false;  // the ordinary tiles behind the groups start on an even row
+  const int NG = (nv + 3) / 4;
+  if (NG > 9 || n < 4 * kGramTile) return false;  // the producer/consumer instantiations that carry the sums
+  gg->ngt = (g->nwcon + G - 1) / G;
+  gg->rg = rg;
+  gg->nwcon = g->nwcon;
+  gg->trows = G * (int)period;
+  gg->G = G;
+  gg->period = (int)period;
+  gg->nw = g->nw;
+  gg->ncols = g->ncols;
+  gg->alpha = g->alpha;
+  return true;
+}
+
 int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, int *nblocks,
                    int *nslots, const double *const *S, double *const *Zout, int kpend, double b0,
-                   int preweighted_last) {
+                   int preweighted_last, const GramGroups *groups, bool *groups_done) {
+  if (groups_done) *groups_done = false;
   if (nv > kWgramMaxVecs || nv < 1) {
     set_error("wgram panel width %d outside 1..%d", nv, kWgramMaxVecs);
     return PO_ERR_ARG;
@@ -595,15 +784,17 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   count_bytes(c, nv + 1 + 2 * kpend, n);  // panel + weights (+ S read, Z written)
   const int tcol = preweighted_last ? nv - 1 : -1;
   const int NG = wgram_groups(nv);
-  const int64_t ntiles = (n + kGramTile - 1) / kGramTile;
+  int64_t ntiles = (n + kGramTile - 1) / kGramTile;
   PtrTable pt, st;
-  PtrTableW zt;
+  PtrTableW zt, ut;
   for (int j = 0; j < kMaxPanel; j++) {
     pt.p[j] = j < nv ? V[j] : nullptr;
     st.p[j] = (S && j < kpend) ? S[j] : nullptr;
     zt.p[j] = (Zout && j < kpend) ? Zout[j] : nullptr;
+    ut.p[j] = nullptr;
   }
   int grid = 0;
+  GramGeom gg;
   // resident wavefronts per SIMD the kernel is compiled for (register budget 512 / OCC per lane)
   static const int occ_env = getenv("PAROPT_AMD_WGRAM_OCC") ? atoi(getenv("PAROPT_AMD_WGRAM_OCC")) : 0;
   // PAROPT_AMD_WGRAM_PC=0: the single-role form (every wavefront loads, stages and multiplies) for all widths
@@ -613,6 +804,27 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // 8 % faster than the output split on the plain form (2.93 vs 3.18 ms = 0.75 of the HBM peak) and 2 % with the L-SR1
   // columns formed in the pass -- once its operand fetches stay ds_read_b64 (see gram_tile_rows)
   const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", 1) != 0;
+  if (use_pc && wgram_groups_geom(groups, nv, n, kpend, &gg)) {
+    // the pass also takes the structured panel image (see GramGeom): group tiles first, ordinary tiles behind them
+    ntiles = gg.ngt + (n - gg.rg + kGramTile - 1) / kGramTile;
+    for (int j = 0; j < gg.ncols; j++) ut.p[j] = groups->U[j];
+    count_bytes(c, (double)gg.ncols, gg.nwcon);
+#define PO_WGG(NGv)                                                                                                  \
+  case NGv:                                                                                                          \
+    if (NGv >= kGramRowSplitMinNG && row_split)                                                                      \
+      PO_TRY((wgram_pc_launch_t<NGv, 0, 1, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid, &gg, &ut)));     \
+    else                                                                                                             \
+      PO_TRY((wgram_pc_launch_t<NGv, 0, 0, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid, &gg, &ut)));     \
+    break;
+    switch (NG) {
+      PO_WGG(1) PO_WGG(2) PO_WGG(3) PO_WGG(4) PO_WGG(5) PO_WGG(6) PO_WGG(7) PO_WGG(8) PO_WGG(9)
+    }
+#undef PO_WGG
+    if (groups_done) *groups_done = true;
+    *nblocks = grid;
+    *nslots = (NG * (NG + 1) / 2) * 16;
+    return PO_OK;
+  }
 #define PO_WG(NGv)                                                                                     \
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \
@@ -658,7 +870,7 @@ int wgram_debug_stamps(double out[8]) {
 
 static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
                             const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last,
-                            bool may_defer);
+                            bool may_defer, const GramGroups *groups = nullptr, bool *groups_done = nullptr);
 
 // Panels wider than one launch (kWgramMaxVecs columns: registers and LDS of the kernel) are processed by column
 // BLOCKS: the columns are cut into nb blocks of <= kWgramMaxVecs / 2 columns (multiples of 4) and every pair of
@@ -666,10 +878,12 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
 // block streamed nb - 1 times: slower per column than the single launch, but there is no limit on the width (the
 // reference has none either: src/ParOptInteriorPoint.cpp:1935-1950, 2648-2654).
 int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
-            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last, bool may_defer) {
+            const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last, bool may_defer,
+            const GramGroups *groups, bool *groups_done) {
+  if (groups_done) *groups_done = false;
   if (nv <= 0) return PO_OK;
   if (nv <= kWgramMaxVecs)
-    return wgram_one_launch(c, d, V, nv, n, W, S, Zout, kpend, b0, preweighted_last, may_defer);
+    return wgram_one_launch(c, d, V, nv, n, W, S, Zout, kpend, b0, preweighted_last, may_defer, groups, groups_done);
   if (kpend > 0 || preweighted_last) {
     set_error("wgram: a panel of %d columns is processed in blocks, which cannot form L-SR1 columns or carry a "
               "pre-weighted column", nv);
@@ -702,7 +916,7 @@ int k_wgram(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, 
 
 static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int nv, int64_t n, double *W,
                             const double *const *S, double *const *Zout, int kpend, double b0, int preweighted_last,
-                            bool may_defer) {
+                            bool may_defer, const GramGroups *groups, bool *groups_done) {
   if (nv <= 0) return PO_OK;
   int grid = 0, nslots = 0;
   // (the block sums live on the heap: a deferred launch unpacks them at the flush of the enclosing batch)
@@ -711,7 +925,7 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
   // right after the launch)
   const bool timed = c->time_wgram != 0 && !defer;
   if (timed) PO_HIP(hipEventRecord(c->ev0, c->stream));
-  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last));
+  PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last, groups, groups_done));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
   auto blocks = std::make_shared<std::vector<double>>(nslots);
   PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks->data(), !defer));  // !defer: synchronises the stream

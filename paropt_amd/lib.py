@@ -285,6 +285,9 @@ SIGNATURES = {
     "po_mma_set_iteration_callback": (C.c_int, [po_mma, TR_ITER_FN, C.c_void_p]),
     "po_wgram": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
     "po_wgram_with_rhs": (C.c_int, [po_vec, vec_p, C.c_int, c_double_p]),
+    "po_group_panel": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, vec_p]),
+    "po_wgram_with_groups": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double,
+                                       vec_p, C.c_int, c_double_p, c_int_p]),
     "po_bench_mdot": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p, c_double_p]),
     "po_bench_wgram": (C.c_int, [po_vec, vec_p, C.c_int, C.c_int, c_double_p]),
     "po_qn_get_pivots": (C.c_int, [po_qn, c_int_pp, c_int_p]),

@@ -209,6 +209,80 @@ def test_wgram_with_preweighted_rhs_column(ctx, n, nv):
     np.testing.assert_array_equal(W, W.T)
 
 
+def _group_sums(dn, P, nwcon, nw, skip, alpha):
+    """alpha * (rounded products d * p added in index order over each group): the arithmetic of both kernels."""
+    period = nw + skip
+    U = np.zeros((nwcon, P.shape[1]))
+    base = np.arange(nwcon) * period
+    for k in range(nw):
+        U = U + dn[base + k, None] * P[base + k, :]
+    return alpha * U
+
+
+@pytest.mark.parametrize("n,nwcon,nw,skip", [
+    (2000, 100, 20, 0),      # config 4's pattern: the groups cover every variable
+    (2001, 100, 20, 0),      # odd length
+    (3000, 100, 20, 0),      # ordinary tiles behind the group tiles
+    (70001, 3332, 20, 1),    # odd period: an even number of groups per tile
+    (70001, 9000, 7, 0),
+    (5000, 190, 24, 2),      # the widest group the fused form takes
+    (5000, 160, 11, 20),
+    (4001, 2000, 2, 0),      # 64 groups per tile, the last variable outside every group
+    (600, 25, 24, 0),        # a handful of tiles only
+])
+@pytest.mark.parametrize("nv,rhs_last", [(4, False), (5, True), (13, True), (24, False), (25, True), (36, True)])
+def test_wgram_with_structured_panel_image(ctx, n, nwcon, nw, skip, nv, rhs_last):
+    """The structured sparse-Jacobian panel image U = alpha Aw (d o P) riding in the Gram pass (wgram.hip: GramGeom):
+    U has the bits of the stand-alone kernel (and of the same sums in numpy), W is the weighted Gram."""
+    import paropt_amd as pa
+
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)]
+    dn = hnp(n, 9, scale=1.0, shift=0.5)
+    P = np.stack([hnp(n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)], axis=1)
+    ncols = nv - 1 if rhs_last else nv
+    U = [pa.PVec(ctx, nwcon) for _ in range(ncols)]
+    U2 = [pa.PVec(ctx, nwcon) for _ in range(ncols)]
+    for u in U:
+        u.set(123.0)
+    W, fused = pa.wgram_with_groups(d, V, nwcon, nw, skip, -1.0, U, rhs_last=rhs_last)
+    ref = P.T @ (dn[:, None] * P)
+    if rhs_last:
+        ref[:, nv - 1] = P.T @ P[:, nv - 1]
+        ref[nv - 1, :] = ref[:, nv - 1]
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
+    np.testing.assert_array_equal(W, W.T)
+    assert fused, "this shape is one the fused kernel covers"
+    pa.group_panel(d, V[:ncols], nwcon, nw, skip, -1.0, U2)
+    want = _group_sums(dn, P[:, :ncols], nwcon, nw, skip, -1.0)
+    for j in range(ncols):
+        np.testing.assert_array_equal(U2[j].to_numpy(), want[:, j])
+        np.testing.assert_array_equal(U[j].to_numpy(), want[:, j])
+
+
+@pytest.mark.parametrize("n,nwcon,nw,skip,nv", [(300, 10, 20, 0, 5),      # below the producer/consumer form's size
+                                                (5000, 30, 129, 0, 5),    # a group wider than a tile
+                                                (5000, 100, 25, 0, 5),    # ... than the sums' register budget
+                                                (5000, 100, 21, 0, 5),    # (an odd period IS covered: six groups per tile)
+                                                (5000, 100, 20, 0, 44)])  # wider than the instantiations that carry it
+def test_wgram_with_groups_declines_what_it_does_not_cover(ctx, n, nwcon, nw, skip, nv):
+    import paropt_amd as pa
+
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.1 * j) for j in range(nv)]
+    U = [pa.PVec(ctx, nwcon) for _ in range(nv)]
+    for u in U:
+        u.set(123.0)
+    W, fused = pa.wgram_with_groups(d, V, nwcon, nw, skip, -1.0, U)
+    if (nw + skip) == 21:
+        assert fused
+        np.testing.assert_allclose(W, pa.wgram(d, V), rtol=0, atol=1e-13 * n * 10)
+    else:
+        assert not fused
+        np.testing.assert_array_equal(W, pa.wgram(d, V))
+        assert all((u.to_numpy() == 123.0).all() for u in U)
+
+
 def test_live_mdot_timing_hook(ctx):
     """po_ctx_time_mdot: launches of exactly the requested width are timed with HIP events, others are not."""
     import paropt_amd as pa
