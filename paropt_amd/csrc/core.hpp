@@ -227,6 +227,25 @@ constexpr int kBpcStream = 4;  // workgroups per CU, few-stream kernels
 int grid_for(Ctx *c, int64_t n);           // persistent grid, kBpcStream workgroups per CU
 int grid_for(Ctx *c, int64_t n, int bpc);  // ... with an explicit workgroups-per-CU cap
 
+// A w-sized vector standing in for an n-sized panel column (round 4): element i of the column is
+// 0.0 + scale * w[g] when variable i is one of the first nw variables of group g = i / period (groups start at
+// variable 0, g < nwcon), else 0.0 -- exactly what k_group_scatter_set (wcon.hpp; Problem::setSparseJacobianTranspose
+// of the structured Jacobian) would write into an n-sized vector, formed in registers by the pass that would have
+// read that vector: one launch, one n-sized write and one n-sized read less per use.  The passes treat it as the LAST
+// column of their panel (same accumulation order as when it was a stored column).  n < 2^31.
+struct GroupCol {
+  const double *w = nullptr;  // nullptr: no such column
+  double scale = 0.0;
+  unsigned period = 1, nw = 0;
+  long long nwcon = 0;
+};
+
+struct GroupCols2 {  // up to two grouped columns behind a panel, with their coefficients in two coefficient sets
+  GroupCol g[2];
+  double ca[2] = {0.0, 0.0}, cb[2] = {0.0, 0.0};
+  int count = 0;
+};
+
 // ---- vector kernels (kernels.hip) -----------------------------------------------------------
 int k_fill(Ctx *c, double *y, int64_t n, double alpha);
 int k_fill_hash(Ctx *c, double *y, int64_t n, uint64_t seed, uint64_t aid, int64_t offset,
@@ -236,8 +255,9 @@ int k_sign(Ctx *c, double *y, const double *x, int64_t n);  // y_i = x_i >= 0 ? 
 int k_scale(Ctx *c, double *y, int64_t n, double alpha);
 int k_axpy(Ctx *c, double *y, double alpha, const double *x, int64_t n);
 // y <- a*x + b*y + sum_j alpha[j]*V[j]   (x may be null when a == 0; b == 0 never reads y)
+// ybase != nullptr: the b*y term reads that grouped column instead of y (y is only written)
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
-                 const double *const *V, int nv, int64_t n);
+                 const double *const *V, int nv, int64_t n, const GroupCol *ybase = nullptr);
 // y1 <- a1*x1 + sum_j c1[j]*V[j] and y2 <- a2*x2 + sum_j c2[j]*V[j] in ONE pass over V (nv <= kMaxPanel)
 int k_panel_axpy2(Ctx *c, double *y1, double a1, const double *x1, const double *c1, double *y2, double a2,
                   const double *x2, const double *c2, const double *const *V, int nv, int64_t n);
@@ -291,9 +311,10 @@ struct Bounds {  // the per-element data every bound-aware kernel needs
 // (computeKKTRes :1337-1446 + computeComp :2742-2820 + computeResNorm :1588-1723)
 // yqn != nullptr: the same pass also completes the quasi-Newton gradient difference, yqn += [lo]zl - [up]zu - rx
 // beta_mu2 >= 0: out has 13 entries, the last two are max|rzl|, max|rzu| for that second barrier term
+// gcol != nullptr: one more column with coefficient gcoef behind the nc columns of A
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
               int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn = nullptr,
-              double beta_mu2 = -1.0);
+              double beta_mu2 = -1.0, const GroupCol *gcol = nullptr, double gcoef = 0.0);
 // k_update_mult_yqn + k_kkt_res(..., yqn) in one pass (see kernels.hip): the bound multipliers take their step
 // zl <- max(zl + a pzl, eps) here, y_qn gets both brackets, rx / out are those of the new point
 int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z, int nc,
@@ -303,7 +324,8 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      // lean step (pxs != nullptr): pzl / pzu are not read but formed from the design step pxs, the
                      // old point xold and the old multipliers with the barrier term of the step's solve
                      const double *pxs = nullptr, const double *xold = nullptr, double beta_mu_step = 0.0,
-                     double beta_mu2 = -1.0);  // as k_kkt_res
+                     double beta_mu2 = -1.0,  // as k_kkt_res
+                     const GroupCol *gcol = nullptr, double gcoef = 0.0);  // as k_kkt_res
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);
@@ -352,7 +374,10 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   int store_step = 1,  // 0: nothing of the step, 1: px, pzl, pzu (and va), 2: px only
                   int ca0 = 0,  // the nca constraint columns are P[ca0 .. ca0 + nca)
                   const double *const *vs = nullptr, int nvirt = 0, double b0v = 0.0,  // P[j] - b0v vs[j], j < nvirt
-                  double dinv_diag = 0.0);  // t == nullptr: Dinv (this diagonal) and t re-formed from the bound data and rx
+                  double dinv_diag = 0.0,  // t == nullptr: Dinv (this diagonal) and t re-formed from the bound data and rx
+                  // grouped columns behind P (panel positions nv, nv + 1): they enter the two row sums with (ca, cb);
+                  // no panel dots are taken for them (out keeps its layout {dots[nv], max_x, max_z})
+                  const GroupCols2 *gcols = nullptr);
 // store_step == 0 above leaves (px, pzl, pzu, va) unwritten; this refinement pass recomputes that first step from
 // (t1, a1) and applies the refinement (t2, a2) on top in ONE sweep over P: out = {max_x, max_z} of the final step
 int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const double *dinv, const double *a1,
@@ -365,7 +390,9 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               // px.px | max_x, max_z | max|px|} of the final step (see solve2r_kernel) instead of `out`
               const double *g = nullptr, double *merit_out = nullptr,
               // t1 == nullptr: Dinv (diagonal dinv_diag) and t1 re-formed from the bound data and rx in registers
-              double dinv_diag = 0.0);
+              double dinv_diag = 0.0,
+              // stored right-hand side form: one more column behind P with coefficients gc1 / gc2 in the two sets
+              const GroupCol *gcol = nullptr, double gc1 = 0.0, double gc2 = 0.0);
 // (pzl, pzu) of a lean step as vectors: [L] (rzl - zl px) / (x - lb), [U] (rzu + zu px) / (ub - x)
 int k_form_pz(Ctx *c, const Bounds &b, const double *px, double beta_mu, int64_t n, double *pzl, double *pzu);
 // multiplier update fused with y_qn = rx - [lo]zl_old + [up]zu_old + az*va (see kernels.hip)

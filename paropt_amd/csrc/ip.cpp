@@ -440,7 +440,9 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       for (Vec *a : Ac) A.push_back(a->d);
       zc = vars.z;
     }
-    if (has_w) {  // + Aw^T zw as one more panel column (:1358-1361)
+    GroupCol gcol;  // + Aw^T zw as one more panel column (:1358-1361): described (structured problems) or stored
+    const bool have_gcol = has_w && !acz_mode && prob->sparseTransposeColumn(1.0, x, wvar[0], &gcol);
+    if (has_w && !have_gcol) {
       if (prob->setSparseJacobianTranspose(1.0, x, wvar[0], tvec) != 0) return PO_ERR_USER;
       A.push_back(tvec->d);
       zc.push_back(1.0);
@@ -454,10 +456,10 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
                               rx->d, out, yqn_complete ? yqn_complete->d : nullptr, zl->d, pzl->d, zu->d, pzu->d,
                               upd->a, upd->eps, (yqn_complete || az_acz != 0.0) ? vA->d : nullptr,
                               upd->az, acz_mode ? acz->d : nullptr, az_acz, pz_stored ? nullptr : px->d,
-                              pz_stored ? nullptr : xt->d, step_beta_mu, beta_mu2));
+                              pz_stored ? nullptr : xt->d, step_beta_mu, beta_mu2, have_gcol ? &gcol : nullptr, 1.0));
     } else {
       PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
-                       yqn_complete ? yqn_complete->d : nullptr, beta_mu2));
+                       yqn_complete ? yqn_complete->d : nullptr, beta_mu2, have_gcol ? &gcol : nullptr, 1.0));
     }
   } else {
     PO_TRY(k_res_norms(ctx, bounds(), beta_mu, n, out));
@@ -1627,10 +1629,15 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
   const bool fast_yqn = do_qn && analytic_panel_dots && ((!has_w && vA_valid) || fast_w);
   if (fast_w) {
     // vA <- sz Aw^T pzw + sum_j step.z[j] A_j   (step.z already carries sz: scaleKKTStep)
-    if (prob->setSparseJacobianTranspose(sz, x, wstepv[0], vA) != 0) return PO_ERR_USER;
     std::vector<const double *> Aold;
     for (Vec *a : Ac) Aold.push_back(a->d);
-    if (c > 0) PO_TRY(k_panel_axpy(ctx, vA->d, 0.0, nullptr, 1.0, step.z.data(), Aold.data(), c, n));
+    GroupCol gcol;  // (structured problems: the first term is formed by the pass itself)
+    if (prob->sparseTransposeColumn(sz, x, wstepv[0], &gcol)) {
+      PO_TRY(k_panel_axpy(ctx, vA->d, 0.0, nullptr, 1.0, step.z.data(), Aold.data(), c, n, &gcol));
+    } else {
+      if (prob->setSparseJacobianTranspose(sz, x, wstepv[0], vA) != 0) return PO_ERR_USER;
+      if (c > 0) PO_TRY(k_panel_axpy(ctx, vA->d, 0.0, nullptr, 1.0, step.z.data(), Aold.data(), c, n));
+    }
   }
   if (has_w) PO_TRY(k_w_update(ctx, wv(), wp(), alpha * sx, alpha * sz, eps, nw));  // :4177-4183
   // acz = A^T z follows z += alpha*sz*pz through va = A^T pz when the solves kept va; otherwise it is rebuilt

@@ -229,18 +229,35 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
     PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2, wyw));  // ... and wyw += wtmp2
-    if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    // the two extra columns Aw^T wtmp2 (coefficient 1 in the step's row sum) and Aw^T pzw (1 in the residual's): n-sized
+    // vectors from Problem::setSparseJacobianTranspose, or -- structured problems -- described and formed by the pass
+    GroupCols2 gcs;
+    const bool grouped = prob->sparseTransposeColumn(1.0, x, wtmp2, &gcs.g[0]);
+    if (!grouped && prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     // sparse blocks of the step first: pzw = wstepv[0] feeds the residual column Aw^T pzw (its minima wait for
     // those of the design blocks unless user code runs in between)
     if (prob->reductionsBatchable()) minbatch.begin();
     PO_TRY(k_w_step(ctx, wv(), wr(), wyw->d, 0, tau, wp(), nw, mins_w));
-    if (prob->setSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) return PO_ERR_USER;
+    if (grouped) {
+      if (!prob->sparseTransposeColumn(1.0, x, wstepv[0], &gcs.g[1])) {
+        set_error("internal: the problem describes one sparse transpose column but not the other");
+        return PO_ERR_ARG;
+      }
+      gcs.count = 2;
+      gcs.ca[0] = 1.0;
+      gcs.cb[1] = 1.0;
+    } else if (prob->setSparseJacobianTranspose(1.0, x, wstepv[0], xt) != 0) {
+      return PO_ERR_USER;
+    }
     std::vector<const double *> P1(P);
     std::vector<double> a1(alpha.begin(), alpha.begin() + m), c2(m + 2, 0.0);
-    P1.push_back(d1v->d);
-    a1.push_back(1.0);
-    P1.push_back(xt->d);
-    a1.push_back(0.0);
+    if (!grouped) {
+      P1.push_back(d1v->d);
+      a1.push_back(1.0);
+      P1.push_back(xt->d);
+      a1.push_back(0.0);
+    }
+    const int np1 = (int)P1.size();
     for (int i = 0; i < c; i++) c2[i] = alpha[i];  // = step.z
     double diag = options.real("qn_sigma");
     if (qn && !seq_lin) {
@@ -258,25 +275,32 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     // Of the step only px is stored (w_lean): the refinement's sparse rows need Aw px as a vector, the bound-
     // multiplier steps are re-formed from px by the refinement pass (two output streams less)
     const int sstep = w_lean ? 2 : 1;
-    PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, a1.data(), c2.data(), P1.data(), m + 2, beta_mu, tau,
-                         rx->d, diag, n, px->d, pzl->d, pzu->d, nullptr, nullptr, 0, so.data(), y_qn->d, sstep));
+    PO_TRY(k_solve2_dots(ctx, bounds(), tvec->d, Dinv->d, a1.data(), c2.data(), P1.data(), np1, beta_mu, tau,
+                         rx->d, diag, n, px->d, pzl->d, pzu->d, nullptr, nullptr, 0, so.data(), y_qn->d, sstep, 0,
+                         nullptr, 0, 0.0, 0.0, grouped ? &gcs : nullptr));
     px_first_only = sstep == 2;
     std::swap(d1v->d, y_qn->d);
     PO_TRY(minbatch.end());
     tdots.assign(so.begin(), so.begin() + m);
     tdots_valid = true;
     residual_fused = true;
-    mins_x[0] = so[m + 2];
-    mins_x[1] = so[m + 3];
+    mins_x[0] = so[np1];  // out = {dots[np1], max_x, max_z}
+    mins_x[1] = so[np1 + 1];
   } else if (m > 0 && (int)Uw.size() >= m && panel_valid) {
     std::vector<const double *> Uc(m);
     for (int j = 0; j < m; j++) Uc[j] = Uw[j]->d;
     PO_TRY(prob->sparseCorrection(Uc.data(), m, alpha.data(), Cw, wtmp2, wyw));  // ... and wyw += wtmp2
-    if (prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
+    // the extra column Aw^T wtmp2 (coefficient 1): stored, or (structured problems, refinement of a px-only first
+    // step) described and formed by the pass itself
+    GroupCol gcol;
+    const bool grouped = first_px_only && prob->sparseTransposeColumn(1.0, x, wtmp2, &gcol);
+    if (!grouped && prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     std::vector<const double *> P1(P);
     std::vector<double> a1(alpha.begin(), alpha.begin() + m);
-    P1.push_back(d1v->d);
-    a1.push_back(1.0);
+    if (!grouped) {
+      P1.push_back(d1v->d);
+      a1.push_back(1.0);
+    }
     minbatch.begin();
     if (first_px_only) {
       // Refinement on top of a first step of which only px was stored: solve2r_kernel in its stored right-hand side
@@ -289,9 +313,10 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
       const bool lean = take_merit && lean_step && lean_step_allowed && iterate_logs_valid && fast_yqn_w &&
                         !prob->linear_constraints && options.integer("iterative_refinement_steps") == 1;
       std::vector<double> azero(m + 1, 0.0);
-      PO_TRY(k_solve2r(ctx, bounds(), px->d, tvec->d, Dinv->d, azero.data(), a1.data(), P1.data(), m + 1, beta_mu, tau,
-                       n, xt->d, lean ? nullptr : pzl->d, lean ? nullptr : pzu->d, nullptr, 0, mins_x, nullptr, nullptr,
-                       0.0, 0, nullptr, 0, 0.0, take_merit ? g->d : nullptr, take_merit ? fused_merit : nullptr, 0.0));
+      PO_TRY(k_solve2r(ctx, bounds(), px->d, tvec->d, Dinv->d, azero.data(), a1.data(), P1.data(), (int)P1.size(), beta_mu,
+                       tau, n, xt->d, lean ? nullptr : pzl->d, lean ? nullptr : pzu->d, nullptr, 0, mins_x, nullptr,
+                       nullptr, 0.0, 0, nullptr, 0, 0.0, take_merit ? g->d : nullptr,
+                       take_merit ? fused_merit : nullptr, 0.0, grouped ? &gcol : nullptr, 0.0, 1.0));
       std::swap(px->d, xt->d);
       if (lean) {
         pz_stored = false;

@@ -346,6 +346,38 @@ __device__ __forceinline__ double2 panel_sum(const PtrTable &P, const CoefTable 
   return make_double2(acc.x, acc.y);
 }
 
+// The pair (2q, 2q+1) of a grouped column (core.hpp: GroupCol), as k_group_scatter_set would have stored it, in two
+// steps: gcol_request issues the two loads (clamped indices, no arithmetic on the loaded values: nothing waits for
+// them), gcol_value turns them into the column's entries where they are consumed.  (With the arithmetic inside the
+// request, a prefetch of the next tile waited for ALL its loads on the spot: solve2_dots lost 16 %.)
+struct GRaw {
+  f64x2 raw;
+  int valid;  // bit 0 / 1: element 2q / 2q + 1 belongs to a group
+};
+__device__ __forceinline__ GRaw gcol_request(const GroupCol &gc, int64_t q, int64_t n) {
+  GRaw r;
+  const unsigned r0 = (unsigned)(2 * q);
+  const unsigned g0 = r0 / gc.period, k0 = r0 - g0 * gc.period;
+  unsigned g1 = g0, k1 = k0 + 1;
+  if (k1 == gc.period) {
+    g1 = g0 + 1;
+    k1 = 0;
+  }
+  const bool v0 = k0 < gc.nw && (long long)g0 < gc.nwcon;
+  const bool v1 = k1 < gc.nw && (long long)g1 < gc.nwcon && 2 * q + 1 < n;
+  const unsigned last = (unsigned)(gc.nwcon - 1);
+  r.raw.x = gc.w[g0 < last ? g0 : last];
+  r.raw.y = gc.w[g1 < last ? g1 : last];
+  r.valid = (v0 ? 1 : 0) | (v1 ? 2 : 0);
+  return r;
+}
+__device__ __forceinline__ f64x2 gcol_value(const GroupCol &gc, const GRaw &r) {
+  f64x2 v;
+  v.x = (r.valid & 1) ? __dadd_rn(0.0, __dmul_rn(gc.scale, r.raw.x)) : 0.0;
+  v.y = (r.valid & 2) ? __dadd_rn(0.0, __dmul_rn(gc.scale, r.raw.y)) : 0.0;
+  return v;
+}
+
 // two coefficient sets over the same panel in one pass (solve + refinement residual)
 template <int B>
 __device__ __forceinline__ void panel_batch2(const PtrTable &P, const CoefTable &a, const CoefTable &b2,
@@ -435,8 +467,10 @@ __device__ __forceinline__ void panel_sum3(const PtrTable &P, const CoefTable &a
 // y <- a*x + b*y + sum_j alpha_j V_j : runtime panel width, no per-column registers needed.
 __global__ void __launch_bounds__(kBlock)
     panel_axpy_kernel(double *__restrict__ y, double a, const double *__restrict__ x, double b,
-                      CoefTable alpha, PtrTable V, int nv, int64_t n) {
+                      CoefTable alpha, PtrTable V, int nv, int64_t n, GroupCol ybase) {
   PO_PAIR_LOOP(q, n) {
+    GRaw graw;
+    if (ybase.w && b != 0.0) graw = gcol_request(ybase, q, n);
     double2 acc = make_double2(0.0, 0.0);
     if (a != 0.0) {
       double2 v = ld2(x, q, n);
@@ -444,7 +478,13 @@ __global__ void __launch_bounds__(kBlock)
       acc.y = a * v.y;
     }
     if (b != 0.0) {
-      double2 v = ld2(y, q, n);
+      double2 v;
+      if (ybase.w) {
+        const f64x2 gbv = gcol_value(ybase, graw);
+        v = make_double2(gbv.x, gbv.y);
+      } else {
+        v = ld2(y, q, n);
+      }
       acc.x += b * v.x;
       acc.y += b * v.y;
     }
@@ -486,18 +526,20 @@ static void fill_tables(const double *alpha, const double *const *V, int nv, Coe
 }
 
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
-                 const double *const *V, int nv, int64_t n) {
+                 const double *const *V, int nv, int64_t n, const GroupCol *ybase) {
   if (n <= 0) return PO_OK;
   // panels wider than one kernel's argument tables go in slabs: the first carries a*x + b*y, the others accumulate
   int j0 = 0;
   do {
     const int w = nv - j0 > kMaxPanel ? kMaxPanel : nv - j0;
     const double aa = j0 == 0 ? a : 0.0, bb = j0 == 0 ? b : 1.0;
-    count_bytes(c, w + 1 + (aa != 0.0 ? 1 : 0) + (bb != 0.0 ? 1 : 0), n);
+    const bool gb = ybase && ybase->w && j0 == 0 && bb != 0.0;  // the b*y term of the first slab from the grouped column
+    count_bytes(c, w + 1 + (aa != 0.0 ? 1 : 0) + ((bb != 0.0 && !gb) ? 1 : 0), n);
+    if (gb) count_bytes(c, 1.0, ybase->nwcon);
     CoefTable ct;
     PtrTable pt;
     fill_tables(alpha ? alpha + j0 : nullptr, V ? V + j0 : nullptr, w, &ct, &pt);
-    PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, kBpcPanel), y, aa, x, bb, ct, pt, w, n);
+    PO_LAUNCH(panel_axpy_kernel, grid_for(c, n, kBpcPanel), y, aa, x, bb, ct, pt, w, n, gb ? *ybase : GroupCol());
     j0 += w;
   } while (j0 < nv);
   return PO_OK;
@@ -884,7 +926,7 @@ __device__ __forceinline__ void res_bound_max2(const BE &e, double beta_mu2, dou
 __global__ void __launch_bounds__(kBlock)
     kkt_res_kernel(Bounds b, const double *__restrict__ g, PtrTable A, CoefTable z, int nc,
                    double beta_mu, int64_t n, double *__restrict__ rx, double *__restrict__ yqn,
-                   double beta_mu2, double *__restrict__ partials) {
+                   double beta_mu2, GroupCol gcol, double gcoef, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -902,7 +944,15 @@ __global__ void __launch_bounds__(kBlock)
     }
     r.x += -1.0 * gv.x;
     r.y += -1.0 * gv.y;
-    const double2 ps = panel_sum(A, z, nc, q);
+    // (the grouped column's entries are requested before the panel: its two dependent loads overlap the panel's)
+    GRaw graw;
+    if (gcol.w) graw = gcol_request(gcol, q, n);
+    double2 ps = panel_sum(A, z, nc, q);
+    if (gcol.w) {
+      const f64x2 gcv = gcol_value(gcol, graw);
+      ps.x += gcoef * gcv.x;
+      ps.y += gcoef * gcv.y;
+    }
     r.x += ps.x;
     r.y += ps.y;
     if (!_has2) r.y = 0.0;
@@ -935,11 +985,12 @@ __global__ void __launch_bounds__(kBlock)
 }
 
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
-              int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn, double beta_mu2) {
+              int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn, double beta_mu2,
+              const GroupCol *gcol, double gcoef) {
   if (nc > kMaxPanel) {  // wide A^T z: one collapsed column
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
-    return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, beta_mu2);
+    return k_kkt_res(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, beta_mu2, gcol, gcoef);
   }
   count_bytes(c, 7 + nc + (yqn ? 2 : 0), n);
   const int grid = grid_for(c, n, kBpcPanel);
@@ -947,7 +998,9 @@ int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, 
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
-  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, beta_mu2, c->d_partials);
+  if (gcol) count_bytes(c, 1.0, gcol->nwcon);
+  PO_LAUNCH(kkt_res_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, beta_mu2, gcol ? *gcol : GroupCol(), gcoef,
+            c->d_partials);
   return reduce_finish(c, grid, 8, 0, beta_mu2 >= 0.0 ? 5 : 3, out);
 }
 
@@ -1232,12 +1285,14 @@ __global__ void __launch_bounds__(kBlock)
                    double beta_mu, double tau, const double *__restrict__ rx, double diag, int64_t n,
                    double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                    double *__restrict__ va, int nca, int ca0, VirtCols vc, const double *__restrict__ g,
-                   double dinv_diag, double *__restrict__ partials) {
+                   double dinv_diag, GroupCol gcol, double gc1, double gc2, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double mins[2] = {1.0, 1.0};
   double ms[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double mx[1] = {0.0};
   PO_PAIR_LOOP(q, n) {
+    GRaw graw;  // the grouped column's entries: requested first, used behind the panel sums
+    if (!RECT && gcol.w) graw = gcol_request(gcol, q, n);
     const double2 zero2 = make_double2(0.0, 0.0);
     double2 a1A = zero2, a2A = zero2, acc1 = zero2, acc2 = zero2, arA = zero2, accr = zero2;
     if (RECT) {
@@ -1251,6 +1306,13 @@ __global__ void __launch_bounds__(kBlock)
     } else {
       panel_sum2(P, a1, a2, nca, q, a1A, a2A);
       panel_sum2(P, a1, a2, nv, q, acc1, acc2, nca);
+      if (gcol.w) {  // one more column behind the panel (core.hpp: GroupCol), coefficients gc1 / gc2
+        const f64x2 gv = gcol_value(gcol, graw);
+        acc1.x += gc1 * gv.x;
+        acc1.y += gc1 * gv.y;
+        acc2.x += gc2 * gv.x;
+        acc2.y += gc2 * gv.y;
+      }
     }
     acc1.x += a1A.x;
     acc1.y += a1A.y;
@@ -1339,8 +1401,14 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               const double *a2, const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px,
               double *pzl, double *pzu, double *va, int nca, double out[2], const double *ar, const double *rx,
               double diag, int ca0, const double *const *vs, int nvirt, double b0v, const double *g,
-              double *merit_out, double dinv_diag) {
+              double *merit_out, double dinv_diag, const GroupCol *gcol, double gc1, double gc2) {
   count_bytes(c, nv + nvirt + 7 + (t1 ? 2 : 0) + (pzl ? 2 : 0) + (va ? 1 : 0) + (g ? 1 : 0), n);
+  if (gcol && t2 == nullptr) {
+    set_error("k_solve2r: a grouped column is only taken in the stored right-hand side form");
+    return PO_ERR_ARG;
+  }
+  if (gcol) count_bytes(c, 1.0, gcol->nwcon);
+  const GroupCol gcv = gcol ? *gcol : GroupCol();
   if (!t1 && (t2 != nullptr || !rx)) {
     set_error("k_solve2r: Dinv / t can only be re-formed in the recomputed right-hand side form");
     return PO_ERR_ARG;
@@ -1380,21 +1448,21 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
     }
     if (g && merit_out) {
       PO_LAUNCH((solve2r_kernel<1, 1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px,
-                pzl, pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+                pzl, pzu, va, nca, ca0, vc, g, dinv_diag, gcv, gc1, gc2, c->d_partials);
       // {7 sums, 2 minima, 1 maximum} land in merit_out[0..10); the minima are copied to `out` by the caller's hook
       (void)out;
       return reduce_finish(c, grid, 7, 2, 1, merit_out);
     }
     PO_LAUNCH((solve2r_kernel<1, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+              pzu, va, nca, ca0, vc, g, dinv_diag, gcv, gc1, gc2, c->d_partials);
   } else if (g && merit_out) {
     PO_LAUNCH((solve2r_kernel<0, 1>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+              pzu, va, nca, ca0, vc, g, dinv_diag, gcv, gc1, gc2, c->d_partials);
     (void)out;
     return reduce_finish(c, grid, 7, 2, 1, merit_out);
   } else {
     PO_LAUNCH((solve2r_kernel<0, 0>), grid, b, t1, t2, dinv, ct1, ct2, ctr, pt, nv, beta_mu, tau, rx, diag, n, px, pzl,
-              pzu, va, nca, ca0, vc, g, dinv_diag, c->d_partials);
+              pzu, va, nca, ca0, vc, g, dinv_diag, gcv, gc1, gc2, c->d_partials);
   }
   return reduce_finish(c, grid, 0, 2, 0, out);
 }
@@ -1458,7 +1526,8 @@ __global__ void __launch_bounds__(kBlock, OCC)
                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
                        double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
-                       int store_step, int ca0, VirtCols vc, double dinv_diag, double *__restrict__ partials) {
+                       int store_step, int ca0, VirtCols vc, double dinv_diag, GroupCols2 gcs,
+                       double *__restrict__ partials) {
   extern __shared__ double s2lds[];  // [4][NPASS][128] column slices, [4*64*6] partial sums, [128] t', [8]
   double *pt = s2lds;
   double *sacc = s2lds + 4 * NPASS * kS2Tile;
@@ -1475,6 +1544,11 @@ __global__ void __launch_bounds__(kBlock, OCC)
   const int64_t qlast = (n - 1) >> 1;
   f64x2 buf[NPASS];
   f64x2 sbuf[VIRT ? 3 : 1];  // S partners of this wave's unformed L-SR1 columns (they lead the panel: j < 12)
+  // the grouped column this wave adds behind its own columns (if any), prefetched with them
+  const int gmine = (gcs.count > 0 && wave == (nv & 3)) ? 0 : ((gcs.count > 1 && wave == ((nv + 1) & 3)) ? 1 : -1);
+  GRaw gbuf;
+  gbuf.raw = (f64x2){0.0, 0.0};
+  gbuf.valid = 0;
   f64x2 eb[8];  // wave 0: x, lb, ub, zl, zu, t, dinv, rx of the tile
   int64_t q = 0;
   bool in = false;
@@ -1493,6 +1567,7 @@ __global__ void __launch_bounds__(kBlock, OCC)
         sbuf[it] = ld_stream(vc.s[j < vc.count ? j : 0] + 2 * q);                            \
       }                                                                                      \
     }                                                                                        \
+    if (gmine >= 0) gbuf = gcol_request(gcs.g[gmine], q, n);                                 \
   }
 #define PO_S2_PREFETCH_E(Q)                                                                  \
   {                                                                                          \
@@ -1529,6 +1604,14 @@ __global__ void __launch_bounds__(kBlock, OCC)
       a2 += cb * v;
       aA += cA * v;
       *reinterpret_cast<f64x2 *>(myslice + it * kS2Tile) = v;
+    }
+    // grouped columns (core.hpp: GroupCol) at panel positions nv, nv + 1: the wave that would have held them as
+    // stored columns adds them behind its own columns (same order of additions)
+    if (gmine >= 0) {
+      f64x2 v = gcol_value(gcs.g[gmine], gbuf);
+      if (!inc) v = (f64x2){0.0, 0.0};
+      a1 += gcs.ca[gmine] * v;
+      a2 += gcs.cb[gmine] * v;
     }
     // [value][wave][lane]: consecutive lanes hit consecutive 8-byte slots (the [lane][value] layout of round 2's
     // first version cost 21 % LDS bank-conflict cycles, profiles/r02_pmc_counters.json)
@@ -1638,7 +1721,8 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
                               double tau, const double *rx, double diag, int64_t n, int64_t ntiles, double *px,
                               double *pzl, double *pzu, double *tout, double *va, int nca, double *traw,
-                              int store_step, int ca0, const VirtCols &vc, double dinv_diag, int *grid_out) {
+                              int store_step, int ca0, const VirtCols &vc, double dinv_diag, int *grid_out,
+                              const GroupCols2 &gcs) {
   const size_t lds = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1655,7 +1739,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
   hipLaunchKernelGGL((solve2_dots_kernel<NP, OCC, VIRT>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt, nv,
                      beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc,
-                     dinv_diag, c->d_partials);
+                     dinv_diag, gcs, c->d_partials);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;
@@ -1671,13 +1755,13 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     constexpr int OV = NP <= 16 ? 2 : 1; /* with unformed columns: three more prefetch registers */        \
     if (vc.count > 0)                                                                                      \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
     else if (occ_env == OA || (occ_env == 0 && store_step && NP <= 8))                                     \
       PO_TRY((solve2_dots_launch<NP, OA, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
     else                                                                                                   \
       PO_TRY((solve2_dots_launch<NP, OD, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
-                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid))); \
+                                            px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
   } break;
 
 // out = {dots[nv] = P^T t', max_x, max_z}
@@ -1685,8 +1769,10 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *coef2, const double *const *P, int nv, double beta_mu, double tau,
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
                   double *tout, double *va, int nca, double *out, double *traw, int store_step, int ca0,
-                  const double *const *vs, int nvirt, double b0v, double dinv_diag) {
+                  const double *const *vs, int nvirt, double b0v, double dinv_diag, const GroupCols2 *gcols) {
   count_bytes(c, nv + nvirt + 6 + (t ? 2 : 0) + (store_step ? 3 + (va ? 1 : 0) : 0) + ((traw || tout) ? 1 : 0), n);
+  const GroupCols2 gcs = gcols ? *gcols : GroupCols2();
+  for (int e = 0; e < gcs.count; e++) count_bytes(c, 1.0, gcs.g[e].nwcon);
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
     return PO_ERR_ARG;
@@ -2085,11 +2171,14 @@ __global__ void __launch_bounds__(kBlock)
                           const double *__restrict__ pzl, double *__restrict__ zu, const double *__restrict__ pzu,
                           double a, double eps, const double *__restrict__ va, double az, double *__restrict__ acz,
                           double az_acz, const double *__restrict__ pxs, const double *__restrict__ xold,
-                          double beta_mu_step, double beta_mu2, double *__restrict__ partials) {
+                          double beta_mu_step, double beta_mu2, GroupCol gcol, double gcoef,
+                          double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   PO_PAIR_LOOP(q, n) {
+    GRaw graw;  // the grouped column's entries: requested first, used by the panel sum below
+    if (gcol.w) graw = gcol_request(gcol, q, n);
     const double2 _x = ld2(b.x, q, n), _lb = ld2(b.lb, q, n), _ub = ld2(b.ub, q, n);
     // pxs != nullptr ("lean step"): the refinement pass did not store the bound-multiplier steps; they are formed
     // here from the design step px, the OLD point (xold) and the old multipliers by the first-solve formula
@@ -2162,6 +2251,11 @@ __global__ void __launch_bounds__(kBlock)
       ps = make_double2(fma(1.0, aczv.x, 0.0), fma(1.0, aczv.y, 0.0));
     } else {
       ps = panel_sum(A, z, nc, q);
+      if (gcol.w) {
+        const f64x2 gcv = gcol_value(gcol, graw);
+        ps.x += gcoef * gcv.x;
+        ps.y += gcoef * gcv.y;
+      }
     }
     r.x += ps.x;
     r.y += ps.y;
@@ -2196,12 +2290,16 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      double beta_mu, int64_t n, double *rx, double *out, double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz, const double *pxs, const double *xold,
-                     double beta_mu_step, double beta_mu2) {
+                     double beta_mu_step, double beta_mu2, const GroupCol *gcol, double gcoef) {
+  if (acz && gcol) {
+    set_error("kkt_res_update: a grouped column cannot follow the A^T z vector of the linear-constraint mode");
+    return PO_ERR_ARG;
+  }
   if (nc > kMaxPanel) {
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
     return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz,
-                            pxs, xold, beta_mu_step, beta_mu2);
+                            pxs, xold, beta_mu_step, beta_mu2, gcol, gcoef);
   }
   count_bytes(c, (yqn ? 14 : 11) + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
   const int grid = grid_for(c, n, kBpcPanel);
@@ -2209,8 +2307,9 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
   PtrTable pt;
   CoefTable ct;
   fill_tables(z, A, nc, &ct, &pt);
+  if (gcol) count_bytes(c, 1.0, gcol->nwcon);
   PO_LAUNCH(kkt_res_update_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz,
-            az_acz, pxs, xold, beta_mu_step, beta_mu2, c->d_partials);
+            az_acz, pxs, xold, beta_mu_step, beta_mu2, gcol ? *gcol : GroupCol(), gcoef, c->d_partials);
   return reduce_finish(c, grid, 8, 0, beta_mu2 >= 0.0 ? 5 : 3, out);
 }
 

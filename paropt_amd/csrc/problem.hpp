@@ -60,6 +60,9 @@ class Problem {
   // out <- alpha Aw(x)^T pzw (overwrites): by default a zero fill followed by the call above; a problem that can
   // write every entry in one pass overrides it
   virtual int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
+  // Structured problems describe that n-sized vector instead of writing it (core.hpp: GroupCol): the pass that would
+  // have read it forms its entries from pzw in registers.  false (the default): the caller materialises the vector.
+  virtual bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) { return false; }
   virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A);
   // U_j = Aw (d o P_j) for a whole panel; the default goes column by column through
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
@@ -190,6 +193,7 @@ class SeparableProblem : public Problem {
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override;
   int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override;
   bool sparseGramGroups(Vec *x, GramGroups *g) override;
+  bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) override;
   int setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;

@@ -502,6 +502,16 @@ int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P
   return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
 }
 
+bool SeparableProblem::sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) {
+  static const bool off = getenv("PAROPT_AMD_NO_GROUP_COLS") != nullptr;
+  if (off || csr || nwcon <= 0 || gmap.start != 0 || nlocal >= 2000000000LL) return false;
+  col->w = pzw->d;
+  col->scale = -alpha;  // Aw = -(group indicator): the value k_group_scatter_set(..., -alpha, ...) stores
+  col->period = (unsigned)(gmap.nw + gmap.skip);
+  col->nw = (unsigned)gmap.nw;
+  col->nwcon = gmap.nwcon;
+  return true;
+}
 bool SeparableProblem::sparseGramGroups(Vec *x, GramGroups *g) {
   if (csr || nwblock > 1 || nwcon <= 0) return false;
   g->nwcon = gmap.nwcon;

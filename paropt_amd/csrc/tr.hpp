@@ -94,6 +94,9 @@ class TrustRegionSubproblem : public Problem {
   }
   int sparseFactor(Vec *, Vec *d, Vec *cw) override { return prob->sparseFactor(xk, d, cw); }
   bool sparseGramGroups(Vec *, GramGroups *g) override { return prob->sparseGramGroups(xk, g); }
+  bool sparseTransposeColumn(double alpha, Vec *, Vec *pzw, GroupCol *col) override {
+    return prob->sparseTransposeColumn(alpha, xk, pzw, col);
+  }
   int sparseFactorFromSlacks(Vec *, Vec *d, const WVars &v, Vec *cw) override {
     return prob->sparseFactorFromSlacks(xk, d, v, cw);
   }
@@ -214,6 +217,9 @@ class InfeasSubproblem : public Problem {  // :468-650
   }
   int sparseFactor(Vec *x, Vec *d, Vec *cw) override { return sub->sparseFactor(x, d, cw); }
   bool sparseGramGroups(Vec *x, GramGroups *g) override { return sub->sparseGramGroups(x, g); }
+  bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) override {
+    return sub->sparseTransposeColumn(alpha, x, pzw, col);
+  }
   int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override {
     return sub->sparseFactorFromSlacks(x, d, v, cw);
   }
