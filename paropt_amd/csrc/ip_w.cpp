@@ -232,7 +232,8 @@ int InteriorPoint::solveKKTW(const Dense &b, double mu, bool use_qn, bool refine
     // the two extra columns Aw^T wtmp2 (coefficient 1 in the step's row sum) and Aw^T pzw (1 in the residual's): n-sized
     // vectors from Problem::setSparseJacobianTranspose, or -- structured problems -- described and formed by the pass
     GroupCols2 gcs;
-    const bool grouped = prob->sparseTransposeColumn(1.0, x, wtmp2, &gcs.g[0]);
+    static const bool s2d_grouped = getenv("PAROPT_AMD_GROUP_COLS_S2D") ? atoi(getenv("PAROPT_AMD_GROUP_COLS_S2D")) != 0 : true;
+    const bool grouped = s2d_grouped && prob->sparseTransposeColumn(1.0, x, wtmp2, &gcs.g[0]);
     if (!grouped && prob->setSparseJacobianTranspose(1.0, x, wtmp2, d1v) != 0) return PO_ERR_USER;
     // sparse blocks of the step first: pzw = wstepv[0] feeds the residual column Aw^T pzw (its minima wait for
     // those of the design blocks unless user code runs in between)
