@@ -25,7 +25,7 @@ sub["C4_DOUBLES"] = "%.0f" % (c4["iteration_bytes"] / 8 / c4["config"]["n_global
 sub["C4_GB"] = "%.1f" % (c4["iteration_bytes"] / 1e9)
 sub["MDOT_MS"] = "%.2f" % c3["roofline"]["avg_launch_ms"]
 sub["MDOT_FRAC"] = "%.2f" % c3["roofline"]["frac"]
-sub["WGRAM_C3"] = k3("wgram_pc_kernel<11,3,1>")
+sub["WGRAM_C3"] = k3("wgram_pc_kernel<11,3,1,0>")
 sub["WGRAM_C4"] = "%.2f ms" % p4["wgram_pc_kernel<7,0,1,1>"][1] if "wgram_pc_kernel<7,0,1,1>" in p4 else "1.07 ms"
 sub["KKT_C3"] = k3("kkt_res_update_kernel")
 sub["DINV_C3"] = k3("dinv_d1_kernel")
@@ -52,7 +52,7 @@ def line(tag, r, extra=""):
         cb.get("value", float("nan")), cb.get("whole_run_it_per_s", float("nan")), cb.get("cores", 0), extra)
 sub["RECORD_TABLE"] = "\n".join([
     line("2: quadratic, n = 10 M, m = 8, L-BFGS(20)", c2, "292–295 it/s (under the profiler)"),
-    line("3: convex, n = 50 M, m = 32, L-SR1(10) — the metric", c3, "42.9 it/s (40.6 on its slowest box)"),
+    line("3: convex, n = 50 M, m = 32, L-SR1(10) — the metric", c3, "42.9 it/s (40.6 on its slowest box); this round 40.6 on a box whose copy ceiling was 5.3 TB/s (`r04_bench_c3_slow_store_box.json`)"),
     line("4: n = 20 M, m = 4, 1 M weighting constraints, L-BFGS(10)", c4, "125.4 it/s, 85 launches, 8 syncs"),
     line("5: trust region + eigenvalue model, n = 5 M", c5, "10.3 TR it/s = 664 inner it/s, 29.8 / 9.1"),
 ])
