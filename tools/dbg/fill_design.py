@@ -61,7 +61,7 @@ def shares(p, n=7):
     return ", ".join("`%s` %.1f %%%s" % (k.rstrip(","), v[2], (" (%s)" % v[3]) if v[3] else "") for k, v in rows)
 sub["C3_SHARES"] = shares(p3)
 sub["C4_PMC"] = shares(p4, 9)
-sub["PER_RANK"] = "23.5 / 11.8 / 5.93 / 3.09 ms per iteration at n/1, n/2, n/4, n/8 (`profiles/r03_per_rank_sizes.txt`: 95–98 % of perfect before any collective)"
+sub["PER_RANK"] = "config 3: 23.35 / 11.60 / 5.85 / 3.02 ms per iteration at n/1, n/2, n/4, n/8 (96.5 % of perfect before any collective); config 4: 5.74 / 2.99 / 1.62 ms at n/1, n/2, n/4 (88.9 %) (`profiles/r04_per_rank_sizes.txt`, `tools/per_rank_sizes.sh`)"
 sub["PRED"] = "≈ 90 %"
 src = open(os.path.join(R, "tools", "dbg", "DESIGN.md.in")).read()
 missing = set(re.findall(r"@([A-Z0-9_]+)@", src)) - set(sub)
