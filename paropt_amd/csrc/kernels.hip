@@ -1770,7 +1770,7 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *rx, double diag, int64_t n, double *px, double *pzl, double *pzu,
                   double *tout, double *va, int nca, double *out, double *traw, int store_step, int ca0,
                   const double *const *vs, int nvirt, double b0v, double dinv_diag, const GroupCols2 *gcols) {
-  count_bytes(c, nv + nvirt + 6 + (t ? 2 : 0) + (store_step ? 3 + (va ? 1 : 0) : 0) + ((traw || tout) ? 1 : 0), n);
+  count_bytes(c, nv + nvirt + 6 + (t ? 2 : 0) + (store_step == 1 ? 3 + (va ? 1 : 0) : (store_step == 2 ? 1 : 0)) + ((traw || tout) ? 1 : 0), n);
   const GroupCols2 gcs = gcols ? *gcols : GroupCols2();
   for (int e = 0; e < gcs.count; e++) count_bytes(c, 1.0, gcs.g[e].nwcon);
   if (nv > kMaxPanel || nv < 1) {
