@@ -398,7 +398,8 @@ int po_ip_get_quasi_newton(po_ip ip, po_qn *qn);            /* borrowed */
 int po_ip_write_solution_file(po_ip ip, const char *filename); /* .cpp:883-972 */
 int po_ip_read_solution_file(po_ip ip, const char *filename);  /* .cpp:983-1104 (restart) */
 /* Per-iteration observer, called at the point the reference calls prob->writeOutput
- * (.cpp:4620-4630); used by the parity tests to snapshot the state. */
+ * (.cpp:4620-4630); used by the parity tests to snapshot the state.  An OBSERVER: it may read the iterate (also through
+ * po_vec_get_array views) but must not write it mid-solve -- sums of the current point are carried between passes. */
 typedef int (*po_ip_iteration_fn)(void *user, int iter);
 int po_ip_set_iteration_callback(po_ip ip, po_ip_iteration_fn fn, void *user);
 /* The iteration table of the last optimize() in the reference's paropt.out column layout

@@ -1246,7 +1246,15 @@ int InteriorPoint::scaleKKTStep(double tau, double comp, double *alpha_x, double
     // sum of the iterate's sparse slacks from its residual pass)
     if (has_w) wprod = w_sums[0] + ax * w_comp_poly[0] + az * w_comp_poly[1] + ax * az * w_comp_poly[2];
     // everything was taken by the refinement pass: the complementarity at the scaled step is
-    // S00 + ax S10 + az S01 + ax az S11 with S00 / the bound count from the residual pass of this iterate
+    // S00 + ax S10 + az S01 + ax az S11 with S00 / the bound count from the residual pass of this iterate.
+    // Tolerance: near convergence S00 and the S10 / S01 terms nearly cancel, so the polynomial carries a relative
+    // error of a few ulp of S00 where the direct sum of products has a few ulp of the result; the value only feeds the
+    // comp_new > 10 comp test below (a factor-of-ten threshold), and the cmpEq tokens of all reference trajectories are
+    // reproduced with it (tests/test_gpu_ip.py; A/B against the plain pass: test_write_saving_fusions_...).
+    // Validity: comp_prod / iterate_logs belong to (x, zl, zu) as the last residual pass saw them.  Every internal
+    // writer of the iterate clears the flags; an iteration callback or a getArray view must not WRITE the iterate
+    // mid-solve (po_ip_set_iteration_callback: an observer) -- resetDesignAndBounds / readSolutionFile between solves
+    // refresh mirrors and flags (refreshLiveMirror)
     out[0] = comp_prod + ax * fused_merit[0] + az * fused_merit[1] + ax * az * fused_merit[2];
     out[1] = comp_count;
     merit_cache[0] = iterate_logs[0];
