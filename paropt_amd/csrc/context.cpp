@@ -50,6 +50,21 @@ static int alloc_h_red(Ctx *c, size_t doubles) {
     (void)hipGetLastError();
     c->h_red_dev = nullptr;
   }
+  // the completion flag of the final reduction stages (see Ctx::h_flag): allocated once
+  if (c->h_red_dev && !c->h_flag && !getenv("PAROPT_AMD_NO_FLAG_POLL")) {
+    if (hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault) == hipSuccess &&
+        hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0) == hipSuccess &&
+        hipMalloc((void **)&c->d_ticket, sizeof(unsigned)) == hipSuccess &&
+        hipMemset(c->d_ticket, 0, sizeof(unsigned)) == hipSuccess) {
+      *c->h_flag = 0;
+    } else {
+      (void)hipGetLastError();
+      if (c->h_flag) (void)hipHostFree(c->h_flag);
+      if (c->d_ticket) (void)hipFree(c->d_ticket);
+      c->h_flag = c->h_flag_dev = nullptr;
+      c->d_ticket = nullptr;
+    }
+  }
   return PO_OK;
 }
 
@@ -239,6 +254,8 @@ int ctx_destroy(Ctx *c) {
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_gather) (void)hipFree(c->d_gather);
   if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->h_flag) (void)hipHostFree(c->h_flag);
+  if (c->d_ticket) (void)hipFree(c->d_ticket);
   for (int i = 0; i < 2; i++)
     if (c->wide_scratch[i]) (void)hipFree(c->wide_scratch[i]);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -327,9 +344,22 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
     PO_HIP(hipStreamSynchronize(c->stream));
     nparts = c->size;
   } else {
-    // (red_direct: the final stages have written their results into h_red themselves)
+    // (red_direct: the final stages have written their results into h_red themselves, and the last of them has raised
+    // the flag behind its results: poll it -- bounded, then the stream is synchronised as before)
     if (!red_direct(c)) PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
-    PO_HIP(hipStreamSynchronize(c->stream));
+    bool seen = false;
+    if (red_direct(c) && c->h_flag && c->red_seq > c->red_seq_seen) {
+      volatile unsigned long long *f = c->h_flag;
+      const unsigned long long want = c->red_seq;
+      for (long spin = 0; spin < 4000000; spin++) {
+        if (*f == want) {
+          seen = true;
+          break;
+        }
+      }
+      c->red_seq_seen = want;
+    }
+    if (!seen) PO_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_kind == COMM_CALLBACK) {
       double *all = c->h_red + kMaxRed;
       int rc = c->cb_allgather(c->h_red, all, total, c->cb_user);

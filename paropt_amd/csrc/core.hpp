@@ -69,6 +69,13 @@ struct Ctx {
   double *h_red = nullptr;       // pinned [size * kMaxRed]
   double *h_red_dev = nullptr;   // the same memory as the device sees it: without a device-side collective the final
                                  // reduction stage writes its results there (no device-to-host copy command)
+  // ... and raises a sequence number behind them (pinned host memory; the last workgroup of the stage, found with a
+  // device ticket): the host polls it instead of calling hipStreamSynchronize -- 11 instead of 15.7 us per
+  // launch + wait + dependent launch (tools/sync_probe.hip).  red_seq counts the flagged launches, red_seq_seen what
+  // the host has waited for; PAROPT_AMD_NO_FLAG_POLL=1 switches it off.
+  unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr;
+  unsigned *d_ticket = nullptr;
+  unsigned long long red_seq = 0, red_seq_seen = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
   // allocated on first use

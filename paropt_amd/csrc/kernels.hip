@@ -98,12 +98,33 @@ __device__ __forceinline__ void block_reduce_store(double (&a)[N], double *__res
   __syncthreads();
 }
 
+// Completion flag of a final reduction stage whose results go straight into pinned host memory (Ctx::h_flag): every
+// wave fences its result store to system scope, the workgroup meets at a barrier, and the workgroup that draws the
+// last ticket writes the sequence number the host is polling for.  flag == nullptr: nothing (results go to d_red).
+__device__ __forceinline__ void red_raise_flag(volatile unsigned long long *flag, unsigned long long seq,
+                                               unsigned *ticket) {
+  if (!flag) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket, 1u);
+    if (t == gridDim.x - 1) {
+      *ticket = 0;
+      __threadfence_system();
+      *flag = seq;
+    }
+  }
+}
 __global__ void __launch_bounds__(kBlock)
     reduce_final_kernel(const double *__restrict__ partials, int nblocks, int nslots, int nsum,
-                        int nmin, double *__restrict__ out) {
+                        int nmin, double *__restrict__ out, volatile unsigned long long *flag, unsigned long long seq,
+                        unsigned *ticket) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + wave;
-  if (slot >= nslots) return;
+  if (slot >= nslots) {
+    red_raise_flag(flag, seq, ticket);
+    return;
+  }
   const double *p = partials + (size_t)slot * nblocks;
   if (slot < nsum) {
     double acc = 0.0;
@@ -121,14 +142,18 @@ __global__ void __launch_bounds__(kBlock)
     acc = wave_reduce<OP_MAX>(acc);
     if (lane == 0) out[slot] = acc;
   }
+  red_raise_flag(flag, seq, ticket);
 }
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off) {
   const int grid = (nslots + 3) / 4;
   // no device-side collective (one rank, or the host-callback communicator): straight into the pinned host buffer
   double *dst = red_direct(c) ? c->h_red_dev : c->d_red;
+  const bool flagged = red_direct(c) && c->h_flag_dev != nullptr;
+  if (flagged) c->red_seq++;
   hipLaunchKernelGGL(reduce_final_kernel, dim3(grid), dim3(kBlock), 0, c->stream, c->d_partials,
-                     nblocks, nslots, nsum, nmin, dst + dst_off);
+                     nblocks, nslots, nsum, nmin, dst + dst_off, flagged ? c->h_flag_dev : nullptr, c->red_seq,
+                     c->d_ticket);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   return PO_OK;
@@ -143,10 +168,15 @@ struct RedSegTable {
   int nblocks[kMaxSeg], nslots[kMaxSeg], nsum[kMaxSeg], nmin[kMaxSeg], dst[kMaxSeg];
   int count, total;
 };
-__global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable T, double *__restrict__ out) {
+__global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable T, double *__restrict__ out,
+                                                                    volatile unsigned long long *flag,
+                                                                    unsigned long long seq, unsigned *ticket) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * 4 + wave;
-  if (slot >= T.total) return;
+  if (slot >= T.total) {
+    red_raise_flag(flag, seq, ticket);
+    return;
+  }
   int k = 0;
   while (k + 1 < T.count && slot >= T.nslots[k]) {
     slot -= T.nslots[k];
@@ -171,6 +201,7 @@ __global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable 
     acc = wave_reduce<OP_MAX>(acc);
     if (lane == 0) o[slot] = acc;
   }
+  red_raise_flag(flag, seq, ticket);
 }
 int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count) {
   double *dst = red_direct(c) ? c->h_red_dev : c->d_red;
@@ -190,7 +221,10 @@ int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count) {
       T.total += T.nslots[k];
     }
     if (T.total <= 0) continue;
-    hipLaunchKernelGGL(reduce_final_multi_kernel, dim3((T.total + 3) / 4), dim3(kBlock), 0, c->stream, T, dst);
+    const bool flagged = red_direct(c) && c->h_flag_dev != nullptr;
+    if (flagged) c->red_seq++;
+    hipLaunchKernelGGL(reduce_final_multi_kernel, dim3((T.total + 3) / 4), dim3(kBlock), 0, c->stream, T, dst,
+                       flagged ? c->h_flag_dev : nullptr, c->red_seq, c->d_ticket);
     c->n_launches++;
     PO_HIP(hipGetLastError());
   }
