@@ -63,15 +63,15 @@ GOLDEN_WINDOWS = {
     # (oracle/reference_self_agreement.py: 1-4 MPI ranks, four BLAS code paths) | [recorded iterations]
     "ip_convex_hvec_n300_c3": 22,              # 24 | 24 [53]
     "ip_convex_hvec_noprecon_n200_c2": 14,     # 16 | 16 [80]
-    "ipw_convex_n240_c3_w40_mpc": 16,          # state 18, integers 40 | 17 [60]
+    "ipw_convex_n240_c3_w40_mpc": 16,          # state 18 (round 4: 20), integers 40 | 17 [60]
     # L-SR1 (the quasi-Newton type of the metric's configuration)
     "ip_convex_n300_c5_sr1": 14,               # 16 | 16 [25]
     "ip_convex_sigma_sr1_n300_c3": 18,         # 20 | 20 [25]
     "ip_convex_n2000_c32_sr1": 20,             # the whole record | the whole record [20]
     "ip_convex_n2000_c90_sr1": 20,             # the whole record | the whole record [20] (100-column panel)
-    "ip_convex_n100000_c32_sr1_r4": 15,        # state 17, integers the whole record | 16 [20]; n = 1e5 on 4 MPI ranks
+    "ip_convex_n100000_c32_sr1_r4": 15,        # state 17 (round 4: 16), integers the whole record | 16 [20]; n = 1e5 on 4 MPI ranks
     "ipw_convex_n240_c3_w40_sr1": 22,          # 24 | 24 [60]
-    "ipcsr_convex_n200_c2_chain5s3_sr1": 34,   # state 36, integers 46 | 33 [60]
+    "ipcsr_convex_n200_c2_chain5s3_sr1": 34,   # state 36 (round 4: 37), integers 46 (45) | 33 [60]
 }
 
 
