@@ -1831,11 +1831,14 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
   fill_tables(alpha, P, nv, &ct, &pt);
   fill_tables(coef2, P, nv, &ct2, &pt);
   const int need = (nv + 3) / 4;
-  const int np = need <= 4 ? 4 : need <= 8 ? 8 : need <= 11 ? 11 : need <= 12 ? 12 : need <= 16 ? 16
-                 : need <= 20 ? 20 : 24;
+  // (column slots per wave: a slot beyond the panel re-reads column 0 with a zero coefficient -- no HBM traffic, but a
+  // load per tile all the same: 2 and 6 slots for the narrow panels of configs 5 and 4 instead of 4 and 8; same
+  // workgroups per CU, so the same grid and the same bits)
+  const int np = need <= 2 ? 2 : need <= 4 ? 4 : need <= 6 ? 6 : need <= 8 ? 8 : need <= 11 ? 11 : need <= 12 ? 12
+                 : need <= 16 ? 16 : need <= 20 ? 20 : 24;
   switch (np) {
-    PO_S2D_CASE(4) PO_S2D_CASE(8) PO_S2D_CASE(11) PO_S2D_CASE(12) PO_S2D_CASE(16) PO_S2D_CASE(20)
-    PO_S2D_CASE(24)
+    PO_S2D_CASE(2) PO_S2D_CASE(4) PO_S2D_CASE(6) PO_S2D_CASE(8) PO_S2D_CASE(11) PO_S2D_CASE(12) PO_S2D_CASE(16)
+    PO_S2D_CASE(20) PO_S2D_CASE(24)
   }
   return reduce_finish(c, grid, nv, 2, 0, out);
 }
