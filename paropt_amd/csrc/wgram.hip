@@ -804,6 +804,12 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // 8 % faster than the output split on the plain form (2.93 vs 3.18 ms = 0.75 of the HBM peak) and 2 % with the L-SR1
   // columns formed in the pass -- once its operand fetches stay ds_read_b64 (see gram_tile_rows)
   const bool row_split = dbg_switch(SW_WGRAM_RS, "PAROPT_AMD_WGRAM_RS", 1) != 0;
+  // Narrow panels (<= 20 columns) take the single-role form: one workgroup per CU with three 128-row tiles of a few
+  // columns in flight does not cover the HBM latency (5 columns: 0.31 of the peak at any n, 9: 0.45, 17: 0.65), four
+  // single-role workgroups per CU do (0.70 / 0.79 / 0.66-0.77); from 25 columns on the two forms are level and the
+  // producer/consumer form wins beyond (round 4, tools/dbg/wgram_pc_grid.py; PAROPT_AMD_WGRAM_PC_MIN_NG to move it).
+  // (A panel image riding in the pass -- `groups` above -- keeps the producer/consumer form at any width.)
+  static const int pc_min_ng = getenv("PAROPT_AMD_WGRAM_PC_MIN_NG") ? atoi(getenv("PAROPT_AMD_WGRAM_PC_MIN_NG")) : 6;
   if (use_pc && wgram_groups_geom(groups, nv, n, kpend, &gg)) {
     // the pass also takes the structured panel image (see GramGeom): group tiles first, ordinary tiles behind them
     ntiles = gg.ngt + (n - gg.rg + kGramTile - 1) / kGramTile;
@@ -833,7 +839,7 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     constexpr int OCC0A = OCC0 > 1 ? OCC0 - 1 : 1;                                                     \
     constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
     constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
-    if (NGv <= 16 && use_pc && n >= 4 * kGramTile) {                                                   \
+    if (NGv <= 16 && use_pc && n >= 4 * kGramTile && NGv >= pc_min_ng) {                               \
       constexpr int NGc = NGv <= 16 ? NGv : 16;                                                        \
       if (NGv >= kGramRowSplitMinNG && NGv <= kGramRowSplitMaxNG && row_split) {                       \
         constexpr int NGr = NGv <= kGramRowSplitMaxNG ? NGv : kGramRowSplitMaxNG;                      \
