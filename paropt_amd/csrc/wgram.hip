@@ -808,9 +808,10 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // columns in flight does not cover the HBM latency (5 columns: 0.31 of the peak at any n, 9: 0.45, 17: 0.65), four
   // single-role workgroups per CU do (0.70 / 0.79 / 0.66-0.77); from 25 columns on the two forms are level and the
   // producer/consumer form wins beyond (round 4, tools/dbg/wgram_pc_grid.py; PAROPT_AMD_WGRAM_PC_MIN_NG to move it).
-  // (A panel image riding in the pass -- `groups` above -- keeps the producer/consumer form at any width.)
+  // (The same threshold for a panel image riding in the pass: on a narrow panel the single-role Gram plus the
+  // stand-alone panel image are faster than the fused producer/consumer form -- 0.18 + 0.14 against 0.9 ms at 5 columns.)
   static const int pc_min_ng = getenv("PAROPT_AMD_WGRAM_PC_MIN_NG") ? atoi(getenv("PAROPT_AMD_WGRAM_PC_MIN_NG")) : 6;
-  if (use_pc && wgram_groups_geom(groups, nv, n, kpend, &gg)) {
+  if (use_pc && NG >= pc_min_ng && wgram_groups_geom(groups, nv, n, kpend, &gg)) {
     // the pass also takes the structured panel image (see GramGeom): group tiles first, ordinary tiles behind them
     ntiles = gg.ngt + (n - gg.rg + kGramTile - 1) / kGramTile;
     for (int j = 0; j < gg.ncols; j++) ut.p[j] = groups->U[j];
