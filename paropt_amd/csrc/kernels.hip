@@ -1583,7 +1583,12 @@ __global__ void __launch_bounds__(kBlock, OCC)
   GRaw gbuf;
   gbuf.raw = (f64x2){0.0, 0.0};
   gbuf.valid = 0;
-  f64x2 eb[8];  // wave 0: x, lb, ub, zl, zu, t, dinv, rx of the tile
+  // The element epilogue is run by waves 0 and 1 with ONE element per lane (rows 64 w + lane of the tile): half the
+  // dependent fp64 divisions per wave of the former one-wave, two-elements-per-lane form, whose chain bounded the pass.
+  // Element arithmetic is per element, so which lane runs it changes no bit.  eb: x, lb, ub, zl, zu, t, dinv, rx of it.
+  double eb[8];
+  int64_t ie = 0;   // the element (global row) this lane finishes, clamped into range for the loads
+  bool ein = false;  // ... and whether it exists (ie_raw < n)
   int64_t q = 0;
   bool in = false;
 #define PO_S2_PREFETCH(TILE)                                                                 \
@@ -1603,22 +1608,25 @@ __global__ void __launch_bounds__(kBlock, OCC)
     }                                                                                        \
     if (gmine >= 0) gbuf = gcol_request(gcs.g[gmine], q, n);                                 \
   }
-#define PO_S2_PREFETCH_E(Q)                                                                  \
+#define PO_S2_PREFETCH_E(TILE)                                                               \
   {                                                                                          \
-    eb[0] = *reinterpret_cast<const f64x2 *>(b.x + 2 * (Q));                                 \
-    eb[1] = *reinterpret_cast<const f64x2 *>(b.lb + 2 * (Q));                                \
-    eb[2] = *reinterpret_cast<const f64x2 *>(b.ub + 2 * (Q));                                \
-    eb[3] = *reinterpret_cast<const f64x2 *>(b.zl + 2 * (Q));                                \
-    eb[4] = *reinterpret_cast<const f64x2 *>(b.zu + 2 * (Q));                                \
+    const int64_t _ir = (TILE) * kS2Tile + 64 * wave + lane;                                 \
+    ein = _ir < n;                                                                           \
+    ie = ein ? _ir : n - 1;                                                                  \
+    eb[0] = b.x[ie];                                                                         \
+    eb[1] = b.lb[ie];                                                                        \
+    eb[2] = b.ub[ie];                                                                        \
+    eb[3] = b.zl[ie];                                                                        \
+    eb[4] = b.zu[ie];                                                                        \
     if (t) { /* (nullptr: t and Dinv re-formed from the bound data and rx, as dinv_d1_kernel formed them) */ \
-      eb[5] = *reinterpret_cast<const f64x2 *>(t + 2 * (Q));                                 \
-      eb[6] = *reinterpret_cast<const f64x2 *>(dinv + 2 * (Q));                              \
+      eb[5] = t[ie];                                                                         \
+      eb[6] = dinv[ie];                                                                      \
     }                                                                                        \
-    eb[7] = *reinterpret_cast<const f64x2 *>(rx + 2 * (Q));                                  \
+    eb[7] = rx[ie];                                                                          \
   }
   if ((int64_t)blockIdx.x < ntiles) {
     PO_S2_PREFETCH((int64_t)blockIdx.x);
-    if (wave == 0) PO_S2_PREFETCH_E(q);
+    if (wave < 2) PO_S2_PREFETCH_E((int64_t)blockIdx.x);
   }
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t qc = q;  // row pair of this lane in the current tile
@@ -1658,75 +1666,77 @@ __global__ void __launch_bounds__(kBlock, OCC)
     sa[5 * 256] = aA.y;
     __syncthreads();
     const bool more = tile + gridDim.x < ntiles;
-    // wave 0 issues its share of the next tile after the epilogue (keeps the prefetch registers out of the
+    // waves 0 and 1 issue their share of the next tile after the epilogue (keeps the prefetch registers out of the
     // epilogue's register peak)
-    if (more && wave != 0) PO_S2_PREFETCH(tile + gridDim.x);
-    if (wave == 0) {
-      double2 acc = make_double2(0.0, 0.0), acc2 = acc, accA = acc;
+    if (more && wave >= 2) PO_S2_PREFETCH(tile + gridDim.x);
+    if (wave < 2) {
+      // this lane's element: row 64 wave + lane of the tile = component (lane & 1) of row pair 32 wave + lane / 2
+      const int er = 64 * wave + lane, el = er >> 1, ec = er & 1;
+      double acc = 0.0, acc2 = 0.0, accA = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; w++) {
-        const double *sp = sacc + w * 64 + lane;
-        acc.x += sp[0 * 256];
-        acc.y += sp[1 * 256];
-        acc2.x += sp[2 * 256];
-        acc2.y += sp[3 * 256];
-        accA.x += sp[4 * 256];
-        accA.y += sp[5 * 256];
+        const double *sp = sacc + w * 64 + el;
+        acc += sp[(0 + ec) * 256];
+        acc2 += sp[(2 + ec) * 256];
+        accA += sp[(4 + ec) * 256];
       }
-      double2 tp = make_double2(0.0, 0.0);
-      if (inc) {
-        const double2 _x = make_double2(eb[0].x, eb[0].y), _lb = make_double2(eb[1].x, eb[1].y),
-                      _ub = make_double2(eb[2].x, eb[2].y), _zl = make_double2(eb[3].x, eb[3].y),
-                      _zu = make_double2(eb[4].x, eb[4].y);
-        const int64_t q = qc;
-        PO_MAKE_BOUNDS(b, q, n);
-        const double2 r = make_double2(eb[7].x, eb[7].y);
-        double2 tv, dv;
+      double tp = 0.0;
+      const int64_t i = tile * kS2Tile + er;  // (ie, clamped, is what the operands were loaded from)
+      if (ein) {
+        const double _x = eb[0], _lb = eb[1], _ub = eb[2], _zl = eb[3], _zu = eb[4];
+        const BE e = bound_elem(_x, _lb, _ub, _zl, _zu, b.max_bound, b.use_lower, b.use_upper);
+        const double r = eb[7];
+        double tv, dv;
         if (t) {
-          tv = make_double2(eb[5].x, eb[5].y);
-          dv = make_double2(eb[6].x, eb[6].y);
+          tv = eb[5];
+          dv = eb[6];
         } else {
-          // (pad element of an odd n: exactly 0, as the stored Dinv / t have it -- see solve2r_kernel)
-          dv = make_double2(dinv_elem(e0, dinv_diag), _has2 ? dinv_elem(e1, dinv_diag) : 0.0);
-          tv = make_double2(dv.x * d1_elem(e0, r.x, beta_mu), _has2 ? dv.y * d1_elem(e1, r.y, beta_mu) : 0.0);
+          dv = dinv_elem(e, dinv_diag);
+          tv = dv * d1_elem(e, r, beta_mu);
         }
-        if (va && store_step == 1) st2(va, q, n, accA);
-        const Step3 s0 = solve2_elem<0>(e0, tv.x + dv.x * acc.x, beta_mu, 0.0, 0.0, 0.0);
-        Step3 s1 = solve2_elem<0>(e1, tv.y + dv.y * acc.y, beta_mu, 0.0, 0.0, 0.0);
-        if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+        if (va && store_step == 1) va[i] = accA;
+        const Step3 s0 = solve2_elem<0>(e, tv + dv * acc, beta_mu, 0.0, 0.0, 0.0);
         // store_step == 0: the refinement pass recomputes this first step from t and alpha in registers
         // (solve2r_kernel) -- an HBM write costs about four reads on this part (tools/layout_probe.hip)
         // store_step == 2: px only -- the bound-multiplier steps are functions of it and of data every later pass
         // loads anyway (sparse-constraint path, whose refinement residual needs Aw px as a vector)
         if (store_step) {
-          st2(px, q, n, make_double2(s0.px, s1.px));
+          px[i] = s0.px;
           if (store_step == 1) {
-            st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
-            st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+            pzl[i] = s0.pzl;
+            pzu[i] = s0.pzu;
           }
         }
         // raw d1' and t' = Dinv o d1' (the product res_step_elem would form itself)
-        double2 raw;
-        raw.x = res_step_elem(e0, r.x, acc2.x, diag, s0.px, s0.pzl, s0.pzu, 1.0, beta_mu, b.use_lower,
-                              b.use_upper);
-        raw.y = _has2 ? res_step_elem(e1, r.y, acc2.y, diag, s1.px, s1.pzl, s1.pzu, 1.0, beta_mu,
-                                      b.use_lower, b.use_upper)
-                      : 0.0;
-        tp.x = dv.x * raw.x;
-        tp.y = dv.y * raw.y;
+        const double raw = res_step_elem(e, r, acc2, diag, s0.px, s0.pzl, s0.pzu, 1.0, beta_mu, b.use_lower,
+                                         b.use_upper);
+        tp = dv * raw;
         if (traw) {  // the caller applies its own block solve to the raw right-hand side (sparse constraints)
-          st2(traw, q, n, raw);
+          traw[i] = raw;
         } else if (tout) {  // (nullptr: the refinement pass recomputes t' too -- this pass only takes its products)
-          st2(tout, q, n, tp);
+          tout[i] = tp;
         }
-        max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
-        if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+        max_step_elem(b, _x, _lb, _ub, _zl, _zu, s0, tau, mins[0], mins[1]);
+      } else if (i == n && (n & 1)) {
+        // the pad element of an odd length stays 0.0 in every output (what the paired stores of the other passes keep)
+        if (va && store_step == 1) va[i] = 0.0;
+        if (store_step) {
+          px[i] = 0.0;
+          if (store_step == 1) {
+            pzl[i] = 0.0;
+            pzu[i] = 0.0;
+          }
+        }
+        if (traw) {
+          traw[i] = 0.0;
+        } else if (tout) {
+          tout[i] = 0.0;
+        }
       }
-      stp[2 * lane] = tp.x;
-      stp[2 * lane + 1] = tp.y;
+      stp[er] = tp;
       if (more) {
         PO_S2_PREFETCH(tile + gridDim.x);
-        PO_S2_PREFETCH_E(q);  // operands of the next tile (q was advanced by the prefetch above)
+        PO_S2_PREFETCH_E(tile + gridDim.x);
       }
     }
     __syncthreads();
