@@ -52,7 +52,7 @@ def line(tag, r, extra=""):
         cb.get("value", float("nan")), cb.get("whole_run_it_per_s", float("nan")), cb.get("cores", 0), extra)
 sub["RECORD_TABLE"] = "\n".join([
     line("2: quadratic, n = 10 M, m = 8, L-BFGS(20)", c2, "292–295 it/s (under the profiler)"),
-    line("3: convex, n = 50 M, m = 32, L-SR1(10) — the metric", c3, "42.9 it/s (40.6 on its slowest box); this round 40.6 on a box whose copy ceiling was 5.3 TB/s (`r04_bench_c3_slow_store_box.json`)"),
+    line("3: convex, n = 50 M, m = 32, L-SR1(10) — the metric", c3, "42.9 it/s (40.6 on its slowest box); this round 40.6 on a box whose copy ceiling was 5.3 TB/s and 43.0 on one with 6.3 TB/s before the two-wave epilogue (`r04_bench_c3_slow_store_box.json`, `r04_bench_c3_before_two_wave_epilogue.json`; the box of this line: 6.0)"),
     line("4: n = 20 M, m = 4, 1 M weighting constraints, L-BFGS(10)", c4, "125.4 it/s, 85 launches, 8 syncs"),
     line("5: trust region + eigenvalue model, n = 5 M", c5, "10.3 TR it/s = 664 inner it/s, 29.8 / 9.1 (review target: 750)"),
 ])
