@@ -1790,9 +1790,11 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
   return PO_OK;
 }
 
-// (OD / OA: workgroups per CU, default and alternative (PAROPT_AMD_S2D_OCC).  The stored-step form of narrow panels --
-// the sparse-constraint path -- takes the alternative 2 by default: its epilogue keeps the step and the raw right-hand
-// side live beside the prefetched operands, 2.9 vs 3.1 ms per iteration in the solves of config 4.)
+// (OD / OA: workgroups per CU, default and alternative (PAROPT_AMD_S2D_OCC).  Until the element epilogue moved to two
+// waves with one element per lane the stored-step form of narrow panels -- the sparse-constraint path -- took 2 by
+// default (its epilogue kept the step and the raw right-hand side live beside the prefetched operands and spilled at
+// 3); with 129-143 registers it takes 3 like the others: 177.8 -> 181.3 it/s at config 4 in one call.  Wider panels
+// stay at 2: 3 spills there and costs 1 % at config 3, 7 % at config 2.)
 #define PO_S2D_CASE(NP)                                                                                    \
   case NP: {                                                                                               \
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
@@ -1800,7 +1802,7 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
     if (vc.count > 0)                                                                                      \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
                                             px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
-    else if (occ_env == OA || (occ_env == 0 && store_step && NP <= 8))                                     \
+    else if (occ_env == OA)                                                                                \
       PO_TRY((solve2_dots_launch<NP, OA, 0>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
                                             px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
     else                                                                                                   \
