@@ -61,7 +61,7 @@ def shares(p, n=7):
     return ", ".join("`%s` %.1f %%%s" % (k.rstrip(","), v[2], (" (%s)" % v[3]) if v[3] else "") for k, v in rows)
 sub["C3_SHARES"] = shares(p3)
 sub["C4_PMC"] = shares(p4, 9)
-sub["PER_RANK"] = "config 3: 23.35 / 11.60 / 5.85 / 3.02 ms per iteration at n/1, n/2, n/4, n/8 (96.5 % of perfect before any collective); config 4: 5.74 / 2.99 / 1.62 ms at n/1, n/2, n/4 (88.9 %) (`profiles/r04_per_rank_sizes.txt`, `tools/per_rank_sizes.sh`)"
+sub["PER_RANK"] = "config 3: 23.47 / 11.68 / 6.01 / 3.08 ms per iteration at n/1, n/2, n/4, n/8 (95.3 % of perfect before any collective); config 4: 5.68 / 2.93 / 1.57 ms at n/1, n/2, n/4 (90.5 %) (`profiles/r04_per_rank_sizes.txt`, `tools/per_rank_sizes.sh`)"
 sub["PRED"] = "≈ 90 %"
 src = open(os.path.join(R, "tools", "dbg", "DESIGN.md.in")).read()
 missing = set(re.findall(r"@([A-Z0-9_]+)@", src)) - set(sub)
