@@ -357,6 +357,7 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
           break;
         }
       }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the results in h_red are read after the flag, also by the compiler
       c->red_seq_seen = want;
     }
     if (!seen) PO_HIP(hipStreamSynchronize(c->stream));
