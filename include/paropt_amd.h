@@ -58,6 +58,14 @@ void *po_ctx_stream(po_ctx ctx);
 /* Diagnostics: host-synchronising reductions (= collectives when there is more than one rank) and kernel launches
  * issued on this context so far. */
 int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches);
+/* Diagnostics of the completion path of the reductions (round 5): the host does not synchronise the stream after a
+ * reduction but polls a sequence number that the last kernel of the exchange -- the final reduction stage on one rank,
+ * a one-workgroup publish kernel behind ncclAllReduce / ncclAllGather on several -- raises in pinned host memory behind
+ * its results.  flag_waits = polled completions, flag_timeouts = those whose bounded spin (200 ms) ran out and fell
+ * back to hipStreamSynchronize (always correct; a non-zero count in a soak run means the flag path is broken or a
+ * single kernel ran longer than the bound), allreduces / allgathers = RCCL collectives issued. */
+int po_ctx_sync_counters(po_ctx ctx, int64_t *flag_waits, int64_t *flag_timeouts, int64_t *allreduces,
+                         int64_t *allgathers);
 /* Diagnostics: algorithmic HBM bytes of every n-sized launch issued on this context so far -- each operand stream of
  * a launch counted once (8 n bytes), e.g. 8 (nvecs + 1) n for ParOptVec::mdot (src/ParOptVec.cpp:152-170), SURVEY.md
  * 8d's per-kernel figures.  `user` is the part issued from inside the problem's evaluation callbacks (the built-in
@@ -197,6 +205,12 @@ int po_qn_max_size(po_qn qn, int *size);                    /* getMaxLimitedMemo
 /* 0-based pivot rows of the LU factorization of the compact matrix M (the reference's LAPACK mfpiv,
  * src/ParOptQuasiNewton.cpp:375, 743, is 1-based); borrowed, valid until the next update / reset. */
 int po_qn_get_pivots(po_qn qn, const int **mfpiv, int *n);
+/* Test hook of the state-injected known-answer tests: loads msub pairs (device vectors of the local size, copied),
+ * b0 and the small matrices the updates maintain -- B = S^T S, L = strictly lower triangle of S^T Y, D = diag(S^T Y),
+ * column-major with leading dimension ld (src/ParOptQuasiNewton.h:141-147) -- and rebuilds (d0, M, LU, Z) from them
+ * with the arithmetic of update() (computeMatUpdate :339-377; L-SR1 :712-743, columns left unformed). */
+int po_qn_debug_load(po_qn qn, int msub, double b0, const double *B, const double *L, const double *D, int ld,
+                     const po_vec *S, const po_vec *Y);
 
 /* ---- ParOptProblem: src/ParOptProblem.h:42-296 -------------------------------------------- */
 /* User problems are bound the way the reference's own FFI binds them: a table of C callbacks
@@ -426,6 +440,35 @@ int po_ip_get_bounds(po_ip ip, po_vec *lb, po_vec *ub);
 int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *pzu,
                          const double **pz, const double **ps, const double **pt,
                          const double **pzs, const double **pzt);
+/* State-injected known-answer tests (tests/test_gpu_kat.py): the REFERENCE's state at one iteration -- the dump of
+ * its private members made by oracle/ref_driver.cpp -- is loaded into the device solver and the pieces of the KKT
+ * step are compared one by one with what the reference's private methods produced from that same state
+ * (computeKKTRes .cpp:1337, setUpKKTDiagSystem :1832-1971, setUpKKTSystem :2634-2667, computeKKTStep :2700-2737,
+ * the refinement loop :4985-4991).  Usage, after one optimize() call has initialised the solver: write x, zl, zu (and
+ * the sparse blocks) through the borrowed handles of po_ip_get_optimized_point / _sparse, load the limited-memory
+ * pairs with po_qn_debug_load on the handle of po_ip_get_quasi_newton, then po_ip_debug_set_state (dense blocks and
+ * the barrier parameter; evaluates the problem at x) and po_ip_debug_kkt.
+ *   mode 0: ONE bordered solve with the quasi-Newton correction (computeKKTStep), the stored-step kernels;
+ *   mode 1: the kernel sequence of a plain quasi-Newton iteration of optimize() (dinv_d1, fused
+ *           Gram pass over unformed L-SR1 columns, first solve pass, refinement pass) = the step after ONE refinement.
+ * Everything in the dump is borrowed and valid until the next call on the solver.  G and Ce are the Schur complements
+ * AS ASSEMBLED (column-major c x c and k x k, before their LU factorizations), W the weighted Gram matrix
+ * [Ac | Z]^T Dinv [Ac | Z] ((c+k) x (c+k)); gpiv / cpiv 0-based LU pivot rows; res_norms = max_prime, max_dual,
+ * max_infeas, res_norm (computeResNorm :1588-1723); step_mins = the vector part of computeMaxStep (:2942-3103). */
+typedef struct po_ip_kkt_dump {
+  int c, k;
+  po_vec Dinv, res_x;
+  const double *res_z, *res_s, *res_t, *res_zs, *res_zt;
+  double res_norms[4];
+  const double *W, *G, *Ce;
+  const int *gpiv, *cpiv;
+  po_vec px, pzl, pzu;
+  const double *pz, *ps, *pt, *pzs, *pzt;
+  double step_mins[2];
+} po_ip_kkt_dump;
+int po_ip_debug_set_state(po_ip ip, const double *z, const double *s, const double *t, const double *zs,
+                          const double *zt, double mu);
+int po_ip_debug_kkt(po_ip ip, double mu, int mode, double tau, po_ip_kkt_dump *out);
 /* the sparse blocks of that step (borrowed; NULL handles when the problem has no sparse constraints) */
 int po_ip_debug_kkt_step_sparse(po_ip ip, po_vec *pzw, po_vec *psw, po_vec *ptw, po_vec *pzsw, po_vec *pztw);
 

@@ -618,6 +618,26 @@ case("ip_convex_n100000_c32_bfgs10_r1", "ip", ranks=1, problem="convex", n=10000
      vec_stride=25, **dict(ip_common, **{"opt.qn_subspace_size": 10, "opt.qn_type": "bfgs", "opt.max_major_iters": 60}))
 
 
+# --- state-injected single-step known-answer cases: the reference's private-method dumps at one
+# iteration with COMPLETE state (x, zl, zu, dense blocks, mu, the limited-memory pairs S / Y and the small matrices
+# B, L, D behind them), the Schur complements AS ASSEMBLED (Gmat, Ce before dgetrf: the LAPACK tracing shim of
+# ref_driver.cpp), the first step (computeKKTStep) and the step after one refinement (:4985-4991).  Shapes: the
+# metric's (convex, c = 32, L-SR1(10): a 43-column Gram) at n = 2000 and at n = 100 003 (odd; compare-only vectors
+# stored as every 37th entry, problem data left out: a pure function of the case), config 2's (c = 8, L-BFGS(20)),
+# and one with sparse weighting constraints (config 4's form).
+kat_opts = dict(ip_common)
+case("kat_convex_n2000_c32_sr1", "ip", problem="convex", n=2000, c=32, dump_vecs_every=0, kat_iter=12,
+     **dict(kat_opts, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 14}))
+case("kat_convex_n100003_c32_sr1", "ip", problem="convex", n=100003, c=32, dump_vecs_every=0, kat_iter=12,
+     kat_light=1, kat_out_stride=37,
+     **dict(kat_opts, **{"opt.qn_subspace_size": 10, "opt.qn_type": "sr1", "opt.max_major_iters": 13}))
+case("kat_quadratic_n2000_c8_bfgs20", "ip", problem="quadratic", n=2000, c=8, dump_vecs_every=0, kat_iter=24,
+     **dict(kat_opts, **{"opt.qn_subspace_size": 20, "opt.qn_type": "bfgs", "opt.max_major_iters": 26}))
+case("kat_ipw_convex_n400_c4_w80", "ip", problem="convex", n=400, c=4, nwcon=80, nw=5, nwstart=0, nwskip=0,
+     dump_vecs_every=0, kat_iter=9,
+     **dict(kat_opts, **{"opt.qn_subspace_size": 8, "opt.qn_type": "bfgs", "opt.max_major_iters": 11}))
+
+
 def parse_tr_table(text):
     """Rows of the trust-region iteration table (paropt.tr): 13 numeric columns without the wall time, + info."""
     rows, infos = [], []

@@ -44,6 +44,36 @@
 #undef protected
 
 // ---------------------------------------------------------------------------
+// LAPACK tracing shim (single-step known-answer dumps): the reference factors its Schur complements in place
+// (dgetrf on Gmat, src/ParOptInteriorPoint.cpp:1968-1969, and on Ce, :2663-2664), so the matrices it ASSEMBLED are
+// gone by the time a hook can look.  This definition of dgetrf_ takes precedence over the one in libmkl_rt for
+// every caller in this executable; it copies the input matrix while g_getrf_capture is set and forwards to the
+// real routine (dlsym RTLD_NEXT) -- the factorization itself is MKL's, unchanged.
+// ---------------------------------------------------------------------------
+#include <dlfcn.h>
+static bool g_getrf_capture = false;
+static std::vector<double> g_getrf_last;
+static int g_getrf_last_n = 0;
+extern "C" void dgetrf_(int *m, int *n, double *a, int *lda, int *ipiv, int *info) {
+  typedef void (*getrf_fn)(int *, int *, double *, int *, int *, int *);
+  static getrf_fn real = NULL;
+  if (!real) {
+    real = (getrf_fn)dlsym(RTLD_NEXT, "dgetrf_");
+    if (!real) {
+      fprintf(stderr, "ref_driver: the LAPACK library's dgetrf_ was not found\n");
+      abort();
+    }
+  }
+  if (g_getrf_capture && *m == *n) {
+    g_getrf_last_n = *n;
+    g_getrf_last.assign((size_t)(*n) * (*n), 0.0);
+    for (int j = 0; j < *n; j++)
+      for (int i = 0; i < *n; i++) g_getrf_last[i + (size_t)(*n) * j] = a[i + (size_t)(*lda) * j];
+  }
+  real(m, n, a, lda, ipiv, info);
+}
+
+// ---------------------------------------------------------------------------
 // Counter-hash synthetic data: identical in oracle/paropt_oracle.py and in the
 // HIP product (paropt_amd/csrc/problems.hip).  u01(seed, array_id, global index).
 // ---------------------------------------------------------------------------
@@ -562,6 +592,10 @@ struct DumpHook {
   RecFile *rec;
   int kat_iter;  // iteration at which the private single-step KAT is dumped (-1: never)
   int dump_vecs_every;
+  // large-n KATs: kat_light = 1 leaves out what the problem definition implies (g, Ac, lb, ub) and the formed Z
+  // (S, Y are kept); kat_out_stride > 1 stores the compare-only vectors (Dinv, residual, steps) as every
+  // stride-th entry.  The injected state (x, zl, zu, S, Y) is always complete.
+  int kat_light, kat_out_stride;
 };
 
 void SepProblem::writeOutput(int iter, ParOptVec *x) {
@@ -696,13 +730,21 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     ip->computeResNorm(PAROPT_INFTY_NORM, ip->residual, &mp, &md, &mi, &rn);
     double rnorms[4] = {mp, md, mi, rn};
     R.f64("kat/res_norms", rnorms, 4);
-    R.vec("kat/g", ip->g);
-    for (int j = 0; j < c; j++) R.vec(fmt("kat/Ac%d", j).c_str(), ip->Ac[j]);
-    R.vec("kat/lb", ip->lb);
-    R.vec("kat/ub", ip->ub);
+    const bool light = hook->kat_light != 0;
+    const int stride_saved = R.stride;
+    if (!light) {
+      R.vec("kat/g", ip->g);
+      for (int j = 0; j < c; j++) R.vec(fmt("kat/Ac%d", j).c_str(), ip->Ac[j]);
+      R.vec("kat/lb", ip->lb);
+      R.vec("kat/ub", ip->ub);
+    }
     R.vec("kat/x", ip->variables.x);
     R.vec("kat/zl", ip->variables.zl);
     R.vec("kat/zu", ip->variables.zu);
+    if (hook->kat_out_stride > 1) {
+      R.stride = hook->kat_out_stride;
+      R.i32s("kat/out_stride", hook->kat_out_stride);
+    }
     R.vec("kat/res_x", ip->residual.x);
     R.vec("kat/res_zl", ip->residual.zl);
     R.vec("kat/res_zu", ip->residual.zu);
@@ -711,20 +753,76 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     R.f64("kat/res_t", ip->residual.t, c);
     R.f64("kat/res_zs", ip->residual.zs, c);
     R.f64("kat/res_zt", ip->residual.zt, c);
+    if (wn > 0) {  // sparse-constraint blocks of the state and of the residual (w-sized: always complete)
+      const int so = R.stride;
+      R.stride = stride_saved;
+      const char *wnames[5] = {"zw", "sw", "tw", "zsw", "ztw"};
+      ParOptVec *wvars[5] = {ip->variables.zw, ip->variables.sw, ip->variables.tw, ip->variables.zsw,
+                             ip->variables.ztw};
+      ParOptVec *wres[5] = {ip->residual.zw, ip->residual.sw, ip->residual.tw, ip->residual.zsw,
+                            ip->residual.ztw};
+      for (int b = 0; b < 5; b++) {
+        R.vec(fmt("kat/%s", wnames[b]).c_str(), wvars[b]);
+        R.vec(fmt("kat/res_%s", wnames[b]).c_str(), wres[b]);
+      }
+      R.stride = so;
+    }
+    // dense blocks of the state and the scalars the step depends on (state injection on the device side)
+    R.f64("kat/z", ip->variables.z, c);
+    R.f64("kat/s", ip->variables.s, c);
+    R.f64("kat/t", ip->variables.t, c);
+    R.f64("kat/zs", ip->variables.zs, c);
+    R.f64("kat/zt", ip->variables.zt, c);
+    R.f64s("kat/mu", ip->barrier_param);
+    R.f64("kat/c", ip->c, c);
+    R.f64s("kat/fobj", ip->fobj);
+    g_getrf_capture = true;
     ip->setUpKKTDiagSystem(ip->variables, ip->s_qn, ip->wtemp, 1);
     R.vec("kat/Dinv", ip->Dinv);
+    if (c > 0 && g_getrf_last_n == c) R.f64("kat/Gmat", g_getrf_last.data(), (int64_t)c * c);  // as assembled
     R.f64("kat/Gmat_lu", ip->Gmat, (int64_t)c * c);
     R.i32("kat/gpiv", ip->gpiv, c);
+    g_getrf_last_n = 0;
     ip->setUpKKTSystem(ip->variables, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, 1);
+    g_getrf_capture = false;
     if (ip->qn) {
       ParOptScalar b0;
       const ParOptScalar *d0, *M;
       ParOptVec **Z;
       int k = ip->qn->getCompactMat(&b0, &d0, &M, &Z);
-      for (int j = 0; j < k; j++) R.vec(fmt("kat/Z%d", j).c_str(), Z[j]);
+      if (!light)
+        for (int j = 0; j < k; j++) R.vec(fmt("kat/Z%d", j).c_str(), Z[j]);
       if (k > 0) {
+        if (g_getrf_last_n == k) R.f64("kat/Ce", g_getrf_last.data(), (int64_t)k * k);  // as assembled
         R.f64("kat/Ce_lu", ip->Ce, (int64_t)k * k);
         R.i32("kat/cpiv", ip->cpiv, k);
+      }
+      // the limited-memory state behind (b0, d0, M, Z): pairs and the small matrices the update maintains
+      // (src/ParOptQuasiNewton.h:120-147, 196-220), so a device-side test can load exactly this memory
+      ParOptLBFGS *lb_ = dynamic_cast<ParOptLBFGS *>(ip->qn);
+      ParOptLSR1 *sr_ = dynamic_cast<ParOptLSR1 *>(ip->qn);
+      int msub = lb_ ? lb_->msub : (sr_ ? sr_->msub : 0);
+      int msub_max = lb_ ? lb_->msub_max : (sr_ ? sr_->msub_max : 0);
+      ParOptVec **Sv = lb_ ? lb_->S : (sr_ ? sr_->S : NULL);
+      ParOptVec **Yv = lb_ ? lb_->Y : (sr_ ? sr_->Y : NULL);
+      if (Sv) {
+        int sz[2] = {msub, msub_max};
+        R.i32("kat/qn_sizes", sz, 2);
+        R.f64s("kat/qn_b0", b0);
+        R.f64("kat/qn_B", lb_ ? lb_->B : sr_->B, (int64_t)msub_max * msub_max);
+        R.f64("kat/qn_L", lb_ ? lb_->L : sr_->L, (int64_t)msub_max * msub_max);
+        R.f64("kat/qn_D", lb_ ? lb_->D : sr_->D, msub_max);
+        if (k > 0) {
+          R.f64("kat/qn_M", M, (int64_t)k * k);
+          R.f64("kat/qn_d0", d0, k);
+        }
+        const int so = R.stride;
+        R.stride = stride_saved;
+        for (int j = 0; j < msub; j++) {
+          R.vec(fmt("kat/S%d", j).c_str(), Sv[j]);
+          R.vec(fmt("kat/Y%d", j).c_str(), Yv[j]);
+        }
+        R.stride = so;
       }
     }
     ip->computeKKTStep(ip->variables, ip->residual, ip->update, ip->ztemp, ip->s_qn, ip->y_qn,
@@ -737,6 +835,13 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     R.f64("kat/step_t", ip->update.t, c);
     R.f64("kat/step_zs", ip->update.zs, c);
     R.f64("kat/step_zt", ip->update.zt, c);
+    if (wn > 0) {
+      R.vec("kat/step_zw", ip->update.zw);
+      R.vec("kat/step_sw", ip->update.sw);
+      R.vec("kat/step_tw", ip->update.tw);
+      R.vec("kat/step_zsw", ip->update.zsw);
+      R.vec("kat/step_ztw", ip->update.ztw);
+    }
     double comp = ip->computeComp(ip->variables);
     R.f64s("kat/comp", comp);
     double mx, mz;
@@ -745,6 +850,35 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     R.f64("kat/max_step_tau095", ms, 2);
     double compstep = ip->computeCompStep(ip->variables, mx, mz, ip->update);
     R.f64s("kat/comp_step", compstep);
+    // one step of iterative refinement, the sequence of optimize() (:4985-4991): the step the iteration actually
+    // takes with the default iterative_refinement_steps = 1
+    ip->computeKKTRes(ip->variables, ip->barrier_param, ip->residual);
+    ip->addKKTResStep(ip->variables, ip->update, ip->residual, ip->xtemp, 0);
+    R.vec("kat/rres_x", ip->residual.x);  // the refinement's right-hand side: r - K p
+    R.f64("kat/rres_z", ip->residual.z, c);
+    ip->computeKKTStep(ip->variables, ip->residual, ip->refine, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, 1);
+    ip->update.add(ip->refine);
+    R.vec("kat/rstep_x", ip->update.x);
+    R.vec("kat/rstep_zl", ip->update.zl);
+    R.vec("kat/rstep_zu", ip->update.zu);
+    R.f64("kat/rstep_z", ip->update.z, c);
+    R.f64("kat/rstep_s", ip->update.s, c);
+    R.f64("kat/rstep_t", ip->update.t, c);
+    R.f64("kat/rstep_zs", ip->update.zs, c);
+    R.f64("kat/rstep_zt", ip->update.zt, c);
+    if (wn > 0) {
+      R.vec("kat/rstep_zw", ip->update.zw);
+      R.vec("kat/rstep_sw", ip->update.sw);
+      R.vec("kat/rstep_tw", ip->update.tw);
+      R.vec("kat/rstep_zsw", ip->update.zsw);
+      R.vec("kat/rstep_ztw", ip->update.ztw);
+    }
+    ip->computeMaxStep(ip->variables, 0.95, ip->update, &mx, &mz);
+    double rms[2] = {mx, mz};
+    R.f64("kat/rmax_step_tau095", rms, 2);
+    R.stride = stride_saved;
+    // leave the residual as optimize() expects it (it is recomputed right after the hook returns anyway)
+    ip->computeKKTRes(ip->variables, ip->barrier_param, ip->residual);
   }
 }
 
@@ -979,6 +1113,8 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   hook.ip = ip;
   hook.rec = &R;
   hook.kat_iter = (int)geti(A, "kat_iter", -1);
+  hook.kat_light = (int)geti(A, "kat_light", 0);
+  hook.kat_out_stride = (int)geti(A, "kat_out_stride", 1);
   hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
   if (!bench) {
     if (rank == 0) R.open(gets(A, "out", "/tmp/ip.rec").c_str());

@@ -91,6 +91,13 @@ class Context:
         check(lib.po_ctx_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def sync_counters(self):
+        """{flag_waits, flag_timeouts, allreduces, allgathers}: the polled completions of reductions, those that fell back
+        to the stream synchronisation after the bounded spin, and the RCCL collectives issued (po_ctx_sync_counters)."""
+        v = [C.c_int64() for _ in range(4)]
+        check(lib.po_ctx_sync_counters(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("flag_waits", "flag_timeouts", "allreduces", "allgathers"), (x.value for x in v)))
+
     def bench_collective(self, count, pure_sum=True, reps=50):
         """{median, min, max} host microseconds of one reduction exchange of `count` doubles (collective)."""
         out = (C.c_double * 3)()
@@ -333,6 +340,21 @@ class _QuasiNewton:
 
     def setInitDiagonalType(self, t):
         check(lib.po_qn_set_diag_type(self._h, 1 if t in (1, "yts_over_sts") else 0))
+
+    def debugLoad(self, b0, B, Lm, D, S, Y):
+        """po_qn_debug_load: take over a complete limited-memory state (test hook).  B, Lm are (ld x ld) arrays in the
+        reference's column-major storage (flat), D has ld entries, S / Y are lists of numpy vectors of the local size."""
+        msub = len(S)
+        ld = len(D)
+        Bf = np.ascontiguousarray(B, dtype=np.float64).ravel()
+        Lf = np.ascontiguousarray(Lm, dtype=np.float64).ravel()
+        Df = np.ascontiguousarray(D, dtype=np.float64).ravel()
+        sv = [PVec(self.ctx, len(v)).from_numpy(v) for v in S]
+        yv = [PVec(self.ctx, len(v)).from_numpy(v) for v in Y]
+        sh = (L.po_vec * max(msub, 1))(*[v.handle.value for v in sv])
+        yh = (L.po_vec * max(msub, 1))(*[v.handle.value for v in yv])
+        check(lib.po_qn_debug_load(self._h, msub, float(b0), Bf.ctypes.data_as(L.c_double_p),
+                                   Lf.ctypes.data_as(L.c_double_p), Df.ctypes.data_as(L.c_double_p), ld, sh, yh))
 
     def getCompactMat(self):
         k, b0 = C.c_int(), C.c_double()
@@ -935,6 +957,43 @@ class InteriorPoint:
         if wh[0]:
             for name, h in zip(("zw", "sw", "tw", "zsw", "ztw"), wh):
                 out[name] = PVec(self.ctx, handle=h, owned=False).to_numpy()
+        return out
+
+    def debugSetState(self, z, s, t, zs, zt, mu):
+        """po_ip_debug_set_state: dense blocks + barrier parameter of an injected state (x, zl, zu and the sparse
+        blocks are written through getOptimizedPoint() / getOptimizedSparse() handles beforehand)."""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (z, s, t, zs, zt)]
+        check(lib.po_ip_debug_set_state(self._h, *[a.ctypes.data_as(L.c_double_p) for a in arrs], float(mu)))
+
+    def debugKKT(self, mu, mode, tau=0.95):
+        """po_ip_debug_kkt: the pieces of one KKT step at the current state as numpy copies (mode 0: one bordered
+        solve; mode 1: the fused kernel sequence of a plain iteration = the step after one refinement)."""
+        d = L.KKTDump()
+        check(lib.po_ip_debug_kkt(self._h, float(mu), int(mode), float(tau), C.byref(d)))
+        c, k = d.c, d.k
+        m = c + k
+
+        def arr(p, cnt):
+            return np.array([p[i] for i in range(cnt)], dtype=np.float64)
+
+        def vec(h):
+            return PVec(self.ctx, handle=L.po_vec(h), owned=False).to_numpy()
+
+        out = dict(c=c, k=k, Dinv=vec(d.Dinv), res_x=vec(d.res_x), res_z=arr(d.res_z, c), res_s=arr(d.res_s, c),
+                   res_t=arr(d.res_t, c), res_zs=arr(d.res_zs, c), res_zt=arr(d.res_zt, c),
+                   res_norms=np.array(list(d.res_norms)),
+                   W=arr(d.W, m * m).reshape(m, m).T, G=arr(d.G, c * c).reshape(c, c).T,
+                   Ce=arr(d.Ce, k * k).reshape(k, k).T if k > 0 else np.zeros((0, 0)),
+                   gpiv=np.array([d.gpiv[i] for i in range(c)], dtype=np.int64) + 1,
+                   cpiv=np.array([d.cpiv[i] for i in range(k)], dtype=np.int64) + 1,
+                   step_x=vec(d.px), step_zl=vec(d.pzl), step_zu=vec(d.pzu), step_z=arr(d.pz, c),
+                   step_s=arr(d.ps, c), step_t=arr(d.pt, c), step_zs=arr(d.pzs, c), step_zt=arr(d.pzt, c),
+                   step_mins=np.array(list(d.step_mins)))
+        wh = [L.po_vec() for _ in range(5)]
+        check(lib.po_ip_debug_kkt_step_sparse(self._h, *[C.byref(h) for h in wh]))
+        if wh[0]:
+            for name, h in zip(("zw", "sw", "tw", "zsw", "ztw"), wh):
+                out["step_" + name] = PVec(self.ctx, handle=h, owned=False).to_numpy()
         return out
 
     def snapshot(self):

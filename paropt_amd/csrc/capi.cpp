@@ -67,6 +67,15 @@ int po_ctx_counters(po_ctx ctx, int64_t *reductions, int64_t *launches) {
   if (launches) *launches = ctx->n_launches;
   return PO_OK;
 }
+int po_ctx_sync_counters(po_ctx ctx, int64_t *flag_waits, int64_t *flag_timeouts, int64_t *allreduces,
+                         int64_t *allgathers) {
+  PO_CHECK_PTR(ctx);
+  if (flag_waits) *flag_waits = ctx->n_flag_waits;
+  if (flag_timeouts) *flag_timeouts = ctx->n_flag_timeouts;
+  if (allreduces) *allreduces = ctx->n_allreduce;
+  if (allgathers) *allgathers = ctx->n_allgather;
+  return PO_OK;
+}
 int po_ctx_algorithmic_bytes(po_ctx ctx, double *total, double *user) {
   PO_CHECK_PTR(ctx);
   if (total) *total = ctx->alg_bytes;
@@ -490,6 +499,24 @@ int po_qn_get_pivots(po_qn qn, const int **mfpiv, int *n) {
   if (mfpiv) *mfpiv = qn->qn->pivots().data();
   if (n) *n = (int)qn->qn->pivots().size();
   return PO_OK;
+}
+int po_qn_debug_load(po_qn qn, int msub, double b0, const double *B, const double *L, const double *D, int ld,
+                     const po_vec *S, const po_vec *Y) {
+  PO_CHECK_PTR(qn);
+  if (msub > 0) {
+    PO_CHECK_PTR(B);
+    PO_CHECK_PTR(L);
+    PO_CHECK_PTR(D);
+    PO_CHECK_PTR(S);
+    PO_CHECK_PTR(Y);
+  }
+  std::vector<Vec *> s(msub > 0 ? msub : 1, nullptr), y(msub > 0 ? msub : 1, nullptr);
+  for (int j = 0; j < msub; j++) {
+    s[j] = S[j];
+    y[j] = Y[j];
+  }
+  qn->zhandles.clear();
+  return qn->qn->debugLoad(msub, b0, B, L, D, ld, s.data(), y.data());
 }
 int po_qn_max_size(po_qn qn, int *size) {
   PO_CHECK_PTR(qn);
@@ -1032,6 +1059,54 @@ int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *p
   if (pt) *pt = p->step.t.data();
   if (pzs) *pzs = p->step.zs.data();
   if (pzt) *pzt = p->step.zt.data();
+  return PO_OK;
+}
+
+int po_ip_debug_set_state(po_ip ip, const double *z, const double *s, const double *t, const double *zs,
+                          const double *zt, double mu) {
+  PO_CHECK_PTR(ip);
+  InteriorPoint *p = ip->ip;
+  if (p->c > 0) {
+    PO_CHECK_PTR(z);
+    PO_CHECK_PTR(s);
+    PO_CHECK_PTR(t);
+    PO_CHECK_PTR(zs);
+    PO_CHECK_PTR(zt);
+  }
+  return p->debugSetState(z, s, t, zs, zt, mu);
+}
+int po_ip_debug_kkt(po_ip ip, double mu, int mode, double tau, po_ip_kkt_dump *out) {
+  PO_CHECK_PTR(ip);
+  PO_CHECK_PTR(out);
+  InteriorPoint *p = ip->ip;
+  if (mode != 0 && mode != 1) return PO_ERR_ARG;
+  PO_TRY(p->debugKKT(mu, mode, tau));
+  memset(out, 0, sizeof(*out));
+  out->c = p->c;
+  out->k = (int)p->cPivots().size();
+  out->Dinv = static_cast<po_vec>(p->dinvVec());
+  out->res_x = static_cast<po_vec>(p->rxVec());
+  out->res_z = p->res.z.data();
+  out->res_s = p->res.s.data();
+  out->res_t = p->res.t.data();
+  out->res_zs = p->res.zs.data();
+  out->res_zt = p->res.zt.data();
+  for (int i = 0; i < 4; i++) out->res_norms[i] = p->debug_norms[i];
+  out->W = p->gramMatrix().data();
+  out->G = p->Gmat0.data();
+  out->Ce = p->Ce0.data();
+  out->gpiv = p->gPivots().data();
+  out->cpiv = p->cPivots().data();
+  out->px = static_cast<po_vec>(p->px);
+  out->pzl = static_cast<po_vec>(p->pzl);
+  out->pzu = static_cast<po_vec>(p->pzu);
+  out->pz = p->step.z.data();
+  out->ps = p->step.s.data();
+  out->pt = p->step.t.data();
+  out->pzs = p->step.zs.data();
+  out->pzt = p->step.zt.data();
+  out->step_mins[0] = p->stepMins()[0];
+  out->step_mins[1] = p->stepMins()[1];
   return PO_OK;
 }
 

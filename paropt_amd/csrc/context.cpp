@@ -38,21 +38,33 @@ void dbg_switch_set(int id, int value) {
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off);
 int launch_reduce_final_multi(Ctx *c, const Ctx::PendingRed *pend, int count);
+int launch_red_publish(Ctx *c, const double *src, int count);
 // (Re)allocates the pinned result buffer and the alias the device writes through (see Ctx::h_red_dev).
 static int alloc_h_red(Ctx *c, size_t doubles) {
   if (c->h_red) (void)hipHostFree(c->h_red);
   c->h_red = nullptr;
   c->h_red_dev = nullptr;
-  PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * doubles, hipHostMallocDefault));
-  // (coherent pinned memory: what a kernel wrote there is visible to the host once the stream has been synchronised)
+  // Coherent (fine-grained), mapped pinned memory, asked for explicitly: a kernel's system-scope stores there are
+  // visible to a polling host thread without a stream synchronisation (the completion flag below relies on it)
+  if (hipHostMalloc((void **)&c->h_red, sizeof(double) * doubles, hipHostMallocMapped | hipHostMallocCoherent) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    c->h_red = nullptr;
+    PO_HIP(hipHostMalloc((void **)&c->h_red, sizeof(double) * doubles, hipHostMallocDefault));
+    c->h_red_coherent = 0;
+  } else {
+    c->h_red_coherent = 1;
+  }
   if (getenv("PAROPT_AMD_NO_DIRECT_RED") ||
       hipHostGetDevicePointer((void **)&c->h_red_dev, c->h_red, 0) != hipSuccess) {
     (void)hipGetLastError();
     c->h_red_dev = nullptr;
   }
   // the completion flag of the final reduction stages (see Ctx::h_flag): allocated once
-  if (c->h_red_dev && !c->h_flag && !getenv("PAROPT_AMD_NO_FLAG_POLL")) {
-    if (hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocDefault) == hipSuccess &&
+  // (without the explicit coherence guarantee the flag is not used at all: results behind a flag the host has seen
+  // could themselves be stale)
+  if (c->h_red_dev && !c->h_flag && c->h_red_coherent && !getenv("PAROPT_AMD_NO_FLAG_POLL")) {
+    if (hipHostMalloc((void **)&c->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
         hipHostGetDevicePointer((void **)&c->h_flag_dev, c->h_flag, 0) == hipSuccess &&
         hipMalloc((void **)&c->d_ticket, sizeof(unsigned)) == hipSuccess &&
         hipMemset(c->d_ticket, 0, sizeof(unsigned)) == hipSuccess) {
@@ -70,6 +82,7 @@ static int alloc_h_red(Ctx *c, size_t doubles) {
 
 
 static int comm_self_test(Ctx *c);
+static void free_overflow(Ctx *c, const double *keep);
 
 // ---- RCCL through dlopen: the library is only needed for world sizes > 1 ----------------------
 struct Id128 {  // ncclUniqueId: 128 opaque bytes passed BY VALUE to ncclCommInitRank
@@ -250,6 +263,7 @@ int ctx_destroy(Ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
+  free_overflow(c, nullptr);
   if (c->partials_base) (void)hipFree(c->partials_base);
   if (c->d_red) (void)hipFree(c->d_red);
   if (c->d_gather) (void)hipFree(c->d_gather);
@@ -280,8 +294,20 @@ static int grow_partials(Ctx *c, size_t doubles) {
   return PO_OK;
 }
 // Region for the first-stage partials of the launch about to be issued (c->d_partials).  Outside a batch: the arena
-// itself.  Inside a batch: a region of its own, so that the final stage can wait for the flush; when the arena is
-// full the queued reductions are flushed first (always safe: a flush only makes results available earlier).
+// itself.  Inside a batch: a region of its own, so that the final stage can wait for the flush.  When the arena is
+// full the region is a chunk of its own (freed after the flush): whether THIS rank's arena is full depends on its
+// local grid sizes, so a flush here -- a collective -- could be issued by one rank and not by its peers.
+static void free_overflow(Ctx *c, const double *keep) {
+  std::vector<double *> kept;
+  for (double *p : c->partials_overflow) {
+    if (p == keep) {
+      kept.push_back(p);
+    } else {
+      (void)hipFree(p);
+    }
+  }
+  c->partials_overflow.swap(kept);
+}
 int ensure_partials(Ctx *c, size_t doubles) {
   const bool queued = c->batch_depth > 0 || !c->batch_pend.empty();
   if (!queued) {
@@ -292,8 +318,12 @@ int ensure_partials(Ctx *c, size_t doubles) {
   }
   const size_t need = (doubles + 63) & ~(size_t)63;  // 512-byte granules
   if (c->partials_cursor + need > c->partials_cap) {
-    PO_TRY(batch_flush(c));
-    if (need > c->partials_cap) PO_TRY(grow_partials(c, need));
+    double *chunk = nullptr;
+    PO_HIP(hipMalloc((void **)&chunk, need * sizeof(double)));
+    c->partials_overflow.push_back(chunk);
+    c->d_partials = chunk;
+    c->partials_last = need;
+    return PO_OK;
   }
   c->d_partials = c->partials_base + c->partials_cursor;
   c->partials_cursor += need;
@@ -308,6 +338,40 @@ int ensure_partials(Ctx *c, size_t doubles) {
 // host-callback communicator) straight into the pinned host buffer -- no device-to-host copy command before the sync.
 bool red_direct(const Ctx *c) { return c->comm_kind != COMM_RCCL && c->h_red_dev != nullptr; }
 
+// Host side of the completion flag: poll the sequence number the last flagged launch raises behind its results.
+// Bounded (200 ms of spinning with pause instructions, far beyond any queue of kernels ahead of the final stage);
+// past the bound the stream is synchronised -- always correct, and counted (Ctx::n_flag_timeouts, po_ctx_sync_counters)
+// so that a flag that is never raised shows up in a soak test instead of degrading silently.
+static int wait_results(Ctx *c) {
+  volatile unsigned long long *f = c->h_flag;
+  const unsigned long long want = c->red_seq;
+  bool seen = false;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  c->n_flag_waits++;
+  for (long spin = 0;; spin++) {
+    if (*f == want) {
+      seen = true;
+      break;
+    }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_ia32_pause();
+#endif
+    if ((spin & 1023) == 1023) {
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > 0.2) break;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the results in h_red are read after the flag, also by the compiler
+  c->red_seq_seen = want;
+  if (!seen) {
+    c->n_flag_timeouts++;
+    PO_HIP(hipStreamSynchronize(c->stream));
+  }
+  return PO_OK;
+}
+
 static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **parts_out, int *nparts_out) {
   const size_t bytes = sizeof(double) * (size_t)total;
   int nparts = 1;
@@ -320,6 +384,7 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
     fprintf(stderr, "== host sync %ld (%d values)\n", c->n_reductions, total);
     backtrace_symbols_fd(frames + 1, nf > 1 ? nf - 1 : 0, 2);
   }
+  const bool can_poll = c->h_red_dev && c->h_flag_dev && c->h_flag;
   if (c->comm_kind == COMM_RCCL && c->rccl_allreduce && pure_sum) {
     // the MPI_Allreduce(SUM) sites of the reference (dot/mdot/Gram entries, src/ParOptVec.cpp:124-170,
     // src/ParOptInteriorPoint.cpp:1957) -> ONE ncclAllReduce over xGMI on the solver's stream, in place in d_red;
@@ -331,8 +396,16 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
       return PO_ERR_COMM;
     }
     c->n_allreduce++;
-    PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
-    PO_HIP(hipStreamSynchronize(c->stream));
+    // results -> pinned host memory + completion flag by a one-workgroup kernel behind the collective, polled by the
+    // host (round 5: the completion path of the single-rank runs; it replaces copy command + stream synchronisation
+    // exactly where the exchanges ARE the scaling loss, at n / 8 per rank)
+    if (can_poll) {
+      PO_TRY(launch_red_publish(c, c->d_red, total));
+      PO_TRY(wait_results(c));
+    } else {
+      PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
+      PO_HIP(hipStreamSynchronize(c->stream));
+    }
   } else if (c->comm_kind == COMM_RCCL) {
     c->n_allgather++;
     int rc = g_rccl.AllGather(c->d_red, c->d_gather, (size_t)total, /*ncclDouble*/ 8, c->rccl_comm, c->stream);
@@ -340,27 +413,23 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
       set_error("ncclAllGather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
       return PO_ERR_COMM;
     }
-    PO_HIP(hipMemcpyAsync(c->h_red, c->d_gather, bytes * c->size, hipMemcpyDeviceToHost, c->stream));
-    PO_HIP(hipStreamSynchronize(c->stream));
+    if (can_poll) {
+      PO_TRY(launch_red_publish(c, c->d_gather, total * c->size));
+      PO_TRY(wait_results(c));
+    } else {
+      PO_HIP(hipMemcpyAsync(c->h_red, c->d_gather, bytes * c->size, hipMemcpyDeviceToHost, c->stream));
+      PO_HIP(hipStreamSynchronize(c->stream));
+    }
     nparts = c->size;
   } else {
     // (red_direct: the final stages have written their results into h_red themselves, and the last of them has raised
     // the flag behind its results: poll it -- bounded, then the stream is synchronised as before)
     if (!red_direct(c)) PO_HIP(hipMemcpyAsync(c->h_red, c->d_red, bytes, hipMemcpyDeviceToHost, c->stream));
-    bool seen = false;
     if (red_direct(c) && c->h_flag && c->red_seq > c->red_seq_seen) {
-      volatile unsigned long long *f = c->h_flag;
-      const unsigned long long want = c->red_seq;
-      for (long spin = 0; spin < 4000000; spin++) {
-        if (*f == want) {
-          seen = true;
-          break;
-        }
-      }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // the results in h_red are read after the flag, also by the compiler
-      c->red_seq_seen = want;
+      PO_TRY(wait_results(c));
+    } else {
+      PO_HIP(hipStreamSynchronize(c->stream));
     }
-    if (!seen) PO_HIP(hipStreamSynchronize(c->stream));
     if (c->comm_kind == COMM_CALLBACK) {
       double *all = c->h_red + kMaxRed;
       int rc = c->cb_allgather(c->h_red, all, total, c->cb_user);
@@ -526,6 +595,10 @@ static void combine_segment(const double *parts, int nparts, int stride, int off
 }
 
 void batch_abort(Ctx *c) {
+  if (!c->partials_overflow.empty()) {
+    (void)hipStreamSynchronize(c->stream);
+    free_overflow(c, nullptr);
+  }
   c->batch_pend.clear();
   c->batch_after.clear();
   c->batch_cursor = 0;
@@ -533,7 +606,7 @@ void batch_abort(Ctx *c) {
   c->mdot_timing_pending = false;
 }
 
-int batch_flush(Ctx *c) {
+int batch_flush(Ctx *c, const double *keep_partials) {
   if (c->batch_pend.empty()) {
     // nothing queued: deferred host work (if any slipped in) still runs
     std::vector<std::function<void()>> after;
@@ -557,6 +630,8 @@ int batch_flush(Ctx *c) {
   PO_TRY(exchange_reduced(c, total, pure_sum, &parts, &nparts));
   c->n_batched += (long)pend.size() - 1;
   for (const Ctx::PendingRed &p : pend) combine_segment(parts, nparts, total, p.off, p.nsum, p.nmin, p.nmax, p.host_out);
+  // (the host has the results: every first-stage kernel that wrote into an overflow chunk has finished)
+  if (!c->partials_overflow.empty()) free_overflow(c, keep_partials);
   for (auto &f : after) f();
   return PO_OK;
 }
@@ -568,14 +643,22 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
     return PO_ERR_ARG;
   }
   const bool queued = c->batch_depth > 0 || !c->batch_pend.empty();
+  // (the slot counts are the same on every rank: this flush is issued by all ranks or by none)
+  const double *part = c->d_partials;
   if (queued && c->batch_cursor + nslots > kMaxRed) {
-    PO_TRY(batch_flush(c));
-    // (the partials of THIS reduction are still waiting in their region: the next one must not land on them)
-    if (c->d_partials >= c->partials_base)
-      c->partials_cursor = (size_t)(c->d_partials - c->partials_base) + c->partials_last;
+    // The partials of THIS reduction are still waiting in their region.  The flush resets the arena cursor and runs
+    // the deferred host work, which may itself issue reductions (ensure_partials moves d_partials / partials_last):
+    // region and length are taken before, and the cursor is put back behind the region afterwards so that nothing
+    // lands on it.
+    const size_t len = c->partials_last;
+    PO_TRY(batch_flush(c, part));
+    if (part >= c->partials_base && part < c->partials_base + c->partials_cap) {
+      const size_t end = (size_t)(part - c->partials_base) + len;
+      if (c->partials_cursor < end) c->partials_cursor = end;
+    }
   }
   if (c->batch_depth > 0 || !c->batch_pend.empty()) {
-    c->batch_pend.push_back(Ctx::PendingRed{c->batch_cursor, nsum, nmin, nmax, host_out, c->d_partials, nblocks});
+    c->batch_pend.push_back(Ctx::PendingRed{c->batch_cursor, nsum, nmin, nmax, host_out, part, nblocks});
     c->batch_cursor += nslots;
     if (now || c->batch_depth == 0) return batch_flush(c);
     return PO_OK;

@@ -76,6 +76,9 @@ struct Ctx {
   unsigned long long *h_flag = nullptr, *h_flag_dev = nullptr;
   unsigned *d_ticket = nullptr;
   unsigned long long red_seq = 0, red_seq_seen = 0;
+  int h_red_coherent = 0;                   // h_red / h_flag were allocated with the explicit coherence flags
+  long n_flag_waits = 0, n_flag_timeouts = 0;  // polled completions, and those that fell back to the stream sync
+  std::vector<double *> partials_overflow;  // regions handed out while the arena was full (freed after the flush)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
   // allocated on first use
@@ -148,7 +151,9 @@ struct VirtCols {
 // Inside a BatchScope the call returns before host_out is valid unless `now` is set (which flushes the batch).
 int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *host_out, bool now = false);
 bool red_direct(const Ctx *c);  // the final stages write straight into the pinned host buffer (no RCCL collective)
-int batch_flush(Ctx *c);  // collective + host sync for everything queued; runs the after_reduce() work in order
+// collective + host sync for everything queued; runs the after_reduce() work in order (keep_partials: an overflow
+// region that is still waiting for its final stage and must survive the flush)
+int batch_flush(Ctx *c, const double *keep_partials = nullptr);
 void batch_abort(Ctx *c);  // forget everything queued (error paths)
 // Host work that reads the result of the preceding reduce_finish: immediately outside a batch, at the flush inside.
 template <class F>
@@ -219,7 +224,7 @@ struct BatchScope {
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
 enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_REDO_DT = 2, SW_LEAN_STEP = 3, SW_WGRAM_PRIO = 4,
                  SW_WGRAM_ABLATE = 5, SW_FUSED_MERIT = 6, SW_REDO_DT1 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_LINCOMB_BPC = 10,
-                 SW_SPARE11 = 11, SW_COUNT = 12 };  // one entry per use: an A/B run changes one thing
+                 SW_PERTURB_W = 11, SW_COUNT = 12 };  // one entry per use: an A/B run changes one thing
 int dbg_switch(int id, const char *env, int dflt);
 void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);

@@ -703,12 +703,19 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   // W -= U^T Cw U (d1v is free again: scratch of the panel image; tvec holds t)
   if (has_w) PO_TRY(sparseGramCorrection(P, m, fuse_tw ? d1v : tvec, wbatch.open, panel_done));
   PO_TRY(wbatch.end());
+  // test aid: a relative perturbation of 1e-9 in one Gram entry, which the known-answer tests must detect
+  // (tests/test_gpu_kat.py::test_kat_detects_a_perturbed_gram)
+  if (m > 1 && dbg_switch(SW_PERTURB_W, "PAROPT_AMD_PERTURB_W", 0) != 0) {
+    W[1] *= 1.0 + 1e-9;
+    W[m] = W[1];
+  }
   // G = W_AA + diag(s/zs + t/zt)   (:1952-1970)
   Gf.assign((size_t)c * c, 0.0);
   gpiv.assign(c, 0);
   for (int j = 0; j < c; j++)
     for (int i = 0; i < c; i++) Gf[i + (size_t)c * j] = W[i + (size_t)m * j];
   for (int i = 0; i < c; i++) Gf[(size_t)i * (c + 1)] += vars.s[i] / vars.zs[i] + vars.t[i] / vars.zt[i];
+  Gmat0 = Gf;
   if (c > 0) lu_factor(c, Gf.data(), c, gpiv.data());
   // Ce = W_ZZ - W_ZA G^-1 W_AZ - M / (d0 d0^T)   (:2634-2667 via SURVEY.md 3.4)
   Cef.clear();
@@ -730,7 +737,10 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
         Cef[i + (size_t)k * j] = v;
       }
     }
+    Ce0 = Cef;
     lu_factor(k, Cef.data(), k, cpiv.data());
+  } else {
+    Ce0.clear();
   }
   return PO_OK;
 }
@@ -1191,6 +1201,62 @@ int InteriorPoint::debugKKTStep(double mu) {
     PO_TRY(solveKKT(res, mu, true, false, 0.95, step));
   }
   sx = sz = 1.0;
+  return PO_OK;
+}
+
+int InteriorPoint::debugSetState(const double *z, const double *s, const double *t, const double *zs,
+                                 const double *zt, double mu) {
+  PO_TRY(createQuasiNewton());
+  for (int i = 0; i < c; i++) {
+    vars.z[i] = z[i];
+    vars.s[i] = s[i];
+    vars.t[i] = t[i];
+    vars.zs[i] = zs[i];
+    vars.zt[i] = zt[i];
+  }
+  barrier_param = mu;
+  {
+    const std::string nt = options.str("norm_type");
+    norm_type = nt == "infinity" ? 0 : (nt == "l1" ? 1 : 2);
+  }
+  // nothing carried between the passes of an iteration survives a state written from outside
+  cwx_valid = trial_cw_valid = false;
+  residual_cached = false;
+  iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
+  w_comp_valid = w_merit_cache_valid = merit_cache_valid = false;
+  px_first_only = false;
+  spec_enabled = spec_valid = false;
+  acz_valid = false;
+  ptpx_valid = tdots_valid = t0_valid = false;
+  step_deferred = false;
+  s_qn_from_trial = false;
+  corrector_active = false;
+  inexact_newton_step = false;
+  pz_stored = true;
+  panel_valid = false;
+  if (prob->evalObjCon(x, &fobj, cvals.data()) != 0) return PO_ERR_USER;
+  if (prob->evalObjConGradient(x, g, Ac.data()) != 0) return PO_ERR_USER;
+  ac_valid = true;
+  return PO_OK;
+}
+
+int InteriorPoint::debugKKT(double mu, int mode, double tau) {
+  if (mode == 0) {
+    PO_TRY(debugKKTStep(mu));
+  } else {
+    PO_TRY(createQuasiNewton());
+    PO_TRY(computeResidual(mu, true));
+    allow_virtual_z = analytic_panel_dots && fused_dots && options.integer("iterative_refinement_steps") == 1 &&
+                      !options.integer("use_diag_hessian") && !options.integer("sequential_linear_method");
+    const int setup_rc = setUpKKTSystem(true, false, &mu);
+    allow_virtual_z = false;
+    PO_TRY(setup_rc);
+    lean_step_allowed = false;  // (pzl, pzu) are stored: the test reads them
+    PO_TRY(computeKKTStepWithRefinement(mu, true, tau));
+    PO_TRY(batch_flush(ctx));
+  }
+  denseResidual(mu, res);
+  resNorms(res, &debug_norms[0], &debug_norms[1], &debug_norms[2], &debug_norms[3]);
   return PO_OK;
 }
 

@@ -90,6 +90,22 @@ class InteriorPoint {
   int writeSolutionFile(const char *filename);
   int readSolutionFile(const char *filename);
   int debugKKTStep(double mu);
+  // State-injected known-answer tests (po_ip_debug_set_state / po_ip_debug_kkt): the caller has written x, zl, zu
+  // (and the sparse blocks) through the borrowed handles; this takes the dense blocks and mu, evaluates the problem
+  // at x (objective, constraints, gradient, Jacobian) and drops every quantity carried between passes.
+  int debugSetState(const double *z, const double *s, const double *t, const double *zs, const double *zt, double mu);
+  // mode 0: residual + Schur complements + ONE bordered solve, the stored-step kernels (computeKKTStep :2700-2737);
+  // mode 1: the sequence of a plain quasi-Newton iteration of optimize() -- dinv_d1, the fused Gram pass (unformed
+  //         L-SR1 columns), first solve pass with the refinement's products, refinement pass -- with the
+  //         bound-multiplier steps stored.  Afterwards the matrices AS ASSEMBLED are kept in Gmat0 / Ce0.
+  int debugKKT(double mu, int mode, double tau);
+  std::vector<double> Gmat0, Ce0;   // G and Ce before their LU factorizations (last setUpKKTSystem)
+  double debug_norms[4] = {0, 0, 0, 0};  // max_prime, max_dual, max_infeas, res_norm of the last debugKKT
+  const std::vector<double> &gramMatrix() const { return W; }
+  const std::vector<int> &cPivots() const { return cpiv; }
+  const double *stepMins() const { return step_mins; }
+  Vec *dinvVec() { return Dinv; }
+  Vec *rxVec() { return rx; }
   void flushHistory();
   // checkGradients(dh) (:6196-6199): the problem's finite-difference check at the current point; the report text
   // (what the reference prints) is returned

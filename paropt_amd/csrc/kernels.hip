@@ -101,6 +101,8 @@ __device__ __forceinline__ void block_reduce_store(double (&a)[N], double *__res
 // Completion flag of a final reduction stage whose results go straight into pinned host memory (Ctx::h_flag): every
 // wave fences its result store to system scope, the workgroup meets at a barrier, and the workgroup that draws the
 // last ticket writes the sequence number the host is polling for.  flag == nullptr: nothing (results go to d_red).
+// Called from exactly ONE program point of each kernel, by every thread of the workgroup (the barrier inside is a
+// convergent operation: waves without a slot fall through to the same call instead of returning early).
 __device__ __forceinline__ void red_raise_flag(volatile unsigned long long *flag, unsigned long long seq,
                                                unsigned *ticket) {
   if (!flag) return;
@@ -115,34 +117,56 @@ __device__ __forceinline__ void red_raise_flag(volatile unsigned long long *flag
     }
   }
 }
+// one slot of a final stage: sum / min / max of its first-stage partials over the blocks, lane-strided + butterfly
+__device__ __forceinline__ void red_final_slot(const double *__restrict__ p, int nblocks, int slot, int nsum, int nmin,
+                                               double *__restrict__ o, int lane) {
+  if (slot < nsum) {
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += p[b];
+    acc = wave_reduce<OP_SUM>(acc);
+    if (lane == 0) o[slot] = acc;
+  } else if (slot < nsum + nmin) {
+    double acc = INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmin(acc, p[b]);
+    acc = wave_reduce<OP_MIN>(acc);
+    if (lane == 0) o[slot] = acc;
+  } else {
+    double acc = -INFINITY;
+    for (int b = lane; b < nblocks; b += 64) acc = fmax(acc, p[b]);
+    acc = wave_reduce<OP_MAX>(acc);
+    if (lane == 0) o[slot] = acc;
+  }
+}
 __global__ void __launch_bounds__(kBlock)
     reduce_final_kernel(const double *__restrict__ partials, int nblocks, int nslots, int nsum,
                         int nmin, double *__restrict__ out, volatile unsigned long long *flag, unsigned long long seq,
                         unsigned *ticket) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slot = blockIdx.x * 4 + wave;
-  if (slot >= nslots) {
-    red_raise_flag(flag, seq, ticket);
-    return;
-  }
-  const double *p = partials + (size_t)slot * nblocks;
-  if (slot < nsum) {
-    double acc = 0.0;
-    for (int b = lane; b < nblocks; b += 64) acc += p[b];
-    acc = wave_reduce<OP_SUM>(acc);
-    if (lane == 0) out[slot] = acc;
-  } else if (slot < nsum + nmin) {
-    double acc = INFINITY;
-    for (int b = lane; b < nblocks; b += 64) acc = fmin(acc, p[b]);
-    acc = wave_reduce<OP_MIN>(acc);
-    if (lane == 0) out[slot] = acc;
-  } else {
-    double acc = -INFINITY;
-    for (int b = lane; b < nblocks; b += 64) acc = fmax(acc, p[b]);
-    acc = wave_reduce<OP_MAX>(acc);
-    if (lane == 0) out[slot] = acc;
-  }
+  const bool active = slot < nslots;  // wave-uniform
+  if (active) red_final_slot(partials + (size_t)slot * nblocks, nblocks, slot, nsum, nmin, out, lane);
   red_raise_flag(flag, seq, ticket);
+}
+
+// After a device-side collective (RCCL): copies its `count` results from device memory into the pinned host buffer
+// and raises the completion flag behind them, so that the host polls instead of queueing a device-to-host copy and
+// synchronising the stream -- the completion path single-rank runs already had (one workgroup).
+__global__ void __launch_bounds__(kBlock) red_publish_kernel(const double *__restrict__ src, int count,
+                                                             double *__restrict__ dst,
+                                                             volatile unsigned long long *flag,
+                                                             unsigned long long seq) {
+  for (int i = threadIdx.x; i < count; i += kBlock) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) *flag = seq;
+}
+int launch_red_publish(Ctx *c, const double *src, int count) {
+  c->red_seq++;
+  hipLaunchKernelGGL(red_publish_kernel, dim3(1), dim3(kBlock), 0, c->stream, src, count, c->h_red_dev, c->h_flag_dev,
+                     c->red_seq);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  return PO_OK;
 }
 
 int launch_reduce_final(Ctx *c, int nblocks, int nslots, int nsum, int nmin, int dst_off) {
@@ -173,33 +197,15 @@ __global__ void __launch_bounds__(kBlock) reduce_final_multi_kernel(RedSegTable 
                                                                     unsigned long long seq, unsigned *ticket) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int slot = blockIdx.x * 4 + wave;
-  if (slot >= T.total) {
-    red_raise_flag(flag, seq, ticket);
-    return;
-  }
-  int k = 0;
-  while (k + 1 < T.count && slot >= T.nslots[k]) {
-    slot -= T.nslots[k];
-    k++;
-  }
-  const int nblocks = T.nblocks[k], nsum = T.nsum[k], nmin = T.nmin[k];
-  const double *p = T.part[k] + (size_t)slot * nblocks;
-  double *o = out + T.dst[k];
-  if (slot < nsum) {
-    double acc = 0.0;
-    for (int b = lane; b < nblocks; b += 64) acc += p[b];
-    acc = wave_reduce<OP_SUM>(acc);
-    if (lane == 0) o[slot] = acc;
-  } else if (slot < nsum + nmin) {
-    double acc = INFINITY;
-    for (int b = lane; b < nblocks; b += 64) acc = fmin(acc, p[b]);
-    acc = wave_reduce<OP_MIN>(acc);
-    if (lane == 0) o[slot] = acc;
-  } else {
-    double acc = -INFINITY;
-    for (int b = lane; b < nblocks; b += 64) acc = fmax(acc, p[b]);
-    acc = wave_reduce<OP_MAX>(acc);
-    if (lane == 0) o[slot] = acc;
+  const bool active = slot < T.total;  // wave-uniform
+  if (active) {
+    int k = 0;
+    while (k + 1 < T.count && slot >= T.nslots[k]) {
+      slot -= T.nslots[k];
+      k++;
+    }
+    red_final_slot(T.part[k] + (size_t)slot * T.nblocks[k], T.nblocks[k], slot, T.nsum[k], T.nmin[k], out + T.dst[k],
+                   lane);
   }
   red_raise_flag(flag, seq, ticket);
 }
@@ -877,8 +883,11 @@ int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, d
   PO_TRY(reduce_finish(c, grid, nv, 0, 0, out, timed && !defer));
   if (timed) {
     auto harvest = [c] {
+      // (the results reached the host through the completion flag, possibly without a stream synchronisation: the
+      // event is waited for itself, so that no sample is dropped as "not ready")
       float ms = 0.0f;
-      if (hipEventElapsedTime(&ms, c->ev_mdot0, c->ev_mdot1) == hipSuccess) {
+      if (hipEventSynchronize(c->ev_mdot1) == hipSuccess &&
+          hipEventElapsedTime(&ms, c->ev_mdot0, c->ev_mdot1) == hipSuccess) {
         c->mdot_ms += ms;
         c->mdot_count++;
       }

@@ -207,6 +207,33 @@ int CompactQuasiNewton::storePair(Vec *s, Vec *y, const double *sS, const double
   return PO_OK;
 }
 
+int CompactQuasiNewton::debugLoad(int msub_, double b0_, const double *B_, const double *L_, const double *D_, int ld,
+                                  Vec *const *S_, Vec *const *Y_) {
+  if (msub_ < 0 || msub_ > msub_max || ld < msub_) {
+    set_error("po_qn_debug_load: %d pairs do not fit the subspace of %d (ld %d)", msub_, msub_max, ld);
+    return PO_ERR_ARG;
+  }
+  reset();
+  msub = msub_;
+  b0 = b0_;
+  const int m = msub_max;
+  for (int j = 0; j < msub; j++) {
+    if (!S_[j] || !Y_[j] || S_[j]->n != n || Y_[j]->n != n) {
+      set_error("po_qn_debug_load: pair %d does not have the local size %lld", j, (long long)n);
+      return PO_ERR_ARG;
+    }
+    PO_TRY(k_copy(ctx, S[j]->d, S_[j]->d, n));
+    PO_TRY(k_copy(ctx, Y[j]->d, Y_[j]->d, n));
+    D[j] = D_[j];
+    for (int i = 0; i < msub; i++) {
+      B[i + (size_t)m * j] = B_[i + (size_t)ld * j];
+      L[i + (size_t)m * j] = L_[i + (size_t)ld * j];
+    }
+  }
+  if (msub > 0) rebuildCompact();
+  return PO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 void LBFGS::computeMatUpdate() {  // :339-377
   const int k = msub, m = msub_max;
@@ -336,6 +363,11 @@ int LSR1::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {  // :636-7
   const double epsilon_precision = 1e-12;
   b0 = (sTy > epsilon_precision * yTy) ? yTy / sTy : 1.0;
   PO_TRY(storePair(s, y, dots.data(), dots.data() + mold, sTs, sTy));
+  rebuildCompact();
+  return PO_OK;
+}
+
+void LSR1::rebuildCompact() {  // M = b0 B - L - L^T - D (:712-728), Z_i = Y_i - b0 S_i, LU of M (:743)
   const int k = msub, m = msub_max;
   M.assign((size_t)k * k, 0.0);
   for (int i = 0; i < k; i++)
@@ -352,9 +384,8 @@ int LSR1::updateWithZTs(Vec *s, Vec *y, const double *zTs, int *rc) {  // :636-7
   Z.clear();
   d0.assign(k, 1.0);
   for (int i = 0; i < k; i++) Z.push_back(Zown[i]);
-  z_pending = true;
+  z_pending = k > 0;
   factorM();
-  return PO_OK;
 }
 
 bool LSR1::pendingZ(std::vector<const double *> *Yp, std::vector<const double *> *Sp,

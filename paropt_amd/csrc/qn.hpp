@@ -64,10 +64,19 @@ class CompactQuasiNewton {
   virtual void pendingZDone() {}
   virtual int ensureZ() const { return PO_OK; }
 
+  // Test hook (po_qn_debug_load, state-injected known-answer tests): takes over a complete limited-memory state --
+  // msub_ pairs, b0 and the small matrices the updates maintain (B = S^T S, the strictly lower triangle L of S^T Y,
+  // D = diag(S^T Y); column-major with leading dimension ld, as src/ParOptQuasiNewton.h:141-147 holds them) -- and
+  // rebuilds (d0, M, its LU factors, Z) from it with the arithmetic of update().  L-SR1 columns are left unformed,
+  // as after an update.
+  int debugLoad(int msub_, double b0_, const double *B_, const double *L_, const double *D_, int ld, Vec *const *S_,
+                Vec *const *Y_);
+
   Ctx *ctx;
   int64_t n;
 
  protected:
+  virtual void rebuildCompact() {}  // (d0, M, LU, Z) from (b0, B, L, D, msub): the tail of update()
   // append / rotate a pair and refresh B, D, L from dots already available on the host:
   // sS[i] = s.S_i, sY[i] = s.Y_i for the pairs held BEFORE the update (old ordering)
   int storePair(Vec *s, Vec *y, const double *sS, const double *sY, double sTs, double sTy);
@@ -101,6 +110,9 @@ class LBFGS : public CompactQuasiNewton {
   bool reductionsBatchable() const override { return true; }
   int getMaxLimitedMemorySize() override { return 2 * msub_max; }
 
+ protected:
+  void rebuildCompact() override { computeMatUpdate(); }
+
  private:
   void computeMatUpdate();
   int update_type;
@@ -121,6 +133,9 @@ class LSR1 : public CompactQuasiNewton {
                 double *b0_) const override;
   void pendingZDone() override { z_pending = false; }
   int ensureZ() const override;
+
+ protected:
+  void rebuildCompact() override;
 
  private:
   mutable bool z_pending;

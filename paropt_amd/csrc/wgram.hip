@@ -935,9 +935,11 @@ static int wgram_one_launch(Ctx *c, const double *d, const double *const *V, int
   PO_TRY(k_wgram_launch(c, d, V, nv, n, &grid, &nslots, S, Zout, kpend, b0, preweighted_last, groups, groups_done));
   if (timed) PO_HIP(hipEventRecord(c->ev1, c->stream));
   auto blocks = std::make_shared<std::vector<double>>(nslots);
-  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks->data(), !defer));  // !defer: synchronises the stream
+  PO_TRY(reduce_finish(c, grid, nslots, 0, 0, blocks->data(), !defer));  // !defer: the results are on the host
   if (timed) {
+    // (the host may have seen the completion flag without synchronising the stream: the event is waited for itself)
     float ms = 0.0f;
+    PO_HIP(hipEventSynchronize(c->ev1));
     PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     const int w = kpend > 0 ? 1 : 0;
     c->wgram_ms[w] += ms;

@@ -74,6 +74,17 @@ class ProblemSparseCallbacks(C.Structure):
 
 # Every symbol include/paropt_amd.h declares, with its signature (restype is always int unless
 # stated).  tests/test_capi_symbols.py checks this table against the header and the .so.
+class KKTDump(C.Structure):
+    """po_ip_kkt_dump (include/paropt_amd.h): borrowed views of the pieces of one KKT step."""
+    _fields_ = [("c", C.c_int), ("k", C.c_int), ("Dinv", po_vec), ("res_x", po_vec),
+                ("res_z", c_double_p), ("res_s", c_double_p), ("res_t", c_double_p), ("res_zs", c_double_p),
+                ("res_zt", c_double_p), ("res_norms", C.c_double * 4),
+                ("W", c_double_p), ("G", c_double_p), ("Ce", c_double_p), ("gpiv", c_int_p), ("cpiv", c_int_p),
+                ("px", po_vec), ("pzl", po_vec), ("pzu", po_vec),
+                ("pz", c_double_p), ("ps", c_double_p), ("pt", c_double_p), ("pzs", c_double_p), ("pzt", c_double_p),
+                ("step_mins", C.c_double * 2)]
+
+
 SIGNATURES = {
     "po_last_error": (C.c_char_p, []),
     "po_version": (C.c_char_p, []),
@@ -84,6 +95,7 @@ SIGNATURES = {
     "po_ctx_stream": (C.c_void_p, [po_ctx]),
     "po_ctx_memcpy": (C.c_int, [po_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     "po_ctx_counters": (C.c_int, [po_ctx, c_i64_p, c_i64_p]),
+    "po_ctx_sync_counters": (C.c_int, [po_ctx, c_i64_p, c_i64_p, c_i64_p, c_i64_p]),
     "po_ctx_algorithmic_bytes": (C.c_int, [po_ctx, c_double_p, c_double_p]),
     "po_live_objects": (C.c_int, [c_i64_p, c_i64_p]),
     "po_live_host_mirrors": (C.c_int, [c_i64_p]),
@@ -215,6 +227,10 @@ SIGNATURES = {
         + [C.POINTER(c_double_p)] * 5,
     ),
     "po_ip_debug_kkt_step_sparse": (C.c_int, [po_ip] + [C.POINTER(po_vec)] * 5),
+    "po_ip_debug_set_state": (C.c_int, [po_ip] + [c_double_p] * 5 + [C.c_double]),
+    "po_ip_debug_kkt": (C.c_int, [po_ip, C.c_double, C.c_int, C.c_double, C.POINTER(KKTDump)]),
+    "po_qn_debug_load": (C.c_int, [po_qn, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, C.c_int,
+                                   vec_p, vec_p]),
     "po_tr_create": (C.c_int, [po_problem, C.POINTER(po_tr)]),
     "po_tr_destroy": (C.c_int, [po_tr]),
     "po_tr_set_option_str": (C.c_int, [po_tr, C.c_char_p, C.c_char_p]),

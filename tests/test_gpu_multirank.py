@@ -324,6 +324,48 @@ def test_rccl_plumbing_single_rank(monkeypatch):
     lat = ctx.bench_collective(64, True, 10)
     assert lat["median_us"] > 0 and ctx.comm_info()[1] == nred  # the latency probe is not counted either
     np.testing.assert_array_equal(ctx.allreduce(np.array([3.0, 4.0]), "sum"), [3.0, 4.0])
+    # round 5: behind the collective a one-workgroup kernel publishes the results into pinned host memory and raises
+    # the completion flag; the host polled it for every exchange above and never ran out of its bounded spin
+    sc = ctx.sync_counters()
+    assert sc["flag_waits"] >= nred + ngat and sc["flag_timeouts"] == 0, sc
+    assert sc["allreduces"] == ctx.comm_info()[1] and sc["allgathers"] == ctx.comm_info()[2]
+
+
+@pytest.mark.parametrize("forced_rccl", [False, True])
+def test_completion_flag_soak(monkeypatch, forced_rccl):
+    """1e5 reductions (2e4 through the forced single-rank RCCL communicator: ncclAllReduce / ncclAllGather + publish
+    kernel) finish through the polled completion flag: not one bounded spin runs out (po_ctx_sync_counters), every
+    result equals the first one bit for bit, and batched reductions (one flag for several) are among them."""
+    import ctypes as C
+
+    import paropt_amd as pa
+    from paropt_amd.lib import check, lib
+
+    ctx = pa.Context(0)
+    if forced_rccl:
+        monkeypatch.setenv("PAROPT_AMD_FORCE_RCCL", "1")
+        buf = (C.c_char * 128)()
+        check(lib.po_rccl_unique_id(buf))
+        check(lib.po_ctx_comm_init_rccl(ctx.handle, 0, 1, buf))
+    n = 4099
+    x = pa.PVec(ctx, n).fill_hash(0, 10, 0, 2.0, -1.0)
+    y = pa.PVec(ctx, n).fill_hash(0, 11, 0, 2.0, -1.0)
+    V = [pa.PVec(ctx, n).fill_hash(0, 20 + j, 0, 2.0, -1.0) for j in range(3)]
+    first = (x.dot(y), x.maxabs(), tuple(x.mdot(V)))
+    reps = 20000 if forced_rccl else 100000
+    xh, yh = x.handle, y.handle
+    out = C.c_double()
+    for i in range(reps):
+        if i % 1000 == 0:  # the slower Python paths now and then: max (all-gather form under RCCL) and a panel
+            assert (x.dot(y), x.maxabs(), tuple(x.mdot(V))) == first
+        else:
+            check(lib.po_vec_dot(xh, yh, C.byref(out)))
+            assert out.value == first[0]
+    sc = ctx.sync_counters()
+    assert sc["flag_waits"] >= reps and sc["flag_timeouts"] == 0, sc
+    if forced_rccl:
+        assert sc["allreduces"] >= reps - reps // 1000 and sc["allgathers"] >= reps // 1000, sc
+    ctx.close()
 
 
 def _worker_ckpt(rank, world, port, q, args, opts, path):
