@@ -500,6 +500,12 @@ int po_bench_stream(po_vec x, po_vec y, int kind, int reps, double *avg_ms);
  * quasi-Newton columns) timed in isolation on synthetic vectors; `report` receives a JSON array of
  * {kernel, avg_ms, min_ms, alg_GB, GBps, frac_hbm_8TBps, TFLOPs} (tools/microbench.py). */
 int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, char *report, int report_len);
+/* Roofline table of the vector API and the quasi-Newton products at size n (tools/microbench.py --vec-api): every
+ * ParOptVec operation (src/ParOptVec.cpp:32-204), mdot / the multi-vector axpy at 10 and 40 vectors, LBFGS::mult /
+ * multAdd with 20 pairs and LSR1::mult / multAdd with 10 (src/ParOptQuasiNewton.cpp:390-459, 760-809), each with
+ * SURVEY.md 8d's algorithmic bytes, the HIP-event time of `reps` back-to-back calls, and beside it the measured
+ * ceiling of its stream mix (a trivial kernel moving the same input / output streams).  JSON array in `report`. */
+int po_bench_vec_api(po_ctx ctx, int64_t n, int reps, char *report, int report_len);
 
 /* ---- ParOptTrustRegion over the quadratic / compact-eigenvalue subproblem ------------------------
  * src/ParOptTrustRegion.h:376-480, set up as ParOptOptimizer does for algorithm = "tr"

@@ -168,8 +168,11 @@ def main():
             n, d, ia = disagreement(g, v, True)
             acc = merge(acc, n, d, ia)
             variants.append("cbwr=%s" % cbwr)
+        # (the Rosenbrock objective chains rank-local variables only -- as the reference's own example does, SURVEY.md
+        # 8d C1 -- so another rank count is another problem: code-path variants only)
+        same_problem = case["args"].get("problem") != "rosenbrock"
         for r in (1, 2, 3, 4):
-            if r != r0 and shardable(case, r) and shardable(case, r0):
+            if same_problem and r != r0 and shardable(case, r) and shardable(case, r0):
                 v = run_variant(case, r, None)
                 n, d, ia = disagreement(g, v, False)
                 acc = merge(acc, n, d, ia)

@@ -28,6 +28,7 @@ from .api import (  # noqa: F401
     bench_mdot,
     bench_kernels,
     bench_stream,
+    bench_vec_api,
     bench_wgram,
     wgram,
     wgram_with_groups,

@@ -1498,6 +1498,15 @@ def bench_kernels(ctx, n, c, k, reps=5):
     return json.loads(buf.value.decode())
 
 
+def bench_vec_api(ctx, n, reps=10):
+    """Roofline rows of the vector API and the quasi-Newton products at size n (po_bench_vec_api): list of dicts."""
+    import json
+
+    buf = C.create_string_buffer(32768)
+    check(lib.po_bench_vec_api(ctx.handle, int(n), int(reps), buf, len(buf)))
+    return json.loads(buf.value.decode())
+
+
 def bench_stream(x, y, kind, reps=10):
     """Average kernel ms of a read-only stream (kind 0: x.y) or a copy (kind 1: y <- x), HIP events."""
     ms = C.c_double()

@@ -172,3 +172,221 @@ extern "C" int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, c
   for (Vec *v : all) vec_decref(v);
   return rc;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// po_bench_vec_api (round 5): every ParOptVec operation north_star names (dot / norm / maxabs / l1norm / axpy / scale /
+// copyValues / set / zeroEntries, src/ParOptVec.cpp:32-204), the multi-vector axpy behind ParOptQuasiNewton::mult
+// (:414-416) and LBFGS / LSR1 mult + multAdd (src/ParOptQuasiNewton.cpp:390-459, 760-809) at size n, each beside the
+// CEILING of its stream mix on the same GPU in the same process: a trivial kernel that moves the same number of
+// input and output streams (16 B per lane, non-temporal, same persistent grid) and does nothing else.  Algorithmic
+// bytes per SURVEY.md 8d: dot 16n, axpy 24n, scale / copy 16n, norm / maxabs / l1norm / set 8n, maxpy 8 (nv + 2) n,
+// quasi-Newton mult 8 (2k + 3) n.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+typedef double bk_f64x2 __attribute__((ext_vector_type(2)));
+struct MixPtrs {
+  const double *in[48];
+  double *out[2];
+};
+template <int NIN, int NOUT>
+__global__ void __launch_bounds__(kBlock) trivial_mix_kernel(MixPtrs P, int64_t npairs, double *sink) {
+  bk_f64x2 carry = {0.0, 0.0};
+  for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * kBlock) {
+    bk_f64x2 acc = {1.0, 2.0};
+#pragma unroll
+    for (int j = 0; j < NIN; j++) acc += __builtin_nontemporal_load(reinterpret_cast<const bk_f64x2 *>(P.in[j] + 2 * q));
+#pragma unroll
+    for (int j = 0; j < NOUT; j++) __builtin_nontemporal_store(acc, reinterpret_cast<bk_f64x2 *>(P.out[j] + 2 * q));
+    carry += acc;
+  }
+  if (NOUT == 0 && carry.x + carry.y == 1.234567e300) sink[0] = carry.x;  // keeps the loads of a read-only mix alive
+}
+template <int NIN, int NOUT>
+int launch_mix(Ctx *c, const MixPtrs &P, int64_t n, int bpc, double *sink) {
+  const int64_t npairs = n >> 1;  // whole pairs only: the vectors' padding is not part of the measurement
+  hipLaunchKernelGGL((trivial_mix_kernel<NIN, NOUT>), dim3(grid_for(c, n, bpc)), dim3(kBlock), 0, c->stream, P, npairs,
+                     sink);
+  PO_HIP(hipGetLastError());
+  return PO_OK;
+}
+int run_mix(Ctx *c, int nin, int nout, const MixPtrs &P, int64_t n, double *sink) {
+  const int bpc = nin > 4 ? kBpcPanel : kBpcStream;
+#define PO_MIX(I, O) \
+  if (nin == I && nout == O) return launch_mix<I, O>(c, P, n, bpc, sink)
+  PO_MIX(1, 0);
+  PO_MIX(2, 0);
+  PO_MIX(0, 1);
+  PO_MIX(1, 1);
+  PO_MIX(2, 1);
+  PO_MIX(11, 0);
+  PO_MIX(11, 1);
+  PO_MIX(12, 1);
+  PO_MIX(41, 0);
+  PO_MIX(41, 1);
+  PO_MIX(42, 1);
+#undef PO_MIX
+  set_error("po_bench_vec_api: no trivial kernel for the mix %d in / %d out", nin, nout);
+  return PO_ERR_ARG;
+}
+
+struct ApiTimer {
+  Ctx *c;
+  std::string out;
+  int reps;
+  // events around `reps` back-to-back calls (the calls of reductions include their final stage and the host's wait)
+  template <class F>
+  int time(F f, double *avg_ms) {
+    PO_TRY(f());  // warm-up
+    PO_HIP(hipStreamSynchronize(c->stream));
+    PO_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int r = 0; r < reps; r++) PO_TRY(f());
+    PO_HIP(hipEventRecord(c->ev1, c->stream));
+    PO_HIP(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    PO_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / reps;
+    return PO_OK;
+  }
+  void row(const char *name, const char *ref, double bytes, double ms, const char *mix, double ceil_ms, double ceil_bytes) {
+    char line[768];
+    const double gbps = bytes / (ms * 1e-3) * 1e-9, cg = ceil_bytes / (ceil_ms * 1e-3) * 1e-9;
+    snprintf(line, sizeof(line),
+             "%s{\"op\": \"%s\", \"reference\": \"%s\", \"alg_GB\": %.4f, \"avg_ms\": %.4f, \"GBps\": %.1f, "
+             "\"frac_hbm_8TBps\": %.3f, \"mix\": \"%s\", \"ceiling_ms\": %.4f, \"ceiling_GBps\": %.1f, "
+             "\"frac_of_ceiling\": %.3f}",
+             out.empty() ? "" : ",\n ", name, ref, bytes * 1e-9, ms, gbps, gbps / 8000.0, mix, ceil_ms, cg,
+             ceil_ms / ms);
+    out += line;
+  }
+};
+}  // namespace
+
+extern "C" int po_bench_vec_api(po_ctx ctx, int64_t n, int reps, char *report, int report_len) {
+  if (!ctx || !report || n < 2 || reps < 1) return PO_ERR_ARG;
+  Ctx *cx = ctx;
+  std::vector<Vec *> all;
+  auto mk = [&](uint64_t aid, double scale, double shift) -> Vec * {
+    Vec *v = vec_new(cx, n);
+    if (v) {
+      all.push_back(v);
+      (void)k_fill_hash(cx, v->d, n, 11, aid, 0, scale, shift);
+    }
+    return v;
+  };
+  int rc = PO_OK;
+  double *sink = nullptr;
+  LBFGS *bfgs = nullptr;
+  LSR1 *sr1 = nullptr;
+  auto body = [&]() -> int {
+    PO_HIP(hipMalloc((void **)&sink, 64));
+    Vec *x = mk(1, 2.0, -1.0), *y = mk(2, 2.0, -1.0);
+    if (!x || !y) return PO_ERR_HIP;
+    std::vector<const double *> V;
+    for (int j = 0; j < 41; j++) {
+      Vec *v = mk(100 + j, 2.0, -1.0);
+      if (!v) return PO_ERR_HIP;
+      V.push_back(v->d);
+    }
+    const double N = (double)n;
+    ApiTimer T{cx, "", reps};
+    std::vector<double> coef(48, 1e-3), o(64, 0.0);
+    MixPtrs P;
+    for (int j = 0; j < 48; j++) P.in[j] = V[j % 41];
+    P.in[0] = x->d;
+    P.out[0] = y->d;
+    P.out[1] = y->d;
+    auto ceiling = [&](int nin, int nout, double *ms) -> int {
+      return T.time([&] { return run_mix(cx, nin, nout, P, n, sink); }, ms);
+    };
+    double ms = 0.0, c10 = 0.0, c20 = 0.0, c01 = 0.0, c11 = 0.0, c21 = 0.0;
+    PO_TRY(ceiling(1, 0, &c10));
+    PO_TRY(ceiling(2, 0, &c20));
+    PO_TRY(ceiling(0, 1, &c01));
+    PO_TRY(ceiling(1, 1, &c11));
+    PO_TRY(ceiling(2, 1, &c21));
+    double r = 0.0;
+    PO_TRY(T.time([&] { return k_reduce1(cx, RED_DOT, x->d, y->d, n, &r); }, &ms));
+    T.row("dot", "src/ParOptVec.cpp:124-143", 16.0 * N, ms, "2 in / 0 out", c20, 16.0 * N);
+    PO_TRY(T.time([&] { return k_reduce1(cx, RED_SUMSQ, x->d, nullptr, n, &r); }, &ms));
+    T.row("norm", "src/ParOptVec.cpp:63-80", 8.0 * N, ms, "1 in / 0 out", c10, 8.0 * N);
+    PO_TRY(T.time([&] { return k_reduce1(cx, RED_AMAX, x->d, nullptr, n, &r); }, &ms));
+    T.row("maxabs", "src/ParOptVec.cpp:85-101", 8.0 * N, ms, "1 in / 0 out", c10, 8.0 * N);
+    PO_TRY(T.time([&] { return k_reduce1(cx, RED_ASUM, x->d, nullptr, n, &r); }, &ms));
+    T.row("l1norm", "src/ParOptVec.cpp:106-119", 8.0 * N, ms, "1 in / 0 out", c10, 8.0 * N);
+    PO_TRY(T.time([&] { return k_axpy(cx, y->d, 1e-9, x->d, n); }, &ms));
+    T.row("axpy", "src/ParOptVec.cpp:189-204", 24.0 * N, ms, "2 in / 1 out", c21, 24.0 * N);
+    PO_TRY(T.time([&] { return k_scale(cx, y->d, n, 1.0000001); }, &ms));
+    T.row("scale", "src/ParOptVec.cpp:177-184", 16.0 * N, ms, "1 in / 1 out", c11, 16.0 * N);
+    PO_TRY(T.time([&] { return k_copy(cx, y->d, x->d, n); }, &ms));
+    T.row("copyValues", "src/ParOptVec.cpp:46-56", 16.0 * N, ms, "1 in / 1 out", c11, 16.0 * N);
+    PO_TRY(T.time([&] { return k_fill(cx, y->d, n, 0.25); }, &ms));
+    T.row("set", "src/ParOptVec.cpp:32-36", 8.0 * N, ms, "0 in / 1 out", c01, 8.0 * N);
+    PO_TRY(T.time([&] { return k_fill(cx, y->d, n, 0.0); }, &ms));
+    T.row("zeroEntries", "src/ParOptVec.cpp:41", 8.0 * N, ms, "0 in / 1 out", c01, 8.0 * N);
+    // headline kernel and the multi-vector axpy of ParOptQuasiNewton::mult, k = 10 and 40
+    for (int k : {10, 40}) {
+      double cm0 = 0.0, cm1 = 0.0, cq = 0.0, m_mdot = 0.0, m_maxpy = 0.0;
+      PO_TRY(ceiling(k + 1, 0, &cm0));
+      PO_TRY(ceiling(k + 1, 1, &cm1));  // y <- b0 x + sum: x + k columns in, y out (mult)
+      PO_TRY(ceiling(k + 2, 1, &cq));   // y <- y + ...: y read as well (maxpy / multAdd)
+      char nm[64], mix[64];
+      PO_TRY(T.time([&] { return k_mdot(cx, x->d, V.data(), k, n, o.data()); }, &m_mdot));
+      snprintf(nm, sizeof(nm), "mdot(nvecs=%d)", k);
+      snprintf(mix, sizeof(mix), "%d in / 0 out", k + 1);
+      T.row(nm, "src/ParOptVec.cpp:152-170", 8.0 * (k + 1) * N, m_mdot, mix, cm0, 8.0 * (k + 1) * N);
+      PO_TRY(T.time([&] { return k_panel_axpy(cx, y->d, 0.0, nullptr, 1.0, coef.data(), V.data(), k, n); }, &m_maxpy));
+      snprintf(nm, sizeof(nm), "maxpy(nvecs=%d)", k);
+      snprintf(mix, sizeof(mix), "%d in / 1 out", k + 1);
+      T.row(nm, "src/ParOptQuasiNewton.cpp:414-416", 8.0 * (k + 2) * N, m_maxpy, mix, cm1, 8.0 * (k + 2) * N);
+    }
+    // quasi-Newton products: L-BFGS with 20 pairs (k = 40 columns: config 2) and L-SR1 with 10 (config 3)
+    Vec *s = mk(900, 2.0, -1.0), *yv = mk(901, 0.0, 0.0);
+    if (!s || !yv) return PO_ERR_HIP;
+    bfgs = new LBFGS(cx, n, 20);
+    sr1 = new LSR1(cx, n, 10);
+    for (int i = 0; i < 20; i++) {  // y = 2 s + 0.1 u: positive curvature, every pair accepted
+      int code = 0;
+      PO_TRY(k_fill_hash(cx, s->d, n, 11, 1000 + i, 0, 2.0, -1.0));
+      PO_TRY(k_fill_hash(cx, yv->d, n, 11, 2000 + i, 0, 0.1, 0.0));
+      PO_TRY(k_axpy(cx, yv->d, 2.0, s->d, n));
+      PO_TRY(bfgs->update(s, yv, &code));
+      if (code != 0) {
+        set_error("po_bench_vec_api: synthetic pair %d was not accepted (code %d)", i, code);
+        return PO_ERR_ARG;
+      }
+      if (i < 10) PO_TRY(sr1->update(s, yv, &code));
+    }
+    PO_TRY(sr1->ensureZ());
+    struct QnCase {
+      CompactQuasiNewton *qn;
+      const char *name, *name_add, *ref, *ref_add;
+      int k;
+    } cases[2] = {{bfgs, "LBFGS::mult(k=40)", "LBFGS::multAdd(k=40)", "src/ParOptQuasiNewton.cpp:390-418",
+                   "src/ParOptQuasiNewton.cpp:431-459", 40},
+                  {sr1, "LSR1::mult(k=10)", "LSR1::multAdd(k=10)", "src/ParOptQuasiNewton.cpp:760-778",
+                   "src/ParOptQuasiNewton.cpp:791-809", 10}};
+    for (const QnCase &q : cases) {
+      double cm0 = 0.0, cm1 = 0.0, cm2 = 0.0;
+      PO_TRY(ceiling(q.k + 1, 0, &cm0));
+      PO_TRY(ceiling(q.k + 1, 1, &cm1));
+      PO_TRY(ceiling(q.k + 2, 1, &cm2));
+      char mix[96];
+      PO_TRY(T.time([&] { return q.qn->mult(x, y); }, &ms));
+      snprintf(mix, sizeof(mix), "%d in / 0 out + %d in / 1 out", q.k + 1, q.k + 1);
+      T.row(q.name, q.ref, 8.0 * (2 * q.k + 3) * N, ms, mix, cm0 + cm1, 8.0 * (2 * q.k + 3) * N);
+      PO_TRY(T.time([&] { return q.qn->multAdd(1e-9, x, y); }, &ms));
+      snprintf(mix, sizeof(mix), "%d in / 0 out + %d in / 1 out", q.k + 1, q.k + 2);
+      T.row(q.name_add, q.ref_add, 8.0 * (2 * q.k + 4) * N, ms, mix, cm0 + cm2, 8.0 * (2 * q.k + 4) * N);
+    }
+    snprintf(report, (size_t)report_len, "[%s]", T.out.c_str());
+    return PO_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(cx->stream);
+  delete bfgs;
+  delete sr1;
+  if (sink) (void)hipFree(sink);
+  for (Vec *v : all) vec_decref(v);
+  return rc;
+}

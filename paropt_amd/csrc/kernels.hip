@@ -1806,7 +1806,9 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
 // stay at 2: 3 spills there and costs 1 % at config 3, 7 % at config 2.)
 #define PO_S2D_CASE(NP)                                                                                    \
   case NP: {                                                                                               \
-    constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : (NP <= 12 ? 3 : 2);            \
+    /* (round 5: the alternatives of the wide panels -- 3 workgroups per CU at 11 / 12 slots, 2 at 20 / 24 --       \
+       spilled to scratch and are gone: every instantiation left is scratch-free, tests/test_kernel_resources.py) */ \
+    constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : OD;                            \
     constexpr int OV = NP <= 16 ? 2 : 1; /* with unformed columns: three more prefetch registers */        \
     if (vc.count > 0)                                                                                      \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
@@ -1899,7 +1901,9 @@ __global__ void __launch_bounds__(kBlock)
     const BE es[2] = {e0, e1};
     const double rr[2] = {r.x, r.y}, pp[2] = {p.x, p.y}, ll[2] = {l.x, l.y}, uu[2] = {u.x, u.y},
                  aa[2] = {acc.x, acc.y};
-    for (int k = 0; k < (_has2 ? 2 : 1); k++) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {  // (a compile-time trip count keeps the element arrays in registers)
+      if (k == 1 && !_has2) break;
       double v = rr[k] - diag * pp[k] + aa[k];
       if (b.use_lower) v += ll[k];
       if (b.use_upper) v -= uu[k];

@@ -836,10 +836,12 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   case NGv: {                                                                                          \
     /* measured at NG = 11 (n = 50 M): the plain form is fastest compiled for 3 wavefronts per SIMD, the form   \
        that also forms the L-SR1 columns for 2 (its extra prefetch registers spill at 3) */                     \
-    constexpr int OCC0 = NGv <= 8 ? 4 : (NGv <= 11 ? 3 : (NGv <= 14 ? 2 : 1));                         \
+    /* (round 5: 11 groups at 3 wavefronts per SIMD and the column-forming form of 10 / 11 groups at 3 spilled   \
+       to scratch: 2 there; every instantiation left is scratch-free, tests/test_kernel_resources.py) */        \
+    constexpr int OCC0 = NGv <= 8 ? 4 : (NGv <= 10 ? 3 : (NGv <= 14 ? 2 : 1));                         \
     constexpr int OCC0A = OCC0 > 1 ? OCC0 - 1 : 1;                                                     \
     constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
-    constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 11 ? 3 : 1);                                          \
+    constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 9 ? 3 : OCCZ);                                        \
     if (NGv <= 16 && use_pc && n >= 4 * kGramTile && NGv >= pc_min_ng) {                               \
       constexpr int NGc = NGv <= 16 ? NGv : 16;                                                        \
       if (NGv >= kGramRowSplitMinNG && NGv <= kGramRowSplitMaxNG && row_split) {                       \

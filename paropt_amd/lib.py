@@ -311,6 +311,7 @@ SIGNATURES = {
     "po_ip_get_bounds": (C.c_int, [po_ip, C.POINTER(po_vec), C.POINTER(po_vec)]),
     "po_bench_kernels": (C.c_int, [po_ctx, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "po_bench_stream": (C.c_int, [po_vec, po_vec, C.c_int, C.c_int, c_double_p]),
+    "po_bench_vec_api": (C.c_int, [po_ctx, C.c_int64, C.c_int, C.c_char_p, C.c_int]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
