@@ -112,6 +112,55 @@ GOLDEN_WINDOWS_ORACLE = {
 }
 
 
+# ---- tolerance schedule of the trajectory comparisons (round 5) -----------------------------------------------------
+# tests/golden/self_disagreement.json (oracle/reference_self_disagreement.py, build container): for every trajectory
+# golden and every iteration k, by how much the UNMODIFIED REFERENCE differs from that golden when only the summation
+# order of its reductions changes (three other BLAS code paths, 1-4 MPI ranks), in the normalisations of the checks.
+# The device path is held to
+#       tol(k) = max(1e-12, FACTOR x the largest self-disagreement of iterations 0..k),       FACTOR = 100
+# -- not asked to follow a golden more closely than the reference follows itself, and not allowed the flat 1e-6 / 1e-5
+# of rounds 1-4, eight orders above the agreement actually reached.  Measured on MI355X with
+# tools/trajectory_errors.py (profiles/r05_trajectory_errors.json): the device's deviation is at most 0.41 x tol(k) on
+# every golden and every quantity, except the two below, which get a larger factor with the reason stated.
+SCHEDULE_FLOOR = 1e-12
+SCHEDULE_FACTOR = 100.0
+SCHEDULE_FACTOR_BY_GOLDEN = {
+    # deliberately broken bounds: x is moved off its bounds by the repair, the first iterations are ill-conditioned;
+    # device deviation 140 x the reference's self-disagreement at iteration 2 (6.4e-12 vs 4.6e-14), same ratio later
+    "ip_convex_badbounds7_n300_c3": 300.0,
+    # CSR constraints: the reference runs (golden and variants alike) use the driver's dense LAPACK factorization of
+    # S = C + Aw D^-1 Aw^T (METIS absent: ParOptSparseCholesky cannot be built, VERDICT r3 / r4 "partial"), the device a
+    # level-scheduled sparse Cholesky in elimination order -- another algorithm, not another summation order; from
+    # iteration 34 on (predictor-corrector steps at mu ~ 1e-9) its deviation is 20 x tol(k) of the plain factor
+    "ipcsr_convex_n200_c2_chain5s3_mpc": 3000.0,
+}
+_SD = None
+
+
+def tolerance_schedule(name):
+    """tol(quantity, k) for golden `name`; quantity in mu / fobj / norms / dense / wnorms / vec."""
+    import json
+
+    global _SD
+    if _SD is None:
+        with open(os.path.join(GOLDEN_DIR, "self_disagreement.json")) as f:
+            _SD = json.load(f)
+    assert name in _SD, "no reference self-disagreement record for %s (oracle/reference_self_disagreement.py)" % name
+    d = _SD[name]
+    factor = SCHEDULE_FACTOR_BY_GOLDEN.get(name, SCHEDULE_FACTOR)
+    vec = sorted((int(k), v) for k, v in d["vec"].items())
+
+    def tol(quantity, k):
+        if quantity == "vec":
+            worst = max([v for kk, v in vec if kk <= k] or [0.0])
+        else:
+            series = d[quantity]
+            worst = max(series[: k + 1]) if series else 0.0  # (past the shortest variant: everything recorded)
+        return max(SCHEDULE_FLOOR, factor * worst)
+
+    return tol
+
+
 def oracle_window(name, default):
     return GOLDEN_WINDOWS_ORACLE.get(name, default)
 

@@ -3,9 +3,10 @@ GPU parity of the interior-point path (through the C ABI).
 
   * against the golden trajectories of the compiled reference (tests/golden/ip_*.npz):
     integer bookkeeping (iteration / evaluation counters, quasi-Newton size, info tokens)
-    bit-exact over the compared window; mu, fobj, vector norms to 1e-6 relative; dense multipliers
-    to 1e-5 (the iteration is nonlinear, the product re-associates every reduction and fuses
-    the Schur complements: DESIGN.md "Parity");
+    bit-exact over the compared window; mu, fobj, vector norms, dense multipliers and vectors to the tolerance
+    SCHEDULE of tests/conftest.py: at iteration k, max(1e-12, 100 x the reference's own self-disagreement up to k)
+    (the iteration is nonlinear, the product re-associates every reduction and fuses the Schur complements:
+    DESIGN.md "Parity");
   * against the numpy oracle on larger hash-seeded instances where no golden exists;
   * single KKT step against the reference's private-method dump (1e-5 of the step's max).
 """
@@ -13,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import (GOLDEN_WINDOWS, golden_names, golden_vec_view, golden_window, ip_options_from_case,
-                      load_golden)
+                      load_golden, tolerance_schedule)
 
 pytestmark = pytest.mark.gpu
 
@@ -88,11 +89,13 @@ def test_ip_trajectory_golden(ctx, name):
     g, case = load_golden(name)
     ip, snaps = run_gpu(ctx, case, want_vectors=True)
     nref = 1 + max(int(k[2:5]) for k in g if k.startswith("it") and k.endswith("/mu"))
-    # per-golden windows (tests/conftest.py, measured by tools/agreement_windows.py); an L-SR1 golden without an
-    # entry gets the conservative 8
-    window = golden_window(name, 8 if "sr1" in name else 25)
+    # the WHOLE recorded trajectory (round 5: the tolerance schedule follows the reference's own round-off growth, so
+    # no flat window is needed), except the goldens of GOLDEN_WINDOWS, whose integer bookkeeping the reference itself
+    # does not reproduce past the listed iteration (tests/conftest.py)
+    window = golden_window(name, nref)
     ncmp = min(window, nref, len(snaps))
     assert ncmp >= min(window, nref)
+    tol = tolerance_schedule(name)
     for k in range(ncmp):
         p = "it%03d/" % k
         s = snaps[k]
@@ -104,17 +107,29 @@ def test_ip_trajectory_golden(ctx, name):
         for key in ("gpiv", "mfpiv", "clamped"):
             if p + key in g:
                 np.testing.assert_array_equal(np.asarray(s[key]), g[p + key], err_msg="%s @%d" % (key, k))
-        rt = 1e-6
-        assert abs(s["mu"] - g[p + "mu"][0]) <= rt * abs(g[p + "mu"][0]), "mu @%d" % k
-        assert abs(s["fobj"] - g[p + "fobj"][0]) <= rt * max(1.0, abs(g[p + "fobj"][0])), "fobj @%d" % k
-        used = ~np.isnan(s["norms"])  # a side the problem declares unused has no multiplier vector
-        np.testing.assert_allclose(s["norms"][used], g[p + "norms"][used], rtol=rt, err_msg="norms @%d" % k)
+        # state: the tolerance schedule of tests/conftest.py -- max(1e-12, 100 x what the REFERENCE's own trajectory
+        # moves by up to iteration k when only the summation order of its reductions changes), in the normalisations
+        # of oracle/reference_self_disagreement.py
+        err = abs(s["mu"] - g[p + "mu"][0]) / abs(g[p + "mu"][0])
+        assert err <= tol("mu", k), "mu @%d: %.2e > %.2e" % (k, err, tol("mu", k))
+        err = abs(s["fobj"] - g[p + "fobj"][0]) / max(1.0, abs(g[p + "fobj"][0]))
+        assert err <= tol("fobj", k), "fobj @%d: %.2e > %.2e" % (k, err, tol("fobj", k))
+        na, nb = np.asarray(s["norms"]), np.asarray(g[p + "norms"])
+        used = ~(np.isnan(na) | np.isnan(nb)) & (nb != 0)  # a side the problem declares unused has no multiplier vector
+        if used.any():
+            err = (np.abs(na[used] - nb[used]) / np.abs(nb[used])).max()
+            assert err <= tol("norms", k), "norms @%d: %.2e > %.2e" % (k, err, tol("norms", k))
         for key in ("z", "s", "t", "zs", "zt"):
             ref = g[p + key]
-            np.testing.assert_allclose(s[key], ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()),
-                                       err_msg="%s @%d" % (key, k))
+            if ref.size:
+                err = np.abs(s[key] - ref).max() / max(1.0, np.abs(ref).max())
+                assert err <= tol("dense", k), "%s @%d: %.2e > %.2e" % (key, k, err, tol("dense", k))
         if p + "wnorms" in g:
-            np.testing.assert_allclose(s["wnorms"], g[p + "wnorms"], rtol=rt, err_msg="wnorms @%d" % k)
+            wa, wb = np.asarray(s["wnorms"]), np.asarray(g[p + "wnorms"])
+            nz = wb != 0
+            if nz.any():
+                err = (np.abs(wa[nz] - wb[nz]) / np.abs(wb[nz])).max()
+                assert err <= tol("wnorms", k), "wnorms @%d: %.2e > %.2e" % (k, err, tol("wnorms", k))
         if p + "x" in g:
             keys = ("x", "zl", "zu") + (("zw", "sw", "tw", "zsw", "ztw") if p + "zw" in g else ())
             for key in keys:
@@ -122,8 +137,8 @@ def test_ip_trajectory_golden(ctx, name):
                     continue
                 ref = g[p + key]
                 mine_v = golden_vec_view(s[key], case) if key in ("x", "zl", "zu") else s[key]
-                np.testing.assert_allclose(mine_v, ref, rtol=0, atol=1e-6 * max(1.0, np.abs(ref).max()),
-                                           err_msg="%s @%d" % (key, k))
+                err = np.abs(mine_v - ref).max() / max(1.0, np.abs(ref).max())
+                assert err <= tol("vec", k), "%s @%d: %.2e > %.2e" % (key, k, err, tol("vec", k))
     if "check_flag" in g:  # bound repairs of initAndCheckDesignAndBounds: flag bits and the repaired bounds
         assert ip.getDebugInts()["check_flag"] == int(g["check_flag"][0])
         if "it000/lb" in g:
