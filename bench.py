@@ -46,6 +46,7 @@ QN_SIZE = 10
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (spec); the measured sustained rate is in profiles/
 USER_LIB = os.path.join(ROOT, "examples", "librandom_convex_user.so")
+WEIGHTING_LIB = os.path.join(ROOT, "examples", "libweighting_user.so")  # config 4 as a user's ParOptSparseProblem
 
 
 # ------------------------------------------------------------------------------------------------
@@ -501,14 +502,32 @@ def main():
 
     # ---- the same workload through the user-side boundary (facade) ----
     boundary = None
-    facade_ok = a.problem == "convex" and a.nwcon == 0 and os.path.exists(USER_LIB)
+    user_lib = USER_LIB if a.nwcon == 0 else WEIGHTING_LIB
+    facade_ok = a.problem == "convex" and os.path.exists(user_lib)
     if a.boundary in ("facade", "both"):
         if not facade_ok:
-            msg = "the facade workload is config 3 (convex, no sparse constraints) and needs %s" % USER_LIB
+            msg = "the facade workloads are configs 3 and 4 (convex) and need %s" % user_lib
             if a.boundary == "facade":
                 log("error: " + msg)
                 sys.exit(5)
             log("skipping the facade measurement: " + msg)
+        elif a.nwcon > 0:
+            # config 4: the weighting constraints reach the library ONLY through the reference's ParOptSparseProblem
+            # interface (setSparseJacobianData pattern + the entries the gradient callback writes); the library
+            # recognises the grouped pattern and runs its fused group kernels
+            up = pa.UserLibraryProblem(ctx, user_lib, a.n, a.ncon, prefix="wt", nwcon=a.nwcon, nw=a.nw)
+            fac = {"reference_semantics": measure(up, lambda: up.ownKernelBytes(True))}
+            up.close()
+            boundary = {"what": "config 4 as a USER ParOptSparseProblem subclass on include/ParOptAMD.hpp, compiled "
+                                "outside libparopt_amd.so with its own HIP kernels (examples/weighting_amd.cpp): the "
+                                "weighting constraints are handed over as the CSR pattern of setSparseJacobianData "
+                                "(src/ParOptProblem.h:306-312) and the Jacobian entries written by "
+                                "evalSparseObjConGradient; the library recognises the grouped pattern (checked on the "
+                                "device after every gradient evaluation) and takes the fused group kernels; "
+                                "evalObjConGradient rewrites the dense Jacobian and all sparse entries at every call",
+                        **{k: summary(v) for k, v in fac.items()}}
+            if a.boundary == "facade":
+                variants = {"facade_reference_semantics": fac["reference_semantics"]}
         else:
             up = pa.UserLibraryProblem(ctx, USER_LIB, a.n, a.ncon)
             fac = {"reference_semantics": measure(up, lambda: up.ownKernelBytes(True))}

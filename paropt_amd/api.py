@@ -664,7 +664,9 @@ class UserLibraryProblem:
     <prefix>_problem_sizes(void*, int64*, int64*), <prefix>_problem_destroy(void*), and optionally
     <prefix>_problem_set_linear_constraints / _set_deferred_reductions(void*, int), _own_kernel_bytes(void*, int)."""
 
-    def __init__(self, ctx, path, nglobal, ncon, seed=0, prefix="rc"):
+    def __init__(self, ctx, path, nglobal, ncon, seed=0, prefix="rc", nwcon=0, nw=0):
+        """nwcon > 0: <prefix>_problem_create_weighting(ctx, nglobal, ncon, seed, nwcon, nw) instead (a problem with one
+        sparse constraint per group of nw consecutive variables, examples/weighting_amd.cpp)."""
         self.ctx = ctx
         self._lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         f = lambda name: getattr(self._lib, "%s_problem_%s" % (prefix, name))
@@ -675,13 +677,19 @@ class UserLibraryProblem:
         f("sizes").argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         f("destroy").argtypes = [C.c_void_p]
         self._f = f
-        self._obj = C.c_void_p(f("create")(ctx.handle, int(nglobal), int(ncon), int(seed)))
+        if nwcon > 0:
+            f("create_weighting").restype = C.c_void_p
+            f("create_weighting").argtypes = [L.po_ctx, C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int]
+            self._obj = C.c_void_p(f("create_weighting")(ctx.handle, int(nglobal), int(ncon), int(seed), int(nwcon),
+                                                         int(nw)))
+        else:
+            self._obj = C.c_void_p(f("create")(ctx.handle, int(nglobal), int(ncon), int(seed)))
         if not self._obj:
             raise L.ParOptAMDError(-1, "user library failed to create its problem")
         self._h = L.po_problem(f("handle")(self._obj))
         nl, off = C.c_int64(), C.c_int64()
         f("sizes")(self._obj, C.byref(nl), C.byref(off))
-        self.nvars, self.offset, self.ncon, self.nwcon = nl.value, off.value, int(ncon), 0
+        self.nvars, self.offset, self.ncon, self.nwcon = nl.value, off.value, int(ncon), int(nwcon)
 
     @property
     def handle(self):

@@ -279,6 +279,8 @@ int k_panel_lincomb(Ctx *c, double *const *dst, double a, const double *const *X
 enum Red1 { RED_DOT = 0, RED_SUMSQ = 1, RED_ASUM = 2, RED_AMAX = 3 };
 int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, double *out);
 int k_mdot(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, double *out);
+// out = {smallest, largest} entry of x[0..n) (x need not be a padded vector: the tail element is read alone)
+int k_minmax(Ctx *c, const double *x, int64_t n, double out[2]);
 // launch-only variant for the roofline bench (no host sync); result stays in partials
 int k_stream_launch(Ctx *c, int kind, double *x, double *y, int64_t n);  // bench: 0 = x.y, 1 = y <- x
 int k_mdot_launch(Ctx *c, const double *x, const double *const *V, int nv, int64_t n, int *nblocks);

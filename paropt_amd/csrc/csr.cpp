@@ -652,8 +652,48 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   return PO_OK;
 }
 
+int CsrSparse::setPatternLight(const int *rowp, const int *cols) {
+  nnz = rowp[w];
+  user_rowp.assign(rowp, rowp + w + 1);
+  user_cols.assign(cols, cols + nnz);
+  PO_HIP(hipSetDevice(ctx->device));
+  if (vals != data) dfree(vals);
+  vals = nullptr;
+  dfree(data);
+  const size_t vbytes = ((size_t)nnz + 4) * sizeof(double);
+  PO_HIP(hipMalloc((void **)&data, vbytes));
+  PO_HIP(hipMemset(data, 0, vbytes));
+  vals = data;
+  if (cw) vec_decref(cw);
+  cw = vec_new(ctx, w);
+  if (!cw) return PO_ERR_HIP;
+  light = true;
+  return PO_OK;
+}
+
+int CsrSparse::upgradeFromLight() {
+  if (!light) return PO_OK;
+  // keep what the user wrote: the analysis reallocates the value array
+  double *keep = data;
+  Vec *keep_cw = cw;
+  data = nullptr;
+  vals = nullptr;
+  cw = nullptr;
+  light = false;
+  const std::vector<int> rp(user_rowp), cl(user_cols);
+  int rc = setPattern(rp.data(), cl.data());
+  if (rc == PO_OK && nnz > 0 &&
+      hipMemcpyAsync(data, keep, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+    rc = PO_ERR_HIP;
+  if (rc == PO_OK && keep_cw && cw) rc = k_copy(ctx, cw->d, keep_cw->d, w);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(keep);
+  if (keep_cw) vec_decref(keep_cw);
+  return rc;
+}
+
 int CsrSparse::valuesChanged() {
-  if (vals == data || nnz == 0) return PO_OK;
+  if (light || vals == data || nnz == 0) return PO_OK;
   return k_csr_gather(ctx, vals, data, d_src, nnz);
 }
 

@@ -62,6 +62,13 @@ class CsrSparse {
   CsrSparse(Ctx *c, int64_t n_, int64_t w_);
   ~CsrSparse();
   int setPattern(const int *rowp, const int *cols);
+  // The pattern was recognised as the grouped one (problem.hpp): only what the user's callbacks and
+  // getSparseJacobianData need -- host copies of the pattern, the value array, the constraint vector -- and NO
+  // symbolic analysis (at w = 1 M rows it would cost seconds and hundreds of MB that the block form never uses).
+  // upgradeFromLight() runs the analysis after all, keeping the values (the entries turned out not to be uniform).
+  int setPatternLight(const int *rowp, const int *cols);
+  int upgradeFromLight();
+  bool light = false;
   // the user's value array in the user's entry order (device, nnz doubles) and the constraint values
   double *data = nullptr;
   Vec *cw = nullptr;

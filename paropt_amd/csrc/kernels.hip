@@ -799,6 +799,34 @@ int k_reduce1(Ctx *c, int kind, const double *x, const double *y, int64_t n, dou
   return reduce_finish(c, grid, 1, 0, 0, out);
 }
 
+// smallest and largest entry (the uniformity check of a grouped sparse Jacobian, Problem::csrValuesChanged)
+__global__ void __launch_bounds__(kBlock)
+    minmax_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ partials) {
+  __shared__ double sm[4];
+  double mn[1] = {INFINITY}, mx[1] = {-INFINITY};
+  const int64_t npairs = n >> 1;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (int64_t)gridDim.x * blockDim.x) {
+    const double2 v = ld2(x, q, n);
+    mn[0] = fmin(mn[0], fmin(v.x, v.y));
+    mx[0] = fmax(mx[0], fmax(v.x, v.y));
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    mn[0] = fmin(mn[0], x[n - 1]);
+    mx[0] = fmax(mx[0], x[n - 1]);
+  }
+  block_reduce_store<1, OP_MIN>(mn, partials, 0, sm);
+  block_reduce_store<1, OP_MAX>(mx, partials, 1, sm);
+}
+int k_minmax(Ctx *c, const double *x, int64_t n, double out[2]) {
+  // (collective: a rank without entries takes part with {+inf, -inf})
+  if (n < 0) n = 0;
+  count_bytes(c, 1, n);
+  const int grid = grid_for(c, n);
+  PO_TRY(ensure_partials(c, (size_t)grid * 2));
+  PO_LAUNCH(minmax_kernel, grid, x, n, c->d_partials);
+  return reduce_finish(c, grid, 0, 1, 1, out, true);
+}
+
 // ---------------------------------------------------------------------------------------------
 // mdot: out_j = sum_i x_i V_j[i]   (ParOptBasicVec::mdot, src/ParOptVec.cpp:152-170)
 // x is read once per block of NVB panel columns; the NVB accumulators live in VGPRs.

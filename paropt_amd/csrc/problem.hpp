@@ -62,7 +62,7 @@ class Problem {
   virtual int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out);
   // Structured problems describe that n-sized vector instead of writing it (core.hpp: GroupCol): the pass that would
   // have read it forms its entries from pzw in registers.  false (the default): the caller materialises the vector.
-  virtual bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) { return false; }
+  virtual bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col);
   virtual int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A);
   // U_j = Aw (d o P_j) for a whole panel; the default goes column by column through
   // addSparseJacobian with `work` (n-sized) as scratch, structured problems do it in one pass
@@ -71,7 +71,7 @@ class Problem {
   // Structured problems (one constraint per group of consecutive variables) let that panel image ride in the Gram
   // pass over the same panel (k_wgram's `groups`, one pass over P instead of two): the map and the Jacobian's
   // entry value, or false (the default: the panel image is sparseJacobianPanel's pass of its own)
-  virtual bool sparseGramGroups(Vec *x, GramGroups *g) { return false; }
+  virtual bool sparseGramGroups(Vec *x, GramGroups *g);
   // (yx, yw) = K0^-1 (bx, bw) of ParOptQuasiDefBlockMat::apply (src/ParOptSparseMat.cpp:122-190) with
   // the diagonal blocks d (n) and cw (w): yx = d o bx; yw = cw o (bw - Aw yx); yx = d o (bx + Aw^T yw).
   // The default is that sequence through the Jacobian callbacks (11 n-sized passes); structured problems
@@ -106,6 +106,24 @@ class Problem {
   // owned.  Sets nwcon / nwinequality.
   int setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols);
   CsrSparse *csr = nullptr;
+  // Structured ("grouped") sparse Jacobian: constraint i acts on the nw consecutive local variables
+  // start + i (nw + skip) + [0, nw) and every entry of the Jacobian has the same value group_alpha -- the weighting
+  // constraints of multi-material topology optimisation (examples/dmo_truss/dmo_truss_analysis.py:650-679,
+  // examples/rosenbrock/rosenbrock.cpp:131-184).  Aw D^-1 Aw^T is then diagonal, the quasi-definite solve is the scalar
+  // block form, and every sparse hook below runs a fused group kernel (wcon.hip, the panel image inside the Gram pass,
+  // grouped columns formed in registers).  Two ways in (round 5):
+  //   * the library's own SeparableProblem::setWeighting (group_alpha = -1), and
+  //   * ANY problem that hands its pattern to setSparseJacobianData (the reference's ParOptSparseProblem interface,
+  //     src/ParOptProblem.h:301-335): the pattern is RECOGNISED there (rows of equal length nw, consecutive columns,
+  //     equal spacing), no symbolic analysis is made, and after every gradient evaluation the entries the user wrote
+  //     are checked for equality on the device (one pass over nnz values): differing entries switch the problem to the
+  //     general CSR path (analysis + sparse Cholesky) for good.  PAROPT_AMD_NO_CSR_GROUPS=1 switches the recognition off.
+  bool grouped = false;
+  GroupMap gmap;
+  double group_alpha = -1.0;
+  // call after the user's evaluation wrote csr->data (CallbackProblem::evalObjConGradient)
+  int csrValuesChanged();
+  long csr_group_fallbacks = 0;  // times a recognised pattern had to be given up (entries not all equal)
   // block form with nwblock > 1 (ParOptQuasiDefBlockMat, src/ParOptSparseMat.cpp:11-229): consecutive blocks of
   // nwblock constraints may share variables inside a block; addSparseInnerProduct then fills the packed upper
   // triangles of the nwblock x nwblock blocks (nwcon (nwblock+1)/2 entries)
@@ -181,23 +199,10 @@ class SeparableProblem : public Problem {
   int chain_span = 0, chain_stride = 0, chain_reverse = 0;
   Vec *chain_tmp = nullptr;
   int chainHessian(Vec *zw, Vec *px, Vec *h);
+  // (the Jacobian hooks of the weighting constraints are the base class's grouped forms)
   int evalSparseCon(Vec *x, Vec *out) override;
-  int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
-  int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
-  int setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override;
-  int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override;
-  int sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
-                          Vec *work) override;
-  int sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
-                    Vec *wwork) override;
-  int sparseFactor(Vec *x, Vec *d, Vec *cw) override;
-  int sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) override;
-  bool sparseGramGroups(Vec *x, GramGroups *g) override;
-  bool sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) override;
-  int setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override;
   int evalHvecProduct(Vec *x, const double *z, Vec *zw, Vec *px, Vec *hvec) override;
   int evalHessianDiag(Vec *x, const double *z, Vec *zw, Vec *hdiag) override;
-  GroupMap gmap;
   int bounds_mode = 0;  // po_problem_set_bounds_mode: deliberately broken bounds (k_bounds_mode)
 
   int kind;

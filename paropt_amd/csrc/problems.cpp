@@ -15,13 +15,49 @@ static void shard(int64_t n, int rank, int size, int64_t *nlocal, int64_t *offse
 }
 
 // ---- CSR form (ParOptSparseProblem) and the generic fallbacks ------------------------------------
+int comm_allreduce_host(Ctx *c, double *values, int count, int op);  // context.cpp
+
+// Rows of equal length nw with consecutive columns at equal spacing: the grouped pattern of problem.hpp
+static bool recognise_groups(int64_t n, int64_t w, const int *rowp, const int *cols, GroupMap *gm) {
+  if (w <= 0 || rowp[0] != 0) return false;
+  const int64_t nw = rowp[1] - rowp[0];
+  if (nw <= 0 || nw > (1 << 20)) return false;
+  const int64_t start = cols[0];
+  int64_t period = nw;
+  if (w > 1) {
+    if (rowp[2] - rowp[1] != nw) return false;
+    period = (int64_t)cols[rowp[1]] - start;
+  }
+  if (start < 0 || period < nw || start + (w - 1) * period + nw > n) return false;
+  for (int64_t i = 0; i < w; i++) {
+    if (rowp[i + 1] - rowp[i] != nw) return false;
+    const int *cr = cols + rowp[i];
+    const int64_t c0 = start + i * period;
+    for (int64_t k = 0; k < nw; k++)
+      if (cr[k] != c0 + k) return false;
+  }
+  gm->nwcon = w;
+  gm->start = start;
+  gm->nw = (int)nw;
+  gm->skip = (int)(period - nw);
+  return true;
+}
+
 int Problem::setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *rowp, const int *cols) {
   if (nwcon_ < 0 || nwineq_ < 0 || nwineq_ > nwcon_ || !rowp || (rowp[nwcon_] > 0 && !cols)) {
     set_error("setSparseJacobianData: bad arguments");
     return PO_ERR_ARG;
   }
+  static const bool no_groups = getenv("PAROPT_AMD_NO_CSR_GROUPS") != nullptr;
+  GroupMap gm;
+  bool rec = !no_groups && nwblock == 1 && ((nwcon_ == 0 && ctx->size > 1) || recognise_groups(nlocal, nwcon_, rowp, cols, &gm));
+  if (ctx->size > 1) {  // all ranks or none (the two paths issue different reductions): collective
+    double flag = rec ? 1.0 : 0.0;
+    PO_TRY(comm_allreduce_host(ctx, &flag, 1, 1));
+    rec = flag != 0.0;
+  }
   CsrSparse *m = new CsrSparse(ctx, nlocal, nwcon_);
-  int rc = m->setPattern(rowp, cols);
+  int rc = rec ? m->setPatternLight(rowp, cols) : m->setPattern(rowp, cols);
   if (rc != PO_OK) {
     delete m;
     return rc;
@@ -30,7 +66,36 @@ int Problem::setSparseJacobianData(int64_t nwcon_, int64_t nwineq_, const int *r
   csr = m;
   nwcon = nwcon_;
   nwinequality = nwineq_;
+  grouped = rec;
+  gmap = rec ? gm : GroupMap();
+  group_alpha = 0.0;  // known after the first gradient evaluation (csrValuesChanged)
   return PO_OK;
+}
+
+int Problem::csrValuesChanged() {
+  if (!csr) return PO_OK;
+  if (!grouped) return csr->valuesChanged();
+  // every entry the same value?  {min, max} over the nnz values the user just wrote (one pass + host result)
+  double mm[2] = {0.0, 0.0};
+  PO_TRY(k_minmax(ctx, csr->data, csr->nnz, mm));  // over all ranks: every rank takes the same decision
+  if (mm[0] > mm[1]) {  // no entries anywhere
+    group_alpha = 0.0;
+    return PO_OK;
+  }
+  if (mm[0] == mm[1]) {
+    group_alpha = mm[0];
+    return PO_OK;
+  }
+  // not the uniform weighting pattern after all: the general path from here on (analysis of the pattern once, device
+  // sparse Cholesky), with the values already written
+  if (ctx->rank == 0 && csr_group_fallbacks == 0)
+    fprintf(stderr, "paropt_amd: the sparse Jacobian has the grouped pattern but entries in [%g, %g]: general CSR path\n",
+            mm[0], mm[1]);
+  csr_group_fallbacks++;
+  grouped = false;
+  gmap = GroupMap();
+  PO_TRY(csr->upgradeFromLight());
+  return csr->valuesChanged();
 }
 Problem::~Problem() {
   delete csr;
@@ -39,7 +104,7 @@ Problem::~Problem() {
   if (blk_flag) (void)hipFree(blk_flag);
 }
 const char *Problem::sparseFactorInfo() {
-  if (csr) return csr->factorInfo();
+  if (csr && !grouped) return csr->factorInfo();
   factor_info = "nblock: " + std::to_string(nwblock);  // ParOptQuasiDefBlockMat::getFactorInfo (:218-221)
   return factor_info.c_str();
 }
@@ -76,30 +141,40 @@ int Problem::evalSparseCon(Vec *, Vec *out) {
   return k_copy(ctx, out->d, csr->cw->d, nwcon) != PO_OK;
 }
 int Problem::addSparseJacobian(double alpha, Vec *, Vec *px, Vec *out) {  // .cpp:762-788
+  if (grouped) return k_group_sum(ctx, gmap, out->d, 1, 0.0, alpha * group_alpha, px->d);
   if (!csr) return 0;
   return csr->spmv(alpha, px->d, out->d) != PO_OK;
 }
 int Problem::setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
+  if (grouped) return k_group_scatter_set(ctx, gmap, out->d, alpha * group_alpha, pzw->d, nlocal);
   PO_TRY(k_fill(ctx, out->d, out->n, 0.0));
   return addSparseJacobianTranspose(alpha, x, pzw, out) != 0 ? PO_ERR_USER : PO_OK;
 }
 int Problem::addSparseJacobianTranspose(double alpha, Vec *, Vec *pzw, Vec *out) {  // .cpp:790-816
+  if (grouped) return k_group_scatter(ctx, gmap, out->d, alpha * group_alpha, pzw->d, nlocal);
   if (!csr) return 0;
   return csr->spmvT(alpha, pzw->d, out->d) != PO_OK;
 }
 int Problem::setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
+  // out = alpha Aw px = alpha group_alpha (group sums of px), every entry written
+  if (grouped) return k_group_sum(ctx, gmap, out->d, 0, 0.0, alpha * group_alpha, px->d);
   PO_TRY(k_fill(ctx, out->d, nwcon, 0.0));
   return addSparseJacobian(alpha, x, px, out) != 0 ? PO_ERR_USER : PO_OK;
 }
 int Problem::sparseFactorFromSlacks(Vec *x, Vec *d, const WVars &v, Vec *cw) {
+  // grouped with entries +-1: Cdiag from the slack blocks, the group sums of d and the reciprocal in ONE launch
+  if (grouped && nwblock == 1 && group_alpha * group_alpha == 1.0) return k_group_factor(ctx, gmap, v, d->d, cw->d);
   PO_TRY(k_w_cdiag(ctx, v, nwcon, cw->d));
   return sparseFactor(x, d, cw);
 }
 int Problem::addSparseInnerProduct(double alpha, Vec *, Vec *cvec, Vec *A) {
+  if (grouped) return k_group_sum(ctx, gmap, A->d, 1, 0.0, alpha * (group_alpha * group_alpha), cvec->d);
   if (!csr) return 0;
   return csr->innerProduct(alpha, cvec->d, A->d) != PO_OK;
 }
 int Problem::sparseFactor(Vec *x, Vec *d, Vec *cw) {
+  // grouped: Cw = 1 / (Cdiag + alpha^2 (sum of d over the group)): the group sum and the reciprocal in one launch
+  if (grouped && nwblock == 1) return k_group_sum(ctx, gmap, cw->d, 1, 0.0, group_alpha * group_alpha, d->d, 1);
   if (csr) return csr->factor(d->d, cw->d);
   if (nwblock > 1) {  // :60-112
     const int64_t nb = nwcon / nwblock;
@@ -125,7 +200,7 @@ int Problem::sparseFactor(Vec *x, Vec *d, Vec *cw) {
   return k_recip(ctx, cw->d, nwcon);
 }
 int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **weights) {
-  if (csr) {
+  if (csr && !grouped) {
     *weights = csr->unitWeights();
     return csr->halfSolve(U, nv);
   }
@@ -138,12 +213,12 @@ int Problem::sparseHalfSolve(double *const *U, int nv, Vec *cw, const double **w
 }
 
 int Problem::sparseCorrection(const double *const *U, int nv, const double *alpha, Vec *cw, Vec *out, Vec *acc) {
-  if (!csr && nwblock == 1 && nv <= kMaxPanel) {
+  if ((!csr || grouped) && nwblock == 1 && nv <= kMaxPanel) {
     // scalar block form: sum, scale by -cw and the caller's accumulation in ONE w-sized launch (round 4; the same
     // operations in the same order as the three launches below)
     return k_w_correction(ctx, U, nv, alpha, cw->d, nwcon, out->d, acc ? acc->d : nullptr);
   }
-  if (csr) {
+  if (csr && !grouped) {
     PO_TRY(csr->correction(U, nv, alpha, out->d));
   } else {
     PO_TRY(k_panel_axpy(ctx, out->d, 0.0, nullptr, 0.0, alpha, U, nv, nwcon));
@@ -161,6 +236,7 @@ int Problem::sparseCorrection(const double *const *U, int nv, const double *alph
 
 int Problem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv, double *const *U,
                                  Vec *work) {
+  if (grouped) return k_group_panel(ctx, gmap, P, nv, d->d, group_alpha, U);
   if (csr) return csr->panelPermuted(d->d, P, nv, U);
   for (int j = 0; j < nv; j++) {
     PO_TRY(k_mul(ctx, work->d, 1.0, d->d, P[j], nlocal));
@@ -257,8 +333,39 @@ int Problem::checkGradients(double dh, Vec *x, bool check_hvec, Vec *xt, Vec *px
   return rc;
 }
 
+bool Problem::sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) {
+  static const bool off = getenv("PAROPT_AMD_NO_GROUP_COLS") != nullptr;
+  if (off || !grouped || nwcon <= 0 || gmap.start != 0 || nlocal >= 2000000000LL) return false;
+  col->w = pzw->d;
+  col->scale = alpha * group_alpha;  // the value k_group_scatter_set(..., alpha * group_alpha, ...) stores
+  col->period = (unsigned)(gmap.nw + gmap.skip);
+  col->nw = (unsigned)gmap.nw;
+  col->nwcon = gmap.nwcon;
+  return true;
+}
+bool Problem::sparseGramGroups(Vec *x, GramGroups *g) {
+  if (!grouped || nwblock > 1 || nwcon <= 0) return false;
+  g->nwcon = gmap.nwcon;
+  g->start = gmap.start;
+  g->nw = gmap.nw;
+  g->skip = gmap.skip;
+  g->alpha = group_alpha;  // as in sparseJacobianPanel
+  return true;
+}
+
 int Problem::sparseApplyK0(Vec *x, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx, Vec *yw,
-                           Vec *) {
+                           Vec *wwork) {
+  if (grouped && nwblock == 1) {
+    // u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx + alpha yw[group]); one launch where the map tiles
+    bool done = false;
+    PO_TRY(k_group_k0(ctx, gmap, d->d, bx, cw->d, bw, group_alpha, nlocal, yx->d, yw->d, &done));
+    if (done) return PO_OK;
+    const double *P[1] = {bx};
+    double *U[1] = {wwork->d};
+    PO_TRY(k_group_panel(ctx, gmap, P, 1, d->d, group_alpha, U));
+    PO_TRY(k_w_apply_mid(ctx, cw->d, bw, wwork->d, nwcon, yw->d));
+    return k_group_apply(ctx, gmap, d->d, bx, group_alpha, yw->d, nlocal, yx->d);
+  }
   if (csr) return csr->applyK0(d->d, bx, bw, yx->d, yw->d);
   const int64_t n = nlocal, w = nwcon;
   PO_TRY(k_mul(ctx, yx->d, 1.0, d->d, bx, n));
@@ -308,7 +415,7 @@ int CallbackProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
     int rc = csr_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g), only_g ? nullptr : h.data(),
                           csr->data, csr->nnz);
     if (rc != 0) return rc;
-    return csr->valuesChanged() != PO_OK;
+    return csrValuesChanged() != PO_OK;
   }
   return cb.eval_obj_con_gradient(cb.user, static_cast<po_vec>(x), static_cast<po_vec>(g),
                                   only_g ? nullptr : h.data());
@@ -445,6 +552,8 @@ int SeparableProblem::setWeighting(int64_t nwg, int nw, int64_t nwstart, int nws
   gmap.start = lstart;
   gmap.nw = nw;
   gmap.skip = nwskip;
+  grouped = true;
+  group_alpha = -1.0;  // Aw = -(group indicator)
   nwcon = count;
   nwinequality = nwineq - first;
   if (nwinequality < 0) nwinequality = 0;
@@ -478,78 +587,7 @@ int SeparableProblem::setChain(int span, int stride, int reverse_cols) {
 }
 int SeparableProblem::evalSparseCon(Vec *x, Vec *out) {
   if (csr) return Problem::evalSparseCon(x, out);
-  return k_group_sum(ctx, gmap, out->d, 0, 1.0, -1.0, x->d);
-}
-int SeparableProblem::addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
-  if (csr) return Problem::addSparseJacobian(alpha, x, px, out);
-  return k_group_sum(ctx, gmap, out->d, 1, 0.0, -alpha, px->d);
-}
-int SeparableProblem::addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
-  if (csr) return Problem::addSparseJacobianTranspose(alpha, x, pzw, out);
-  return k_group_scatter(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
-}
-int SeparableProblem::setSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) {
-  if (csr) return Problem::setSparseJacobianTranspose(alpha, x, pzw, out);
-  return k_group_scatter_set(ctx, gmap, out->d, -alpha, pzw->d, nlocal);
-}
-int SeparableProblem::addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) {
-  if (csr) return Problem::addSparseInnerProduct(alpha, x, cvec, A);
-  return k_group_sum(ctx, gmap, A->d, 1, 0.0, alpha, cvec->d);
-}
-int SeparableProblem::sparseJacobianPanel(Vec *x, Vec *d, const double *const *P, int nv,
-                                          double *const *U, Vec *work) {
-  if (csr) return Problem::sparseJacobianPanel(x, d, P, nv, U, work);
-  return k_group_panel(ctx, gmap, P, nv, d->d, -1.0, U);
-}
-
-bool SeparableProblem::sparseTransposeColumn(double alpha, Vec *x, Vec *pzw, GroupCol *col) {
-  static const bool off = getenv("PAROPT_AMD_NO_GROUP_COLS") != nullptr;
-  if (off || csr || nwcon <= 0 || gmap.start != 0 || nlocal >= 2000000000LL) return false;
-  col->w = pzw->d;
-  col->scale = -alpha;  // Aw = -(group indicator): the value k_group_scatter_set(..., -alpha, ...) stores
-  col->period = (unsigned)(gmap.nw + gmap.skip);
-  col->nw = (unsigned)gmap.nw;
-  col->nwcon = gmap.nwcon;
-  return true;
-}
-bool SeparableProblem::sparseGramGroups(Vec *x, GramGroups *g) {
-  if (csr || nwblock > 1 || nwcon <= 0) return false;
-  g->nwcon = gmap.nwcon;
-  g->start = gmap.start;
-  g->nw = gmap.nw;
-  g->skip = gmap.skip;
-  g->alpha = -1.0;  // Aw = -(group indicator), as in sparseJacobianPanel above
-  return true;
-}
-
-// the weighting constraints are linear, so only f (and Rosenbrock's c0) contribute
-// Aw = -(group indicator): u = Aw (d o bx) in one tiled pass, yw = cw (bw - u), yx = d (bx - yw[group])
-// Cw = 1 / (Cdiag + sum of d over the group): the group sum and the reciprocal in one launch
-int SeparableProblem::sparseFactor(Vec *xv, Vec *d, Vec *cw) {
-  if (csr || nwblock > 1) return Problem::sparseFactor(xv, d, cw);
-  return k_group_sum(ctx, gmap, cw->d, 1, 0.0, 1.0, d->d, 1);
-}
-// ... and with Cdiag formed from the slack blocks in the same launch
-int SeparableProblem::sparseFactorFromSlacks(Vec *xv, Vec *d, const WVars &v, Vec *cw) {
-  if (csr || nwblock > 1) return Problem::sparseFactorFromSlacks(xv, d, v, cw);
-  return k_group_factor(ctx, gmap, v, d->d, cw->d);
-}
-// out = alpha Aw px = -alpha (group sums of px), every entry written
-int SeparableProblem::setSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) {
-  if (csr) return Problem::setSparseJacobian(alpha, x, px, out);
-  return k_group_sum(ctx, gmap, out->d, 0, 0.0, -alpha, px->d);
-}
-int SeparableProblem::sparseApplyK0(Vec *xv, Vec *d, Vec *cw, const double *bx, const double *bw, Vec *yx,
-                                    Vec *yw, Vec *wwork) {
-  if (csr) return Problem::sparseApplyK0(xv, d, cw, bx, bw, yx, yw, wwork);
-  bool done = false;
-  PO_TRY(k_group_k0(ctx, gmap, d->d, bx, cw->d, bw, -1.0, nlocal, yx->d, yw->d, &done));  // one launch (round 4)
-  if (done) return PO_OK;
-  const double *P[1] = {bx};
-  double *U[1] = {wwork->d};
-  PO_TRY(k_group_panel(ctx, gmap, P, 1, d->d, -1.0, U));
-  PO_TRY(k_w_apply_mid(ctx, cw->d, bw, wwork->d, nwcon, yw->d));
-  return k_group_apply(ctx, gmap, d->d, bx, -1.0, yw->d, nlocal, yx->d);
+  return k_group_sum(ctx, gmap, out->d, 0, 1.0, -1.0, x->d);  // cw_i = 1 - sum of the group
 }
 // Hessian of the Lagrangian f - z^T c - zw^T cw.  The weighting constraints are linear; a chain constraint
 // cw_i = 1 - sum x^2 adds 2 zw_i on the diagonal entries of its variables.
@@ -632,7 +670,7 @@ int SeparableProblem::evalObjConGradient(Vec *x, Vec *g, Vec **Ac) {
   const int64_t n = nlocal;
   if (csr) {
     PO_TRY(k_chain_jac(ctx, x->d, nwcon, chain_span, chain_stride, chain_reverse, csr->data));
-    PO_TRY(csr->valuesChanged());
+    PO_TRY(csrValuesChanged());
   }
   if (kind == PO_PROBLEM_ROSENBROCK) {
     if (!Ac) return 1;  // nonlinear constraints: the flag must not be set
