@@ -130,7 +130,8 @@ def run_reference_mdot(drv, mpiexec, ranks, n, nvecs, reps, timeout):
     return None
 
 
-def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, problem="convex", budget_s=60.0):
+def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, problem="convex", budget_s=60.0,
+                 full_size=False):
     """The unmodified reference (oracle/_ref/ref_driver: the reference's C++ + MKL under MPICH) timed on this box's
     host cores to the protocol of BASELINE.md section 4: K = qn_size + 8 major iterations from a cold quasi-Newton
     memory (abs_res_tol = 1e-30), optimize() only; WHOLE-RUN rate and STEADY-STATE rate (the iterations that run with
@@ -194,6 +195,31 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
                 one(n_fit)
             best_n = runs[-1]["n"]
             same = [r for r in runs if r["n"] == best_n]
+            # --cpu-full-size (builder runs only, never the driver's default): ONE run of the reference at the workload's
+            # own n, so that the linear scaling of the sampled rate rests on a measurement.  Guarded by
+            # the host's free memory: the reference holds about 30 + 2 c + 4 k design-sized vectors.
+            full = None
+            if full_size and n > best_n:
+                kcols = qn_size * (2 if qn == "bfgs" else 1)
+                need = 8.0 * n * (30 + 2 * ncon + 4 * kcols)
+                avail = 0.0
+                try:
+                    with open("/proc/meminfo") as f:
+                        for ln in f:
+                            if ln.startswith("MemAvailable:"):
+                                avail = 1024.0 * float(ln.split()[1])
+                except Exception:
+                    pass
+                if avail > 1.3 * need:
+                    nf, sf, pf, wf, ef = run_reference(drv, mpiexec, ranks, n, ncon, K, qn, qn_size, problem, nwcon, nw, 1800)
+                    if nf > 0:
+                        full = {"n": n, "iterations": nf, "seconds": sf, "wall_s": wf, "whole_run_it_per_s": nf / sf,
+                                "steady_state_it_per_s": steady(pf), "iteration_seconds": [round(v, 4) for v in pf],
+                                "host_mem_available_GB": avail * 1e-9, "estimated_need_GB": need * 1e-9}
+                    else:
+                        full = {"error": ef}
+                else:
+                    full = {"skipped": "host memory: %.0f GB available, about %.0f GB needed" % (avail * 1e-9, need * 1e-9)}
             best = max(same, key=lambda r: r["whole_run_it_per_s"])
             best_ss = max((r["steady_state_it_per_s"] for r in same if r["steady_state_it_per_s"]), default=None)
             scale = best_n / float(n)
@@ -224,6 +250,7 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
                    "implied_host_GBps": traffic / best["seconds"] * 1e-9,
                    "mdot_ms": mdot, "mdot_seconds_spent": time.time() - t_md,
                    "host": cpus, "wall_s_incl_launch": time.time() - t_start, "probes": runs,
+                   "full_size_run": full,
                    "sample": "unmodified reference (%d MPICH ranks x sequential MKL; ranks = cores this process may use: "
                              "affinity %d, cgroup quota %s, os.cpu_count %d), same problem at n=%d, K = %d major iterations "
                              "from a cold quasi-Newton memory (BASELINE.md section 4), optimize() only; `value` = the "
@@ -278,6 +305,8 @@ def parse_args(argv=None):
                          "`boundary`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds the CPU baseline leg may take")
+    ap.add_argument("--cpu-full-size", action="store_true",
+                    help="also run the reference ONCE at the workload's own n (minutes; builder runs only)")
     ap.add_argument("--cpu-iters", type=int, default=0,
                     help="major iterations of a CPU baseline run (default and minimum: qn_size + 8, so that at least "
                          "six run with full quasi-Newton memory)")
@@ -396,6 +425,20 @@ def main():
             log("native RCCL communicator failed (%r); falling back to torch.distributed all_gather" % (e,))
             ctx.init_callback_from_torch(device=torch.device("cuda", local_rank))
             comm_kind = "torch.distributed(nccl) callback"
+    forced_rccl = world == 1 and os.environ.get("PAROPT_AMD_FORCE_RCCL", "0") == "1"
+    if forced_rccl:
+        # One rank, but every reduction goes through the REAL RCCL path the multi-GPU runs take: ncclAllReduce /
+        # ncclAllGather on the solver's stream, the publish kernel and the polled completion flag (context.cpp).  Run at
+        # the per-rank size of an N-GPU job this measures what one rank of that job does, collectives included, except
+        # the wire time of the <= 8.5 KB payloads (tools/per_rank_sizes.sh).
+        import ctypes as C
+
+        from paropt_amd.lib import check, lib
+
+        buf = (C.c_char * 128)()
+        check(lib.po_rccl_unique_id(buf))
+        check(lib.po_ctx_comm_init_rccl(ctx.handle, 0, 1, buf))
+        comm_kind = "rccl (forced single-rank communicator)"
     ranks_seen = ctx.rank_size()[1]  # what the communicator of the solver actually spans
     if ranks_seen != world:
         log("error: the solver's communicator spans %d ranks, the job has %d" % (ranks_seen, world))
@@ -618,7 +661,7 @@ def main():
     # ---- N > 1: what one reduction exchange costs on this communicator (the iteration pays host_syncs_per_iter
     # of them), in the two forms the solver uses ----
     collective = None
-    if world > 1:
+    if world > 1 or forced_rccl:
         collective = {"allreduce_2628_doubles": ctx.bench_collective(2628, True, 50),
                       "allgather_16_doubles": ctx.bench_collective(16, False, 50),
                       "what": "final-stage payload -> collective -> device-to-host copy -> host sync, median of 50 "
@@ -627,7 +670,8 @@ def main():
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(a.n, a.ncon, a.cpu_iters, log, a.nwcon, a.nw, a.qn, a.qn_size, a.problem, a.cpu_budget)
+            cpu = cpu_baseline(a.n, a.ncon, a.cpu_iters, log, a.nwcon, a.nw, a.qn, a.qn_size, a.problem, a.cpu_budget,
+                               a.cpu_full_size)
         niter = det["niter"]
         kind, nred, ngat = ctx.comm_info()
         head_sum = summary(variants[head])
@@ -682,6 +726,8 @@ def main():
             "boundary": boundary,
             "roofline": roofline,
             "collective_us": collective,
+            # polled completions of the reductions and those that ran out of their bounded spin (po_ctx_sync_counters)
+            "sync_counters": ctx.sync_counters(),
             "cpu_baseline": cpu,
             "phase_ms_per_iter": {k: 1e3 * v / niter for k, v in det["phases"].items()},
             "user_eval_ms_per_iter": head_sum["user_eval_ms_per_iter"],

@@ -405,9 +405,10 @@ __device__ __forceinline__ GRaw gcol_request(const GroupCol &gc, int64_t q, int6
   }
   const bool v0 = k0 < gc.nw && (long long)g0 < gc.nwcon;
   const bool v1 = k1 < gc.nw && (long long)g1 < gc.nwcon && 2 * q + 1 < n;
-  const unsigned last = (unsigned)(gc.nwcon - 1);
-  r.raw.x = gc.w[g0 < last ? g0 : last];
-  r.raw.y = gc.w[g1 < last ? g1 : last];
+  // (an empty map loads nothing: nwcon - 1 would wrap, and w may be a null vector then; wave-uniform test)
+  const unsigned last = gc.nwcon > 0 ? (unsigned)(gc.nwcon - 1) : 0u;
+  r.raw.x = gc.nwcon > 0 ? gc.w[g0 < last ? g0 : last] : 0.0;
+  r.raw.y = gc.nwcon > 0 ? gc.w[g1 < last ? g1 : last] : 0.0;
   r.valid = (v0 ? 1 : 0) | (v1 ? 2 : 0);
   return r;
 }
@@ -565,9 +566,23 @@ static void fill_tables(const double *alpha, const double *const *V, int nv, Coe
   }
 }
 
+// A grouped column (core.hpp: GroupCol) is index arithmetic on 32-bit row numbers with a division by its period: every
+// launcher that takes one checks the description here, whoever produced it.
+static int gcol_check(const GroupCol *g, int64_t n, const char *who) {
+  if (!g || !g->w) return PO_OK;
+  if (g->period == 0 || g->nw > g->period || g->nwcon < 0 || n >= 2147483647LL ||
+      (g->nwcon > 0 && (int64_t)(g->nwcon - 1) * g->period + g->nw > n)) {
+    set_error("%s: bad grouped column (period %u, nw %u, nwcon %lld, n %lld)", who, g->period, g->nw,
+              (long long)g->nwcon, (long long)n);
+    return PO_ERR_ARG;
+  }
+  return PO_OK;
+}
+
 int k_panel_axpy(Ctx *c, double *y, double a, const double *x, double b, const double *alpha,
                  const double *const *V, int nv, int64_t n, const GroupCol *ybase) {
   if (n <= 0) return PO_OK;
+  PO_TRY(gcol_check(ybase, n, "k_panel_axpy"));
   // panels wider than one kernel's argument tables go in slabs: the first carries a*x + b*y, the others accumulate
   int j0 = 0;
   do {
@@ -1058,6 +1073,7 @@ __global__ void __launch_bounds__(kBlock)
 int k_kkt_res(Ctx *c, const Bounds &b, const double *g, const double *const *A, const double *z,
               int nc, double beta_mu, int64_t n, double *rx, double *out, double *yqn, double beta_mu2,
               const GroupCol *gcol, double gcoef) {
+  PO_TRY(gcol_check(gcol, n, "k_kkt_res"));
   if (nc > kMaxPanel) {  // wide A^T z: one collapsed column
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
@@ -1474,6 +1490,7 @@ int k_solve2r(Ctx *c, const Bounds &b, const double *t1, const double *t2, const
               double diag, int ca0, const double *const *vs, int nvirt, double b0v, const double *g,
               double *merit_out, double dinv_diag, const GroupCol *gcol, double gc1, double gc2) {
   count_bytes(c, nv + nvirt + 7 + (t1 ? 2 : 0) + (pzl ? 2 : 0) + (va ? 1 : 0) + (g ? 1 : 0), n);
+  PO_TRY(gcol_check(gcol, n, "k_solve2r"));
   if (gcol && t2 == nullptr) {
     set_error("k_solve2r: a grouped column is only taken in the stored right-hand side form");
     return PO_ERR_ARG;
@@ -1857,6 +1874,7 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
                   const double *const *vs, int nvirt, double b0v, double dinv_diag, const GroupCols2 *gcols) {
   count_bytes(c, nv + nvirt + 6 + (t ? 2 : 0) + (store_step == 1 ? 3 + (va ? 1 : 0) : (store_step == 2 ? 1 : 0)) + ((traw || tout) ? 1 : 0), n);
   const GroupCols2 gcs = gcols ? *gcols : GroupCols2();
+  for (int e = 0; e < gcs.count; e++) PO_TRY(gcol_check(&gcs.g[e], n, "k_solve2_dots"));
   for (int e = 0; e < gcs.count; e++) count_bytes(c, 1.0, gcs.g[e].nwcon);
   if (nv > kMaxPanel || nv < 1) {
     set_error("panel of %d vectors outside 1..%d", nv, kMaxPanel);
@@ -2381,6 +2399,7 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz, const double *pxs, const double *xold,
                      double beta_mu_step, double beta_mu2, const GroupCol *gcol, double gcoef) {
+  PO_TRY(gcol_check(gcol, n, "k_kkt_res_update"));
   if (acz && gcol) {
     set_error("kkt_res_update: a grouped column cannot follow the A^T z vector of the linear-constraint mode");
     return PO_ERR_ARG;

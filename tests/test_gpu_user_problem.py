@@ -147,10 +147,12 @@ def test_user_weighting_problem_takes_the_fused_group_path(ctx, n, c, nw, iters)
         for key in ("gpiv", "mfpiv", "clamped"):
             if key in sa:
                 np.testing.assert_array_equal(np.asarray(sa[key]), np.asarray(sb[key]), err_msg=key)
-        assert abs(sa["mu"] - sb["mu"]) <= 1e-9 * abs(sa["mu"])
-        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-10 * max(1.0, abs(sa["fobj"]))
-        np.testing.assert_allclose(sb["wnorms"], sa["wnorms"], rtol=1e-9)
-    np.testing.assert_allclose(b["x"], a["x"], rtol=0, atol=1e-7)
+        # (two device runs whose f and cw are summed in another order: round-off level differences grow along the
+        # trajectory like any reduction-order change, cf. tests/golden/self_disagreement.json)
+        assert abs(sa["mu"] - sb["mu"]) <= 1e-7 * abs(sa["mu"])
+        assert abs(sa["fobj"] - sb["fobj"]) <= 1e-7 * max(1.0, abs(sa["fobj"]))
+        np.testing.assert_allclose(sb["wnorms"], sa["wnorms"], rtol=1e-6)
+    np.testing.assert_allclose(b["x"], a["x"], rtol=0, atol=1e-6)
     # the library's launches: the built-in problem's evaluation kernels are the library's own and counted, the user's
     # are not -- per optimize() the user route shows FEWER library launches, and never the column-by-column path
     # (that would be ~ (c + k) launches more per iteration)
