@@ -1069,10 +1069,17 @@ class ParOptEigenQuasiNewton : public ParOptCompactQuasiNewton {
 };
 
 // The subproblem interface (src/ParOptTrustRegion.h:15-151).  The two library forms below implement it on the
-// device; ParOptTrustRegion drives those (a user-written subclass has no device-side counterpart: INTEGRATION.md 5).
+// device.  A USER-written subclass (round 5) is driven through a callback table: ParOptTrustRegion / ParOptOptimizer::
+// setTrustRegionSubproblem take it like a library one (po_trsub_create_callbacks) -- its seven
+// virtuals and its ParOptProblem side (getVarsAndBounds / evalObjCon / evalObjConGradient of the MODEL, in the step)
+// are called from the device solver.
 class ParOptTrustRegionSubproblem : public ParOptProblem {
  public:
-  explicit ParOptTrustRegionSubproblem(ParOptComm _comm) : ParOptProblem(_comm) {}
+  explicit ParOptTrustRegionSubproblem(ParOptComm _comm) : ParOptProblem(_comm), user_sub(NULL) {}
+  ~ParOptTrustRegionSubproblem() {
+    if (user_sub) po_trsub_destroy(user_sub);
+    for (ParOptVec *v : keep) v->decref();
+  }
   virtual ParOptCompactQuasiNewton *getQuasiNewton() = 0;
   virtual void initModelAndBounds(double tr_size) = 0;
   virtual void setTrustRegionBounds(double tr_size) = 0;
@@ -1084,8 +1091,115 @@ class ParOptTrustRegionSubproblem : public ParOptProblem {
   virtual int getLinearModel(ParOptVec **_xk = NULL, ParOptScalar *fk = NULL, ParOptVec **gk = NULL,
                              const ParOptScalar **ck = NULL, ParOptVec ***Ak = NULL, ParOptVec **lb = NULL,
                              ParOptVec **ub = NULL) = 0;
-  // the library object behind a library-backed subproblem (NULL for a user-written one)
-  virtual po_trsub subHandle() { return NULL; }
+  // The library object behind the subproblem: a library-backed one returns its own; a user-written one gets a
+  // callback-backed object on first use, built over the subproblem's own ParOptProblem side (ParOptProblem::handle():
+  // sizes, inequality counts and -- already in model form -- its sparse-constraint callbacks).
+  virtual po_trsub subHandle() {
+    if (!user_sub) {
+      po_problem self = ParOptProblem::handle();
+      if (!self) return NULL;
+      po_trsub_callbacks cb;
+      memset(&cb, 0, sizeof(cb));
+      cb.user = this;
+      cb.get_quasi_newton = &ParOptTrustRegionSubproblem::ts_qn;
+      cb.init_model_and_bounds = &ParOptTrustRegionSubproblem::ts_init;
+      cb.set_trust_region_bounds = &ParOptTrustRegionSubproblem::ts_bounds;
+      cb.eval_trial_step_and_update = &ParOptTrustRegionSubproblem::ts_trial;
+      cb.accept_trial_step = &ParOptTrustRegionSubproblem::ts_accept;
+      cb.reject_trial_step = &ParOptTrustRegionSubproblem::ts_reject;
+      cb.get_quasi_newton_update_type = &ParOptTrustRegionSubproblem::ts_utype;
+      cb.get_linear_model = &ParOptTrustRegionSubproblem::ts_model;
+      cb.get_vars_and_bounds = &ParOptTrustRegionSubproblem::ts_vars;
+      cb.eval_obj_con = &ParOptTrustRegionSubproblem::ts_eval;
+      cb.eval_obj_con_gradient = &ParOptTrustRegionSubproblem::ts_grad;
+      cb.sparse_constraints_are_model = 1;
+      if (po_trsub_create_callbacks(self, &cb, &user_sub) != 0) {
+        fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+        user_sub = NULL;
+      }
+    }
+    return user_sub;
+  }
+  // the po_problem the interior point is built on: the callback-backed subproblem (NOT the plain problem side)
+  po_problem handle() {
+    po_trsub h = subHandle();
+    po_problem p = NULL;
+    if (h) po_trsub_problem(h, &p);
+    return p;
+  }
+
+ private:
+  typedef ParOptTrustRegionSubproblem Self;
+  static Self *me(void *u) { return static_cast<Self *>(u); }
+  static int ts_qn(void *u, po_qn *qn) {
+    ParOptCompactQuasiNewton *q = me(u)->getQuasiNewton();
+    *qn = q ? q->handle() : NULL;
+    return 0;
+  }
+  static int ts_init(void *u, double tr) {
+    me(u)->initModelAndBounds(tr);
+    return 0;
+  }
+  static int ts_bounds(void *u, double tr) {
+    me(u)->setTrustRegionBounds(tr);
+    return 0;
+  }
+  static int ts_trial(void *u, int flag, po_vec step, const double *z, po_vec zw, double *fobj, double *cons) {
+    Arg vs(step, 0), vw(zw, 0);
+    return me(u)->evalTrialStepAndUpdate(flag, vs.p(), const_cast<double *>(z), zw ? vw.p() : NULL, fobj, cons);
+  }
+  static int ts_accept(void *u, po_vec step, const double *z, po_vec zw) {
+    Arg vs(step, 0), vw(zw, 0);
+    return me(u)->acceptTrialStep(vs.p(), const_cast<double *>(z), zw ? vw.p() : NULL);
+  }
+  static int ts_reject(void *u) {
+    me(u)->rejectTrialStep();
+    return 0;
+  }
+  static int ts_utype(void *u) { return me(u)->getQuasiNewtonUpdateType(); }
+  static int ts_model(void *u, po_vec *xk, double *fk, po_vec *gk, const double **ck, const po_vec **Ak, po_vec *lb,
+                      po_vec *ub) {
+    Self *s = me(u);
+    ParOptVec *vx = NULL, *vg = NULL, *vl = NULL, *vu = NULL, **va = NULL;
+    const int m = s->getLinearModel(&vx, fk, &vg, ck, &va, &vl, &vu);
+    if (!vx || !vg || !vl || !vu) return 1;
+    *xk = vx->handle();
+    *gk = vg->handle();
+    *lb = vl->handle();
+    *ub = vu->handle();
+    s->akh.resize(m > 0 ? m : 1);
+    for (int i = 0; i < m; i++) s->akh[i] = va[i]->handle();
+    *Ak = s->akh.data();
+    return 0;
+  }
+  static int ts_vars(void *u, po_vec x, po_vec l, po_vec up) {
+    Arg vx(x, 1), vl(l, 1), vu(up, 1);
+    me(u)->getVarsAndBounds(vx.p(), vl.p(), vu.p());
+    return 0;
+  }
+  static int ts_eval(void *u, po_vec step, double *fobj, double *cons) {
+    Arg vs(step, 0);
+    return me(u)->evalObjCon(step ? vs.p() : NULL, fobj, cons);
+  }
+  static int ts_grad(void *u, po_vec step, po_vec g, const po_vec *Ac) {
+    Self *s = me(u);
+    int fail = 0;
+    {
+      Arg vs(step, 0), vg(g, 1);
+      std::vector<Arg *> args;
+      std::vector<ParOptVec *> va(s->ncon > 0 ? s->ncon : 1, (ParOptVec *)NULL);
+      for (int j = 0; Ac && j < s->ncon; j++) {
+        args.push_back(new Arg(Ac[j], 1));
+        va[j] = args.back()->p();
+      }
+      fail = s->evalObjConGradient(vs.p(), vg.p(), (Ac || s->ncon == 0) ? va.data() : NULL);
+      for (Arg *a : args) delete a;
+    }
+    return fail;
+  }
+  po_trsub user_sub;
+  std::vector<po_vec> akh;
+  std::vector<ParOptVec *> keep;
 };
 
 // common part of the two library-backed subproblems: everything forwards to the po_trsub object
@@ -1250,8 +1364,8 @@ class ParOptTrustRegion : public ParOptBase {
     }
     options->incref();
     if (!subproblem->subHandle()) {
-      fprintf(stderr, "ParOptAMD: ParOptTrustRegion needs a library-backed subproblem (ParOptQuadraticSubproblem or "
-                      "ParOptEigenSubproblem)\n");
+      fprintf(stderr, "ParOptAMD: the trust-region subproblem could not be attached to the library: %s\n",
+              po_last_error());
     } else if (po_tr_create_subproblem(subproblem->subHandle(), &tr) != 0) {
       fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
     }

@@ -597,6 +597,37 @@ int po_trsub_get_quasi_newton_update_type(po_trsub sub, int *type);
 /* getLinearModel (.h:91-95): returns the number of dense constraints in *m; borrowed pointers */
 int po_trsub_get_linear_model(po_trsub sub, po_vec *xk, double *fk, po_vec *gk, const double **ck,
                               const po_vec **Ak, po_vec *lb, po_vec *ub, int *m);
+/* A subproblem written by the USER: the virtuals of ParOptTrustRegionSubproblem (src/ParOptTrustRegion.h:15-151) plus the
+ * ParOptProblem side the interior point solves (the model in the step s: bounds lk - xk <= s <= uk - xk, model
+ * objective and constraints and their gradients; eval_obj_con is also called with step == NULL for the values at
+ * s = 0, as the reference's driver does, src/ParOptTrustRegion.cpp:1255).  Every callback returns 0 on success;
+ * get_quasi_newton may report NULL (no quasi-Newton term).  get_linear_model hands out BORROWED handles of the
+ * user's own vectors (xk, gk, Ak[m], lb, ub) and host values (fk, ck[m]); the library reads it after
+ * init_model_and_bounds and after every accept_trial_step.  The sparse constraints (if any) are those of `prob`,
+ * linearised about xk by the library as the reference's subproblems do (.h:345-375).  Used by
+ * ParOptTrustRegion::optimize / ParOptOptimizer::setTrustRegionSubproblem of the facade for user subclasses and by
+ * paropt_amd.TrustRegionSubproblem (Python). */
+typedef struct po_trsub_callbacks {
+  void *user;
+  int (*get_quasi_newton)(void *user, po_qn *qn);
+  int (*init_model_and_bounds)(void *user, double tr_size);
+  int (*set_trust_region_bounds)(void *user, double tr_size);
+  int (*eval_trial_step_and_update)(void *user, int update_flag, po_vec step, const double *z, po_vec zw, double *fobj,
+                                    double *cons);
+  int (*accept_trial_step)(void *user, po_vec step, const double *z, po_vec zw);
+  int (*reject_trial_step)(void *user);
+  int (*get_quasi_newton_update_type)(void *user);
+  int (*get_linear_model)(void *user, po_vec *xk, double *fk, po_vec *gk, const double **ck, const po_vec **Ak,
+                          po_vec *lb, po_vec *ub);
+  int (*get_vars_and_bounds)(void *user, po_vec step, po_vec lower, po_vec upper);
+  int (*eval_obj_con)(void *user, po_vec step, double *fobj, double *cons);
+  int (*eval_obj_con_gradient)(void *user, po_vec step, po_vec g, const po_vec *Ac);
+  /* 0: the sparse constraints of `prob` are those of the ORIGINAL problem and are linearised about xk by the library
+   * (cw(xk) + Aw(xk) s), as the reference's own subproblems do; non-zero: `prob` is the subproblem's own problem
+   * side, whose sparse callbacks already evaluate the model in the step (a facade subclass) */
+  int sparse_constraints_are_model;
+} po_trsub_callbacks;
+int po_trsub_create_callbacks(po_problem prob, const po_trsub_callbacks *callbacks, po_trsub *out);
 /* ParOptTrustRegion(subproblem, options) and optimize(ip) (src/ParOptTrustRegion.cpp:660-718, 2365-2384).  `ip` must
  * have been created on po_trsub_problem(sub).  Options set on `tr` that the interior-point registry lacks (tr_*,
  * filter_*) are carried into the solver's registry at the call: one registry serves both, as the reference's shared

@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     TrustRegion,
     TrustRegionSubproblem,
     QuadraticSubproblem,
+    UserTrustRegionSubproblem,
     EigenSubproblem,
     EigenQuasiNewton,
     CompactEigenApprox,

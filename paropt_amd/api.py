@@ -1190,6 +1190,138 @@ class TrustRegionSubproblem:
                 [wrap(L.po_vec(Ak[i])) for i in range(m.value)], wrap(lb), wrap(ub))
 
 
+class UserTrustRegionSubproblem(TrustRegionSubproblem):
+    """A trust-region subproblem written by the USER: subclass and override the virtuals of
+    ParOptTrustRegionSubproblem (reference src/ParOptTrustRegion.h:15-151) -- all arguments are device vectors (PVec),
+    multipliers numpy arrays:
+
+        getQuasiNewton() -> LBFGS / LSR1 / EigenQuasiNewton or None
+        initModelAndBounds(tr_size); setTrustRegionBounds(tr_size)
+        evalTrialStepAndUpdate(update_flag, step, z, zw) -> (fail, fobj, cons)
+        acceptTrialStep(step, z, zw) -> fail;  rejectTrialStep();  getQuasiNewtonUpdateType() -> int
+        getLinearModel() -> (xk, fk, gk, ck, Ak, lb, ub)            (the user's own vectors; borrowed by the driver)
+
+    and the ParOptProblem side the interior point solves (the model in the step):
+
+        getVarsAndBounds(step, lower, upper)                         (filled in place)
+        evalObjCon(step or None) -> (fail, fobj, cons)               (None: the values at a zero step)
+        evalObjConGradient(step, g, A) -> fail                       (A is None when only g is wanted)
+
+    ``TrustRegion(sub, options).optimize(InteriorPoint(sub, options))`` then drives it exactly like the library's own
+    subproblems (po_trsub_create_callbacks)."""
+
+    def __init__(self, problem):
+        super().__init__(problem)
+        ctx, m = self.ctx, self.ncon
+        self._pending_exc = None
+        wrap = lambda h: PVec(ctx, handle=L.po_vec(h), owned=False) if h else None  # noqa: E731
+
+        def guard(fn):
+            def g(*args):
+                if self._pending_exc is not None:
+                    return 1
+                try:
+                    return int(fn(*args) or 0)
+                except BaseException as e:  # noqa: BLE001 - re-raised by _raise_pending()
+                    self._pending_exc = e
+                    return 1
+            return g
+
+        @guard
+        def _getqn(user, out):
+            q = self.getQuasiNewton()
+            out[0] = q._h if q is not None else None
+            return 0
+
+        @guard
+        def _init(user, tr):
+            return self.initModelAndBounds(tr)
+
+        @guard
+        def _setb(user, tr):
+            return self.setTrustRegionBounds(tr)
+
+        @guard
+        def _trial(user, flag, step, z, zw, fobj, cons):
+            fail, f, c = self.evalTrialStepAndUpdate(flag, wrap(step), np.array([z[i] for i in range(m)]), wrap(zw))
+            fobj[0] = float(f)
+            for i in range(m):
+                cons[i] = float(c[i])
+            return fail
+
+        @guard
+        def _accept(user, step, z, zw):
+            za = np.array([z[i] for i in range(m)]) if z else None
+            return self.acceptTrialStep(wrap(step), za, wrap(zw))
+
+        @guard
+        def _reject(user):
+            return self.rejectTrialStep()
+
+        def _utype(user):
+            try:
+                return int(self.getQuasiNewtonUpdateType())
+            except BaseException as e:  # noqa: BLE001
+                self._pending_exc = self._pending_exc or e
+                return 0
+
+        @guard
+        def _model(user, xk, fk, gk, ck, Ak, lb, ub):
+            vx, f, vg, c, A, vl, vu = self.getLinearModel()
+            # the arrays handed out must outlive the call: kept on the object until the next call
+            self._ck_arr = (C.c_double * max(1, m))(*[float(v) for v in c])
+            self._ak_arr = (L.po_vec * max(1, m))(*[a.handle.value for a in A])
+            xk[0], gk[0], lb[0], ub[0] = vx.handle.value, vg.handle.value, vl.handle.value, vu.handle.value
+            fk[0] = float(f)
+            ck[0] = C.cast(self._ck_arr, L.c_double_p)
+            Ak[0] = C.cast(self._ak_arr, L.vec_p)
+            return 0
+
+        @guard
+        def _bounds(user, step, lo, up):
+            return self.getVarsAndBounds(wrap(step), wrap(lo), wrap(up))
+
+        @guard
+        def _eval(user, step, fobj, cons):
+            fail, f, c = self.evalObjCon(wrap(step))
+            fobj[0] = float(f)
+            for i in range(m):
+                cons[i] = float(c[i])
+            return fail
+
+        @guard
+        def _grad(user, step, g, Ac):
+            A = [wrap(Ac[i]) for i in range(m)] if Ac else None
+            return self.evalObjConGradient(wrap(step), wrap(g), A)
+
+        cb = L.TrSubCallbacks()
+        self._fns = (L.TRSUB_GETQN_FN(_getqn), L.TRSUB_SIZE_FN(_init), L.TRSUB_SIZE_FN(_setb), L.TRSUB_TRIAL_FN(_trial),
+                     L.TRSUB_ACCEPT_FN(_accept), L.TRSUB_VOID_FN(_reject), L.TRSUB_VOID_FN(_utype),
+                     L.TRSUB_MODEL_FN(_model), L.TRSUB_BOUNDS_FN(_bounds), L.TRSUB_EVAL_FN(_eval), L.TRSUB_GRAD_FN(_grad))
+        cb.user = None
+        (cb.get_quasi_newton, cb.init_model_and_bounds, cb.set_trust_region_bounds, cb.eval_trial_step_and_update,
+         cb.accept_trial_step, cb.reject_trial_step, cb.get_quasi_newton_update_type, cb.get_linear_model,
+         cb.get_vars_and_bounds, cb.eval_obj_con, cb.eval_obj_con_gradient) = self._fns
+        self._cb_struct = cb
+        check(lib.po_trsub_create_callbacks(problem.handle, C.byref(cb), C.byref(self._h)))
+
+    def _raise_pending(self):
+        e, self._pending_exc = self._pending_exc, None
+        if e is not None:
+            raise e
+        super()._raise_pending()
+
+    # the virtuals (the base class's versions of these names call INTO the library: a user subproblem defines them)
+    def getQuasiNewton(self):
+        return None
+
+    def getQuasiNewtonUpdateType(self):
+        return 0
+
+    def rejectTrialStep(self):
+        return 0
+
+
 class QuadraticSubproblem(TrustRegionSubproblem):
     """ParOptQuadraticSubproblem(problem, qn) (.h:153-300); qn may be None."""
 

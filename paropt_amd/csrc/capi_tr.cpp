@@ -382,6 +382,31 @@ int po_trsub_create_eigen(po_problem prob, po_qn eig_qn, po_trsub *out) {
   h->sub = new EigenSubproblem(prob->p, e);
   return finish_trsub(h, out);
 }
+int po_trsub_create_callbacks(po_problem prob, const po_trsub_callbacks *callbacks, po_trsub *out) {
+  PO_CHECK_PTR(prob);
+  PO_CHECK_PTR(callbacks);
+  PO_CHECK_PTR(out);
+  if (!callbacks->init_model_and_bounds || !callbacks->set_trust_region_bounds ||
+      !callbacks->eval_trial_step_and_update || !callbacks->accept_trial_step || !callbacks->get_linear_model ||
+      !callbacks->get_vars_and_bounds || !callbacks->eval_obj_con || !callbacks->eval_obj_con_gradient) {
+    po::set_error("po_trsub_create_callbacks: a required callback is missing (only get_quasi_newton, "
+                  "reject_trial_step and get_quasi_newton_update_type are optional)");
+    return PO_ERR_ARG;
+  }
+  po_trsub_s *h = new po_trsub_s();
+  CallbackSubproblem *cs = new CallbackSubproblem(prob->p, *callbacks);
+  h->sub = cs;
+  const int rc = cs->allocateModel();
+  if (rc != PO_OK) {
+    delete cs;
+    delete h;
+    return rc;
+  }
+  h->face.p = h->sub;
+  h->qnh.qn = nullptr;  // asked for when needed: the user's object may not exist yet
+  *out = h;
+  return PO_OK;
+}
 int po_trsub_destroy(po_trsub sub) {
   if (!sub) return PO_OK;
   delete sub->sub;

@@ -257,6 +257,99 @@ void TrustRegionSubproblem::acceptModel() {
   }
 }
 
+// ---- user-written subproblem behind a callback table ----------------------------------------------------------
+static inline po_vec PV(Vec *v) { return static_cast<po_vec>(v); }
+void CallbackSubproblem::dropModel() {
+  Vec **all[] = {&xk, &gk, &lb, &ub};
+  for (Vec **v : all) {
+    vec_decref(*v);
+    *v = nullptr;
+  }
+  for (Vec *v : Ak) vec_decref(v);
+  Ak.clear();
+}
+CallbackSubproblem::~CallbackSubproblem() { dropModel(); }
+int CallbackSubproblem::allocateModel() {
+  // only the driver's scratch that no callback provides; the model vectors are borrowed in syncLinearModel
+  t = vec_new(ctx, nlocal);
+  xtemp = vec_new(ctx, nlocal);
+  return (t && xtemp) ? PO_OK : PO_ERR_HIP;
+}
+int CallbackSubproblem::syncLinearModel() {
+  po_vec hx = nullptr, hg = nullptr, hl = nullptr, hu = nullptr;
+  const double *c = nullptr;
+  const po_vec *A = nullptr;
+  double f = 0.0;
+  if (!cb.get_linear_model || cb.get_linear_model(cb.user, &hx, &f, &hg, &c, &A, &hl, &hu) != 0) {
+    set_error("trust-region subproblem: getLinearModel failed");
+    return PO_ERR_USER;
+  }
+  if (!hx || !hg || !hl || !hu || (m > 0 && (!c || !A))) {
+    set_error("trust-region subproblem: getLinearModel returned a NULL part of the model");
+    return PO_ERR_USER;
+  }
+  dropModel();
+  auto take = [&](po_vec h) -> Vec * {
+    Vec *v = h;
+    v->ref++;
+    return v;
+  };
+  xk = take(hx);
+  gk = take(hg);
+  lb = take(hl);
+  ub = take(hu);
+  fk = f;
+  for (int i = 0; i < m; i++) {
+    if (!A[i] || A[i]->n != nlocal) {
+      set_error("trust-region subproblem: getLinearModel: constraint gradient %d is missing or has the wrong size", i);
+      return PO_ERR_USER;
+    }
+    ck[i] = c[i];
+    Ak.push_back(take(A[i]));
+  }
+  zts_valid = false;
+  return PO_OK;
+}
+CompactQuasiNewton *CallbackSubproblem::getQuasiNewton() {
+  po_qn q = nullptr;
+  if (cb.get_quasi_newton && cb.get_quasi_newton(cb.user, &q) == 0 && q) return q->qn;
+  return nullptr;
+}
+int CallbackSubproblem::initModelAndBounds(double tr_size) {
+  if (!cb.init_model_and_bounds || cb.init_model_and_bounds(cb.user, tr_size) != 0) return PO_ERR_USER;
+  return syncLinearModel();
+}
+int CallbackSubproblem::setTrustRegionBounds(double tr_size) {
+  return (cb.set_trust_region_bounds && cb.set_trust_region_bounds(cb.user, tr_size) == 0) ? PO_OK : PO_ERR_USER;
+}
+int CallbackSubproblem::evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
+                                               double *cons) {
+  if (!cb.eval_trial_step_and_update) return PO_ERR_USER;
+  return cb.eval_trial_step_and_update(cb.user, update_flag, PV(step), z, PV(zw), fobj, cons) == 0 ? PO_OK : PO_ERR_USER;
+}
+int CallbackSubproblem::acceptTrialStep(Vec *step, const double *z, Vec *zw) {
+  if (!cb.accept_trial_step || cb.accept_trial_step(cb.user, PV(step), z, PV(zw)) != 0) return PO_ERR_USER;
+  return syncLinearModel();
+}
+void CallbackSubproblem::rejectTrialStep() {
+  if (cb.reject_trial_step) cb.reject_trial_step(cb.user);
+}
+int CallbackSubproblem::getQuasiNewtonUpdateType() const {
+  return cb.get_quasi_newton_update_type ? cb.get_quasi_newton_update_type(cb.user) : 0;
+}
+int CallbackSubproblem::getVarsAndBounds(Vec *x, Vec *l, Vec *u) {
+  return cb.get_vars_and_bounds ? cb.get_vars_and_bounds(cb.user, PV(x), PV(l), PV(u)) : 1;
+}
+int CallbackSubproblem::evalObjCon(Vec *step, double *fobj, double *cons) {
+  return cb.eval_obj_con ? cb.eval_obj_con(cb.user, PV(step), fobj, cons) : 1;
+}
+int CallbackSubproblem::evalObjConGradient(Vec *step, Vec *g, Vec **Ac) {
+  if (!cb.eval_obj_con_gradient) return 1;
+  std::vector<po_vec> h(m > 0 ? m : 1, nullptr);
+  for (int i = 0; Ac && i < m; i++) h[i] = PV(Ac[i]);
+  return cb.eval_obj_con_gradient(cb.user, PV(step), PV(g), (Ac || m == 0) ? h.data() : nullptr);
+}
+
 // ---- quadratic --------------------------------------------------------------------------------
 int QuadraticSubproblem::evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw,
                                                 double *fobj, double *cons) {  // :175-212

@@ -68,12 +68,12 @@ class TrustRegionSubproblem : public Problem {
   int allocate();
   virtual CompactQuasiNewton *getQuasiNewton() = 0;
   virtual int initModelAndBounds(double tr_size);
-  int setTrustRegionBounds(double tr_size);
+  virtual int setTrustRegionBounds(double tr_size);
   virtual int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
                                      double *cons) = 0;
   virtual int acceptTrialStep(Vec *step, const double *z, Vec *zw) = 0;
-  void rejectTrialStep();
-  int getQuasiNewtonUpdateType() const { return qn_update_type; }
+  virtual void rejectTrialStep();
+  virtual int getQuasiNewtonUpdateType() const { return qn_update_type; }
   // linear model values at a step: f = fk + gk.s, cons = ck + Ak s (one panel-dot pass)
   int evalLinearModel(Vec *step, double *f, double *cons);
 
@@ -179,6 +179,51 @@ class EigenSubproblem : public TrustRegionSubproblem {  // ParOptCompactEigenval
   int modelDots(Vec *step, std::vector<double> &dots, int *kq);
 };
 
+
+// A subproblem written by the USER (round 5): the seven virtuals of ParOptTrustRegionSubproblem
+// (src/ParOptTrustRegion.h:15-151) and the ParOptProblem side the interior point solves, as a callback table
+// (po_trsub_create_callbacks; the facade's ParOptTrustRegionSubproblem subclasses and Python's TrustRegionSubproblem
+// arrive here).  The driver and the steering problem read the linear model through the base-class members (xk, fk, gk,
+// ck, Ak, lb, ub): they are BORROWED from the user's getLinearModel after every call that moves the base point.
+class CallbackSubproblem : public TrustRegionSubproblem {
+ public:
+  CallbackSubproblem(Problem *p, const po_trsub_callbacks &cb_) : TrustRegionSubproblem(p), cb(cb_) {}
+  ~CallbackSubproblem();
+  int allocateModel();  // no storage of its own: borrows the user's model vectors
+  CompactQuasiNewton *getQuasiNewton() override;
+  int initModelAndBounds(double tr_size) override;
+  int setTrustRegionBounds(double tr_size) override;
+  int evalTrialStepAndUpdate(int update_flag, Vec *step, const double *z, Vec *zw, double *fobj,
+                             double *cons) override;
+  int acceptTrialStep(Vec *step, const double *z, Vec *zw) override;
+  void rejectTrialStep() override;
+  int getQuasiNewtonUpdateType() const override;
+  int getVarsAndBounds(Vec *x, Vec *l, Vec *u) override;
+  int evalObjCon(Vec *step, double *fobj, double *cons) override;
+  int evalObjConGradient(Vec *step, Vec *g, Vec **Ac) override;
+  bool reductionsBatchable() override { return false; }  // user code: every reduction returns its value at once
+  // sparse_constraints_are_model: `prob` already IS the model's problem side (called with the step)
+  int evalSparseCon(Vec *step, Vec *out) override {
+    return cb.sparse_constraints_are_model ? prob->evalSparseCon(step, out) : TrustRegionSubproblem::evalSparseCon(step, out);
+  }
+  int addSparseJacobian(double alpha, Vec *x, Vec *px, Vec *out) override {
+    return cb.sparse_constraints_are_model ? prob->addSparseJacobian(alpha, x, px, out)
+                                           : TrustRegionSubproblem::addSparseJacobian(alpha, x, px, out);
+  }
+  int addSparseJacobianTranspose(double alpha, Vec *x, Vec *pzw, Vec *out) override {
+    return cb.sparse_constraints_are_model ? prob->addSparseJacobianTranspose(alpha, x, pzw, out)
+                                           : TrustRegionSubproblem::addSparseJacobianTranspose(alpha, x, pzw, out);
+  }
+  int addSparseInnerProduct(double alpha, Vec *x, Vec *cvec, Vec *A) override {
+    return cb.sparse_constraints_are_model ? prob->addSparseInnerProduct(alpha, x, cvec, A)
+                                           : TrustRegionSubproblem::addSparseInnerProduct(alpha, x, cvec, A);
+  }
+  po_trsub_callbacks cb;
+
+ private:
+  int syncLinearModel();
+  void dropModel();
+};
 
 class InfeasSubproblem : public Problem {  // :468-650
  public:

@@ -549,9 +549,40 @@ __global__ void __launch_bounds__(512, 1)
     const bool stamp = want_stamps && blockIdx.x == 0 && wave == 4;
     const unsigned long long st_c0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
     const unsigned long long st_r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
+    // GS == 2 (round 5): the group sums of the panel image are taken by the PRODUCER waves, off the consumers' critical
+    // path (matrix work only): behind the barrier that publishes tile t the 256 producer lanes request the operands of
+    // their (column, group) pair from tile t's buffer, stage tile t + 1 and issue the loads of tile t + 4 while the
+    // requests are in flight, then add (same rounded products, same order: the bits of group_panel_tiled_kernel) and
+    // store.  Branch-free like the rest of the producers' loop (a lane without a pair reads clamped addresses and
+    // stores 0.0 to the pad element behind the first output column), so that hipcc keeps exact counts of the
+    // outstanding prefetch loads; the first step "finishes" a tile that does not exist the same way.
+    [[maybe_unused]] GramGroupOps gops;
+    [[maybe_unused]] int g2_u = 0, g2_gi = 0, g2_uc = 0;
+    [[maybe_unused]] bool g2_lane = false;
+    if constexpr (GS == 2) {
+      const int ptid = tid - 256;
+      g2_u = ptid / gg.G;
+      g2_gi = ptid - g2_u * gg.G;
+      g2_lane = g2_u < gg.ncols;
+      g2_uc = g2_lane ? g2_u : 0;
+    }
+    typedef __attribute__((address_space(1))) double g2double;
+    [[maybe_unused]] g2double *g2_up = nullptr;
+    if constexpr (GS == 2) g2_up = (g2double *)utab[g2_uc];  // (published by the barrier above)
+#define PO_GS2_REQUEST(BUF) gram_groups_request((BUF), (BUF) + M * kGramLd, gg, g2_uc, g2_gi, gops)
+#define PO_GS2_FINISH(TIDX)                                                                                   \
+  {                                                                                                           \
+    const int64_t _tile = first + (TIDX) * stride;                                                            \
+    const int64_t _g0 = _tile * gg.G;                                                                         \
+    const bool _mine = g2_lane && (TIDX) >= 0 && _tile < gg.ngt && _g0 + g2_gi < gg.nwcon;                    \
+    const double _sum = gram_groups_sum(gg, gops);                                                            \
+    const int64_t _idx = _mine ? _g0 + g2_gi : gg.nwcon;                                                      \
+    g2_up[_idx] = _mine ? _sum : 0.0;                                                                         \
+  }
 #define PO_PC_STEP(R)                                                                                         \
   if (it + (R) < nt) {                                                                                        \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
+    if constexpr (GS == 2) PO_GS2_REQUEST(lds + (size_t)((it + (R) + 1) & 1) * kBufDoubles);                  \
     const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
     else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
@@ -559,6 +590,7 @@ __global__ void __launch_bounds__(512, 1)
     const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
     const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
+    if constexpr (GS == 2) PO_GS2_FINISH(it + (R) - 1);                                                       \
     __syncthreads();                                                                                          \
     if (stamp) {                                                                                              \
       const unsigned long long _t3 = __builtin_amdgcn_s_memtime();                                            \
@@ -573,6 +605,17 @@ __global__ void __launch_bounds__(512, 1)
       PO_PC_STEP(2)
     }
 #undef PO_PC_STEP
+    if constexpr (GS == 2) {
+      // the sums of the last tile (staged and published by the last step's barrier; the consumers overwrite the tile
+      // buffers only behind the trailing barrier below)
+      if (nt > 0) {
+        const double *bl = lds + (size_t)((nt - 1) & 1) * kBufDoubles;
+        PO_GS2_REQUEST(bl);
+        PO_GS2_FINISH(nt - 1);
+      }
+    }
+#undef PO_GS2_REQUEST
+#undef PO_GS2_FINISH
     if (stamp && lane == 0) {
       g_wgram_stamp[2] = st_stage;
       g_wgram_stamp[3] = st_load;
@@ -592,8 +635,8 @@ __global__ void __launch_bounds__(512, 1)
     unsigned long long sc_wait = 0, sc_work = 0;
     const bool cstamp = want_stamps && blockIdx.x == 0 && wave == 0;
     // (GS) this lane's pair of a full tile of G groups; the last group tile may hold fewer groups (recomputed there)
-    int gs_u = 0, gs_gi = 0;
-    if constexpr (GS != 0) {
+    [[maybe_unused]] int gs_u = 0, gs_gi = 0;
+    if constexpr (GS == 1) {
       gs_u = tid / gg.G;
       gs_gi = tid - gs_u * gg.G;
     }
@@ -604,11 +647,11 @@ __global__ void __launch_bounds__(512, 1)
       const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
       if (ablate == 1) continue;  // tuning: no matrix work
       // (GS) phase 1: request the operands of this lane's group sum before the matrix work
-      [[maybe_unused]] GramGroupOps gops;
+      [[maybe_unused]] GramGroupOps gops;  // (GS == 1: the consumers take the sums)
       [[maybe_unused]] bool gs_on = false, gs_mine = false;
       [[maybe_unused]] int gs_ng = 0, pu = 0, pgi = 0;
       [[maybe_unused]] int64_t gs_g0 = 0;
-      if constexpr (GS != 0) {
+      if constexpr (GS == 1) {
         const int64_t tile = first + it * stride;
         gs_on = tile < gg.ngt;
         if (gs_on) {
@@ -625,7 +668,7 @@ __global__ void __launch_bounds__(512, 1)
         }
       }
       if constexpr (RS) {
-        if constexpr (GS != 0) {
+        if constexpr (GS == 1) {
           auto request = [&]() {
             if (gs_on && gs_mine && ablate != 5) gram_groups_request(bt, bt + M * kGramLd, gg, pu, pgi, gops);
           };
@@ -642,7 +685,7 @@ __global__ void __launch_bounds__(512, 1)
         }
       }
       // (GS) phase 2: the ordered sum and its store (a GLOBAL store: the pointer from LDS is generic)
-      if constexpr (GS != 0) {
+      if constexpr (GS == 1) {
         if (gs_on) {
           if (gs_mine && ablate != 6) {  // (tuning: 4 = no store, 5 = no operand requests, 6 = neither sums nor store)
             typedef __attribute__((address_space(1))) double gdouble;
@@ -816,9 +859,15 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     ntiles = gg.ngt + (n - gg.rg + kGramTile - 1) / kGramTile;
     for (int j = 0; j < gg.ncols; j++) ut.p[j] = groups->U[j];
     count_bytes(c, (double)gg.ncols, gg.nwcon);
+    // round 5: the sums on the PRODUCER waves (GS = 2) where every (column, group) pair of a tile finds a producer
+    // lane; PAROPT_AMD_GS_PRODUCER=0 puts them back on the consumers (A/B, same bits)
+    const bool gs_prod = gg.G * gg.ncols <= 256 && dbg_switch(SW_GS_PRODUCER, "PAROPT_AMD_GS_PRODUCER", 1) != 0;
 #define PO_WGG(NGv)                                                                                                  \
   case NGv:                                                                                                          \
-    if (NGv >= kGramRowSplitMinNG && row_split)                                                                      \
+    if (NGv >= kGramRowSplitMinNG && row_split && gs_prod)                                                           \
+      PO_TRY((wgram_pc_launch_t<(NGv >= kGramRowSplitMinNG ? NGv : kGramRowSplitMinNG), 0, 1, 2>(                    \
+          c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid, &gg, &ut)));                                         \
+    else if (NGv >= kGramRowSplitMinNG && row_split)                                                                 \
       PO_TRY((wgram_pc_launch_t<NGv, 0, 1, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid, &gg, &ut)));     \
     else                                                                                                             \
       PO_TRY((wgram_pc_launch_t<NGv, 0, 0, 1>(c, d, pt, nv, n, ntiles, st, zt, 0, 0.0, tcol, &grid, &gg, &ut)));     \

@@ -74,6 +74,28 @@ class ProblemSparseCallbacks(C.Structure):
 
 # Every symbol include/paropt_amd.h declares, with its signature (restype is always int unless
 # stated).  tests/test_capi_symbols.py checks this table against the header and the .so.
+# po_trsub_callbacks (include/paropt_amd.h): a user-written ParOptTrustRegionSubproblem
+TRSUB_GETQN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(po_qn))
+TRSUB_SIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)
+TRSUB_TRIAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, po_vec, c_double_p, po_vec, c_double_p, c_double_p)
+TRSUB_ACCEPT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, po_vec)
+TRSUB_VOID_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+TRSUB_MODEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(po_vec), c_double_p, C.POINTER(po_vec),
+                             C.POINTER(c_double_p), C.POINTER(vec_p), C.POINTER(po_vec), C.POINTER(po_vec))
+TRSUB_BOUNDS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, po_vec)
+TRSUB_EVAL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, c_double_p, c_double_p)
+TRSUB_GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, po_vec, po_vec, vec_p)
+
+
+class TrSubCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("get_quasi_newton", TRSUB_GETQN_FN), ("init_model_and_bounds", TRSUB_SIZE_FN),
+                ("set_trust_region_bounds", TRSUB_SIZE_FN), ("eval_trial_step_and_update", TRSUB_TRIAL_FN),
+                ("accept_trial_step", TRSUB_ACCEPT_FN), ("reject_trial_step", TRSUB_VOID_FN),
+                ("get_quasi_newton_update_type", TRSUB_VOID_FN), ("get_linear_model", TRSUB_MODEL_FN),
+                ("get_vars_and_bounds", TRSUB_BOUNDS_FN), ("eval_obj_con", TRSUB_EVAL_FN),
+                ("eval_obj_con_gradient", TRSUB_GRAD_FN), ("sparse_constraints_are_model", C.c_int)]
+
+
 class KKTDump(C.Structure):
     """po_ip_kkt_dump (include/paropt_amd.h): borrowed views of the pieces of one KKT step."""
     _fields_ = [("c", C.c_int), ("k", C.c_int), ("Dinv", po_vec), ("res_x", po_vec),
@@ -266,6 +288,7 @@ SIGNATURES = {
     "po_eigqn_update_multipliers": (C.c_int, [po_qn, c_double_p]),
     "po_eigqn_get_multiplier_index": (C.c_int, [po_qn, c_int_p]),
     "po_trsub_create_quadratic": (C.c_int, [po_problem, po_qn, C.POINTER(po_trsub)]),
+    "po_trsub_create_callbacks": (C.c_int, [po_problem, C.POINTER(TrSubCallbacks), C.POINTER(po_trsub)]),
     "po_trsub_create_eigen": (C.c_int, [po_problem, po_qn, C.POINTER(po_trsub)]),
     "po_trsub_destroy": (C.c_int, [po_trsub]),
     "po_trsub_set_eigen_model_update": (C.c_int, [po_trsub, EIG_UPDATE_FN, C.c_void_p]),

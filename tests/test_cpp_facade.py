@@ -277,6 +277,41 @@ def test_cpp_eigenvalue_example_reproduces_reference_rows(tmp_path, driver):
     np.testing.assert_allclose(float(last[4]), g["final/xnorm"][0], rtol=1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("driver", ["objects", "optimizer"])
+def test_cpp_user_written_trust_region_subproblem(tmp_path, driver):
+    """The extension point SURVEY 8b names: a ParOptTrustRegionSubproblem subclass WRITTEN BY THE USER
+    (examples/user_subproblem_amd.cpp restates the reference's quadratic model, src/ParOptTrustRegion.cpp:27-466, on the
+    facade's vector and quasi-Newton classes) under ParOptTrustRegion(subproblem)->optimize(ip) and under
+    ParOptOptimizer::setTrustRegionSubproblem (src/ParOptOptimizer.cpp:226-237): the table it prints is the compiled
+    reference's (golden tr_quadratic_n200_c3_bfgs), row for row."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tr_helpers import compare_tr
+    from tr_helpers import parse_tr_table as parse_rows
+    from test_gpu_tr import TR_INEXACT_ROWS
+
+    exe = build(tmp_path, "user_subproblem_amd")
+    name = "tr_quadratic_n200_c3_bfgs"
+    g, case = load_golden(name)
+    a = case["args"]
+    cmd = [exe, "n=%d" % a["n"], "c=%d" % a["c"], "driver=" + driver]
+    for k, v in a.items():
+        if k.startswith("opt.") and k != "opt.write_output_frequency":
+            cmd.append("%s=%s" % (k, v))
+        if k.startswith("tr."):
+            cmd.append("opt.%s=%s" % (k[3:], v))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    table = parse_rows(res.stdout)
+    rows = [table[k] for k in sorted(table)]
+    n = compare_tr(g, rows, [], None, 60, check_snaps=False, inexact_rows=TR_INEXACT_ROWS.get(name, set()))
+    assert n >= 12 and len(rows) == int(g["final/iter_count"][0])
+    last = [ln for ln in res.stdout.splitlines() if ln.startswith("final:")][0].split()
+    assert abs(float(last[2]) - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+
+
 def test_eigenvalue_example_compiles_with_the_reference_header_names(tmp_path):
     """The class set of src/ParOptTrustRegion.h / src/ParOptCompactEigenvalueApprox.h is there under the reference's
     header names (include/paropt_compat, MPI_Comm communicators): a translation unit that includes only those headers

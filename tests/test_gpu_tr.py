@@ -235,6 +235,155 @@ def test_tr_objects_assembled_like_the_reference(ctx, name):
         np.testing.assert_array_equal(np.array(v1), np.array(v2))
 
 
+def _user_quadratic_subproblem(pa, prob, qn):
+    """ParOptQuadraticSubproblem (reference src/ParOptTrustRegion.cpp:27-466) restated by a USER on the public vector
+    and quasi-Newton API: the model f(s) = fk + gk.s + 1/2 s.B s, c(s) = ck + Ak s about the current point, trust-region
+    bounds on the step, quasi-Newton update from the Lagrangian gradient difference at an evaluated trial point."""
+    import ctypes as C
+
+    import paropt_amd.lib as L
+
+    ctx, n, m = prob.ctx, prob.nvars, prob.ncon
+    vec = lambda: pa.PVec(ctx, n)  # noqa: E731
+
+    class UserQuadratic(pa.UserTrustRegionSubproblem):
+        def __init__(self):
+            self.xk, self.lb, self.ub, self.lk, self.uk = vec(), vec(), vec(), vec(), vec()
+            self.gk, self.gt, self.t, self.xt, self.bs = vec(), vec(), vec(), vec(), vec()
+            self.Ak, self.At = [vec() for _ in range(m)], [vec() for _ in range(m)]
+            self.fk, self.ft, self.ck, self.ct = 0.0, 0.0, np.zeros(m), np.zeros(m)
+            self.update_type = 0
+            super().__init__(prob)
+
+        # -- evaluations of the ORIGINAL problem through the C ABI --
+        def _eval(self, x, g, A):
+            f, con = C.c_double(), np.zeros(max(1, m))
+            assert L.lib.po_problem_eval_obj_con(prob.handle, x.handle, C.byref(f), con.ctypes.data_as(L.c_double_p)) == 0
+            arr = (L.po_vec * max(1, m))(*[v.handle.value for v in A])
+            assert L.lib.po_problem_eval_obj_con_gradient(prob.handle, x.handle, g.handle, arr) == 0
+            return f.value, con[:m].copy()
+
+        def getQuasiNewton(self):
+            return qn
+
+        def initModelAndBounds(self, tr):  # :141-151
+            assert L.lib.po_problem_get_vars_and_bounds(prob.handle, self.xk.handle, self.lb.handle, self.ub.handle) == 0
+            self.setTrustRegionBounds(tr)
+            self.fk, self.ck = self._eval(self.xk, self.gk, self.Ak)
+            return 0
+
+        def setTrustRegionBounds(self, tr):  # :153-173: bounds on the STEP
+            x, lo, up = self.xk.to_numpy(), self.lb.to_numpy(), self.ub.to_numpy()
+            self.lk.from_numpy(np.maximum(-tr, lo - x))
+            self.uk.from_numpy(np.minimum(tr, up - x))
+            return 0
+
+        def evalTrialStepAndUpdate(self, flag, step, z, zw):  # :175-212
+            self.xt.copyValues(self.xk)
+            self.xt.axpy(1.0, step)
+            self.ft, self.ct = self._eval(self.xt, self.gt, self.At)
+            if qn is not None and flag:
+                # y = [gt - At^T z] - [gk - Ak^T z]
+                self.t.copyValues(self.gt)
+                self.t.axpy(-1.0, self.gk)
+                for i in range(m):
+                    self.t.axpy(-z[i], self.At[i])
+                    self.t.axpy(z[i], self.Ak[i])
+                self.update_type = qn.update(step, self.t)
+            return 0, self.ft, self.ct
+
+        def acceptTrialStep(self, step, z, zw):  # :214-224
+            self.xk.axpy(1.0, step)
+            self.fk, self.ck = self.ft, self.ct.copy()
+            self.gk, self.gt = self.gt, self.gk
+            self.Ak, self.At = self.At, self.Ak
+            return 0
+
+        def rejectTrialStep(self):
+            self.ft, self.ct = 0.0, np.zeros(m)
+            return 0
+
+        def getQuasiNewtonUpdateType(self):
+            return self.update_type
+
+        def getLinearModel(self):
+            return self.xk, self.fk, self.gk, self.ck, self.Ak, self.lb, self.ub
+
+        # -- the model as the interior point's problem --
+        def getVarsAndBounds(self, step, lo, up):  # :278-285: start in the middle of the box
+            step.copyValues(self.lk)
+            step.axpy(1.0, self.uk)
+            step.scale(0.5)
+            lo.copyValues(self.lk)
+            up.copyValues(self.uk)
+            return 0
+
+        def evalObjCon(self, step):  # :290-323
+            if step is None:
+                return 0, self.fk, self.ck
+            dots = step.mdot([self.gk] + self.Ak)
+            f = self.fk + dots[0]
+            if qn is not None:
+                qn.mult(step, self.bs)
+                f += 0.5 * step.dot(self.bs)
+            return 0, f, self.ck + np.asarray(dots[1:])
+
+        def evalObjConGradient(self, step, g, A):  # :328-343
+            g.copyValues(self.gk)
+            if qn is not None:
+                qn.multAdd(1.0, step, g)
+            if A is not None:
+                for i in range(m):
+                    A[i].copyValues(self.Ak[i])
+            return 0
+
+    return UserQuadratic()
+
+
+def test_user_written_trust_region_subproblem(ctx):
+    """The extension point SURVEY 8b names (src/ParOptTrustRegion.h:15-151, src/ParOptOptimizer.cpp:226-237): a
+    ParOptTrustRegionSubproblem written by the user -- here ParOptQuadraticSubproblem restated on the public vector /
+    quasi-Newton API in Python -- under ParOptTrustRegion(subproblem)->optimize(ip) reproduces the compiled reference's
+    iteration table of tr_quadratic_n200_c3_bfgs, and the run of the library's own quadratic subproblem."""
+    import paropt_amd as pa
+
+    name = "tr_quadratic_n200_c3_bfgs"
+    g, case = load_golden(name)
+    a = case["args"]
+    prob = pa.SeparableProblem(ctx, a["problem"], a["n"], a.get("c", 2), a.get("seed", 0),
+                               a.get("eig_min", 1.0), a.get("eig_max", 100.0))
+    opts, tropts = tr_options_from_case(case)
+    opts.pop("write_output_frequency", None)
+    qn = pa.LBFGS(ctx, prob.nvars, opts.get("qn_subspace_size", 10), opts.get("qn_update_type", "skip_negative_curvature"))
+    sub = _user_quadratic_subproblem(pa, prob, qn)
+    ip = pa.InteriorPoint(sub, opts)
+    tr = pa.TrustRegion(sub, dict(tropts, **({"penalty_gamma": opts["penalty_gamma"]} if "penalty_gamma" in opts else {})))
+    rows = []
+    tr.setIterationCallback(lambda i: rows.append(tr.getLastRow()) if i > 0 else None)
+    tr.optimize(ip)
+    rows.append(tr.getLastRow())
+    st = tr.getState()
+    final = dict(iter_count=st["iter_count"], fk=st["fk"], ck=st["ck"], x=sub.xk.to_numpy(),
+                 z=ip.getOptimizedPoint()[1])
+    n = compare_tr(g, rows, [], final, 60, check_snaps=False, inexact_rows=TR_INEXACT_ROWS.get(name, set()))
+    assert n >= 12
+    assert final["iter_count"] == int(g["final/iter_count"][0])
+    assert abs(final["fk"] - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
+    np.testing.assert_allclose(final["x"], g["final/x"], rtol=0, atol=1e-5 * max(1.0, np.abs(g["final/x"]).max()))
+    # ... and the library's own quadratic subproblem on the same case: the same accept / reject decisions and
+    # interior-point iteration counts in every row, values to the table's print precision
+    tr2, ip2, sub2, rows2, final2 = run_gpu_tr_objects(ctx, case)
+    assert len(rows2) == len(rows)
+    for (v1, t1), (v2, t2) in zip(rows, rows2):
+        assert t1 == t2
+        np.testing.assert_allclose(np.array(v1), np.array(v2), rtol=1e-6, atol=1e-9)
+    # an exception inside a user callback stops the driver and is re-raised
+    sub3 = _user_quadratic_subproblem(pa, prob, qn)
+    sub3.setTrustRegionBounds = lambda tr_size: (_ for _ in ()).throw(RuntimeError("user bug"))
+    with pytest.raises(RuntimeError):
+        pa.TrustRegion(sub3, tropts).optimize(pa.InteriorPoint(sub3, opts))
+
+
 def test_eigen_objects_standalone(ctx):
     """ParOptCompactEigenApprox / ParOptEigenQuasiNewton on their own (src/ParOptCompactEigenvalueApprox.cpp:52-290)
     against numpy: multAdd, evalApproximation(+Gradient), and the combined compact matrix B = B_qn - z0 H M H^T through
