@@ -260,6 +260,24 @@ def cpu_baseline(n, ncon, iters, log, nwcon=0, nw=0, qn="sr1", qn_size=QN_SIZE, 
                              "implied_host_GBps = the reference sequence's traffic model (SURVEY 3.4) / seconds" % (
                                  ranks, cpus["affinity"], cpus["cgroup_quota_cpus"], cpus["os_cpu_count"], best_n, K,
                                  kfull, len(same), best_n, n, n_md)}
+            # a full-size measurement on record (builder run with --cpu-full-size, committed under profiles/): what the
+            # linear scaling of the sampled rate is worth at the workload's own n
+            try:
+                rec_path = os.path.join(ROOT, "profiles", "r05_bench_c3_cpu_full_size.json")
+                with open(rec_path) as f:
+                    rec = json.loads(f.readline())
+                rc, fs = rec["config"], rec["cpu_baseline"]["full_size_run"]
+                if (rc["n_global"], rc["ncon"], rc["nwcon"], rc["qn"]) == (n, ncon, nwcon, qn) and fs and "seconds" in fs:
+                    res["full_size_on_record"] = {
+                        "file": "profiles/r05_bench_c3_cpu_full_size.json", "n": fs["n"], "cores": rec["cpu_baseline"]["cores"],
+                        "steady_state_it_per_s": fs["steady_state_it_per_s"], "whole_run_it_per_s": fs["whole_run_it_per_s"],
+                        "scaled_sample_of_that_run_it_per_s": rec["cpu_baseline"]["steady_state_it_per_s"],
+                        "note": "ONE run of the unmodified reference at the workload's own n on a builder box (K = 18): the "
+                                "rate scaled linearly from the n / 4 sample of the same box was 2.1 x higher -- the host's "
+                                "memory system does not scale linearly to 45 GB of vectors; `value` above is the scaled "
+                                "sample of THIS box and overestimates the CPU by about that factor"}
+            except Exception:
+                pass
             if (cpus.get("loadavg_1min") or 0.0) > 0.75 * ranks:
                 res["note"] = ("the host's 1-minute load average (%.1f) was already at the level of the %d granted cores "
                                "before the ranks started: other jobs share the cores' memory system, compare "

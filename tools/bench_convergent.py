@@ -41,9 +41,12 @@ def gpu_run(n, ncon, qn_size, tol, max_iters, repeats):
         dt = time.perf_counter() - t0
         red1, lau1 = ctx.counters()
         niter, neval, ngeval = ip.getIterationCounters()
-        last = [ln for ln in ip.getHistory().splitlines() if ln[:5].strip().isdigit()][-1].split()
+        hist = ip.getHistory()
+        last = [ln for ln in hist.splitlines() if ln[:5].strip().isdigit()][-1].split()
+        msgs = [ln.strip() for ln in hist.splitlines() if ln.startswith("ParOpt")]
         runs.append({"seconds": dt, "niter": niter, "neval": neval, "ngeval": ngeval, "fobj": ip.getObjective()[0],
-                     "converged": "Successfully converged" in ip.getHistory(),
+                     "converged": "Successfully converged" in hist,
+                     "termination": msgs[-1] if msgs else ("max_major_iters reached" if niter >= max_iters else ""),
                      "final_opt_infeas_dual": [float(last[8]), float(last[9]), float(last[10])],
                      "mu": ip.getBarrierParameter(), "host_syncs": red1 - red0, "launches": lau1 - lau0,
                      "algorithmic_GB": (ctx.algorithmic_bytes()[0] - by0) * 1e-9})
@@ -91,7 +94,7 @@ def main():
     ap.add_argument("--ncon", type=int, default=32)
     ap.add_argument("--qn-size", type=int, default=20)
     ap.add_argument("--tol", type=float, default=1e-6)
-    ap.add_argument("--max-iters", type=int, default=1000)
+    ap.add_argument("--max-iters", type=int, default=6000)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--cpu-n", type=int, default=5_000_000)
     ap.add_argument("--cpu-budget", type=float, default=900.0)
