@@ -859,9 +859,11 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     ntiles = gg.ngt + (n - gg.rg + kGramTile - 1) / kGramTile;
     for (int j = 0; j < gg.ncols; j++) ut.p[j] = groups->U[j];
     count_bytes(c, (double)gg.ncols, gg.nwcon);
-    // round 5: the sums on the PRODUCER waves (GS = 2) where every (column, group) pair of a tile finds a producer
-    // lane; PAROPT_AMD_GS_PRODUCER=0 puts them back on the consumers (A/B, same bits)
-    const bool gs_prod = gg.G * gg.ncols <= 256 && dbg_switch(SW_GS_PRODUCER, "PAROPT_AMD_GS_PRODUCER", 1) != 0;
+    // round 5 experiment, OFF by default: the sums on the PRODUCER waves (GS = 2: same bits; all 621 GPU tests pass with
+    // it).  Measured in one process at config 4 (tools/ab_switch.py, profiles/r05_ab_gs_producer.jsonl): 5.93 against
+    // 5.52 ms per iteration, the Gram phase 1.76 against 1.46 ms -- the producers' staging + load issue + 40 operand
+    // requests is the longer path of a tile, not the consumers' matrix work + sums.  PAROPT_AMD_GS_PRODUCER=1 selects it.
+    const bool gs_prod = gg.G * gg.ncols <= 256 && dbg_switch(SW_GS_PRODUCER, "PAROPT_AMD_GS_PRODUCER", 0) != 0;
 #define PO_WGG(NGv)                                                                                                  \
   case NGv:                                                                                                          \
     if (NGv >= kGramRowSplitMinNG && row_split && gs_prod)                                                           \
