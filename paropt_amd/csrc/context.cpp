@@ -103,9 +103,12 @@ static RcclApi g_rccl;
 
 static int load_rccl() {
   if (g_rccl.handle) return PO_OK;
-  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // PAROPT_AMD_RCCL_LIB names the library file explicitly (a C++ program that does not run under torch's loader
+  // finds RCCL on the default search path or under /opt/rocm/lib only)
+  const char *names[] = {getenv("PAROPT_AMD_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void *h = nullptr;
   for (const char *nm : names) {
+    if (!nm || !*nm) continue;
     h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (h) break;
   }

@@ -289,9 +289,16 @@ int CallbackSubproblem::syncLinearModel() {
     return PO_ERR_USER;
   }
   dropModel();
+  // The user's vectors may carry LIVE host mirrors (filled through getArray pointers, e.g. by the original problem's
+  // host-array callbacks): the kernels below read the device arrays directly, so what the host wrote is uploaded here,
+  // as po_vec_release_array(v, 1) would (src/ParOptVec.cpp:212-217: the pointer is the data).
+  int up_rc = PO_OK;
   auto take = [&](po_vec h) -> Vec * {
     Vec *v = h;
     v->ref++;
+    if (v->h_live && v->h && v->n > 0 &&
+        hipMemcpyAsync(v->d, v->h, sizeof(double) * (size_t)v->n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      up_rc = PO_ERR_HIP;
     return v;
   };
   xk = take(hx);
@@ -308,6 +315,11 @@ int CallbackSubproblem::syncLinearModel() {
     Ak.push_back(take(A[i]));
   }
   zts_valid = false;
+  if (up_rc != PO_OK) {
+    set_error("trust-region subproblem: uploading a live host mirror of the linear model failed");
+    return up_rc;
+  }
+  PO_HIP(hipStreamSynchronize(ctx->stream));  // the pinned mirrors may be rewritten by the user at once
   return PO_OK;
 }
 CompactQuasiNewton *CallbackSubproblem::getQuasiNewton() {
