@@ -210,6 +210,42 @@ int InteriorPoint::evalObjBarrierDeriv(const Dense &p, double *pmerit_) {
   return PO_OK;
 }
 
+// The small least-squares problem of the Krylov step, on the host: the upper Hessenberg matrix of the Arnoldi
+// relation as full columns (entry (r, col), r <= col + 1), reduced to triangular form column by column with plane
+// rotations that are also applied to the right-hand side; solve() back-substitutes the leading block.
+struct KrylovLeastSquares {
+  int ld;
+  std::vector<double> hcol, rot_c, rot_s, rhs;
+  explicit KrylovLeastSquares(int msub)
+      : ld(msub + 1), hcol((size_t)(msub + 1) * msub, 0.0), rot_c(msub, 0.0), rot_s(msub, 0.0), rhs(msub + 1, 0.0) {}
+  double &h(int r, int col) { return hcol[(size_t)col * ld + r]; }
+  // column `col` is complete (rows 0 .. col + 1): apply the earlier rotations, make and apply its own
+  void closeColumn(int col) {
+    for (int r = 0; r < col; r++) {
+      const double a = h(r, col), b = h(r + 1, col);
+      h(r, col) = a * rot_c[r] + b * rot_s[r];
+      h(r + 1, col) = -a * rot_s[r] + b * rot_c[r];
+    }
+    const double a = h(col, col), b = h(col + 1, col);
+    const double len = sqrt(a * a + b * b);
+    rot_c[col] = a / len;
+    rot_s[col] = b / len;
+    h(col, col) = a * rot_c[col] + b * rot_s[col];
+    h(col + 1, col) = -a * rot_s[col] + b * rot_c[col];
+    const double g = rhs[col];
+    rhs[col] = g * rot_c[col];
+    rhs[col + 1] = -g * rot_s[col];
+  }
+  // out[0..k) = R^-1 rhs[0..k) for the leading k columns (out may be rhs itself)
+  void solve(int k, double *out) {
+    for (int r = k - 1; r >= 0; r--) {
+      double v = rhs[r];
+      for (int col = r + 1; col < k; col++) v = v - h(r, col) * out[col];
+      out[r] = v / h(r, r);
+    }
+  }
+};
+
 int InteriorPoint::computeKKTGMRESStep(double rtol, double atol, bool use_qn, double tau, int *gmres_iters) {
   const int msub = options.integer("gmres_subspace_size");
   *gmres_iters = 0;
@@ -226,8 +262,9 @@ int InteriorPoint::computeKKTGMRESStep(double rtol, double atol, bool use_qn, do
   const double mu = barrier_param;
   if (has_w) PO_TRY(computeResidualW(mu));
   denseResidual(mu, res);
-  std::vector<double> H((size_t)(msub + 1) * (msub + 2) / 2, 0.0), alpha(msub + 1, 0.0), gres(msub + 1, 0.0),
-      y(msub, 0.0), fproj(msub, 0.0), aproj(msub, 0.0), Qcos(msub, 0.0), Qsin(msub, 0.0);
+  KrylovLeastSquares ls(msub);
+  std::vector<double> &gres = ls.rhs;
+  std::vector<double> alpha(msub + 1, 0.0), y(msub, 0.0), fproj(msub, 0.0), aproj(msub, 0.0);
   // |b|: the x block from the residual pass, the bound blocks from its sums, the dense blocks here
   double beta = 0.0;
   for (int i = 0; i < c; i++) {
@@ -294,43 +331,23 @@ int InteriorPoint::computeKKTGMRESStep(double rtol, double atol, bool use_qn, do
       PO_TRY(k_panel_axpy(ctx, Wk[i + 1]->d, 1.0, Wk[i]->d, 1.0, cf.data(), V.data(), (int)V.size(), n));
     }
     alpha[i + 1] = alpha[i];
-    const int hptr = (i + 1) * (i + 2) / 2 - 1;
-    for (int j = i; j >= 0; j--) {  // modified Gram-Schmidt, as the reference (:5986-5996)
+    for (int j = i; j >= 0; j--) {  // modified Gram-Schmidt against the basis, newest vector first (as :5986-5996)
       double d = 0.0;
       PO_TRY(k_reduce1(ctx, RED_DOT, Wk[i + 1]->d, Wk[j]->d, n, &d));
-      H[j + hptr] = d + beta * alpha[i + 1] * alpha[j];
-      PO_TRY(k_axpy(ctx, Wk[i + 1]->d, -H[j + hptr], Wk[j]->d, n));
-      alpha[i + 1] -= H[j + hptr] * alpha[j];
+      const double hj = d + beta * alpha[i + 1] * alpha[j];
+      ls.h(j, i) = hj;
+      PO_TRY(k_axpy(ctx, Wk[i + 1]->d, -hj, Wk[j]->d, n));
+      alpha[i + 1] -= hj * alpha[j];
     }
     double nrm2 = 0.0;
     PO_TRY(k_reduce1(ctx, RED_SUMSQ, Wk[i + 1]->d, nullptr, n, &nrm2));
-    H[i + 1 + hptr] = sqrt(nrm2 + beta * alpha[i + 1] * alpha[i + 1]);
-    PO_TRY(k_scale(ctx, Wk[i + 1]->d, n, 1.0 / H[i + 1 + hptr]));
-    alpha[i + 1] *= 1.0 / H[i + 1 + hptr];
-    for (int kk = 0; kk < i; kk++) {
-      const double h1 = H[kk + hptr], h2 = H[kk + 1 + hptr];
-      H[kk + hptr] = h1 * Qcos[kk] + h2 * Qsin[kk];
-      H[kk + 1 + hptr] = -h1 * Qsin[kk] + h2 * Qcos[kk];
-    }
-    double h1 = H[i + hptr], h2 = H[i + 1 + hptr];
-    const double sq = sqrt(h1 * h1 + h2 * h2);
-    Qcos[i] = h1 / sq;
-    Qsin[i] = h2 / sq;
-    H[i + hptr] = h1 * Qcos[i] + h2 * Qsin[i];
-    H[i + 1 + hptr] = -h1 * Qsin[i] + h2 * Qcos[i];
-    h1 = gres[i];
-    gres[i] = h1 * Qcos[i];
-    gres[i + 1] = -h1 * Qsin[i];
+    const double hlast = sqrt(nrm2 + beta * alpha[i + 1] * alpha[i + 1]);
+    ls.h(i + 1, i) = hlast;
+    PO_TRY(k_scale(ctx, Wk[i + 1]->d, n, 1.0 / hlast));
+    alpha[i + 1] *= 1.0 / hlast;
+    ls.closeColumn(i);
     niters++;
-    for (int j = niters - 1; j >= 0; j--) {
-      y[j] = gres[j];
-      for (int kk = j + 1; kk < niters; kk++) {
-        const int hp = (kk + 1) * (kk + 2) / 2 - 1;
-        y[j] = y[j] - H[j + hp] * y[kk];
-      }
-      const int hp = (j + 1) * (j + 2) / 2 - 1;
-      y[j] = y[j] / H[j + hp];
-    }
+    ls.solve(niters, y.data());  // the current solution's coefficients (the rotated right-hand side is left alone)
     double fpr = 0.0, cpr = 0.0;
     for (int j = 0; j < niters; j++) {
       fpr += y[j] * fproj[j];
@@ -341,14 +358,7 @@ int InteriorPoint::computeKKTGMRESStep(double rtol, double atol, bool use_qn, do
       if (fabs(gres[i + 1]) < atol || fabs(gres[i + 1]) < rtol * bnorm) break;
     }
   }
-  for (int i = niters - 1; i >= 0; i--) {
-    for (int j = i + 1; j < niters; j++) {
-      const int hp = (j + 1) * (j + 2) / 2 - 1;
-      gres[i] = gres[i] - H[i + hp] * gres[j];
-    }
-    const int hp = (i + 1) * (i + 2) / 2 - 1;
-    gres[i] = gres[i] / H[i + hp];
-  }
+  ls.solve(niters, gres.data());
   // u_x = sum gres_i W_i ; gamma scales every other block of the right-hand side
   double gamma = gres[0] * alpha[0];
   {
