@@ -204,6 +204,47 @@ int main(int argc, char *argv[]) {
   ParOptOptimizer *optimizer = NULL;
   ParOptInteriorPoint *ip = NULL;
   ParOptTrustRegion *tr = NULL;
+  if (driver == "infeas") {
+    // ParOptInfeasSubproblem (src/ParOptTrustRegion.h:293-374) built by hand over the user-written subproblem and over
+    // the library's ParOptQuadraticSubproblem on the same problem: the steering LP of the first trust-region iteration
+    // (linear objective scaled by 0.5, linearised constraints, sequential linear method), one solve each
+    ParOptQuadraticSubproblem *libsub = new ParOptQuadraticSubproblem(problem, qn);
+    libsub->incref();
+    ParOptTrustRegionSubproblem *subs[2] = {subproblem, libsub};
+    options->setOption("sequential_linear_method", 1);
+    options->setOption("use_line_search", 0);
+    for (int k = 0; k < 2; k++) {
+      subs[k]->initModelAndBounds(options->getFloatOption("tr_init_size"));
+      ParOptInfeasSubproblem *infeas = new ParOptInfeasSubproblem(
+          subs[k], ParOptInfeasSubproblem::PAROPT_LINEAR_OBJECTIVE, ParOptInfeasSubproblem::PAROPT_LINEAR_CONSTRAINT);
+      infeas->incref();
+      infeas->setObjectiveScaling(0.5);
+      ParOptInteriorPoint *solver = new ParOptInteriorPoint(infeas, options);
+      solver->incref();
+      solver->optimize();
+      ParOptVec *step = NULL;
+      ParOptScalar *z = NULL;
+      solver->getOptimizedPoint(&step, &z, NULL, NULL, NULL);
+      ParOptScalar f = 0.0;
+      std::vector<ParOptScalar> con(m > 0 ? m : 1, 0.0);
+      infeas->evalObjCon(step, &f, con.data());
+      printf("infeas %s: fobj %.15e |step| %.15e maxabs %.15e z", k == 0 ? "user" : "library", f, step->norm(),
+             step->maxabs());
+      for (int i = 0; i < m; i++) printf(" %.15e", z[i]);
+      printf(" con");
+      for (int i = 0; i < m; i++) printf(" %.15e", con[i]);
+      printf("\n");
+      solver->decref();
+      infeas->decref();
+    }
+    libsub->decref();
+    subproblem->decref();
+    qn->decref();
+    options->decref();
+    problem->decref();
+    po_ctx_destroy(ctx);
+    return 0;
+  }
   if (driver == "optimizer") {
     optimizer = new ParOptOptimizer(problem, options);
     optimizer->incref();

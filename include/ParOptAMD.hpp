@@ -1351,6 +1351,58 @@ class ParOptEigenSubproblem : public ParOptLibrarySubproblem {
   void (*updateEigenModel)(void *, ParOptVec *, ParOptCompactEigenApprox *);
 };
 
+// ParOptInfeasSubproblem (src/ParOptTrustRegion.h:293-374, .cpp:468-650): the steering problem of the trust-region
+// driver as a ParOptProblem of its own -- works over any subproblem (the two library ones and user-written subclasses)
+class ParOptInfeasSubproblem : public ParOptProblem {
+ public:
+  static const int PAROPT_SUBPROBLEM_OBJECTIVE = 1;
+  static const int PAROPT_LINEAR_OBJECTIVE = 2;
+  static const int PAROPT_CONSTANT_OBJECTIVE = 3;
+  static const int PAROPT_SUBPROBLEM_CONSTRAINT = 1;
+  static const int PAROPT_LINEAR_CONSTRAINT = 2;
+
+  ParOptInfeasSubproblem(ParOptTrustRegionSubproblem *_prob, int subproblem_objective, int subproblem_constraint)
+      : ParOptProblem(_prob->getMPIComm()), prob(_prob), infeas(NULL) {
+    prob->incref();
+    int nv = 0, nc = 0, nwc = 0, nineq = 0, nwineq = 0;
+    prob->getProblemSizes(&nv, &nc, &nwc);
+    prob->getNumInequalities(&nineq, &nwineq);
+    setProblemSizes(nv, nc, nwc);
+    setNumInequalities(nineq, nwineq);
+    if (!prob->subHandle() ||
+        po_infeas_create(prob->subHandle(), subproblem_objective, subproblem_constraint, &infeas) != 0)
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  ~ParOptInfeasSubproblem() {
+    if (infeas) po_problem_destroy(infeas);
+    prob->decref();
+  }
+  void setObjectiveScaling(ParOptScalar _scale) {
+    if (infeas) po_infeas_set_objective_scaling(infeas, _scale);
+  }
+  po_problem handle() { return infeas; }
+  ParOptQuasiDefMat *createQuasiDefMat() { return prob->createQuasiDefMat(); }
+  int isSparseInequality() { return prob->isSparseInequality(); }
+  int useLowerBounds() { return 1; }
+  int useUpperBounds() { return 1; }
+  void getVarsAndBounds(ParOptVec *x, ParOptVec *lb, ParOptVec *ub) {
+    if (po_problem_get_vars_and_bounds(infeas, x->handle(), lb->handle(), ub->handle()) != 0)
+      fprintf(stderr, "ParOptAMD: %s\n", po_last_error());
+  }
+  int evalObjCon(ParOptVec *x, ParOptScalar *fobj, ParOptScalar *cons) {
+    return po_problem_eval_obj_con(infeas, x->handle(), fobj, cons) != 0;
+  }
+  int evalObjConGradient(ParOptVec *x, ParOptVec *g, ParOptVec **Ac) {
+    std::vector<po_vec> hs(ncon > 0 ? ncon : 1, (po_vec)NULL);
+    for (int i = 0; Ac && i < ncon; i++) hs[i] = Ac[i]->handle();
+    return po_problem_eval_obj_con_gradient(infeas, x->handle(), g->handle(), Ac ? hs.data() : NULL) != 0;
+  }
+
+ private:
+  ParOptTrustRegionSubproblem *prob;
+  po_problem infeas;
+};
+
 // ParOptTrustRegion (src/ParOptTrustRegion.h:376-480): SL1QP with the adaptive penalty update, or the filter method
 class ParOptTrustRegion : public ParOptBase {
  public:

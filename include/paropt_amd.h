@@ -628,6 +628,18 @@ typedef struct po_trsub_callbacks {
   int sparse_constraints_are_model;
 } po_trsub_callbacks;
 int po_trsub_create_callbacks(po_problem prob, const po_trsub_callbacks *callbacks, po_trsub *out);
+/* ParOptInfeasSubproblem(subproblem, subproblem_objective, subproblem_constraint) (src/ParOptTrustRegion.h:293-374,
+ * .cpp:468-650): the problem the trust-region driver's steering step (minimizeInfeas, .cpp:1105-1228) hands to the
+ * interior point, as a po_problem of its own.  The selectors are the reference's constants: objective 1 = the
+ * subproblem's model, 2 = the linear model fk + gk^T p, 3 = the constant fk; constraint 1 = the subproblem's model,
+ * 2 = the linearisation ck + Ak p.  Bounds, sizes and sparse constraints are the subproblem's.  `sub` is borrowed and
+ * must outlive the result; destroy with po_problem_destroy. */
+/* a user-written subproblem (po_trsub_create_callbacks) lends its model vectors to the library, which re-reads
+ * getLinearModel at initModelAndBounds / acceptTrialStep; call this after changing the model OUTSIDE the trust-region
+ * driver (no-op for the library's own subproblems).  po_infeas_create does it once itself. */
+int po_trsub_sync_linear_model(po_trsub sub);
+int po_infeas_create(po_trsub sub, int subproblem_objective, int subproblem_constraint, po_problem *out);
+int po_infeas_set_objective_scaling(po_problem infeas, double scale);             /* setObjectiveScaling .h:309 */
 /* ParOptTrustRegion(subproblem, options) and optimize(ip) (src/ParOptTrustRegion.cpp:660-718, 2365-2384).  `ip` must
  * have been created on po_trsub_problem(sub).  Options set on `tr` that the interior-point registry lacks (tr_*,
  * filter_*) are carried into the solver's registry at the call: one registry serves both, as the reference's shared

@@ -16,6 +16,7 @@ from .api import (  # noqa: F401
     QuadraticSubproblem,
     UserTrustRegionSubproblem,
     EigenSubproblem,
+    InfeasSubproblem,
     EigenQuasiNewton,
     CompactEigenApprox,
     EigenApprox,

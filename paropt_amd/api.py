@@ -1179,6 +1179,20 @@ class TrustRegionSubproblem:
         check(lib.po_trsub_get_quasi_newton_update_type(self._h, C.byref(t)))
         return t.value
 
+    # the ParOptProblem side (the model in the step), as the interior point sees it
+    def getVarsAndBounds(self, step, lower, upper):
+        check(lib.po_problem_get_vars_and_bounds(self.handle, step.handle, lower.handle, upper.handle))
+
+    def evalObjCon(self, step):
+        f = C.c_double()
+        con = np.zeros(max(self.ncon, 1))
+        rc = lib.po_problem_eval_obj_con(self.handle, step.handle, C.byref(f), con.ctypes.data_as(L.c_double_p))
+        return rc, f.value, con[: self.ncon]
+
+    def evalObjConGradient(self, step, g, A):
+        hs = (L.po_vec * max(1, self.ncon))(*[a.handle for a in A])
+        return lib.po_problem_eval_obj_con_gradient(self.handle, step.handle, g.handle, hs)
+
     def getLinearModel(self):
         """(xk, fk, gk, ck, Ak, lb, ub) of the current model (borrowed vectors)."""
         xk, gk, lb, ub, Ak = L.po_vec(), L.po_vec(), L.po_vec(), L.po_vec(), L.vec_p()
@@ -1357,6 +1371,54 @@ class EigenSubproblem(TrustRegionSubproblem):
         fn = L.EIG_UPDATE_FN(_cb)
         self._keep.append(fn)
         check(lib.po_trsub_set_eigen_model_update(self._h, fn, None))
+
+
+class InfeasSubproblem:
+    """ParOptInfeasSubproblem(subproblem, subproblem_objective, subproblem_constraint) (reference
+    src/ParOptTrustRegion.h:293-374, .cpp:468-650): the problem of the trust-region driver's steering step as a problem
+    of its own -- ``InteriorPoint(InfeasSubproblem(sub, LINEAR_OBJECTIVE, LINEAR_CONSTRAINT), options)``.  The selector
+    constants are the reference's."""
+
+    SUBPROBLEM_OBJECTIVE, LINEAR_OBJECTIVE, CONSTANT_OBJECTIVE = 1, 2, 3
+    SUBPROBLEM_CONSTRAINT, LINEAR_CONSTRAINT = 1, 2
+
+    def __init__(self, subproblem, subproblem_objective, subproblem_constraint):
+        self.subproblem = subproblem  # borrowed by the library object: kept alive here
+        self.ctx = subproblem.ctx
+        self.nvars, self.ncon, self.nwcon = subproblem.nvars, subproblem.ncon, subproblem.nwcon
+        self._h = L.po_problem()
+        check(lib.po_infeas_create(subproblem._h, int(subproblem_objective), int(subproblem_constraint),
+                                   C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib.po_problem_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _raise_pending(self):
+        self.subproblem._raise_pending()
+
+    def setObjectiveScaling(self, scale):
+        check(lib.po_infeas_set_objective_scaling(self._h, float(scale)))
+
+    def getVarsAndBounds(self, x, lb, ub):
+        check(lib.po_problem_get_vars_and_bounds(self._h, x.handle, lb.handle, ub.handle))
+
+    def evalObjCon(self, x):
+        f = C.c_double()
+        con = np.zeros(max(self.ncon, 1))
+        rc = lib.po_problem_eval_obj_con(self._h, x.handle, C.byref(f), con.ctypes.data_as(L.c_double_p))
+        return rc, f.value, con[: self.ncon]
+
+    def evalObjConGradient(self, x, g, A):
+        hs = (L.po_vec * max(1, self.ncon))(*[a.handle for a in A])
+        return lib.po_problem_eval_obj_con_gradient(self._h, x.handle, g.handle, hs)
 
 
 class TrustRegion:

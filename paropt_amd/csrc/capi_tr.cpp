@@ -432,6 +432,43 @@ int po_trsub_problem(po_trsub sub, po_problem *out) {
   *out = &sub->face;
   return PO_OK;
 }
+int po_trsub_sync_linear_model(po_trsub sub) {
+  PO_CHECK_PTR(sub);
+  CallbackSubproblem *cs = dynamic_cast<CallbackSubproblem *>(sub->sub);
+  return cs ? cs->syncLinearModel() : PO_OK;
+}
+int po_infeas_create(po_trsub sub, int subproblem_objective, int subproblem_constraint, po_problem *out) {
+  PO_CHECK_PTR(sub);
+  PO_CHECK_PTR(out);
+  // the reference's selectors (src/ParOptTrustRegion.h:296-302) -> the library's
+  int obj = -1, con = -1;
+  if (subproblem_objective == 1) obj = InfeasSubproblem::SUBPROBLEM_OBJECTIVE;
+  if (subproblem_objective == 2) obj = InfeasSubproblem::LINEAR_OBJECTIVE;
+  if (subproblem_objective == 3) obj = InfeasSubproblem::CONSTANT_OBJECTIVE;
+  if (subproblem_constraint == 1) con = InfeasSubproblem::SUBPROBLEM_CONSTRAINT;
+  if (subproblem_constraint == 2) con = InfeasSubproblem::LINEAR_CONSTRAINT;
+  if (obj < 0 || con < 0) {
+    po::set_error("ParOptInfeasSubproblem: objective selector %d (1 subproblem, 2 linear, 3 constant) / constraint "
+                  "selector %d (1 subproblem, 2 linear)", subproblem_objective, subproblem_constraint);
+    return PO_ERR_ARG;
+  }
+  // (a user-written subproblem lends its model vectors: taken as they are now)
+  if (CallbackSubproblem *cs = dynamic_cast<CallbackSubproblem *>(sub->sub)) PO_TRY(cs->syncLinearModel());
+  po_problem_s *h = new po_problem_s();
+  h->p = new InfeasSubproblem(sub->sub, obj, con);
+  *out = h;
+  return PO_OK;
+}
+int po_infeas_set_objective_scaling(po_problem infeas, double scale) {
+  PO_CHECK_PTR(infeas);
+  InfeasSubproblem *p = dynamic_cast<InfeasSubproblem *>(infeas->p);
+  if (!p) {
+    po::set_error("setObjectiveScaling: not a ParOptInfeasSubproblem");
+    return PO_ERR_ARG;
+  }
+  p->obj_scale = scale;
+  return PO_OK;
+}
 int po_trsub_get_quasi_newton(po_trsub sub, po_qn *qn) {
   PO_CHECK_PTR(sub);
   PO_CHECK_PTR(qn);

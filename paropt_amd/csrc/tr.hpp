@@ -220,8 +220,11 @@ class CallbackSubproblem : public TrustRegionSubproblem {
   }
   po_trsub_callbacks cb;
 
- private:
+  // re-reads getLinearModel (called by the driver's own entry points; po_trsub_sync_linear_model for a model the
+  // user changed outside the driver)
   int syncLinearModel();
+
+ private:
   void dropModel();
 };
 

@@ -78,12 +78,12 @@ struct GramPlanHolder {
 };
 
 // operands of one 16-row step: a[g] = P[row][4 g + (lane & 3)] for every column group, w = the row weight
-template <int NG>
+template <int NG, int LD = kGramLd>
 __device__ __forceinline__ void gram_fetch(const double *__restrict__ base, const double *__restrict__ dwl, int s,
                                            double (&a)[NG], double &w) {
   w = dwl[16 * s];
 #pragma unroll
-  for (int g = 0; g < NG; g++) a[g] = base[(4 * g) * kGramLd + 16 * s];
+  for (int g = 0; g < NG; g++) a[g] = base[(4 * g) * LD + 16 * s];
 }
 
 template <int NG, int W>
@@ -105,22 +105,22 @@ __device__ __forceinline__ void gram_step(const double (&a)[NG], double w, bool 
   }
 }
 
-template <int NG, int W>
+template <int NG, int W, int TR = kGramTile, int LD = kGramLd>
 __device__ __forceinline__ void gram_tile(const double *__restrict__ pt, const double *__restrict__ dw, int lane,
                                           int tcol, double (&acc)[GramPlanHolder<NG>::NQ]) {
   const int ci = lane & 3;                                 // column within the group
   const int rowoff = ((lane >> 2) & 3) + 4 * (lane >> 4);  // row within the 16-row step: b + 4 k
-  const double *base = pt + ci * kGramLd + rowoff;
+  const double *base = pt + ci * LD + rowoff;
   const double *dwl = dw + rowoff;
   const bool tsel = (4 * (NG - 1) + ci == tcol);
   // the operand fetch of step s + 1 is issued before the matrix instructions of step s
   double a0[NG], a1[NG], w0, w1;
-  gram_fetch<NG>(base, dwl, 0, a0, w0);
+  gram_fetch<NG, LD>(base, dwl, 0, a0, w0);
 #pragma unroll 1
-  for (int s = 0; s < kGramTile / 16; s += 2) {
-    gram_fetch<NG>(base, dwl, s + 1, a1, w1);
+  for (int s = 0; s < TR / 16; s += 2) {
+    gram_fetch<NG, LD>(base, dwl, s + 1, a1, w1);
     gram_step<NG, W>(a0, w0, tsel, acc);
-    if (s + 2 < kGramTile / 16) gram_fetch<NG>(base, dwl, s + 2, a0, w0);
+    if (s + 2 < TR / 16) gram_fetch<NG, LD>(base, dwl, s + 2, a0, w0);
     gram_step<NG, W>(a1, w1, tsel, acc);
   }
 }
@@ -437,15 +437,17 @@ __device__ __forceinline__ void gram_pc_load(GramProducer<NG, ZP> &P, const doub
                                              const double *const (&scol)[ZP > 0 ? ZP : 1], const double *d,
                                              int64_t tile, int64_t ntiles, int64_t n, int64_t ilast, int lane,
                                              const GramGeom &gg) {
-  if (tile >= ntiles) {
-    P.in[R] = false;
-    return;
-  }
+  // BRANCH-FREE on purpose (round 5): a tile past the end re-requests the workgroup's last lines and is staged as
+  // zeros.  With the loads under `if (tile < ntiles)` hipcc's wait-count bookkeeping merged "issued" and "not issued"
+  // at the join and from then on took every load still in flight for kGramDepth-1 tiles YOUNGER than it is: the
+  // staging of tile t waited with vmcnt(NG) instead of vmcnt(NG + 2 (NG + 1)), i.e. for the loads of tiles t + 1 and
+  // t + 2 as well -- the three-tile prefetch ran one tile deep (profiles/r05_wgram_vmcnt.txt).
+  const bool live = tile < ntiles;
   int64_t row0;
   int nrows;
-  gram_tile_geom(gg, tile, row0, nrows);
+  gram_tile_geom(gg, live ? tile : ntiles - 1, row0, nrows);
   int64_t i = row0 + 2 * lane;
-  const bool in = (2 * lane < nrows) && (i < n);
+  const bool in = live && (2 * lane < nrows) && (i < n);
   // (lanes outside the tile: any in-range pair will do, its value is not used -- with group tiles one of THIS tile's,
   // whose lines the instruction requests anyway)
   int64_t alt = row0 + 2 * (lane & 3);
@@ -579,16 +581,16 @@ __global__ void __launch_bounds__(512, 1)
     const int64_t _idx = _mine ? _g0 + g2_gi : gg.nwcon;                                                      \
     g2_up[_idx] = _mine ? _sum : 0.0;                                                                         \
   }
+    // (no condition around a step's loads -- see gram_pc_load -- and none around the steps of the main loop: whole
+    // rounds of kGramDepth steps run unconditionally, the last nt % kGramDepth steps behind them)
 #define PO_PC_STEP(R)                                                                                         \
-  if (it + (R) < nt) {                                                                                        \
+  {                                                                                                           \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
     if constexpr (GS == 2) PO_GS2_REQUEST(lds + (size_t)((it + (R) + 1) & 1) * kBufDoubles);                  \
     const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
-    else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
-    if (stamp) __builtin_amdgcn_s_waitcnt(0);                                                                 \
+    gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);                       \
     const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
+    gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
     const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if constexpr (GS == 2) PO_GS2_FINISH(it + (R) - 1);                                                       \
     __syncthreads();                                                                                          \
@@ -599,11 +601,14 @@ __global__ void __launch_bounds__(512, 1)
       st_wait += _t3 - _t2;                                                                                   \
     }                                                                                                         \
   }
-    for (int64_t it = 0; it < nt; it += kGramDepth) {
+    int64_t it = 0;
+    for (; it + kGramDepth <= nt; it += kGramDepth) {
       PO_PC_STEP(0)
       PO_PC_STEP(1)
       PO_PC_STEP(2)
     }
+    if (it < nt) PO_PC_STEP(0)
+    if (it + 1 < nt) PO_PC_STEP(1)
 #undef PO_PC_STEP
     if constexpr (GS == 2) {
       // the sums of the last tile (staged and published by the last step's barrier; the consumers overwrite the tile
@@ -725,6 +730,154 @@ __global__ void __launch_bounds__(512, 1)
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Producer / consumer form for WIDE panels (17-20 column groups = 65-80 columns, e.g. c = 32 constraints + an
+// L-BFGS(20) memory + the pre-weighted column: 73), round 5.  Two 128-row tile buffers of 80 columns do not fit the
+// 160 KB of LDS, so these panels ran the single-role kernel with ONE wavefront per SIMD (0.34 of the HBM peak: load
+// wait, staging and matrix work in series).  Here the tile is 64 rows (row stride 72 doubles == 8 mod 32, the same
+// banking as 136), two buffers = 93 KB at 80 columns.  A producer wavefront loads TWO columns per instruction (lanes
+// 0-31 the 32 row pairs of column j, lanes 32-63 those of column j + 4) and keeps three or four tiles in flight; the
+// consumers split the OUTPUT (column groups dealt to the four wavefronts, as in the single-role kernel), four 16-row
+// steps per tile.  Same slot layout of the partial sums; the summation order differs from the single-role form's
+// (64- instead of 128-row tiles), which only panels of this width ever see.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kG64Tile = 64;
+constexpr int kG64Ld = kG64Tile + 8;
+
+template <int NG, int W>
+__device__ __forceinline__ void gram64_consume(const double *__restrict__ lds, int64_t nt,
+                                               double *__restrict__ partials, int tcol, int lane) {
+  constexpr int M = 4 * NG;
+  constexpr int NQ = GramPlanHolder<NG>::NQ;
+  constexpr int kBufDoubles = M * kG64Ld + kG64Tile;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+  for (int64_t it = 0; it < nt; it++) {
+    __syncthreads();  // tile `it` is staged in buffer it % 2
+    const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
+    gram_tile<NG, W, kG64Tile, kG64Ld>(bt, bt + M * kG64Ld, lane, tcol, acc);
+  }
+  __syncthreads();
+  gram_store<NG, W>(acc, lane, partials);
+}
+
+template <int NH, int D>
+struct Gram64Producer {
+  f64x2 buf[D][NH];
+  f64x2 dbuf[D];
+  bool in[D];
+};
+
+template <int NG>
+__global__ void __launch_bounds__(512, 1)
+    wgram_pc64_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
+                      double *__restrict__ partials, int tcol, int prio) {
+  constexpr int M = 4 * NG;
+  constexpr int NH = (NG + 1) / 2;      // loads per producer wavefront and tile (two columns each)
+  constexpr int D = 4;                  // tiles a producer keeps in flight (registers: 4 (NH + 1) per tile and lane)
+  constexpr int kBufDoubles = M * kG64Ld + kG64Tile;
+  extern __shared__ double lds[];  // two tile buffers
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int b2 = 0; b2 < 2; b2++)
+    for (int idx = tid; idx < (M - nv) * kG64Ld; idx += 512) lds[b2 * kBufDoubles + nv * kG64Ld + idx] = 0.0;
+  const int64_t first = blockIdx.x, stride = gridDim.x;
+  const int64_t nt = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  __syncthreads();
+  if (wave >= 4) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    const int pw = wave - 4, half = lane >> 5, rp = lane & 31;
+    const int j0 = pw + 4 * half;  // this lane's column of load h: j0 + 8 h
+    const double *colp[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) colp[h] = V.p[j0 + 8 * h < nv ? j0 + 8 * h : nv - 1];
+    const int64_t ilast = ((n - 1) >> 1) << 1;
+    Gram64Producer<NH, D> P;
+    // (loads unconditional, steps of the main loop unconditional: see gram_pc_load)
+#define PO_G64_LOAD(R, TILE)                                                             \
+  {                                                                                      \
+    const int64_t _t = (TILE);                                                           \
+    int64_t _i = _t * kG64Tile + 2 * rp;                                                 \
+    const bool _in = _t < ntiles && _i < n;                                              \
+    if (!_in) _i = ilast;                                                                \
+    P.in[R] = _in;                                                                       \
+    _Pragma("unroll") for (int h = 0; h < NH; h++) P.buf[R][h] = ld_nt(colp[h] + _i);    \
+    P.dbuf[R] = *reinterpret_cast<const f64x2 *>(d + _i);                                \
+  }
+#define PO_G64_STEP(R)                                                                   \
+  {                                                                                      \
+    double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                           \
+    const bool _in = P.in[R];                                                            \
+    _Pragma("unroll") for (int h = 0; h < NH; h++) {                                     \
+      f64x2 v = P.buf[R][h];                                                             \
+      if (!_in) v = (f64x2){0.0, 0.0};                                                   \
+      const int _j = j0 + 8 * h;                                                         \
+      if (_j < nv) *reinterpret_cast<f64x2 *>(bt + _j * kG64Ld + 2 * rp) = v;            \
+    }                                                                                    \
+    if (pw == 0 && half == 0)                                                            \
+      *reinterpret_cast<f64x2 *>(bt + M * kG64Ld + 2 * rp) = _in ? P.dbuf[R] : (f64x2){0.0, 0.0}; \
+    PO_G64_LOAD(R, first + (it + (R) + D) * stride);                                     \
+    __syncthreads();                                                                     \
+  }
+    PO_G64_LOAD(0, first);
+    PO_G64_LOAD(1, first + stride);
+    PO_G64_LOAD(2, first + 2 * stride);
+    if constexpr (D == 4) PO_G64_LOAD(3, first + 3 * stride);
+    int64_t it = 0;
+    for (; it + D <= nt; it += D) {
+      PO_G64_STEP(0)
+      PO_G64_STEP(1)
+      PO_G64_STEP(2)
+      if constexpr (D == 4) PO_G64_STEP(3)
+    }
+    if (it < nt) PO_G64_STEP(0)
+    if (it + 1 < nt) PO_G64_STEP(1)
+    if constexpr (D == 4) {
+      if (it + 2 < nt) PO_G64_STEP(2)
+    }
+#undef PO_G64_STEP
+#undef PO_G64_LOAD
+    __syncthreads();  // matches the consumers' trailing barrier
+  } else {
+    // ------------------------------------------------ consumers ------------------------------------------------
+    // (one whole loop per wavefront role, dispatched once: with the role switch inside a shared loop the accumulators of
+    // the four roles end up in disjoint register ranges -- 248 registers and spills at 19 groups against 156-195 here)
+    switch (wave) {
+      case 0: gram64_consume<NG, 0>(lds, nt, partials, tcol, lane); break;
+      case 1: gram64_consume<NG, 1>(lds, nt, partials, tcol, lane); break;
+      case 2: gram64_consume<NG, 2>(lds, nt, partials, tcol, lane); break;
+      default: gram64_consume<NG, 3>(lds, nt, partials, tcol, lane); break;
+    }
+  }
+}
+
+template <int NG>
+static int wgram_pc64_launch_t(Ctx *c, const double *d, const PtrTable &pt, int nv, int64_t n, int tcol, int *grid_out) {
+  const size_t lds = (size_t)2 * (4 * NG * kG64Ld + kG64Tile) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(wgram_pc64_kernel<NG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t ntiles = (n + kG64Tile - 1) / kG64Tile;
+  int64_t g = (int64_t)c->num_cu;  // one workgroup per CU
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
+  const int prio = dbg_switch(SW_WGRAM_PRIO, "PAROPT_AMD_WGRAM_PRIO", 2);
+  hipLaunchKernelGGL((wgram_pc64_kernel<NG>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
+                     c->d_partials, tcol, prio);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  *grid_out = (int)g;
+  return PO_OK;
 }
 
 template <int NG, int ZP, int RS, int GS = 0>
@@ -853,6 +1006,8 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
   // producer/consumer form wins beyond (round 4, tools/dbg/wgram_pc_grid.py; PAROPT_AMD_WGRAM_PC_MIN_NG to move it).
   // (The same threshold for a panel image riding in the pass: on a narrow panel the single-role Gram plus the
   // stand-alone panel image are faster than the fused producer/consumer form -- 0.18 + 0.14 against 0.9 ms at 5 columns.)
+  // PAROPT_AMD_WGRAM_PC64=0: panels of 65-80 columns on the single-role kernel, as before round 5 (A/B)
+  static const bool use_pc64 = !(getenv("PAROPT_AMD_WGRAM_PC64") && atoi(getenv("PAROPT_AMD_WGRAM_PC64")) == 0);
   static const int pc_min_ng = getenv("PAROPT_AMD_WGRAM_PC_MIN_NG") ? atoi(getenv("PAROPT_AMD_WGRAM_PC_MIN_NG")) : 6;
   if (use_pc && NG >= pc_min_ng && wgram_groups_geom(groups, nv, n, kpend, &gg)) {
     // the pass also takes the structured panel image (see GramGeom): group tiles first, ordinary tiles behind them
@@ -893,7 +1048,10 @@ int k_wgram_launch(Ctx *c, const double *d, const double *const *V, int nv, int6
     constexpr int OCC0A = OCC0 > 1 ? OCC0 - 1 : 1;                                                     \
     constexpr int OCCZ = NGv <= 7 ? 3 : (NGv <= 13 ? 2 : 1);                                           \
     constexpr int OCCZA = NGv <= 7 ? 4 : (NGv <= 9 ? 3 : OCCZ);                                        \
-    if (NGv <= 16 && use_pc && n >= 4 * kGramTile && NGv >= pc_min_ng) {                               \
+    if (NGv >= 17 && use_pc && use_pc64 && kpend == 0 && n >= 4 * kGramTile) {                         \
+      constexpr int NGw = NGv >= 17 ? NGv : 17;                                                        \
+      PO_TRY((wgram_pc64_launch_t<NGw>(c, d, pt, nv, n, tcol, &grid)));                                \
+    } else if (NGv <= 16 && use_pc && n >= 4 * kGramTile && NGv >= pc_min_ng) {                        \
       constexpr int NGc = NGv <= 16 ? NGv : 16;                                                        \
       if (NGv >= kGramRowSplitMinNG && NGv <= kGramRowSplitMaxNG && row_split) {                       \
         constexpr int NGr = NGv <= kGramRowSplitMaxNG ? NGv : kGramRowSplitMaxNG;                      \

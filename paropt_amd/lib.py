@@ -293,6 +293,9 @@ SIGNATURES = {
     "po_trsub_destroy": (C.c_int, [po_trsub]),
     "po_trsub_set_eigen_model_update": (C.c_int, [po_trsub, EIG_UPDATE_FN, C.c_void_p]),
     "po_trsub_problem": (C.c_int, [po_trsub, C.POINTER(po_problem)]),
+    "po_trsub_sync_linear_model": (C.c_int, [po_trsub]),
+    "po_infeas_create": (C.c_int, [po_trsub, C.c_int, C.c_int, C.POINTER(po_problem)]),
+    "po_infeas_set_objective_scaling": (C.c_int, [po_problem, C.c_double]),
     "po_trsub_get_quasi_newton": (C.c_int, [po_trsub, C.POINTER(po_qn)]),
     "po_trsub_init_model_and_bounds": (C.c_int, [po_trsub, C.c_double]),
     "po_trsub_set_trust_region_bounds": (C.c_int, [po_trsub, C.c_double]),

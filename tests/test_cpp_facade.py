@@ -312,6 +312,26 @@ def test_cpp_user_written_trust_region_subproblem(tmp_path, driver):
     assert abs(float(last[2]) - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
 
 
+def test_cpp_infeas_subproblem_over_user_written_and_library_subproblems(tmp_path):
+    """ParOptInfeasSubproblem (src/ParOptTrustRegion.h:293-374) as a facade class: built by hand over the USER-WRITTEN
+    quadratic subproblem and over the library's ParOptQuadraticSubproblem of the same problem (driver=infeas of
+    examples/user_subproblem_amd.cpp), the steering LP of the first trust-region iteration comes out the same."""
+    exe = build(tmp_path, "user_subproblem_amd")
+    res = subprocess.run([exe, "n=200", "c=3", "driver=infeas", "opt.abs_res_tol=1e-9", "opt.tr_init_size=0.1"],
+                         capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr
+    lines = {ln.split()[1].rstrip(":"): ln.split() for ln in res.stdout.splitlines() if ln.startswith("infeas ")}
+    assert set(lines) == {"user", "library"}, res.stdout + res.stderr
+
+    def nums(tok):
+        return [float(v) for v in tok if v[0] in "-0123456789" and v[-1] in "0123456789"]
+
+    u, lb = np.array(nums(lines["user"])), np.array(nums(lines["library"]))
+    assert u.shape == lb.shape and u.size == 3 + 3 + 3
+    assert abs(u[1]) > 1e-3 and abs(u[2] - 0.1) < 1e-6  # a real step, at the trust-region bound somewhere
+    np.testing.assert_allclose(u, lb, rtol=1e-8, atol=1e-10)
+
+
 def test_eigenvalue_example_compiles_with_the_reference_header_names(tmp_path):
     """The class set of src/ParOptTrustRegion.h / src/ParOptCompactEigenvalueApprox.h is there under the reference's
     header names (include/paropt_compat, MPI_Comm communicators): a translation unit that includes only those headers
@@ -336,6 +356,9 @@ def test_eigenvalue_example_compiles_with_the_reference_header_names(tmp_path):
         "  ParOptOptimizer *opt = new ParOptOptimizer(p, o); opt->setTrustRegionSubproblem(qs); opt->optimize();\n"
         "  ip->checkGradients(1e-6); ip->setBFGSUpdateType(PAROPT_DAMPED_UPDATE); ip->setUseDiagHessian(0);\n"
         "  ip->checkMeritFuncGradient(NULL, 1e-6);\n"
+        "  ParOptInfeasSubproblem *inf = new ParOptInfeasSubproblem(sub, ParOptInfeasSubproblem::PAROPT_LINEAR_OBJECTIVE,\n"
+        "      ParOptInfeasSubproblem::PAROPT_LINEAR_CONSTRAINT);\n"
+        "  inf->setObjectiveScaling(0.5); ParOptProblem *as_problem = inf; (void)as_problem;\n"
         "}\n")
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-c", "-I" + os.path.join(ROOT, "include", "paropt_compat"),
                            "-I/opt/conda/include", str(src), "-o", str(tmp_path / "uses_tr_classes.o")])

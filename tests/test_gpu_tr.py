@@ -557,3 +557,85 @@ def test_trust_region_with_a_panel_wider_than_one_launch(ctx):
     mine = [t for _, t in rows]
     ref = [list(t["info"]) for t in otr.trace]
     assert mine == ref, (mine, ref)
+
+
+def test_infeas_subproblem_as_a_public_class(ctx):
+    """ParOptInfeasSubproblem (src/ParOptTrustRegion.h:293-374, .cpp:468-650) -- the problem of the driver's steering
+    step -- as a class of its own over a subproblem: all six selector pairs evaluate what the reference's
+    evalObjCon / evalObjConGradient (.cpp:541-612) define (scaled subproblem / linear / constant objective; subproblem /
+    linearised constraints), the (subproblem, subproblem) pair drives the interior point through the very iterations of
+    the subproblem itself, and the steering LP (linear, linear) solved by the sequential linear method reaches the
+    optimum of the same elastic LP solved by scipy."""
+    import paropt_amd as pa
+    from scipy.optimize import linprog
+
+    n, c, scale, tr_size = 300, 3, 2.5, 0.1
+    prob = pa.SeparableProblem(ctx, "quadratic", n, c, 1)
+    qn = pa.LBFGS(ctx, prob.nvars, 5)
+    sub = pa.QuadraticSubproblem(prob, qn)
+    sub.initModelAndBounds(tr_size)
+    xk, fk, gk, ck, Ak, lb, ub = sub.getLinearModel()
+    g_np, A_np = gk.to_numpy(), np.array([a.to_numpy() for a in Ak])
+    vec = lambda: pa.PVec(ctx, n)  # noqa: E731
+    lo, hi, step = vec(), vec(), vec()
+    sub.getVarsAndBounds(step, lo, hi)
+    lo_np, hi_np = lo.to_numpy(), hi.to_numpy()
+    assert np.all(hi_np - lo_np > 0) and np.all(hi_np <= tr_size + 1e-15) and np.all(lo_np >= -tr_size - 1e-15)
+    rng = np.random.default_rng(11)
+    p = lo_np + (hi_np - lo_np) * rng.random(n)
+    step.from_numpy(p)
+    _, fs, cs = sub.evalObjCon(step)
+    gs, As = vec(), [vec() for _ in range(c)]
+    assert sub.evalObjConGradient(step, gs, As) == 0
+    I = pa.InfeasSubproblem
+    for obj in (I.SUBPROBLEM_OBJECTIVE, I.LINEAR_OBJECTIVE, I.CONSTANT_OBJECTIVE):
+        for con in (I.SUBPROBLEM_CONSTRAINT, I.LINEAR_CONSTRAINT):
+            inf = I(sub, obj, con)
+            inf.setObjectiveScaling(scale)
+            l2, h2, s2 = vec(), vec(), vec()
+            inf.getVarsAndBounds(s2, l2, h2)
+            assert np.array_equal(l2.to_numpy(), lo_np) and np.array_equal(h2.to_numpy(), hi_np)
+            rc, f, cons = inf.evalObjCon(step)
+            assert rc == 0
+            want_f = {I.SUBPROBLEM_OBJECTIVE: fs, I.LINEAR_OBJECTIVE: fk + g_np @ p, I.CONSTANT_OBJECTIVE: fk}[obj] * scale
+            want_c = cs if con == I.SUBPROBLEM_CONSTRAINT else ck + A_np @ p
+            assert abs(f - want_f) <= 1e-12 * max(1.0, abs(want_f)), (obj, con)
+            np.testing.assert_allclose(cons, want_c, rtol=0, atol=1e-12 * max(1.0, np.abs(want_c).max()))
+            g, A = vec(), [vec() for _ in range(c)]
+            assert inf.evalObjConGradient(step, g, A) == 0
+            want_g = {I.SUBPROBLEM_OBJECTIVE: gs.to_numpy(), I.LINEAR_OBJECTIVE: g_np,
+                      I.CONSTANT_OBJECTIVE: np.zeros(n)}[obj] * scale
+            np.testing.assert_allclose(g.to_numpy(), want_g, rtol=0, atol=1e-13 * max(1.0, np.abs(want_g).max()))
+            for i in range(c):
+                want = As[i].to_numpy() if con == I.SUBPROBLEM_CONSTRAINT else A_np[i]
+                assert np.array_equal(A[i].to_numpy(), want)
+    with pytest.raises(pa.ParOptAMDError):
+        I(sub, 0, 1)
+    with pytest.raises(pa.ParOptAMDError):
+        I(sub, 1, 3)
+    # (subproblem, subproblem), scale 1: the interior point walks the iterations of the subproblem itself
+    opts = {"max_major_iters": 40, "abs_res_tol": 1e-8, "write_output_frequency": 0}
+    same = I(sub, I.SUBPROBLEM_OBJECTIVE, I.SUBPROBLEM_CONSTRAINT)
+    ip_a, ip_b = pa.InteriorPoint(sub, opts), pa.InteriorPoint(same, opts)
+    ip_a.optimize()
+    ip_b.optimize()
+    table = lambda ip: [ln for ln in ip.getHistory().splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
+    assert len(table(ip_a)) > 5 and table(ip_a) == table(ip_b)
+    assert np.array_equal(ip_a.getOptimizedPoint()[0].to_numpy(), ip_b.getOptimizedPoint()[0].to_numpy())
+    # the steering LP as minimizeInfeas sets it up (.cpp:1146-1166): linear objective and constraints, sequential
+    # linear method; against the same elastic LP  min scale g.p + gamma sum(t),  ck + A p + t >= 0,  t >= 0
+    gamma = 1000.0
+    lp = I(sub, I.LINEAR_OBJECTIVE, I.LINEAR_CONSTRAINT)
+    lp.setObjectiveScaling(scale)
+    ip = pa.InteriorPoint(lp, dict(opts, sequential_linear_method=True, max_major_iters=200, penalty_gamma=gamma,
+                                   abs_res_tol=1e-9))
+    ip.optimize()
+    assert "Successfully converged" in ip.getHistory()
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    cost = np.concatenate([scale * g_np, gamma * np.ones(c)])
+    res = linprog(cost, A_ub=-np.hstack([A_np, np.eye(c)]), b_ub=ck,
+                  bounds=[(lo_np[i], hi_np[i]) for i in range(n)] + [(0, None)] * c, method="highs")
+    assert res.status == 0
+    t = np.maximum(0.0, -(ck + A_np @ x))
+    mine = scale * g_np @ x + gamma * t.sum()
+    assert abs(mine - res.fun) <= 1e-6 * max(1.0, abs(res.fun)), (mine, res.fun)

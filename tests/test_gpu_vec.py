@@ -209,6 +209,30 @@ def test_wgram_with_preweighted_rhs_column(ctx, n, nv):
     np.testing.assert_array_equal(W, W.T)
 
 
+@pytest.mark.parametrize("n", [512, 513, 575, 641, 4097, 70001, 300007])
+@pytest.mark.parametrize("nv,rhs_last", [(65, False), (68, True), (69, False), (72, False), (73, True), (76, False),
+                                         (77, True), (80, False)])
+def test_wgram_wide_panel_producer_consumer(ctx, n, nv, rhs_last):
+    """Panels of 65-80 columns (config 3's data with an L-BFGS(20) memory: 32 + 40 + the pre-weighted column = 73) take
+    the 64-row producer/consumer kernel (wgram.hip: wgram_pc64_kernel) from n = 512 on: tile edges (n mod 64 = 0, 1,
+    63), ragged last column groups, the pre-weighted column in the last group, and more tiles than workgroups."""
+    import paropt_amd as pa
+
+    if n > 100000 and nv not in (73, 80):
+        pytest.skip("largest n for the bench's width and the widest panel")
+    d = hvec(ctx, n, 9, scale=1.0, shift=0.5)
+    V = [hvec(ctx, n, 20 + j, scale=2.0, shift=-1.0 + 0.02 * j) for j in range(nv)]
+    dn = hnp(n, 9, scale=1.0, shift=0.5)
+    P = np.stack([hnp(n, 20 + j, scale=2.0, shift=-1.0 + 0.02 * j) for j in range(nv)], axis=1)
+    ref = P.T @ (dn[:, None] * P)
+    if rhs_last:
+        ref[:, nv - 1] = P.T @ P[:, nv - 1]
+        ref[nv - 1, :] = ref[:, nv - 1]
+    W = pa.wgram(d, V, rhs_last=rhs_last)
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-13 * max(n, 64) * 10)
+    np.testing.assert_array_equal(W, W.T)
+
+
 def _group_sums(dn, P, nwcon, nw, skip, alpha):
     """alpha * (rounded products d * p added in index order over each group): the arithmetic of both kernels."""
     period = nw + skip
