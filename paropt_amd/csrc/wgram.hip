@@ -437,17 +437,15 @@ __device__ __forceinline__ void gram_pc_load(GramProducer<NG, ZP> &P, const doub
                                              const double *const (&scol)[ZP > 0 ? ZP : 1], const double *d,
                                              int64_t tile, int64_t ntiles, int64_t n, int64_t ilast, int lane,
                                              const GramGeom &gg) {
-  // BRANCH-FREE on purpose (round 5): a tile past the end re-requests the workgroup's last lines and is staged as
-  // zeros.  With the loads under `if (tile < ntiles)` hipcc's wait-count bookkeeping merged "issued" and "not issued"
-  // at the join and from then on took every load still in flight for kGramDepth-1 tiles YOUNGER than it is: the
-  // staging of tile t waited with vmcnt(NG) instead of vmcnt(NG + 2 (NG + 1)), i.e. for the loads of tiles t + 1 and
-  // t + 2 as well -- the three-tile prefetch ran one tile deep (profiles/r05_wgram_vmcnt.txt).
-  const bool live = tile < ntiles;
+  if (tile >= ntiles) {
+    P.in[R] = false;
+    return;
+  }
   int64_t row0;
   int nrows;
-  gram_tile_geom(gg, live ? tile : ntiles - 1, row0, nrows);
+  gram_tile_geom(gg, tile, row0, nrows);
   int64_t i = row0 + 2 * lane;
-  const bool in = live && (2 * lane < nrows) && (i < n);
+  const bool in = (2 * lane < nrows) && (i < n);
   // (lanes outside the tile: any in-range pair will do, its value is not used -- with group tiles one of THIS tile's,
   // whose lines the instruction requests anyway)
   int64_t alt = row0 + 2 * (lane & 3);
@@ -581,16 +579,24 @@ __global__ void __launch_bounds__(512, 1)
     const int64_t _idx = _mine ? _g0 + g2_gi : gg.nwcon;                                                      \
     g2_up[_idx] = _mine ? _sum : 0.0;                                                                         \
   }
-    // (no condition around a step's loads -- see gram_pc_load -- and none around the steps of the main loop: whole
-    // rounds of kGramDepth steps run unconditionally, the last nt % kGramDepth steps behind them)
+    // (Round 5, measured and NOT kept: with the loads under `if (tile < ntiles)` and the steps under `if (it + R < nt)`
+    // hipcc's wait-count bookkeeping merges "issued" and "not issued" at the joins and from then on takes every load in
+    // flight for kGramDepth-1 tiles younger than it is: tile t is staged behind vmcnt(NG) instead of
+    // vmcnt(NG + 2 (NG + 1)), i.e. behind the loads of tiles t + 1 and t + 2 as well.  A branch-free version (clamped
+    // loads past the end, whole rounds of three unconditional steps) does get the exact counts -- and is not faster:
+    // 43.7 / 43.9 against 43.0 / 43.9 it/s at config 3, 180.5 / 181.0 against 183.2 / 181.0 at config 4, 308 against 313
+    // at config 2, one call, profiles/r05_ab_wgram_producers_pc64.jsonl.  A tile period is longer than the HBM latency,
+    // so the loads issued one step ago have landed either way.  The 64-row form below is written branch-free.)
 #define PO_PC_STEP(R)                                                                                         \
-  {                                                                                                           \
+  if (it + (R) < nt) {                                                                                        \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
     if constexpr (GS == 2) PO_GS2_REQUEST(lds + (size_t)((it + (R) + 1) & 1) * kBufDoubles);                  \
     const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);                       \
+    if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
+    else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
+    if (stamp) __builtin_amdgcn_s_waitcnt(0);                                                                 \
     const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
+    if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
     const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if constexpr (GS == 2) PO_GS2_FINISH(it + (R) - 1);                                                       \
     __syncthreads();                                                                                          \
@@ -601,14 +607,11 @@ __global__ void __launch_bounds__(512, 1)
       st_wait += _t3 - _t2;                                                                                   \
     }                                                                                                         \
   }
-    int64_t it = 0;
-    for (; it + kGramDepth <= nt; it += kGramDepth) {
+    for (int64_t it = 0; it < nt; it += kGramDepth) {
       PO_PC_STEP(0)
       PO_PC_STEP(1)
       PO_PC_STEP(2)
     }
-    if (it < nt) PO_PC_STEP(0)
-    if (it + 1 < nt) PO_PC_STEP(1)
 #undef PO_PC_STEP
     if constexpr (GS == 2) {
       // the sums of the last tile (staged and published by the last step's barrier; the consumers overwrite the tile
@@ -799,7 +802,8 @@ __global__ void __launch_bounds__(512, 1)
     for (int h = 0; h < NH; h++) colp[h] = V.p[j0 + 8 * h < nv ? j0 + 8 * h : nv - 1];
     const int64_t ilast = ((n - 1) >> 1) << 1;
     Gram64Producer<NH, D> P;
-    // (loads unconditional, steps of the main loop unconditional: see gram_pc_load)
+    // (loads unconditional -- a tile past the end re-requests the last lines and is staged as zeros -- and whole rounds
+    // of D unconditional steps: hipcc then counts the loads in flight exactly, see the note in wgram_pc_kernel)
 #define PO_G64_LOAD(R, TILE)                                                             \
   {                                                                                      \
     const int64_t _t = (TILE);                                                           \

@@ -3,7 +3,7 @@
 #   1. the unprofiled bench line with the CPU reference beside it      -> gpurun_out/r05_bench_<cfg>.json
 #   2. the same command under rocprofv3 --kernel-trace --stats         -> gpurun_out/r05_rocprofv3_kernel_stats_<cfg>.csv
 #   3. PMC passes (FETCH_SIZE, WRITE_SIZE; counters only + kernel trace) -> gpurun_out/r05_pmc_<cfg>.json / .txt
-#   usage (repo root on the GPU box):  bash tools/collect_r05.sh c2|c3|c4|c5 [nopmc]
+#   usage (repo root on the GPU box):  bash tools/collect_r05.sh c2|c3|c3l|c4|c5 [nopmc]   (c3l: config 3 with L-BFGS(20), the 73-column panel)
 set -u
 cfg=${1:-c3}
 pmc=${2:-pmc}
@@ -12,6 +12,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 case $cfg in
   c3) prog=bench.py; args="--steps 20 --warmup 5" ;;
+  c3l) prog=bench.py; args="--qn bfgs --qn-size 20 --steps 20 --warmup 22 --boundary builtin" ;;
   c2) prog=bench.py; args="--nglobal 10000000 --ncon 8 --qn bfgs --qn-size 20 --problem quadratic --steps 20 --warmup 22 --boundary builtin" ;;
   c4) prog=bench.py; args="--nglobal 20000000 --ncon 4 --nwcon 1000000 --nw 20 --qn bfgs --steps 20 --warmup 12 --boundary both" ;;
   c5) prog=tools/bench_tr.py; args="" ;;
