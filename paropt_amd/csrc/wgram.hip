@@ -751,17 +751,30 @@ constexpr int kG64Ld = kG64Tile + 8;
 
 template <int NG, int W>
 __device__ __forceinline__ void gram64_consume(const double *__restrict__ lds, int64_t nt,
-                                               double *__restrict__ partials, int tcol, int lane) {
+                                               double *__restrict__ partials, int tcol, int lane, bool cstamp) {
   constexpr int M = 4 * NG;
   constexpr int NQ = GramPlanHolder<NG>::NQ;
   constexpr int kBufDoubles = M * kG64Ld + kG64Tile;
   double acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+  unsigned long long sc_wait = 0, sc_work = 0;
   for (int64_t it = 0; it < nt; it++) {
+    const unsigned long long _t0 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();  // tile `it` is staged in buffer it % 2
+    const unsigned long long _t1 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
     const double *bt = lds + (size_t)(it & 1) * kBufDoubles;
     gram_tile<NG, W, kG64Tile, kG64Ld>(bt, bt + M * kG64Ld, lane, tcol, acc);
+    if (cstamp) {
+      if (acc[0] == 1.2345e301) sc_work++;  // (read an accumulator: the stamp follows the matrix work)
+      const unsigned long long _t2 = __builtin_amdgcn_s_memtime();
+      sc_wait += _t1 - _t0;
+      sc_work += _t2 - _t1;
+    }
+  }
+  if (cstamp && lane == 0) {
+    g_wgram_stamp[0] = sc_wait;
+    g_wgram_stamp[1] = sc_work;
   }
   __syncthreads();
   gram_store<NG, W>(acc, lane, partials);
@@ -777,7 +790,7 @@ struct Gram64Producer {
 template <int NG>
 __global__ void __launch_bounds__(512, 1)
     wgram_pc64_kernel(const double *__restrict__ d, PtrTable V, int nv, int64_t n, int64_t ntiles,
-                      double *__restrict__ partials, int tcol, int prio) {
+                      double *__restrict__ partials, int tcol, int prio, int want_stamps) {
   constexpr int M = 4 * NG;
   constexpr int NH = (NG + 1) / 2;      // loads per producer wavefront and tile (two columns each)
   constexpr int D = 4;                  // tiles a producer keeps in flight (registers: 4 (NH + 1) per tile and lane)
@@ -814,10 +827,15 @@ __global__ void __launch_bounds__(512, 1)
     _Pragma("unroll") for (int h = 0; h < NH; h++) P.buf[R][h] = ld_nt(colp[h] + _i);    \
     P.dbuf[R] = *reinterpret_cast<const f64x2 *>(d + _i);                                \
   }
+    unsigned long long st_stage = 0, st_load = 0, st_wait = 0;
+    const bool stamp = want_stamps && blockIdx.x == 0 && wave == 4;  // (PAROPT_AMD_WGRAM_ABLATE=16, as in wgram_pc_kernel)
+    const unsigned long long st_c0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long st_r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
 #define PO_G64_STEP(R)                                                                   \
   {                                                                                      \
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                           \
     const bool _in = P.in[R];                                                            \
+    const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;             \
     _Pragma("unroll") for (int h = 0; h < NH; h++) {                                     \
       f64x2 v = P.buf[R][h];                                                             \
       if (!_in) v = (f64x2){0.0, 0.0};                                                   \
@@ -826,8 +844,17 @@ __global__ void __launch_bounds__(512, 1)
     }                                                                                    \
     if (pw == 0 && half == 0)                                                            \
       *reinterpret_cast<f64x2 *>(bt + M * kG64Ld + 2 * rp) = _in ? P.dbuf[R] : (f64x2){0.0, 0.0}; \
+    if (stamp) __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): the staging stores have left */ \
+    const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;             \
     PO_G64_LOAD(R, first + (it + (R) + D) * stride);                                     \
+    const unsigned long long _t2 = stamp ? __builtin_amdgcn_s_memtime() : 0;             \
     __syncthreads();                                                                     \
+    if (stamp) {                                                                         \
+      const unsigned long long _t3 = __builtin_amdgcn_s_memtime();                       \
+      st_stage += _t1 - _t0;                                                             \
+      st_load += _t2 - _t1;                                                              \
+      st_wait += _t3 - _t2;                                                              \
+    }                                                                                    \
   }
     PO_G64_LOAD(0, first);
     PO_G64_LOAD(1, first + stride);
@@ -847,16 +874,24 @@ __global__ void __launch_bounds__(512, 1)
     }
 #undef PO_G64_STEP
 #undef PO_G64_LOAD
+    if (stamp && lane == 0) {
+      g_wgram_stamp[2] = st_stage;
+      g_wgram_stamp[3] = st_load;
+      g_wgram_stamp[4] = st_wait;
+      g_wgram_stamp[5] = (unsigned long long)nt;
+      g_wgram_stamp[6] = __builtin_amdgcn_s_memtime() - st_c0;
+      g_wgram_stamp[7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
     __syncthreads();  // matches the consumers' trailing barrier
   } else {
     // ------------------------------------------------ consumers ------------------------------------------------
     // (one whole loop per wavefront role, dispatched once: with the role switch inside a shared loop the accumulators of
     // the four roles end up in disjoint register ranges -- 248 registers and spills at 19 groups against 156-195 here)
     switch (wave) {
-      case 0: gram64_consume<NG, 0>(lds, nt, partials, tcol, lane); break;
-      case 1: gram64_consume<NG, 1>(lds, nt, partials, tcol, lane); break;
-      case 2: gram64_consume<NG, 2>(lds, nt, partials, tcol, lane); break;
-      default: gram64_consume<NG, 3>(lds, nt, partials, tcol, lane); break;
+      case 0: gram64_consume<NG, 0>(lds, nt, partials, tcol, lane, want_stamps && blockIdx.x == 0); break;
+      case 1: gram64_consume<NG, 1>(lds, nt, partials, tcol, lane, false); break;
+      case 2: gram64_consume<NG, 2>(lds, nt, partials, tcol, lane, false); break;
+      default: gram64_consume<NG, 3>(lds, nt, partials, tcol, lane, false); break;
     }
   }
 }
@@ -876,8 +911,9 @@ static int wgram_pc64_launch_t(Ctx *c, const double *d, const PtrTable &pt, int 
   if (g < 1) g = 1;
   PO_TRY(ensure_partials(c, (size_t)g * (NG * (NG + 1) / 2) * 16));
   const int prio = dbg_switch(SW_WGRAM_PRIO, "PAROPT_AMD_WGRAM_PRIO", 2);
+  const int stamps = (dbg_switch(SW_WGRAM_ABLATE, "PAROPT_AMD_WGRAM_ABLATE", 0) & 16) != 0;
   hipLaunchKernelGGL((wgram_pc64_kernel<NG>), dim3((int)g), dim3(512), lds, c->stream, d, pt, nv, n, ntiles,
-                     c->d_partials, tcol, prio);
+                     c->d_partials, tcol, prio, stamps);
   c->n_launches++;
   PO_HIP(hipGetLastError());
   *grid_out = (int)g;

@@ -312,6 +312,7 @@ def test_cpp_user_written_trust_region_subproblem(tmp_path, driver):
     assert abs(float(last[2]) - g["final/fk"][0]) <= 1e-6 * max(1.0, abs(g["final/fk"][0]))
 
 
+@pytest.mark.gpu
 def test_cpp_infeas_subproblem_over_user_written_and_library_subproblems(tmp_path):
     """ParOptInfeasSubproblem (src/ParOptTrustRegion.h:293-374) as a facade class: built by hand over the USER-WRITTEN
     quadratic subproblem and over the library's ParOptQuadraticSubproblem of the same problem (driver=infeas of

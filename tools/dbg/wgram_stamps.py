@@ -25,7 +25,7 @@ for rep in range(3):
     print("kernel %.3f ms, %d tiles per workgroup -> %.3f us per tile | shader cycles per tile (s_memtime): consumer wait %.0f "
           "work %.0f | producer stage (incl. wait for its loads) %.0f load-issue %.0f barrier-wait %.0f | implied clock "
           "%.2f GHz, %.1f B/cycle/CU" % (ms, nt, ms * 1e3 / nt, o[0] / nt, o[1] / nt, o[2] / nt, o[3] / nt, o[4] / nt,
-                                          cyc / (ms * 1e3 / nt) * 1e-3, (m + 1) * 128 * 8 / cyc))
+                                          cyc / (ms * 1e3 / nt) * 1e-3, (m + 1) * int(os.environ.get("STAMP_ROWS", "128")) * 8 / cyc))
     if o[7] > 0:
         print("   loop: %.0f s_memtime ticks in %.3f ms of the 100 MHz counter -> s_memtime runs at %.0f MHz" % (
             o[6], o[7] / 1e5, o[6] / o[7] * 100.0))
