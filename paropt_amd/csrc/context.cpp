@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
-static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 int dbg_switch(int id, const char *env, int dflt) {
   if (id >= 0 && id < SW_COUNT && g_dbg_switch[id] >= 0) return g_dbg_switch[id];
   const char *e = env ? getenv(env) : nullptr;

@@ -224,7 +224,7 @@ struct BatchScope {
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
 enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_REDO_DT = 2, SW_LEAN_STEP = 3, SW_WGRAM_PRIO = 4,
                  SW_WGRAM_ABLATE = 5, SW_FUSED_MERIT = 6, SW_REDO_DT1 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_LINCOMB_BPC = 10,
-                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_COUNT = 13 };  // one entry per use: an A/B run changes one thing
+                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_S2D_TWO = 13, SW_COUNT = 14 };  // one entry per use: an A/B run changes one thing
 int dbg_switch(int id, const char *env, int dflt);
 void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);

@@ -1814,6 +1814,218 @@ __global__ void __launch_bounds__(kBlock, OCC)
   block_reduce_store<2, OP_MIN>(mins, partials, nv, sm);
 }
 
+// -------------------------------------------------------------------------------------------------
+// TWO TILES PER STEP (round 5; narrow panels, NPASS <= 6, no unformed columns).  What bounds the form above on a narrow
+// panel is the instruction stream of the element epilogue -- 13 IEEE divisions per element -- which two of the four
+// wavefronts run while the other two wait (HISTORY R5.11).  Here a workgroup takes its next TWO tiles (the same tiles
+// in the same order as above: blockIdx.x + k gridDim.x, k = 2 m and 2 m + 1) at once: waves 0-1 finish the elements of
+// the first, waves 2-3 those of the second, at the same time.  The columns stay in registers (no LDS slices: the request
+// for the next pair goes out behind the dots, and the other workgroups of the CU cover its latency -- R5.11 measured that
+// they do), every wave takes the dots of its own columns with the first tile's t' and THEN with the second's: the order
+// in which the form above adds them, so every sum keeps its bits.
+// -------------------------------------------------------------------------------------------------
+template <int NPASS, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC)
+    solve2_dots2_kernel(Bounds b, const double *t, const double *__restrict__ dinv, CoefTable alpha,
+                        CoefTable coef2, PtrTable P, int nv, double beta_mu, double tau,
+                        const double *__restrict__ rx, double diag, int64_t n, int64_t ntiles,
+                        double *__restrict__ px, double *__restrict__ pzl, double *__restrict__ pzu,
+                        double *tout, double *__restrict__ va, int nca, double *__restrict__ traw,
+                        int store_step, int ca0, double dinv_diag, GroupCols2 gcs,
+                        double *__restrict__ partials) {
+  extern __shared__ double s2lds[];  // [2][4*64*6] partial sums, [2][128] t', [8]
+  double *sacc = s2lds;
+  double *stp = s2lds + 2 * (4 * 64 * 6);
+  double *sm = stp + 2 * kS2Tile;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ex = wave >> 1, eh = wave & 1;  // epilogue: rows 64 eh + lane of tile `ex` of the pair
+  double dotacc[NPASS];
+#pragma unroll
+  for (int it = 0; it < NPASS; it++) dotacc[it] = 0.0;
+  double mins[2] = {1.0, 1.0};
+  const int64_t qlast = (n - 1) >> 1;
+  f64x2 buf[2][NPASS];
+  const int gmine = (gcs.count > 0 && wave == (nv & 3)) ? 0 : ((gcs.count > 1 && wave == ((nv + 1) & 3)) ? 1 : -1);
+  GRaw gbuf[2];
+  bool in[2] = {false, false};
+  double eb[8];
+  bool ein = false;
+#pragma unroll
+  for (int x = 0; x < 2; x++) {
+    gbuf[x].raw = (f64x2){0.0, 0.0};
+    gbuf[x].valid = 0;
+  }
+  // columns of both tiles of the pair that starts at FIRST, and this wave's element operands of its own tile
+#define PO_S22_REQUEST(FIRST)                                                                \
+  {                                                                                          \
+    _Pragma("unroll") for (int x = 0; x < 2; x++) {                                          \
+      const int64_t _tile = (FIRST) + x * (int64_t)gridDim.x;                                \
+      int64_t _q = _tile * 64 + lane;                                                        \
+      in[x] = _tile < ntiles && 2 * _q < n;                                                  \
+      if (!in[x]) _q = qlast;                                                                \
+      _Pragma("unroll") for (int it = 0; it < NPASS; it++) {                                 \
+        const int j = wave + 4 * it;                                                         \
+        buf[x][it] = ld_stream(P.p[j < nv ? j : 0] + 2 * _q);                                \
+      }                                                                                      \
+      if (gmine >= 0) gbuf[x] = gcol_request(gcs.g[gmine], _q, n);                           \
+    }                                                                                        \
+    const int64_t _mine = (FIRST) + ex * (int64_t)gridDim.x;                                 \
+    const int64_t _ir = _mine * kS2Tile + 64 * eh + lane;                                    \
+    ein = _mine < ntiles && _ir < n;                                                         \
+    const int64_t _ie = ein ? _ir : n - 1;                                                   \
+    eb[0] = b.x[_ie];                                                                        \
+    eb[1] = b.lb[_ie];                                                                       \
+    eb[2] = b.ub[_ie];                                                                       \
+    eb[3] = b.zl[_ie];                                                                       \
+    eb[4] = b.zu[_ie];                                                                       \
+    if (t) {                                                                                 \
+      eb[5] = t[_ie];                                                                        \
+      eb[6] = dinv[_ie];                                                                     \
+    }                                                                                        \
+    eb[7] = rx[_ie];                                                                         \
+  }
+  if ((int64_t)blockIdx.x < ntiles) PO_S22_REQUEST((int64_t)blockIdx.x);
+  for (int64_t first = blockIdx.x; first < ntiles; first += 2 * (int64_t)gridDim.x) {
+    const bool has2 = first + gridDim.x < ntiles;  // (workgroup-uniform)
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+      f64x2 a1 = (f64x2){0.0, 0.0}, a2 = a1, aA = a1;
+#pragma unroll
+      for (int it = 0; it < NPASS; it++) {
+        const int j = wave + 4 * it;  // coefficient tables are zero beyond nv
+        f64x2 v = buf[x][it];
+        if (!in[x]) v = (f64x2){0.0, 0.0};
+        buf[x][it] = v;  // (what the form above parks in LDS)
+        const double ca = alpha.a[j], cb = coef2.a[j], cA = (j >= ca0 && j < ca0 + nca) ? ca : 0.0;
+        a1 += ca * v;
+        a2 += cb * v;
+        aA += cA * v;
+      }
+      if (gmine >= 0) {
+        f64x2 v = gcol_value(gcs.g[gmine], gbuf[x]);
+        if (!in[x]) v = (f64x2){0.0, 0.0};
+        a1 += gcs.ca[gmine] * v;
+        a2 += gcs.cb[gmine] * v;
+      }
+      double *sa = sacc + x * (4 * 64 * 6) + wave * 64 + lane;
+      sa[0 * 256] = a1.x;
+      sa[1 * 256] = a1.y;
+      sa[2 * 256] = a2.x;
+      sa[3 * 256] = a2.y;
+      sa[4 * 256] = aA.x;
+      sa[5 * 256] = aA.y;
+    }
+    __syncthreads();
+    if (ex == 0 || has2) {
+      const int64_t tile = first + ex * (int64_t)gridDim.x;
+      const int er = 64 * eh + lane, el = er >> 1, ec = er & 1;
+      double acc = 0.0, acc2 = 0.0, accA = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const double *sp = sacc + ex * (4 * 64 * 6) + w * 64 + el;
+        acc += sp[(0 + ec) * 256];
+        acc2 += sp[(2 + ec) * 256];
+        accA += sp[(4 + ec) * 256];
+      }
+      double tp = 0.0;
+      const int64_t i = tile * kS2Tile + er;
+      if (ein) {
+        const double _x = eb[0], _lb = eb[1], _ub = eb[2], _zl = eb[3], _zu = eb[4];
+        const BE e = bound_elem(_x, _lb, _ub, _zl, _zu, b.max_bound, b.use_lower, b.use_upper);
+        const double r = eb[7];
+        double tv, dv;
+        if (t) {
+          tv = eb[5];
+          dv = eb[6];
+        } else {
+          dv = dinv_elem(e, dinv_diag);
+          tv = dv * d1_elem(e, r, beta_mu);
+        }
+        if (va && store_step == 1) va[i] = accA;
+        const Step3 s0 = solve2_elem<0>(e, tv + dv * acc, beta_mu, 0.0, 0.0, 0.0);
+        if (store_step) {
+          px[i] = s0.px;
+          if (store_step == 1) {
+            pzl[i] = s0.pzl;
+            pzu[i] = s0.pzu;
+          }
+        }
+        const double raw = res_step_elem(e, r, acc2, diag, s0.px, s0.pzl, s0.pzu, 1.0, beta_mu, b.use_lower,
+                                         b.use_upper);
+        tp = dv * raw;
+        if (traw) {
+          traw[i] = raw;
+        } else if (tout) {
+          tout[i] = tp;
+        }
+        max_step_elem(b, _x, _lb, _ub, _zl, _zu, s0, tau, mins[0], mins[1]);
+      } else if (i == n && (n & 1)) {
+        if (va && store_step == 1) va[i] = 0.0;
+        if (store_step) {
+          px[i] = 0.0;
+          if (store_step == 1) {
+            pzl[i] = 0.0;
+            pzu[i] = 0.0;
+          }
+        }
+        if (traw) {
+          traw[i] = 0.0;
+        } else if (tout) {
+          tout[i] = 0.0;
+        }
+      }
+      stp[ex * kS2Tile + er] = tp;
+    }
+    __syncthreads();
+    {
+      const f64x2 tt = *reinterpret_cast<const f64x2 *>(stp + 2 * lane);
+#pragma unroll
+      for (int it = 0; it < NPASS; it++) dotacc[it] = fma(buf[0][it].x, tt.x, fma(buf[0][it].y, tt.y, dotacc[it]));
+    }
+    if (has2) {
+      const f64x2 tt = *reinterpret_cast<const f64x2 *>(stp + kS2Tile + 2 * lane);
+#pragma unroll
+      for (int it = 0; it < NPASS; it++) dotacc[it] = fma(buf[1][it].x, tt.x, fma(buf[1][it].y, tt.y, dotacc[it]));
+    }
+    if (first + 2 * (int64_t)gridDim.x < ntiles) PO_S22_REQUEST(first + 2 * (int64_t)gridDim.x);
+  }
+#undef PO_S22_REQUEST
+#pragma unroll
+  for (int it = 0; it < NPASS; it++) {
+    const double v = wave_reduce<OP_SUM>(dotacc[it]);
+    const int j = wave + 4 * it;
+    if (lane == 0 && j < nv) partials[(size_t)j * gridDim.x + blockIdx.x] = v;
+  }
+  __syncthreads();
+  block_reduce_store<2, OP_MIN>(mins, partials, nv, sm);
+}
+
+template <int NP, int OCC>
+static int solve2_dots2_launch(Ctx *c, const Bounds &b, const double *t, const double *dinv, const CoefTable &ct,
+                               const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu, double tau,
+                               const double *rx, double diag, int64_t n, int64_t ntiles, double *px, double *pzl,
+                               double *pzu, double *tout, double *va, int nca, double *traw, int store_step, int ca0,
+                               double dinv_diag, int *grid_out, const GroupCols2 &gcs) {
+  const size_t lds = sizeof(double) * (size_t)(2 * (4 * 64 * 6) + 2 * kS2Tile + 8);
+  // the grid of the one-tile form (same tiles per workgroup, same partial sums)
+  const size_t lds1 = sizeof(double) * (size_t)(4 * NP * kS2Tile + 4 * 64 * 6 + kS2Tile + 8);
+  int per_cu = (int)((160 * 1024) / lds1);
+  if (per_cu > OCC) per_cu = OCC;
+  if (per_cu < 1) per_cu = 1;
+  int64_t g = (int64_t)c->num_cu * per_cu;
+  if (g > ntiles) g = ntiles;
+  if (g < 1) g = 1;
+  PO_TRY(ensure_partials(c, (size_t)g * (nv + 2)));
+  hipLaunchKernelGGL((solve2_dots2_kernel<NP, OCC>), dim3((int)g), dim3(kBlock), lds, c->stream, b, t, dinv, ct, ct2, pt,
+                     nv, beta_mu, tau, rx, diag, n, ntiles, px, pzl, pzu, tout, va, nca, traw, store_step, ca0,
+                     dinv_diag, gcs, c->d_partials);
+  c->n_launches++;
+  PO_HIP(hipGetLastError());
+  *grid_out = (int)g;
+  return PO_OK;
+}
+
 template <int NP, int OCC, int VIRT>
 static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const double *t, const double *dinv,
                               const CoefTable &ct, const CoefTable &ct2, const PtrTable &pt, int nv, double beta_mu,
@@ -1855,7 +2067,12 @@ static int solve2_dots_launch(Ctx *c, int grid_cap, const Bounds &b, const doubl
        spilled to scratch and are gone: every instantiation left is scratch-free, tests/test_kernel_resources.py) */ \
     constexpr int OD = NP <= 8 ? 3 : (NP <= 16 ? 2 : 1), OA = NP <= 8 ? 2 : OD;                            \
     constexpr int OV = NP <= 16 ? 2 : 1; /* with unformed columns: three more prefetch registers */        \
-    if (vc.count > 0)                                                                                      \
+    /* (two tiles per step up to 6 slots per wave: 8 slots would need 168 + 13 registers at three workgroups per CU) */ \
+    if (NP <= 6 && vc.count == 0 && two_tiles && occ_env != OA) {                                          \
+      constexpr int NP2 = NP <= 6 ? NP : 6;                                                                \
+      PO_TRY((solve2_dots2_launch<NP2, 3>(c, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, px, pzl, \
+                                          pzu, tout, va, nca, traw, store_step, ca0, dinv_diag, &grid, gcs))); \
+    } else if (vc.count > 0)                                                                               \
       PO_TRY((solve2_dots_launch<NP, OV, 1>(c, 0, b, t, dinv, ct, ct2, pt, nv, beta_mu, tau, rx, diag, n, ntiles, \
                                             px, pzl, pzu, tout, va, nca, traw, store_step, ca0, vc, dinv_diag, &grid, gcs))); \
     else if (occ_env == OA)                                                                                \
@@ -1895,6 +2112,11 @@ int k_solve2_dots(Ctx *c, const Bounds &b, const double *t, const double *dinv, 
   const int64_t ntiles = (((n + 1) >> 1) + 63) / 64;
   int grid = 0;
   static const int occ_env = getenv("PAROPT_AMD_S2D_OCC") ? atoi(getenv("PAROPT_AMD_S2D_OCC")) : 0;
+  // PAROPT_AMD_S2D_TWO=1: narrow panels two tiles per step (solve2_dots2_kernel; same bits either way).  OFF by
+  // default: measured in one call (profiles/r05_ab_solve2_dots_two_tiles.jsonl) the kernels are 9-15 % faster at
+  // n = 5 M (config 5: 93.5 / 137.9 / 174.5 us against 109 / 150.9 / 194.9) and 5-7 % SLOWER at n = 20 M (config 4:
+  // 1053 against 1006 us), and neither line moves (782 / 794 against 791 / 783 inner it/s, 178.0 against 178.0 it/s).
+  const bool two_tiles = dbg_switch(SW_S2D_TWO, "PAROPT_AMD_S2D_TWO", 0) != 0;
   PtrTable pt;
   CoefTable ct, ct2;
   fill_tables(alpha, P, nv, &ct, &pt);

@@ -1149,3 +1149,51 @@ def test_reset_design_and_bounds_wins_over_a_live_mirror(ctx, tmp_path):
     np.testing.assert_array_equal(view, xopt)
 
 
+
+
+@pytest.mark.parametrize("case", ["c2_bfgs5", "c8_bfgs6", "c4_weighting", "c3_mehrotra", "c1_small"])
+def test_first_solve_pass_two_tiles_per_step_keeps_every_bit(ctx, case):
+    """Narrow panels (up to 24 columns, no unformed L-SR1 columns) take the first solve pass two tiles per step
+    (solve2_dots2_kernel: all four wavefronts in the element epilogue; the dots of a workgroup's tiles are still added
+    in tile order).  Against the one-tile form (debug switch 13 = 0) in the same process: every iterate, multiplier,
+    norm and counter the same bits -- sizes with several tiles per workgroup, an odd number of tiles per workgroup, an
+    odd n, fewer tiles than workgroups, and the grouped columns of the weighting constraints."""
+    import paropt_amd as pa
+    from paropt_amd import lib as L
+
+    SW_S2D_TWO = 13
+    cfg = {
+        "c2_bfgs5": dict(kind="convex", n=400003, c=2, opts={"qn_type": "bfgs", "qn_subspace_size": 5}),
+        "c8_bfgs6": dict(kind="quadratic", n=300001, c=8, opts={"qn_type": "bfgs", "qn_subspace_size": 6}),
+        "c4_weighting": dict(kind="convex", n=400000, c=4, nwcon=20000, nw=20, opts={"qn_type": "bfgs", "qn_subspace_size": 4}),
+        "c3_mehrotra": dict(kind="convex", n=700001, c=3,
+                            opts={"qn_type": "bfgs", "qn_subspace_size": 3, "barrier_strategy": "mehrotra"}),
+        "c1_small": dict(kind="quadratic", n=20011, c=1, opts={"qn_type": "bfgs", "qn_subspace_size": 2}),
+    }[case]
+
+    def run(two):
+        L.lib.po_debug_set_switch(SW_S2D_TWO, 1 if two else 0)
+        try:
+            prob = pa.SeparableProblem(ctx, cfg["kind"], cfg["n"], cfg["c"], 3)
+            if "nwcon" in cfg:
+                prob.setWeighting(cfg["nwcon"], cfg["nw"])
+            ip = pa.InteriorPoint(prob, dict({"abs_res_tol": 1e-9, "start_affine_multiplier_min": 0.01, "max_major_iters": 16,
+                                              "write_output_frequency": 0}, **cfg["opts"]))
+            sn = []
+            ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+            ip.optimize()
+            x, z, zl, zu = ip.getOptimizedPoint()[:4]
+            return sn, x.to_numpy(), np.array(z), zl.to_numpy(), zu.to_numpy(), ip.getHistory()
+        finally:
+            L.lib.po_debug_set_switch(SW_S2D_TWO, -1)
+
+    a, b = run(False), run(True)
+    assert len(a[0]) == len(b[0]) >= 8
+    for sa, sb in zip(a[0], b[0]):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
+        np.testing.assert_array_equal(sa["norms"], sb["norms"])
+    for va, vb in zip(a[1:5], b[1:5]):
+        np.testing.assert_array_equal(va, vb)
+    table = lambda h: [ln for ln in h.splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
+    assert len(table(a[5])) >= 8 and table(a[5]) == table(b[5])
