@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 5, sixteenth GPU call: the recognised-chain regression tests, the sweep suite, and the two campaigns again
+mkdir -p gpurun_out
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+python -m pytest tests/test_gpu_random_sweep.py -m gpu -q --no-header 2>&1 | tail -8
+( echo "# round 5, final build (after the fix the first run of this campaign led to: setChain reset the recognised group map): PAROPT_SWEEP_CASES=600 PAROPT_SWEEP_SEED=808"
+  PAROPT_SWEEP_CASES=600 PAROPT_SWEEP_SEED=808 timeout 1500 python3 tests/test_gpu_random_sweep.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | cut -c1-900
+  echo
+  echo "# the same build with the first solve pass two tiles per step (PAROPT_AMD_S2D_TWO=1): PAROPT_SWEEP_CASES=400 PAROPT_SWEEP_SEED=909"
+  PAROPT_AMD_S2D_TWO=1 PAROPT_SWEEP_CASES=400 PAROPT_SWEEP_SEED=909 timeout 1200 python3 tests/test_gpu_random_sweep.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | cut -c1-900
+) > gpurun_out/r05_sweep_campaigns.txt
+grep -c "CASE" gpurun_out/r05_sweep_campaigns.txt
+grep "differ\|ERROR" gpurun_out/r05_sweep_campaigns.txt | cut -c1-300
