@@ -18,9 +18,16 @@ NCASES = int(os.environ.get("PAROPT_SWEEP_CASES", "24"))
 SEED = int(os.environ.get("PAROPT_SWEEP_SEED", "20261003"))
 
 
-def draw(rng):
+SMALL_NS = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 513, 700, 1023, 1025, 1500, 2049, 3000]
+# several tiles per workgroup in every persistent kernel (768 workgroups x 128 rows in the first solve pass, 256 x 128 in
+# the producer/consumer Gram), odd lengths, one tile more than a whole round: the sizes the fixed goldens hold only at
+# n = 100 000 / 100 003
+LARGE_NS = [32769, 65537, 98305, 100003, 131071, 196613, 262147, 300001, 393217]
+
+
+def draw(rng, ns=SMALL_NS):
     problem = rng.choice(["convex", "quadratic", "quadratic", "rosenbrock"])
-    n = rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 257, 511, 513, 700, 1023, 1025, 1500, 2049, 3000])
+    n = rng.choice(ns)
     if problem == "rosenbrock":
         n = max(n, 8)
         c = 2
@@ -100,7 +107,8 @@ def draw(rng):
         wt = (nwcon, nw, start, skip, nwineq)
         opts.setdefault("starting_point_strategy", "affine_step")
         opts["penalty_gamma"] = 1000.0
-    if wt is None and n >= 63 and rng.random() < 0.15:
+    if wt is None and n >= 63 and rng.random() < 0.15 and n <= 5000:
+        # (n <= 5000: the oracle holds the chain Jacobian as a dense matrix)
         # the CSR form (ParOptSparseProblem): overlapping chain constraints, device sparse Cholesky
         extra["chain"] = (rng.choice([2, 3]), rng.choice([1, 2]))
         opts.setdefault("starting_point_strategy", "affine_step")
@@ -112,6 +120,14 @@ def draw(rng):
 def cases():
     rng = random.Random(SEED)
     return [draw(rng) for _ in range(NCASES)]
+
+
+NLARGE = int(os.environ.get("PAROPT_SWEEP_LARGE_CASES", "12"))
+
+
+def large_cases():
+    rng = random.Random(SEED + 1)
+    return [draw(rng, LARGE_NS) for _ in range(NLARGE)]
 
 
 def _make_ctx():
@@ -164,6 +180,12 @@ RECOGNISED_CHAINS = [
     ("quadratic", 64, 3, dict(_BASE, qn_type="bfgs", qn_subspace_size=4, barrier_strategy="monotone", norm_type="l2"),
      None, {"chain": (2, 3)}),
 ]
+
+
+@pytest.mark.parametrize("idx", range(NLARGE))
+def test_random_large_case_against_oracle(ctx, idx):
+    """The same draws at sizes where every persistent kernel runs several tiles per workgroup (LARGE_NS)."""
+    _compare_case_with_oracle(ctx, 20000 + idx, large_cases()[idx])
 
 
 @pytest.mark.parametrize("k", range(len(RECOGNISED_CHAINS)))
@@ -465,6 +487,21 @@ if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaig
             nbad += 1  # an error of the library is a finding of the campaign like any other: report it and go on
             print("CASE %d %r\n     -> ERROR %s: %s" % (i, cases()[i], type(e).__name__, str(e)[:500]), flush=True)
     print("%d of %d cases differ" % (nbad, NCASES))
+    nbad = 0
+    for i in range(NLARGE):
+        try:
+            test_random_large_case_against_oracle(c, i)
+        except AssertionError as e:
+            nbad += 1
+            print("LARGE CASE %d %r\n     -> %s" % (i, large_cases()[i], " | ".join(str(e).strip().splitlines()[:6])[:700]), flush=True)
+        except BaseException as e:  # pytest.skip
+            if type(e).__name__ == "Skipped":
+                continue
+            if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                raise
+            nbad += 1
+            print("LARGE CASE %d %r\n     -> ERROR %s: %s" % (i, large_cases()[i], type(e).__name__, str(e)[:500]), flush=True)
+    print("%d of %d large cases differ" % (nbad, NLARGE))
     nbad = nrun = 0
     for i in range(0, NCASES, 3):
         try:
