@@ -34,7 +34,8 @@ def main():
     env = dict(os.environ, MKL_NUM_THREADS="1", PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
     nbad = nskip = 0
     only = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]  # FUZZ_ONLY=i,j: these draws only
-    for i, (problem, n, c, opts, wt, extra) in enumerate(T.cases()):
+    drawn = T.large_cases() if os.environ.get("FUZZ_LARGE") else T.cases()  # FUZZ_LARGE=1: the large-n draws
+    for i, (problem, n, c, opts, wt, extra) in enumerate(drawn):
         if only and i not in only:
             continue
         wargs = dict(nwcon=wt[0], nw=wt[1], nwstart=wt[2], nwskip=wt[3], nwineq=wt[4]) if wt else {}
