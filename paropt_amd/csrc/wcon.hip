@@ -139,70 +139,80 @@ __global__ void __launch_bounds__(kBlock)
 }
 // out_i = (init ? out_i : cst) + alpha * (group sum of v), same tiling with a single column
 // recip != 0: out_i = 1 / (...) (the factor Cw = 1 / (Cdiag + Aw D^-1 Aw^T) of the scalar block form in one launch)
-__global__ void __launch_bounds__(kBlock)
-    group_sum_tiled_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
-                           const double *__restrict__ v, int G, int64_t ntiles, int recip) {
-  __shared__ double sm[kGroupTile];
-  const int period = m.nw + m.skip;
-  const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
-  const int tid = threadIdx.x;
-  const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
-  // tile geometry + unconditional loads on clamped indices (both requests of a lane in flight together); the next
-  // tile of this workgroup is requested before the row sums of the current one (round 4: the kernel was bound by
-  // one load latency after the other per tile)
-  auto tile_load = [&](int64_t tile, double &a0, double &a1) {
-    const int64_t g0 = tile * G;
-    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
-    const int64_t v0 = m.start + g0 * (int64_t)period;
-    const int nvv = (ng - 1) * period + m.nw;
-    a0 = v[v0 + (tid < nvv ? tid : 0)];
-    a1 = v[v0 + (tid + kBlock < nvv ? tid + kBlock : 0)];
-  };
-  double c0 = 0.0, c1 = 0.0;
-  if ((int64_t)blockIdx.x < ntiles) tile_load(blockIdx.x, c0, c1);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t g0 = tile * G;
-    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
-    const int nvv = (ng - 1) * period + m.nw;
-    if (tid < nvv) sm[s0] = c0;
-    if (tid + kBlock < nvv) sm[s1] = c1;
-    if (tile + gridDim.x < ntiles) tile_load(tile + gridDim.x, c0, c1);
-    __syncthreads();
-    if (tid < ng) {
-      const double sacc = row_sum(sm + tid * rstride, m.nw);
-      const double val = (init ? out[g0 + tid] : cst) + alpha * sacc;
-      out[g0 + tid] = recip ? 1.0 / val : val;
-    }
-    __syncthreads();
-  }
+// (round 5: TWO tiles ahead.  One tile of 4 KB per workgroup and eight workgroups per CU keep 32 KB per CU in flight -- half
+// of what the HBM latency asks for; the kernels ran at 3.5 / 2.2 TB/s (group_factor had no prefetch at all).  The requests
+// are unconditional on clamped tile indices and the two register sets alternate instead of being copied, so that the
+// compiler's wait counts stay exact: a tile is staged behind vmcnt(2), with the next tile's two loads still in flight.)
+struct GroupTileRegs {
+  double a0, a1;
+};
+__device__ __forceinline__ void group_tile_request(const GroupMap &m, const double *__restrict__ v, int G, int64_t ntiles,
+                                                   int64_t tile, int tid, int period, GroupTileRegs &r) {
+  const int64_t tl = tile < ntiles ? tile : ntiles - 1;
+  const int64_t g0 = tl * G;
+  const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
+  const int64_t v0 = m.start + g0 * (int64_t)period;
+  const int nvv = (ng - 1) * period + m.nw;
+  r.a0 = v[v0 + (tid < nvv ? tid : 0)];
+  r.a1 = v[v0 + (tid + kBlock < nvv ? tid + kBlock : 0)];
 }
-// Cw_i = 1 / (sw_i/zsw_i + tw_i/ztw_i + sum of d over group i): w_cdiag_kernel + group_sum_tiled_kernel(recip) in
-// one launch (same expressions, same order)
-__global__ void __launch_bounds__(kBlock)
-    group_factor_tiled_kernel(GroupMap m, WVars v, const double *__restrict__ d, double *__restrict__ cw, int G,
-                              int64_t ntiles) {
+// out_i = (init ? out_i : cst) + alpha * (group sum of v), same tiling with a single column
+// recip != 0: out_i = 1 / (...) (the factor Cw = 1 / (Cdiag + Aw D^-1 Aw^T) of the scalar block form in one launch)
+// FACTOR: Cw_i = 1 / (sw_i/zsw_i + tw_i/ztw_i + sum of d over group i): w_cdiag_kernel + the reciprocal form in one launch
+// (same expressions, same order)
+template <int FACTOR>
+__global__ void __launch_bounds__(kBlock, 8)  // (the launch is 8 workgroups per CU: at 88 registers only 5 were resident)
+    group_sum_tiled_kernel(GroupMap m, double *__restrict__ out, int init, double cst, double alpha,
+                           const double *__restrict__ v, int G, int64_t ntiles, int recip, WVars wv) {
   __shared__ double sm[kGroupTile];
   const int period = m.nw + m.skip;
   const int pad = (period & 1) ? 0 : 1, rstride = period + pad;
   const int tid = threadIdx.x;
   const int s0 = tid + pad * (tid / period), s1 = tid + kBlock + pad * ((tid + kBlock) / period);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int64_t g0 = tile * G;
-    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);
-    const int64_t v0 = m.start + g0 * (int64_t)period;
-    const int nvv = (ng - 1) * period + m.nw;
-    const double a0 = d[v0 + (tid < nvv ? tid : 0)], a1 = d[v0 + (tid + kBlock < nvv ? tid + kBlock : 0)];
-    if (tid < nvv) sm[s0] = a0;
-    if (tid + kBlock < nvv) sm[s1] = a1;
-    __syncthreads();
-    if (tid < ng) {
-      const int64_t i = g0 + tid;
-      const double cd = v.sw[i] / v.zsw[i] + v.tw[i] / v.ztw[i];
-      const double val = cd + 1.0 * row_sum(sm + tid * rstride, m.nw);
-      cw[i] = 1.0 / val;
-    }
-    __syncthreads();
+  const int64_t stride = gridDim.x;
+  GroupTileRegs ra, rb;
+  group_tile_request(m, v, G, ntiles, blockIdx.x, tid, period, ra);
+  group_tile_request(m, v, G, ntiles, blockIdx.x + stride, tid, period, rb);
+#define PO_GROUP_TILE(R, TILE)                                                                  \
+  {                                                                                             \
+    const int64_t _tile = (TILE);                                                               \
+    const int64_t g0 = _tile * G;                                                               \
+    const int ng = (int)((m.nwcon - g0) < G ? (m.nwcon - g0) : G);                              \
+    const int nvv = (ng - 1) * period + m.nw;                                                   \
+    if (tid < nvv) sm[s0] = R.a0;                                                               \
+    if (tid + kBlock < nvv) sm[s1] = R.a1;                                                      \
+    /* the w-sized operands of this tile's results are requested BEFORE the tile two ahead: loads complete in      \
+       order, so behind it their wait would be a wait for that tile as well */                                    \
+    const int64_t i = g0 + (tid < ng ? tid : 0);                                                \
+    double o0 = cst, o1 = 0.0, o2 = 0.0, o3 = 0.0;                                              \
+    if (FACTOR) {                                                                               \
+      o0 = wv.sw[i];                                                                            \
+      o1 = wv.zsw[i];                                                                           \
+      o2 = wv.tw[i];                                                                            \
+      o3 = wv.ztw[i];                                                                           \
+    } else if (init) {                                                                          \
+      o0 = out[i];                                                                              \
+    }                                                                                           \
+    group_tile_request(m, v, G, ntiles, _tile + 2 * stride, tid, period, R);                    \
+    __syncthreads();                                                                            \
+    if (tid < ng) {                                                                             \
+      const double sacc = row_sum(sm + tid * rstride, m.nw);                                    \
+      if (FACTOR) {                                                                             \
+        const double cd = o0 / o1 + o2 / o3;                                                    \
+        const double val = cd + 1.0 * sacc;                                                     \
+        out[i] = 1.0 / val;                                                                     \
+      } else {                                                                                  \
+        const double val = o0 + alpha * sacc;                                                   \
+        out[i] = recip ? 1.0 / val : val;                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    __syncthreads();                                                                            \
   }
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += 2 * stride) {
+    PO_GROUP_TILE(ra, tile)
+    if (tile + stride < ntiles) PO_GROUP_TILE(rb, tile + stride)
+  }
+#undef PO_GROUP_TILE
 }
 static bool group_tiling(const GroupMap &m, int *G, int64_t *ntiles);
 int k_group_factor(Ctx *c, const GroupMap &m, const WVars &v, const double *d, double *cw) {
@@ -216,7 +226,7 @@ int k_group_factor(Ctx *c, const GroupMap &m, const WVars &v, const double *d, d
   count_bytes(c, 1.0, m.nwcon * (int64_t)m.nw);
   count_bytes(c, 5.0, m.nwcon);
   int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
-  PO_WLAUNCH(group_factor_tiled_kernel, (int)grid, m, v, d, cw, G, ntiles);
+  PO_WLAUNCH(group_sum_tiled_kernel<1>, (int)grid, m, cw, 0, 0.0, 1.0, d, G, ntiles, 1, v);
   return PO_OK;
 }
 
@@ -254,7 +264,7 @@ int k_group_sum(Ctx *c, const GroupMap &m, double *out, int init, double cst, do
   int64_t ntiles = 0;
   if (group_tiling(m, &G, &ntiles)) {
     int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
-    PO_WLAUNCH(group_sum_tiled_kernel, (int)grid, m, out, init, cst, alpha, v, G, ntiles, recip);
+    PO_WLAUNCH(group_sum_tiled_kernel<0>, (int)grid, m, out, init, cst, alpha, v, G, ntiles, recip, WVars());
     return PO_OK;
   }
   PO_WLAUNCH(group_sum_kernel, wgrid(c, m.nwcon), m, out, init, cst, alpha, v, recip);
