@@ -405,7 +405,9 @@ int k_group_panel(Ctx *c, const GroupMap &m, const double *const *P, int nv, con
   int G = 0;
   int64_t ntiles = 0;
   if (group_tiling(m, &G, &ntiles)) {
-    int64_t grid = ntiles < (int64_t)c->num_cu * 8 ? ntiles : (int64_t)c->num_cu * 8;
+    // (workgroups per CU that are actually resident: 32 KB of LDS per workgroup in the 8-column form, 16 KB in the other)
+    const int per_cu = nv > 4 ? 4 : 8;
+    int64_t grid = ntiles < (int64_t)c->num_cu * per_cu ? ntiles : (int64_t)c->num_cu * per_cu;
     if (nv > 4) {
       PO_WLAUNCH(group_panel_tiled_kernel<8>, (int)grid, m, pt, nv, d, alpha, ut, G, ntiles);
     } else {
@@ -447,7 +449,7 @@ int k_group_apply(Ctx *c, const GroupMap &m, const double *d, const double *bx, 
 // same order, the tile kept in registers between the two halves.  A tile is G whole PERIODS (G * period <=
 // kGroupTile), so consecutive tiles cover [start, start + nwcon * period) without gaps; what lies before `start`
 // and after the last period is element-wise.
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 8)  // (launched 8 per CU; without the bound 106 registers = 4 resident)
     group_k0_tiled_kernel(GroupMap m, const double *__restrict__ d, const double *__restrict__ bx,
                           const double *__restrict__ cw, const double *__restrict__ bw, double alpha, int64_t n,
                           double *__restrict__ yx, double *__restrict__ yw, int G, int64_t ntiles) {
