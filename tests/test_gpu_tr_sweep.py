@@ -72,6 +72,12 @@ def cases():
     return [draw(rng) for _ in range(NCASES)]
 
 
+def cases_for(seed, ncases):
+    """The draws of a given seed, independent of the environment (fixture: oracle/make_tr_sweep_reference.py)."""
+    rng = random.Random(seed)
+    return [draw(rng) for _ in range(ncases)]
+
+
 def oracle_ip_options(tro):
     """Options of the interior point the oracle's driver runs on: the reference shares ONE options object between
     ParOptTrustRegion and ParOptInteriorPoint (src/ParOptOptimizer.cpp:108-183), so `penalty_gamma` -- which the driver
@@ -140,6 +146,71 @@ def test_random_trust_region_case_against_oracle(ctx, idx):
     _run_case(ctx, idx, cases()[idx])
 
 
+# ---- the device's driver against the COMPILED REFERENCE itself ---------------------------------------------------
+# tests/golden/tr_sweep_reference_s535353_n150.npz (oracle/make_tr_sweep_reference.py): iteration count, final
+# objective and the info column of every table row of the unmodified reference on 150 draws of this generator.
+FIXTURE_SEED, FIXTURE_N = 535353, 150
+# draws on which the device's table leaves the reference's (each listed in profiles/r05_tr_sweep_reference_fixture.txt):
+# an accept / reject or subproblem-count decision after a steering solve that ended elsewhere -- the reference and the
+# numpy driver part ways on the same kind of draw (oracle/fuzz_tr_vs_reference.py)
+FIXTURE_KNIFE_EDGE = {
+    53: "convex n = 8193, steering on the subproblem's own objective and constraints: rows 1-3 equal, the fourth steering "
+        "solve stops after 195 iterations on the device and at the cap of 200 in the reference, a different accept / "
+        "reject path from there",
+    129: "quadratic n = 1000, same steering selectors: the third steering solve ends at the cap of 200 on the device and "
+         "after 113 iterations in the reference, the subproblem solve behind it takes 17 against 18 iterations; the other "
+         "nine rows are equal",
+}
+_fixture_cache = {}
+
+
+def _fixture():
+    if "g" not in _fixture_cache:
+        import json
+
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                 "tr_sweep_reference_s%d_n%d.npz" % (FIXTURE_SEED, FIXTURE_N)))
+        drawn = cases_for(FIXTURE_SEED, FIXTURE_N)
+        assert json.loads(str(g["cases_repr"])) == [repr(cs) for cs in drawn]  # the generator has not drifted
+        _fixture_cache["g"], _fixture_cache["cases"] = g, drawn
+    return _fixture_cache["g"], _fixture_cache["cases"]
+
+
+def _strip(toks):
+    return [t.split("/")[0] if "/" in t and t.replace("/", "").isdigit() else t for t in toks]
+
+
+@pytest.mark.parametrize("idx", range(FIXTURE_N))
+def test_random_trust_region_case_against_reference_fixture(ctx, idx):
+    import json
+
+    import paropt_amd as pa
+
+    g, drawn = _fixture()
+    if idx in FIXTURE_KNIFE_EDGE:
+        pytest.skip(FIXTURE_KNIFE_EDGE[idx])
+    case = drawn[idx]
+    problem, n, c, m, tro, wt, extra = case
+    what = (idx,) + tuple(case)
+    pre = "d%04d/" % idx
+    prob = pa.SeparableProblem(ctx, problem, n, c, extra.get("seed", 0), 1.0, extra.get("eig_max", 100.0))
+    if wt:
+        prob.setWeighting(*wt)
+    if extra.get("chain"):
+        prob.setChain(*extra["chain"])
+    tr = pa.TrustRegion(prob, dict(tro, qn_subspace_size=m, max_major_iters=200, output_file="", tr_output_file=""))
+    rows = []
+    tr.setIterationCallback(lambda i: rows.append(tr.getLastRow()) if i > 0 else None)
+    tr.optimize()
+    rows.append(tr.getLastRow())
+    st = tr.getState()
+    ref_tokens = json.loads(str(g[pre + "tokens"]))
+    assert st["iter_count"] == int(g[pre + "iter_count"][0]), ("iter_count", st["iter_count"], int(g[pre + "iter_count"][0]), what)
+    assert [_strip(t) for _, t in rows] == [_strip(t) for t in ref_tokens], ("row tokens", [t for _, t in rows], ref_tokens, what)
+    fk = float(g[pre + "fk"][0])
+    assert abs(st["fk"] - fk) <= 1e-6 * max(1.0, abs(fk)), ("fk", st["fk"], fk, what)
+
+
 if __name__ == "__main__":
     import paropt_amd as pa
 
@@ -160,3 +231,19 @@ if __name__ == "__main__":
             nbad += 1
             print("TR CASE %d %r\n     -> ERROR %s: %s" % (i, case, type(e).__name__, str(e)[:500]), flush=True)
     print("%d of %d trust-region cases differ (%d skipped)" % (nbad, NCASES, nskip))
+    if os.environ.get("PAROPT_TR_SWEEP_FIXTURE", "0") == "1":
+        nbad = 0
+        for i in range(FIXTURE_N):
+            try:
+                test_random_trust_region_case_against_reference_fixture(c, i)
+            except AssertionError as e:
+                nbad += 1
+                print("TR FIXTURE CASE %d %r\n     -> %s" % (i, _fixture()[1][i], " | ".join(str(e).strip().splitlines()[:6])[:1200]), flush=True)
+            except BaseException as e:  # pytest.skip
+                if type(e).__name__ == "Skipped":
+                    continue
+                if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                    raise
+                nbad += 1
+                print("TR FIXTURE CASE %d %r\n     -> ERROR %s: %s" % (i, _fixture()[1][i], type(e).__name__, str(e)[:500]), flush=True)
+        print("%d of %d fixture cases differ from the compiled reference" % (nbad, FIXTURE_N))
