@@ -2,7 +2,7 @@
 """TEST INFRASTRUCTURE (not part of the product): runs the drawn cases of tests/test_gpu_tr_sweep.py through the COMPILED
 REFERENCE (oracle/_ref/ref_driver tr: ParOptTrustRegion over ParOptQuadraticSubproblem, unmodified sources) and stores
 its iteration count, final objective, final point norm and the info column of every row of its table as a fixture:
-tests/golden/tr_sweep_reference_s<seed>_n<N>.npz.  tests/test_gpu_tr_sweep.py::
+tests/golden/sweep_tr_reference_s<seed>_n<N>.npz.  tests/test_gpu_tr_sweep.py::
 test_random_trust_region_case_against_reference_fixture then holds the DEVICE's driver to the reference itself.
 
     python oracle/make_tr_sweep_reference.py [ncases=150] [seed=535353]
@@ -62,7 +62,7 @@ def main():
     out["meta"] = np.array(json.dumps({"seed": seed, "ncases": ncases,
                                        "what": "compiled reference (oracle/_ref/ref_driver tr) on the draws of "
                                                "tests/test_gpu_tr_sweep.py::cases_for(seed, ncases)"}))
-    path = os.path.join(ROOT, "tests", "golden", "tr_sweep_reference_s%d_n%d.npz" % (seed, ncases))
+    path = os.path.join(ROOT, "tests", "golden", "sweep_tr_reference_s%d_n%d.npz" % (seed, ncases))
     np.savez_compressed(path, **out)
     print("%s: %d draws, %d bytes" % (path, ncases, os.path.getsize(path)))
 

@@ -147,7 +147,7 @@ def test_random_trust_region_case_against_oracle(ctx, idx):
 
 
 # ---- the device's driver against the COMPILED REFERENCE itself ---------------------------------------------------
-# tests/golden/tr_sweep_reference_s535353_n150.npz (oracle/make_tr_sweep_reference.py): iteration count, final
+# tests/golden/sweep_tr_reference_s535353_n150.npz (oracle/make_tr_sweep_reference.py): iteration count, final
 # objective and the info column of every table row of the unmodified reference on 150 draws of this generator.
 FIXTURE_SEED, FIXTURE_N = 535353, 150
 # draws on which the device's table leaves the reference's (each listed in profiles/r05_tr_sweep_reference_fixture.txt):
@@ -169,7 +169,7 @@ def _fixture():
         import json
 
         g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                 "tr_sweep_reference_s%d_n%d.npz" % (FIXTURE_SEED, FIXTURE_N)))
+                                 "sweep_tr_reference_s%d_n%d.npz" % (FIXTURE_SEED, FIXTURE_N)))
         drawn = cases_for(FIXTURE_SEED, FIXTURE_N)
         assert json.loads(str(g["cases_repr"])) == [repr(cs) for cs in drawn]  # the generator has not drifted
         _fixture_cache["g"], _fixture_cache["cases"] = g, drawn
