@@ -7,6 +7,7 @@ tests/test_gpu_random_sweep.py::test_random_case_against_reference_fixture then 
 on drawn cases (no numpy oracle in between).  Runs only where the reference was compiled (the build container).
 
     python oracle/make_sweep_reference.py [ncases=400] [seed=424242]
+    python oracle/make_sweep_reference.py --large [ncases=40] [seed=434343]     (n = 32 769 ... 393 217)
 """
 import json
 import os
@@ -43,14 +44,16 @@ def driver_args(problem, n, c, opts, wt, extra):
 
 
 def main():
-    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 424242
+    argv = [a for a in sys.argv[1:] if a != "--large"]
+    large = "--large" in sys.argv  # the draws at n = 32 769 ... 393 217 (large_cases_for): sweep_reference_large_s<seed>_n<N>.npz
+    ncases = int(argv[0]) if len(argv) > 0 else (40 if large else 400)
+    seed = int(argv[1]) if len(argv) > 1 else (434343 if large else 424242)
     import test_gpu_random_sweep as T  # (its info_tokens, from tests/test_gpu_ip.py, parses the reference's table too)
     from oracle.make_golden import DRIVER, read_rec
 
     env = dict(os.environ, MKL_NUM_THREADS="1", PATH="/opt/conda/bin:" + os.environ.get("PATH", ""))
     out = {}
-    drawn = T.cases_for(seed, ncases)
+    drawn = T.large_cases_for(seed, ncases) if large else T.cases_for(seed, ncases)
     nfail = 0
     for i, case in enumerate(drawn):
         problem, n, c, opts, wt, extra = case
@@ -80,7 +83,7 @@ def main():
     out["cases_repr"] = np.array(json.dumps([repr(cs) for cs in drawn]))
     out["meta"] = np.array(json.dumps({"seed": seed, "ncases": ncases, "what": "compiled reference (oracle/_ref/ref_driver ip) on the "
                                        "draws of tests/test_gpu_random_sweep.py::cases_for(seed, ncases)", "driver_failures": nfail}))
-    path = os.path.join(ROOT, "tests", "golden", "sweep_reference_s%d_n%d.npz" % (seed, ncases))
+    path = os.path.join(ROOT, "tests", "golden", "sweep_reference_%ss%d_n%d.npz" % ("large_" if large else "", seed, ncases))
     np.savez_compressed(path, **out)
     print("%s: %d draws, %d driver failures, %d bytes" % (path, ncases, nfail, os.path.getsize(path)))
 

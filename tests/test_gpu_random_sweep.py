@@ -122,6 +122,11 @@ def cases():
     return [draw(rng) for _ in range(NCASES)]
 
 
+def large_cases_for(seed, ncases):
+    rng = random.Random(seed)
+    return [draw(rng, LARGE_NS) for _ in range(ncases)]
+
+
 def cases_for(seed, ncases):
     """The draws of a given seed, independent of the environment (fixtures: oracle/make_sweep_reference.py)."""
     rng = random.Random(seed)
@@ -206,17 +211,25 @@ FIXTURE_KNIFE_EDGE = {
 _fixture_cache = {}
 
 
-def _fixture():
-    if "g" not in _fixture_cache:
+# ... and 40 draws at n = 32 769 ... 393 217 (several tiles per workgroup in every persistent kernel):
+# tests/golden/sweep_reference_large_s434343_n40.npz (oracle/make_sweep_reference.py --large)
+LARGE_FIXTURE_SEED, LARGE_FIXTURE_N = 434343, 40
+LARGE_FIXTURE_KNIFE_EDGE = {}
+
+
+def _fixture(large=False):
+    key = "large" if large else "small"
+    if key not in _fixture_cache:
         import json
 
+        seed, nc = (LARGE_FIXTURE_SEED, LARGE_FIXTURE_N) if large else (FIXTURE_SEED, FIXTURE_N)
         g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                 "sweep_reference_s%d_n%d.npz" % (FIXTURE_SEED, FIXTURE_N)))
-        drawn = cases_for(FIXTURE_SEED, FIXTURE_N)
+                                 "sweep_reference_%ss%d_n%d.npz" % ("large_" if large else "", seed, nc)))
+        drawn = large_cases_for(seed, nc) if large else cases_for(seed, nc)
         # the generator has not drifted from the one the fixture was made with
         assert json.loads(str(g["cases_repr"])) == [repr(cs) for cs in drawn]
-        _fixture_cache["g"], _fixture_cache["cases"] = g, drawn
-    return _fixture_cache["g"], _fixture_cache["cases"]
+        _fixture_cache[key] = (g, drawn)
+    return _fixture_cache[key]
 
 
 def _run_device(ctx, case):
@@ -241,11 +254,21 @@ def _run_device(ctx, case):
 
 @pytest.mark.parametrize("idx", range(FIXTURE_N))
 def test_random_case_against_reference_fixture(ctx, idx):
+    _compare_with_fixture(ctx, idx, False)
+
+
+@pytest.mark.parametrize("idx", range(LARGE_FIXTURE_N))
+def test_random_large_case_against_reference_fixture(ctx, idx):
+    _compare_with_fixture(ctx, idx, True)
+
+
+def _compare_with_fixture(ctx, idx, large):
     import json
 
-    g, drawn = _fixture()
-    if idx in FIXTURE_KNIFE_EDGE:
-        pytest.skip(FIXTURE_KNIFE_EDGE[idx])
+    g, drawn = _fixture(large)
+    skips = LARGE_FIXTURE_KNIFE_EDGE if large else FIXTURE_KNIFE_EDGE
+    if idx in skips:
+        pytest.skip(skips[idx])
     case = drawn[idx]
     problem, n, c, opts, wt, extra = case
     what = (idx,) + tuple(case)
@@ -597,6 +620,21 @@ if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaig
                 nbad += 1
                 print("FIXTURE CASE %d %r\n     -> ERROR %s: %s" % (i, _fixture()[1][i], type(e).__name__, str(e)[:500]), flush=True)
         print("%d of %d fixture cases differ from the compiled reference" % (nbad, FIXTURE_N))
+        nbad = 0
+        for i in range(LARGE_FIXTURE_N):
+            try:
+                test_random_large_case_against_reference_fixture(c, i)
+            except AssertionError as e:
+                nbad += 1
+                print("LARGE FIXTURE CASE %d %r\n     -> %s" % (i, _fixture(True)[1][i], " | ".join(str(e).strip().splitlines()[:6])[:700]), flush=True)
+            except BaseException as e:  # pytest.skip
+                if type(e).__name__ == "Skipped":
+                    continue
+                if isinstance(e, (KeyboardInterrupt, SystemExit)):
+                    raise
+                nbad += 1
+                print("LARGE FIXTURE CASE %d %r\n     -> ERROR %s: %s" % (i, _fixture(True)[1][i], type(e).__name__, str(e)[:500]), flush=True)
+        print("%d of %d large fixture cases differ from the compiled reference" % (nbad, LARGE_FIXTURE_N))
     nbad = 0
     for i in range(NLARGE):
         try:
