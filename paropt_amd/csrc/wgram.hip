@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(512, 1)
 // 160 KB of LDS, so these panels ran the single-role kernel with ONE wavefront per SIMD (0.34 of the HBM peak: load
 // wait, staging and matrix work in series).  Here the tile is 64 rows (row stride 72 doubles == 8 mod 32, the same
 // banking as 136), two buffers = 93 KB at 80 columns.  A producer wavefront loads TWO columns per instruction (lanes
-// 0-31 the 32 row pairs of column j, lanes 32-63 those of column j + 4) and keeps three or four tiles in flight; the
+// 0-31 the 32 row pairs of column j, lanes 32-63 those of column j + 4) and keeps four tiles in flight; the
 // consumers split the OUTPUT (column groups dealt to the four wavefronts, as in the single-role kernel), four 16-row
 // steps per tile.  Same slot layout of the partial sums; the summation order differs from the single-role form's
 // (64- instead of 128-row tiles), which only panels of this width ever see.
