@@ -337,6 +337,11 @@ __global__ void __launch_bounds__(kBlock, OCC)
 // buffer (it+1)%2 is free (filled by the producers during step `it`).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kGramDepth = 3;  // tiles a producer keeps in flight
+#ifdef PO_WGRAM_NO_FULL_STAGE  // (A/B builds: the staging with per-lane selects on every tile)
+#define PO_WGRAM_FULL_STAGE 0
+#else
+#define PO_WGRAM_FULL_STAGE 1
+#endif
 
 // PAROPT_AMD_WGRAM_ABLATE=16: cycle stamps of workgroup 0 (s_memtime), read by po_debug_wgram_stamps:
 // [0] consumer barrier wait, [1] consumer matrix work, [2] producer staging (incl. the wait for its loads),
@@ -462,11 +467,15 @@ __device__ __forceinline__ void gram_pc_load(GramProducer<NG, ZP> &P, const doub
   P.dbuf[R] = *reinterpret_cast<const f64x2 *>(d + i);
 }
 
-template <int NG, int ZP, int R>
+// FULL: every lane of the wavefront holds rows of the tile (all tiles but a panel's last one, and the tiles of whole
+// groups): the per-lane "outside the tile -> stage zero" selects -- four 32-bit selects per column and tile, a third of
+// the producers' vector instructions, issued on the SIMD the matrix instructions of the consumer wavefront run on --
+// are left out (round 5; the caller tests `in` across the wavefront, a scalar branch).
+template <int NG, int ZP, int R, bool FULL = false>
 __device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *__restrict__ pt,
                                               double *__restrict__ dw, double *const (&zcol)[ZP > 0 ? ZP : 1], int pw,
                                               int nv, int kpend, double b0, int lane) {
-  const bool in = P.in[R];
+  const bool in = FULL ? true : P.in[R];
 #pragma unroll
   for (int it = 0; it < NG; it++) {
     const int j = pw + 4 * it;
@@ -476,7 +485,7 @@ __device__ __forceinline__ void gram_pc_stage(GramProducer<NG, ZP> &P, double *_
       v.y -= b0 * P.sbuf[R][it].y;
       if (in && zcol[it]) __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(zcol[it] + P.row[R]));
     }
-    if (!in) v = (f64x2){0.0, 0.0};
+    if (!FULL && !in) v = (f64x2){0.0, 0.0};
     if (j < nv) *reinterpret_cast<f64x2 *>(pt + j * kGramLd + 2 * lane) = v;
   }
   if (pw == 0) *reinterpret_cast<f64x2 *>(dw + 2 * lane) = in ? P.dbuf[R] : (f64x2){0.0, 0.0};
@@ -592,8 +601,13 @@ __global__ void __launch_bounds__(512, 1)
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                                                \
     if constexpr (GS == 2) PO_GS2_REQUEST(lds + (size_t)((it + (R) + 1) & 1) * kBufDoubles);                  \
     const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
-    if (ablate != 2) gram_pc_stage<NG, ZP, (R)>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);      \
-    else if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                         \
+    if (ablate == 2) {                                                                                        \
+      if (P.buf[R][0].x == 1.2345e301) bt[0] = P.buf[R][NG - 1].y;                                            \
+    } else if (PO_WGRAM_FULL_STAGE && __all(P.in[R])) {                                                       \
+      gram_pc_stage<NG, ZP, (R), true>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);               \
+    } else {                                                                                                  \
+      gram_pc_stage<NG, ZP, (R), false>(P, bt, bt + M * kGramLd, zcol, pw, nv, kpend, b0, lane);              \
+    }                                                                                                         \
     if (stamp) __builtin_amdgcn_s_waitcnt(0);                                                                 \
     const unsigned long long _t1 = stamp ? __builtin_amdgcn_s_memtime() : 0;                                  \
     if (ablate != 3) gram_pc_load<NG, ZP, (R)>(P, colp, scol, d, first + (it + (R) + kGramDepth) * stride, ntiles, n, ilast, lane, gg); \
@@ -836,11 +850,18 @@ __global__ void __launch_bounds__(512, 1)
     double *bt = lds + (size_t)((it + (R)) & 1) * kBufDoubles;                           \
     const bool _in = P.in[R];                                                            \
     const unsigned long long _t0 = stamp ? __builtin_amdgcn_s_memtime() : 0;             \
-    _Pragma("unroll") for (int h = 0; h < NH; h++) {                                     \
-      f64x2 v = P.buf[R][h];                                                             \
-      if (!_in) v = (f64x2){0.0, 0.0};                                                   \
-      const int _j = j0 + 8 * h;                                                         \
-      if (_j < nv) *reinterpret_cast<f64x2 *>(bt + _j * kG64Ld + 2 * rp) = v;            \
+    if (PO_WGRAM_FULL_STAGE && __all(_in)) { /* (no per-lane selects: see gram_pc_stage) */ \
+      _Pragma("unroll") for (int h = 0; h < NH; h++) {                                   \
+        const int _j = j0 + 8 * h;                                                       \
+        if (_j < nv) *reinterpret_cast<f64x2 *>(bt + _j * kG64Ld + 2 * rp) = P.buf[R][h]; \
+      }                                                                                  \
+    } else {                                                                             \
+      _Pragma("unroll") for (int h = 0; h < NH; h++) {                                   \
+        f64x2 v = P.buf[R][h];                                                           \
+        if (!_in) v = (f64x2){0.0, 0.0};                                                 \
+        const int _j = j0 + 8 * h;                                                       \
+        if (_j < nv) *reinterpret_cast<f64x2 *>(bt + _j * kG64Ld + 2 * rp) = v;          \
+      }                                                                                  \
     }                                                                                    \
     if (pw == 0 && half == 0)                                                            \
       *reinterpret_cast<f64x2 *>(bt + M * kG64Ld + 2 * rp) = _in ? P.dbuf[R] : (f64x2){0.0, 0.0}; \
