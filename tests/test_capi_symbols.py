@@ -53,3 +53,21 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_null_handles_are_refused_not_dereferenced():
+    """Entry points added in round 5 (state injection, user-written subproblems, ParOptInfeasSubproblem) answer a NULL
+    handle with an error code and a message -- no GPU needed to check that they do not dereference it."""
+    import ctypes as C
+
+    import paropt_amd.lib as L
+
+    lib = L.lib
+    out = L.po_problem()
+    assert lib.po_infeas_create(None, 1, 2, C.byref(out)) != 0
+    assert lib.po_infeas_set_objective_scaling(None, 1.0) != 0
+    assert lib.po_trsub_sync_linear_model(None) != 0
+    assert lib.po_trsub_problem(None, C.byref(out)) != 0
+    assert lib.po_trsub_destroy(None) == 0  # (like free(NULL))
+    assert lib.po_problem_destroy(None) == 0
+    assert len(lib.po_last_error()) > 0
