@@ -301,7 +301,12 @@ def _compare_with_fixture(ctx, idx, large):
 
 @pytest.mark.parametrize("idx", range(NLARGE))
 def test_random_large_case_against_oracle(ctx, idx):
-    """The same draws at sizes where every persistent kernel runs several tiles per workgroup (LARGE_NS)."""
+    """The same draws at sizes where every persistent kernel runs several tiles per workgroup (LARGE_NS).  In the suite
+    these sizes are held to the compiled reference's fixture (test_random_large_case_against_reference_fixture: data, the
+    same on every box); the oracle-based form -- whose numpy sums over 1e5 terms depend on the host's library -- runs on
+    request (PAROPT_SWEEP_LARGE_ORACLE=1) and in the campaign (python tests/test_gpu_random_sweep.py)."""
+    if os.environ.get("PAROPT_SWEEP_LARGE_ORACLE", "0") != "1" and "PAROPT_SWEEP_LARGE_CASES" not in os.environ:
+        pytest.skip("oracle-based large-n sweep: on request (PAROPT_SWEEP_LARGE_ORACLE=1); the suite uses the reference fixture")
     _compare_case_with_oracle(ctx, 20000 + idx, large_cases()[idx])
 
 
@@ -587,6 +592,7 @@ def test_random_quasi_newton_sequence_against_oracle(ctx, idx):
 
 
 if __name__ == "__main__":  # python tests/test_gpu_random_sweep.py: the campaign with one line per failing case
+    os.environ.setdefault("PAROPT_SWEEP_LARGE_ORACLE", "1")  # (the campaign runs the oracle-based large-n draws)
     c = _make_ctx()
     nbad = 0
     for i in range(NCASES):

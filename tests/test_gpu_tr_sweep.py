@@ -220,6 +220,8 @@ def test_random_trust_region_case_against_reference_fixture(ctx, idx):
 if __name__ == "__main__":
     import paropt_amd as pa
 
+    os.environ.setdefault("PAROPT_TR_SWEEP_ORACLE", "1")
+
     c = pa.Context(0)
     nbad = nskip = 0
     for i, case in enumerate(cases()):
