@@ -69,8 +69,11 @@ def test_no_vector_register_spills(meta):
 def test_hot_kernels_of_the_metric_fit_their_occupancy(meta):
     """The instantiations config 3 runs: register counts within the budget of the occupancy they
     are compiled for (512 / OCC per lane, unified file)."""
+    # (round 5: the tiled group kernels are launched eight workgroups per CU -- 64 registers per lane; left to itself
+    # the compiler took 88-106 and five or four of the eight were resident, HISTORY R5.15)
     want = {r"mdot_kernelILi32E": 128, r"wgram_pc_kernelILi11ELi3ELi1ELi0E": 256, r"solve2_dots_kernelILi11ELi2ELi1E": 256,
-            r"solve2r_kernelILi1ELi1E": 128}
+            r"solve2r_kernelILi1ELi1E": 128, r"group_sum_tiled_kernelILi[01]E": 64, r"group_k0_tiled_kernel": 64,
+            r"wgram_pc64_kernelILi(17|18|19|20)E": 256}
     for pat, budget in want.items():
         hits = [(n, v) for n, v in meta.items() if re.search(pat, n)]
         assert hits, pat
