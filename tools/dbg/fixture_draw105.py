@@ -1,3 +1,6 @@
+"""Draw 105 of the compiled reference's fixture (tests/golden/sweep_reference_s424242_n400.npz), the one the suite skips by
+name: a CSR chain whose diagonal block goes indefinite.  Prints the device's iterations and its iteration table (the
+sparse Cholesky reports the breakdown).  usage: python tools/dbg/fixture_draw105.py"""
 import os, sys
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import test_gpu_random_sweep as T
