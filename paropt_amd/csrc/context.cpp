@@ -26,7 +26,12 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
-static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+double host_now() {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 int dbg_switch(int id, const char *env, int dflt) {
   if (id >= 0 && id < SW_COUNT && g_dbg_switch[id] >= 0) return g_dbg_switch[id];
   const char *e = env ? getenv(env) : nullptr;
@@ -59,6 +64,15 @@ static int alloc_h_red(Ctx *c, size_t doubles) {
       hipHostGetDevicePointer((void **)&c->h_red_dev, c->h_red, 0) != hipSuccess) {
     (void)hipGetLastError();
     c->h_red_dev = nullptr;
+  }
+  // A reallocation that lost the coherence guarantee (or the device alias) takes the flag away with it: results
+  // behind a flag the host has seen must not sit in memory that may be read stale.  Nothing is in
+  // flight here: the buffer is resized at communicator set-up only.
+  if (c->h_flag && (!c->h_red_coherent || !c->h_red_dev)) {
+    (void)hipHostFree(c->h_flag);
+    c->h_flag = c->h_flag_dev = nullptr;
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
+    c->d_ticket = nullptr;
   }
   // the completion flag of the final reduction stages (see Ctx::h_flag): allocated once
   // (without the explicit coherence guarantee the flag is not used at all: results behind a flag the host has seen
@@ -246,6 +260,7 @@ int ctx_create(int device, Ctx **out) {
   PO_HIP(hipGetDeviceProperties(&prop, device));
   po_ctx_s *c = new po_ctx_s();
   c->device = device;
+  c->host_trace = getenv("PAROPT_AMD_HOST_TRACE") != nullptr;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_blocks = c->num_cu * 8;  // upper bound used only to size the partials buffer
   PO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -265,6 +280,15 @@ int ctx_destroy(Ctx *c) {
   if (!c) return PO_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->host_trace && c->rank == 0) {
+    fprintf(stderr,
+            "paropt_amd host trace: %ld synchronising reductions; host time between a result and the next launch "
+            "%.1f us avg (%ld gaps, %.3f s); inside launch calls %.2f us avg (%ld launches, %.3f s); waiting for results "
+            "%.3f s\n",
+            c->n_reductions, c->host_gap_n ? 1e6 * c->host_gap_s / c->host_gap_n : 0.0, c->host_gap_n, c->host_gap_s,
+            c->host_launch_n ? 1e6 * c->host_launch_s / c->host_launch_n : 0.0, c->host_launch_n, c->host_launch_s,
+            c->host_wait_s);
+  }
   if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
   free_overflow(c, nullptr);
   if (c->partials_base) (void)hipFree(c->partials_base);
@@ -357,7 +381,7 @@ static int wait_results(Ctx *c) {
       seen = true;
       break;
     }
-#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
     __builtin_ia32_pause();
 #endif
     if ((spin & 1023) == 1023) {
@@ -380,6 +404,7 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
   int nparts = 1;
   const double *parts = c->h_red;
   c->n_reductions++;
+  const double ht0 = c->host_trace ? host_now() : 0.0;
   static const bool trace = getenv("PAROPT_AMD_SYNC_TRACE") != nullptr;  // development aid: who synchronises?
   if (trace) {
     void *frames[12];
@@ -446,6 +471,11 @@ static int exchange_reduced(Ctx *c, int total, bool pure_sum, const double **par
   }
   *parts_out = parts;
   *nparts_out = nparts;
+  if (c->host_trace) {
+    c->host_t_sync = host_now();
+    c->host_wait_s += c->host_t_sync - ht0;
+    c->host_gap_open = true;
+  }
   return PO_OK;
 }
 
@@ -609,7 +639,12 @@ void batch_abort(Ctx *c) {
   c->mdot_timing_pending = false;
 }
 
-int batch_flush(Ctx *c, const double *keep_partials) {
+int batch_flush(Ctx *c, const double *keep_partials, size_t keep_len) {
+  // where the arena cursor restarts: behind a region the caller still needs (its partials wait for the NEXT final
+  // stage) -- set BEFORE the deferred host work runs, which may issue reductions of its own
+  size_t cursor0 = 0;
+  if (keep_partials && keep_partials >= c->partials_base && keep_partials < c->partials_base + c->partials_cap)
+    cursor0 = (size_t)(keep_partials - c->partials_base) + keep_len;
   if (c->batch_pend.empty()) {
     // nothing queued: deferred host work (if any slipped in) still runs
     std::vector<std::function<void()>> after;
@@ -623,7 +658,7 @@ int batch_flush(Ctx *c, const double *keep_partials) {
   after.swap(c->batch_after);
   const int total = c->batch_cursor;
   c->batch_cursor = 0;
-  c->partials_cursor = 0;
+  c->partials_cursor = cursor0;
   // the final stages of everything queued: ONE launch (same per-slot arithmetic as the single-reduction kernel)
   PO_TRY(launch_reduce_final_multi(c, pend.data(), (int)pend.size()));
   bool pure_sum = true;
@@ -651,10 +686,10 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
   if (queued && c->batch_cursor + nslots > kMaxRed) {
     // The partials of THIS reduction are still waiting in their region.  The flush resets the arena cursor and runs
     // the deferred host work, which may itself issue reductions (ensure_partials moves d_partials / partials_last):
-    // region and length are taken before, and the cursor is put back behind the region afterwards so that nothing
-    // lands on it.
+    // region and length are taken before and handed to the flush, which restarts the cursor BEHIND the region before
+    // that host work runs; the check below only restates it.
     const size_t len = c->partials_last;
-    PO_TRY(batch_flush(c, part));
+    PO_TRY(batch_flush(c, part, len));
     if (part >= c->partials_base && part < c->partials_base + c->partials_cap) {
       const size_t end = (size_t)(part - c->partials_base) + len;
       if (c->partials_cursor < end) c->partials_cursor = end;

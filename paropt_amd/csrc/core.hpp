@@ -78,6 +78,12 @@ struct Ctx {
   unsigned long long red_seq = 0, red_seq_seen = 0;
   int h_red_coherent = 0;                   // h_red / h_flag were allocated with the explicit coherence flags
   long n_flag_waits = 0, n_flag_timeouts = 0;  // polled completions, and those that fell back to the stream sync
+  // development aid (PAROPT_AMD_HOST_TRACE=1, printed when the context is destroyed): host time between the return of
+  // a synchronising reduction and the next kernel launch (what the GPU idles for beyond the round trip itself), the
+  // time spent inside the launch calls, and the time spent waiting for results
+  bool host_trace = false, host_gap_open = false;
+  double host_t_sync = 0.0, host_gap_s = 0.0, host_launch_s = 0.0, host_wait_s = 0.0;
+  long host_gap_n = 0, host_launch_n = 0;
   std::vector<double *> partials_overflow;  // regions handed out while the arena was full (freed after the flush)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
@@ -153,7 +159,7 @@ int reduce_finish(Ctx *c, int nblocks, int nsum, int nmin, int nmax, double *hos
 bool red_direct(const Ctx *c);  // the final stages write straight into the pinned host buffer (no RCCL collective)
 // collective + host sync for everything queued; runs the after_reduce() work in order (keep_partials: an overflow
 // region that is still waiting for its final stage and must survive the flush)
-int batch_flush(Ctx *c, const double *keep_partials = nullptr);
+int batch_flush(Ctx *c, const double *keep_partials = nullptr, size_t keep_len = 0);
 void batch_abort(Ctx *c);  // forget everything queued (error paths)
 // Host work that reads the result of the preceding reduce_finish: immediately outside a batch, at the flush inside.
 template <class F>
@@ -224,10 +230,29 @@ struct BatchScope {
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
 enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_REDO_DT = 2, SW_LEAN_STEP = 3, SW_WGRAM_PRIO = 4,
                  SW_WGRAM_ABLATE = 5, SW_FUSED_MERIT = 6, SW_REDO_DT1 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_LINCOMB_BPC = 10,
-                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_S2D_TWO = 13, SW_COUNT = 14 };  // one entry per use: an A/B run changes one thing
+                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_S2D_TWO = 13, SW_MPC_FUSE = 14, SW_MPC_POLY = 15, SW_COUNT = 16 };  // one entry per use: an A/B run changes one thing
 int dbg_switch(int id, const char *env, int dflt);
+double host_now();  // seconds, monotonic
+// around a kernel launch when Ctx::host_trace is on (see Ctx): begin closes the gap behind the last synchronisation
+inline double host_trace_begin(Ctx *c);
+inline void host_trace_end(Ctx *c, double t0);
 void dbg_switch_set(int id, int value);  // value < 0: back to environment / default
 int ensure_partials(Ctx *c, size_t doubles);
+inline double host_trace_begin(Ctx *c) {
+  if (!c->host_trace) return 0.0;
+  const double t = host_now();
+  if (c->host_gap_open) {
+    c->host_gap_s += t - c->host_t_sync;
+    c->host_gap_n++;
+    c->host_gap_open = false;
+  }
+  return t;
+}
+inline void host_trace_end(Ctx *c, double t0) {
+  if (!c->host_trace) return;
+  c->host_launch_s += host_now() - t0;
+  c->host_launch_n++;
+}
 // `streams` n-sized fp64 operand streams read or written by the launch being issued
 inline void count_bytes(Ctx *c, double streams, int64_t n) {
   const double b = 8.0 * streams * (double)n;
@@ -362,6 +387,18 @@ int k_dinv_d1(Ctx *c, const Bounds &b, double diag, const double *hdiag, const d
 // Mehrotra corrector products of the affine step (addMehrotraCorrectorResidual :1765-1788)
 int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 int64_t n, double *cl, double *cu);
+// predictor-corrector strategy, corrector right-hand side in ONE pass (round 6): k_corrector + k_d1 + k_mdot with the
+// bits of that sequence; (cl, cu) are not stored (k_solve2c re-forms them).  out = P^T t [nv], nv <= kCorrDotsMax
+constexpr int kCorrDotsMax = 15;
+int k_corr_d1_dots(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu, const double *rx,
+                   const double *dinv, double beta_mu, const double *const *V, int nv, int64_t n, double *t,
+                   double *out);
+// ... and the corrector solve that follows: k_solve2 (first solve, corrector terms re-formed from the affine step in
+// (px, pzl, pzu), which it overwrites) + the sums of k_comp_merit in polynomial form.
+// out[12] = {S10, S01, S11, ppos, pneg, g.px, px.px, pos log, neg log | max_x, max_z | max|px|}
+int k_solve2c(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+              const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px, double *pzl,
+              double *pzu, double *va, int nca, const double *g, int want_logs, double out[12]);
 // Second half of the bordered solve.  acc = sum_j alpha_j P_j ; dx = t + Dinv*acc.
 //   first solve  (refine == 0): px = dx; pzl = [L](rzl - zl dx)/(x-lb); pzu = [U](rzu + zu dx)/(ub-x)
 //   refinement   (refine == 1): r'zl = rzl - [L]((x-lb) pzl + px zl), r'zu likewise;

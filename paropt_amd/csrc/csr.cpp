@@ -594,10 +594,15 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   PO_HIP(hipSetDevice(ctx->device));
   if (vals != data) dfree(vals);
   vals = nullptr;
-  dfree(data);
   const size_t vbytes = ((size_t)nnz + 4) * sizeof(double);
-  PO_HIP(hipMalloc((void **)&data, vbytes));
-  PO_HIP(hipMemset(data, 0, vbytes));
+  if (adopt_data) {  // upgradeFromLight: the user-visible value array (and what the user wrote into it) stays
+    data = adopt_data;
+    adopt_data = nullptr;
+  } else {
+    dfree(data);
+    PO_HIP(hipMalloc((void **)&data, vbytes));
+    PO_HIP(hipMemset(data, 0, vbytes));
+  }
   if (sym.identity_src) {
     vals = data;
   } else {
@@ -643,9 +648,14 @@ int CsrSparse::setPattern(const int *rowp, const int *cols) {
   PO_HIP(hipMemset(ones, 0, ((size_t)w + 4) * sizeof(double)));
   PO_HIP(hipDeviceSynchronize());
   PO_TRY(k_fill(ctx, ones, w, 1.0));
-  if (cw) vec_decref(cw);
-  cw = vec_new(ctx, w);
-  if (!cw) return PO_ERR_HIP;
+  if (adopt_cw) {  // (the same Vec object: handles the user holds stay valid)
+    cw = adopt_cw;
+    adopt_cw = nullptr;
+  } else {
+    if (cw) vec_decref(cw);
+    cw = vec_new(ctx, w);
+    if (!cw) return PO_ERR_HIP;
+  }
   nlevels_f = (int)sym.fwd_ptr.size() - 1;
   spmv_group = group_for(w > 0 ? (double)nnz / (double)w : 0.0);
   spmvT_group = group_for(n > 0 ? (double)nnz / (double)n : 0.0);
@@ -673,22 +683,28 @@ int CsrSparse::setPatternLight(const int *rowp, const int *cols) {
 
 int CsrSparse::upgradeFromLight() {
   if (!light) return PO_OK;
-  // keep what the user wrote: the analysis reallocates the value array
-  double *keep = data;
-  Vec *keep_cw = cw;
+  // The analysis runs after all.  The user-visible value array `data` (po_problem_get_sparse_jacobian_data hands it
+  // out as a borrowed pointer, like the reference's getSparseJacobianData) and the constraint-value vector `cw` are
+  // ADOPTED by setPattern, not reallocated: a caller that cached either keeps a valid pointer, and what the gradient
+  // callback just wrote stays in place.
+  adopt_data = data;
+  adopt_cw = cw;
   data = nullptr;
   vals = nullptr;
   cw = nullptr;
   light = false;
   const std::vector<int> rp(user_rowp), cl(user_cols);
   int rc = setPattern(rp.data(), cl.data());
-  if (rc == PO_OK && nnz > 0 &&
-      hipMemcpyAsync(data, keep, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-    rc = PO_ERR_HIP;
-  if (rc == PO_OK && keep_cw && cw) rc = k_copy(ctx, cw->d, keep_cw->d, w);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipFree(keep);
-  if (keep_cw) vec_decref(keep_cw);
+  if (adopt_data) {  // setPattern failed before it took them over
+    data = adopt_data;
+    adopt_data = nullptr;
+    if (!vals) vals = data;
+  }
+  if (adopt_cw) {
+    if (cw && cw != adopt_cw) vec_decref(cw);
+    cw = adopt_cw;
+    adopt_cw = nullptr;
+  }
   return rc;
 }
 
@@ -710,6 +726,10 @@ int CsrSparse::innerProduct(double alpha, const double *cvec, double *out) {
 }
 
 int CsrSparse::colSum(double scale, const double *y, double *out) {
+  if (light) {  // no transposed index was built (setPatternLight): the caller owns the grouped form of this product
+    set_error("CsrSparse::colSum on a light (grouped) pattern");
+    return PO_ERR_ARG;
+  }
   return k_csr_colsum(ctx, d_colp, d_rowsT, n, scale, y, out);
 }
 

@@ -69,6 +69,8 @@ class CsrSparse {
   int setPatternLight(const int *rowp, const int *cols);
   int upgradeFromLight();
   bool light = false;
+  double *adopt_data = nullptr;  // upgradeFromLight -> setPattern: keep these allocations instead of new ones
+  Vec *adopt_cw = nullptr;
   // the user's value array in the user's entry order (device, nnz doubles) and the constraint values
   double *data = nullptr;
   Vec *cw = nullptr;

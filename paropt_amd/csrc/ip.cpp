@@ -705,7 +705,8 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   PO_TRY(wbatch.end());
   // test aid: a relative perturbation of 1e-9 in one Gram entry, which the known-answer tests must detect
   // (tests/test_gpu_kat.py::test_kat_detects_a_perturbed_gram)
-  if (m > 1 && dbg_switch(SW_PERTURB_W, "PAROPT_AMD_PERTURB_W", 0) != 0) {
+  // -- reachable only through po_debug_set_switch and only inside po_ip_debug_kkt (no environment variable)
+  if (m > 1 && debug_keep_schur && dbg_switch(SW_PERTURB_W, nullptr, 0) != 0) {
     W[1] *= 1.0 + 1e-9;
     W[m] = W[1];
   }
@@ -715,7 +716,7 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   for (int j = 0; j < c; j++)
     for (int i = 0; i < c; i++) Gf[i + (size_t)c * j] = W[i + (size_t)m * j];
   for (int i = 0; i < c; i++) Gf[(size_t)i * (c + 1)] += vars.s[i] / vars.zs[i] + vars.t[i] / vars.zt[i];
-  Gmat0 = Gf;
+  if (debug_keep_schur) Gmat0 = Gf;  // as assembled, for po_ip_debug_kkt only
   if (c > 0) lu_factor(c, Gf.data(), c, gpiv.data());
   // Ce = W_ZZ - W_ZA G^-1 W_AZ - M / (d0 d0^T)   (:2634-2667 via SURVEY.md 3.4)
   Cef.clear();
@@ -737,7 +738,7 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
         Cef[i + (size_t)k * j] = v;
       }
     }
-    Ce0 = Cef;
+    if (debug_keep_schur) Ce0 = Cef;
     lu_factor(k, Cef.data(), k, cpiv.data());
   } else {
     Ce0.clear();
@@ -769,13 +770,30 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
       have_panel = true;
     }
   };
-  const double *cl = (corrector_active && !refine_pass) ? s_qn->d : nullptr;
-  const double *cu = (corrector_active && !refine_pass) ? y_qn->d : nullptr;
+  const bool corr = corrector_active && !refine_pass;
+  // (corrector_fused: the corrector products are formed inside the two passes below from the affine step in
+  // (px, pzl, pzu), nothing was stored in s_qn / y_qn)
+  const bool corr_fused = corr && corrector_fused && m >= 1 && m <= kCorrDotsMax;
+  const double *cl = (corr && !corr_fused) ? s_qn->d : nullptr;
+  const double *cu = (corr && !corr_fused) ? y_qn->d : nullptr;
+  if (corr && corrector_fused && !corr_fused) {
+    set_error("internal: fused corrector solve with a panel of %d columns", m);
+    return PO_ERR_ARG;
+  }
   // t = Dinv o d1 and P^T t were produced by setUpKKTSystem's Gram pass when the right-hand side was known then
-  const bool have_t0 = !refine_pass && t0_valid && t0_mu == mu && !cl && (int)t0dots.size() == m;
-  if (!refine_pass && !have_t0) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
+  const bool have_t0 = !refine_pass && t0_valid && t0_mu == mu && !corr && (int)t0dots.size() == m;
   std::vector<double> dots(m > 0 ? m : 1, 0.0);
-  if (have_t0) {
+  if (corr_fused) {
+    // corrector products, t = Dinv o d1 and P^T t in ONE pass (the bits of k_corrector + k_d1 + k_mdot)
+    need_panel();
+    PO_TRY(k_corr_d1_dots(ctx, bounds(), px->d, pzl->d, pzu->d, rx->d, Dinv->d, beta_mu, P.data(), m, n, tvec->d,
+                          dots.data()));
+  } else if (!refine_pass && !have_t0) {
+    PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
+  }
+  if (corr_fused) {
+    // (dots are in place)
+  } else if (have_t0) {
     for (int i = 0; i < m; i++) dots[i] = t0dots[i];
   } else if (refine_pass && tdots_valid && (int)tdots.size() == m) {
     dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
@@ -851,7 +869,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
   std::vector<const double *> Yp, Sp;
   std::vector<double *> Zo;
   double b0z = 0.0;
-  const bool first_fused = fuse && fused_dots && m > 0 && !cl;
+  const bool first_fused = fuse && fused_dots && m > 0 && !corr;
   const bool virt = virtual_z && recompute_first_step && recompute_rhs && !have_panel && k > 0 && k <= kMaxVirt &&
                     (first_fused || (refine_pass && step_deferred && virt_first)) && qn &&
                     qn->pendingZ(&Yp, &Sp, &Zo, &b0z) && (int)Yp.size() == k;
@@ -909,7 +927,7 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     step_deferred = false;
     // the same sweep takes the sums the complementarity check of scaleKKTStep and the merit derivative need of the
     // final step (see solve2r_kernel): no separate pass over the step afterwards
-    const bool take_merit = fuse_merit && recompute_rhs && !cl && dbg_switch(SW_FUSED_MERIT, nullptr, 1) != 0;
+    const bool take_merit = fuse_merit && recompute_rhs && !corr && dbg_switch(SW_FUSED_MERIT, nullptr, 1) != 0;
     const double *gm = take_merit ? g->d : nullptr;
     double *mo = take_merit ? fused_merit : nullptr;
     // lean step: (pzl, pzu) stay in registers; their only consumer left, the multiplier update, re-forms them
@@ -941,6 +959,25 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
         fused_merit_valid = true;
       });
     }
+  } else if (corr_fused) {
+    step_deferred = false;
+    // corrector solve: the corrector terms re-formed from the affine step this pass overwrites, and the sums of
+    // scaleKKTStep / evalMeritInitDeriv of the step it has in registers (k_comp_merit and its round trip disappear)
+    const bool want_logs = !iterate_logs_valid;
+    PO_TRY(k_solve2c(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu, tau, n, px->d, pzl->d,
+                     pzu->d, vA->d, c, g->d, want_logs ? 1 : 0, corr_out));
+    after_reduce(ctx, [this, want_logs] {
+      for (int i = 0; i < 7; i++) fused_merit[i] = corr_out[i];
+      fused_merit[7] = step_mins[0] = corr_out[9];
+      fused_merit[8] = step_mins[1] = corr_out[10];
+      fused_merit[9] = corr_out[11];
+      if (want_logs) {  // the barrier sums of the iterate, as k_comp_merit takes them
+        iterate_logs[0] = corr_out[7];
+        iterate_logs[1] = corr_out[8];
+        iterate_logs_valid = true;
+      }
+      fused_merit_valid = true;
+    });
   } else {
     if (!refine_pass) step_deferred = false;
     PO_TRY(k_solve2(ctx, bounds(), tvec->d, Dinv->d, alpha.data(), P.data(), m, beta_mu,
@@ -1241,6 +1278,11 @@ int InteriorPoint::debugSetState(const double *z, const double *s, const double 
 }
 
 int InteriorPoint::debugKKT(double mu, int mode, double tau) {
+  struct KeepSchur {  // G and Ce as assembled are copied for the dump of THIS call only
+    bool &f;
+    explicit KeepSchur(bool &f_) : f(f_) { f = true; }
+    ~KeepSchur() { f = false; }
+  } keep(debug_keep_schur);
   if (mode == 0) {
     PO_TRY(debugKKTStep(mu));
   } else {
@@ -2206,7 +2248,15 @@ int InteriorPoint::optimize(const char *checkpoint) {
         if (step.zt[i] < 0.0) max_z = std::min(max_z, -vars.zt[i] / step.zt[i]);
       }
       double cs[2];
-      PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
+      if (fused_merit_valid && !has_w && dbg_switch(SW_MPC_POLY, "PAROPT_AMD_MPC_POLY", 1) != 0) {
+        // the refinement pass of the affine solve took the complementarity polynomial of its step (solve2r_kernel):
+        // S00 + ax S10 + az S01 + ax az S11 at the probe lengths, S00 / the bound count from the residual pass of this
+        // iterate -- no pass over the step and no host round trip (round 6; scaleKKTStep uses the same form)
+        cs[0] = comp_prod + max_x * fused_merit[0] + max_z * fused_merit[1] + max_x * max_z * fused_merit[2];
+        cs[1] = comp_count;
+      } else {
+        PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
+      }
       double prod = cs[0] / options.real("rel_bound_barrier"), count = cs[1];
       if (has_w) {
         double wprod = 0.0;
@@ -2230,7 +2280,10 @@ int InteriorPoint::optimize(const char *checkpoint) {
       if (barrier_strategy == B_MPC) {
         // corrector: res.zl -= px*pzl, res.zu += px*pzu, res.zs -= ps*pzs, res.zt -= pt*pzt of the
         // affine step (:1729-1789); no refinement with the corrector (:5040-5041)
-        PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
+        // (one-pass corrector right-hand side + corrector solve with the merit sums: see solveKKT)
+        corrector_fused = !has_w && c + wk >= 1 && c + wk <= kCorrDotsMax && use_line_search &&
+                          dbg_switch(SW_MPC_FUSE, "PAROPT_AMD_MPC_FUSE", 1) != 0;
+        if (!corrector_fused) PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
         denseResidual(barrier_param, res);
         for (int i = 0; i < c; i++) {
           res.zs[i] -= step.s[i] * step.zs[i];
@@ -2244,6 +2297,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
         int rcs = has_w ? solveKKTW(res, barrier_param, use_qn, false, tau, step)
                         : solveKKT(res, barrier_param, use_qn, false, tau, step);
         corrector_active = false;
+        corrector_fused = false;
         PO_TRY(rcs);
         sx = sz = 1.0;
       } else {

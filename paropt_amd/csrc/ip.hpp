@@ -99,7 +99,8 @@ class InteriorPoint {
   //         L-SR1 columns), first solve pass with the refinement's products, refinement pass -- with the
   //         bound-multiplier steps stored.  Afterwards the matrices AS ASSEMBLED are kept in Gmat0 / Ce0.
   int debugKKT(double mu, int mode, double tau);
-  std::vector<double> Gmat0, Ce0;   // G and Ce before their LU factorizations (last setUpKKTSystem)
+  std::vector<double> Gmat0, Ce0;   // G and Ce before their LU factorizations (filled inside debugKKT only)
+  bool debug_keep_schur = false;
   double debug_norms[4] = {0, 0, 0, 0};  // max_prime, max_dual, max_infeas, res_norm of the last debugKKT
   const std::vector<double> &gramMatrix() const { return W; }
   const std::vector<int> &cPivots() const { return cpiv; }
@@ -175,6 +176,10 @@ class InteriorPoint {
   bool residual_fused;  // the last first-pass solve already wrote the refinement rhs t'
   bool residual_cached; // rx / norms of the CURRENT state were already evaluated (step update)
   bool corrector_active;  // Mehrotra predictor-corrector: s_qn / y_qn hold the corrector products
+  // ... unless the corrector solve forms them itself (round 6: k_corr_d1_dots + k_solve2c, two launches and two host
+  // round trips instead of five and three); corr_out: what k_solve2c reduced
+  bool corrector_fused = false;
+  double corr_out[12] = {0};
   int norm_type;          // 0 infinity, 1 l1, 2 l2 (ParOptNormType)
   std::vector<double> tdots;  // P^T t' produced by the fused first solve pass
   bool tdots_valid;

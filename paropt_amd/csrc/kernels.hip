@@ -254,10 +254,12 @@ int grid_for(Ctx *c, int64_t n, int bpc) {
 }
 int grid_for(Ctx *c, int64_t n) { return grid_for(c, n, kBpcStream); }
 
-#define PO_LAUNCH(kernel, grid, ...)                                                      \
+#define PO_LAUNCH(kernel, grid, ...)                                                     \
   do {                                                                                    \
+    const double _ht0 = host_trace_begin(c);                                              \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, __VA_ARGS__);      \
     c->n_launches++;                                                                      \
+    host_trace_end(c, _ht0);                                                              \
     PO_HIP(hipGetLastError());                                                            \
   } while (0)
 
@@ -1219,6 +1221,71 @@ int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, co
   if (n <= 0) return PO_OK;
   PO_LAUNCH(corrector_kernel, grid_for(c, n), b, px, pzl, pzu, n, cl, cu);
   return PO_OK;
+}
+
+// Corrector right-hand side of the predictor-corrector strategy in ONE pass (round 6): the corrector products of the
+// affine step (corrector_kernel), t = Dinv o d1 with them (d1_kernel) and the panel products P^T t (mdot_kernel) --
+// three launches, two n-sized writes (cl, cu) and their re-reads, and the re-read of t by the product pass.  Same
+// expressions, same grid and per-thread order as those three kernels: the same bits in t and in the products.
+// (cl, cu) are not stored: the corrector solve (solve2c_kernel) re-forms them from the affine step it overwrites.
+template <int NVB>
+__global__ void __launch_bounds__(kBlock)
+    corr_d1_dots_kernel(Bounds b, const double *__restrict__ px, const double *__restrict__ pzl,
+                        const double *__restrict__ pzu, const double *__restrict__ rx,
+                        const double *__restrict__ dinv, double beta_mu, PtrTable V, int64_t n,
+                        double *__restrict__ t, double *__restrict__ partials) {
+  __shared__ double sm[4 * NVB];
+  double acc[NVB];
+  const double *vp[NVB];
+#pragma unroll
+  for (int j = 0; j < NVB; j++) {
+    acc[j] = 0.0;
+    vp[j] = V.p[j];
+  }
+  PO_PAIR_LOOP(q, n) {
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 p = ld2(px, q, n), l = ld2(pzl, q, n), u = ld2(pzu, q, n);
+    const double2 r = ld2(rx, q, n), dv = ld2(dinv, q, n);
+    // (explicitly rounded products: corrector_kernel stores them, and a product contracted into the subtraction of
+    // d1_elem would be another number)
+    const double c0x = e0.L ? __dmul_rn(p.x, l.x) : 0.0, c0y = e1.L ? __dmul_rn(p.y, l.y) : 0.0;
+    const double c1x = e0.U ? __dmul_rn(p.x, u.x) : 0.0, c1y = e1.U ? __dmul_rn(p.y, u.y) : 0.0;
+    double2 tv = make_double2(__dmul_rn(dv.x, d1_elem(e0, r.x, beta_mu, c0x, c1x)),
+                              __dmul_rn(dv.y, d1_elem(e1, r.y, beta_mu, c0y, c1y)));
+    if (!_has2) tv.y = 0.0;  // what st2 stores, and what the product pass would have read back
+    st2(t, q, n, tv);
+#pragma unroll
+    for (int j = 0; j < NVB; j++) {
+      const f64x2 w = ld_stream(vp[j] + 2 * q);
+      acc[j] = fma(tv.x, w.x, fma(tv.y, w.y, acc[j]));
+    }
+  }
+  block_reduce_store<NVB, OP_SUM>(acc, partials, 0, sm);
+}
+
+#define PO_CORR_CASE(NVB)                                                                              \
+  case NVB:                                                                                            \
+    PO_LAUNCH(corr_d1_dots_kernel<NVB>, grid, b, px, pzl, pzu, rx, dinv, beta_mu, pt, n, t, c->d_partials); \
+    break;
+int k_corr_d1_dots(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu, const double *rx,
+                   const double *dinv, double beta_mu, const double *const *V, int nv, int64_t n, double *t,
+                   double *out) {
+  if (nv < 1 || nv > kCorrDotsMax) {
+    set_error("k_corr_d1_dots: %d panel columns (1..%d)", nv, kCorrDotsMax);
+    return PO_ERR_ARG;
+  }
+  count_bytes(c, nv + 11, n);
+  const int grid = grid_for(c, n, 5);  // mdot's grid: the products come out with mdot's bits
+  PO_TRY(ensure_partials(c, (size_t)grid * nv));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(nullptr, V, nv, &ct, &pt);
+  switch (nv) {
+    PO_CORR_CASE(1) PO_CORR_CASE(2) PO_CORR_CASE(3) PO_CORR_CASE(4) PO_CORR_CASE(5) PO_CORR_CASE(6) PO_CORR_CASE(7)
+    PO_CORR_CASE(8) PO_CORR_CASE(9) PO_CORR_CASE(10) PO_CORR_CASE(11) PO_CORR_CASE(12) PO_CORR_CASE(13)
+    PO_CORR_CASE(14) PO_CORR_CASE(15)
+  }
+  return reduce_finish(c, grid, nv, 0, 0, out);
 }
 
 // second half of the bordered solve ------------------------------------------------------------
@@ -2352,6 +2419,97 @@ int k_comp_merit(Ctx *c, const Bounds &b, const double *px, const double *pzl, c
   PO_TRY(ensure_partials(c, (size_t)grid * 9));
   PO_LAUNCH(comp_merit_kernel, grid, b, px, pzl, pzu, ax, az, g, n, c->d_partials);
   return reduce_finish(c, grid, 8, 0, 1, out);
+}
+
+// Corrector solve of the predictor-corrector strategy (round 6): solve2_kernel<0, 0> with the corrector terms re-formed
+// from the affine step it overwrites (cl = [L] px pzl, cu = [U] px pzu: corrector_kernel's expressions), plus every
+// sum scaleKKTStep's complementarity check and evalMeritInitDeriv need of the step it has in registers -- the separate
+// pass comp_merit_kernel and its host round trip disappear.  The complementarity at the scaled step is the polynomial
+// S00 + ax S10 + az S01 + ax az S11 of solve2r_kernel; the merit pieces and the barrier sums of the iterate are taken
+// element by element as comp_merit_kernel takes them, on comp_merit_kernel's grid.
+// slots: sums {S10, S01, S11, ppos, pneg, g.px, px.px, pos log, neg log}, minima {max_x, max_z}, maximum {|px|}
+__global__ void __launch_bounds__(kBlock)
+    solve2c_kernel(Bounds b, const double *__restrict__ t, const double *__restrict__ dinv, CoefTable alpha, PtrTable P,
+                   int nv, double beta_mu, double tau, int64_t n, double *__restrict__ px, double *__restrict__ pzl,
+                   double *__restrict__ pzu, double *__restrict__ va, int nca, const double *__restrict__ g,
+                   int want_logs, double *__restrict__ partials) {
+  __shared__ double sm[4 * 9];
+  double mins[2] = {1.0, 1.0};
+  double ms[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double mx[1] = {0.0};
+  PO_PAIR_LOOP(q, n) {
+    const double2 accA = panel_sum(P, alpha, nca, q);
+    if (va) st2(va, q, n, accA);
+    double2 acc = panel_sum(P, alpha, nv, q, nca);
+    acc.x += accA.x;
+    acc.y += accA.y;
+    PO_LOAD_BOUNDS(b, q, n);
+    const double2 tv = ld2(t, q, n), dv = ld2(dinv, q, n);
+    const double dx0 = tv.x + dv.x * acc.x, dx1 = tv.y + dv.y * acc.y;
+    const double2 pa = ld2(px, q, n), la = ld2(pzl, q, n), ua = ld2(pzu, q, n);  // the affine step
+    const double c0x = e0.L ? __dmul_rn(pa.x, la.x) : 0.0, c0y = e1.L ? __dmul_rn(pa.y, la.y) : 0.0;  // (rounded: see
+    const double c1x = e0.U ? __dmul_rn(pa.x, ua.x) : 0.0, c1y = e1.U ? __dmul_rn(pa.y, ua.y) : 0.0;  // corr_d1_dots_kernel)
+    const Step3 s0 = solve2_elem<0>(e0, dx0, beta_mu, 0.0, 0.0, 0.0, c0x, c1x);
+    Step3 s1 = solve2_elem<0>(e1, dx1, beta_mu, 0.0, 0.0, 0.0, c0y, c1y);
+    if (!_has2) s1.px = s1.pzl = s1.pzu = 0.0;
+    st2(px, q, n, make_double2(s0.px, s1.px));
+    st2(pzl, q, n, make_double2(s0.pzl, s1.pzl));
+    st2(pzu, q, n, make_double2(s0.pzu, s1.pzu));
+    max_step_elem(b, _x.x, _lb.x, _ub.x, _zl.x, _zu.x, s0, tau, mins[0], mins[1]);
+    if (_has2) max_step_elem(b, _x.y, _lb.y, _ub.y, _zl.y, _zu.y, s1, tau, mins[0], mins[1]);
+    const double2 gv = ld2(g, q, n);
+    if (e0.L) {
+      ms[0] += _zl.x * s0.px;
+      ms[1] += s0.pzl * e0.xl;
+      ms[2] += s0.pzl * s0.px;
+    }
+    if (e1.L) {
+      ms[0] += _zl.y * s1.px;
+      ms[1] += s1.pzl * e1.xl;
+      ms[2] += s1.pzl * s1.px;
+    }
+    if (e0.U) {
+      ms[0] -= _zu.x * s0.px;
+      ms[1] += s0.pzu * e0.xu;
+      ms[2] -= s0.pzu * s0.px;
+    }
+    if (e1.U) {
+      ms[0] -= _zu.y * s1.px;
+      ms[1] += s1.pzu * e1.xu;
+      ms[2] -= s1.pzu * s1.px;
+    }
+    if (want_logs) {
+      barrier_elem(e0, ms[7], ms[8]);
+      barrier_elem(e1, ms[7], ms[8]);
+    }
+    if (e0.L) { if (s0.px > 0.0) ms[3] += s0.px / e0.xl; else ms[4] += s0.px / e0.xl; }
+    if (e1.L) { if (s1.px > 0.0) ms[3] += s1.px / e1.xl; else ms[4] += s1.px / e1.xl; }
+    if (e0.U) { if (s0.px > 0.0) ms[4] -= s0.px / e0.xu; else ms[3] -= s0.px / e0.xu; }
+    if (e1.U) { if (s1.px > 0.0) ms[4] -= s1.px / e1.xu; else ms[3] -= s1.px / e1.xu; }
+    ms[5] += gv.x * s0.px + gv.y * s1.px;
+    ms[6] += s0.px * s0.px + s1.px * s1.px;
+    mx[0] = fmax(mx[0], fmax(fabs(s0.px), fabs(s1.px)));
+  }
+  block_reduce_store<9, OP_SUM>(ms, partials, 0, sm);
+  block_reduce_store<2, OP_MIN>(mins, partials, 9, sm);
+  block_reduce_store<1, OP_MAX>(mx, partials, 11, sm);
+}
+int k_solve2c(Ctx *c, const Bounds &b, const double *t, const double *dinv, const double *alpha,
+              const double *const *P, int nv, double beta_mu, double tau, int64_t n, double *px, double *pzl,
+              double *pzu, double *va, int nca, const double *g, int want_logs, double out[12]) {
+  if (nv > kMaxPanel) {
+    set_error("k_solve2c: panel of %d vectors exceeds kMaxPanel=%d", nv, kMaxPanel);
+    return PO_ERR_ARG;
+  }
+  count_bytes(c, nv + 14 + (va ? 1 : 0), n);
+  const int grid = grid_for(c, n);  // comp_merit_kernel's grid
+  PO_TRY(ensure_partials(c, (size_t)grid * 12));
+  PtrTable pt;
+  CoefTable ct;
+  fill_tables(alpha, P, nv, &ct, &pt);
+  PO_LAUNCH(solve2c_kernel, grid, b, t, dinv, ct, pt, nv, beta_mu, tau, n, px, pzl, pzu, va, nca, g, want_logs,
+            c->d_partials);
+  return reduce_finish(c, grid, 9, 2, 1, out);
 }
 
 __device__ __forceinline__ double clamp_elem(double v, bool has_l, double lb, bool has_u, double ub,

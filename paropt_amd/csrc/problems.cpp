@@ -597,7 +597,12 @@ int SeparableProblem::chainHessian(Vec *zw, Vec *px, Vec *h) {
   if (!csr || !zw) return PO_OK;
   if (!chain_tmp) chain_tmp = vec_new(ctx, nlocal);
   if (!chain_tmp) return PO_ERR_HIP;
-  PO_TRY(csr->colSum(2.0, zw->d, chain_tmp->d));
+  // a recognised chain (stride >= span, uniform entries) keeps the light pattern: no transposed index on the device.
+  // Its rows are the groups of gmap, so the column sums are the group scatter (same value per entry: 2 zw_g).
+  if (grouped || csr->light)
+    PO_TRY(k_group_scatter_set(ctx, gmap, chain_tmp->d, 2.0, zw->d, nlocal));
+  else
+    PO_TRY(csr->colSum(2.0, zw->d, chain_tmp->d));
   if (px) PO_TRY(k_mul(ctx, chain_tmp->d, 1.0, chain_tmp->d, px->d, nlocal));
   return k_axpy(ctx, h->d, 1.0, chain_tmp->d, nlocal);
 }

@@ -17,8 +17,10 @@ namespace po {
 
 #define PO_WLAUNCH(kernel, grid, ...)                                                     \
   do {                                                                                    \
+    const double _ht0 = host_trace_begin(c);                                              \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, __VA_ARGS__);      \
     c->n_launches++;                                                                      \
+    host_trace_end(c, _ht0);                                                              \
     PO_HIP(hipGetLastError());                                                            \
   } while (0)
 

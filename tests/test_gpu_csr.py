@@ -487,3 +487,41 @@ def test_quasidef_solve_random_soak(ctx):
         yx_ref = d * (bx + A.T @ yw_ref)
         np.testing.assert_allclose(yx.to_numpy(), yx_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(yx_ref).max()))
     assert worst <= 1e-9
+
+
+def test_borrowed_jacobian_pointer_survives_the_grouped_fallback(ctx):
+    """getSparseJacobianData hands out the value array as a borrowed pointer (reference
+    src/ParOptProblem.cpp:689-703: valid for the problem's lifetime).  A chain with stride >= span is recognised as the
+    grouped pattern and, at the first gradient evaluation with non-uniform entries, falls back to the general CSR path
+    in the middle of optimize() -- the analysis then ADOPTS the value array instead of reallocating it: the pointer a
+    caller cached before is still the array the library reads, and it holds the entries of the last evaluation."""
+    import paropt_amd as pa
+    from paropt_amd import lib as L
+
+    n = 64
+    prob = pa.SeparableProblem(ctx, "quadratic", n, 3)
+    prob.setChain(2, 3)  # non-uniform start: immediate fall-back
+
+    def borrowed():
+        rowp, cols = L.c_int_p(), L.c_int_p()
+        data, nnz = C.c_void_p(), C.c_int64()
+        L.check(L.lib.po_problem_get_sparse_jacobian_data(prob._h, C.byref(rowp), C.byref(cols), C.byref(data), C.byref(nnz)))
+        return data.value, nnz.value
+
+    before, nnz = borrowed()
+    assert before and nnz == 2 * ((n - 2) // 3 + 1)
+    ip = pa.InteriorPoint(prob, {"qn_subspace_size": 4, "max_major_iters": 3, "write_output_frequency": 0})
+    ip.optimize()
+    after, nnz2 = borrowed()
+    assert (after, nnz2) == (before, nnz)
+    # the array behind the cached pointer holds the Jacobian of the last gradient evaluation: -2 x on the pattern
+    x = ip.getOptimizedPoint()[0].to_numpy()
+    vals = np.empty(nnz)
+    L.check(L.lib.po_ctx_synchronize(ctx.handle))
+    path = next(line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line)  # the runtime in use
+    hip = C.CDLL(path)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(vals.ctypes.data, before, 8 * nnz, 2) == 0  # device -> host
+    rows = (n - 2) // 3 + 1
+    expect = np.array([-2.0 * x[3 * i + k] for i in range(rows) for k in range(2)])
+    np.testing.assert_allclose(vals, expect, rtol=0, atol=1e-14)

@@ -1197,3 +1197,66 @@ def test_first_solve_pass_two_tiles_per_step_keeps_every_bit(ctx, case):
         np.testing.assert_array_equal(va, vb)
     table = lambda h: [ln for ln in h.splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
     assert len(table(a[5])) >= 8 and table(a[5]) == table(b[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["seq_lin_c3", "bfgs_c3", "seq_lin_c5_large", "quadratic_odd_small"])
+def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
+    """Round 6: under mehrotra_predictor_corrector the corrector right-hand side is ONE pass (corr_d1_dots_kernel: the
+    bits of corrector + d1 + mdot), the corrector solve takes the sums of scaleKKTStep / evalMeritInitDeriv itself
+    (solve2c_kernel: same step, polynomial complementarity) and the affine step's complementarity comes from the
+    polynomial its refinement pass took -- 3 launches and one to two host round trips per iteration less.  Against the
+    plain sequence (debug switches 14 / 15 = 0) in the same process on convergent iterations: counters and table tokens
+    equal, iterates to round-off (the merit sums are cut differently and the polynomial re-associates the
+    complementarity: 1e-16-level changes in the barrier parameter and the merit derivative)."""
+    import paropt_amd as pa
+    from paropt_amd import lib as L
+
+    SW_MPC_FUSE, SW_MPC_POLY = 14, 15
+    cfg = {
+        "seq_lin_c3": dict(kind="convex", n=20001, c=3, iters=16, opts={"qn_type": "bfgs", "qn_subspace_size": 3,
+                                                                         "sequential_linear_method": True}),
+        "bfgs_c3": dict(kind="quadratic", n=300, c=3, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 10}),
+        # (more than one pair per thread: the grids cover 2 x 256 x 4 x 256 and 2 x 256 x 5 x 256 elements per sweep)
+        "seq_lin_c5_large": dict(kind="convex", n=1200003, c=5, iters=24, opts={"qn_type": "bfgs", "qn_subspace_size": 3,
+                                                                                "sequential_linear_method": True}),
+        "quadratic_odd_small": dict(kind="quadratic", n=511, c=2, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 4,
+                                                                                  "sequential_linear_method": True}),
+    }[case]
+
+    def run(fuse, poly):
+        L.lib.po_debug_set_switch(SW_MPC_FUSE, fuse)
+        L.lib.po_debug_set_switch(SW_MPC_POLY, poly)
+        try:
+            prob = pa.SeparableProblem(ctx, cfg["kind"], cfg["n"], cfg["c"], 5)
+            # (every solve starts monotone, reference :4427-4441: the predictor-corrector takes over at the first
+            # barrier reduction)
+            ip = pa.InteriorPoint(prob, dict({"abs_res_tol": 1e-9, "start_affine_multiplier_min": 0.01,
+                                              "max_major_iters": cfg["iters"],
+                                              "barrier_strategy": "mehrotra_predictor_corrector",
+                                              "write_output_frequency": 0}, **cfg["opts"]))
+            sn = []
+            ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+            n0 = ctx.counters()[1]
+            ip.optimize()
+            launches = ctx.counters()[1] - n0
+            x, z, zl, zu = ip.getOptimizedPoint()[:4]
+            return sn, x.to_numpy(), np.array(z), zl.to_numpy(), zu.to_numpy(), ip.getHistory(), launches
+        finally:
+            L.lib.po_debug_set_switch(SW_MPC_FUSE, -1)
+            L.lib.po_debug_set_switch(SW_MPC_POLY, -1)
+
+    a = run(0, 0)
+    for fuse, poly in ((1, 0), (1, 1)):
+        b = run(fuse, poly)
+        assert b[6] < a[6], ("the predictor-corrector phase was not reached, or the fused path not taken", a[6], b[6])
+        assert len(a[0]) == len(b[0]) >= 8
+        for k, (sa, sb) in enumerate(zip(a[0], b[0])):
+            np.testing.assert_array_equal(sa["counters"], sb["counters"], err_msg="counters @%d" % k)
+            assert abs(sa["mu"] - sb["mu"]) <= 1e-9 * abs(sa["mu"]), (k, sa["mu"], sb["mu"])
+            assert abs(sa["fobj"] - sb["fobj"]) <= 1e-9 * max(1.0, abs(sa["fobj"])), (k, sa["fobj"], sb["fobj"])
+            np.testing.assert_allclose(sa["norms"], sb["norms"], rtol=1e-9)
+        for va, vb in zip(a[1:5], b[1:5]):
+            np.testing.assert_allclose(va, vb, rtol=0, atol=1e-8 * max(1.0, float(np.abs(va).max())))
+        tokens = lambda h: [ln.split()[15:] for ln in h.splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
+        assert len(tokens(a[5])) >= 8 and tokens(a[5]) == tokens(b[5])

@@ -190,6 +190,12 @@ RECOGNISED_CHAINS = [
      None, {"chain": (2, 5)}),
     ("quadratic", 64, 3, dict(_BASE, qn_type="bfgs", qn_subspace_size=4, barrier_strategy="monotone", norm_type="l2"),
      None, {"chain": (2, 3)}),
+    # the Hessian of a recognised chain (2 zw on its variables) is taken while the pattern is still light (no
+    # transposed index on the device): use_diag_hessian evaluates it at the uniform start, before any fall-back
+    ("rosenbrock", 130, 2, dict(_BASE, qn_type="bfgs", qn_subspace_size=4, barrier_strategy="monotone", norm_type="infinity",
+                                use_diag_hessian=True, max_major_iters=5), None, {"chain": (2, 2)}),
+    ("rosenbrock", 97, 2, dict(_BASE, qn_type="bfgs", qn_subspace_size=3, barrier_strategy="monotone", norm_type="l2",
+                               use_diag_hessian=True, max_major_iters=5), None, {"chain": (3, 4)}),
 ]
 
 
@@ -313,6 +319,38 @@ def test_random_large_case_against_oracle(ctx, idx):
 @pytest.mark.parametrize("k", range(len(RECOGNISED_CHAINS)))
 def test_recognised_chain_patterns_against_oracle(ctx, k):
     _compare_case_with_oracle(ctx, 10000 + k, RECOGNISED_CHAINS[k])
+
+
+@pytest.mark.parametrize("chain", [(2, 2), (3, 5)])
+def test_hessian_vector_product_of_a_recognised_chain(ctx, chain):
+    """evalHvecProduct / evalHessianDiag of a chain problem whose CSR pattern was recognised as grouped (light
+    pattern: d_colp / d_rowsT are never uploaded).  The Newton-Krylov step asks for Hessian-vector products with the
+    sparse multipliers at the uniform start, while the problem is still grouped: the column sums 2 zw come from the
+    group scatter (the library dereferenced null device pointers before).  Compared with the same problem forced onto
+    the general CSR path (PAROPT_AMD_NO_CSR_GROUPS is read once per process, so the comparison is with the oracle)."""
+    import paropt_amd as pa
+    from oracle import paropt_oracle as po
+
+    n = 101
+    opts = {"qn_type": "bfgs", "qn_subspace_size": 3, "max_major_iters": 3, "use_hvec_product": True,
+            "gmres_subspace_size": 4, "nk_switch_tol": 1e3, "max_gmres_rtol": 1.0, "abs_res_tol": 1e-8,
+            "start_affine_multiplier_min": 0.01}
+    prob = pa.SeparableProblem(ctx, "rosenbrock", n, 2)
+    prob.setChain(*chain)
+    ip = pa.InteriorPoint(prob, dict(opts, write_output_frequency=0))
+    rep = ip.checkGradients(1e-6)
+    assert "Hessian-vector product test" in rep, rep
+    gsn = []
+    ip.setIterationCallback(lambda k: gsn.append(ip.snapshot()))
+    ip.optimize()
+    oip = po.InteriorPoint(po.SepProblem("rosenbrock", n, 2, chain=chain), opts)
+    osn = []
+    oip.hook = lambda s, k: osn.append(s.snapshot())
+    oip.optimize()
+    assert len(gsn) >= 2 and len(gsn) == len(osn)
+    for k in range(len(gsn)):
+        np.testing.assert_array_equal(gsn[k]["counters"], osn[k]["counters"])
+        assert abs(gsn[k]["fobj"] - osn[k]["fobj"]) <= 1e-8 * max(1.0, abs(osn[k]["fobj"])), (k, gsn[k]["fobj"], osn[k]["fobj"])
 
 
 def _compare_case_with_oracle(ctx, idx, case):

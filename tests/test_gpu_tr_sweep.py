@@ -166,6 +166,13 @@ FIXTURE_KNIFE_EDGE = {
     129: "quadratic n = 1000, same steering selectors: the third steering solve ends at the cap of 200 on the device and "
          "after 113 iterations in the reference, the subproblem solve behind it takes 17 against 18 iterations; the other "
          "nine rows are equal",
+    64: "quadratic n = 1000, linear objective / subproblem constraint selectors: the fourth steering solve is a degenerate "
+        "linear program (penalty parameter 6e13 on an infeasibility of 3e-15: its Armijo decisions are taken on round-off). "
+        "The reference runs it to the cap of 200 iterations; the device took 21 until round 6 (same rows as the reference) "
+        "and takes 12 since the corrector solve of the predictor-corrector strategy sums its merit pieces itself "
+        "(solve2c_kernel: the same step, sums cut differently) -- its fourth step is then rejected where the reference's is "
+        "accepted.  With the plain sequence (PAROPT_AMD_MPC_FUSE=0) all ten rows are the reference's "
+        "(profiles/r06_tr_fixture_case64.txt)",
 }
 _fixture_cache = {}
 
