@@ -628,15 +628,17 @@ def main():
     achieved = alg_bytes / (ms * 1e-3) * 1e-9
     traffic, traffic_src = None, None
     # PMC bytes per launch from committed rocprofv3 passes (NOT measured in this run) of this exact shape: round 4's
-    # collection of the configuration (tools/collect_r04.sh: per-kernel FETCH_SIZE / WRITE_SIZE), else the older files
-    try:
-        if nl == 50_000_000 and a.ncon == 32:
-            k = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_c3.json")))["void po::mdot_kernel<32>"]
-            traffic = k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]
-            traffic_src = ("profiles/r04_pmc_c3.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command, "
-                           "%d launches; not collected in this run)" % k["FETCH_SIZE"]["dispatches"])
-    except Exception:
-        pass
+    # collection of the configuration (per-kernel FETCH_SIZE / WRITE_SIZE), else the older files
+    # (the newest collection on record first: tools/collect_r06.sh, then the earlier rounds')
+    for fn in ("r06_pmc_c3.json", "r05_pmc_c3_final_build.json", "r05_pmc_c3.json", "r04_pmc_c3.json"):
+        try:
+            if traffic is None and nl == 50_000_000 and a.ncon == 32:
+                k = json.load(open(os.path.join(ROOT, "profiles", fn)))["void po::mdot_kernel<32>"]
+                traffic = k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]
+                traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same command, "
+                               "%d launches; not collected in this run)" % (fn, k["FETCH_SIZE"]["dispatches"]))
+        except Exception:
+            pass
     for fn in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
         if traffic is not None:
             break

@@ -243,6 +243,23 @@ int comm_init_callback(Ctx *c, int rank, int size, po_allgather_fn fn, void *use
   return PO_OK;
 }
 
+// development aid: see Ctx::host_trace (contexts that are never destroyed report at exit)
+static std::vector<Ctx *> g_traced;
+static void host_trace_report(Ctx *c) {
+  if (c->rank != 0) return;
+  fprintf(stderr,
+          "paropt_amd host trace: %ld synchronising reductions; host time between a result and the next launch "
+          "%.1f us avg (%ld gaps below 500 us, %ld of them above 20 us, %.3f s; %ld longer ones, %.3f s); inside launch "
+          "calls %.2f us avg (%ld launches, %.3f s); waiting for results %.3f s\n",
+          c->n_reductions, c->host_gap_n ? 1e6 * c->host_gap_s / c->host_gap_n : 0.0, c->host_gap_n, c->host_gap_n20,
+          c->host_gap_s, c->host_gap_long_n, c->host_gap_long_s,
+          c->host_launch_n ? 1e6 * c->host_launch_s / c->host_launch_n : 0.0, c->host_launch_n, c->host_launch_s,
+          c->host_wait_s);
+}
+static void host_trace_atexit() {
+  for (Ctx *c : g_traced)
+    if (c) host_trace_report(c);
+}
 int ctx_create(int device, Ctx **out) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -261,6 +278,10 @@ int ctx_create(int device, Ctx **out) {
   po_ctx_s *c = new po_ctx_s();
   c->device = device;
   c->host_trace = getenv("PAROPT_AMD_HOST_TRACE") != nullptr;
+  if (c->host_trace) {
+    if (g_traced.empty()) atexit(host_trace_atexit);
+    g_traced.push_back(c);
+  }
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   c->max_blocks = c->num_cu * 8;  // upper bound used only to size the partials buffer
   PO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -280,14 +301,10 @@ int ctx_destroy(Ctx *c) {
   if (!c) return PO_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  if (c->host_trace && c->rank == 0) {
-    fprintf(stderr,
-            "paropt_amd host trace: %ld synchronising reductions; host time between a result and the next launch "
-            "%.1f us avg (%ld gaps, %.3f s); inside launch calls %.2f us avg (%ld launches, %.3f s); waiting for results "
-            "%.3f s\n",
-            c->n_reductions, c->host_gap_n ? 1e6 * c->host_gap_s / c->host_gap_n : 0.0, c->host_gap_n, c->host_gap_s,
-            c->host_launch_n ? 1e6 * c->host_launch_s / c->host_launch_n : 0.0, c->host_launch_n, c->host_launch_s,
-            c->host_wait_s);
+  if (c->host_trace) {
+    for (auto &p : g_traced)
+      if (p == c) p = nullptr;
+    host_trace_report(c);
   }
   if (c->rccl_comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->rccl_comm);
   free_overflow(c, nullptr);

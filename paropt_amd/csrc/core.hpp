@@ -83,7 +83,8 @@ struct Ctx {
   // time spent inside the launch calls, and the time spent waiting for results
   bool host_trace = false, host_gap_open = false;
   double host_t_sync = 0.0, host_gap_s = 0.0, host_launch_s = 0.0, host_wait_s = 0.0;
-  long host_gap_n = 0, host_launch_n = 0;
+  long host_gap_n = 0, host_launch_n = 0, host_gap_n20 = 0, host_gap_long_n = 0;
+  double host_gap_long_s = 0.0;
   std::vector<double *> partials_overflow;  // regions handed out while the arena was full (freed after the flush)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
@@ -242,8 +243,15 @@ inline double host_trace_begin(Ctx *c) {
   if (!c->host_trace) return 0.0;
   const double t = host_now();
   if (c->host_gap_open) {
-    c->host_gap_s += t - c->host_t_sync;
-    c->host_gap_n++;
+    const double g = t - c->host_t_sync;
+    if (g < 500e-6) {  // (longer: between solves, around callbacks of the caller -- counted apart)
+      c->host_gap_s += g;
+      c->host_gap_n++;
+      if (g > 20e-6) c->host_gap_n20++;
+    } else {
+      c->host_gap_long_s += g;
+      c->host_gap_long_n++;
+    }
     c->host_gap_open = false;
   }
   return t;

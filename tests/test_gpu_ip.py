@@ -1200,7 +1200,7 @@ def test_first_solve_pass_two_tiles_per_step_keeps_every_bit(ctx, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["seq_lin_c3", "bfgs_c3", "seq_lin_c5_large", "quadratic_odd_small"])
+@pytest.mark.parametrize("case", ["seq_lin_c3", "bfgs_c3", "quadratic_c2_large", "quadratic_odd_small"])
 def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
     """Round 6: under mehrotra_predictor_corrector the corrector right-hand side is ONE pass (corr_d1_dots_kernel: the
     bits of corrector + d1 + mdot), the corrector solve takes the sums of scaleKKTStep / evalMeritInitDeriv itself
@@ -1218,8 +1218,8 @@ def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
                                                                          "sequential_linear_method": True}),
         "bfgs_c3": dict(kind="quadratic", n=300, c=3, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 10}),
         # (more than one pair per thread: the grids cover 2 x 256 x 4 x 256 and 2 x 256 x 5 x 256 elements per sweep)
-        "seq_lin_c5_large": dict(kind="convex", n=1200003, c=5, iters=24, opts={"qn_type": "bfgs", "qn_subspace_size": 3,
-                                                                                "sequential_linear_method": True}),
+        "quadratic_c2_large": dict(kind="quadratic", n=1200003, c=2, iters=24,
+                                   opts={"qn_type": "bfgs", "qn_subspace_size": 3, "init_barrier_param": 1e-3}),
         "quadratic_odd_small": dict(kind="quadratic", n=511, c=2, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 4,
                                                                                   "sequential_linear_method": True}),
     }[case]
