@@ -26,7 +26,7 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
-static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static int g_dbg_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 double host_now() {
   struct timespec t;
   clock_gettime(CLOCK_MONOTONIC, &t);

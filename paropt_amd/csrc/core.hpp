@@ -231,7 +231,7 @@ struct BatchScope {
 // po_debug_set_switch wins, else the environment variable, else the default.  Not part of the interface.
 enum DbgSwitch { SW_WGRAM_RS = 0, SW_LINCOMB_2D = 1, SW_REDO_DT = 2, SW_LEAN_STEP = 3, SW_WGRAM_PRIO = 4,
                  SW_WGRAM_ABLATE = 5, SW_FUSED_MERIT = 6, SW_REDO_DT1 = 7, SW_BPC3 = 8, SW_BPC4 = 9, SW_LINCOMB_BPC = 10,
-                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_S2D_TWO = 13, SW_MPC_FUSE = 14, SW_MPC_POLY = 15, SW_COUNT = 16 };  // one entry per use: an A/B run changes one thing
+                 SW_PERTURB_W = 11, SW_GS_PRODUCER = 12, SW_S2D_TWO = 13, SW_MPC_FUSE = 14, SW_MPC_POLY = 15, SW_SPEC_DT = 16, SW_COUNT = 17 };  // one entry per use: an A/B run changes one thing
 int dbg_switch(int id, const char *env, int dflt);
 double host_now();  // seconds, monotonic
 // around a kernel launch when Ctx::host_trace is on (see Ctx): begin closes the gap behind the last synchronisation
@@ -372,7 +372,11 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      // old point xold and the old multipliers with the barrier term of the step's solve
                      const double *pxs = nullptr, const double *xold = nullptr, double beta_mu_step = 0.0,
                      double beta_mu2 = -1.0,  // as k_kkt_res
-                     const GroupCol *gcol = nullptr, double gcoef = 0.0);  // as k_kkt_res
+                     const GroupCol *gcol = nullptr, double gcoef = 0.0,  // as k_kkt_res
+                     // dinv_out != nullptr: also Dinv (diagonal spec_diag) and t = Dinv o d1 (spec_beta_mu) of the new
+                     // point, as k_dinv_d1 would form them from what this pass has just stored
+                     double *dinv_out = nullptr, double *t_out = nullptr, double spec_diag = 0.0,
+                     double spec_beta_mu = 0.0);
 // the mu-dependent part only (when the barrier parameter changes): out = {comp product,
 // count, max|rzl|, max|rzu|}
 int k_res_norms(Ctx *c, const Bounds &b, double beta_mu, int64_t n, double out[11]);

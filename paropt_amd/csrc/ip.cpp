@@ -410,6 +410,7 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
   const double mu2 = spec ? nextMonotoneMu() : 0.0;
   const double beta_mu2 = spec ? options.real("rel_bound_barrier") * mu2 : -1.0;
   spec_valid = false;
+  spec_dt_valid = false;  // (rx is about to change: a Dinv / t pair left by an earlier pass is stale)
   // sparse and design blocks of the residual share one collective + sync (the problem's sparse callbacks run in
   // between: built-in problems only)
   BatchScope wbatch(ctx, has_w && prob->reductionsBatchable());
@@ -452,11 +453,25 @@ int InteriorPoint::computeResidual(double mu, bool vectors, Vec *yqn_complete, c
       // multiplier step by recurrence unless it has just been rebuilt from the new multipliers
       const double az_acz = (acz_mode && upd->acz_follow && !acz_rebuilt) ? upd->az : 0.0;
       // (lean step: px and the old point -- xt after the swap of computeStepAndUpdate -- instead of pzl / pzu)
+      // No quasi-Newton update follows (a fixed approximation, the sequential linear method): the diagonal of the next
+      // KKT system is known already, so this pass also leaves Dinv and t = Dinv o d1 of the next first solve behind
+      // (spec_dt_*: setUpKKTSystem skips its pass over the bound data when diagonal and barrier parameter still match)
+      const bool spec_dt = spec_dt_want && !has_w && fused_tdots && !options.integer("use_diag_hessian") &&
+                           dbg_switch(SW_SPEC_DT, "PAROPT_AMD_SPEC_DT", 1) != 0;
+      const double sdiag = spec_dt ? options.real("qn_sigma") + ((qn && !options.integer("sequential_linear_method"))
+                                                                    ? qn->diag() : 0.0) : 0.0;
+      const double sbmu = spec_dt ? options.real("rel_bound_barrier") * spec_dt_mu : 0.0;
       PO_TRY(k_kkt_res_update(ctx, bounds(), g->d, A.data(), zc.data(), acz_mode ? 0 : (int)A.size(), beta_mu, n,
                               rx->d, out, yqn_complete ? yqn_complete->d : nullptr, zl->d, pzl->d, zu->d, pzu->d,
                               upd->a, upd->eps, (yqn_complete || az_acz != 0.0) ? vA->d : nullptr,
                               upd->az, acz_mode ? acz->d : nullptr, az_acz, pz_stored ? nullptr : px->d,
-                              pz_stored ? nullptr : xt->d, step_beta_mu, beta_mu2, have_gcol ? &gcol : nullptr, 1.0));
+                              pz_stored ? nullptr : xt->d, step_beta_mu, beta_mu2, have_gcol ? &gcol : nullptr, 1.0,
+                              spec_dt ? Dinv->d : nullptr, spec_dt ? tvec->d : nullptr, sdiag, sbmu));
+      if (spec_dt) {
+        spec_dt_valid = true;
+        spec_dt_diag = sdiag;
+        spec_dt_bmu = sbmu;
+      }
     } else {
       PO_TRY(k_kkt_res(ctx, bounds(), g->d, A.data(), zc.data(), (int)A.size(), beta_mu, n, rx->d, out,
                        yqn_complete ? yqn_complete->d : nullptr, beta_mu2, have_gcol ? &gcol : nullptr, 1.0));
@@ -590,7 +605,14 @@ int InteriorPoint::setUpKKTSystem(bool use_qn, bool diag_only, const double *rhs
   // sparse constraints: the RAW right-hand side d1 of the first solve (the block solve applies to it) comes out of
   // the same pass over the bound data as Dinv (round 4; it is used below when the fused first solve is taken)
   const bool raw_d1_w = has_w && rhs_mu && fused_tdots && !corrector_active;
-  if (fuse_t) {
+  const bool have_spec_dt = spec_dt_valid;
+  spec_dt_valid = false;  // consumed here, or overwritten below
+  if (fuse_t && have_spec_dt && !use_hdiag && spec_dt_diag == b0 + sigma &&
+      spec_dt_bmu == options.real("rel_bound_barrier") * (*rhs_mu)) {
+    // the residual pass of this iterate left exactly this Dinv and t behind (kkt_res_update_kernel)
+    t_is_plain_dinv_d1 = true;
+    t0_diag = b0 + sigma;
+  } else if (fuse_t) {
     PO_TRY(k_dinv_d1(ctx, bounds(), b0 + sigma, use_hdiag ? hdiag->d : nullptr, rx->d,
                      options.real("rel_bound_barrier") * (*rhs_mu), n, Dinv->d, tvec->d));
     t_is_plain_dinv_d1 = !use_hdiag;
@@ -1862,7 +1884,12 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     if (fast_yqn) {
       // residual of the next iteration at (x+, z+, zl+, zu+): rx+ = [lo]zl+ - [up]zu+ - g+ + A+^T z+
       // ... and y_qn += [lo]zl+ - [up]zu+ - rx+ in the same pass (the residual kernel has all three in registers)
-      PO_TRY(computeResidual(barrier_param, true, y_qn, fuse_upd ? &upd : nullptr));
+      // (sequential linear method: the quasi-Newton update that follows does not enter the next KKT diagonal, so this
+      // pass can leave Dinv and t of the next first solve behind as the pass without an update does -- spec_dt_*)
+      spec_dt_want = fuse_upd && options.integer("sequential_linear_method") != 0;
+      const int rcr = computeResidual(barrier_param, true, y_qn, fuse_upd ? &upd : nullptr);
+      spec_dt_want = false;
+      PO_TRY(rcr);
       residual_cached = true;
     } else {
       std::vector<double> mz(c > 0 ? c : 1);
@@ -1898,7 +1925,10 @@ int InteriorPoint::computeStepAndUpdate(double alpha, int eval_obj_con, int perf
     *update_type = 0;
   }
   if (fuse_upd_noqn) {
-    PO_TRY(computeResidual(barrier_param, true, nullptr, &upd));
+    spec_dt_want = true;  // (the barrier parameter of the next first solve: spec_dt_mu, set by optimize())
+    const int rc = computeResidual(barrier_param, true, nullptr, &upd);
+    spec_dt_want = false;
+    PO_TRY(rc);
     residual_cached = true;
   }
   return PO_OK;
@@ -1987,6 +2017,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
   cwx_valid = trial_cw_valid = false;
   residual_cached = false;
   iterate_logs_valid = trial_logs_valid = fused_merit_valid = false;
+  spec_dt_valid = spec_dt_want = false;
   w_comp_valid = w_merit_cache_valid = false;
   px_first_only = false;
   spec_enabled = spec_valid = false;
@@ -2171,6 +2202,8 @@ int InteriorPoint::optimize(const char *checkpoint) {
     }
 
     const bool mehrotra = (barrier_strategy == B_MEHROTRA || barrier_strategy == B_MPC);
+    // (what the first solve of the NEXT iteration will most likely take as its barrier parameter: see spec_dt_valid)
+    spec_dt_mu = mehrotra ? 0.0 : barrier_param;
     double tau = min_frac;
     if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
 

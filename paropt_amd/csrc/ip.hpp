@@ -179,6 +179,10 @@ class InteriorPoint {
   // ... unless the corrector solve forms them itself (round 6: k_corr_d1_dots + k_solve2c, two launches and two host
   // round trips instead of five and three); corr_out: what k_solve2c reduced
   bool corrector_fused = false;
+  // Dinv / t of the next first solve left behind by the residual pass of the new point (no quasi-Newton update in
+  // between: round 6); valid for the diagonal and the barrier parameter recorded with them
+  bool spec_dt_valid = false, spec_dt_want = false;
+  double spec_dt_diag = 0.0, spec_dt_bmu = 0.0, spec_dt_mu = 0.0;
   double corr_out[12] = {0};
   int norm_type;          // 0 infinity, 1 l1, 2 l2 (ParOptNormType)
   std::vector<double> tdots;  // P^T t' produced by the fused first solve pass

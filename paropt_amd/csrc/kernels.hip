@@ -2660,7 +2660,8 @@ __global__ void __launch_bounds__(kBlock)
                           double a, double eps, const double *__restrict__ va, double az, double *__restrict__ acz,
                           double az_acz, const double *__restrict__ pxs, const double *__restrict__ xold,
                           double beta_mu_step, double beta_mu2, GroupCol gcol, double gcoef,
-                          double *__restrict__ partials) {
+                          double *__restrict__ dinv_out, double *__restrict__ t_out, double spec_diag,
+                          double spec_beta_mu, double *__restrict__ partials) {
   __shared__ double sm[4 * 8];
   double sums[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   double maxs[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2749,6 +2750,14 @@ __global__ void __launch_bounds__(kBlock)
     r.y += ps.y;
     if (!_has2) r.y = 0.0;
     st2(rx, q, n, r);
+    if (dinv_out) {
+      // Dinv and t = Dinv o d1 of the NEXT iteration's first solve, from the operands this pass holds anyway (round 6;
+      // the expressions of dinv_d1_kernel: the same bits): when no quasi-Newton update follows, the diagonal of the
+      // next KKT system is known here, and the pass over the bound data at the head of setUpKKTSystem disappears
+      const double2 dv = make_double2(dinv_elem(e0, spec_diag), dinv_elem(e1, spec_diag));
+      st2(dinv_out, q, n, dv);
+      st2(t_out, q, n, make_double2(dv.x * d1_elem(e0, r.x, spec_beta_mu), dv.y * d1_elem(e1, r.y, spec_beta_mu)));
+    }
     const double cl = b.use_lower ? 1.0 : 0.0, cu = b.use_upper ? -1.0 : 0.0;
     if (yqn) {
       y.x = __dadd_rn(y.x, __fma_rn(-1.0, r.x, __fma_rn(cu, _zu.x, __fma_rn(cl, _zl.x, 0.0))));
@@ -2778,7 +2787,8 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
                      double beta_mu, int64_t n, double *rx, double *out, double *yqn, double *zl,
                      const double *pzl, double *zu, const double *pzu, double a, double eps, const double *va,
                      double az, double *acz, double az_acz, const double *pxs, const double *xold,
-                     double beta_mu_step, double beta_mu2, const GroupCol *gcol, double gcoef) {
+                     double beta_mu_step, double beta_mu2, const GroupCol *gcol, double gcoef, double *dinv_out,
+                     double *t_out, double spec_diag, double spec_beta_mu) {
   PO_TRY(gcol_check(gcol, n, "k_kkt_res_update"));
   if (acz && gcol) {
     set_error("kkt_res_update: a grouped column cannot follow the A^T z vector of the linear-constraint mode");
@@ -2788,9 +2798,9 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
     const double *w = nullptr, one = 1.0;
     PO_TRY(collapse_range(c, 0, z, A, 0, nc, n, &w));
     return k_kkt_res_update(c, b, g, &w, &one, 1, beta_mu, n, rx, out, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz, az_acz,
-                            pxs, xold, beta_mu_step, beta_mu2, gcol, gcoef);
+                            pxs, xold, beta_mu_step, beta_mu2, gcol, gcoef, dinv_out, t_out, spec_diag, spec_beta_mu);
   }
-  count_bytes(c, (yqn ? 14 : 11) + (acz ? (az_acz != 0.0 ? 2 : 1) : nc), n);
+  count_bytes(c, (yqn ? 14 : 11) + (acz ? (az_acz != 0.0 ? 2 : 1) : nc) + (dinv_out ? 2 : 0), n);
   const int grid = grid_for(c, n, kBpcPanel);
   PO_TRY(ensure_partials(c, (size_t)grid * 13));
   PtrTable pt;
@@ -2798,7 +2808,8 @@ int k_kkt_res_update(Ctx *c, const Bounds &b, const double *g, const double *con
   fill_tables(z, A, nc, &ct, &pt);
   if (gcol) count_bytes(c, 1.0, gcol->nwcon);
   PO_LAUNCH(kkt_res_update_kernel, grid, b, g, pt, ct, nc, beta_mu, n, rx, yqn, zl, pzl, zu, pzu, a, eps, va, az, acz,
-            az_acz, pxs, xold, beta_mu_step, beta_mu2, gcol ? *gcol : GroupCol(), gcoef, c->d_partials);
+            az_acz, pxs, xold, beta_mu_step, beta_mu2, gcol ? *gcol : GroupCol(), gcoef, dinv_out, t_out, spec_diag,
+            spec_beta_mu, c->d_partials);
   return reduce_finish(c, grid, 8, 0, beta_mu2 >= 0.0 ? 5 : 3, out);
 }
 

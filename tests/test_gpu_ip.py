@@ -1260,3 +1260,59 @@ def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
             np.testing.assert_allclose(va, vb, rtol=0, atol=1e-8 * max(1.0, float(np.abs(va).max())))
         tokens = lambda h: [ln.split()[15:] for ln in h.splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
         assert len(tokens(a[5])) >= 8 and tokens(a[5]) == tokens(b[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["seq_lin", "fixed_bfgs", "seq_lin_mpc", "odd_small"])
+def test_dinv_and_rhs_left_by_the_residual_pass_keep_every_bit(ctx, case):
+    """Round 6: when no quasi-Newton update follows the step (a fixed approximation -- the trust-region subproblem
+    solves -- or the sequential linear method) the diagonal of the next KKT system is known when the residual of the new
+    point is taken, and that pass (kkt_res_update_kernel) leaves Dinv and t = Dinv o d1 of the next first solve behind:
+    setUpKKTSystem skips its pass over the bound data whenever diagonal and barrier parameter still match (they do not
+    at a barrier switch: the plain pass runs).  Same expressions on the same operands: against the plain sequence
+    (debug switch 16 = 0) in the same process every iterate, multiplier, norm, counter and table row has the same bits,
+    with one launch less per iteration."""
+    import paropt_amd as pa
+    from paropt_amd import lib as L
+
+    SW_SPEC_DT = 16
+    cfg = {
+        "seq_lin": dict(kind="convex", n=400003, c=3, iters=14, opts={"qn_type": "bfgs", "qn_subspace_size": 3,
+                                                                       "sequential_linear_method": True}),
+        "fixed_bfgs": dict(kind="quadratic", n=300001, c=4, iters=14,
+                           opts={"qn_type": "bfgs", "qn_subspace_size": 4, "use_quasi_newton_update": False}),
+        "seq_lin_mpc": dict(kind="convex", n=20001, c=3, iters=16,
+                            opts={"qn_type": "bfgs", "qn_subspace_size": 3, "sequential_linear_method": True,
+                                  "barrier_strategy": "mehrotra_predictor_corrector"}),
+        "odd_small": dict(kind="quadratic", n=511, c=2, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 4,
+                                                                        "sequential_linear_method": True,
+                                                                        "barrier_strategy": "mehrotra"}),
+    }[case]
+
+    def run(spec):
+        L.lib.po_debug_set_switch(SW_SPEC_DT, spec)
+        try:
+            prob = pa.SeparableProblem(ctx, cfg["kind"], cfg["n"], cfg["c"], 7)
+            ip = pa.InteriorPoint(prob, dict({"abs_res_tol": 1e-9, "start_affine_multiplier_min": 0.01,
+                                              "max_major_iters": cfg["iters"], "write_output_frequency": 0}, **cfg["opts"]))
+            sn = []
+            ip.setIterationCallback(lambda k: sn.append(ip.snapshot()))
+            n0 = ctx.counters()[1]
+            ip.optimize()
+            launches = ctx.counters()[1] - n0
+            x, z, zl, zu = ip.getOptimizedPoint()[:4]
+            return sn, x.to_numpy(), np.array(z), zl.to_numpy(), zu.to_numpy(), ip.getHistory(), launches
+        finally:
+            L.lib.po_debug_set_switch(SW_SPEC_DT, -1)
+
+    a, b = run(0), run(1)
+    assert len(a[0]) == len(b[0]) >= 8
+    assert b[6] <= a[6] - (len(a[0]) - 4), ("one launch less in (nearly) every iteration", a[6], b[6], len(a[0]))
+    for sa, sb in zip(a[0], b[0]):
+        np.testing.assert_array_equal(sa["counters"], sb["counters"])
+        assert sa["fobj"] == sb["fobj"] and sa["mu"] == sb["mu"]
+        np.testing.assert_array_equal(sa["norms"], sb["norms"])
+    for va, vb in zip(a[1:5], b[1:5]):
+        np.testing.assert_array_equal(va, vb)
+    table = lambda h: [ln for ln in h.splitlines() if ln[:5].strip().isdigit()]  # noqa: E731
+    assert len(table(a[5])) >= 8 and table(a[5]) == table(b[5])

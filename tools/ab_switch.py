@@ -40,7 +40,7 @@ def main():
         variants.append([(int(p.split("=")[0]), int(p.split("=")[1])) for p in v.split(",") if p])
 
     def apply(v):
-        for i in range(13):
+        for i in range(17):
             lib.po_debug_set_switch(i, -1)
         for i, val in v:
             lib.po_debug_set_switch(i, val)

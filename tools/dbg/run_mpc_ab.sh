@@ -1,3 +1,15 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_ip.py -m gpu -q -k "predictor_corrector_fused" 2>&1 | grep -E "^E  |passed|failed" | head
+python -m pytest tests -m gpu -q 2>&1 | tail -4 | head -2
+rm -f gpurun_out/r06_ab_spec_dt.jsonl
+for v in "0 0 0" "1 1 0" "1 1 1" "0 0 0" "1 1 0" "1 1 1"; do
+  set -- $v
+  PAROPT_AMD_MPC_FUSE=$1 PAROPT_AMD_MPC_POLY=$2 PAROPT_AMD_SPEC_DT=$3 python tools/bench_tr.py --no-cpu-baseline --repeats 3 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readlines()[-1])
+d['switches'] = {'PAROPT_AMD_MPC_FUSE': $1, 'PAROPT_AMD_MPC_POLY': $2, 'PAROPT_AMD_SPEC_DT': $3}
+print(json.dumps({k: d.get(k) for k in ('switches', 'value', 'inner_ip_iterations', 'inner_ip_iterations_per_s', 'ms_per_inner_iteration', 'launches_per_inner_iteration', 'host_syncs_per_inner_iteration', 'seconds_min', 'seconds_max')}))
+" | tee -a gpurun_out/r06_ab_config5.jsonl
+done
+bash tools/collect_r06.sh c5 > /dev/null 2>&1
+head -c 400 gpurun_out/r06_bench_c5.json
