@@ -810,18 +810,16 @@ int InteriorPoint::solveKKT(const Dense &b, double mu, bool use_qn, bool refine_
     need_panel();
     PO_TRY(k_corr_d1_dots(ctx, bounds(), px->d, pzl->d, pzu->d, rx->d, Dinv->d, beta_mu, P.data(), m, n, tvec->d,
                           dots.data()));
-  } else if (!refine_pass && !have_t0) {
-    PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
-  }
-  if (corr_fused) {
-    // (dots are in place)
-  } else if (have_t0) {
-    for (int i = 0; i < m; i++) dots[i] = t0dots[i];
-  } else if (refine_pass && tdots_valid && (int)tdots.size() == m) {
-    dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
-  } else if (m > 0) {
-    need_panel();
-    PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+  } else {
+    if (!refine_pass && !have_t0) PO_TRY(k_d1(ctx, bounds(), rx->d, Dinv->d, beta_mu, n, tvec->d, cl, cu));
+    if (have_t0) {
+      for (int i = 0; i < m; i++) dots[i] = t0dots[i];
+    } else if (refine_pass && tdots_valid && (int)tdots.size() == m) {
+      dots = tdots;  // P^T t' came out of the fused first pass (k_solve2_dots)
+    } else if (m > 0) {
+      need_panel();
+      PO_TRY(k_mdot(ctx, tvec->d, P.data(), m, n, dots.data()));
+    }
   }
   if (!refine_pass) first_t_recomputable = have_t0 && t_is_plain_dinv_d1;  // tvec / Dinv are dinv_d1's for this mu
   if (!refine_pass) t0_valid = false;  // tvec is overwritten by the passes below
@@ -2314,7 +2312,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
         // corrector: res.zl -= px*pzl, res.zu += px*pzu, res.zs -= ps*pzs, res.zt -= pt*pzt of the
         // affine step (:1729-1789); no refinement with the corrector (:5040-5041)
         // (one-pass corrector right-hand side + corrector solve with the merit sums: see solveKKT)
-        corrector_fused = !has_w && c + wk >= 1 && c + wk <= kCorrDotsMax && use_line_search &&
+        corrector_fused = !has_w && c + wk >= 1 && c + wk <= kCorrDotsMax &&
                           dbg_switch(SW_MPC_FUSE, "PAROPT_AMD_MPC_FUSE", 1) != 0;
         if (!corrector_fused) PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
         denseResidual(barrier_param, res);

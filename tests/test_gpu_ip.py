@@ -1200,7 +1200,7 @@ def test_first_solve_pass_two_tiles_per_step_keeps_every_bit(ctx, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["seq_lin_c3", "bfgs_c3", "quadratic_c2_large", "quadratic_odd_small"])
+@pytest.mark.parametrize("case", ["seq_lin_c3", "bfgs_c3", "quadratic_c2_large", "quadratic_odd_small", "no_line_search"])
 def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
     """Round 6: under mehrotra_predictor_corrector the corrector right-hand side is ONE pass (corr_d1_dots_kernel: the
     bits of corrector + d1 + mdot), the corrector solve takes the sums of scaleKKTStep / evalMeritInitDeriv itself
@@ -1222,6 +1222,8 @@ def test_predictor_corrector_fused_corrector_against_its_plain_form(ctx, case):
                                    opts={"qn_type": "bfgs", "qn_subspace_size": 3, "init_barrier_param": 1e-3}),
         "quadratic_odd_small": dict(kind="quadratic", n=511, c=2, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 4,
                                                                                   "sequential_linear_method": True}),
+        "no_line_search": dict(kind="quadratic", n=3001, c=3, iters=30, opts={"qn_type": "bfgs", "qn_subspace_size": 5,
+                                                                              "use_line_search": False}),
     }[case]
 
     def run(fuse, poly):
