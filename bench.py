@@ -480,6 +480,7 @@ def main():
         """R optimize() runs on `prob`; returns (median seconds of the K timed iterations, sorted times, details of
         the median run, all runs)."""
         ip = pa.InteriorPoint(prob, opts)
+        ip.setCallbackTiming(True)  # user_eval_ms_per_iter below (event records around the problem's callbacks)
         stamp = {}
 
         def cb(k):

@@ -265,7 +265,9 @@ typedef int (*po_eval_sparse_obj_con_gradient_fn)(void *user, po_vec x, po_vec g
 int po_problem_set_sparse_jacobian_data(po_problem p, int64_t nwcon, int64_t nwinequality, const int *rowp,
                                         const int *cols, po_eval_sparse_obj_con_fn eval_sparse_obj_con,
                                         po_eval_sparse_obj_con_gradient_fn eval_sparse_obj_con_gradient);
-/* getSparseJacobianData (src/ParOptProblem.cpp:689-703): host pattern, device values; returns nnz in *nnz */
+/* getSparseJacobianData (src/ParOptProblem.cpp:689-703): host pattern, device values; returns nnz in *nnz.
+ * Borrowed pointers, valid until the next po_problem_set_sparse_jacobian_data or the problem's destruction -- also
+ * across the library's own change of path when a recognised grouped pattern turns out to have non-uniform entries. */
 int po_problem_get_sparse_jacobian_data(po_problem p, const int **rowp, const int **cols, double **data,
                                         int64_t *nnz);
 /* ParOptQuasiDefMat (src/ParOptSparseMat.h:18-62) of any problem with sparse constraints, block or CSR form:
@@ -422,6 +424,11 @@ int po_ip_get_history(po_ip ip, const char **text);
 /* Time (seconds, HIP events on the context stream) spent per phase during the last optimize;
  * names is a ';'-separated list matching seconds[]. */
 int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, int *count);
+/* The "user_eval" entry of po_ip_get_phase_times -- stream time of the problem's callbacks -- needs a pair of event
+ * records around every callback; each is a packet between two kernels and costs the stream some dispatch latency
+ * (1.5 % of an inner iteration at n = 5 M, nothing measurable at n >= 10 M), so it is OFF by default: on != 0 switches
+ * it on for the solves that follow (bench.py does, for the figure it reports).  No reference counterpart. */
+int po_ip_set_callback_timing(po_ip ip, int on);
 /* Single-step entry points used by the known-answer tests (reference private methods
  * computeKKTRes/setUpKKTDiagSystem/setUpKKTSystem/computeKKTStep, .cpp:1337, 1832, 2634, 2700):
  * computes the KKT step at the current state with barrier mu into internal step storage and

@@ -943,6 +943,12 @@ class InteriorPoint:
         check(lib.po_ip_get_history(self._h, C.byref(t)))
         return t.value.decode()
 
+    def setCallbackTiming(self, on=True):
+        """Event timing of the problem's callbacks (the "user_eval" entry of getPhaseTimes): off by default, every
+        event record costs the stream some dispatch latency (po_ip_set_callback_timing)."""
+        check(lib.po_ip_set_callback_timing(self._h, 1 if on else 0))
+        return self
+
     def getPhaseTimes(self):
         names, secs, cnt = C.c_char_p(), L.c_double_p(), C.c_int()
         check(lib.po_ip_get_phase_times(self._h, C.byref(names), C.byref(secs), C.byref(cnt)))

@@ -1013,6 +1013,11 @@ int po_ip_get_history(po_ip ip, const char **text) {
   *text = ip->ip->history.c_str();
   return PO_OK;
 }
+int po_ip_set_callback_timing(po_ip ip, int on) {
+  PO_CHECK_PTR(ip);
+  ip->ip->user_timing = on != 0;
+  return PO_OK;
+}
 int po_ip_get_phase_times(po_ip ip, const char **names, const double **seconds, int *count) {
   PO_CHECK_PTR(ip);
   InteriorPoint *p = ip->ip;

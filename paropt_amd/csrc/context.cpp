@@ -250,11 +250,13 @@ static void host_trace_report(Ctx *c) {
   fprintf(stderr,
           "paropt_amd host trace: %ld synchronising reductions; host time between a result and the next launch "
           "%.1f us avg (%ld gaps below 500 us, %ld of them above 20 us, %.3f s; %ld longer ones, %.3f s); inside launch "
-          "calls %.2f us avg (%ld launches, %.3f s); waiting for results %.3f s\n",
+          "calls %.2f us avg (%ld launches, %.3f s); waiting for results %.3f s; host time between two launches without "
+          "a synchronisation in between %.1f us avg (%ld intervals, %ld above 30 us: %.3f s)\n",
           c->n_reductions, c->host_gap_n ? 1e6 * c->host_gap_s / c->host_gap_n : 0.0, c->host_gap_n, c->host_gap_n20,
           c->host_gap_s, c->host_gap_long_n, c->host_gap_long_s,
           c->host_launch_n ? 1e6 * c->host_launch_s / c->host_launch_n : 0.0, c->host_launch_n, c->host_launch_s,
-          c->host_wait_s);
+          c->host_wait_s, c->host_inter_n ? 1e6 * c->host_inter_s / c->host_inter_n : 0.0, c->host_inter_n,
+          c->host_inter_n30, c->host_inter_s30);
 }
 static void host_trace_atexit() {
   for (Ctx *c : g_traced)

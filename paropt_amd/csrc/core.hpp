@@ -84,7 +84,8 @@ struct Ctx {
   bool host_trace = false, host_gap_open = false;
   double host_t_sync = 0.0, host_gap_s = 0.0, host_launch_s = 0.0, host_wait_s = 0.0;
   long host_gap_n = 0, host_launch_n = 0, host_gap_n20 = 0, host_gap_long_n = 0;
-  double host_gap_long_s = 0.0;
+  double host_gap_long_s = 0.0, host_t_launch_end = 0.0, host_inter_s = 0.0, host_inter_s30 = 0.0;
+  long host_inter_n = 0, host_inter_n30 = 0;
   std::vector<double *> partials_overflow;  // regions handed out while the arena was full (freed after the flush)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // immediate timings (recorded, synchronised and read in one call)
   // two n-sized scratch vectors for panels wider than one kernel's argument tables (kernels.hip: collapse_range);
@@ -242,6 +243,17 @@ int ensure_partials(Ctx *c, size_t doubles);
 inline double host_trace_begin(Ctx *c) {
   if (!c->host_trace) return 0.0;
   const double t = host_now();
+  if (!c->host_gap_open && c->host_t_launch_end > 0.0) {  // two launches with no synchronisation in between
+    const double g = t - c->host_t_launch_end;
+    if (g < 500e-6) {
+      c->host_inter_s += g;
+      c->host_inter_n++;
+      if (g > 30e-6) {
+        c->host_inter_n30++;
+        c->host_inter_s30 += g;
+      }
+    }
+  }
   if (c->host_gap_open) {
     const double g = t - c->host_t_sync;
     if (g < 500e-6) {  // (longer: between solves, around callbacks of the caller -- counted apart)
@@ -258,7 +270,8 @@ inline double host_trace_begin(Ctx *c) {
 }
 inline void host_trace_end(Ctx *c, double t0) {
   if (!c->host_trace) return;
-  c->host_launch_s += host_now() - t0;
+  c->host_t_launch_end = host_now();
+  c->host_launch_s += c->host_t_launch_end - t0;
   c->host_launch_n++;
 }
 // `streams` n-sized fp64 operand streams read or written by the launch being issued

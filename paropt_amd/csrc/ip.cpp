@@ -230,6 +230,7 @@ void InteriorPoint::phaseEnd(const char *name) {
 
 void InteriorPoint::userBegin() {
   ctx->in_user = 1;
+  if (!user_timing) return;
   if (!user_events_ready) {
     for (int i = 0; i < 2 * kUserRing; i++)
       if (hipEventCreate(&user_ev[i]) != hipSuccess) return;
@@ -240,7 +241,7 @@ void InteriorPoint::userBegin() {
 }
 void InteriorPoint::userEnd() {
   ctx->in_user = 0;
-  if (!user_events_ready) return;
+  if (!user_timing || !user_events_ready) return;
   (void)hipEventRecord(user_ev[2 * user_pending + 1], ctx->stream);
   user_pending++;
 }

@@ -3,6 +3,7 @@
 // (ip_w.cpp).  Same public method names, option names/defaults and return codes; every n- or
 // w-sized operation is a HIP kernel launch (core.hpp, wcon.hpp).
 #pragma once
+#include <stdlib.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -138,6 +139,11 @@ class InteriorPoint {
   std::vector<std::string> phase_names;
   std::vector<double> phase_seconds;
   std::string phase_names_joined;
+  // Event timing of the problem's callbacks (the "user_eval" phase).  Off by default (round 6): every event record
+  // is a packet between two kernels and costs the stream dispatch latency -- 850 / 853 against 863 / 866 inner it/s
+  // at config 5 in one call (5-6 callbacks per 1.2 ms inner iteration), nothing measurable at n >= 10 M.
+  // po_ip_set_callback_timing switches it on (bench.py does, for the figure it reports).
+  bool user_timing = getenv("PAROPT_AMD_USER_TIMING") != nullptr;
 
   // step storage (exposed for the single-step known-answer tests)
   Vec *px, *pzl, *pzu;

@@ -243,6 +243,7 @@ SIGNATURES = {
     "po_ip_set_iteration_callback": (C.c_int, [po_ip, ITER_FN, C.c_void_p]),
     "po_ip_get_history": (C.c_int, [po_ip, C.POINTER(C.c_char_p)]),
     "po_ip_get_phase_times": (C.c_int, [po_ip, C.POINTER(C.c_char_p), C.POINTER(c_double_p), c_int_p]),
+    "po_ip_set_callback_timing": (C.c_int, [po_ip, C.c_int]),
     "po_ip_debug_kkt_step": (
         C.c_int,
         [po_ip, C.c_double, C.POINTER(po_vec), C.POINTER(po_vec), C.POINTER(po_vec)]
