@@ -156,6 +156,31 @@ extern "C" int po_bench_kernels(po_ctx ctx, int64_t n, int c, int k, int reps, c
         return k_solve2(cx, b, t->d, dinv->d, coef.data(), P.data(), m, 1e-3, 0, 0.95, n, px->d, pzl->d, pzu->d,
                         out.data(), nullptr, rx->d, 1.0, t2->d, va->d, c);
       }));
+      // round 6: the predictor-corrector's corrector right-hand side and solve, each as ONE pass (panels of <= 15
+      // columns: the first min(m, 15) columns here), beside the kernels they replace (corrector + d1 + mdot: rows
+      // above / below; solve2(first) + comp_merit)
+      {
+        const int mc = m < kCorrDotsMax ? m : kCorrDotsMax;
+        if (mc > 0) {
+          PO_TRY(T.run("corrector", 8.0 * 8 * N, 0.0,
+                       [&] { return k_corrector(cx, b, px->d, pzl->d, pzu->d, n, t2->d, yq->d); }));
+          PO_TRY(T.run("corr_d1_dots(min(c+k,15) columns)", 8.0 * (mc + 11) * N, 2.0 * mc * N, [&] {
+            return k_corr_d1_dots(cx, b, px->d, pzl->d, pzu->d, rx->d, dinv->d, 1e-3, P.data(), mc, n, t2->d, out.data());
+          }));
+          PO_TRY(T.run("solve2c(min(c+k,15) columns)", 8.0 * (mc + 15) * N, 0.0, [&] {
+            return k_solve2c(cx, b, t->d, dinv->d, coef.data(), P.data(), mc, 1e-3, 0.95, n, px->d, pzl->d, pzu->d, va->d,
+                             c < mc ? c : mc, g->d, 1, out.data());
+          }));
+          (void)k_fill_hash(cx, px->d, n, 7, 10, 0, 2.0, -1.0);  // (the solve overwrote the step: restore the inputs)
+          (void)k_fill_hash(cx, pzl->d, n, 7, 11, 0, 2.0, -1.0);
+          (void)k_fill_hash(cx, pzu->d, n, 7, 12, 0, 2.0, -1.0);
+        }
+      }
+      PO_TRY(T.run("kkt_res_update(+ Dinv, t of the next solve)", 8.0 * (c + 13) * N, 0.0, [&] {
+        return k_kkt_res_update(cx, b, g->d, P.data(), coef.data(), c, 1e-3, n, t2->d, out.data(), nullptr, zl->d, pzl->d,
+                                zu->d, pzu->d, 0.0, 1e-14, nullptr, 0.0, nullptr, 0.0, nullptr, nullptr, 0.0, -1.0,
+                                nullptr, 0.0, yq->d, xt->d, 1.0, 1e-3);
+      }));
       PO_TRY(T.run("comp_merit", 8.0 * 9 * N, 0.0, [&] {
         return k_comp_merit(cx, b, px->d, pzl->d, pzu->d, 0.5, 0.5, g->d, n, out.data());
       }));

@@ -1217,7 +1217,7 @@ __global__ void __launch_bounds__(kBlock)
 }
 int k_corrector(Ctx *c, const Bounds &b, const double *px, const double *pzl, const double *pzu,
                 int64_t n, double *cl, double *cu) {
-  count_bytes(c, 10, n);
+  count_bytes(c, 8, n);  // x, lb, ub (the bound predicates), px, pzl, pzu in; cl, cu out (zl / zu are not used)
   if (n <= 0) return PO_OK;
   PO_LAUNCH(corrector_kernel, grid_for(c, n), b, px, pzl, pzu, n, cl, cu);
   return PO_OK;
