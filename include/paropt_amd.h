@@ -458,6 +458,10 @@ int po_ip_debug_kkt_step(po_ip ip, double mu, po_vec *px, po_vec *pzl, po_vec *p
  *   mode 0: ONE bordered solve with the quasi-Newton correction (computeKKTStep), the stored-step kernels;
  *   mode 1: the kernel sequence of a plain quasi-Newton iteration of optimize() (dinv_d1, fused
  *           Gram pass over unformed L-SR1 columns, first solve pass, refinement pass) = the step after ONE refinement.
+ *   mode 2: the predictor-corrector step of optimize() (.cpp:4956-5045; no sparse constraints): affine solve with one
+ *           refinement, probe to the boundary, the Mehrotra rule, corrector right-hand side (:1729-1789) and solve.
+ *           The new barrier parameter is po_ip_get_barrier_parameter afterwards; step_mins are the corrector step's
+ *           for the fraction to the boundary of that parameter (max(min_fraction_to_boundary, 1 - mu)).
  * Everything in the dump is borrowed and valid until the next call on the solver.  G and Ce are the Schur complements
  * AS ASSEMBLED (column-major c x c and k x k, before their LU factorizations), W the weighted Gram matrix
  * [Ac | Z]^T Dinv [Ac | Z] ((c+k) x (c+k)); gpiv / cpiv 0-based LU pivot rows; res_norms = max_prime, max_dual,

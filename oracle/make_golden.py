@@ -637,6 +637,22 @@ case("kat_ipw_convex_n400_c4_w80", "ip", problem="convex", n=400, c=4, nwcon=80,
      dump_vecs_every=0, kat_iter=9,
      **dict(kat_opts, **{"opt.qn_subspace_size": 8, "opt.qn_type": "bfgs", "opt.max_major_iters": 11}))
 
+# --- the predictor-corrector step from the reference's own state (round 6): affine step + one refinement, probe to
+# the boundary, complementarity there, the Mehrotra rule, corrector residual (addMehrotraCorrectorResidual) and ONE
+# solve -- src/ParOptInteriorPoint.cpp:4956-5045 through the private methods (kat_mpc=1).  Shapes: config 5's steering
+# solve (sequential linear method, panel = the c constraint gradients), a quasi-Newton panel of 14 columns (c = 8,
+# L-BFGS(3): the widest the one-pass corrector kernels take), and an odd n = 30 011 with strided compare-only vectors.
+mpc_opts = dict(kat_opts, **{"opt.barrier_strategy": "mehrotra_predictor_corrector"})
+case("kat_mpc_convex_n2000_c4_seqlin", "ip", problem="convex", n=2000, c=4, dump_vecs_every=0, kat_iter=14, kat_mpc=1,
+     kat_use_qn=0,
+     **dict(mpc_opts, **{"opt.qn_subspace_size": 3, "opt.qn_type": "bfgs", "opt.sequential_linear_method": 1,
+                         "opt.max_major_iters": 16}))
+case("kat_mpc_quadratic_n2000_c8_bfgs3", "ip", problem="quadratic", n=2000, c=8, dump_vecs_every=0, kat_iter=7, kat_mpc=1,
+     **dict(mpc_opts, **{"opt.qn_subspace_size": 3, "opt.qn_type": "bfgs", "opt.max_major_iters": 9}))
+case("kat_mpc_quadratic_n30011_c3_bfgs4", "ip", problem="quadratic", n=30011, c=3, dump_vecs_every=0, kat_iter=8,
+     kat_mpc=1, kat_light=1, kat_out_stride=11,
+     **dict(mpc_opts, **{"opt.qn_subspace_size": 4, "opt.qn_type": "bfgs", "opt.max_major_iters": 10}))
+
 
 def parse_tr_table(text):
     """Rows of the trust-region iteration table (paropt.tr): 13 numeric columns without the wall time, + info."""

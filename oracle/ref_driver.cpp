@@ -596,6 +596,8 @@ struct DumpHook {
   // (S, Y are kept); kat_out_stride > 1 stores the compare-only vectors (Dinv, residual, steps) as every
   // stride-th entry.  The injected state (x, zl, zu, S, Y) is always complete.
   int kat_light, kat_out_stride;
+  int kat_use_qn;  // the use_qn argument of the private methods (1; 0 for the sequential linear method)
+  int kat_mpc;  // also the predictor-corrector step (affine step, Mehrotra rule, corrector solve) from that state
 };
 
 void SepProblem::writeOutput(int iter, ParOptVec *x) {
@@ -722,6 +724,7 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     }
   }
   if (iter == hook->kat_iter) {
+    const int uq = hook->kat_use_qn;  // use_qn of the private methods (optimize(): 0 under the sequential linear method)
     // Single-step KAT through the private methods, in the order optimize() uses
     // them (src/ParOptInteriorPoint.cpp:4670,4971-4982). All scratch that is touched
     // is recomputed by optimize() right after this hook returns.
@@ -777,13 +780,13 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     R.f64("kat/c", ip->c, c);
     R.f64s("kat/fobj", ip->fobj);
     g_getrf_capture = true;
-    ip->setUpKKTDiagSystem(ip->variables, ip->s_qn, ip->wtemp, 1);
+    ip->setUpKKTDiagSystem(ip->variables, ip->s_qn, ip->wtemp, uq);
     R.vec("kat/Dinv", ip->Dinv);
     if (c > 0 && g_getrf_last_n == c) R.f64("kat/Gmat", g_getrf_last.data(), (int64_t)c * c);  // as assembled
     R.f64("kat/Gmat_lu", ip->Gmat, (int64_t)c * c);
     R.i32("kat/gpiv", ip->gpiv, c);
     g_getrf_last_n = 0;
-    ip->setUpKKTSystem(ip->variables, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, 1);
+    ip->setUpKKTSystem(ip->variables, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, uq);
     g_getrf_capture = false;
     if (ip->qn) {
       ParOptScalar b0;
@@ -826,7 +829,7 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
       }
     }
     ip->computeKKTStep(ip->variables, ip->residual, ip->update, ip->ztemp, ip->s_qn, ip->y_qn,
-                       ip->wtemp, 1);
+                       ip->wtemp, uq);
     R.vec("kat/step_x", ip->update.x);
     R.vec("kat/step_zl", ip->update.zl);
     R.vec("kat/step_zu", ip->update.zu);
@@ -856,7 +859,7 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     ip->addKKTResStep(ip->variables, ip->update, ip->residual, ip->xtemp, 0);
     R.vec("kat/rres_x", ip->residual.x);  // the refinement's right-hand side: r - K p
     R.f64("kat/rres_z", ip->residual.z, c);
-    ip->computeKKTStep(ip->variables, ip->residual, ip->refine, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, 1);
+    ip->computeKKTStep(ip->variables, ip->residual, ip->refine, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, uq);
     ip->update.add(ip->refine);
     R.vec("kat/rstep_x", ip->update.x);
     R.vec("kat/rstep_zl", ip->update.zl);
@@ -876,6 +879,56 @@ void SepProblem::writeOutput(int iter, ParOptVec *x) {
     ip->computeMaxStep(ip->variables, 0.95, ip->update, &mx, &mz);
     double rms[2] = {mx, mz};
     R.f64("kat/rmax_step_tau095", rms, 2);
+    if (hook->kat_mpc) {
+      // The predictor-corrector step from the same state, in the order of optimize() (:4956-5045): affine residual
+      // (mu = 0), step + one refinement, probe to the boundary (tau = 1), complementarity there, the Mehrotra rule,
+      // residual at the new barrier parameter + corrector terms, ONE solve (no refinement with the corrector).
+      // setUpKKTDiagSystem / setUpKKTSystem above do not depend on mu.
+      const double mu_saved = ip->barrier_param;
+      ip->computeKKTRes(ip->variables, 0.0, ip->residual);
+      ip->computeKKTStep(ip->variables, ip->residual, ip->update, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, uq);
+      ip->computeKKTRes(ip->variables, 0.0, ip->residual);
+      ip->addKKTResStep(ip->variables, ip->update, ip->residual, ip->xtemp, 0);
+      ip->computeKKTStep(ip->variables, ip->residual, ip->refine, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, uq);
+      ip->update.add(ip->refine);
+      R.vec("kat/aff_step_x", ip->update.x);
+      R.vec("kat/aff_step_zl", ip->update.zl);
+      R.vec("kat/aff_step_zu", ip->update.zu);
+      R.f64("kat/aff_step_z", ip->update.z, c);
+      R.f64("kat/aff_step_s", ip->update.s, c);
+      R.f64("kat/aff_step_t", ip->update.t, c);
+      R.f64("kat/aff_step_zs", ip->update.zs, c);
+      R.f64("kat/aff_step_zt", ip->update.zt, c);
+      double ax, az;
+      ip->computeMaxStep(ip->variables, 1.0, ip->update, &ax, &az);
+      double ams[2] = {ax, az};
+      R.f64("kat/aff_max_step_tau1", ams, 2);
+      const double comp_affine = ip->computeCompStep(ip->variables, ax, az, ip->update);
+      R.f64s("kat/comp_affine", comp_affine);
+      const double s1 = comp_affine / comp;
+      double sigma = s1 * s1 * s1;
+      if (sigma < 0.01) sigma = 0.01;
+      double mu_new = sigma * comp;
+      const double abs_res_tol = ip->options->getFloatOption("abs_res_tol");
+      if (mu_new < 0.09999 * abs_res_tol) mu_new = 0.09999 * abs_res_tol;
+      R.f64s("kat/mpc_mu", mu_new);
+      ip->barrier_param = mu_new;
+      ip->computeKKTRes(ip->variables, mu_new, ip->residual);
+      ip->addMehrotraCorrectorResidual(ip->update, ip->residual);
+      ip->computeKKTStep(ip->variables, ip->residual, ip->update, ip->ztemp, ip->s_qn, ip->y_qn, ip->wtemp, uq);
+      R.vec("kat/mpc_step_x", ip->update.x);
+      R.vec("kat/mpc_step_zl", ip->update.zl);
+      R.vec("kat/mpc_step_zu", ip->update.zu);
+      R.f64("kat/mpc_step_z", ip->update.z, c);
+      R.f64("kat/mpc_step_s", ip->update.s, c);
+      R.f64("kat/mpc_step_t", ip->update.t, c);
+      R.f64("kat/mpc_step_zs", ip->update.zs, c);
+      R.f64("kat/mpc_step_zt", ip->update.zt, c);
+      ip->computeMaxStep(ip->variables, 0.95, ip->update, &ax, &az);
+      double cms[2] = {ax, az};
+      R.f64("kat/mpc_max_step_tau095", cms, 2);
+      ip->barrier_param = mu_saved;
+    }
     R.stride = stride_saved;
     // leave the residual as optimize() expects it (it is recomputed right after the hook returns anyway)
     ip->computeKKTRes(ip->variables, ip->barrier_param, ip->residual);
@@ -1115,6 +1168,8 @@ static int mode_ip(std::map<std::string, std::string> &A, MPI_Comm comm, int ran
   hook.kat_iter = (int)geti(A, "kat_iter", -1);
   hook.kat_light = (int)geti(A, "kat_light", 0);
   hook.kat_out_stride = (int)geti(A, "kat_out_stride", 1);
+  hook.kat_mpc = (int)geti(A, "kat_mpc", 0);
+  hook.kat_use_qn = (int)geti(A, "kat_use_qn", 1);
   hook.dump_vecs_every = (int)geti(A, "dump_vecs_every", 0);
   if (!bench) {
     if (rank == 0) R.open(gets(A, "out", "/tmp/ip.rec").c_str());

@@ -1084,7 +1084,7 @@ int po_ip_debug_kkt(po_ip ip, double mu, int mode, double tau, po_ip_kkt_dump *o
   PO_CHECK_PTR(ip);
   PO_CHECK_PTR(out);
   InteriorPoint *p = ip->ip;
-  if (mode != 0 && mode != 1) return PO_ERR_ARG;
+  if (mode < 0 || mode > 2) return PO_ERR_ARG;
   PO_TRY(p->debugKKT(mu, mode, tau));
   memset(out, 0, sizeof(*out));
   out->c = p->c;

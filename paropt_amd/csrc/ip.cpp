@@ -1306,6 +1306,22 @@ int InteriorPoint::debugKKT(double mu, int mode, double tau) {
   } keep(debug_keep_schur);
   if (mode == 0) {
     PO_TRY(debugKKTStep(mu));
+  } else if (mode == 2) {
+    // the predictor-corrector step of optimize() from the injected state (round 6): residual and complementarity of the
+    // iterate, KKT system for the affine right-hand side (mu = 0), then mehrotraStep -- affine solve + refinement, the
+    // Mehrotra rule, corrector right-hand side and solve.  Leaves the new barrier parameter in barrier_param.
+    PO_TRY(createQuasiNewton());
+    const bool use_qn = !options.integer("sequential_linear_method");
+    barrier_param = mu;
+    PO_TRY(computeResidual(mu, true));
+    const double comp = compFromSums(comp_prod, comp_count, vars, w_sums[0]);
+    const double rhs_mu = 0.0;
+    PO_TRY(setUpKKTSystem(use_qn, false, &rhs_mu));
+    double tau_new = tau;
+    PO_TRY(mehrotraStep(use_qn, comp, true, options.real("min_fraction_to_boundary"), options.real("abs_res_tol"),
+                        &tau_new));
+    (void)tau_new;
+    PO_TRY(batch_flush(ctx));
   } else {
     PO_TRY(createQuasiNewton());
     PO_TRY(computeResidual(mu, true));
@@ -1320,6 +1336,82 @@ int InteriorPoint::debugKKT(double mu, int mode, double tau) {
   }
   denseResidual(mu, res);
   resNorms(res, &debug_norms[0], &debug_norms[1], &debug_norms[2], &debug_norms[3]);
+  return PO_OK;
+}
+
+// The Mehrotra strategies' step from a set-up KKT system (optimize() :4956-5045): affine (mu = 0) predictor with one
+// refinement, probe to the boundary (tau = 1), complementarity there, sigma = (comp_affine / comp)^3 >= 0.01, the new
+// barrier parameter, then either the corrector solve (predictor-corrector: affine products in the residual, no
+// refinement) or a plain solve at the new parameter.  Leaves the step in (px, pzl, pzu, step), the new barrier
+// parameter in barrier_param and the fraction to the boundary that goes with it in *tau_out.
+int InteriorPoint::mehrotraStep(bool use_qn, double comp, bool corrector, double min_frac, double abs_res_tol,
+                                double *tau_out) {
+  // affine (mu = 0) predictor step, probed all the way to the boundary (:4956-5009)
+  PO_TRY(computeKKTStepWithRefinement(0.0, use_qn, 1.0));
+  double max_x = std::min(1.0, step_mins[0]), max_z = std::min(1.0, step_mins[1]);
+  for (int i = 0; i < c; i++) {
+    if (step.s[i] < 0.0) max_x = std::min(max_x, -vars.s[i] / step.s[i]);
+    if (step.t[i] < 0.0) max_x = std::min(max_x, -vars.t[i] / step.t[i]);
+    if (step.zs[i] < 0.0) max_z = std::min(max_z, -vars.zs[i] / step.zs[i]);
+    if (step.zt[i] < 0.0) max_z = std::min(max_z, -vars.zt[i] / step.zt[i]);
+  }
+  double cs[2];
+  if (fused_merit_valid && !has_w && dbg_switch(SW_MPC_POLY, "PAROPT_AMD_MPC_POLY", 1) != 0) {
+    // the refinement pass of the affine solve took the complementarity polynomial of its step (solve2r_kernel):
+    // S00 + ax S10 + az S01 + ax az S11 at the probe lengths, S00 / the bound count from the residual pass of this
+    // iterate -- no pass over the step and no host round trip (round 6; scaleKKTStep uses the same form)
+    cs[0] = comp_prod + max_x * fused_merit[0] + max_z * fused_merit[1] + max_x * max_z * fused_merit[2];
+    cs[1] = comp_count;
+  } else {
+    PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
+  }
+  double prod = cs[0] / options.real("rel_bound_barrier"), count = cs[1];
+  if (has_w) {
+    double wprod = 0.0;
+    PO_TRY(wCompStep(max_x, max_z, &wprod));
+    prod += wprod;
+    count += 2.0 * nw_global;
+  }
+  for (int i = 0; i < c; i++) {
+    prod += ((vars.s[i] + max_x * step.s[i]) * (vars.zs[i] + max_z * step.zs[i]) +
+             (vars.t[i] + max_x * step.t[i]) * (vars.zt[i] + max_z * step.zt[i]));
+    count += 2.0;
+  }
+  const double comp_affine = count != 0.0 ? prod / count : 0.0;
+  const double s1 = comp_affine / comp;
+  double sigma = s1 * s1 * s1;
+  if (sigma < 0.01) sigma = 0.01;
+  barrier_param = sigma * comp;
+  if (barrier_param < 0.09999 * abs_res_tol) barrier_param = 0.09999 * abs_res_tol;
+  double tau = min_frac;
+  if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
+  *tau_out = tau;
+  if (corrector) {
+    // corrector: res.zl -= px*pzl, res.zu += px*pzu, res.zs -= ps*pzs, res.zt -= pt*pzt of the
+    // affine step (:1729-1789); no refinement with the corrector (:5040-5041)
+    // (one-pass corrector right-hand side + corrector solve with the merit sums: see solveKKT)
+    corrector_fused = !has_w && c + wk >= 1 && c + wk <= kCorrDotsMax &&
+                      dbg_switch(SW_MPC_FUSE, "PAROPT_AMD_MPC_FUSE", 1) != 0;
+    if (!corrector_fused) PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
+    denseResidual(barrier_param, res);
+    for (int i = 0; i < c; i++) {
+      res.zs[i] -= step.s[i] * step.zs[i];
+      res.zt[i] -= step.t[i] * step.zt[i];
+    }
+    if (has_w) {
+      PO_TRY(computeResidualW(barrier_param));
+      PO_TRY(k_w_corrector(ctx, wp(), wr(), nw));
+    }
+    corrector_active = true;
+    int rcs = has_w ? solveKKTW(res, barrier_param, use_qn, false, tau, step)
+                    : solveKKT(res, barrier_param, use_qn, false, tau, step);
+    corrector_active = false;
+    corrector_fused = false;
+    PO_TRY(rcs);
+    sx = sz = 1.0;
+  } else {
+    PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
+  }
   return PO_OK;
 }
 
@@ -2270,71 +2362,7 @@ int InteriorPoint::optimize(const char *checkpoint) {
       lean_step_allowed = false;
       PO_TRY(step_rc);
     } else {
-      // affine (mu = 0) predictor step, probed all the way to the boundary (:4956-5009)
-      PO_TRY(computeKKTStepWithRefinement(0.0, use_qn, 1.0));
-      double max_x = std::min(1.0, step_mins[0]), max_z = std::min(1.0, step_mins[1]);
-      for (int i = 0; i < c; i++) {
-        if (step.s[i] < 0.0) max_x = std::min(max_x, -vars.s[i] / step.s[i]);
-        if (step.t[i] < 0.0) max_x = std::min(max_x, -vars.t[i] / step.t[i]);
-        if (step.zs[i] < 0.0) max_z = std::min(max_z, -vars.zs[i] / step.zs[i]);
-        if (step.zt[i] < 0.0) max_z = std::min(max_z, -vars.zt[i] / step.zt[i]);
-      }
-      double cs[2];
-      if (fused_merit_valid && !has_w && dbg_switch(SW_MPC_POLY, "PAROPT_AMD_MPC_POLY", 1) != 0) {
-        // the refinement pass of the affine solve took the complementarity polynomial of its step (solve2r_kernel):
-        // S00 + ax S10 + az S01 + ax az S11 at the probe lengths, S00 / the bound count from the residual pass of this
-        // iterate -- no pass over the step and no host round trip (round 6; scaleKKTStep uses the same form)
-        cs[0] = comp_prod + max_x * fused_merit[0] + max_z * fused_merit[1] + max_x * max_z * fused_merit[2];
-        cs[1] = comp_count;
-      } else {
-        PO_TRY(k_comp_step(ctx, bounds(), px->d, pzl->d, pzu->d, max_x, max_z, n, cs));
-      }
-      double prod = cs[0] / options.real("rel_bound_barrier"), count = cs[1];
-      if (has_w) {
-        double wprod = 0.0;
-        PO_TRY(wCompStep(max_x, max_z, &wprod));
-        prod += wprod;
-        count += 2.0 * nw_global;
-      }
-      for (int i = 0; i < c; i++) {
-        prod += ((vars.s[i] + max_x * step.s[i]) * (vars.zs[i] + max_z * step.zs[i]) +
-                 (vars.t[i] + max_x * step.t[i]) * (vars.zt[i] + max_z * step.zt[i]));
-        count += 2.0;
-      }
-      const double comp_affine = count != 0.0 ? prod / count : 0.0;
-      const double s1 = comp_affine / comp;
-      double sigma = s1 * s1 * s1;
-      if (sigma < 0.01) sigma = 0.01;
-      barrier_param = sigma * comp;
-      if (barrier_param < 0.09999 * abs_res_tol) barrier_param = 0.09999 * abs_res_tol;
-      tau = min_frac;
-      if (1.0 - barrier_param >= tau) tau = 1.0 - barrier_param;
-      if (barrier_strategy == B_MPC) {
-        // corrector: res.zl -= px*pzl, res.zu += px*pzu, res.zs -= ps*pzs, res.zt -= pt*pzt of the
-        // affine step (:1729-1789); no refinement with the corrector (:5040-5041)
-        // (one-pass corrector right-hand side + corrector solve with the merit sums: see solveKKT)
-        corrector_fused = !has_w && c + wk >= 1 && c + wk <= kCorrDotsMax &&
-                          dbg_switch(SW_MPC_FUSE, "PAROPT_AMD_MPC_FUSE", 1) != 0;
-        if (!corrector_fused) PO_TRY(k_corrector(ctx, bounds(), px->d, pzl->d, pzu->d, n, s_qn->d, y_qn->d));
-        denseResidual(barrier_param, res);
-        for (int i = 0; i < c; i++) {
-          res.zs[i] -= step.s[i] * step.zs[i];
-          res.zt[i] -= step.t[i] * step.zt[i];
-        }
-        if (has_w) {
-          PO_TRY(computeResidualW(barrier_param));
-          PO_TRY(k_w_corrector(ctx, wp(), wr(), nw));
-        }
-        corrector_active = true;
-        int rcs = has_w ? solveKKTW(res, barrier_param, use_qn, false, tau, step)
-                        : solveKKT(res, barrier_param, use_qn, false, tau, step);
-        corrector_active = false;
-        corrector_fused = false;
-        PO_TRY(rcs);
-        sx = sz = 1.0;
-      } else {
-        PO_TRY(computeKKTStepWithRefinement(barrier_param, use_qn, tau));
-      }
+      PO_TRY(mehrotraStep(use_qn, comp, barrier_strategy == B_MPC, min_frac, abs_res_tol, &tau));
     }
     }
     phaseEnd("kkt_step");

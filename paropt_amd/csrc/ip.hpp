@@ -297,6 +297,7 @@ class InteriorPoint {
   int solveKKT(const Dense &b, double mu, bool use_qn, bool refine_pass, double tau, Dense &out,
                bool fuse_residual = false);
   int computeKKTStepWithRefinement(double mu, bool use_qn, double tau);
+  int mehrotraStep(bool use_qn, double comp, bool corrector, double min_frac, double abs_res_tol, double *tau_out);
   int scaleKKTStep(double tau, double comp, double *alpha_x, double *alpha_z, int *ceq,
                    bool inexact = false);
   int evalMeritInitDeriv(double max_x, double *merit, double *pmerit);

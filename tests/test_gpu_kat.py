@@ -249,3 +249,80 @@ def test_kat_detects_a_perturbed_gram(ctx, name, mode):
     # ... and the unperturbed run of the same solver object passes
     d = ip.debugKKT(g["kat/mu"][0], mode)
     check_pieces(name, g, d, stride, first_step=(mode == 0))
+
+
+# ---- the predictor-corrector step (round 6) -------------------------------------------------------------------------
+# tests/golden/kat_mpc_*.npz: from the reference's own state at one iteration, its private methods in the order of
+# optimize() :4956-5045 -- affine residual (mu = 0), computeKKTStep + one refinement, computeMaxStep(tau = 1),
+# computeCompStep there, the Mehrotra rule, computeKKTRes at the new barrier parameter + addMehrotraCorrectorResidual
+# (:1729-1789), ONE computeKKTStep.  The device runs mehrotraStep() of optimize() from the injected state
+# (po_ip_debug_kkt mode 2): with the round's kernels (corrector right-hand side in one pass, corrector solve with the
+# merit sums, affine complementarity from the polynomial) and with the plain sequence they replace.
+MPC_CASES = ["kat_mpc_convex_n2000_c4_seqlin", "kat_mpc_quadratic_n2000_c8_bfgs3", "kat_mpc_quadratic_n30011_c3_bfgs4"]
+
+
+@pytest.mark.parametrize("name", MPC_CASES)
+def test_kat_predictor_corrector_step_from_reference_state(ctx, name):
+    launches = {}
+    for fused in (1, 0):
+        launches[fused] = _mpc_kat(ctx, name, fused)
+    assert launches[1] <= launches[0] - 4, launches  # (comp_step, corrector, d1, mdot, comp_merit against two passes)
+
+
+def _mpc_kat(ctx, name, fused):
+    import paropt_amd.lib as L
+
+    SW_MPC_FUSE, SW_MPC_POLY = 14, 15
+    ip, g, stride = inject(ctx, name)
+    c = len(g["kat/z"])
+    L.lib.po_debug_set_switch(SW_MPC_FUSE, fused)
+    L.lib.po_debug_set_switch(SW_MPC_POLY, fused)
+    try:
+        n0 = ctx.counters()[1]
+        d = ip.debugKKT(g["kat/mu"][0], 2)
+        nlaunch = ctx.counters()[1] - n0
+    finally:
+        L.lib.po_debug_set_switch(SW_MPC_FUSE, -1)
+        L.lib.po_debug_set_switch(SW_MPC_POLY, -1)
+    tag = name + ("" if fused else "_plain")
+    # the diagonal system (no quasi-Newton diagonal under the sequential linear method) and its Schur complement
+    ulp = np.abs(d["Dinv"][::stride] - g["kat/Dinv"]) / np.spacing(np.abs(g["kat/Dinv"]))
+    record(tag, "Dinv_ulp", ulp.max(), TOL_DINV_ULP)
+    assert ulp.max() <= TOL_DINV_ULP
+    G = colmajor(g["kat/Gmat"])
+    err = np.abs(d["G"] - G).max() / np.abs(G).max()
+    record(tag, "G", err, TOL_MAT)
+    assert err <= TOL_MAT
+    np.testing.assert_array_equal(d["gpiv"], g["kat/gpiv"])
+    # the Mehrotra rule: mu = max(0.01, (comp_affine / comp)^3) comp -- three times the relative error of the affine
+    # complementarity, which the fused form takes from the polynomial S00 + ax S10 + az S01 + ax az S11
+    mu_new = ip.getBarrierParameter()
+    err = abs(mu_new - g["kat/mpc_mu"][0]) / g["kat/mpc_mu"][0]
+    record(tag, "mpc_mu", err, TOL_STEP)
+    assert err <= TOL_STEP, "barrier parameter of the Mehrotra rule: %g vs %g" % (mu_new, g["kat/mpc_mu"][0])
+    # the corrector step
+    for key in ("x", "zl", "zu", "z", "s", "t", "zs", "zt"):
+        ref = g["kat/mpc_step_" + key]
+        mine = d["step_" + key]
+        if key in ("x", "zl", "zu"):
+            mine = mine[::stride]
+        err = np.abs(mine - ref).max() / max(np.abs(ref).max(), 1e-300)
+        record(tag, "mpc_step_" + key, err, TOL_STEP)
+        assert err <= TOL_STEP, "corrector step %s: %g of its largest entry" % (key, err)
+    # fraction to the boundary of the corrector step: the device took it with tau = max(min fraction, 1 - mu_new), the
+    # record with 0.95 -- both are tau x (the smallest ratio), capped at 1
+    tau_dev = max(0.95, 1.0 - mu_new)
+    smin = np.minimum(1.0, d["step_mins"])
+    for blk, var, i in (("s", "s", 0), ("t", "t", 0), ("zs", "zs", 1), ("zt", "zt", 1)):
+        p, v = d["step_" + blk], g["kat/" + var]
+        neg = p < 0.0
+        if neg.any():
+            smin[i] = min(smin[i], (-tau_dev * v[neg] / p[neg]).min())
+    ref = g["kat/mpc_max_step_tau095"]
+    for i in range(2):
+        if smin[i] < 1.0 and ref[i] < 1.0:
+            err = abs(smin[i] / tau_dev * 0.95 - ref[i]) / ref[i]
+            record(tag, "mpc_max_step_%d" % i, err, TOL_MAXSTEP)
+            assert err <= TOL_MAXSTEP, ("max step", i, smin, ref)
+    assert c == d["c"]
+    return nlaunch
