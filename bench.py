@@ -362,6 +362,29 @@ def launch_children(a, argv):
     return rc
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout of a rank carries the ONE JSON line and nothing else: libraries loaded below write there too (RCCL prints
+    its version banner to the C stdout of every rank that creates a communicator, buffered until the process exits --
+    i.e. BEHIND the line), so file descriptor 1 is pointed at stderr for the run and the line goes to the saved one."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def stub_rank(a, rank, world):
     """PAROPT_BENCH_STUB=1 (CPU test of the launcher plumbing): no GPU work, gloo only."""
     import torch
@@ -375,8 +398,8 @@ def stub_rank(a, rank, world):
     else:
         seen = 1
     if rank == 0:
-        print(json.dumps({"metric": "stub", "n_gpus": seen, "steps": a.steps, "warmup": a.warmup, "stub": True,
-                          "gpus_arg": a.gpus}), flush=True)
+        emit_line({"metric": "stub", "n_gpus": seen, "steps": a.steps, "warmup": a.warmup, "stub": True,
+                   "gpus_arg": a.gpus})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -390,6 +413,7 @@ def main():
     if a.gpus > 1 and not in_job:
         sys.exit(launch_children(a, argv))
 
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -753,7 +777,7 @@ def main():
             "phase_ms_per_iter": {k: 1e3 * v / niter for k, v in det["phases"].items()},
             "user_eval_ms_per_iter": head_sum["user_eval_ms_per_iter"],
         }
-        print(json.dumps(res), flush=True)
+        emit_line(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
